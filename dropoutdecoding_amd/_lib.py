@@ -1,0 +1,93 @@
+"""ctypes binding of libdropdec.so (include/dropdec.h).  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdropdec.so")
+
+# every symbol include/dropdec.h declares (tests/test_cabi.py checks the library exports all of them)
+SYMBOLS = [
+    "dd_version", "dd_last_error", "dd_arch",
+    "dd_rng_create", "dd_rng_destroy", "dd_rng_seed", "dd_rng_uniform",
+    "dd_uncertainty_workspace_bytes", "dd_vision_uncertainty", "dd_overlap_keep", "dd_sample_masks", "dd_vote",
+    "dd_argmax_rows",
+    "dd_lm_create", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_synthetic",
+    "dd_lm_prefill", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
+    "dd_lm_xchg_stride", "dd_lm_xchg_ptr", "dd_lm_get", "dd_lm_set_next_token", "dd_lm_step_algorithmic_bytes",
+    "dd_lm_time_sweep",
+]
+
+
+class DDError(RuntimeError):
+    pass
+
+
+class LMConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32),
+                ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+                ("head_dim", C.c_int32), ("rms_eps", C.c_float), ("rope_theta", C.c_float),
+                ("max_seq", C.c_int32), ("max_visual", C.c_int32), ("k_top", C.c_int32), ("mask_mode", C.c_int32),
+                ("vote_on", C.c_int32), ("leak_mask", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library; raises if it has not been built (python -m dropoutdecoding_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DDError(f"{LIB_PATH} is missing: build it with `python -m dropoutdecoding_amd.build` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
+    lib.dd_version.restype = C.c_int
+    lib.dd_last_error.restype = C.c_char_p
+    lib.dd_arch.restype = C.c_char_p
+    lib.dd_rng_create.argtypes = [C.c_uint32, C.POINTER(vp)]
+    lib.dd_rng_destroy.argtypes = [vp]
+    lib.dd_rng_seed.argtypes = [vp, C.c_uint32, vp]
+    lib.dd_rng_uniform.argtypes = [vp, vp, C.c_int, vp]
+    lib.dd_uncertainty_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.dd_uncertainty_workspace_bytes.restype = C.c_size_t
+    lib.dd_vision_uncertainty.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp,
+                                          C.c_size_t, vp]
+    lib.dd_overlap_keep.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.dd_sample_masks.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,
+                                    vp, vp]
+    lib.dd_vote.argtypes = [vp, C.c_int, vp, vp]
+    lib.dd_argmax_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.dd_lm_create.argtypes = [C.POINTER(LMConfigC), C.POINTER(vp)]
+    lib.dd_lm_destroy.argtypes = [vp]
+    lib.dd_lm_device_bytes.argtypes = [vp]
+    lib.dd_lm_device_bytes.restype = C.c_size_t
+    lib.dd_lm_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    lib.dd_lm_load_synthetic.argtypes = [vp, C.c_uint32, C.c_float]
+    lib.dd_lm_prefill.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.dd_lm_decode_step.argtypes = [vp, C.POINTER(C.c_double), C.c_int, vp, vp, vp]
+    lib.dd_lm_step_base.argtypes = [vp, C.POINTER(C.c_double), C.c_int, vp, vp, vp]
+    lib.dd_lm_step_members.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.dd_lm_step_commit.argtypes = [vp, C.c_int, vp]
+    lib.dd_lm_xchg_stride.argtypes = [vp]
+    lib.dd_lm_xchg_stride.restype = C.c_size_t
+    lib.dd_lm_xchg_ptr.argtypes = [vp]
+    lib.dd_lm_xchg_ptr.restype = vp
+    lib.dd_lm_get.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
+    lib.dd_lm_set_next_token.argtypes = [vp, C.c_int32, vp]
+    lib.dd_lm_step_algorithmic_bytes.argtypes = [vp, C.c_int]
+    lib.dd_lm_step_algorithmic_bytes.restype = C.c_double
+    lib.dd_lm_time_sweep.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().dd_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")          # the reference raises ValueError on bad shapes (llava.py:134-138)
+        raise DDError(f"{what}: rc={rc}: {msg}")

@@ -1,0 +1,13 @@
+"""The operator API for K and the per-member maximum drop probabilities.
+
+Same dict, same keys, same defaults as the reference's models/config.py:1-4; it is read at every decode step
+(reference models/llava.py:340), so late mutation by a CLI is honoured.
+"""
+settings = {}
+settings['voting_numbers'] = [0.3, 0.5, 0.7]
+settings['use_avg'] = False          # read by nobody in the reference either (models/llava.py:37-52 is never called)
+settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap" (models/llavanext.py:547-550)
+
+# K = 8 is not reachable from the reference CLI (chair_test.py:163-175); BASELINE configs 3-5 use this list.
+VOTING_NUMBERS_K8 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+VOTING_NUMBERS_K4 = [0.1, 0.3, 0.5, 0.7]   # chair_test.py:170

@@ -1,0 +1,646 @@
+// Dropout-specific kernels: uncertainty scorer, top-k ids, keep set, mask sampler, vote, RNG.
+// gfx950 / wave64.  Reference anchors are quoted per entry point in include/dropdec.h.
+#include <stdarg.h>
+
+#include "dd_common.h"
+
+// ----------------------------------------------------------------------------------------------
+// error string (thread local)
+// ----------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void dd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dd_last_error(void) { return g_err; }
+extern "C" int dd_version(void) { return 100; }
+extern "C" const char* dd_arch(void) { return "gfx950"; }
+
+// ----------------------------------------------------------------------------------------------
+// block-level helpers (blockDim.x multiple of 64, <= 1024)
+// ----------------------------------------------------------------------------------------------
+struct ArgMax {
+  float v;
+  int i;
+};
+// ordering used everywhere: larger value first, then lower index (torch.argmax: first maximal index)
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(a.v, o);
+    int oi = __shfl_xor(a.i, o);
+    if (better(ov, oi, a.v, a.i)) {
+      a.v = ov;
+      a.i = oi;
+    }
+  }
+  return a;
+}
+
+__device__ ArgMax block_argmax(ArgMax a, ArgMax* sh /*>= 16 entries*/) {
+  a = wave_argmax(a);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = a;
+  __syncthreads();
+  ArgMax r = sh[0];
+  for (int j = 1; j < nw; ++j)
+    if (better(sh[j].v, sh[j].i, r.v, r.i)) r = sh[j];
+  return r;
+}
+
+__device__ double block_sum_d(double v, double* sh /*>= 16*/) {
+  v = dd_wave_sum_d(v);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  for (int j = 0; j < nw; ++j) r += sh[j];
+  return r;
+}
+
+__device__ float block_max_f(float v, float* sh) {
+  v = dd_wave_max(v);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int j = 1; j < nw; ++j) r = fmaxf(r, sh[j]);
+  return r;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Uncertainty scorer (calculate_vision_uncertainty, reference models/llava.py:710-756)
+//   pass A: per row softmax statistics (max, sum exp) + top-k ids        (llava.py:722, 428-441)
+//   pass B: partial column sums of p over row chunks, B2 combine -> p_avg (llava.py:732)
+//   pass C: per row epi / alea / var                                      (llava.py:728,735-739)
+// HBM-bound: 3 reads of the [L][V] fp32 logits; rows are streamed with 16-byte loads.
+// ----------------------------------------------------------------------------------------------
+#define UNC_THREADS 512
+#define UNC_LSPLIT 8
+
+__global__ __launch_bounds__(UNC_THREADS) void k_row_stats_topk(const float* __restrict__ logits, int V, int ld,
+                                                                float* __restrict__ row_max, float* __restrict__ row_sum,
+                                                                int k_top, float* __restrict__ topk_vals,
+                                                                int32_t* __restrict__ topk_ids) {
+  __shared__ ArgMax sh_am[16];
+  __shared__ double sh_d[16];
+  __shared__ float sh_f[16];
+  const float* x = logits + (size_t)blockIdx.x * ld;
+  float m = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += UNC_THREADS) m = fmaxf(m, x[v]);
+  m = block_max_f(m, sh_f);
+  double s = 0;
+  for (int v = threadIdx.x; v < V; v += UNC_THREADS) s += (double)expf(x[v] - m);
+  s = block_sum_d(s, sh_d);
+  if (threadIdx.x == 0) {
+    row_max[blockIdx.x] = m;
+    row_sum[blockIdx.x] = (float)s;
+  }
+  // top-k by repeated "next in (value desc, index asc) order" selection; the row is L2-resident
+  float pv = INFINITY;
+  int pi = -1;
+  for (int j = 0; j < k_top; ++j) {
+    ArgMax a = {-INFINITY, 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += UNC_THREADS) {
+      float xv = x[v];
+      bool after = (xv < pv) || (xv == pv && v > pi);
+      if (after && better(xv, v, a.v, a.i)) {
+        a.v = xv;
+        a.i = v;
+      }
+    }
+    a = block_argmax(a, sh_am);
+    pv = a.v;
+    pi = a.i;
+    if (threadIdx.x == 0) {
+      if (topk_vals) topk_vals[(size_t)blockIdx.x * k_top + j] = a.v;
+      if (topk_ids) topk_ids[(size_t)blockIdx.x * k_top + j] = a.i;
+    }
+  }
+}
+
+// grid (ceil(V/256), UNC_LSPLIT): partial[ls][v] = sum over rows of chunk ls of p[l][v]
+__global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ logits, int L, int V, int ld,
+                                                     const float* __restrict__ row_max, const float* __restrict__ row_sum,
+                                                     double* __restrict__ partial) {
+  int v = blockIdx.x * 256 + threadIdx.x;
+  int ls = blockIdx.y;
+  int per = (L + UNC_LSPLIT - 1) / UNC_LSPLIT;
+  int l0 = ls * per, l1 = min(L, l0 + per);
+  if (v >= V) return;
+  double acc = 0;
+  for (int l = l0; l < l1; ++l) acc += (double)(expf(logits[(size_t)l * ld + v] - row_max[l]) / row_sum[l]);
+  partial[(size_t)ls * V + v] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_col_combine(const double* __restrict__ partial, int L, int V,
+                                                     float* __restrict__ p_avg) {
+  int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  double acc = 0;
+  for (int ls = 0; ls < UNC_LSPLIT; ++ls) acc += partial[(size_t)ls * V + v];
+  p_avg[v] = (float)(acc / (double)L);
+}
+
+__global__ __launch_bounds__(UNC_THREADS) void k_row_epi(const float* __restrict__ logits, int V, int ld,
+                                                         const float* __restrict__ row_max,
+                                                         const float* __restrict__ row_sum,
+                                                         const float* __restrict__ p_avg, float* __restrict__ var_tok,
+                                                         float* __restrict__ epi_tok, float* __restrict__ alea_tok) {
+  __shared__ double sh_d[16];
+  const float* x = logits + (size_t)blockIdx.x * ld;
+  float m = row_max[blockIdx.x], s = row_sum[blockIdx.x];
+  double epi = 0, alea = 0, sp = 0, sp2 = 0;
+  for (int v = threadIdx.x; v < V; v += UNC_THREADS) {
+    float p = expf(x[v] - m) / s;
+    float lp = logf(p + 1e-10f);
+    float lpa = logf(p_avg[v] + 1e-10f);
+    epi += (double)(p * (lp - lpa));
+    alea += (double)(p * lp);
+    sp += (double)p;
+    sp2 += (double)p * (double)p;
+  }
+  epi = block_sum_d(epi, sh_d);
+  alea = block_sum_d(alea, sh_d);
+  sp = block_sum_d(sp, sh_d);
+  sp2 = block_sum_d(sp2, sh_d);
+  if (threadIdx.x == 0) {
+    epi_tok[blockIdx.x] = (float)epi;
+    alea_tok[blockIdx.x] = (float)(-alea);
+    double mean = sp / V;
+    var_tok[blockIdx.x] = (float)((sp2 - (double)V * mean * mean) / (double)(V - 1));  // unbiased (torch.var)
+  }
+}
+
+__global__ __launch_bounds__(256) void k_means3(const float* a, const float* b, const float* c, int L, float* out3) {
+  __shared__ double sh_d[16];
+  double sa = 0, sb = 0, sc = 0;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    sa += a[l];
+    sb += b[l];
+    sc += c[l];
+  }
+  sa = block_sum_d(sa, sh_d);
+  sb = block_sum_d(sb, sh_d);
+  sc = block_sum_d(sc, sh_d);
+  if (threadIdx.x == 0) {
+    out3[0] = (float)(sa / L);
+    out3[1] = (float)(sb / L);
+    out3[2] = (float)(sc / L);
+  }
+}
+
+extern "C" size_t dd_uncertainty_workspace_bytes(int L, int V) {
+  // row_max[L] row_sum[L] p_avg[V] (fp32) + partial[UNC_LSPLIT][V] (fp64), 256-byte aligned pieces
+  size_t a = ((size_t)L * 4 + 255) / 256 * 256;
+  size_t p = ((size_t)V * 4 + 255) / 256 * 256;
+  return 2 * a + p + (size_t)UNC_LSPLIT * V * 8 + 256;
+}
+
+extern "C" int dd_vision_uncertainty(const float* logits, int L, int V, int ld, float* var_tok, float* epi_tok,
+                                     float* alea_tok, float* scalars3, int k_top, float* topk_vals,
+                                     int32_t* topk_ids, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(logits && var_tok && epi_tok && alea_tok && ws, "dd_vision_uncertainty: null pointer");
+  DD_REQUIRE(L >= 1 && V >= 2 && ld >= V, "dd_vision_uncertainty: bad shape L=%d V=%d ld=%d", L, V, ld);
+  DD_REQUIRE(k_top >= 0 && k_top <= DD_MAX_TOPK && k_top <= V, "dd_vision_uncertainty: k_top=%d out of range", k_top);
+  DD_REQUIRE(ws_bytes >= dd_uncertainty_workspace_bytes(L, V), "dd_vision_uncertainty: workspace too small");
+  size_t a = ((size_t)L * 4 + 255) / 256 * 256, p = ((size_t)V * 4 + 255) / 256 * 256;
+  char* base = (char*)ws;
+  float* row_max = (float*)base;
+  float* row_sum = (float*)(base + a);
+  float* p_avg = (float*)(base + 2 * a);
+  double* partial = (double*)(base + 2 * a + p);
+  k_row_stats_topk<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, row_max, row_sum, k_top, topk_vals, topk_ids);
+  DD_CHECK_LAUNCH();
+  k_col_partial<<<dim3((V + 255) / 256, UNC_LSPLIT), 256, 0, st>>>(logits, L, V, ld, row_max, row_sum, partial);
+  DD_CHECK_LAUNCH();
+  k_col_combine<<<(V + 255) / 256, 256, 0, st>>>(partial, L, V, p_avg);
+  DD_CHECK_LAUNCH();
+  k_row_epi<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, row_max, row_sum, p_avg, var_tok, epi_tok, alea_tok);
+  DD_CHECK_LAUNCH();
+  if (scalars3) {
+    k_means3<<<1, 256, 0, st>>>(var_tok, epi_tok, alea_tok, L, scalars3);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// argmax over rows; keep set (get_overlap_image_tokens, reference models/llava.py:443-482)
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_argmax_rows(const float* __restrict__ x, int V, int ld, int32_t* out) {
+  __shared__ ArgMax sh[16];
+  const float* r = x + (size_t)blockIdx.x * ld;
+  ArgMax a = {-INFINITY, 0x7fffffff};
+  for (int v = threadIdx.x; v < V; v += 1024) {
+    float xv = r[v];
+    if (better(xv, v, a.v, a.i)) {
+      a.v = xv;
+      a.i = v;
+    }
+  }
+  a = block_argmax(a, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = a.i;
+}
+
+extern "C" int dd_argmax_rows(const float* x, int R, int V, int ld, int32_t* out, void* stream_) {
+  DD_REQUIRE(x && out && R >= 1 && V >= 1 && ld >= V, "dd_argmax_rows: bad arguments");
+  k_argmax_rows<<<R, 1024, 0, (hipStream_t)stream_>>>(x, V, ld, out);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+__global__ __launch_bounds__(1024) void k_overlap_keep(const float* __restrict__ x, int V,
+                                                       const int32_t* __restrict__ topk, int L, int k,
+                                                       uint8_t* __restrict__ keep, int32_t* __restrict__ argmax_out,
+                                                       const int32_t* __restrict__ argmax_in) {
+  __shared__ ArgMax sh[16];
+  int tok;
+  if (argmax_in) {
+    tok = argmax_in[0];
+  } else {
+    ArgMax a = {-INFINITY, 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += 1024) {
+      float xv = x[v];
+      if (better(xv, v, a.v, a.i)) {
+        a.v = xv;
+        a.i = v;
+      }
+    }
+    a = block_argmax(a, sh);
+    tok = a.i;
+  }
+  if (threadIdx.x == 0 && argmax_out) argmax_out[0] = tok;
+  for (int l = threadIdx.x; l < L; l += 1024) {
+    bool hit = false;
+    for (int j = 0; j < k; ++j) hit |= (topk[(size_t)l * k + j] == tok);
+    keep[l] = hit ? 1 : 0;
+  }
+}
+
+extern "C" int dd_overlap_keep(const float* step_logits, int V, const int32_t* topk_ids, int L, int k, uint8_t* keep,
+                               int32_t* argmax_out, void* stream_) {
+  DD_REQUIRE(step_logits && topk_ids && keep && V >= 1 && L >= 1 && k >= 1, "dd_overlap_keep: bad arguments");
+  k_overlap_keep<<<1, 1024, 0, (hipStream_t)stream_>>>(step_logits, V, topk_ids, L, k, keep, argmax_out, nullptr);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// internal variant used by the engine: argmax already on the device
+int dd_overlap_keep_from_argmax(const int32_t* argmax_dev, const int32_t* topk_ids, int L, int k, uint8_t* keep,
+                                hipStream_t st) {
+  k_overlap_keep<<<1, 1024, 0, st>>>(nullptr, 0, topk_ids, L, k, keep, nullptr, argmax_dev);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// mt19937 (torch CPU default generator) in device memory: 624 words + read index
+// ----------------------------------------------------------------------------------------------
+struct dd_rng {
+  uint32_t* state;  // device, 625 words
+};
+
+#define MT_N 624
+#define MT_M 397
+
+__global__ void k_mt_seed(uint32_t* st, uint32_t seed) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t x = seed;
+    st[0] = x;
+    for (int j = 1; j < MT_N; ++j) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)j;
+      st[j] = x;
+    }
+    st[MT_N] = MT_N;
+  }
+}
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// Regenerate the 624 words held in LDS. The sequential recurrence new[i] = f(old[i], old[i+1], x[i+397 mod 624])
+// only reaches back 227 places, so it runs as three block-parallel sweeps plus the last word.
+__device__ void mt_twist_block(uint32_t* mt) {
+  const int segs[4][2] = {{0, 227}, {227, 454}, {454, 623}, {623, 624}};
+  for (int s = 0; s < 4; ++s) {
+    __syncthreads();
+    uint32_t nv = 0;
+    int i = segs[s][0] + (int)threadIdx.x;
+    bool act = i < segs[s][1];
+    if (act) nv = mt_mix(mt[i], mt[(i + 1) % MT_N], mt[(i + MT_M) % MT_N]);
+    __syncthreads();
+    if (act) mt[i] = nv;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float mt_temper_uniform(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return (float)(y & 0xFFFFFFu) * 5.9604644775390625e-08f;  // * 2^-24, exact
+}
+
+// Fill out[0..n) (LDS or global) with the next n uniforms; mt in LDS, *idx block-uniform.
+__device__ void mt_fill_block(uint32_t* mt, int* idx_sh, float* out, int n) {
+  int pos = 0;
+  while (pos < n) {
+    __syncthreads();
+    int idx = *idx_sh;
+    if (idx >= MT_N) {
+      mt_twist_block(mt);
+      idx = 0;
+    }
+    int take = min(n - pos, MT_N - idx);
+    for (int t = threadIdx.x; t < take; t += blockDim.x) out[pos + t] = mt_temper_uniform(mt[idx + t]);
+    __syncthreads();
+    if (threadIdx.x == 0) *idx_sh = idx + take;
+    pos += take;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_mt_uniform(uint32_t* st, float* out, int n) {
+  __shared__ uint32_t mt[MT_N];
+  __shared__ int idx_sh;
+  for (int i = threadIdx.x; i < MT_N; i += blockDim.x) mt[i] = st[i];
+  if (threadIdx.x == 0) idx_sh = (int)st[MT_N];
+  __syncthreads();
+  mt_fill_block(mt, &idx_sh, out, n);
+  for (int i = threadIdx.x; i < MT_N; i += blockDim.x) st[i] = mt[i];
+  if (threadIdx.x == 0) st[MT_N] = (uint32_t)idx_sh;
+}
+
+extern "C" int dd_rng_create(uint32_t seed, dd_rng** out) {
+  DD_REQUIRE(out, "dd_rng_create: null out");
+  dd_rng* r = new dd_rng();
+  hipError_t e = hipMalloc((void**)&r->state, (MT_N + 1) * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    delete r;
+    dd_set_error("dd_rng_create: hipMalloc -> %s", hipGetErrorString(e));
+    return DD_ENOMEM;
+  }
+  k_mt_seed<<<1, 64>>>(r->state, seed);
+  DD_CHECK_LAUNCH();
+  DD_HIP(hipDeviceSynchronize());
+  *out = r;
+  return DD_OK;
+}
+extern "C" int dd_rng_destroy(dd_rng* r) {
+  if (!r) return DD_OK;
+  hipFree(r->state);
+  delete r;
+  return DD_OK;
+}
+extern "C" int dd_rng_seed(dd_rng* r, uint32_t seed, void* stream_) {
+  DD_REQUIRE(r, "dd_rng_seed: null rng");
+  k_mt_seed<<<1, 64, 0, (hipStream_t)stream_>>>(r->state, seed);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+extern "C" int dd_rng_uniform(dd_rng* r, float* out, int n, void* stream_) {
+  DD_REQUIRE(r && out && n >= 0, "dd_rng_uniform: bad arguments");
+  if (n == 0) return DD_OK;
+  k_mt_uniform<<<1, 1024, 0, (hipStream_t)stream_>>>(r->state, out, n);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+uint32_t* dd_rng_state_ptr(dd_rng* r) { return r ? r->state : nullptr; }
+
+// ----------------------------------------------------------------------------------------------
+// Mask sampler: one workgroup, all K members of a step (get_image_attention_mask "epis")
+// ----------------------------------------------------------------------------------------------
+#define MASK_MAX_L 8192
+#define MASK_THREADS 1024
+
+struct MaskParams {
+  const float* epi;
+  int L, K, mode, rng_mode;
+  const uint8_t* keep;
+  const float* uniforms;  // [K][L] (injected) or nullptr
+  uint32_t* rng_state;    // mt19937 state or nullptr
+  uint8_t* drop;          // [K][L]
+  int32_t* n_drop;        // [K]
+  int32_t* idx;           // [K][L] or nullptr
+  uint8_t* drop_bits;     // optional [ceil(K/8)][L]: bit (k&7) of plane k>>3 = member k dropped (engine layout)
+  float scale[64];        // f32(mprob - 0.1)   (reference llava.py:646: python double, rounded when it meets fp32)
+  float q[64];            // f32(1 - mprob)     (reference instructblip.py:450)
+};
+
+__device__ float block_min_max(const float* e, int L, bool want_max, float* sh) {
+  float v = want_max ? -INFINITY : INFINITY;
+  for (int l = threadIdx.x; l < L; l += blockDim.x) v = want_max ? fmaxf(v, e[l]) : fminf(v, e[l]);
+  if (!want_max) v = -v;
+  v = block_max_f(v, sh);
+  return want_max ? v : -v;
+}
+
+// exclusive prefix of `flag` over the block in thread order; returns prefix, *total gets the block total
+__device__ int block_exclusive_scan_flag(bool flag, int* sh /*>=17*/, int* total) {
+  unsigned long long b = __ballot(flag);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int within = __popcll(b & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) sh[w] = __popcll(b);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int j = 0; j < nw; ++j) {
+    if (j < w) off += sh[j];
+    tot += sh[j];
+  }
+  *total = tot;
+  return off + within;
+}
+
+__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* e = (float*)smem;                       // [Lp]
+  float* u = e + MASK_MAX_L;                     // [Lp] uniforms of the current member, or sort buffer
+  uint8_t* running = (uint8_t*)(u + MASK_MAX_L);  // [L]
+  uint32_t* mt = (uint32_t*)(running + MASK_MAX_L);
+  __shared__ float sh_f[16];
+  __shared__ int sh_i[17];
+  __shared__ int idx_sh;
+  const int L = P.L, tid = threadIdx.x;
+
+  for (int l = tid; l < L; l += MASK_THREADS) {
+    e[l] = P.epi[l];
+    running[l] = 0;
+  }
+  if (P.rng_mode == DD_RNG_MT19937) {
+    for (int i = tid; i < MT_N; i += MASK_THREADS) mt[i] = P.rng_state[i];
+    if (tid == 0) idx_sh = (int)P.rng_state[MT_N];
+  }
+  __syncthreads();
+  float lo = 0.f, hi = 0.f;
+  if (P.mode != DD_MASK_IBLIP_QUANTILE) {
+    lo = block_min_max(e, L, false, sh_f);  // torch.quantile(e, 0) == min   (llava.py:641)
+    hi = block_min_max(e, L, true, sh_f);   // torch.quantile(e, 1) == max   (llava.py:642)
+  } else {
+    // ascending bitonic sort of e into u (padded with +inf): torch.quantile sorts first
+    int Lp = 1;
+    while (Lp < L) Lp <<= 1;
+    for (int l = tid; l < Lp; l += MASK_THREADS) u[l] = l < L ? e[l] : INFINITY;
+    __syncthreads();
+    for (int k2 = 2; k2 <= Lp; k2 <<= 1) {
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < Lp; i += MASK_THREADS) {
+          int ixj = i ^ j;
+          if (ixj > i) {
+            float a = u[i], b = u[ixj];
+            bool up = ((i & k2) == 0);
+            if ((a > b) == up) {
+              u[i] = b;
+              u[ixj] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  for (int k = 0; k < P.K; ++k) {
+    if (P.mode != DD_MASK_LLAVA_CUMULATIVE) {  // reset: llavanext.py:546, instructblip.py:121
+      for (int l = tid; l < L; l += MASK_THREADS) running[l] = 0;
+    }
+    float thr = 0.f;
+    if (P.mode == DD_MASK_IBLIP_QUANTILE) {
+      // torch.quantile(e, q) with linear interpolation, fp32: rank = q*(n-1); lerp(sorted[floor], sorted[ceil], frac)
+      // ATen's lerp: weight < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w), contracted to one fma on the CPU build.
+      float rank = P.q[k] * (float)(L - 1);
+      float fl = floorf(rank);
+      int i0 = (int)fl, i1 = (int)ceilf(rank);
+      float w = rank - fl;
+      float a = u[i0], b = u[i1], diff = b - a;
+      thr = (w < 0.5f) ? fmaf(w, diff, a) : fmaf(-diff, 1.0f - w, b);
+    } else if (P.rng_mode == DD_RNG_MT19937) {
+      mt_fill_block(mt, &idx_sh, u, L);  // one rand_like(e) per member (llava.py:650)
+    }
+    __syncthreads();
+    const float scale = P.scale[k];
+    const float range = __fsub_rn(hi, lo);
+    int total = 0, cnt = 0;
+    for (int base = 0; base < L; base += MASK_THREADS) {
+      int l = base + tid;
+      bool dropped = false;
+      if (l < L) {
+        bool d;
+        if (P.mode == DD_MASK_IBLIP_QUANTILE) {
+          d = e[l] >= thr;  // instructblip.py:453
+        } else {
+          float r = (P.rng_mode == DD_RNG_MT19937) ? u[l] : P.uniforms[(size_t)k * L + l];
+          // p = 0.1 + (mprob-0.1)*(clamp(e,lo,hi)-lo)/(hi-lo), every step rounded to fp32 (llava.py:646-647)
+          float c = fminf(fmaxf(e[l], lo), hi);
+          float p = __fadd_rn(0.1f, __fdiv_rn(__fmul_rn(scale, __fsub_rn(c, lo)), range));
+          d = r < p;  // llava.py:653 (NaN p when hi == lo: nothing dropped)
+        }
+        uint8_t run = running[l] | (d ? 1 : 0);                      // llava.py:654-657, in place
+        if (P.mode != DD_MASK_NEXT_NO_OVERLAP && P.keep[l]) run = 0;  // llava.py:660 keep-restore
+        running[l] = run;
+        P.drop[(size_t)k * L + l] = run;
+        dropped = run != 0;
+      }
+      int off = block_exclusive_scan_flag(dropped, sh_i, &total);
+      if (P.idx && dropped) P.idx[(size_t)k * L + cnt + off] = l;
+      cnt += total;
+    }
+    if (P.idx)
+      for (int l = cnt + tid; l < L; l += MASK_THREADS) P.idx[(size_t)k * L + l] = -1;
+    if (tid == 0) P.n_drop[k] = cnt;  // masked_numbers (llava.py:661-662)
+    __syncthreads();
+    if (P.drop_bits) {
+      for (int l = tid; l < L; l += MASK_THREADS) {
+        uint8_t* bp = P.drop_bits + (size_t)(k >> 3) * L + l;
+        uint8_t cur = (k & 7) ? *bp : 0;
+        *bp = cur | (uint8_t)((running[l] ? 1 : 0) << (k & 7));
+      }
+    }
+    __syncthreads();
+  }
+  if (P.rng_mode == DD_RNG_MT19937) {
+    for (int i = tid; i < MT_N; i += MASK_THREADS) P.rng_state[i] = mt[i];
+    if (tid == 0) P.rng_state[MT_N] = (uint32_t)idx_sh;
+  }
+}
+
+int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
+                         int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
+                         int32_t* idx, uint8_t* drop_bits, hipStream_t st) {
+  DD_REQUIRE(epi && mprobs && drop && n_drop, "dd_sample_masks: null pointer");
+  DD_REQUIRE(L >= 1 && L <= MASK_MAX_L, "dd_sample_masks: L=%d out of range (1..%d)", L, MASK_MAX_L);
+  DD_REQUIRE(K >= 1 && K <= 64, "dd_sample_masks: K=%d out of range (1..64)", K);
+  DD_REQUIRE(mode >= 0 && mode <= 3, "dd_sample_masks: unknown mode %d", mode);
+  DD_REQUIRE(mode == DD_MASK_NEXT_NO_OVERLAP || keep, "dd_sample_masks: keep flags required for mode %d", mode);
+  if (mode != DD_MASK_IBLIP_QUANTILE) {
+    DD_REQUIRE(rng_mode == DD_RNG_INJECTED || rng_mode == DD_RNG_MT19937, "dd_sample_masks: unknown rng mode %d", rng_mode);
+    DD_REQUIRE(rng_mode != DD_RNG_INJECTED || uniforms, "dd_sample_masks: injected rng needs uniforms");
+    DD_REQUIRE(rng_mode != DD_RNG_MT19937 || rng_state, "dd_sample_masks: mt19937 rng needs a dd_rng");
+  } else {
+    rng_mode = DD_RNG_INJECTED;
+  }
+  MaskParams P;
+  memset(&P, 0, sizeof(P));
+  P.epi = epi, P.L = L, P.K = K, P.mode = mode, P.rng_mode = rng_mode, P.keep = keep, P.uniforms = uniforms;
+  P.rng_state = rng_state, P.drop = drop, P.n_drop = n_drop, P.idx = idx, P.drop_bits = drop_bits;
+  for (int k = 0; k < K; ++k) {
+    P.scale[k] = (float)(mprobs[k] - 0.1);  // double subtraction, then one rounding to fp32
+    P.q[k] = (float)(1.0 - mprobs[k]);
+  }
+  size_t smem = (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  k_sample_masks<<<1, MASK_THREADS, smem, st>>>(P);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+extern "C" int dd_sample_masks(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
+                               int rng_mode, const float* uniforms, dd_rng* rng, uint8_t* drop, int32_t* n_drop,
+                               int32_t* idx, void* stream_) {
+  return dd_sample_masks_impl(epi, L, mprobs, K, keep, mode, rng_mode, uniforms, rng ? rng->state : nullptr, drop,
+                              n_drop, idx, nullptr, (hipStream_t)stream_);
+}
+
+// ----------------------------------------------------------------------------------------------
+// vote (select_by_vote, reference models/llava.py:22-36)
+// ----------------------------------------------------------------------------------------------
+__global__ void k_vote(const int32_t* __restrict__ ids, int K, int32_t* __restrict__ out2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int best_k = 0, best_c = 0;
+  for (int k = 0; k < K; ++k) {
+    bool first = true;
+    for (int j = 0; j < k; ++j) first &= (ids[j] != ids[k]);
+    if (!first) continue;  // Counter keys are in first-insertion order
+    int c = 0;
+    for (int j = 0; j < K; ++j) c += (ids[j] == ids[k]);
+    if (c > best_c) {      // strict: ties keep the earlier-inserted id (Counter.most_common)
+      best_c = c;
+      best_k = k;
+    }
+  }
+  out2[0] = best_k;        // first member whose argmax is the majority id
+  out2[1] = ids[best_k];
+}
+
+extern "C" int dd_vote(const int32_t* ids, int K, int32_t* out2, void* stream_) {
+  DD_REQUIRE(ids && out2 && K >= 1 && K <= 4096, "dd_vote: bad arguments");
+  k_vote<<<1, 64, 0, (hipStream_t)stream_>>>(ids, K, out2);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}

@@ -1,0 +1,615 @@
+// The LM engine behind dd_lm_*: owns packed weights, the shared read-only prefix KV cache, per-member new-row
+// scratch, and enqueues a whole ensemble decode step (un-masked pass -> keep set -> masks -> packed K-member
+// sweep -> vote -> commit) on one HIP stream with no host synchronisation.
+// Replaces the reference's decode branch of forward(): models/llava.py:254-376 (see include/dropdec.h).
+#include <math.h>
+
+#include <vector>
+
+#include "dd_lm_kernels.h"
+
+int dd_overlap_keep_from_argmax(const int32_t* argmax_dev, const int32_t* topk_ids, int L, int k, uint8_t* keep,
+                                hipStream_t st);
+int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
+                         int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
+                         int32_t* idx, uint8_t* drop_bits, hipStream_t st);
+uint32_t* dd_rng_state_ptr(dd_rng* r);
+
+#define MAX_MEMBERS 16
+#define MAX_NEW_TOKENS 8192
+
+struct LayerW {
+  u32x4_t *wqkv, *wo, *wgu, *wdown;
+  float *norm1, *norm2;
+};
+
+struct dd_lm {
+  dd_lm_config cfg;
+  int d, dff, V, Vpad, H, Hkv, q_dim, kv_dim, Lyr, T_cap, Lmax;
+  int S_d, S_q, S_ff, qkv_tiles, q_tiles, k_tiles;
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+  // weights
+  std::vector<LayerW> lw;
+  u32x4_t* lm_head = nullptr;
+  float* final_norm = nullptr;
+  uint16_t* embed = nullptr;
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  // kv
+  float *kc = nullptr, *vc = nullptr;
+  size_t lsk = 0, lsv = 0;
+  // decode scratch
+  float *xa, *qbuf, *knew, *vnew, *ssq_a, *ssq_b, *part_o, *part_ml, *hidden;
+  u32x4_t *xop_d, *xop_q, *xop_ff;
+  float *base_logits, *member_logits, *last_logits, *last_hidden;
+  int32_t *argmax_base, *member_tok, *member_vote, *tokens;
+  uint8_t *keep, *drop, *drop_bits, *leak_bits;
+  int32_t* n_drop;
+  DDState* state;
+  // prefill scratch
+  float *px, *pq, *image_logits;
+  uint16_t *p1_hi, *p1_lo, *p2_hi, *p2_lo;
+  int32_t* row_index;
+  float *epi, *alea, *var, *scalars, *topk_vals;
+  int32_t* topk_ids;
+  void* unc_ws;
+  size_t unc_ws_bytes;
+  double* kv_sums;
+  // exchange (K-shard)
+  float* xchg = nullptr;
+  int32_t* xchg_ids = nullptr;
+  // host mirrors
+  int T_host = 0, span_start = 0, L = 0, n_tok_host = 0, last_K = 0;
+  bool prefilled = false;
+  bool have_leak = false;
+  int bit0 = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <typename T>
+static int dalloc(dd_lm* h, T** p, size_t n) {
+  void* q = nullptr;
+  size_t b = n * sizeof(T);
+  if (b == 0) b = 16;
+  hipError_t e = hipMalloc(&q, b);
+  if (e != hipSuccess) {
+    dd_set_error("hipMalloc(%zu bytes) -> %s", b, hipGetErrorString(e));
+    return DD_ENOMEM;
+  }
+  hipMemset(q, 0, b);
+  h->allocs.push_back(q);
+  h->bytes += b;
+  *p = (T*)q;
+  return DD_OK;
+}
+#define DA(ptr, n)                          \
+  do {                                      \
+    int rc__ = dalloc(h, &(ptr), (size_t)(n)); \
+    if (rc__ != DD_OK) {                    \
+      dd_lm_destroy(h);                     \
+      return rc__;                          \
+    }                                       \
+  } while (0)
+#define RC(expr)              \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != DD_OK) return rc__; \
+  } while (0)
+
+extern "C" int dd_lm_destroy(dd_lm* h) {
+  if (!h) return DD_OK;
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return DD_OK;
+}
+
+extern "C" size_t dd_lm_device_bytes(const dd_lm* h) { return h ? h->bytes : 0; }
+
+extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
+  DD_REQUIRE(c && out, "dd_lm_create: null argument");
+  DD_REQUIRE(c->head_dim == 128, "dd_lm_create: head_dim must be 128 (got %d)", c->head_dim);
+  DD_REQUIRE(c->hidden_size % 256 == 0 && c->intermediate_size % 256 == 0,
+             "dd_lm_create: hidden (%d) and intermediate (%d) sizes must be multiples of 256", c->hidden_size,
+             c->intermediate_size);
+  DD_REQUIRE(c->num_heads % c->num_kv_heads == 0, "dd_lm_create: heads %% kv_heads != 0");
+  int G = c->num_heads / c->num_kv_heads;
+  DD_REQUIRE(G == 1 || G == 2 || G == 4, "dd_lm_create: GQA group %d unsupported", G);
+  DD_REQUIRE((c->num_heads * 128) % 256 == 0, "dd_lm_create: num_heads*128 must be a multiple of 256");
+  DD_REQUIRE(c->max_seq >= 2 && c->max_visual >= 1 && c->max_visual <= 8192, "dd_lm_create: bad max_seq/max_visual");
+  DD_REQUIRE(c->k_top >= 1 && c->k_top <= DD_MAX_TOPK, "dd_lm_create: k_top out of range");
+  DD_REQUIRE(c->mask_mode >= 0 && c->mask_mode <= 3, "dd_lm_create: mask_mode");
+  dd_lm* h = new dd_lm();
+  h->cfg = *c;
+  h->d = c->hidden_size, h->dff = c->intermediate_size, h->V = c->vocab_size, h->Vpad = (c->vocab_size + 15) / 16 * 16;
+  h->H = c->num_heads, h->Hkv = c->num_kv_heads, h->q_dim = h->H * 128, h->kv_dim = h->Hkv * 128;
+  h->Lyr = c->num_layers, h->T_cap = (c->max_seq + 63) / 64 * 64, h->Lmax = c->max_visual;
+  h->S_d = h->d / 32, h->S_q = h->q_dim / 32, h->S_ff = h->dff / 32;
+  h->q_tiles = h->q_dim / 16, h->k_tiles = h->kv_dim / 16, h->qkv_tiles = (h->q_dim + 2 * h->kv_dim) / 16;
+  const int d = h->d, dff = h->dff, T = h->T_cap;
+  h->lw.resize(h->Lyr);
+  for (int l = 0; l < h->Lyr; ++l) {
+    LayerW& w = h->lw[l];
+    DA(w.wqkv, (size_t)h->qkv_tiles * h->S_d * 64);
+    DA(w.wo, (size_t)(d / 16) * h->S_q * 64);
+    DA(w.wgu, (size_t)(2 * dff / 16) * h->S_d * 64);
+    DA(w.wdown, (size_t)(d / 16) * h->S_ff * 64);
+    DA(w.norm1, d);
+    DA(w.norm2, d);
+  }
+  DA(h->lm_head, (size_t)(h->Vpad / 16) * h->S_d * 64);
+  DA(h->final_norm, d);
+  DA(h->embed, (size_t)h->V * d);
+  DA(h->rope_cos, (size_t)T * 64);
+  DA(h->rope_sin, (size_t)T * 64);
+  h->lsk = (size_t)h->Hkv * 32 * T * 4;
+  h->lsv = (size_t)h->Hkv * T * 128;
+  DA(h->kc, h->lsk * h->Lyr);
+  DA(h->vc, h->lsv * h->Lyr);
+  // decode scratch
+  DA(h->xa, 8 * (size_t)d);
+  DA(h->qbuf, 8 * (size_t)h->q_dim);
+  DA(h->knew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
+  DA(h->vnew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
+  DA(h->ssq_a, (size_t)(d / 16) * 8);
+  DA(h->ssq_b, (size_t)(d / 16) * 8);
+  int max_splits = T / 64;
+  DA(h->part_o, (size_t)h->Hkv * max_splits * 8 * G * 128);
+  DA(h->part_ml, (size_t)h->Hkv * max_splits * 8 * G * 2);
+  DA(h->hidden, 8 * (size_t)d);
+  DA(h->xop_d, (size_t)h->S_d * 64);
+  DA(h->xop_q, (size_t)h->S_q * 64);
+  DA(h->xop_ff, (size_t)h->S_ff * 64);
+  DA(h->base_logits, h->Vpad);
+  DA(h->member_logits, (size_t)MAX_MEMBERS * h->Vpad);
+  DA(h->last_logits, h->Vpad);
+  DA(h->last_hidden, d);
+  DA(h->argmax_base, 4);
+  DA(h->member_tok, MAX_MEMBERS);
+  DA(h->member_vote, MAX_MEMBERS);
+  DA(h->tokens, MAX_NEW_TOKENS);
+  DA(h->keep, h->Lmax);
+  DA(h->drop, (size_t)MAX_MEMBERS * h->Lmax);
+  DA(h->drop_bits, (size_t)(MAX_MEMBERS / 8) * h->Lmax);
+  DA(h->leak_bits, h->Lmax);
+  DA(h->n_drop, MAX_MEMBERS);
+  DA(h->state, 1);
+  // prefill scratch
+  DA(h->px, (size_t)T * d);
+  DA(h->pq, (size_t)T * h->q_dim);
+  size_t p1 = (size_t)T * (d > h->q_dim ? d : h->q_dim);
+  DA(h->p1_hi, p1);
+  DA(h->p1_lo, p1);
+  DA(h->p2_hi, (size_t)T * dff);
+  DA(h->p2_lo, (size_t)T * dff);
+  DA(h->image_logits, (size_t)(h->Lmax + 1) * h->Vpad);
+  DA(h->row_index, h->Lmax + 1);
+  DA(h->epi, h->Lmax);
+  DA(h->alea, h->Lmax);
+  DA(h->var, h->Lmax);
+  DA(h->scalars, 4);
+  DA(h->topk_vals, (size_t)h->Lmax * DD_MAX_TOPK);
+  DA(h->topk_ids, (size_t)h->Lmax * DD_MAX_TOPK);
+  h->unc_ws_bytes = dd_uncertainty_workspace_bytes(h->Lmax, h->V);
+  char* ws;
+  DA(ws, h->unc_ws_bytes);
+  h->unc_ws = ws;
+  DA(h->kv_sums, (size_t)h->Lyr * 2);
+  DA(h->xchg, dd_lm_xchg_stride(h));
+  DA(h->xchg_ids, 2 * MAX_MEMBERS);
+  // RoPE table: inv_freq exactly as HF computes it (fp32 pow and reciprocal), cos/sin on the device
+  std::vector<float> inv(64);
+  for (int i = 0; i < 64; ++i) inv[i] = 1.0f / powf(c->rope_theta, (float)(2 * i) / 128.0f);
+  float* inv_dev;
+  DA(inv_dev, 64);
+  if (hipMemcpy(inv_dev, inv.data(), 64 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      ddk_rope_table(h->rope_cos, h->rope_sin, T, inv_dev, nullptr) != DD_OK || hipDeviceSynchronize() != hipSuccess) {
+    dd_set_error("dd_lm_create: rope table init failed");
+    dd_lm_destroy(h);
+    return DD_EHIP;
+  }
+  (void)hipEventCreate(&h->ev0);
+  (void)hipEventCreate(&h->ev1);
+  *out = h;
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// weights
+// -----------------------------------------------------------------------------------------------
+extern "C" int dd_lm_load_tensor(dd_lm* h, int id, int layer, const uint16_t* src, int rows, int cols, int on_device) {
+  DD_REQUIRE(h && src, "dd_lm_load_tensor: null argument");
+  DD_REQUIRE(id >= DD_T_EMBED && id <= DD_T_LM_HEAD, "dd_lm_load_tensor: unknown tensor id %d", id);
+  bool per_layer = !(id == DD_T_EMBED || id == DD_T_FINAL_NORM || id == DD_T_LM_HEAD);
+  DD_REQUIRE(!per_layer || (layer >= 0 && layer < h->Lyr), "dd_lm_load_tensor: layer %d out of range", layer);
+  const int d = h->d, dff = h->dff;
+  int er = 0, ec = 0;  // expected shape
+  switch (id) {
+    case DD_T_EMBED: er = h->V, ec = d; break;
+    case DD_T_LM_HEAD: er = h->V, ec = d; break;
+    case DD_T_ATTN_NORM: case DD_T_MLP_NORM: case DD_T_FINAL_NORM: er = 1, ec = d; break;
+    case DD_T_WQ: er = h->q_dim, ec = d; break;
+    case DD_T_WK: case DD_T_WV: er = h->kv_dim, ec = d; break;
+    case DD_T_WO: er = d, ec = h->q_dim; break;
+    case DD_T_WGATE: case DD_T_WUP: er = dff, ec = d; break;
+    case DD_T_WDOWN: er = d, ec = dff; break;
+  }
+  DD_REQUIRE((size_t)rows * cols == (size_t)er * ec && (er == 1 || (rows == er && cols == ec)),
+             "dd_lm_load_tensor: tensor %d expects %d x %d, got %d x %d", id, er, ec, rows, cols);
+  size_t n = (size_t)rows * cols;
+  const uint16_t* dev = src;
+  uint16_t* staging = nullptr;
+  if (!on_device) {
+    DD_HIP(hipMalloc((void**)&staging, n * 2));
+    hipError_t e = hipMemcpy(staging, src, n * 2, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(staging);
+      dd_set_error("dd_lm_load_tensor: H2D copy failed: %s", hipGetErrorString(e));
+      return DD_EHIP;
+    }
+    dev = staging;
+  }
+  int rc = DD_OK;
+  LayerW* w = per_layer ? &h->lw[layer] : nullptr;
+  switch (id) {
+    case DD_T_EMBED: rc = hipMemcpy(h->embed, dev, n * 2, hipMemcpyDeviceToDevice) == hipSuccess ? DD_OK : DD_EHIP; break;
+    case DD_T_ATTN_NORM: rc = ddk_bf16_to_f32(dev, w->norm1, d, nullptr); break;
+    case DD_T_MLP_NORM: rc = ddk_bf16_to_f32(dev, w->norm2, d, nullptr); break;
+    case DD_T_FINAL_NORM: rc = ddk_bf16_to_f32(dev, h->final_norm, d, nullptr); break;
+    case DD_T_WQ: rc = ddk_pack_weight(dev, rows, cols, w->wqkv, 0, 1, PACK_ROPE, h->q_tiles, nullptr); break;
+    case DD_T_WK: rc = ddk_pack_weight(dev, rows, cols, w->wqkv, h->q_tiles, 1, PACK_ROPE, h->k_tiles, nullptr); break;
+    case DD_T_WV: rc = ddk_pack_weight(dev, rows, cols, w->wqkv, h->q_tiles + h->k_tiles, 1, PACK_PLAIN, h->k_tiles, nullptr); break;
+    case DD_T_WO: rc = ddk_pack_weight(dev, rows, cols, w->wo, 0, 1, PACK_PLAIN, d / 16, nullptr); break;
+    case DD_T_WGATE: rc = ddk_pack_weight(dev, rows, cols, w->wgu, 0, 2, PACK_PLAIN, dff / 16, nullptr); break;
+    case DD_T_WUP: rc = ddk_pack_weight(dev, rows, cols, w->wgu, 1, 2, PACK_PLAIN, dff / 16, nullptr); break;
+    case DD_T_WDOWN: rc = ddk_pack_weight(dev, rows, cols, w->wdown, 0, 1, PACK_PLAIN, d / 16, nullptr); break;
+    case DD_T_LM_HEAD: rc = ddk_pack_weight(dev, rows, cols, h->lm_head, 0, 1, PACK_PLAIN, h->Vpad / 16, nullptr); break;
+  }
+  hipError_t e = hipDeviceSynchronize();
+  if (staging) (void)hipFree(staging);
+  if (rc != DD_OK) return rc;
+  DD_HIP(e);
+  return DD_OK;
+}
+
+extern "C" int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std) {
+  DD_REQUIRE(h, "dd_lm_load_synthetic: null handle");
+  const int d = h->d, dff = h->dff;
+  uint32_t s = seed * 2654435761u + 1;
+  for (int l = 0; l < h->Lyr; ++l) {
+    LayerW& w = h->lw[l];
+    RC(ddk_fill_synthetic((uint16_t*)w.wqkv, (size_t)h->qkv_tiles * h->S_d * 512, s++, std, nullptr));
+    RC(ddk_fill_synthetic((uint16_t*)w.wo, (size_t)(d / 16) * h->S_q * 512, s++, std, nullptr));
+    RC(ddk_fill_synthetic((uint16_t*)w.wgu, (size_t)(2 * dff / 16) * h->S_d * 512, s++, std, nullptr));
+    RC(ddk_fill_synthetic((uint16_t*)w.wdown, (size_t)(d / 16) * h->S_ff * 512, s++, std, nullptr));
+    RC(ddk_fill_const_f32(w.norm1, d, 1.0f, nullptr));
+    RC(ddk_fill_const_f32(w.norm2, d, 1.0f, nullptr));
+  }
+  RC(ddk_fill_synthetic((uint16_t*)h->lm_head, (size_t)(h->Vpad / 16) * h->S_d * 512, s++, std, nullptr));
+  RC(ddk_fill_const_f32(h->final_norm, d, 1.0f, nullptr));
+  RC(ddk_fill_synthetic(h->embed, (size_t)h->V * d, s++, 1.0f, nullptr));
+  DD_HIP(hipDeviceSynchronize());
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// small state kernels
+// -----------------------------------------------------------------------------------------------
+__global__ void k_state_after_prefill(DDState* st, int T0, const int32_t* first_tok, int32_t* tokens) {
+  if (threadIdx.x == 0) {
+    st->T = T0;
+    st->pos = T0;
+    st->n_tok = 1;
+    st->cur_tok = first_tok[0];
+    st->winner = 0;
+    st->voted = first_tok[0];
+    tokens[0] = first_tok[0];
+  }
+}
+// pos rule: LLaVA-family llava.py:283 (sum(mask)-1 == T); InstructBLIP under transformers 5.x: cache position == T
+__global__ void k_step_begin(DDState* st) {
+  if (threadIdx.x == 0) st->pos = st->T;
+}
+__global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int32_t* argmax_base,
+                                                   const int32_t* member_tok, const float* base_logits,
+                                                   const float* member_logits, int Vpad, float* last_logits,
+                                                   int32_t* tokens, const uint8_t* drop_bits, int L, uint8_t* leak_bits,
+                                                   int leak, const float* hidden_rows, int d, float* last_hidden) {
+  int win = K > 0 ? st->winner : 0;
+  const float* src = K > 0 ? member_logits + (size_t)win * Vpad : base_logits;
+  for (int i = threadIdx.x; i < Vpad; i += 1024) last_logits[i] = src[i];
+  if (leak && K > 0)
+    for (int l = threadIdx.x; l < L; l += 1024)
+      leak_bits[l] = (drop_bits[(size_t)((K - 1) >> 3) * L + l] >> ((K - 1) & 7)) & 1;  // Q2: last member's zeros stay
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tok = K > 0 ? member_tok[win] : argmax_base[0];
+    int n = st->n_tok;
+    if (n < MAX_NEW_TOKENS) tokens[n] = tok;
+    st->n_tok = n + 1;
+    st->cur_tok = tok;
+    st->T = st->T + 1;
+  }
+}
+__global__ void k_set_token(DDState* st, int tok) {
+  if (threadIdx.x == 0) st->cur_tok = tok;
+}
+
+// -----------------------------------------------------------------------------------------------
+// prefill
+// -----------------------------------------------------------------------------------------------
+extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_start, int span_len, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && embeds, "dd_lm_prefill: null argument");
+  DD_REQUIRE(T0 >= 1 && T0 < h->T_cap, "dd_lm_prefill: T0=%d out of range (KV capacity %d)", T0, h->T_cap);
+  // reference llava.py:134-138 raises ValueError on an image-token / feature count mismatch; same contract here
+  DD_REQUIRE(span_len >= 1 && span_len <= h->Lmax && span_start >= 0 && span_start + span_len <= T0,
+             "dd_lm_prefill: visual span [%d, %d) does not fit the %d input positions (max_visual %d)", span_start,
+             span_start + span_len, T0, h->Lmax);
+  const int d = h->d, dff = h->dff, L = span_len;
+  DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)T0 * d * 4, hipMemcpyDeviceToDevice, st));
+  for (int l = 0; l < h->Lyr; ++l) {
+    LayerW& w = h->lw[l];
+    RC(ddk_rmsnorm_split(h->px, T0, d, w.norm1, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st));
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.W = w.wqkv, g.n_tiles = h->qkv_tiles;
+    g.qbuf = h->pq, g.kc = h->kc + (size_t)l * h->lsk, g.vc = h->vc + (size_t)l * h->lsv, g.T_cap = h->T_cap;
+    g.q_tiles = h->q_tiles, g.k_tiles = h->k_tiles, g.q_dim = h->q_dim, g.kv_dim = h->kv_dim, g.pos0 = 0;
+    g.rope_cos = h->rope_cos, g.rope_sin = h->rope_sin;
+    RC(ddk_gemm(EPI_QKV, g, st));
+    RC(ddk_attn_prefill(h->pq, g.kc, g.vc, T0, h->T_cap, h->H, h->Hkv, h->p1_hi, h->p1_lo, st));
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_q, g.W = w.wo, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
+    RC(ddk_gemm(EPI_RESID, g, st));
+    RC(ddk_rmsnorm_split(h->px, T0, d, w.norm2, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st));
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.W = w.wgu, g.n_tiles = 2 * dff / 16;
+    g.o_hi = h->p2_hi, g.o_lo = h->p2_lo, g.ld_planes = dff;
+    RC(ddk_gemm(EPI_SILU, g, st));
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->p2_hi, g.a_lo = h->p2_lo, g.M = T0, g.S = h->S_ff, g.W = w.wdown, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
+    RC(ddk_gemm(EPI_RESID, g, st));
+  }
+  // lm_head over the visual span + the last position only (the reference projects all T0 positions,
+  // llava.py:294-305, but consumes just these: llava.py:311-314 and HF's greedy argmax)
+  std::vector<int32_t> rows(L + 1);
+  for (int i = 0; i < L; ++i) rows[i] = span_start + i;
+  rows[L] = T0 - 1;
+  DD_HIP(hipMemcpyAsync(h->row_index, rows.data(), (L + 1) * 4, hipMemcpyHostToDevice, st));
+  DD_HIP(hipStreamSynchronize(st));  // rows is a host temporary
+  RC(ddk_rmsnorm_split(h->px, L + 1, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, h->row_index, h->pq, st));
+  DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq + (size_t)L * d, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = L + 1, g.S = h->S_d, g.W = h->lm_head, g.n_tiles = h->Vpad / 16;
+  g.out = h->image_logits, g.ldo = h->Vpad, g.n_valid = h->V;
+  RC(ddk_gemm(EPI_STORE, g, st));
+  RC(dd_vision_uncertainty(h->image_logits, L, h->V, h->Vpad, h->var, h->epi, h->alea, h->scalars, h->cfg.k_top,
+                           h->topk_vals, h->topk_ids, h->unc_ws, h->unc_ws_bytes, st));
+  DD_HIP(hipMemcpyAsync(h->last_logits, h->image_logits + (size_t)L * h->Vpad, (size_t)h->Vpad * 4,
+                        hipMemcpyDeviceToDevice, st));
+  RC(dd_argmax_rows(h->last_logits, 1, h->V, h->Vpad, h->argmax_base, st));
+  k_state_after_prefill<<<1, 64, 0, st>>>(h->state, T0, h->argmax_base, h->tokens);
+  DD_CHECK_LAUNCH();
+  DD_HIP(hipMemsetAsync(h->leak_bits, 0, h->Lmax, st));
+  h->T_host = T0, h->span_start = span_start, h->L = L, h->n_tok_host = 1, h->prefilled = true, h->have_leak = false;
+  h->last_K = 0;
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// one packed sweep of nb rows through all layers + lm_head
+// -----------------------------------------------------------------------------------------------
+static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st) {
+  const int d = h->d, dff = h->dff;
+  RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, st));
+  int ssq_n = 1;
+  for (int l = 0; l < h->Lyr; ++l) {
+    LayerW& w = h->lw[l];
+    float* knew = h->knew + ((size_t)l * MAX_MEMBERS + row0) * h->kv_dim;
+    float* vnew = h->vnew + ((size_t)l * MAX_MEMBERS + row0) * h->kv_dim;
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = nb, a.xop = h->xop_d;
+    a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.qbuf = h->qbuf, a.knew = knew, a.vnew = vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
+    a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = h->state;
+    RC(ddk_gemv(EPI_QKV, a, st));
+    AttnDecodeArgs t;
+    memset(&t, 0, sizeof(t));
+    t.qbuf = h->qbuf, t.kc = h->kc + (size_t)l * h->lsk, t.vc = h->vc + (size_t)l * h->lsv, t.T_cap = h->T_cap;
+    t.T = h->T_host, t.nb = nb, t.n_heads = h->H, t.n_kv = h->Hkv, t.drop_bits = bits;
+    t.bit0 = bits ? h->bit0 : 0;
+    t.span_start = h->span_start, t.span_len = h->L, t.part_o = h->part_o, t.part_ml = h->part_ml;
+    t.knew = knew, t.vnew = vnew, t.xop_out = h->xop_q;
+    RC(ddk_attn_decode(t, st));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_q;
+    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b;
+    RC(ddk_gemv(EPI_RESID, a, st));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = nb, a.xop = h->xop_d;
+    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.xop_next = h->xop_ff;
+    RC(ddk_gemv(EPI_SILU, a, st));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_ff;
+    a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
+    a.xop_next = h->xop_d, a.ssq_out = h->ssq_a;
+    RC(ddk_gemv(EPI_RESID, a, st));
+    ssq_n = d / 16;
+  }
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = nb, a.xop = h->xop_d;
+  a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+  a.out = logits_out, a.ldo = h->Vpad, a.n_valid = h->V;
+  RC(ddk_gemv(EPI_STORE, a, st));
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// decode step, phased
+// -----------------------------------------------------------------------------------------------
+extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h, "dd_lm_step_base: null handle");
+  if (!h->prefilled) {
+    dd_set_error("dd_lm_step_base: decode before prefill");
+    return DD_ESTATE;
+  }
+  DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS, "dd_lm_step: K=%d out of range (0..%d)", K, MAX_MEMBERS);
+  DD_REQUIRE(K == 0 || mprobs, "dd_lm_step: mprobs required");
+  if (h->T_host + 1 >= h->T_cap) {
+    dd_set_error("dd_lm_step: KV cache full (%d tokens)", h->T_cap);
+    return DD_ESTATE;
+  }
+  DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
+  k_step_begin<<<1, 64, 0, st>>>(h->state);
+  DD_CHECK_LAUNCH();
+  const uint8_t* base_bits = (h->cfg.leak_mask && h->have_leak) ? h->leak_bits : nullptr;
+  h->bit0 = 0;
+  RC(lm_sweep(h, 1, base_bits, 0, h->base_logits, st));
+  RC(dd_argmax_rows(h->base_logits, 1, h->V, h->Vpad, h->argmax_base, st));
+  h->last_K = K;
+  if (K == 0) return DD_OK;
+  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, st));
+  int rng_mode = uniforms ? DD_RNG_INJECTED : DD_RNG_MT19937;
+  DD_REQUIRE(h->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || uniforms || rng, "dd_lm_step: an rng or uniforms is required");
+  RC(dd_sample_masks_impl(h->epi, h->L, mprobs, K, h->keep, h->cfg.mask_mode, rng_mode, uniforms,
+                          dd_rng_state_ptr(rng), h->drop, h->n_drop, nullptr, h->drop_bits, st));
+  return DD_OK;
+}
+
+extern "C" int dd_lm_step_members(dd_lm* h, int m_lo, int m_hi, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && h->prefilled, "dd_lm_step_members: bad state");
+  DD_REQUIRE(m_lo >= 0 && m_lo <= m_hi && m_hi <= h->last_K, "dd_lm_step_members: range [%d,%d) outside K=%d", m_lo,
+             m_hi, h->last_K);
+  for (int g0 = m_lo; g0 < m_hi;) {
+    int g1 = ((g0 >> 3) + 1) * 8;
+    if (g1 > m_hi) g1 = m_hi;
+    int nb = g1 - g0;
+    // rows of this pass are members g0..g1-1: row m reads bit (g0 & 7) + m of plane g0 >> 3
+    const uint8_t* bits = h->drop_bits + (size_t)(g0 >> 3) * h->L;
+    h->bit0 = g0 & 7;
+    RC(lm_sweep(h, nb, bits, g0, h->member_logits + (size_t)g0 * h->Vpad, st));
+    RC(dd_argmax_rows(h->member_logits + (size_t)g0 * h->Vpad, nb, h->V, h->Vpad, h->member_tok + g0, st));
+    if (h->cfg.vote_on == DD_VOTE_HIDDEN) {
+      RC(ddk_final_norm_rows(h->xa, nb, h->d, h->final_norm, h->cfg.rms_eps, h->hidden, st));
+      RC(dd_argmax_rows(h->hidden, nb, h->d, h->d, h->member_vote + g0, st));
+    }
+    g0 = g1;
+  }
+  return DD_OK;
+}
+
+extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && h->prefilled && K == h->last_K, "dd_lm_step_commit: bad state (K=%d, expected %d)", K, h ? h->last_K : -1);
+  if (K > 0) {
+    const int32_t* ids = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
+    RC(dd_vote(ids, K, &h->state->winner, st));
+  }
+  RC(ddk_commit_kv(h->knew, h->vnew, h->Lyr, MAX_MEMBERS, h->kv_dim, h->kc, h->vc, h->lsk, h->lsv, h->T_cap, h->state,
+                   K > 0 ? 1 : 0, st));
+  k_step_end<<<1, 1024, 0, st>>>(h->state, K, h->argmax_base, h->member_tok, h->base_logits, h->member_logits, h->Vpad,
+                                 h->last_logits, h->tokens, h->drop_bits, h->L, h->leak_bits, h->cfg.leak_mask, h->hidden,
+                                 h->d, h->last_hidden);
+  DD_CHECK_LAUNCH();
+  h->T_host += 1;
+  h->n_tok_host += 1;
+  if (h->cfg.leak_mask && K > 0) h->have_leak = true;
+  return DD_OK;
+}
+
+extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
+  RC(dd_lm_step_base(h, mprobs, K, rng, uniforms, stream));
+  if (K > 0) RC(dd_lm_step_members(h, 0, K, stream));
+  return dd_lm_step_commit(h, K, stream);
+}
+
+extern "C" size_t dd_lm_xchg_stride(const dd_lm* h) {
+  return h ? (size_t)h->Vpad + (size_t)h->Lyr * 2 * h->kv_dim : 0;
+}
+extern "C" float* dd_lm_xchg_ptr(dd_lm* h) { return h ? h->xchg : nullptr; }
+
+extern "C" int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream_) {
+  DD_REQUIRE(h && token >= 0 && token < h->V, "dd_lm_set_next_token: bad token %d", token);
+  k_set_token<<<1, 64, 0, (hipStream_t)stream_>>>(h->state, token);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// read-backs
+// -----------------------------------------------------------------------------------------------
+extern "C" int dd_lm_get(dd_lm* h, int what, void* dst, size_t bytes, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && dst, "dd_lm_get: null argument");
+  DD_HIP(hipStreamSynchronize(st));
+  const void* src = nullptr;
+  size_t avail = 0;
+  const int K = h->last_K, L = h->L;
+  switch (what) {
+    case DD_GET_TOKENS: src = h->tokens, avail = (size_t)h->n_tok_host * 4; break;
+    case DD_GET_LOGITS: src = h->last_logits, avail = (size_t)h->V * 4; break;
+    case DD_GET_EPI: src = h->epi, avail = (size_t)L * 4; break;
+    case DD_GET_ALEA: src = h->alea, avail = (size_t)L * 4; break;
+    case DD_GET_VAR: src = h->var, avail = (size_t)L * 4; break;
+    case DD_GET_UNCERT_SCALARS: src = h->scalars, avail = 12; break;
+    case DD_GET_TOPK_IDS: src = h->topk_ids, avail = (size_t)L * h->cfg.k_top * 4; break;
+    case DD_GET_TOPK_VALS: src = h->topk_vals, avail = (size_t)L * h->cfg.k_top * 4; break;
+    case DD_GET_DROP: src = h->drop, avail = (size_t)K * L; break;
+    case DD_GET_N_DROP: src = h->n_drop, avail = (size_t)K * 4; break;
+    case DD_GET_MEMBER_ARGMAX: src = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok, avail = (size_t)K * 4; break;
+    case DD_GET_WINNER: src = &h->state->winner, avail = 8; break;
+    case DD_GET_BASE_LOGITS: src = h->base_logits, avail = (size_t)h->V * 4; break;
+    case DD_GET_KEEP: src = h->keep, avail = (size_t)L; break;
+    case DD_GET_SEQ_LEN: src = &h->state->T, avail = 4; break;
+    case DD_GET_HIDDEN: src = h->last_hidden, avail = (size_t)h->d * 4; break;
+    case DD_GET_IMAGE_LOGITS: {
+      DD_REQUIRE(bytes <= (size_t)L * h->V * 4, "dd_lm_get: image logits: at most %zu bytes", (size_t)L * h->V * 4);
+      size_t rows = bytes / ((size_t)h->V * 4);
+      DD_HIP(hipMemcpy2D(dst, (size_t)h->V * 4, h->image_logits, (size_t)h->Vpad * 4, (size_t)h->V * 4, rows,
+                         hipMemcpyDeviceToHost));
+      return DD_OK;
+    }
+    case DD_GET_KV_SUMS:
+      RC(ddk_kv_sums(h->kc, h->vc, h->Lyr, h->lsk, h->lsv, h->Hkv, h->T_cap, h->T_host, h->kv_sums, st));
+      DD_HIP(hipStreamSynchronize(st));
+      src = h->kv_sums, avail = (size_t)h->Lyr * 16;
+      break;
+    default: DD_REQUIRE(false, "dd_lm_get: unknown item %d", what);
+  }
+  DD_REQUIRE(bytes <= avail, "dd_lm_get(%d): asked for %zu bytes, only %zu available", what, bytes, avail);
+  DD_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return DD_OK;
+}
+
+extern "C" double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K) {
+  if (!h) return 0;
+  // Bytes_tok = sweeps * W_lm + sweeps * T * kv_tok, sweeps = 2 for dropout steps (base + packed
+  // members), 1 for the stock greedy step.  W_lm in bf16; kv_tok at the cache's storage width (fp32 here).
+  double params = (double)h->Lyr * ((double)(h->q_dim + 2 * h->kv_dim) * h->d + (double)h->d * h->q_dim + 3.0 * h->d * h->dff) +
+                  (double)h->V * h->d;
+  double w = params * 2.0;
+  double kv_tok = (double)h->Lyr * 2 * h->kv_dim * 4.0;
+  int sweeps = K > 0 ? 1 + (K + 7) / 8 : 1;
+  return sweeps * (w + (double)h->T_host * kv_tok);
+}
+
+extern "C" int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && h->prefilled && mean_ms && nb >= 1 && nb <= 8 && iters >= 1, "dd_lm_time_sweep: bad arguments");
+  RC(lm_sweep(h, nb, nullptr, 0, h->member_logits, st));  // warm
+  DD_HIP(hipEventRecord(h->ev0, st));
+  for (int i = 0; i < iters; ++i) RC(lm_sweep(h, nb, nullptr, 0, h->member_logits, st));
+  DD_HIP(hipEventRecord(h->ev1, st));
+  DD_HIP(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  DD_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *mean_ms = ms / iters;
+  return DD_OK;
+}

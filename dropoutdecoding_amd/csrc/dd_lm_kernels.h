@@ -1,0 +1,131 @@
+// Internal launch interface of the LM kernels (dd_lm_kernels.hip) used by dd_engine.hip.
+#pragma once
+#include "dd_common.h"
+
+// Device-resident sequence state: kernels read lengths/positions from here so that a whole
+// decode step is enqueued without the host knowing anything but the (deterministic) length.
+struct DDState {
+  int32_t T;        // committed KV length == number of cached keys every row attends to
+  int32_t pos;      // RoPE position of the token being decoded
+  int32_t n_tok;    // tokens emitted so far
+  int32_t cur_tok;  // input token of the step being decoded
+  int32_t winner;   // last vote: member index
+  int32_t voted;    // last vote: id
+  int32_t pad[2];
+};
+
+// ---- weight layout ------------------------------------------------------------------------
+// W[N][K] bf16 (HF: out_features x in_features) is stored as 16x32 MFMA operand tiles:
+//   tile (nt, ks) = 64 lanes x 16 bytes at ((nt * S + ks) * 64 + lane), S = K/32,
+//   lane = (h << 4) | r holds W[row(nt, r)][ks*32 + 8h + 0..7]
+// so one wave instruction streams 1 KiB contiguous and feeds v_mfma_f32_16x16x32_bf16 directly.
+// row(nt, r) = nt*16 + r except inside rotary heads (PACK_ROPE), where tile tt of a head holds
+// rows {8tt..8tt+7} and {64+8tt..64+8tt+7} so that both halves of a rotate_half pair meet in one tile.
+#define PACK_PLAIN 0
+#define PACK_ROPE 1
+
+int ddk_pack_weight(const uint16_t* src_dev, int rows, int cols, u32x4_t* dst, int dst_tile0, int tile_stride,
+                    int pack_mode, int n_src_tiles, hipStream_t st);
+int ddk_fill_synthetic(uint16_t* dst_bf16, size_t n, uint32_t seed, float std, hipStream_t st);
+int ddk_fill_const_f32(float* dst, size_t n, float v, hipStream_t st);
+int ddk_bf16_to_f32(const uint16_t* src, float* dst, int n, hipStream_t st);
+int ddk_rope_table(float* cos_t, float* sin_t, int max_seq, const float* inv_freq_dev, hipStream_t st);
+
+// ---- decode (NB <= 8 rows against one weight sweep) ------------------------------------------
+// The x operand of every decode GEMV arrives PACKED from its producer: [S][64 lanes][8 bf16] where
+// lane (h<<4)|c holds, for k = ks*32 + 8h + 0..7, the hi bf16 part of row c (c < 8) or the lo part of
+// row c-8 (c >= 8) of a fp32 activation: x = hi + lo carries ~16 mantissa bits through the bf16 MFMA.
+// RMSNorm is folded: the producer packs z = norm_weight * x, the consumer multiplies its outputs by
+// rstd(row) = 1/sqrt(mean(x^2)+eps), assembled from the producer's per-workgroup sums of squares.
+#define EPI_STORE 0   // out[m][n] = y
+#define EPI_RESID 1   // x[m][n] += y; packs z = normw_next * x for the next GEMV; emits sum-of-squares slots
+#define EPI_SILU 2    // tile pair (gate, up): xop_next <- split(silu(g) * u)
+#define EPI_QKV 3     // rotary q/k + v scattered to qbuf / new-row KV scratch
+
+struct GemvArgs {
+  const u32x4_t* W;
+  int S;                // K / 32
+  int n_tiles;          // number of 16-row tiles (EPI_SILU: number of gate/up PAIRS)
+  int nb;               // live rows (1..8)
+  const u32x4_t* xop;   // [S][64]
+  const float* ssq_in;  // [ssq_n][8] partial sums of squares of the un-normalised input, or nullptr
+  int ssq_n;
+  float inv_k;          // 1 / K
+  float eps;
+  // epilogue
+  float* out;           // EPI_STORE: [nb][ldo]; EPI_RESID: x [8][N]
+  int ldo;
+  int n_valid;          // EPI_STORE: columns >= n_valid are not written
+  const float* normw_next;  // EPI_RESID: [N]
+  u32x4_t* xop_next;    // EPI_RESID / EPI_SILU: packed operand for the next GEMV
+  float* ssq_out;       // EPI_RESID: [gridDim.x][8]
+  // EPI_QKV
+  float* qbuf;          // [8][q_dim]
+  float* knew;          // [8][kv_dim] rows of this pass, this layer
+  float* vnew;
+  int q_tiles, k_tiles; // tile counts of the q and k blocks
+  int q_dim, kv_dim;
+  const float* rope_cos; // [max_seq][64]
+  const float* rope_sin;
+  const DDState* state;
+};
+int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
+
+struct AttnDecodeArgs {
+  const float* qbuf;     // [8][q_dim] roped
+  const float* kc;       // this layer: [n_kv][32][T_cap][4]
+  const float* vc;       // this layer: [n_kv][T_cap][128]
+  int T_cap;
+  int T;                 // host copy of the prefix length (grid sizing)
+  int nb, n_heads, n_kv;
+  const uint8_t* drop_bits;  // [span_len] bit (bit0 + m) = row m drops that visual token, or nullptr
+  int bit0;
+  int span_start, span_len;
+  float* part_o;         // [n_kv][splits][R][128]
+  float* part_ml;        // [n_kv][splits][R][2]
+  // combine
+  const float* knew;     // [8][kv_dim] roped new keys of this layer (rows of this pass)
+  const float* vnew;
+  u32x4_t* xop_out;      // packed hi/lo operand for o_proj, [q_dim/32][64]
+};
+int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+
+// ---- prefill (M rows) -------------------------------------------------------------------------
+int ddk_rmsnorm_split(const float* x, int M, int d, const float* w, float eps, uint16_t* hi, uint16_t* lo,
+                      const int32_t* row_index, float* normed_out, hipStream_t st);
+
+struct GemmArgs {
+  const uint16_t* a_hi;  // [M][K] bf16
+  const uint16_t* a_lo;
+  int M, S;
+  const u32x4_t* W;
+  int n_tiles;           // 16-col tiles (EPI_SILU: gate/up tiles interleaved, n_tiles = 2 * d_ff/16)
+  float* out;            // EPI_STORE [M][ldo] / EPI_RESID x[M][ldo]
+  int ldo, n_valid;
+  uint16_t* o_hi;        // EPI_SILU planes [M][ld_planes]
+  uint16_t* o_lo;
+  int ld_planes;
+  // EPI_QKV
+  float* qbuf;           // [M][q_dim]
+  float* kc;             // layer K cache
+  float* vc;
+  int T_cap, q_tiles, k_tiles, q_dim, kv_dim, pos0;
+  const float* rope_cos;
+  const float* rope_sin;
+};
+int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st);
+
+int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
+                     uint16_t* o_hi, uint16_t* o_lo, hipStream_t st);
+
+// ---- small glue -------------------------------------------------------------------------------
+// x[0..8)[d] <- embed[cur_tok] (all rows equal), xop <- split(normw * x), ssq slot 0
+int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
+                   float* ssq, hipStream_t st);
+int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st);
+int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
+                  float* vc, size_t layer_stride_k, size_t layer_stride_v, int T_cap, const DDState* state,
+                  int use_winner, hipStream_t st);
+int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float eps, float* out, hipStream_t st);
+int ddk_kv_sums(const float* kc, const float* vc, int n_layers, size_t lsk, size_t lsv, int n_kv, int T_cap, int T,
+                double* out, hipStream_t st);

@@ -1,0 +1,745 @@
+// LM kernels for the K-way masked-context decode step and the prefill pass (gfx950, wave64).
+//   - decode GEMV: v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the A operand (16 output rows) and the
+//     packed activation hi/lo pairs of up to 8 ensemble rows as the 16 B-operand columns; weights are
+//     streamed straight to VGPRs (1 KiB per wave instruction, non-temporal), K is split over the 8 waves of a
+//     workgroup and reduced through LDS in a fixed order (bit-reproducible).
+//   - decode attention: one wave per (kv head, 64-key split); every K/V tile is loaded once and consumed by
+//     all rows (ensemble members x GQA group) with their own drop bits; flash-decoding style combine.
+//   - prefill GEMM: the same packed weights as the MFMA B operand, activations as hi/lo bf16 planes.
+// Reference anchors: the third-party LM forward the reference calls at models/llava.py:294-303,350-359.
+#include "dd_lm_kernels.h"
+
+#define ROPE_HALF 64
+#define HEAD_DIM 128
+
+// ===============================================================================================
+// packing / init
+// ===============================================================================================
+__global__ __launch_bounds__(256) void k_pack_weight(const uint16_t* __restrict__ src, int rows, int cols,
+                                                     u32x4_t* __restrict__ dst, int dst_tile0, int tile_stride,
+                                                     int pack_mode, int n_src_tiles) {
+  int S = cols >> 5;
+  size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)n_src_tiles * S * 64;
+  if (gid >= total) return;
+  int lane = (int)(gid & 63);
+  size_t q = gid >> 6;
+  int ks = (int)(q % S);
+  int nt = (int)(q / S);
+  int h = lane >> 4, r = lane & 15;
+  int row;
+  if (pack_mode == PACK_ROPE) {
+    int head = nt >> 3, tt = nt & 7;
+    row = head * HEAD_DIM + (r < 8 ? tt * 8 + r : ROPE_HALF + tt * 8 + (r - 8));
+  } else {
+    row = nt * 16 + r;
+  }
+  u32x4_t v = {0u, 0u, 0u, 0u};
+  if (row < rows) v = *(const u32x4_t*)(src + (size_t)row * cols + (size_t)ks * 32 + 8 * h);
+  dst[((size_t)(dst_tile0 + nt * tile_stride) * S + ks) * 64 + lane] = v;
+}
+
+int ddk_pack_weight(const uint16_t* src, int rows, int cols, u32x4_t* dst, int dst_tile0, int tile_stride,
+                    int pack_mode, int n_src_tiles, hipStream_t st) {
+  size_t total = (size_t)n_src_tiles * (cols >> 5) * 64;
+  k_pack_weight<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, rows, cols, dst, dst_tile0, tile_stride,
+                                                                 pack_mode, n_src_tiles);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// deterministic pseudo-random bf16 fill (sum of 4 uniforms ~ normal), synthetic-weights bench mode
+__global__ __launch_bounds__(256) void k_fill_synth(uint16_t* dst, size_t n, uint32_t seed, float std) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h = hash32((uint32_t)i * 0x9e3779b9u + seed) ^ hash32((uint32_t)(i >> 32) + seed * 31u);
+  uint32_t h2 = hash32(h + 0x68bc21ebu);
+  float u = ((h & 0xffff) + (h >> 16) + (h2 & 0xffff) + (h2 >> 16)) * (1.0f / 65536.0f) - 2.0f;  // var = 1/3
+  dst[i] = (uint16_t)dd_bf16_rn(u * 1.7320508f * std);
+}
+int ddk_fill_synthetic(uint16_t* dst, size_t n, uint32_t seed, float std, hipStream_t st) {
+  k_fill_synth<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dst, n, seed, std);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+__global__ void k_fill_const(float* dst, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+int ddk_fill_const_f32(float* dst, size_t n, float v, hipStream_t st) {
+  k_fill_const<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dst, n, v);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+__global__ void k_bf16_to_f32(const uint16_t* src, float* dst, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = dd_bf16_to_f32(src[i]);
+}
+int ddk_bf16_to_f32(const uint16_t* src, float* dst, int n, hipStream_t st) {
+  k_bf16_to_f32<<<(n + 255) / 256, 256, 0, st>>>(src, dst, n);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+// cos/sin[pos][i] = cos/sin(float(pos) * inv_freq[i])   (HF LlamaRotaryEmbedding.forward, fp32)
+__global__ void k_rope_table(float* c, float* s, int max_seq, const float* inv_freq) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= max_seq * ROPE_HALF) return;
+  float ang = __fmul_rn((float)(i / ROPE_HALF), inv_freq[i % ROPE_HALF]);
+  c[i] = cosf(ang);
+  s[i] = sinf(ang);
+}
+int ddk_rope_table(float* c, float* s, int max_seq, const float* inv_freq, hipStream_t st) {
+  k_rope_table<<<(max_seq * ROPE_HALF + 255) / 256, 256, 0, st>>>(c, s, max_seq, inv_freq);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// write the hi/lo split of value y for (row m, k index k) into a packed decode operand
+__device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y) {
+  uint32_t hi, lo;
+  dd_split_hl(y, hi, lo);
+  uint16_t* p = (uint16_t*)xop;
+  int ks = k >> 5, h = (k >> 3) & 3, j = k & 7;
+  size_t base = ((size_t)ks * 64 + h * 16) * 8 + j;
+  p[base + (size_t)m * 8] = (uint16_t)hi;
+  p[base + (size_t)(m + 8) * 8] = (uint16_t)lo;
+}
+
+// ===============================================================================================
+// decode GEMV
+// ===============================================================================================
+#define GEMV_WAVES 8
+#define GEMV_THREADS (GEMV_WAVES * 64)
+#define GEMV_U 8
+
+template <int EPI, int TILES>
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
+  __shared__ float red[TILES * GEMV_WAVES * 256];
+  __shared__ float rstd_sh[8];
+  __shared__ float ssq_sh[8 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S, spw = S / GEMV_WAVES, s0 = wave * spw;
+  const int tile0 = blockIdx.x * TILES;
+
+  f32x4_t acc[TILES];
+  const u32x4_t* wp[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    wp[t] = a.W + ((size_t)(tile0 + t) * S + s0) * 64 + lane;
+  }
+  const u32x4_t* xp = a.xop + (size_t)s0 * 64 + lane;
+
+  // Deep explicit unroll: GEMV_U weight tiles (1 KiB each) + their x fragments are requested before the first
+  // MFMA consumes one, so every wave keeps >= GEMV_U KiB of HBM reads in flight (guide: "load straight to VGPRs,
+  // deep unroll, late vmcnt").
+  int s = 0;
+  for (; s + GEMV_U <= spw; s += GEMV_U) {
+    u32x4_t b[GEMV_U], w[TILES][GEMV_U];
+#pragma unroll
+    for (int u = 0; u < GEMV_U; ++u) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * 64);
+      b[u] = xp[(size_t)(s + u) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < GEMV_U; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                         __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+  }
+  for (; s < spw; ++s) {
+    u32x4_t b = xp[(size_t)s * 64];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      u32x4_t w = __builtin_nontemporal_load(wp[t] + (size_t)s * 64);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w),
+                                                       __builtin_bit_cast(bf16x8_t, b), acc[t], 0, 0, 0);
+    }
+  }
+
+  // rstd of the folded RMSNorm: wave w assembles row w's sum of squares from the producer's slots
+  if (a.ssq_in) {
+    float v = 0.f;
+    for (int i = lane; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)i * 8 + wave];
+    v = dd_wave_sum(v);
+    if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
+  }
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
+  __syncthreads();
+
+  // D[n][c]: lane = (n>>2)*16 + c, reg = n&3.  y[m][n] = sum_w (D_w[n][m] + D_w[n][m+8])   (hi + lo columns)
+  const int t = threadIdx.x;
+  auto tile_sum = [&](int tt, int n, int m) -> float {
+    float y = 0.f;
+    int o = ((n >> 2) * 16 + m) * 4 + (n & 3);
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; ++w) {
+      const float* r = &red[(tt * GEMV_WAVES + w) * 256];
+      y += r[o] + r[o + 32];
+    }
+    return y;
+  };
+
+  if (EPI == EPI_STORE) {
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float y = tile_sum(0, n, m);
+        if (a.ssq_in) y *= rstd_sh[m];
+        int col = tile0 * 16 + n;
+        if (col < a.n_valid) a.out[(size_t)m * a.ldo + col] = y;
+      }
+    }
+  } else if (EPI == EPI_RESID) {
+    float sq = 0.f;
+    int m = t & 7, n = t >> 3;
+    if (t < 128 && m < a.nb) {
+      float y = tile_sum(0, n, m);
+      int col = tile0 * 16 + n;
+      float xn = a.out[(size_t)m * a.ldo + col] + y;
+      a.out[(size_t)m * a.ldo + col] = xn;
+      xop_store(a.xop_next, col, m, a.normw_next[col] * xn);
+      sq = xn * xn;
+    }
+    if (t < 128) ssq_sh[n * 8 + m] = sq;
+    __syncthreads();
+    if (t < 8) {
+      float v = 0.f;
+      for (int i = 0; i < 16; ++i) v += ssq_sh[i * 8 + t];
+      a.ssq_out[(size_t)blockIdx.x * 8 + t] = v;
+    }
+  } else if (EPI == EPI_SILU) {
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float g = tile_sum(0, n, m), u = tile_sum(TILES - 1, n, m);
+        if (a.ssq_in) {
+          g *= rstd_sh[m];
+          u *= rstd_sh[m];
+        }
+        float act = g / (1.0f + expf(-g));  // silu
+        xop_store(a.xop_next, blockIdx.x * 16 + n, m, act * u);
+      }
+    }
+  } else {  // EPI_QKV
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float y = tile_sum(0, n, m);
+        if (a.ssq_in) y *= rstd_sh[m];
+        int nt = tile0;
+        if (nt < a.q_tiles + a.k_tiles) {
+          float yp = tile_sum(0, n ^ 8, m);
+          if (a.ssq_in) yp *= rstd_sh[m];
+          bool is_q = nt < a.q_tiles;
+          int ht = is_q ? nt : nt - a.q_tiles;
+          int head = ht >> 3, f = (ht & 7) * 8 + (n & 7);
+          int pos = a.state->pos;
+          float c = a.rope_cos[(size_t)pos * ROPE_HALF + f], sn = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+          // q*cos + rotate_half(q)*sin, two rounded products then one add (HF apply_rotary_pos_emb)
+          float o = (n < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
+          int i = (n < 8) ? f : ROPE_HALF + f;
+          if (is_q) a.qbuf[(size_t)m * a.q_dim + head * HEAD_DIM + i] = o;
+          else a.knew[(size_t)m * a.kv_dim + head * HEAD_DIM + i] = o;
+        } else {
+          int col = (nt - a.q_tiles - a.k_tiles) * 16 + n;
+          a.vnew[(size_t)m * a.kv_dim + col] = y;
+        }
+      }
+    }
+  }
+}
+
+int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
+  DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv: K=%d must be a multiple of 256", a.S * 32);
+  DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv: nb=%d", a.nb);
+  DD_REQUIRE(!a.ssq_in || a.ssq_n >= 1, "gemv: ssq_n");
+  switch (epi) {
+    case EPI_STORE: k_gemv<EPI_STORE, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    case EPI_RESID: k_gemv<EPI_RESID, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    case EPI_SILU: k_gemv<EPI_SILU, 2><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    case EPI_QKV: k_gemv<EPI_QKV, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    default: DD_REQUIRE(false, "gemv: unknown epilogue %d", epi);
+  }
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// ===============================================================================================
+// decode attention: partial (one wave per kv head x 64-key split) + combine
+// ===============================================================================================
+#define ATT_SPLIT 64
+
+template <int NBT, int G>
+__global__ __launch_bounds__(64) void k_attn_partial(AttnDecodeArgs a) {
+  constexpr int R = NBT * G;
+  __shared__ __align__(16) float q_sh[R * HEAD_DIM];
+  __shared__ __align__(16) float p_sh[ATT_SPLIT * R];
+  const int lane = threadIdx.x, kvh = blockIdx.x, split = blockIdx.y;
+  const int T = a.T, t0 = split * ATT_SPLIT;
+  const int q_dim = a.n_heads * HEAD_DIM;
+  // rows r = g*NBT + m
+  for (int i = lane; i < R * HEAD_DIM; i += 64) {
+    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = r / NBT, m = r % NBT;
+    q_sh[i] = (m < a.nb) ? a.qbuf[(size_t)m * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
+  }
+  __syncthreads();
+  const int kt = t0 + lane;
+  const bool valid = kt < T;
+  float s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = 0.f;
+  const float* kbase = a.kc + ((size_t)kvh * 32 * a.T_cap + (valid ? kt : 0)) * 4;
+#pragma unroll 4
+  for (int d4 = 0; d4 < 32; ++d4) {
+    f32x4_t k4 = *(const f32x4_t*)(kbase + (size_t)d4 * a.T_cap * 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + d4 * 4];
+      s[r] += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+    }
+  }
+  uint32_t bits = 0;
+  if (a.drop_bits && valid && kt >= a.span_start && kt < a.span_start + a.span_len) bits = a.drop_bits[kt - a.span_start];
+  const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int m = r % NBT;
+    float sv = s[r] * scaling;
+    if (!valid || ((bits >> (a.bit0 + m)) & 1u)) sv = -INFINITY;  // a zero in the 2-D mask == additive finfo.min: weight exactly 0
+    float mx = dd_wave_max(sv);
+    float p = (sv == -INFINITY) ? 0.f : expf(sv - mx);
+    float l = dd_wave_sum(p);
+    p_sh[lane * R + r] = p;
+    if (lane == 0) {
+      float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * R + r) * 2;
+      ml[0] = mx;
+      ml[1] = l;
+    }
+  }
+  __syncthreads();
+  // P.V: lanes 0-31 take even keys, 32-63 odd keys; each lane owns 4 consecutive d
+  const int half = lane >> 5, dq = lane & 31;
+  f32x4_t acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nkeys = min(ATT_SPLIT, T - t0);
+  const float* vbase = a.vc + ((size_t)kvh * a.T_cap + t0) * HEAD_DIM + dq * 4;
+#pragma unroll 2
+  for (int kp = 0; kp < ATT_SPLIT / 2; ++kp) {
+    int key = 2 * kp + half;
+    if (2 * kp >= nkeys) break;
+    f32x4_t v4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (key < nkeys) v4 = *(const f32x4_t*)(vbase + (size_t)key * HEAD_DIM);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float p = p_sh[key * R + r];
+      acc[r] += p * v4;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    f32x4_t o = acc[r];
+    o.x += __shfl_xor(o.x, 32);
+    o.y += __shfl_xor(o.y, 32);
+    o.z += __shfl_xor(o.z, 32);
+    o.w += __shfl_xor(o.w, 32);
+    if (half == 0) *(f32x4_t*)(a.part_o + (((size_t)kvh * gridDim.y + split) * R + r) * HEAD_DIM + dq * 4) = o;
+  }
+}
+
+// grid (n_heads), block 128 (thread = d): merges the splits, adds the row's own new key/value, packs hi/lo
+template <int NBT, int G>
+__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits) {
+  constexpr int R = NBT * G;
+  __shared__ float red[2];
+  const int head = blockIdx.x, d = threadIdx.x, kvh = head / G, g = head % G;
+  const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
+  const float scaling = 0.08838834764831845f;
+  for (int m = 0; m < a.nb; ++m) {
+    int r = g * NBT + m;
+    float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
+    float kd = a.knew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
+    float part = dd_wave_sum(qd * kd);
+    __syncthreads();
+    if ((d & 63) == 0) red[d >> 6] = part;
+    __syncthreads();
+    float s_self = (red[0] + red[1]) * scaling;
+    float M = s_self;
+    for (int sp = 0; sp < splits; ++sp) M = fmaxf(M, a.part_ml[(((size_t)kvh * splits + sp) * R + r) * 2]);
+    float w_self = expf(s_self - M);
+    float den = w_self, num = w_self * a.vnew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
+    for (int sp = 0; sp < splits; ++sp) {
+      const float* ml = a.part_ml + (((size_t)kvh * splits + sp) * R + r) * 2;
+      if (ml[0] == -INFINITY) continue;
+      float w = expf(ml[0] - M);
+      den += w * ml[1];
+      num += w * a.part_o[(((size_t)kvh * splits + sp) * R + r) * HEAD_DIM + d];
+    }
+    xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
+  }
+}
+
+template <int NBT, int G>
+static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
+  int splits = (a.T + ATT_SPLIT - 1) / ATT_SPLIT;
+  if (splits > 0) k_attn_partial<NBT, G><<<dim3(a.n_kv, splits), 64, 0, st>>>(a);
+  k_attn_combine<NBT, G><<<a.n_heads, HEAD_DIM, 0, st>>>(a, splits);
+  return DD_OK;
+}
+
+int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
+  DD_REQUIRE(a.n_heads % a.n_kv == 0, "attn: heads %d not a multiple of kv heads %d", a.n_heads, a.n_kv);
+  int G = a.n_heads / a.n_kv;
+  DD_REQUIRE(G == 1 || G == 2 || G == 4, "attn: GQA group %d unsupported (1, 2, 4)", G);
+  bool one = a.nb == 1;
+  if (G == 1) one ? launch_attn<1, 1>(a, st) : launch_attn<8, 1>(a, st);
+  else if (G == 2) one ? launch_attn<1, 2>(a, st) : launch_attn<8, 2>(a, st);
+  else one ? launch_attn<1, 4>(a, st) : launch_attn<8, 4>(a, st);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// ===============================================================================================
+// prefill
+// ===============================================================================================
+// y = w * (x * rsqrt(mean(x^2) + eps)) in HF's op order, written as hi/lo bf16 planes (and optionally fp32)
+__global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__ x, int d, const float* __restrict__ w,
+                                                       float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                       const int32_t* __restrict__ row_index, float* normed) {
+  __shared__ float sh[4];
+  int row = blockIdx.x;
+  const float* xr = x + (size_t)(row_index ? row_index[row] : row) * d;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < d; i += 256) ss += xr[i] * xr[i];
+  ss = dd_wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float rstd = 1.0f / sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)d + eps);
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float y = w[i] * (xr[i] * rstd);
+    uint32_t h, l;
+    dd_split_hl(y, h, l);
+    if (hi) {
+      hi[(size_t)row * d + i] = (uint16_t)h;
+      lo[(size_t)row * d + i] = (uint16_t)l;
+    }
+    if (normed) normed[(size_t)row * d + i] = y;
+  }
+}
+int ddk_rmsnorm_split(const float* x, int M, int d, const float* w, float eps, uint16_t* hi, uint16_t* lo,
+                      const int32_t* row_index, float* normed, hipStream_t st) {
+  k_rmsnorm_split<<<M, 256, 0, st>>>(x, d, w, eps, hi, lo, row_index, normed);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float eps, float* out, hipStream_t st) {
+  return ddk_rmsnorm_split(x, rows, d, w, eps, nullptr, nullptr, nullptr, out, st);
+}
+
+// C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64, operands straight from L2
+#define GEMM_BM 128
+#define GEMM_BN_TILES 8
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m_base = blockIdx.y * GEMM_BM + wr * 64;
+  const int nt_base = blockIdx.x * GEMM_BN_TILES + wc * 4;
+  const int S = a.S, K = S * 32;
+  const int ar = lane & 15, ah = lane >> 4;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const uint16_t* pa_hi[4];
+  const uint16_t* pa_lo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = min(m_base + i * 16 + ar, a.M - 1);
+    pa_hi[i] = a.a_hi + (size_t)row * K + 8 * ah;
+    pa_lo[i] = a.a_lo + (size_t)row * K + 8 * ah;
+  }
+  const u32x4_t* pw[4];
+  bool wv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wv[j] = (nt_base + j) < a.n_tiles;
+    pw[j] = a.W + ((size_t)(wv[j] ? nt_base + j : 0) * S) * 64 + lane;
+  }
+  for (int ks = 0; ks < S; ++ks) {
+    u32x4_t ahi[4], alo[4], w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ahi[i] = *(const u32x4_t*)(pa_hi[i] + (size_t)ks * 32);
+      alo[i] = *(const u32x4_t*)(pa_lo[i] + (size_t)ks * 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = pw[j][(size_t)ks * 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ahi[i]),
+                                                            __builtin_bit_cast(bf16x8_t, w[j]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, alo[i]),
+                                                            __builtin_bit_cast(bf16x8_t, w[j]), acc[i][j], 0, 0, 0);
+      }
+  }
+  // D[m][n]: m = 4*(lane>>4) + reg, n = lane & 15
+  const int c = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nt = nt_base + j;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m_base + i * 16 + 4 * (lane >> 4) + reg;
+        const bool ok = row < a.M && wv[j];
+        float y = acc[i][j][reg];
+        if (EPI == EPI_STORE) {
+          int col = nt * 16 + c;
+          if (ok && col < a.n_valid) a.out[(size_t)row * a.ldo + col] = y;
+        } else if (EPI == EPI_RESID) {
+          int col = nt * 16 + c;
+          if (ok) a.out[(size_t)row * a.ldo + col] += y;
+        } else if (EPI == EPI_SILU) {
+          if ((j & 1) == 0) {
+            float u = acc[i][j + 1][reg];
+            float act = y / (1.0f + expf(-y));
+            uint32_t h, l;
+            dd_split_hl(act * u, h, l);
+            int col = (nt >> 1) * 16 + c;
+            if (ok) {
+              a.o_hi[(size_t)row * a.ld_planes + col] = (uint16_t)h;
+              a.o_lo[(size_t)row * a.ld_planes + col] = (uint16_t)l;
+            }
+          }
+        } else {  // EPI_QKV
+          float yp = __shfl_xor(y, 8);  // partner column c ^ 8 of the same row
+          if (nt < a.q_tiles + a.k_tiles) {
+            bool is_q = nt < a.q_tiles;
+            int ht = is_q ? nt : nt - a.q_tiles;
+            int head = ht >> 3, f = (ht & 7) * 8 + (c & 7);
+            int pos = a.pos0 + min(row, a.M - 1);
+            float cs = a.rope_cos[(size_t)pos * ROPE_HALF + f], sn = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+            float o = (c < 8) ? __fadd_rn(__fmul_rn(y, cs), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, cs), __fmul_rn(yp, sn));
+            int idx = (c < 8) ? f : ROPE_HALF + f;
+            if (ok) {
+              if (is_q) a.qbuf[(size_t)row * a.q_dim + head * HEAD_DIM + idx] = o;
+              else a.kc[(((size_t)head * 32 + (idx >> 2)) * a.T_cap + pos) * 4 + (idx & 3)] = o;
+            }
+          } else if (ok) {
+            int col = (nt - a.q_tiles - a.k_tiles) * 16 + c;
+            int kvh = col / HEAD_DIM, idx = col % HEAD_DIM;
+            int pos = a.pos0 + row;
+            a.vc[((size_t)kvh * a.T_cap + pos) * HEAD_DIM + idx] = y;
+          }
+        }
+      }
+    }
+  }
+}
+
+int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.n_tiles + GEMM_BN_TILES - 1) / GEMM_BN_TILES, (a.M + GEMM_BM - 1) / GEMM_BM);
+  switch (epi) {
+    case EPI_STORE: k_gemm<EPI_STORE><<<grid, 256, 0, st>>>(a); break;
+    case EPI_RESID: k_gemm<EPI_RESID><<<grid, 256, 0, st>>>(a); break;
+    case EPI_SILU: k_gemm<EPI_SILU><<<grid, 256, 0, st>>>(a); break;
+    case EPI_QKV: k_gemm<EPI_QKV><<<grid, 256, 0, st>>>(a); break;
+    default: DD_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+  }
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// causal prefill attention, fp32 VALU, one wave per query row; keys lane-parallel from the transposed K cache
+template <int G>
+__global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ qbuf, const float* __restrict__ kc,
+                                                      const float* __restrict__ vc, int T, int T_cap, int n_heads,
+                                                      uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo) {
+  __shared__ __align__(16) float q_sh[4][HEAD_DIM];
+  __shared__ float p_sh[4][ATT_SPLIT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int head = blockIdx.x, kvh = head / G;
+  const int t = blockIdx.y * 4 + wave;
+  const int q_dim = n_heads * HEAD_DIM;
+  const bool live = t < T;
+  const int tq = live ? t : T - 1;
+  for (int i = lane; i < HEAD_DIM; i += 64) q_sh[wave][i] = qbuf[(size_t)tq * q_dim + head * HEAD_DIM + i];
+  __syncthreads();
+  const float scaling = 0.08838834764831845f;
+  const int half = lane >> 5, dq = lane & 31;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 <= tq; t0 += ATT_SPLIT) {
+    int kt = t0 + lane;
+    bool valid = kt <= tq;
+    const float* kb = kc + ((size_t)kvh * 32 * T_cap + (valid ? kt : 0)) * 4;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d4 = 0; d4 < 32; ++d4) {
+      f32x4_t k4 = *(const f32x4_t*)(kb + (size_t)d4 * T_cap * 4);
+      f32x4_t q4 = *(const f32x4_t*)&q_sh[wave][d4 * 4];
+      s += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+    }
+    s = valid ? s * scaling : -INFINITY;
+    float m_new = fmaxf(m_run, dd_wave_max(s));
+    float p = valid ? expf(s - m_new) : 0.f;
+    float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    l_run = l_run * corr + dd_wave_sum(p);
+    acc *= corr;
+    m_run = m_new;
+    p_sh[wave][lane] = p;
+    __builtin_amdgcn_wave_barrier();
+    int nkeys = min(ATT_SPLIT, tq + 1 - t0);
+    const float* vb = vc + ((size_t)kvh * T_cap + t0) * HEAD_DIM + dq * 4;
+    for (int kp = 0; 2 * kp < nkeys; ++kp) {
+      int key = 2 * kp + half;
+      if (key < nkeys) {
+        f32x4_t v4 = *(const f32x4_t*)(vb + (size_t)key * HEAD_DIM);
+        acc += p_sh[wave][key] * v4;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  acc.x += __shfl_xor(acc.x, 32);
+  acc.y += __shfl_xor(acc.y, 32);
+  acc.z += __shfl_xor(acc.z, 32);
+  acc.w += __shfl_xor(acc.w, 32);
+  if (live && half == 0) {
+    float inv = 1.0f / l_run;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t h, l;
+      dd_split_hl(acc[j] * inv, h, l);
+      size_t o = (size_t)t * q_dim + head * HEAD_DIM + dq * 4 + j;
+      o_hi[o] = (uint16_t)h;
+      o_lo[o] = (uint16_t)l;
+    }
+  }
+}
+
+int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
+                     uint16_t* o_hi, uint16_t* o_lo, hipStream_t st) {
+  int G = n_heads / n_kv;
+  dim3 grid(n_heads, (T + 3) / 4);
+  if (G == 1) k_attn_prefill<1><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
+  else if (G == 2) k_attn_prefill<2><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
+  else if (G == 4) k_attn_prefill<4><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
+  else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// ===============================================================================================
+// glue
+// ===============================================================================================
+__global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict__ embed, int d, const DDState* state,
+                                                     float* __restrict__ x, const float* __restrict__ normw,
+                                                     u32x4_t* __restrict__ xop, float* __restrict__ ssq) {
+  __shared__ float sh[16];
+  int tok = state->cur_tok;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < d; i += 1024) {
+    float e = dd_bf16_to_f32(embed[(size_t)tok * d + i]);
+    ss += e * e;
+    float z = normw[i] * e;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      x[(size_t)m * d + i] = e;
+      xop_store(xop, i, m, z);
+    }
+  }
+  ss = dd_wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float v = 0.f;
+    for (int i = 0; i < 16; ++i) v += sh[i];
+    ssq[threadIdx.x] = v;
+  }
+}
+int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
+                   float* ssq, hipStream_t st) {
+  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+__global__ void k_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, float* x) {
+  int row = blockIdx.x;
+  int tok = tokens[row];
+  for (int i = threadIdx.x; i < d; i += 256) x[(size_t)row * d + i] = dd_bf16_to_f32(embed[(size_t)tok * d + i]);
+}
+int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st) {
+  k_embed_tokens<<<n, 256, 0, st>>>(embed, d, tokens, x);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// append the chosen row's new K/V of every layer at position T  (the winner's cache, reference llava.py:373)
+__global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ knew, const float* __restrict__ vnew,
+                                                   int rows_per_layer, int kv_dim, float* __restrict__ kc,
+                                                   float* __restrict__ vc, size_t lsk, size_t lsv, int T_cap,
+                                                   const DDState* state, int use_winner) {
+  int layer = blockIdx.x;
+  int row = use_winner ? state->winner : 0;
+  int T = state->T;
+  const float* kr = knew + ((size_t)layer * rows_per_layer + row) * kv_dim;
+  const float* vr = vnew + ((size_t)layer * rows_per_layer + row) * kv_dim;
+  float* kl = kc + (size_t)layer * lsk;
+  float* vl = vc + (size_t)layer * lsv;
+  for (int i = threadIdx.x; i < kv_dim; i += 256) {
+    int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
+    kl[(((size_t)kvh * 32 + (idx >> 2)) * T_cap + T) * 4 + (idx & 3)] = kr[i];
+    vl[((size_t)kvh * T_cap + T) * HEAD_DIM + idx] = vr[i];
+  }
+}
+int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
+                  float* vc, size_t lsk, size_t lsv, int T_cap, const DDState* state, int use_winner, hipStream_t st) {
+  k_commit_kv<<<n_layers, 256, 0, st>>>(knew, vnew, rows_per_layer, kv_dim, kc, vc, lsk, lsv, T_cap, state, use_winner);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+__global__ __launch_bounds__(256) void k_kv_sums(const float* kc, const float* vc, size_t lsk, size_t lsv, int n_kv,
+                                                 int T_cap, int T, double* out) {
+  __shared__ double sh[4];
+  int layer = blockIdx.x, which = blockIdx.y;
+  double acc = 0;
+  size_t n = (size_t)n_kv * HEAD_DIM * T;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    int t = (int)(i % T);
+    size_t r = i / T;  // kvh*128 + idx
+    int kvh = (int)(r / HEAD_DIM), idx = (int)(r % HEAD_DIM);
+    float v = which == 0 ? kc[(size_t)layer * lsk + (((size_t)kvh * 32 + (idx >> 2)) * T_cap + t) * 4 + (idx & 3)]
+                         : vc[(size_t)layer * lsv + ((size_t)kvh * T_cap + t) * HEAD_DIM + idx];
+    acc += (double)v;
+  }
+  acc = dd_wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[layer * 2 + which] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+int ddk_kv_sums(const float* kc, const float* vc, int n_layers, size_t lsk, size_t lsv, int n_kv, int T_cap, int T,
+                double* out, hipStream_t st) {
+  k_kv_sums<<<dim3(n_layers, 2), 256, 0, st>>>(kc, vc, lsk, lsv, n_kv, T_cap, T, out);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}

@@ -1,0 +1,255 @@
+"""DropoutEngine — Python handle on the dd_lm_* C-ABI (the K-way masked-context decode step).
+
+It replaces, for one sequence, what the reference's forward() does per token: the un-masked pass, the keep
+set, the K dropout masks, the K masked forwards on copied KV caches, the vote and the return of the
+winner's logits + cache (reference models/llava.py:254-376; llavanext.py:490-600; instructblip.py:59-165).
+torch supplies device memory and the stream; the arithmetic is in libdropdec.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import settings
+from .dropout import (MASK_IBLIP_QUANTILE, MASK_LLAVA_CUMULATIVE, MASK_NEXT_NO_OVERLAP, MASK_NEXT_RESET,
+                      TorchCpuCompatRNG, _stream)
+
+FAMILY_LLAVA = "llava-1.5"
+FAMILY_NEXT = "llava-next"
+FAMILY_IBLIP = "instructblip"
+
+VOTE_LOGITS, VOTE_HIDDEN = 0, 1
+
+# per-family behaviour pinned by SURVEY.md 8(a) Q1-Q5 and tests/golden/g5_*
+_FAMILY = {
+    FAMILY_LLAVA: dict(k_top=5, mask_mode=MASK_LLAVA_CUMULATIVE, vote_on=VOTE_LOGITS, leak_mask=0, seed=24),
+    FAMILY_NEXT: dict(k_top=10, mask_mode=MASK_NEXT_RESET, vote_on=VOTE_LOGITS, leak_mask=0, seed=506),
+    FAMILY_IBLIP: dict(k_top=10, mask_mode=MASK_IBLIP_QUANTILE, vote_on=VOTE_HIDDEN, leak_mask=1, seed=5217),
+}
+
+(GET_TOKENS, GET_LOGITS, GET_EPI, GET_ALEA, GET_VAR, GET_UNCERT_SCALARS, GET_TOPK_IDS, GET_TOPK_VALS, GET_DROP,
+ GET_N_DROP, GET_MEMBER_ARGMAX, GET_WINNER, GET_BASE_LOGITS, GET_IMAGE_LOGITS, GET_KEEP, GET_KV_SUMS, GET_SEQ_LEN,
+ GET_HIDDEN) = range(18)
+
+(T_EMBED, T_ATTN_NORM, T_WQ, T_WK, T_WV, T_WO, T_MLP_NORM, T_WGATE, T_WUP, T_WDOWN, T_FINAL_NORM, T_LM_HEAD) = range(12)
+
+_LAYER_TENSORS = {
+    "input_layernorm.weight": T_ATTN_NORM, "self_attn.q_proj.weight": T_WQ, "self_attn.k_proj.weight": T_WK,
+    "self_attn.v_proj.weight": T_WV, "self_attn.o_proj.weight": T_WO, "post_attention_layernorm.weight": T_MLP_NORM,
+    "mlp.gate_proj.weight": T_WGATE, "mlp.up_proj.weight": T_WUP, "mlp.down_proj.weight": T_WDOWN,
+}
+
+
+@dataclass
+class LMConfig:
+    vocab_size: int
+    hidden_size: int
+    intermediate_size: int
+    num_layers: int
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int = 128
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0
+
+    @classmethod
+    def from_hf(cls, tc) -> "LMConfig":
+        rp = getattr(tc, "rope_parameters", None) or {}
+        theta = rp.get("rope_theta", getattr(tc, "rope_theta", 10000.0))
+        return cls(tc.vocab_size, tc.hidden_size, tc.intermediate_size, tc.num_hidden_layers, tc.num_attention_heads,
+                   getattr(tc, "num_key_value_heads", tc.num_attention_heads),
+                   getattr(tc, "head_dim", None) or tc.hidden_size // tc.num_attention_heads,
+                   tc.rms_norm_eps, float(theta))
+
+
+LLAVA15_7B = LMConfig(32064, 4096, 11008, 32, 32, 32, 128, 1e-5, 10000.0)
+VICUNA_7B = LMConfig(32001, 4096, 11008, 32, 32, 32, 128, 1e-6, 10000.0)
+MISTRAL_7B = LMConfig(32064, 4096, 14336, 32, 32, 8, 128, 1e-5, 1000000.0)
+
+
+class DropoutEngine:
+    def __init__(self, cfg: LMConfig, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
+                 seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None):
+        if family not in _FAMILY:
+            raise ValueError(f"unknown family {family!r}")
+        if not torch.cuda.is_available():
+            raise _lib.DDError("DropoutEngine needs a GPU (MI355X); there is no CPU fallback for the product path")
+        self.lib = _lib.load()
+        self.cfg, self.family = cfg, family
+        fam = dict(_FAMILY[family])
+        if family == FAMILY_NEXT and use_random:
+            fam["mask_mode"] = MASK_NEXT_NO_OVERLAP           # settings['use_random'][0] (llavanext.py:547-550)
+        self.k_top = fam["k_top"]
+        self.device = torch.device(device or "cuda")
+        torch.cuda.set_device(self.device)
+        c = _lib.LMConfigC(cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads,
+                           cfg.num_kv_heads, cfg.head_dim, cfg.rms_eps, cfg.rope_theta, max_seq, max_visual,
+                           fam["k_top"], fam["mask_mode"], fam["vote_on"], fam["leak_mask"])
+        self._h = C.c_void_p()
+        _lib.check(self.lib.dd_lm_create(C.byref(c), C.byref(self._h)), "dd_lm_create")
+        # the reference seeds torch's global generator at import (llava.py:16-20); under chair_test all three
+        # modules are imported so 5217 is in force. Default here: the family's own module seed.
+        self.rng = TorchCpuCompatRNG(fam["seed"] if seed is None else seed)
+        self.L = 0
+        self.masked_numbers: List[int] = []
+
+    # ---- weights ---------------------------------------------------------------------------
+    def _load(self, tid: int, layer: int, t: torch.Tensor) -> None:
+        t = t.detach()
+        if t.dim() == 1:
+            t = t[None]
+        t = t.to(torch.bfloat16).contiguous()
+        _lib.check(self.lib.dd_lm_load_tensor(self._h, tid, layer, t.view(torch.int16).data_ptr(), t.shape[0],
+                                              t.shape[1], 1 if t.is_cuda else 0), f"dd_lm_load_tensor({tid},{layer})")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "") -> None:
+        """HF LlamaForCausalLM / MistralForCausalLM parameter names (optionally under `prefix`)."""
+        g = lambda k: sd[prefix + k]
+        self._load(T_EMBED, 0, g("model.embed_tokens.weight"))
+        self._load(T_FINAL_NORM, 0, g("model.norm.weight"))
+        self._load(T_LM_HEAD, 0, g("lm_head.weight"))
+        for i in range(self.cfg.num_layers):
+            for name, tid in _LAYER_TENSORS.items():
+                self._load(tid, i, g(f"model.layers.{i}.{name}"))
+
+    def load_synthetic(self, seed: int = 0, std: float = 0.02) -> None:
+        _lib.check(self.lib.dd_lm_load_synthetic(self._h, seed, std), "dd_lm_load_synthetic")
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.dd_lm_device_bytes(self._h))
+
+    # ---- the path ---------------------------------------------------------------------------
+    def prefill(self, embeds: torch.Tensor, span_start: int, span_len: int) -> None:
+        if not embeds.is_cuda:
+            raise ValueError("embeds must be on the GPU")
+        e = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
+        if e.shape[1] != self.cfg.hidden_size:
+            raise ValueError(f"embeds have width {e.shape[1]}, model hidden size is {self.cfg.hidden_size}")
+        _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, _stream()),
+                   "dd_lm_prefill")
+        self.L, self.T0 = span_len, e.shape[0]
+        self._last_K = 0
+
+    def _probs(self, mprobs):
+        probs = list(settings["voting_numbers"] if mprobs is None else mprobs)   # read at every step (llava.py:340)
+        return probs, (C.c_double * max(len(probs), 1))(*[float(p) for p in probs])
+
+    def decode_step(self, mprobs: Optional[Sequence[float]] = None, uniforms: Optional[torch.Tensor] = None,
+                    dropout: bool = True) -> None:
+        """Enqueue one ensemble step (no host sync). dropout=False is the stock greedy step (`--original`)."""
+        probs, arr = self._probs(mprobs)
+        K = len(probs) if dropout else 0
+        un = None
+        if uniforms is not None:
+            un = uniforms.float().contiguous()
+            self._keepalive = un
+        _lib.check(self.lib.dd_lm_decode_step(self._h, arr, K, self.rng.handle, un.data_ptr() if un is not None else None,
+                                              _stream()), "dd_lm_decode_step")
+        self._last_K = K
+
+    # phased form for K-sharding (see dist.py)
+    def step_base(self, mprobs=None, uniforms=None) -> int:
+        probs, arr = self._probs(mprobs)
+        un = uniforms.float().contiguous() if uniforms is not None else None
+        self._keepalive = un
+        _lib.check(self.lib.dd_lm_step_base(self._h, arr, len(probs), self.rng.handle,
+                                            un.data_ptr() if un is not None else None, _stream()), "dd_lm_step_base")
+        self._last_K = len(probs)
+        return len(probs)
+
+    def step_members(self, m_lo: int, m_hi: int) -> None:
+        _lib.check(self.lib.dd_lm_step_members(self._h, m_lo, m_hi, _stream()), "dd_lm_step_members")
+
+    def step_commit(self) -> None:
+        _lib.check(self.lib.dd_lm_step_commit(self._h, self._last_K, _stream()), "dd_lm_step_commit")
+
+    def set_next_token(self, token: int) -> None:
+        _lib.check(self.lib.dd_lm_set_next_token(self._h, int(token), _stream()), "dd_lm_set_next_token")
+
+    def generate(self, n_new: int, eos: Optional[int] = None, mprobs=None, dropout: bool = True, chunk: int = 16) -> List[int]:
+        """Greedy loop of HF `_sample`: the prefill's token first, then ensemble steps until EOS or n_new.
+        Steps are enqueued `chunk` at a time; tokens past an EOS inside a chunk are discarded."""
+        toks = self.tokens()
+        while len(toks) < n_new and (eos is None or toks[-1] != eos):
+            for _ in range(min(chunk, n_new - len(toks))):
+                self.decode_step(mprobs, dropout=dropout)
+            toks = self.tokens()
+            if eos is not None and eos in toks:
+                toks = toks[:toks.index(eos) + 1]
+                break
+        return toks[:n_new]
+
+    # ---- read-backs (synchronise) -------------------------------------------------------------
+    def _get(self, what: int, n: int, dtype) -> np.ndarray:
+        out = np.empty(n, dtype=dtype)
+        _lib.check(self.lib.dd_lm_get(self._h, what, out.ctypes.data, out.nbytes, _stream()), f"dd_lm_get({what})")
+        return out
+
+    def n_tokens(self) -> int:
+        torch.cuda.current_stream().synchronize()
+        return self.T() - self.T0 + 1
+
+    def T(self) -> int:
+        return int(self._get(GET_SEQ_LEN, 1, np.int32)[0])
+
+    def tokens(self) -> List[int]:
+        n = self.T() - self.T0 + 1
+        return self._get(GET_TOKENS, n, np.int32).tolist()
+
+    def logits(self) -> np.ndarray:
+        return self._get(GET_LOGITS, self.cfg.vocab_size, np.float32)
+
+    def base_logits(self) -> np.ndarray:
+        return self._get(GET_BASE_LOGITS, self.cfg.vocab_size, np.float32)
+
+    def hidden(self) -> np.ndarray:
+        return self._get(GET_HIDDEN, self.cfg.hidden_size, np.float32)
+
+    def image_logits(self) -> np.ndarray:
+        return self._get(GET_IMAGE_LOGITS, self.L * self.cfg.vocab_size, np.float32).reshape(self.L, -1)
+
+    def vision_uncert_dict(self) -> Dict[str, np.ndarray]:
+        sc = self._get(GET_UNCERT_SCALARS, 3, np.float32)
+        return {"variance_per_token": self._get(GET_VAR, self.L, np.float32)[None],
+                "epis_uncert_per_token": self._get(GET_EPI, self.L, np.float32)[None],
+                "alea_uncert_per_token": self._get(GET_ALEA, self.L, np.float32)[None],
+                "variance": sc[0:1], "epis_uncert": sc[1:2], "alea_uncert": sc[2:3]}
+
+    def topk(self):
+        return (self._get(GET_TOPK_VALS, self.L * self.k_top, np.float32).reshape(self.L, self.k_top),
+                self._get(GET_TOPK_IDS, self.L * self.k_top, np.int32).reshape(self.L, self.k_top))
+
+    def last_step(self) -> Dict[str, np.ndarray]:
+        K = self._last_K
+        w = self._get(GET_WINNER, 2, np.int32)
+        return {"drop": self._get(GET_DROP, K * self.L, np.uint8).reshape(K, self.L).astype(bool),
+                "masked_numbers": self._get(GET_N_DROP, K, np.int32), "keep": self._get(GET_KEEP, self.L, np.uint8).astype(bool),
+                "member_argmax": self._get(GET_MEMBER_ARGMAX, K, np.int32), "winner": int(w[0]), "voted": int(w[1])}
+
+    def kv_sums(self) -> np.ndarray:
+        return self._get(GET_KV_SUMS, self.cfg.num_layers * 2, np.float64).reshape(-1, 2)
+
+    def algorithmic_bytes(self, K: int) -> float:
+        return float(self.lib.dd_lm_step_algorithmic_bytes(self._h, K))
+
+    def time_sweep(self, nb: int, iters: int) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.dd_lm_time_sweep(self._h, nb, iters, C.byref(ms), _stream()), "dd_lm_time_sweep")
+        return float(ms.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.dd_lm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,247 @@
+/*
+ * dropdec.h — C-ABI of the MI355X-native Dropout-Decoding hot path (libdropdec.so).
+ *
+ * The reference (kigb/DropoutDecoding) is pure Python: its "FFI" for this path is the set of
+ * Python methods its forward() overrides call.  Each entry point below names the reference
+ * function (file:line in the reference tree) it replaces.  The Python host side
+ * (dropoutdecoding_amd/) binds these with ctypes; INTEGRATION.md shows the stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DD_E* code and never throws;
+ *     dd_last_error() returns a human-readable message for the calling thread's last failure;
+ *   - pointers named *_dev are device (HBM) pointers owned by the caller unless stated
+ *     otherwise; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - nothing here allocates device memory except dd_lm_create/dd_lm_load_* (and
+ *     dd_rng_create), and nothing synchronises the device except the dd_*_read/_get copies
+ *     that say so;
+ *   - integer results (token ids, top-k ids, mask flags, winner index) are bit-exact with the
+ *     reference's CPU path on identical inputs; floating-point results agree to the tolerances
+ *     stated in tests/ (DESIGN.md "Numerics").
+ */
+#ifndef DROPDEC_H
+#define DROPDEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_OK 0
+#define DD_EINVAL (-1)     /* bad argument / unsupported shape */
+#define DD_EHIP (-2)       /* a HIP runtime call failed */
+#define DD_ENOMEM (-3)
+#define DD_ESTATE (-4)     /* call sequence error (e.g. decode before prefill) */
+
+#define DD_MAX_MEMBERS_PER_PASS 8   /* ensemble members packed into one weight sweep */
+#define DD_MAX_TOPK 16
+
+/* mask-sampler modes: which family's get_image_attention_mask() semantics to follow */
+#define DD_MASK_LLAVA_CUMULATIVE 0  /* models/llava.py:589-662, mask not reset between members (:344) */
+#define DD_MASK_NEXT_RESET 1        /* models/llavanext.py:779-808, reset at :546                       */
+#define DD_MASK_NEXT_NO_OVERLAP 2   /* models/llavanext.py:809-829 ("epis_no_overlap", no keep-restore)  */
+#define DD_MASK_IBLIP_QUANTILE 3    /* models/instructblip.py:447-460, deterministic quantile, reset :121 */
+
+/* where the dropout uniforms come from (models/llava.py:650 `torch.rand_like`) */
+#define DD_RNG_INJECTED 0           /* caller supplies uniforms[K][L] (parity tests)                     */
+#define DD_RNG_MT19937 1            /* torch-CPU-compatible mt19937 stream kept in device memory          */
+
+/* what the ensemble votes on */
+#define DD_VOTE_LOGITS 0            /* models/llava.py:27, models/llavanext.py:31                         */
+#define DD_VOTE_HIDDEN 1            /* models/instructblip.py:125-137 (argmax over the final hidden state) */
+
+int dd_version(void);
+const char* dd_last_error(void);
+/* compiled-for architecture string, e.g. "gfx950" */
+const char* dd_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * RNG: torch's CPU default generator restated on the device.
+ * Replaces torch.manual_seed(seed) (models/llava.py:16-20, llavanext.py:18-21,
+ * instructblip.py:17-21) + the stream torch.rand_like() consumes (models/llava.py:650).
+ * State = 625 uint32 words in device memory (624 mt words + read index).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dd_rng dd_rng;
+int dd_rng_create(uint32_t seed, dd_rng** out);
+int dd_rng_destroy(dd_rng* r);
+int dd_rng_seed(dd_rng* r, uint32_t seed, void* stream);
+/* out_dev[n] = next n float32 uniforms of the stream, (x & 0xFFFFFF) * 2^-24 */
+int dd_rng_uniform(dd_rng* r, float* out_dev, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-visual-token uncertainty scorer.
+ * Replaces calculate_vision_uncertainty(logits) (models/llava.py:710-756; copies at
+ * llavanext.py:878-924, instructblip.py:511-557) and get_topk_token_id (llava.py:428-441).
+ *   logits_dev [L][ld] fp32 (ld >= V; columns >= V ignored)
+ *   var_tok/epi_tok/alea_tok [L] fp32; scalars3 = {mean var, mean epi, mean alea}
+ *   topk_vals [L][k] fp32 / topk_ids [L][k] int32 (either may be NULL), descending, ties ->
+ *   lowest id first
+ *   workspace_dev: at least dd_uncertainty_workspace_bytes(L, V) bytes
+ * ------------------------------------------------------------------------------------------ */
+size_t dd_uncertainty_workspace_bytes(int L, int V);
+int dd_vision_uncertainty(const float* logits_dev, int L, int V, int ld,
+                          float* var_tok_dev, float* epi_tok_dev, float* alea_tok_dev, float* scalars3_dev,
+                          int k_top, float* topk_vals_dev, int32_t* topk_ids_dev,
+                          void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Keep set. Replaces get_overlap_image_tokens (models/llava.py:443-482).
+ *   keep_dev[l] = 1 iff argmax(step_logits) is among topk_ids[l][0..k)
+ *   argmax_dev (optional) receives the argmax (first index among equal maxima)
+ * ------------------------------------------------------------------------------------------ */
+int dd_overlap_keep(const float* step_logits_dev, int V, const int32_t* topk_ids_dev, int L, int k,
+                    uint8_t* keep_dev, int32_t* argmax_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Uncertainty-guided visual-token dropout masks for all K members of one step.
+ * Replaces get_image_attention_mask(method="epis"/"epis_no_overlap") for the three families
+ * (models/llava.py:589-683, llavanext.py:779-829, instructblip.py:447-460) including the
+ * per-family reset / cumulative / keep-restore behaviour of the calling loop
+ * (llava.py:342-346, llavanext.py:544-551, instructblip.py:119-122).
+ *   epi_dev [L] fp32; mprobs_host [K] doubles = settings['voting_numbers'] (models/config.py:2)
+ *   keep_dev [L] u8 (from dd_overlap_keep); ignored for DD_MASK_NEXT_NO_OVERLAP
+ *   rng_mode DD_RNG_INJECTED: uniforms_dev [K][L] fp32;  DD_RNG_MT19937: rng != NULL, the
+ *   stream advances by K*L draws (member-major), exactly like K rand_like(epi) calls
+ *   drop_dev [K][L] u8: 1 = attention mask set to 0 for that member
+ *   n_drop_dev [K] int32 (= the reference's masked_numbers, llava.py:661-662)
+ *   idx_dev (optional) [K][L] int32: ascending indices of dropped tokens, -1 padded
+ * K <= 64, L <= 8192.
+ * ------------------------------------------------------------------------------------------ */
+int dd_sample_masks(const float* epi_dev, int L, const double* mprobs_host, int K,
+                    const uint8_t* keep_dev, int mode, int rng_mode, const float* uniforms_dev, dd_rng* rng,
+                    uint8_t* drop_dev, int32_t* n_drop_dev, int32_t* idx_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Majority vote. Replaces select_by_vote (models/llava.py:22-36, llavanext.py:26-39).
+ *   argmax_ids_dev [K] int32 -> out2_dev = {winner member index, majority token id}
+ *   ties: the id inserted first (lowest member index) wins; winner = first member with it.
+ * ------------------------------------------------------------------------------------------ */
+int dd_vote(const int32_t* argmax_ids_dev, int K, int32_t* out2_dev, void* stream);
+
+/* rows [R][ld] fp32 -> argmax_dev [R] int32 over the first V columns (torch.argmax semantics) */
+int dd_argmax_rows(const float* x_dev, int R, int V, int ld, int32_t* argmax_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The language-model engine: the K-way masked-context decode step.
+ * Replaces the third-party LM the reference calls 1+K times per token
+ * (models/llava.py:294-303,350-359; llavanext.py:505-514,553-562; instructblip.py:68-82,125-140)
+ * together with the KV deep copies (llava.py:292,343), the per-step mask/position rebuild
+ * (llava.py:254-283), the ensemble loop (llava.py:338-359), the vote and the return of the
+ * winner's logits + cache (llava.py:361-376).
+ * Weights are bf16, activations/accumulation fp32, KV cache fp32 (DESIGN.md "Numerics").
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dd_lm_config {
+  int32_t vocab_size;        /* V (real)                                   */
+  int32_t hidden_size;       /* d, multiple of 256                          */
+  int32_t intermediate_size; /* d_ff, multiple of 256                       */
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t num_kv_heads;
+  int32_t head_dim;          /* must be 128                                 */
+  float rms_eps;
+  float rope_theta;
+  int32_t max_seq;           /* KV capacity in tokens                       */
+  int32_t max_visual;        /* max visual-span length L                    */
+  int32_t k_top;             /* 5 (LLaVA-1.5) or 10 (NeXT, InstructBLIP)    */
+  int32_t mask_mode;         /* DD_MASK_*                                   */
+  int32_t vote_on;           /* DD_VOTE_*                                   */
+  int32_t leak_mask;         /* InstructBLIP Q2: base pass sees last member's zeros */
+  int32_t reserved[5];
+} dd_lm_config;
+
+typedef struct dd_lm dd_lm;
+
+/* tensor ids for dd_lm_load_tensor (HF parameter names in comments) */
+#define DD_T_EMBED 0      /* model.embed_tokens.weight            [V][d]      */
+#define DD_T_ATTN_NORM 1  /* layers.i.input_layernorm.weight      [d]         */
+#define DD_T_WQ 2         /* layers.i.self_attn.q_proj.weight     [H*128][d]  */
+#define DD_T_WK 3         /* layers.i.self_attn.k_proj.weight     [Hkv*128][d]*/
+#define DD_T_WV 4         /* layers.i.self_attn.v_proj.weight                 */
+#define DD_T_WO 5         /* layers.i.self_attn.o_proj.weight     [d][H*128]  */
+#define DD_T_MLP_NORM 6   /* layers.i.post_attention_layernorm.weight         */
+#define DD_T_WGATE 7      /* layers.i.mlp.gate_proj.weight        [d_ff][d]   */
+#define DD_T_WUP 8        /* layers.i.mlp.up_proj.weight                      */
+#define DD_T_WDOWN 9      /* layers.i.mlp.down_proj.weight        [d][d_ff]   */
+#define DD_T_FINAL_NORM 10/* model.norm.weight                                */
+#define DD_T_LM_HEAD 11   /* lm_head.weight                       [V][d]      */
+
+int dd_lm_create(const dd_lm_config* cfg, dd_lm** out);
+int dd_lm_destroy(dd_lm* h);
+/* bytes of device memory the handle holds (weights + KV + scratch) */
+size_t dd_lm_device_bytes(const dd_lm* h);
+
+/* Copy one HF-layout bf16 tensor (row-major, `rows` x `cols`) into the engine and re-tile it
+ * for MFMA streaming. src may be a host or a device pointer (src_on_device).  Synchronous. */
+int dd_lm_load_tensor(dd_lm* h, int tensor_id, int layer, const uint16_t* src_bf16, int rows, int cols,
+                      int src_on_device);
+/* Fill every weight with a deterministic pseudo-random bf16 pattern of the given scale
+ * (synthetic-weights benchmark mode; no host traffic). */
+int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std);
+
+/* Prefill: full causal pass over T0 input embeddings (fp32, row-major [T0][d], device),
+ * lm_head over the visual span + last position, top-k ids, uncertainty scorer.
+ * Replaces the prefill branch of forward() (models/llava.py:285-314).  Resets the sequence. */
+int dd_lm_prefill(dd_lm* h, const float* embeds_dev, int T0, int span_start, int span_len, void* stream);
+
+/* One ensemble decode step, enqueued on `stream` without host synchronisation:
+ * embed(last token) -> un-masked pass -> argmax -> keep set -> K masks -> K masked members in
+ * one packed sweep -> vote -> winner's logits/argmax + KV row committed.
+ * mprobs_host[K] = settings['voting_numbers'] read at this step (models/llava.py:340).
+ * K = 0 runs the stock greedy step (`--original`).  rng may be NULL for IBLIP/injected modes;
+ * uniforms_dev (optional, [K][L]) overrides the rng for this step (parity tests). */
+int dd_lm_decode_step(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, const float* uniforms_dev,
+                      void* stream);
+
+/* The same step in three phases, for sharding the K members over ranks:
+ *   phase A: un-masked pass + keep set + masks for ALL K members (every rank, identical);
+ *   phase B: members [m_lo, m_hi) in one packed sweep; fills this rank's slice of the
+ *            exchange record;  the caller then exchanges records between ranks;
+ *   phase C: vote over all K argmax ids, commit the winner (whose row must be present in
+ *            the exchange record on every rank).
+ * Exchange record (fp32 words, device): per member m a block of dd_lm_xchg_stride(h) floats:
+ *   [0] argmax id (as float bits of int32), [1..] logits[V_pad], then the member's new KV
+ *   rows [layers][2][kv_dim]. */
+int dd_lm_step_base(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, const float* uniforms_dev, void* stream);
+int dd_lm_step_members(dd_lm* h, int m_lo, int m_hi, void* stream);
+int dd_lm_step_commit(dd_lm* h, int K, void* stream);
+size_t dd_lm_xchg_stride(const dd_lm* h);
+float* dd_lm_xchg_ptr(dd_lm* h);      /* device pointer, K_max * stride floats, owned by the handle */
+
+/* Read-backs (synchronise `stream` first). what: */
+#define DD_GET_TOKENS 0        /* int32 [n_generated]   tokens emitted so far (incl. the prefill's greedy token) */
+#define DD_GET_LOGITS 1        /* fp32  [V]             logits returned by the last forward                      */
+#define DD_GET_EPI 2           /* fp32  [L]             epis_uncert_per_token                                     */
+#define DD_GET_ALEA 3          /* fp32  [L]                                                                        */
+#define DD_GET_VAR 4           /* fp32  [L]                                                                        */
+#define DD_GET_UNCERT_SCALARS 5/* fp32  [3]             variance, epis_uncert, alea_uncert                         */
+#define DD_GET_TOPK_IDS 6      /* int32 [L][k_top]                                                                 */
+#define DD_GET_TOPK_VALS 7     /* fp32  [L][k_top]                                                                 */
+#define DD_GET_DROP 8          /* u8    [K][L]          last step's drop flags                                     */
+#define DD_GET_N_DROP 9        /* int32 [K]             last step's masked_numbers                                 */
+#define DD_GET_MEMBER_ARGMAX 10/* int32 [K]                                                                        */
+#define DD_GET_WINNER 11       /* int32 [2]             {winner index, voted id}                                   */
+#define DD_GET_BASE_LOGITS 12  /* fp32  [V]             un-masked pass logits of the last step                     */
+#define DD_GET_IMAGE_LOGITS 13 /* fp32  [L][V]          prefill logits over the visual span                        */
+#define DD_GET_KEEP 14         /* u8    [L]                                                                        */
+#define DD_GET_KV_SUMS 15      /* fp64  [layers][2]     sum of K and of V entries over the committed cache         */
+#define DD_GET_SEQ_LEN 16      /* int32 [1]             committed KV length                                        */
+#define DD_GET_HIDDEN 17       /* fp32  [d]             final-normed hidden state behind DD_GET_LOGITS             */
+int dd_lm_get(dd_lm* h, int what, void* dst_host, size_t bytes, void* stream);
+
+/* Force the next decode step's input token (default: the last emitted token). */
+int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream);
+
+/* Roofline bookkeeping: algorithmic HBM bytes of one decode step at the current length
+ * (2 * W_lm + 2 * T * kv_tok for dropout steps) */
+double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K);
+
+/* Time the packed member sweep alone with HIP events on `stream`: runs `iters` sweeps of
+ * `nb` rows at the current length and returns the mean milliseconds (bench.py roofline leg). */
+int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DROPDEC_H */

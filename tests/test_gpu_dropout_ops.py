@@ -1,0 +1,176 @@
+"""HIP kernels of the dropout-specific functions vs the oracle and the reference's golden vectors (through the C-ABI)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dropout_ref as DR
+from oracle.mt19937 import TorchCpuMT19937
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dropoutdecoding_amd import build
+    build.build()
+    from dropoutdecoding_amd import dropout
+    assert torch.cuda.is_available()
+    return dropout
+
+
+def test_rng_is_torch_cpu_stream(ops, golden_dir):
+    g = _load(golden_dir, "g6_rng.npz")
+    for c in range(int(g["n_cases"])):
+        rng = ops.TorchCpuCompatRNG(int(g[f"c{c}_seed"]))
+        mine = np.concatenate([rng.rand(int(n)).cpu().numpy() for n in g[f"c{c}_sizes"]])
+        np.testing.assert_array_equal(mine, g[f"c{c}_draws"])
+    rng = ops.TorchCpuCompatRNG(123)
+    ref = TorchCpuMT19937(123)
+    for n in (1, 623, 624, 625, 5000, 3, 1248):
+        np.testing.assert_array_equal(rng.rand(n).cpu().numpy(), ref.rand_f32(n))
+    rng.manual_seed(5217)
+    np.testing.assert_array_equal(rng.rand(700).cpu().numpy(), TorchCpuMT19937(5217).rand_f32(700))
+
+
+def test_uncertainty_golden(ops, golden_dir):
+    g = _load(golden_dir, "g1_uncertainty.npz")
+    for c in range(int(g["n_cases"])):
+        logits = torch.from_numpy(g[f"c{c}_logits"]).cuda()
+        k = int(g[f"c{c}_k"])
+        d, (vals, ids) = ops.calculate_vision_uncertainty(logits, topk=k)
+        for key, rtol in (("epis_uncert_per_token", 2e-5), ("alea_uncert_per_token", 2e-5), ("variance_per_token", 1e-4),
+                          ("variance", 1e-4), ("epis_uncert", 2e-5), ("alea_uncert", 2e-5)):
+            np.testing.assert_allclose(d[key].cpu().numpy(), g[f"c{c}_{key}"], rtol=rtol, atol=1e-9, err_msg=f"{c} {key}")
+        np.testing.assert_array_equal(ids[0].cpu().numpy(), g[f"c{c}_topk_ids"][0])     # bit-exact index work
+        np.testing.assert_array_equal(vals[0].cpu().numpy(), g[f"c{c}_topk_vals"][0])
+
+
+@pytest.mark.parametrize("L,V,scale", [(576, 32064, 4.0), (32, 32001, 6.0), (7, 130, 2.0)])
+def test_uncertainty_full_size_vs_oracle(ops, L, V, scale):
+    gen = torch.Generator().manual_seed(L + V)
+    logits = (torch.randn(1, L, V, generator=gen) * scale).float()
+    ref = DR.vision_uncertainty(logits)
+    rv, ri = DR.topk_tokens(logits, 10)
+    d, (vals, ids) = ops.calculate_vision_uncertainty(logits.cuda(), topk=10)
+    np.testing.assert_allclose(d["epis_uncert_per_token"].cpu().numpy(), ref["epis_uncert_per_token"].numpy(), rtol=5e-5)
+    np.testing.assert_allclose(d["alea_uncert_per_token"].cpu().numpy(), ref["alea_uncert_per_token"].numpy(), rtol=5e-5)
+    np.testing.assert_allclose(d["variance_per_token"].cpu().numpy(), ref["variance_per_token"].numpy(), rtol=2e-4)
+    np.testing.assert_array_equal(ids[0].cpu().numpy(), ri[0].numpy())
+    np.testing.assert_array_equal(vals[0].cpu().numpy(), rv[0].numpy())
+
+
+def test_uncertainty_padded_rows(ops):
+    """ld > V (the engine's padded vocabulary): padding columns must be ignored."""
+    gen = torch.Generator().manual_seed(3)
+    L, V, ld = 5, 100, 112
+    buf = torch.full((L, ld), 1e30)
+    buf[:, :V] = torch.randn(L, V, generator=gen) * 3
+    ref = DR.vision_uncertainty(buf[None, :, :V].contiguous())
+    d = ops.calculate_vision_uncertainty(buf.cuda()[:, :V])
+    np.testing.assert_allclose(d["epis_uncert_per_token"].cpu().numpy(), ref["epis_uncert_per_token"].numpy(), rtol=5e-5)
+
+
+def test_overlap_keep_golden(ops, golden_dir):
+    g = _load(golden_dir, "g2_overlap.npz")
+    topk = torch.from_numpy(g["topk_ids"]).cuda()
+    for c in range(int(g["n_cases"])):
+        idx, keep = ops.get_overlap_image_tokens(torch.from_numpy(g[f"c{c}_logits"]).cuda(), topk, int(g["start"]))
+        np.testing.assert_array_equal(idx.cpu().numpy(), g[f"c{c}_idx"])
+
+
+def test_argmax_first_maximal_index(ops):
+    x = torch.zeros(3, 1000)
+    x[0, 17] = x[0, 600] = 5.0
+    x[1, 999] = 1.0
+    x[2] = -1.0
+    x[2, 0] = x[2, 5] = 0.5
+    assert ops.argmax_rows(x.cuda()).tolist() == torch.argmax(x, -1).tolist() == [17, 999, 0]
+
+
+MODES = [("llava", DR.MODE_LLAVA_CUMULATIVE), ("next", DR.MODE_NEXT_RESET), ("next_no_overlap", DR.MODE_NEXT_NO_OVERLAP),
+         ("iblip", DR.MODE_IBLIP_QUANTILE)]
+
+
+@pytest.mark.parametrize("fam,mode", MODES)
+@pytest.mark.parametrize("rng_mode", ["injected", "mt19937"])
+def test_masks_golden(ops, golden_dir, fam, mode, rng_mode):
+    g = _load(golden_dir, "g3_masks.npz")
+    for c in range(int(g["n_cases"])):
+        epi = torch.from_numpy(g[f"c{c}_epi"]).cuda()
+        probs = [float(p) for p in g[f"c{c}_probs"]]
+        _, keep = ops.get_overlap_image_tokens(torch.from_numpy(g[f"c{c}_step_logits"]).cuda(),
+                                               torch.from_numpy(g[f"c{c}_topk_ids"]).cuda())
+        if rng_mode == "injected":
+            drop, nd, idx = ops.sample_masks(epi, probs, keep, mode, uniforms=torch.from_numpy(g[f"c{c}_uniforms"]).cuda(),
+                                             want_indices=True)
+        else:
+            rng = ops.TorchCpuCompatRNG(int(g[f"c{c}_seed"]))
+            drop, nd, idx = ops.sample_masks(epi, probs, keep, mode, rng=rng, want_indices=True)
+        start, L = int(g[f"c{c}_start"]), epi.numel()
+        ref = g[f"c{c}_{fam}_masks"][:, start:start + L] == 0
+        np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), ref, err_msg=f"case {c} {fam} {rng_mode}")
+        np.testing.assert_array_equal(nd.cpu().numpy(), ref.sum(1))
+        if fam == "llava":
+            np.testing.assert_array_equal(nd.cpu().numpy(), g[f"c{c}_llava_masked_numbers"])
+        idx = idx.cpu().numpy()
+        for k in range(len(probs)):
+            want = np.nonzero(ref[k])[0]
+            np.testing.assert_array_equal(idx[k, :len(want)], want)        # ascending dropped indices
+            assert (idx[k, len(want):] == -1).all()
+
+
+@pytest.mark.parametrize("fam,mode", MODES)
+def test_masks_random_trials_vs_oracle(ops, fam, mode):
+    rs = np.random.RandomState(hash(fam) % 1000)
+    for trial in range(40):
+        L = int(rs.choice([1, 2, 31, 32, 33, 64, 100, 576, 1000, 2928]))
+        K = int(rs.randint(1, 9))
+        probs = [float(p) for p in rs.choice([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.25, 0.33], K)]
+        epi = torch.from_numpy((rs.rand(L) * 2).astype(np.float32))
+        if trial % 5 == 0 and L > 4:
+            epi[rs.randint(0, L, L // 2)] = epi[0]               # duplicates (quantile ties)
+        keep = torch.from_numpy(rs.rand(L) < 0.05)
+        uni = torch.from_numpy(rs.rand(K, L).astype(np.float32))
+        ref = DR.sample_masks(epi, probs, keep, mode, uni)
+        drop, nd = ops.sample_masks(epi.cuda(), probs, keep.cuda(), mode, uniforms=uni.cuda())
+        np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), ref.numpy(), err_msg=f"trial {trial} L={L} probs={probs}")
+
+
+def test_mask_rng_stream_continues_across_steps(ops):
+    """Two steps of K=3 consume 6 consecutive rand_like(epi) draws of one stream (reference llava.py:650)."""
+    L, probs = 100, [0.3, 0.5, 0.7]
+    epi = torch.linspace(0, 1, L)
+    keep = torch.zeros(L, dtype=torch.bool)
+    rng = ops.TorchCpuCompatRNG(24)
+    ref = TorchCpuMT19937(24)
+    for step in range(2):
+        uni = torch.from_numpy(np.stack([ref.rand_f32(L) for _ in probs]))
+        want = DR.sample_masks(epi, probs, keep, DR.MODE_LLAVA_CUMULATIVE, uni)
+        drop, _ = ops.sample_masks(epi.cuda(), probs, keep.cuda(), DR.MODE_LLAVA_CUMULATIVE, rng=rng)
+        np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), want.numpy())
+
+
+def test_vote_golden_and_random(ops, golden_dir):
+    g = _load(golden_dir, "g4_vote.npz")
+    for c in range(int(g["n_cases"])):
+        ids = g[f"c{c}_ids"]
+        w, t = ops.select_by_vote(torch.from_numpy(ids).cuda())
+        assert w == int(g[f"c{c}_winner"]) and t == int(ids[w])
+    rs = np.random.RandomState(0)
+    for _ in range(50):
+        ids = rs.randint(0, 4, rs.randint(1, 17))
+        assert ops.select_by_vote(torch.from_numpy(ids).cuda()) == DR.vote(ids.tolist())
+
+
+def test_bad_arguments_raise(ops):
+    with pytest.raises(ValueError):
+        ops.sample_masks(torch.zeros(9000).cuda(), [0.3], torch.zeros(9000, dtype=torch.bool).cuda(), 0,
+                         uniforms=torch.zeros(1, 9000).cuda())
+    with pytest.raises(ValueError):
+        ops.calculate_vision_uncertainty(torch.zeros(4, 8))          # CPU tensor: no CPU fallback

@@ -1,0 +1,187 @@
+"""The HIP decode-step engine vs the golden end-to-end vectors (the reference's forward) and vs the oracle.
+
+Tolerances (DESIGN.md "Numerics"): token ids, mask flags, member argmax ids, winner index — exact;
+logits within 1e-3 of the fp32 reference relative to the largest |logit| (north star: "1e-3 relative fp32").
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.decode_ref import FAMILY_IBLIP, FAMILY_LLAVA, FAMILY_NEXT, RefDecoder
+from oracle.lm_ref import LMConfig as RefCfg, random_weights
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def close(a, b, rel=1e-3):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= rel * np.abs(b).max()
+
+
+@pytest.fixture(scope="module")
+def E():
+    from dropoutdecoding_amd import build
+    build.build()
+    from dropoutdecoding_amd import lm
+    return lm
+
+
+def _engine(E, g, family, use_random=False, seed=None, max_seq=256):
+    v, d, f, nl, nh, nkv, hd = [int(x) for x in g["cfg"]]
+    rcfg = RefCfg(v, d, f, nl, nh, nkv, hd, float(g["rms_eps"]), float(g["rope_theta"]))
+    w = random_weights(rcfg, int(g["wseed"]), float(g["std"]))
+    cfg = E.LMConfig(v, d, f, nl, nh, nkv, hd, float(g["rms_eps"]), float(g["rope_theta"]))
+    eng = E.DropoutEngine(cfg, family=family, max_seq=max_seq, max_visual=int(g["span_len"]) + 8, seed=seed,
+                          use_random=use_random)
+    eng.load_state_dict(w)
+    return eng, rcfg, w
+
+
+CASES = [("g5_llava_k3.npz", FAMILY_LLAVA), ("g5_llava_k8.npz", FAMILY_LLAVA), ("g5_next_k4.npz", FAMILY_NEXT),
+         ("g5_next_norestore_k2.npz", FAMILY_NEXT)]
+
+
+@pytest.mark.parametrize("name,family", CASES)
+@pytest.mark.parametrize("rng", ["injected", "mt19937"])
+def test_end_to_end_golden(E, golden_dir, name, family, rng):
+    g = _load(golden_dir, name)
+    use_random = bool(int(g["use_random"]))
+    eng, rcfg, w = _engine(E, g, family, use_random, seed=int(g["rseed"]))
+    probs = [float(p) for p in g["probs"]]
+    s0, L = int(g["span_start"]), int(g["span_len"])
+    eng.prefill(torch.from_numpy(g["embeds"]).cuda(), s0, L)
+    assert close(eng.logits(), g["prefill_logits_last"])
+    assert close(eng.image_logits(), g["prefill_image_logits"])
+    u = eng.vision_uncert_dict()
+    np.testing.assert_allclose(u["epis_uncert_per_token"], g["epis_uncert_per_token"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(u["alea_uncert_per_token"], g["alea_uncert_per_token"], rtol=1e-3)
+    np.testing.assert_allclose(u["variance_per_token"], g["variance_per_token"], rtol=5e-3)
+    assert set(map(tuple, np.sort(eng.topk()[1], 1))) == set(map(tuple, np.sort(g["topk_ids"], 1)))
+    toks = eng.tokens()
+    assert toks == [int(g["tokens"][0])]
+    for s in range(len(g["tokens"]) - 1):
+        uni = torch.from_numpy(g["uniforms"][s]).cuda() if rng == "injected" else None
+        eng.decode_step(probs, uniforms=uni)
+        st = eng.last_step()
+        assert int(np.argmax(eng.base_logits())) == int(g["step_base_argmax"][s])
+        assert close(eng.base_logits(), g["step_base_logits"][s])
+        np.testing.assert_array_equal(st["drop"], g["step_drop"][s].astype(bool), err_msg=f"step {s}")
+        assert st["member_argmax"].tolist() == g["step_member_argmax"][s].tolist()
+        assert st["winner"] == int(g["step_winner"][s])
+        assert close(eng.logits(), g["step_logits"][s])
+        if "step_masked_numbers" in g.files:
+            assert st["masked_numbers"].tolist() == g["step_masked_numbers"][s].tolist()
+    assert eng.tokens() == g["tokens"].tolist()
+    assert eng.T() == int(g["kv_len"])
+    kv = eng.kv_sums()
+    np.testing.assert_allclose(kv[:, 0], g["kv_k_sum"], atol=2e-2)
+    np.testing.assert_allclose(kv[:, 1], g["kv_v_sum"], atol=2e-2)
+    eng.close()
+
+
+def test_end_to_end_golden_instructblip(E, golden_dir):
+    g = _load(golden_dir, "g5_iblip_k3.npz")
+    eng, rcfg, w = _engine(E, g, FAMILY_IBLIP)
+    probs = [float(p) for p in g["probs"]]
+    eng.prefill(torch.from_numpy(g["embeds"]).cuda(), 0, int(g["span_len"]))
+    np.testing.assert_allclose(eng.vision_uncert_dict()["epis_uncert_per_token"], g["epis_uncert_per_token"], rtol=2e-3, atol=1e-6)
+    for s in range(len(g["tokens"]) - 1):
+        eng.decode_step(probs)
+        st = eng.last_step()
+        np.testing.assert_array_equal(st["drop"], g["step_drop"][s].astype(bool), err_msg=f"step {s}")
+        assert st["member_argmax"].tolist() == g["step_member_argmax"][s].tolist()     # Q3: hidden-state argmax
+    assert eng.tokens() == g["tokens"].tolist()
+    eng.close()
+
+
+def test_original_greedy_matches_oracle(E, golden_dir):
+    """`--original` (K=0): stock greedy decode, BASELINE configs[0]."""
+    g = _load(golden_dir, "g5_llava_k3.npz")
+    eng, rcfg, w = _engine(E, g, FAMILY_LLAVA)
+    emb = torch.from_numpy(g["embeds"])
+    s0, L = int(g["span_start"]), int(g["span_len"])
+    ref = RefDecoder(FAMILY_LLAVA, rcfg, w, [], dropout=False)
+    want = ref.generate(emb, s0, L, 10)
+    eng.prefill(emb.cuda(), s0, L)
+    got = eng.generate(10, dropout=False)
+    assert got == want
+    assert close(eng.logits(), ref.records[-1].logits)
+    eng.close()
+
+
+@pytest.mark.parametrize("family,K", [(FAMILY_LLAVA, 8), (FAMILY_NEXT, 3), (FAMILY_IBLIP, 4), (FAMILY_LLAVA, 1)])
+def test_longer_decode_vs_oracle_first_divergence(E, golden_dir, family, K):
+    """24 steps against the oracle on seeded inputs; reports the first divergence and the margin there."""
+    gname = {FAMILY_LLAVA: "g5_llava_k3.npz", FAMILY_NEXT: "g5_next_k4.npz", FAMILY_IBLIP: "g5_iblip_k3.npz"}[family]
+    g = _load(golden_dir, gname)
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8][:K] if K > 1 else [0.5]
+    eng, rcfg, w = _engine(E, g, family, seed=77)
+    ref = RefDecoder(family, rcfg, w, probs, seed=77)
+    emb = torch.from_numpy(g["embeds"])
+    s0, L = int(g["span_start"]), int(g["span_len"])
+    n_new = 25
+    want = ref.generate(emb, s0, L, n_new)
+    eng.prefill(emb.cuda(), s0, L)
+    for s in range(n_new - 1):
+        eng.decode_step(probs)
+        st = eng.last_step()
+        r = ref.records[s]
+        top2 = np.sort(r.logits)[-2:]
+        info = f"step {s}: oracle margin {top2[1] - top2[0]:.3g}"
+        np.testing.assert_array_equal(st["drop"], r.drop, err_msg=info)
+        assert st["member_argmax"].tolist() == r.member_argmax, info
+        assert st["winner"] == r.winner, info
+        assert close(eng.logits(), r.logits), info
+    assert eng.tokens() == want
+    eng.close()
+
+
+def test_prefill_rejects_bad_span(E, golden_dir):
+    g = _load(golden_dir, "g5_llava_k3.npz")
+    eng, _, _ = _engine(E, g, FAMILY_LLAVA)
+    emb = torch.from_numpy(g["embeds"]).cuda()
+    with pytest.raises(ValueError):                       # reference llava.py:134-138: ValueError on count mismatch
+        eng.prefill(emb, 30, 36)
+    with pytest.raises(ValueError):
+        eng.prefill(emb[:, :128], 1, 36)
+    with pytest.raises(Exception):
+        eng.decode_step([0.3])                            # decode before prefill
+    eng.close()
+
+
+def test_properties_mid_size_synthetic(E):
+    """Size-independent properties on a wider model (d=1024, GQA 8/4... ) with synthetic weights:
+    determinism, mprob<=0.1-with-keep... and K members with nothing dropped reproduce the un-masked pass."""
+    cfg = E.LMConfig(4096, 1024, 2816, 4, 8, 8, 128, 1e-5, 10000.0)
+    eng = E.DropoutEngine(cfg, family=FAMILY_IBLIP, max_seq=512, max_visual=64, seed=1)
+    eng.load_synthetic(3, 0.03)
+    gen = torch.Generator().manual_seed(0)
+    emb = torch.randn(80, 1024, generator=gen).cuda()
+    eng.prefill(emb, 4, 64)
+    first = eng.tokens()
+    # InstructBLIP rule drops tokens with epi >= quantile(1 - p): p -> 0 keeps everything except the maximum
+    a = eng.generate(12, mprobs=[0.3, 0.5, 0.7])
+    eng.prefill(emb, 4, 64)
+    b = eng.generate(12, mprobs=[0.3, 0.5, 0.7])
+    assert a == b and a[0] == first[0]                     # deterministic replay
+    eng.prefill(emb, 4, 64)
+    c = eng.generate(12, dropout=False)
+    eng2 = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=512, max_visual=64, seed=1)
+    eng2.load_synthetic(3, 0.03)
+    eng2.prefill(emb, 4, 64)
+    # uniforms = 1.0 can never be < p, so no member drops anything: every member == the un-masked pass
+    ones = torch.ones(8, 64).cuda()
+    for _ in range(11):
+        eng2.decode_step([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8], uniforms=ones)
+        st = eng2.last_step()
+        assert st["drop"].sum() == 0 and st["winner"] == 0 and len(set(st["member_argmax"].tolist())) == 1
+        np.testing.assert_allclose(eng2.logits(), eng2.base_logits(), rtol=0, atol=0)   # bit-identical rows
+    assert eng2.tokens() == c
+    eng.close()
+    eng2.close()
