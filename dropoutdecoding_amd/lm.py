@@ -85,7 +85,8 @@ class DropoutEngine:
         if family == FAMILY_NEXT and use_random:
             fam["mask_mode"] = MASK_NEXT_NO_OVERLAP           # settings['use_random'][0] (llavanext.py:547-550)
         self.k_top = fam["k_top"]
-        self.device = torch.device(device or "cuda")
+        dev = torch.device(device or "cuda")
+        self.device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
         torch.cuda.set_device(self.device)
         c = _lib.LMConfigC(cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads,
                            cfg.num_kv_heads, cfg.head_dim, cfg.rms_eps, cfg.rope_theta, max_seq, max_visual,

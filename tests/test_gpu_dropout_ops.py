@@ -134,7 +134,7 @@ def test_masks_random_trials_vs_oracle(ops, fam, mode):
         probs = [float(p) for p in rs.choice([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.25, 0.33], K)]
         epi = torch.from_numpy((rs.rand(L) * 2).astype(np.float32))
         if trial % 5 == 0 and L > 4:
-            epi[rs.randint(0, L, L // 2)] = epi[0]               # duplicates (quantile ties)
+            epi[rs.randint(0, L, L // 2)] = float(epi[0])               # duplicates (quantile ties)
         keep = torch.from_numpy(rs.rand(L) < 0.05)
         uni = torch.from_numpy(rs.rand(K, L).astype(np.float32))
         ref = DR.sample_masks(epi, probs, keep, mode, uni)
