@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — decoded tokens/s of the Dropout-Decoding hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one image through `CustomLlavaForConditionalGeneration.generate()`: CLIP-L/14-336 front-end +
+prefill of 608 positions (576 visual + 32 prompt tokens) + uncertainty scorer + `--n-new` (128) decoded tokens,
+each by the K=8 ensemble step (un-masked pass, masks, 8 masked members in one packed sweep, vote).  Weights are
+random-init tensors of the real LLaVA-1.5-7B shapes (no network / checkpoints), data is synthetic; EOS is ignored
+so every run decodes the same number of tokens.  N > 1: every rank decodes its own images (the path shards over
+independent images with no data-path collective) -> "scaling": "weak"; `--mode kshard` instead shards the K
+members of ONE stream over the ranks with the RCCL exchange of dropoutdecoding_amd/dist.py.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synthetic_inputs(i: int, vocab: int, image_token: int, prompt_len: int = 32):
+    """uint8[336,336,3] image and a 32-token prompt with exactly one <image> id, from default_rng(i)."""
+    rng = np.random.default_rng(i)
+    img = rng.integers(0, 256, size=(336, 336, 3), dtype=np.uint8)
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    px = ((img.astype(np.float32) / 255.0 - mean) / std).transpose(2, 0, 1)[None]
+    ids = rng.integers(3, 31999, size=prompt_len).astype(np.int64)
+    ids[0] = 1
+    ids[5] = image_token
+    return torch.from_numpy(ids)[None], torch.from_numpy(px)
+
+
+def cpu_baseline(K: int, budget_s: float = 20.0):
+    """The oracle in reference-faithful mode (1+K sequential batch-1 forwards, each on a copied KV cache) timed on
+    the host cores; a bounded sample: decode steps of a 2- and a 4-layer slice of the 7B shapes at T=608,
+    extrapolated linearly to 32 layers (the layers are identical in shape)."""
+    from oracle.decode_ref import FAMILY_LLAVA, RefDecoder
+    from oracle.lm_ref import KVCache, LMConfig
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    T, L, d = 608, 576, 4096
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8][:K]
+    dt = torch.bfloat16
+
+    def make(nl):
+        cfg = LMConfig(32064, 4096, 11008, nl, 32, 32, 128, 1e-5, 10000.0)
+        w = {"model.embed_tokens.weight": torch.randn(cfg.vocab_size, d).to(dt) * 0.02}
+        base = {"q": torch.randn(d, d) * 0.02, "g": torch.randn(11008, d) * 0.02, "dn": torch.randn(d, 11008) * 0.02}
+        for i in range(nl):
+            p = f"model.layers.{i}."
+            s = 1.0 + 0.01 * i
+            w[p + "input_layernorm.weight"] = torch.ones(d, dtype=dt)
+            w[p + "post_attention_layernorm.weight"] = torch.ones(d, dtype=dt)
+            for n in ("q", "k", "v", "o"):
+                w[p + f"self_attn.{n}_proj.weight"] = (base["q"] * s).to(dt)
+            w[p + "mlp.gate_proj.weight"] = (base["g"] * s).to(dt)
+            w[p + "mlp.up_proj.weight"] = (base["g"] * (s + 0.5)).to(dt)
+            w[p + "mlp.down_proj.weight"] = (base["dn"] * s).to(dt)
+        w["model.norm.weight"] = torch.ones(d, dtype=dt)
+        w["lm_head.weight"] = torch.randn(cfg.vocab_size, d).to(dt) * 0.02
+        dec = RefDecoder(FAMILY_LLAVA, cfg, w, probs, seed=5217, dropout=K > 0)
+        dec.cache = KVCache([torch.randn(32, T, 128).to(dt) for _ in range(nl)], [torch.randn(32, T, 128).to(dt) for _ in range(nl)])
+        dec.span_start, dec.L = 5, L
+        dec.epi = torch.rand(L)
+        dec.topk_ids = torch.randint(0, 32000, (L, 5))
+        return dec
+
+    times = {}
+    t_all = time.perf_counter()
+    for nl in (2, 4):
+        dec = make(nl)
+        dec.step(17)                      # warm
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < budget_s / 4 and n < 8):
+            dec.step(17)
+            n += 1
+        times[nl] = (time.perf_counter() - t0) / n
+        del dec
+    per_layer = (times[4] - times[2]) / 2.0
+    t32 = times[2] + per_layer * 30.0
+    return {"value": round(1.0 / t32, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle RefDecoder (reference-faithful: {1 + K} sequential batch-1 forwards on copied KV, torch-CPU bf16), "
+                      f"decode steps at T=608 on 2- and 4-layer slices of the LLaVA-1.5-7B shapes ({times[2]:.2f}s, {times[4]:.2f}s per step), "
+                      f"extrapolated linearly to 32 layers; decode only (prefill excluded); {time.perf_counter() - t_all:.0f}s of CPU work"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-new", type=int, default=128)
+    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--mode", choices=["replicas", "kshard"], default="replicas")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+
+    from dropoutdecoding_amd import build
+    build.build()
+    from dropoutdecoding_amd import config as ddcfg
+    from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
+
+    probs = ddcfg.VOTING_NUMBERS_K8[:args.k] if args.k <= 8 else [0.1 + 0.05 * i for i in range(args.k)]
+    ddcfg.settings["voting_numbers"] = probs
+    model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+    model.original = args.original
+    eng = model.engine
+    if args.mode == "kshard" and world > 1:
+        from dropoutdecoding_amd.dist import KShardDecoder
+        model.kshard = KShardDecoder(eng, rank, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def one(i):
+        ids, px = synthetic_inputs(i, eng.cfg.vocab_size, model.image_token_index)
+        out = model.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), max_new_tokens=args.n_new, eos_token_id=[])
+        assert out.shape[1] == ids.shape[1] + args.n_new
+        return out
+
+    img0 = rank * 10_000 if args.mode == "replicas" else 0
+    for i in range(args.warmup):
+        one(img0 + i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one(img0 + args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    streams = world if args.mode == "replicas" else 1
+    tokens = streams * args.steps * args.n_new
+    value = tokens / dt
+
+    # dominant kernel: the gate/up decode GEMV (44 % of the streamed bytes), HIP events on the launch stream
+    K_eff = 0 if args.original else len(probs)
+    ms, by = eng.time_gemv(2, min(max(K_eff, 1), 8), 96)
+    achieved = by / (ms * 1e-3) / 1e9
+    sweep_ms = eng.time_sweep(min(max(K_eff, 1), 8), 5)
+    sweep_bytes = eng.algorithmic_bytes(0)
+    kinds = {}
+    for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down_proj")):
+        m2, b2 = eng.time_gemv(which, min(max(K_eff, 1), 8), 96)
+        kinds[name] = round(b2 / (m2 * 1e-3) / 1e9, 1)
+
+    if rank == 0:
+        line = {
+            "metric": "decoded tokens/sec LLaVA-1.5-7B K=8 ensemble" if not args.original else "decoded tokens/sec LLaVA-1.5-7B --original",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "LLaVA-1.5-7B Dropout Decoding, 1 synthetic 336x336 image -> 576 visual tokens + 32-token prompt "
+                                   f"(prefill 608), {args.n_new} decoded tokens per image (EOS ignored), K={K_eff} voting_numbers={probs if K_eff else []}, "
+                                   "random-init weights of the real shapes (bf16 weights, fp32 activations/KV)",
+                       "mode": args.mode, "images_per_step_per_gpu": 1, "n_new": args.n_new, "K": K_eff,
+                       "prefill_included": True, "device_bytes": eng.device_bytes},
+            "roofline": {"bound": "hbm", "kernel": "k_gemv<EPI_SILU,2> (gate/up decode GEMV)", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": by, "ms_per_launch": round(ms, 5),
+                         "other_gemv_GBs": kinds,
+                         "packed_sweep": {"ms": round(sweep_ms, 4), "algorithmic_bytes": sweep_bytes,
+                                          "GBs": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 1)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(max(K_eff, 1) if not args.original else 0)
+            except Exception as e:                                     # the GPU number must still be reported
+                line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

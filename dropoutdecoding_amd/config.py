@@ -11,3 +11,14 @@ settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap
 # K = 8 is not reachable from the reference CLI (chair_test.py:163-175); BASELINE configs 3-5 use this list.
 VOTING_NUMBERS_K8 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
 VOTING_NUMBERS_K4 = [0.1, 0.3, 0.5, 0.7]   # chair_test.py:170
+
+# The reference seeds torch's GLOBAL generator at import time of each model module (models/llava.py:16-20 -> 24,
+# models/llavanext.py:18-21 -> 506, models/instructblip.py:17-21 -> 5217); whichever module is imported last wins
+# (under chair_test all three are imported, so 5217 is in force for every model — SURVEY.md A2).  The drop-in
+# modules record their seed here at import; engines created afterwards start their mt19937 stream from it.
+effective_seed = None
+
+
+def _module_imported(seed: int) -> None:
+    global effective_seed
+    effective_seed = seed

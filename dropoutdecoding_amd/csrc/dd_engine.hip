@@ -613,3 +613,50 @@ extern "C" int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms, voi
   *mean_ms = ms / iters;
   return DD_OK;
 }
+
+// Time ONE decode GEMV kind in isolation with HIP events on `stream`, cycling through the layers' weights so that
+// every launch streams bytes that are not resident in the 256 MiB Infinity Cache (bench.py roofline leg).
+// which: 0 qkv, 1 o_proj, 2 gate/up (+SiLU), 3 down_proj.  bytes_per_launch = algorithmic weight bytes (bf16).
+extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms, double* bytes_per_launch,
+                               void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && nb >= 1 && nb <= 8 && iters >= 1,
+             "dd_lm_time_gemv: bad arguments");
+  const int d = h->d, dff = h->dff;
+  auto launch = [&](int l) -> int {
+    LayerW& w = h->lw[l % h->Lyr];
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nb = nb, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.state = h->state;
+    switch (which) {
+      case 0:
+        a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.ssq_in = h->ssq_a, a.ssq_n = d / 16;
+        a.qbuf = h->qbuf, a.knew = h->knew, a.vnew = h->vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
+        a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
+        return ddk_gemv(EPI_QKV, a, st);
+      case 1:
+        a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.out = h->xa, a.ldo = d;
+        a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b;
+        return ddk_gemv(EPI_RESID, a, st);
+      case 2:
+        a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.ssq_in = h->ssq_b, a.ssq_n = d / 16;
+        a.xop_next = h->xop_ff;
+        return ddk_gemv(EPI_SILU, a, st);
+      default:
+        a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.out = h->xa, a.ldo = d;
+        a.normw_next = w.norm1, a.xop_next = h->xop_d, a.ssq_out = h->ssq_a;
+        return ddk_gemv(EPI_RESID, a, st);
+    }
+  };
+  for (int i = 0; i < h->Lyr; ++i) RC(launch(i));  // warm (also evicts)
+  DD_HIP(hipEventRecord(h->ev0, st));
+  for (int i = 0; i < iters; ++i) RC(launch(i));
+  DD_HIP(hipEventRecord(h->ev1, st));
+  DD_HIP(hipEventSynchronize(h->ev1));
+  float ms = 0;
+  DD_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *mean_ms = ms / iters;
+  double rows[4] = {(double)(h->q_dim + 2 * h->kv_dim) * d, (double)d * h->q_dim, 2.0 * dff * d, (double)d * dff};
+  *bytes_per_launch = rows[which] * 2.0;
+  return DD_OK;
+}

@@ -244,6 +244,12 @@ class DropoutEngine:
         _lib.check(self.lib.dd_lm_time_sweep(self._h, nb, iters, C.byref(ms), _stream()), "dd_lm_time_sweep")
         return float(ms.value)
 
+    def time_gemv(self, which: int, nb: int, iters: int):
+        """(mean ms per launch, algorithmic bytes per launch) of one decode GEMV kind; 0 qkv, 1 o, 2 gate/up, 3 down."""
+        ms, by = C.c_float(), C.c_double()
+        _lib.check(self.lib.dd_lm_time_gemv(self._h, which, nb, iters, C.byref(ms), C.byref(by), _stream()), "dd_lm_time_gemv")
+        return float(ms.value), float(by.value)
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self.lib.dd_lm_destroy(self._h)

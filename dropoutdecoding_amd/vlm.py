@@ -1,0 +1,175 @@
+"""generate() surface shared by the three drop-in model wrappers (reference models/{llava,llavanext,instructblip}.py).
+
+What the reference keeps on the model object between forwards is kept here under the same
+attribute names: image_features, vision_uncert_dict, masked_numbers, start_image_pos, end_image_pos,
+start_generation_pos, logits_mask_prob.  The vision front-end (CLIP / Q-Former, projector) and the token
+embedding lookup run as stock PyTorch-ROCm modules — SURVEY.md 8(f) rank 1 lists them as the next row to
+move onto own kernels; everything from the merged input embeddings onwards runs in libdropdec.so.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .config import settings
+from .lm import DropoutEngine, LMConfig
+
+
+def lm_state_dict_from_hf(hf_model) -> Dict[str, torch.Tensor]:
+    """Collect the language model's tensors under LlamaForCausalLM names from either the transformers 4.44 layout
+    (`model.language_model` is a *ForCausalLM) or the 5.x layout (`model.model.language_model` + `model.lm_head`)."""
+    sd = hf_model.state_dict()
+    out = {}
+    for k, v in sd.items():
+        kk = None
+        if k.startswith("language_model.model."):                 # 4.44 wrapper
+            kk = "model." + k[len("language_model.model."):]
+        elif k.startswith("language_model.lm_head."):
+            kk = "lm_head." + k[len("language_model.lm_head."):]
+        elif k.startswith("model.language_model."):               # 5.x wrapper
+            kk = "model." + k[len("model.language_model."):]
+        elif k.startswith("lm_head."):
+            kk = k
+        elif k.startswith("model.layers.") or k.startswith("model.embed_tokens.") or k.startswith("model.norm."):
+            kk = k                                                # a bare *ForCausalLM
+        if kk is not None:
+            out[kk] = v
+    if "lm_head.weight" not in out and "model.embed_tokens.weight" in out:
+        out["lm_head.weight"] = out["model.embed_tokens.weight"]   # tied embeddings
+    return out
+
+
+class DropoutVLM:
+    """Base of the drop-in wrappers.  One model object = one in-flight sequence (as in the reference)."""
+
+    family: str = ""
+    original: bool = False              # True = stock greedy decode (`--original`), no ensemble
+
+    def __init__(self, engine: DropoutEngine, embed_tokens: torch.Tensor, image_token_index: int,
+                 eos_token_id=None, config=None):
+        self.engine = engine
+        self.embed_tokens = embed_tokens            # [V, d] on the GPU (lookup only)
+        self.image_token_index = image_token_index
+        eos = eos_token_id
+        self.eos_token_ids = [] if eos is None else (list(eos) if isinstance(eos, (list, tuple)) else [int(eos)])
+        self.config = config
+        self.device = engine.device
+        self.dtype = embed_tokens.dtype
+        # reference models/llava.py:55-72
+        self.start_generation_pos = 0
+        self.start_image_pos: List[int] = []
+        self.end_image_pos: List[int] = []
+        self.is_first_generation = False
+        self.image_features = None
+        self.logits_mask_prob: List[float] = []
+        self.vision_uncert_dict = None
+        self.masked_numbers: List[int] = []
+        self.collect_diagnostics = False            # per-step host read-backs (masked_numbers etc.) cost a sync each
+
+    # chair_test / pope_test call these on the returned object
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    # ---- family hooks -------------------------------------------------------------------------
+    def _visual_embeds(self, **inputs) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _merge(self, input_ids: torch.Tensor, visual: torch.Tensor):
+        """-> (embeds [T0, d] fp32, span_start). LLaVA families: text embeddings with the visual tokens spliced in
+        at the <image> placeholder (reference llava.py:74-153); accepts ONE placeholder (transformers 4.44
+        processors) or a contiguous run of L placeholders (5.x processors) — SURVEY.md 8(b) version hazard."""
+        ids = input_ids[0]
+        L = visual.shape[0]
+        pos = torch.nonzero(ids == self.image_token_index).flatten()
+        n = pos.numel()
+        if n == 0:
+            raise ValueError("The input provided to the model are wrong. The number of image tokens is 0 while "
+                             "the number of image given to the model is 1.")
+        start = int(pos[0])
+        contiguous = bool((pos == torch.arange(start, start + n, device=pos.device)).all())
+        if not ((n == 1) or (n == L and contiguous)):
+            raise ValueError(f"The input provided to the model are wrong. The number of image tokens is {n} while "
+                             f"the number of image given to the model is 1 ({L} visual tokens). This prevents "
+                             "correct indexing and breaks batch generation.")       # llava.py:134-138
+        emb = torch.nn.functional.embedding(ids.clamp(min=0), self.embed_tokens).float()
+        merged = torch.cat([emb[:start], visual.float(), emb[start + n:]], dim=0)
+        return merged, start
+
+    # ---- the boundary -------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 max_new_tokens: Optional[int] = None, max_length: Optional[int] = None, num_beams: int = 1,
+                 pad_token_id: Optional[int] = None, eos_token_id=None, do_sample: bool = False, **inputs) -> torch.LongTensor:
+        if input_ids is None or input_ids.shape[0] != 1:
+            raise ValueError("Dropout Decoding runs batch size 1 with exactly one image per prompt "
+                             "(reference models/llava.py:75-76)")
+        if num_beams != 1 or do_sample:
+            raise ValueError("the dropout-decoding path is greedy (num_beams=1, do_sample=False)")
+        if max_new_tokens is None:
+            max_new_tokens = 20 if max_length is None else max(1, max_length - input_ids.shape[1])
+        input_ids = input_ids.to(self.device)
+        visual = self._visual_embeds(**inputs)
+        embeds, start = self._merge(input_ids, visual)
+        L = visual.shape[0]
+        # reference llava.py:218-226, 75-78, 285-286
+        self.is_first_generation = True
+        self.logits_mask_prob = []
+        self.start_image_pos, self.end_image_pos = [start], [start + L - 1]
+        self.start_generation_pos = embeds.shape[0]
+        self.masked_numbers = []
+        eng = self.engine
+        eng.prefill(embeds, start, L)
+        eos = self.eos_token_ids if eos_token_id is None else (
+            list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
+        toks = self._decode_loop(max_new_tokens, eos)
+        self.is_first_generation = False
+        self._publish_prefill_diagnostics()
+        new = torch.tensor([toks], dtype=torch.long, device=input_ids.device)
+        return self._format_output(input_ids, new)
+
+    def _decode_loop(self, n_new: int, eos: List[int], chunk: int = 16) -> List[int]:
+        eng = self.engine
+        toks = eng.tokens()
+        dropout = not self.original
+        while len(toks) < n_new and not (eos and toks[-1] in eos):
+            if self.collect_diagnostics:
+                eng.decode_step(dropout=dropout)
+                if dropout:
+                    self.masked_numbers = eng.last_step()["masked_numbers"].tolist()    # llava.py:338,661-662
+                toks = eng.tokens()
+            else:
+                for _ in range(min(chunk, n_new - len(toks))):
+                    eng.decode_step(dropout=dropout)                                    # enqueued, no host sync
+                toks = eng.tokens()
+            hit = [i for i, t in enumerate(toks) if eos and t in eos]
+            if hit:
+                toks = toks[:hit[0] + 1]
+                break
+        return toks[:n_new]
+
+    def _publish_prefill_diagnostics(self) -> None:
+        eng = self.engine
+        dev = self.device
+        u = eng.vision_uncert_dict()
+        self.vision_uncert_dict = {k: torch.from_numpy(v).to(dev) for k, v in u.items()}
+        vals, ids = eng.topk()
+        self.image_features = (torch.from_numpy(vals)[None].to(dev), torch.from_numpy(ids).long()[None].to(dev))
+
+    def _format_output(self, input_ids: torch.Tensor, new: torch.Tensor) -> torch.LongTensor:
+        return torch.cat([input_ids, new], dim=1)                   # LLaVA/NeXT: prompt ids ‖ new ids
+
+
+def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens: int = 1024, prompt_tokens: int = 256,
+                 use_random: bool = False, seed: Optional[int] = None) -> DropoutEngine:
+    max_seq = max_visual + prompt_tokens + max_new_tokens + 8
+    return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random)

@@ -241,6 +241,12 @@ double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K);
  * `nb` rows at the current length and returns the mean milliseconds (bench.py roofline leg). */
 int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stream);
 
+/* Time one decode GEMV kind in isolation (HIP events on `stream`), cycling over the layers' weights so every
+ * launch streams bytes that are not cache-resident. which: 0 qkv, 1 o_proj, 2 gate/up, 3 down_proj.
+ * bytes_per_launch_out = algorithmic (bf16 weight) bytes of one launch. */
+int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, double* bytes_per_launch_out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif
