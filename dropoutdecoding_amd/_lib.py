@@ -43,6 +43,17 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise DDError(f"{LIB_PATH} is missing: build it with `python -m dropoutdecoding_amd.build` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    # torch must be imported BEFORE the dlopen: torch bundles its own libamdhip64.so.7 / libhsa-runtime64 and the
+    # library's DT_NEEDED entries resolve to whichever copy is already in the process (same SONAME).  Loaded first,
+    # libdropdec.so would pull in /opt/rocm's runtime and torch would then fail with "no ROCm-capable device"
+    # (observed on the MI355X box).  One process, one HIP runtime: torch's.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.cuda.current_device()
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
     lib.dd_version.restype = C.c_int
