@@ -281,44 +281,70 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
 // decode attention: partial (one wave per kv head x 64-key split) + combine
 // ===============================================================================================
 #define ATT_SPLIT 64
+#define ATT_MAX_SPLITS 160
 
+// One workgroup (4 waves) per (kv head, 64-key tile).  Every wave requests its share of the K tile (8 of the 32
+// 16-byte d-chunks, keys on lanes) AND of the V tile (16 keys, two per instruction) before anything else, so the
+// whole 64 KiB tile is in flight at once and the kernel pays one memory latency, not 64.  Scores are reduced over
+// the four waves through LDS, softmax statistics are per tile (flash-decoding), P.V partials are reduced the same way.
 template <int NBT, int G>
-__global__ __launch_bounds__(64) void k_attn_partial(AttnDecodeArgs a) {
+__global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * G;
-  __shared__ __align__(16) float q_sh[R * HEAD_DIM];
-  __shared__ __align__(16) float p_sh[ATT_SPLIT * R];
-  const int lane = threadIdx.x, kvh = blockIdx.x, split = blockIdx.y;
+  extern __shared__ __align__(16) float att_sh[];
+  float* q_sh = att_sh;                       // [R][128]
+  float* s_part = q_sh + R * HEAD_DIM;        // [4][R][64]
+  float* p_sh = s_part + 4 * R * ATT_SPLIT;   // [64][R]
+  float* o_part = p_sh + ATT_SPLIT * R;       // [4][R][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kvh = blockIdx.x, split = blockIdx.y;
   const int T = a.T, t0 = split * ATT_SPLIT;
   const int q_dim = a.n_heads * HEAD_DIM;
-  // rows r = g*NBT + m
-  for (int i = lane; i < R * HEAD_DIM; i += 64) {
+  const int nkeys = min(ATT_SPLIT, T - t0);
+  const int half = lane >> 5, dq = lane & 31;
+
+  // 1. all K / V requests of this wave (addresses clamped to the last live key; dead keys get p = 0)
+  const int kt = t0 + min(lane, nkeys - 1);
+  const float* kbase = a.kc + (((size_t)kvh * 32 + wave * 8) * a.T_cap + kt) * 4;
+  f32x4_t k4[8], v4[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k4[i] = *(const f32x4_t*)(kbase + (size_t)i * a.T_cap * 4);
+  const float* vbase = a.vc + ((size_t)kvh * a.T_cap + t0) * HEAD_DIM + dq * 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int key = min(wave * 16 + 2 * j + half, nkeys - 1);
+    v4[j] = *(const f32x4_t*)(vbase + (size_t)key * HEAD_DIM);
+  }
+  uint32_t bits = 0;
+  if (a.drop_bits && lane < nkeys) {
+    int ka = t0 + lane;
+    if (ka >= a.span_start && ka < a.span_start + a.span_len) bits = a.drop_bits[ka - a.span_start];
+  }
+  // 2. q rows (r = g*NBT + m) into LDS
+  for (int i = tid; i < R * HEAD_DIM; i += 256) {
     int r = i / HEAD_DIM, d = i % HEAD_DIM, g = r / NBT, m = r % NBT;
     q_sh[i] = (m < a.nb) ? a.qbuf[(size_t)m * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
   }
   __syncthreads();
-  const int kt = t0 + lane;
-  const bool valid = kt < T;
-  float s[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) s[r] = 0.f;
-  const float* kbase = a.kc + ((size_t)kvh * 32 * a.T_cap + (valid ? kt : 0)) * 4;
-#pragma unroll 4
-  for (int d4 = 0; d4 < 32; ++d4) {
-    f32x4_t k4 = *(const f32x4_t*)(kbase + (size_t)d4 * a.T_cap * 4);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + d4 * 4];
-      s[r] += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
-    }
-  }
-  uint32_t bits = 0;
-  if (a.drop_bits && valid && kt >= a.span_start && kt < a.span_start + a.span_len) bits = a.drop_bits[kt - a.span_start];
-  const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
+  // 3. partial scores over this wave's 32 d values
 #pragma unroll
   for (int r = 0; r < R; ++r) {
+    float sp = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
+      sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
+    }
+    s_part[(wave * R + r) * ATT_SPLIT + lane] = sp;
+  }
+  __syncthreads();
+  // 4. softmax statistics of the tile: wave w owns rows r = w, w+4, ...
+  const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
+  for (int r = wave; r < R; r += 4) {
     int m = r % NBT;
-    float sv = s[r] * scaling;
-    if (!valid || ((bits >> (a.bit0 + m)) & 1u)) sv = -INFINITY;  // a zero in the 2-D mask == additive finfo.min: weight exactly 0
+    float sv = (s_part[(0 * R + r) * ATT_SPLIT + lane] + s_part[(1 * R + r) * ATT_SPLIT + lane]) +
+               (s_part[(2 * R + r) * ATT_SPLIT + lane] + s_part[(3 * R + r) * ATT_SPLIT + lane]);
+    sv *= scaling;
+    if (lane >= nkeys || ((bits >> (a.bit0 + m)) & 1u)) sv = -INFINITY;  // zero in the 2-D mask: weight exactly 0
     float mx = dd_wave_max(sv);
     float p = (sv == -INFINITY) ? 0.f : expf(sv - mx);
     float l = dd_wave_sum(p);
@@ -330,24 +356,16 @@ __global__ __launch_bounds__(64) void k_attn_partial(AttnDecodeArgs a) {
     }
   }
   __syncthreads();
-  // P.V: lanes 0-31 take even keys, 32-63 odd keys; each lane owns 4 consecutive d
-  const int half = lane >> 5, dq = lane & 31;
+  // 5. P.V over this wave's 16 keys (lanes 0-31 even keys, 32-63 odd keys; 4 consecutive d per lane)
   f32x4_t acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int nkeys = min(ATT_SPLIT, T - t0);
-  const float* vbase = a.vc + ((size_t)kvh * a.T_cap + t0) * HEAD_DIM + dq * 4;
-#pragma unroll 2
-  for (int kp = 0; kp < ATT_SPLIT / 2; ++kp) {
-    int key = 2 * kp + half;
-    if (2 * kp >= nkeys) break;
-    f32x4_t v4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (key < nkeys) v4 = *(const f32x4_t*)(vbase + (size_t)key * HEAD_DIM);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float p = p_sh[key * R + r];
-      acc[r] += p * v4;
-    }
+  for (int j = 0; j < 8; ++j) {
+    int key = wave * 16 + 2 * j + half;
+    const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -356,47 +374,80 @@ __global__ __launch_bounds__(64) void k_attn_partial(AttnDecodeArgs a) {
     o.y += __shfl_xor(o.y, 32);
     o.z += __shfl_xor(o.z, 32);
     o.w += __shfl_xor(o.w, 32);
-    if (half == 0) *(f32x4_t*)(a.part_o + (((size_t)kvh * gridDim.y + split) * R + r) * HEAD_DIM + dq * 4) = o;
+    if (half == 0) *(f32x4_t*)&o_part[(wave * R + r) * HEAD_DIM + dq * 4] = o;
+  }
+  __syncthreads();
+  // 6. fixed-order sum over the four waves
+  for (int i = tid; i < R * HEAD_DIM; i += 256) {
+    float o = (o_part[i] + o_part[R * HEAD_DIM + i]) + (o_part[2 * R * HEAD_DIM + i] + o_part[3 * R * HEAD_DIM + i]);
+    a.part_o[((size_t)kvh * gridDim.y + split) * R * HEAD_DIM + i] = o;
   }
 }
 
-// grid (n_heads), block 128 (thread = d): merges the splits, adds the row's own new key/value, packs hi/lo
+// grid (n_heads, nb), block 128 (thread = d): merges the tiles of one (head, row), adds the row's own new key/value
+// (each ensemble member attends to the shared prefix + ITS OWN new token), packs hi/lo for o_proj.
 template <int NBT, int G>
 __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits) {
   constexpr int R = NBT * G;
   __shared__ float red[2];
-  const int head = blockIdx.x, d = threadIdx.x, kvh = head / G, g = head % G;
+  __shared__ float w_sh[ATT_MAX_SPLITS];
+  __shared__ float mx_sh[2], den_sh[2];
+  const int head = blockIdx.x, m = blockIdx.y, d = threadIdx.x, kvh = head / G, g = head % G;
+  const int lane = d & 63, wv = d >> 6;
   const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
   const float scaling = 0.08838834764831845f;
-  for (int m = 0; m < a.nb; ++m) {
-    int r = g * NBT + m;
-    float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
-    float kd = a.knew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
-    float part = dd_wave_sum(qd * kd);
-    __syncthreads();
-    if ((d & 63) == 0) red[d >> 6] = part;
-    __syncthreads();
-    float s_self = (red[0] + red[1]) * scaling;
-    float M = s_self;
-    for (int sp = 0; sp < splits; ++sp) M = fmaxf(M, a.part_ml[(((size_t)kvh * splits + sp) * R + r) * 2]);
-    float w_self = expf(s_self - M);
-    float den = w_self, num = w_self * a.vnew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
-    for (int sp = 0; sp < splits; ++sp) {
-      const float* ml = a.part_ml + (((size_t)kvh * splits + sp) * R + r) * 2;
-      if (ml[0] == -INFINITY) continue;
-      float w = expf(ml[0] - M);
-      den += w * ml[1];
-      num += w * a.part_o[(((size_t)kvh * splits + sp) * R + r) * HEAD_DIM + d];
-    }
-    xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
+  const int r = g * NBT + m;
+  // every load of this block is issued here, before the first dependent use
+  float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
+  float kd = a.knew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
+  float vd = a.vnew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
+  const float* mlb = a.part_ml + ((size_t)kvh * splits * R + r) * 2;
+  const size_t ml_stride = (size_t)R * 2;
+  float ms0 = -INFINITY, ls0 = 0.f, ms1 = -INFINITY, ls1 = 0.f;   // two tiles per thread: up to 256 tiles
+  if (d < splits) { ms0 = mlb[d * ml_stride]; ls0 = mlb[d * ml_stride + 1]; }
+  if (d + 128 < splits) { ms1 = mlb[(d + 128) * ml_stride]; ls1 = mlb[(d + 128) * ml_stride + 1]; }
+  float part = dd_wave_sum(qd * kd);
+  float mloc = dd_wave_max(fmaxf(ms0, ms1));
+  if (lane == 0) { red[wv] = part; mx_sh[wv] = mloc; }
+  __syncthreads();
+  float s_self = (red[0] + red[1]) * scaling;
+  float M = fmaxf(s_self, fmaxf(mx_sh[0], mx_sh[1]));
+  float w0 = (ms0 == -INFINITY) ? 0.f : expf(ms0 - M), w1 = (ms1 == -INFINITY) ? 0.f : expf(ms1 - M);
+  if (d < splits) w_sh[d] = w0;
+  if (d + 128 < splits) w_sh[d + 128] = w1;
+  float dl = dd_wave_sum(w0 * ls0 + w1 * ls1);
+  if (lane == 0) den_sh[wv] = dl;
+  __syncthreads();
+  float w_self = expf(s_self - M);
+  float den = w_self + (den_sh[0] + den_sh[1]);
+  float num = w_self * vd;
+  const float* po = a.part_o + ((size_t)kvh * splits * R + r) * HEAD_DIM + d;
+  const size_t o_stride = (size_t)R * HEAD_DIM;
+  int sp = 0;
+  for (; sp + 8 <= splits; sp += 8) {
+    float o[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) o[u] = po[(size_t)(sp + u) * o_stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) num += w_sh[sp + u] * o[u];
   }
+  for (; sp < splits; ++sp) num += w_sh[sp] * po[(size_t)sp * o_stride];
+  xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
 }
 
 template <int NBT, int G>
 static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
+  constexpr int R = NBT * G;
   int splits = (a.T + ATT_SPLIT - 1) / ATT_SPLIT;
-  if (splits > 0) k_attn_partial<NBT, G><<<dim3(a.n_kv, splits), 64, 0, st>>>(a);
-  k_attn_combine<NBT, G><<<a.n_heads, HEAD_DIM, 0, st>>>(a, splits);
+  DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
+  size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  k_attn_partial<NBT, G><<<dim3(a.n_kv, splits), 256, smem, st>>>(a);
+  k_attn_combine<NBT, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
 }
 
