@@ -55,9 +55,6 @@ struct dd_lm {
   void* unc_ws;
   size_t unc_ws_bytes;
   double* kv_sums;
-  // exchange (K-shard)
-  float* xchg = nullptr;
-  int32_t* xchg_ids = nullptr;
   // host mirrors
   int T_host = 0, span_start = 0, L = 0, n_tok_host = 0, last_K = 0;
   bool prefilled = false;
@@ -196,8 +193,6 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   DA(ws, h->unc_ws_bytes);
   h->unc_ws = ws;
   DA(h->kv_sums, (size_t)h->Lyr * 2);
-  DA(h->xchg, dd_lm_xchg_stride(h));
-  DA(h->xchg_ids, 2 * MAX_MEMBERS);
   // RoPE table: inv_freq exactly as HF computes it (fp32 pow and reciprocal), cos/sin on the device
   std::vector<float> inv(64);
   for (int i = 0; i < 64; ++i) inv[i] = 1.0f / powf(c->rope_theta, (float)(2 * i) / 128.0f);
@@ -533,7 +528,75 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
 extern "C" size_t dd_lm_xchg_stride(const dd_lm* h) {
   return h ? (size_t)h->Vpad + (size_t)h->Lyr * 2 * h->kv_dim : 0;
 }
-extern "C" float* dd_lm_xchg_ptr(dd_lm* h) { return h ? h->xchg : nullptr; }
+
+// ---- K-shard exchange -------------------------------------------------------------
+__global__ void k_xchg_export_ids(const int32_t* tok, const int32_t* vote, int lo, int hi, int K, int32_t* out) {
+  int m = threadIdx.x;
+  if (m < K) {
+    bool mine = m >= lo && m < hi;
+    out[2 * m] = mine ? tok[m] : 0;
+    out[2 * m + 1] = mine ? vote[m] : 0;
+  }
+}
+__global__ void k_xchg_import_ids(const int32_t* in, int K, int32_t* tok, int32_t* vote) {
+  int m = threadIdx.x;
+  if (m < K) {
+    tok[m] = in[2 * m];
+    vote[m] = in[2 * m + 1];
+  }
+}
+// rec = [logits Vpad][layer][k|v][kv_dim]; exported by the rank that ran the winner, zeros elsewhere
+__global__ __launch_bounds__(256) void k_xchg_winner(const DDState* st, int lo, int hi, float* member_logits, float* knew,
+                                                     float* vnew, int Vpad, int kv_dim, int n_layers, int rows_per_layer,
+                                                     float* rec, int import) {
+  int win = st->winner;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)Vpad + (size_t)n_layers * 2 * kv_dim;
+  if (i >= total) return;
+  float* slot;
+  if (i < (size_t)Vpad) {
+    slot = member_logits + (size_t)win * Vpad + i;
+  } else {
+    size_t j = i - Vpad;
+    int layer = (int)(j / (2 * (size_t)kv_dim));
+    int r = (int)(j % (2 * (size_t)kv_dim));
+    float* base = (r < kv_dim) ? knew : vnew;
+    slot = base + ((size_t)layer * rows_per_layer + win) * kv_dim + (r % kv_dim);
+  }
+  if (import) *slot = rec[i];
+  else rec[i] = (win >= lo && win < hi) ? *slot : 0.f;
+}
+
+extern "C" int dd_lm_xchg_export_ids(dd_lm* h, int m_lo, int m_hi, int32_t* ids, void* stream_) {
+  DD_REQUIRE(h && ids && h->last_K >= 1, "dd_lm_xchg_export_ids: bad state");
+  const int32_t* vote = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
+  k_xchg_export_ids<<<1, 64, 0, (hipStream_t)stream_>>>(h->member_tok, vote, m_lo, m_hi, h->last_K, ids);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+extern "C" int dd_lm_xchg_import_ids(dd_lm* h, const int32_t* ids, void* stream_) {
+  DD_REQUIRE(h && ids && h->last_K >= 1, "dd_lm_xchg_import_ids: bad state");
+  k_xchg_import_ids<<<1, 64, 0, (hipStream_t)stream_>>>(ids, h->last_K, h->member_tok, h->member_vote);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+static int xchg_winner(dd_lm* h, int lo, int hi, float* rec, int import, hipStream_t st) {
+  size_t total = dd_lm_xchg_stride(h);
+  k_xchg_winner<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(h->state, lo, hi, h->member_logits, h->knew, h->vnew,
+                                                                h->Vpad, h->kv_dim, h->Lyr, MAX_MEMBERS, rec, import);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+extern "C" int dd_lm_xchg_export_winner(dd_lm* h, int m_lo, int m_hi, float* rec, void* stream_) {
+  DD_REQUIRE(h && rec && h->last_K >= 1, "dd_lm_xchg_export_winner: bad state");
+  const int32_t* ids = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
+  RC(dd_vote(ids, h->last_K, &h->state->winner, stream_));
+  return xchg_winner(h, m_lo, m_hi, rec, 0, (hipStream_t)stream_);
+}
+extern "C" int dd_lm_xchg_import_winner(dd_lm* h, const float* rec, void* stream_) {
+  DD_REQUIRE(h && rec && h->last_K >= 1, "dd_lm_xchg_import_winner: bad state");
+  return xchg_winner(h, 0, 0, (float*)rec, 1, (hipStream_t)stream_);
+}
 
 extern "C" int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream_) {
   DD_REQUIRE(h && token >= 0 && token < h->V, "dd_lm_set_next_token: bad token %d", token);

@@ -1,0 +1,95 @@
+"""Drop-in for the reference's models/instructblip.py: CustomInstructBlipForConditionalGeneration.
+
+Reference behaviour carried over: the 32 Q-Former query embeddings are the visual span
+at positions 0..31 (models/instructblip.py:599-602, 648-651); deterministic top-quantile masks reset per member
+(:121, 447-460); the vote is over the argmax of the members' final HIDDEN state (:125-137) and lm_head is applied to
+the winner; the last member's zeros leak into the next step's un-masked pass (:111-113, 121-122); generate() returns
+`[BOS(2)] ‖ new ids` (:686-695).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import config as _config
+from .lm import FAMILY_IBLIP, LMConfig
+from .vlm import DropoutVLM, build_engine, lm_state_dict_from_hf
+
+seed = 5217                        # reference models/instructblip.py:17
+_config._module_imported(seed)
+
+
+class CustomInstructBlipForConditionalGeneration(DropoutVLM):
+    family = FAMILY_IBLIP
+
+    def __init__(self, engine, embed_tokens, hf_front, eos_token_id=None, config=None):
+        super().__init__(engine, embed_tokens, image_token_index=-1, eos_token_id=eos_token_id, config=config)
+        self._hf = hf_front             # vision_model + qformer + language_projection (+ query_tokens)
+
+    # reference models/instructblip.py:607-633
+    def _visual_embeds(self, pixel_values=None, qformer_input_ids=None, qformer_attention_mask=None,
+                       interpolate_pos_encoding: bool = False, **_):
+        if pixel_values is None:
+            raise ValueError("pixel_values is required")
+        hf, dev = self._hf, self.device
+        dt = next(hf.vision_model.parameters()).dtype
+        image_embeds = hf.vision_model(pixel_values.to(dev, dt), return_dict=True,
+                                       interpolate_pos_encoding=interpolate_pos_encoding).last_hidden_state
+        image_attention_mask = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=dev)
+        query_tokens = hf.query_tokens.expand(image_embeds.shape[0], -1, -1)
+        query_attention_mask = torch.ones(query_tokens.size()[:-1], dtype=torch.long, device=dev)
+        qformer_input_ids = qformer_input_ids.to(dev)
+        if qformer_attention_mask is None:
+            qformer_attention_mask = torch.ones_like(qformer_input_ids)
+        qam = torch.cat([query_attention_mask, qformer_attention_mask.to(dev)], dim=1)
+        q = hf.qformer(input_ids=qformer_input_ids, attention_mask=qam, query_embeds=query_tokens,
+                       encoder_hidden_states=image_embeds, encoder_attention_mask=image_attention_mask, return_dict=True)
+        query_output = q.last_hidden_state[:, : query_tokens.size(1), :]
+        return hf.language_projection(query_output)[0]
+
+    # reference models/instructblip.py:661-664: [query embeds ; prompt embeds], span = positions 0..Q-1
+    def _merge(self, input_ids, visual):
+        ids = input_ids[0]
+        tid = getattr(self.config, "image_token_id", None) if self.config is not None else None
+        if tid is not None:
+            ids = ids[ids != tid]               # newer processors prepend Q placeholders; the reference's did not
+        emb = torch.nn.functional.embedding(ids, self.embed_tokens).float()
+        return torch.cat([visual.float(), emb], dim=0), 0
+
+    def _format_output(self, input_ids, new):
+        bos = 2                                  # instructblip.py:686-692 (LLaMA tokenizer files: </s> id 2)
+        if self.config is not None:
+            arch = (getattr(self.config.text_config, "architectures", None) or ["LLaMAForCausalLM"])[0]
+            if arch != "LLaMAForCausalLM":
+                bos = self.config.text_config.bos_token_id
+        return torch.cat([torch.tensor([[bos]], dtype=torch.long, device=new.device), new], dim=1)
+
+    @classmethod
+    def from_hf_model(cls, hf, max_new_tokens: int = 1024, original: bool = False):
+        cfg = hf.config
+        sd = lm_state_dict_from_hf(hf)
+        lm_cfg = LMConfig.from_hf(cfg.text_config)
+        eng = build_engine(lm_cfg, cls.family, max_visual=cfg.num_query_tokens, max_new_tokens=max_new_tokens,
+                           seed=_config.effective_seed)
+        eng.load_state_dict(sd)
+        dev = eng.device
+        embed = sd["model.embed_tokens.weight"].to(dev, torch.bfloat16)
+        inner = getattr(hf, "model", hf)
+        if not hasattr(inner, "qformer"):
+            inner = hf
+        inner.language_model = None
+        inner = inner.to(dev).eval()
+        gen = getattr(hf, "generation_config", None)
+        eos = getattr(gen, "eos_token_id", None) if gen is not None else None
+        if eos is None:
+            eos = getattr(cfg.text_config, "eos_token_id", None)
+        m = cls(eng, embed, inner, eos, cfg)
+        m.original = original
+        return m
+
+    @classmethod
+    def from_pretrained(cls, model_path, torch_dtype=torch.float16, device_map="auto", max_new_tokens: int = 1024, **kw):
+        from transformers import InstructBlipForConditionalGeneration
+        hf = InstructBlipForConditionalGeneration.from_pretrained(model_path, torch_dtype=torch_dtype, low_cpu_mem_usage=True)
+        return cls.from_hf_model(hf, max_new_tokens=max_new_tokens)

@@ -1,0 +1,72 @@
+"""Drop-in for the reference's models/llavanext.py: CustomLlavaNextForConditionalGeneration (LLaVA-NeXT, anyres).
+
+Differences from LLaVA-1.5 carried over from the reference: the mask is reset before every
+member (models/llavanext.py:546), top-10 ids for the keep set (:652), `settings['use_random'][0]` selects
+"epis_no_overlap" (:547-550), `logits_mask_prob` diagnostic (:584).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import config as _config
+from .config import settings
+from .lm import FAMILY_NEXT, LMConfig
+from .vlm import DropoutVLM, build_engine, lm_state_dict_from_hf
+
+seed = 506                         # reference models/llavanext.py:18
+_config._module_imported(seed)
+
+
+class CustomLlavaNextForConditionalGeneration(DropoutVLM):
+    family = FAMILY_NEXT
+
+    def __init__(self, engine, embed_tokens, hf_vision, image_token_index, eos_token_id=None, config=None):
+        super().__init__(engine, embed_tokens, image_token_index, eos_token_id, config)
+        self._hf = hf_vision            # HF (Llava)NextModel stripped of its language model: tiles -> CLIP -> projector -> unpad/newline packing
+
+    # reference models/llavanext.py:388-443 (per-tile CLIP, projector, pack_image_features with image_newline)
+    def _visual_embeds(self, pixel_values: Optional[torch.Tensor] = None, image_sizes: Optional[torch.Tensor] = None, **_):
+        if pixel_values is None or image_sizes is None:
+            raise ValueError("pixel_values and image_sizes are required")
+        dt = next(self._hf.vision_tower.parameters()).dtype
+        out = self._hf.get_image_features(pixel_values.to(self.device, dt), image_sizes.to(self.device),
+                                          vision_feature_layer=self.config.vision_feature_layer,
+                                          vision_feature_select_strategy=self.config.vision_feature_select_strategy)
+        feats = out.pooler_output if hasattr(out, "pooler_output") else out
+        if isinstance(feats, (list, tuple)):
+            feats = torch.cat(list(feats), dim=0)
+        return feats
+
+    def _decode_loop(self, n_new, eos, chunk: int = 16):
+        # settings['use_random'] is read at every step in the reference (llavanext.py:547); the engine's mode is
+        # fixed per sequence, which is equivalent as long as the flag does not change mid-generation.
+        return super()._decode_loop(n_new, eos, chunk)
+
+    @classmethod
+    def from_hf_model(cls, hf, max_new_tokens: int = 1024, max_visual: int = 2944, original: bool = False):
+        cfg = hf.config
+        sd = lm_state_dict_from_hf(hf)
+        lm_cfg = LMConfig.from_hf(cfg.text_config)
+        eng = build_engine(lm_cfg, cls.family, max_visual=max_visual, max_new_tokens=max_new_tokens,
+                           use_random=bool(settings["use_random"][0]), seed=_config.effective_seed)
+        eng.load_state_dict(sd)
+        dev = eng.device
+        embed = sd["model.embed_tokens.weight"].to(dev, torch.bfloat16)
+        inner = getattr(hf, "model", hf)
+        inner.language_model = None                      # the LM now lives in the engine
+        inner = inner.to(dev).eval()
+        gen = getattr(hf, "generation_config", None)
+        eos = getattr(gen, "eos_token_id", None) if gen is not None else None
+        if eos is None:
+            eos = getattr(cfg.text_config, "eos_token_id", None)
+        m = cls(eng, embed, inner, getattr(cfg, "image_token_index", None) or cfg.image_token_id, eos, cfg)
+        m.original = original
+        return m
+
+    @classmethod
+    def from_pretrained(cls, model_path, torch_dtype=torch.float16, device_map="auto", max_new_tokens: int = 1024, **kw):
+        from transformers import LlavaNextForConditionalGeneration
+        hf = LlavaNextForConditionalGeneration.from_pretrained(model_path, torch_dtype=torch_dtype, low_cpu_mem_usage=True)
+        return cls.from_hf_model(hf, max_new_tokens=max_new_tokens)

@@ -170,6 +170,26 @@ class DropoutEngine:
     def step_commit(self) -> None:
         _lib.check(self.lib.dd_lm_step_commit(self._h, self._last_K, _stream()), "dd_lm_step_commit")
 
+    # exchange records for K-sharding (dist.py); tensors are torch CUDA tensors owned by the caller
+    def xchg_stride(self) -> int:
+        return int(self.lib.dd_lm_xchg_stride(self._h))
+
+    def export_ids(self, m_lo: int, m_hi: int, ids: torch.Tensor) -> None:
+        _lib.check(self.lib.dd_lm_xchg_export_ids(self._h, m_lo, m_hi, ids.data_ptr(), _stream()), "dd_lm_xchg_export_ids")
+
+    def import_ids(self, ids: torch.Tensor) -> None:
+        _lib.check(self.lib.dd_lm_xchg_import_ids(self._h, ids.data_ptr(), _stream()), "dd_lm_xchg_import_ids")
+
+    def export_winner(self, m_lo: int, m_hi: int, rec: torch.Tensor) -> None:
+        _lib.check(self.lib.dd_lm_xchg_export_winner(self._h, m_lo, m_hi, rec.data_ptr(), _stream()), "dd_lm_xchg_export_winner")
+
+    def import_winner(self, rec: torch.Tensor) -> None:
+        _lib.check(self.lib.dd_lm_xchg_import_winner(self._h, rec.data_ptr(), _stream()), "dd_lm_xchg_import_winner")
+
+    def new_xchg_buffers(self):
+        return (torch.zeros(32, dtype=torch.int32, device=self.device),
+                torch.zeros(self.xchg_stride(), dtype=torch.float32, device=self.device))
+
     def set_next_token(self, token: int) -> None:
         _lib.check(self.lib.dd_lm_set_next_token(self._h, int(token), _stream()), "dd_lm_set_next_token")
 

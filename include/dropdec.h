@@ -194,20 +194,27 @@ int dd_lm_prefill(dd_lm* h, const float* embeds_dev, int T0, int span_start, int
 int dd_lm_decode_step(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, const float* uniforms_dev,
                       void* stream);
 
-/* The same step in three phases, for sharding the K members over ranks:
- *   phase A: un-masked pass + keep set + masks for ALL K members (every rank, identical);
- *   phase B: members [m_lo, m_hi) in one packed sweep; fills this rank's slice of the
- *            exchange record;  the caller then exchanges records between ranks;
- *   phase C: vote over all K argmax ids, commit the winner (whose row must be present in
- *            the exchange record on every rank).
- * Exchange record (fp32 words, device): per member m a block of dd_lm_xchg_stride(h) floats:
- *   [0] argmax id (as float bits of int32), [1..] logits[V_pad], then the member's new KV
- *   rows [layers][2][kv_dim]. */
+/* The same step in phases, for sharding the K members over ranks (nothing in the reference to
+ * mirror: its K members run sequentially in one process, models/llava.py:342-359):
+ *   dd_lm_step_base     un-masked pass + keep set + masks for ALL K members (every rank, identical, no comm);
+ *   dd_lm_step_members  members [m_lo, m_hi) in one packed sweep (m_lo..m_hi within one group of 8);
+ *   dd_lm_xchg_export_ids    ids_dev[2*K] int32 <- {token argmax, vote id} of the members this rank ran, 0 elsewhere;
+ *                            the caller all-reduces (sum) ids_dev across ranks;
+ *   dd_lm_xchg_import_ids    all K ids back into the engine;
+ *   dd_lm_xchg_export_winner votes on the device, then rec_dev[dd_lm_xchg_stride] fp32 <- the winner's
+ *                            {logits[V_pad], new KV rows [layers][2][kv_dim]} if this rank ran it, zeros otherwise;
+ *                            the caller all-reduces (sum) rec_dev: a broadcast from a data-dependent root with no
+ *                            host round trip;
+ *   dd_lm_xchg_import_winner the record into the winner's slots;
+ *   dd_lm_step_commit   vote (same result on every rank), append the winner's KV row, emit the token. */
 int dd_lm_step_base(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, const float* uniforms_dev, void* stream);
 int dd_lm_step_members(dd_lm* h, int m_lo, int m_hi, void* stream);
 int dd_lm_step_commit(dd_lm* h, int K, void* stream);
-size_t dd_lm_xchg_stride(const dd_lm* h);
-float* dd_lm_xchg_ptr(dd_lm* h);      /* device pointer, K_max * stride floats, owned by the handle */
+size_t dd_lm_xchg_stride(const dd_lm* h);   /* floats per winner record */
+int dd_lm_xchg_export_ids(dd_lm* h, int m_lo, int m_hi, int32_t* ids_dev, void* stream);
+int dd_lm_xchg_import_ids(dd_lm* h, const int32_t* ids_dev, void* stream);
+int dd_lm_xchg_export_winner(dd_lm* h, int m_lo, int m_hi, float* rec_dev, void* stream);
+int dd_lm_xchg_import_winner(dd_lm* h, const float* rec_dev, void* stream);
 
 /* Read-backs (synchronise `stream` first). what: */
 #define DD_GET_TOKENS 0        /* int32 [n_generated]   tokens emitted so far (incl. the prefill's greedy token) */

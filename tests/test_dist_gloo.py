@@ -1,0 +1,143 @@
+"""World-size-2 (and 3) gloo runs of the K-shard protocol on CPU.
+
+The HIP engine cannot run here, so the phased engine API is implemented by a CPU stand-in built from the oracle;
+what is under test is the host logic of dropoutdecoding_amd/dist.py: member partition, the two all-reduces,
+zero-contribution broadcast of the winner record, identical caches/tokens on every rank.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dropoutdecoding_amd.dist import KShardDecoder, member_range, shard_images
+from oracle import dropout_ref as DR
+from oracle.decode_ref import FAMILY_LLAVA, RefDecoder
+from oracle.lm_ref import LMConfig, lm_hidden, lm_logits, random_weights
+
+CFG = LMConfig(128, 256, 256, 2, 2, 2, 128, 1e-5, 10000.0)
+PROBS = [0.2, 0.4, 0.6, 0.8, 0.5]
+
+
+def test_member_range_partitions():
+    for K in range(1, 9):
+        for world in (1, 2, 3, 4, 8):
+            got = []
+            for r in range(world):
+                lo, hi = member_range(K, r, world)
+                got += list(range(lo, hi))
+            assert got == list(range(K)), (K, world)
+    assert member_range(16, 1, 2) == (8, 16)
+    assert shard_images(10, 1, 4) == [1, 5, 9]
+
+
+class CpuPhasedEngine:
+    """Same phase methods as DropoutEngine, computed with the oracle (CPU)."""
+
+    def __init__(self, dec: RefDecoder, first_token: int):
+        self.d, self.toks = dec, [first_token]
+
+    def new_xchg_buffers(self):
+        n = CFG.vocab_size + CFG.num_layers * 2 * CFG.kv_dim
+        return torch.zeros(32, dtype=torch.int32), torch.zeros(n)
+
+    def step_base(self, mprobs, uniforms=None):
+        d = self.d
+        self.K = len(mprobs)
+        self.x = d.embed(self.toks[-1])
+        self.T = d.cache.length
+        self.orig = d.cache.clone()
+        base = lm_logits(d.cfg, d.w, lm_hidden(d.cfg, d.w, self.x, torch.tensor([self.T]), d.cache.clone()))[0]
+        keep = DR.overlap_keep(base, d.topk_ids)
+        uni = torch.from_numpy(np.stack([d.rng.rand_f32(d.L) for _ in range(self.K)]))   # every rank draws all K
+        self.drop = DR.sample_masks(d.epi, list(mprobs), keep, DR.MODE_LLAVA_CUMULATIVE, uni)
+        self.logits, self.rows, self.ids_all = {}, {}, None
+        return self.K
+
+    def step_members(self, lo, hi):
+        d = self.d
+        for k in range(lo, hi):
+            c = self.orig.clone()
+            km = torch.ones(self.T + 1, dtype=torch.long)
+            km[d.span_start:d.span_start + d.L][self.drop[k]] = 0
+            self.logits[k] = lm_logits(d.cfg, d.w, lm_hidden(d.cfg, d.w, self.x, torch.tensor([self.T]), c, km))[0]
+            self.rows[k] = torch.cat([torch.cat([c.k[i][:, -1].reshape(-1), c.v[i][:, -1].reshape(-1)]) for i in range(d.cfg.num_layers)])
+
+    def export_ids(self, lo, hi, ids):
+        ids.zero_()
+        for k in range(lo, hi):
+            ids[2 * k] = ids[2 * k + 1] = int(torch.argmax(self.logits[k]))
+
+    def import_ids(self, ids):
+        self.ids_all = [int(ids[2 * k + 1]) for k in range(self.K)]
+
+    def export_winner(self, lo, hi, rec):
+        self.win, _ = DR.vote(self.ids_all)
+        rec.zero_()
+        if lo <= self.win < hi:
+            rec.copy_(torch.cat([self.logits[self.win], self.rows[self.win]]))
+
+    def import_winner(self, rec):
+        self.win_logits = rec[:CFG.vocab_size].clone()
+        self.win_rows = rec[CFG.vocab_size:].clone()
+
+    def step_commit(self):
+        d, kv = self.d, CFG.kv_dim
+        for i in range(d.cfg.num_layers):
+            r = self.win_rows[i * 2 * kv:(i + 1) * 2 * kv]
+            d.cache.k[i] = torch.cat([d.cache.k[i], r[:kv].reshape(CFG.num_kv_heads, 1, 128)], dim=1)
+            d.cache.v[i] = torch.cat([d.cache.v[i], r[kv:].reshape(CFG.num_kv_heads, 1, 128)], dim=1)
+        self.toks.append(int(torch.argmax(self.win_logits)))
+
+    def tokens(self):
+        return list(self.toks)
+
+
+def _setup():
+    torch.manual_seed(0)
+    w = random_weights(CFG, 7, 0.06)
+    emb = torch.randn(24, CFG.hidden_size, generator=torch.Generator().manual_seed(1))
+    return w, emb
+
+
+def _worker(rank, world, port, n_new, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    w, emb = _setup()
+    dec = RefDecoder(FAMILY_LLAVA, CFG, w, PROBS, seed=99)
+    first = dec.prefill(emb, 2, 16)
+    ks = KShardDecoder(CpuPhasedEngine(dec, first), rank, world)
+    toks = ks.generate(n_new, PROBS)
+    ksum = float(sum(k.double().sum() for k in dec.cache.k))
+    q.put((rank, toks, ksum))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_kshard_protocol_matches_single_process(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n_new = 6
+    w, emb = _setup()
+    ref = RefDecoder(FAMILY_LLAVA, CFG, w, PROBS, seed=99)
+    want = ref.generate(emb, 2, 16, n_new)
+    want_ksum = float(sum(k.double().sum() for k in ref.cache.k))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_new, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, toks, ksum in out:
+        assert toks == want, (rank, toks, want)
+        assert abs(ksum - want_ksum) < 1e-6 * max(1.0, abs(want_ksum))      # caches identical on every rank

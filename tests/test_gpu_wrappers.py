@@ -1,0 +1,145 @@
+"""generate() surface of the drop-in wrappers on tiny random HF models, and the K-shard phase kernels, on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.decode_ref import FAMILY_IBLIP, FAMILY_LLAVA, FAMILY_NEXT, RefDecoder
+from oracle.lm_ref import LMConfig as RefCfg, bf16_round, random_weights
+
+
+@pytest.fixture(scope="module")
+def built():
+    from dropoutdecoding_amd import build
+    build.build()
+    return True
+
+
+def _ref_weights_from_engine_sd(sd):
+    return {k: bf16_round(v.float().cpu()) for k, v in sd.items()}
+
+
+def test_llava_wrapper_generate_matches_oracle(built):
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+    from dropoutdecoding_amd import config as ddc
+    from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
+    from dropoutdecoding_amd.vlm import lm_state_dict_from_hf
+    torch.manual_seed(0)
+    vc = CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+                          image_size=56, patch_size=14, projection_dim=16)
+    tc = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                     num_key_value_heads=2, head_dim=128, max_position_embeddings=512, tie_word_embeddings=False)
+    cfg = LlavaConfig(vision_config=vc, text_config=tc, image_token_index=511, vision_feature_layer=-2,
+                      vision_feature_select_strategy="default")
+    hf = LlavaForConditionalGeneration(cfg).eval()
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if "language_model" in n or "lm_head" in n:
+                p.mul_(2.5)
+    sd = _ref_weights_from_engine_sd(lm_state_dict_from_hf(hf))
+    ddc.settings["voting_numbers"] = [0.3, 0.5, 0.7]
+    ddc._module_imported(24)
+    m = CustomLlavaForConditionalGeneration.from_hf_model(hf, max_new_tokens=16)
+    ids1 = torch.tensor([[1, 17, 511, 45, 6, 7, 99]])                      # one placeholder (transformers 4.44 processors)
+    idsL = torch.tensor([[1, 17] + [511] * 16 + [45, 6, 7, 99]])           # run of L placeholders (5.x processors)
+    pv = torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(3))
+    out1 = m.generate(input_ids=ids1, attention_mask=torch.ones_like(ids1), pixel_values=pv, max_new_tokens=8,
+                      num_beams=1, pad_token_id=0, eos_token_id=[])
+    assert out1.shape == (1, ids1.shape[1] + 8) and out1[0, :7].tolist() == ids1[0].tolist()
+    # oracle on the same merged embeddings
+    vis = m._visual_embeds(pixel_values=pv)
+    emb, start = m._merge(ids1.cuda(), vis)
+    assert start == 2 and emb.shape[0] == 6 + 16
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, tc.rms_norm_eps, 10000.0)
+    ref = RefDecoder(FAMILY_LLAVA, rc, sd, [0.3, 0.5, 0.7], seed=24)
+    want = ref.generate(emb.cpu(), start, 16, 8)
+    assert out1[0, 7:].tolist() == want
+    assert m.start_image_pos == [2] and m.end_image_pos == [17] and m.start_generation_pos == 22
+    np.testing.assert_allclose(m.vision_uncert_dict["epis_uncert_per_token"].cpu().numpy()[0], ref.epi.numpy(), rtol=5e-3, atol=1e-6)
+    assert m.image_features[1].shape == (1, 16, 5)
+    # second image on the same model object: the rng stream continues (never re-seeded per image)
+    outL = m.generate(input_ids=idsL, pixel_values=pv, max_new_tokens=8, eos_token_id=[])
+    want2 = ref.generate(emb.cpu(), start, 16, 8)
+    assert outL[0, idsL.shape[1]:].tolist() == want2
+    with pytest.raises(ValueError):
+        m.generate(input_ids=torch.tensor([[1, 2, 3]]), pixel_values=pv, max_new_tokens=2)      # no image token
+    with pytest.raises(ValueError):
+        m.generate(input_ids=torch.tensor([[1, 511, 511, 3]]), pixel_values=pv, max_new_tokens=2)  # wrong count
+    # --original: stock greedy
+    m.original = True
+    og = m.generate(input_ids=ids1, pixel_values=pv, max_new_tokens=6, eos_token_id=[])
+    ref0 = RefDecoder(FAMILY_LLAVA, rc, sd, [], dropout=False)
+    assert og[0, 7:].tolist() == ref0.generate(emb.cpu(), start, 16, 6)
+    # EOS stops generation
+    m.original = False
+    eos = want[3]
+    ref3 = RefDecoder(FAMILY_LLAVA, rc, sd, [0.3, 0.5, 0.7], seed=5)
+    m.engine.rng.manual_seed(5)
+    w3 = ref3.generate(emb.cpu(), start, 16, 8, eos=eos)
+    o3 = m.generate(input_ids=ids1, pixel_values=pv, max_new_tokens=8, eos_token_id=eos)
+    assert o3[0, 7:].tolist() == w3 and w3[-1] == eos
+
+
+def test_instructblip_merge_and_output_format(built):
+    from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration as IB
+    from dropoutdecoding_amd import lm
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-6, 10000.0)
+    w = random_weights(rc, 5, 0.05)
+    eng = lm.DropoutEngine(lm.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-6, 10000.0), family=lm.FAMILY_IBLIP, max_seq=128, max_visual=32)
+    eng.load_state_dict(w)
+    m = IB(eng, w["model.embed_tokens.weight"].cuda().to(torch.bfloat16), hf_front=None, eos_token_id=None, config=None)
+    vis = torch.randn(32, 256, generator=torch.Generator().manual_seed(1)).cuda() * 0.7
+    m._visual_embeds = lambda **kw: vis
+    ids = torch.tensor([[1, 17, 45, 6, 7, 99]])
+    out = m.generate(input_ids=ids, pixel_values=torch.zeros(1), max_new_tokens=6, eos_token_id=[])
+    assert out.shape == (1, 7) and int(out[0, 0]) == 2                    # BOS(2) + new ids only (instructblip.py:686-695)
+    emb = torch.cat([vis.cpu(), w["model.embed_tokens.weight"][ids[0]]], 0)
+    ref = RefDecoder(FAMILY_IBLIP, rc, w, [0.3, 0.5, 0.7])
+    assert out[0, 1:].tolist() == ref.generate(emb, 0, 32, 6)
+    assert m.start_image_pos == [0] and m.end_image_pos == [31]
+
+
+@pytest.mark.parametrize("split", [(4, 8), (1, 8), (3, 5)])
+def test_kshard_phase_kernels_two_engines(built, split):
+    """Two engines on one GPU play two ranks: members [0,s) and [s,K); records are summed by hand (what all-reduce does)."""
+    from dropoutdecoding_amd import lm
+    s_, K = split
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    w = random_weights(rc, 11, 0.05)
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8][:K]
+    emb = torch.randn(30, 256, generator=torch.Generator().manual_seed(2)).cuda()
+    engs = []
+    for _ in range(3):
+        e = lm.DropoutEngine(lm.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0), family=lm.FAMILY_LLAVA, max_seq=128,
+                             max_visual=32, seed=42)
+        e.load_state_dict(w)
+        e.prefill(emb, 3, 20)
+        engs.append(e)
+    a, b, single = engs
+    bufs = [e.new_xchg_buffers() for e in (a, b)]
+    for step in range(6):
+        single.decode_step(probs)
+        for e in (a, b):
+            e.step_base(probs)
+        a.step_members(0, s_)
+        b.step_members(s_, K)
+        a.export_ids(0, s_, bufs[0][0])
+        b.export_ids(s_, K, bufs[1][0])
+        ids = bufs[0][0] + bufs[1][0]
+        for e in (a, b):
+            e.import_ids(ids)
+        a.export_winner(0, s_, bufs[0][1])
+        b.export_winner(s_, K, bufs[1][1])
+        rec = bufs[0][1] + bufs[1][1]
+        for e in (a, b):
+            e.import_winner(rec)
+            e.step_commit()
+        st = single.last_step()
+        for e in (a, b):
+            assert e.tokens() == single.tokens(), step
+            np.testing.assert_array_equal(e.logits(), single.logits())
+            np.testing.assert_allclose(e.kv_sums(), single.kv_sums(), rtol=0, atol=0)
+            assert e.last_step()["winner"] == st["winner"]
