@@ -723,3 +723,11 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
   *bytes_per_launch = rows[which] * 2.0;
   return DD_OK;
 }
+
+// Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
+// (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
+extern "C" int dd_set_tuning(int key, int value) {
+  DD_REQUIRE(key >= 0 && key <= 3, "dd_set_tuning: unknown key %d", key);
+  ddk_set_tuning(key, value);
+  return DD_OK;
+}

@@ -70,6 +70,7 @@ struct GemvArgs {
   const DDState* state;
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
+void ddk_set_tuning(int key, int value);
 
 struct AttnDecodeArgs {
   const float* qbuf;     // [8][q_dim] roped

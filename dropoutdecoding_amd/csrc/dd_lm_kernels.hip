@@ -119,15 +119,21 @@ __device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y) {
 // ===============================================================================================
 #define GEMV_WAVES 8
 #define GEMV_THREADS (GEMV_WAVES * 64)
-#define GEMV_U 8
 
-template <int EPI, int TILES>
+// U   = weight tiles requested per wave before the first MFMA consumes one (loads in flight)
+// NT  = non-temporal weight loads (read-once stream, keeps L2/MALL for the x operand and the KV cache)
+// ILV = k-steps interleaved over the 8 waves (wave w takes steps w, w+8, ...: at any instant the workgroup reads
+//       8 consecutive KiB) instead of one contiguous chunk per wave
+template <int EPI, int TILES, int U, int NT, int ILV>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   __shared__ float red[TILES * GEMV_WAVES * 256];
   __shared__ float rstd_sh[8];
   __shared__ float ssq_sh[8 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int S = a.S, spw = S / GEMV_WAVES, s0 = wave * spw;
+  const int S = a.S, spw = S / GEMV_WAVES;
+  constexpr bool DIAG = (ILV == 3);          // timing-only build: x operand := the weight tile (no L2 x traffic)
+  const int s0 = ILV ? wave : wave * spw;
+  constexpr int SS = ILV ? GEMV_WAVES : 1;   // step stride of this wave
   const int tile0 = blockIdx.x * TILES;
 
   f32x4_t acc[TILES];
@@ -138,33 +144,43 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     wp[t] = a.W + ((size_t)(tile0 + t) * S + s0) * 64 + lane;
   }
   const u32x4_t* xp = a.xop + (size_t)s0 * 64 + lane;
+  auto ldw = [](const u32x4_t* p) -> u32x4_t { return NT ? __builtin_nontemporal_load(p) : *p; };
 
-  // Deep explicit unroll: GEMV_U weight tiles (1 KiB each) + their x fragments are requested before the first
-  // MFMA consumes one, so every wave keeps >= GEMV_U KiB of HBM reads in flight (guide: "load straight to VGPRs,
-  // deep unroll, late vmcnt").
   int s = 0;
-  for (; s + GEMV_U <= spw; s += GEMV_U) {
-    u32x4_t b[GEMV_U], w[TILES][GEMV_U];
+  for (; s + U <= spw; s += U) {
+    u32x4_t b[U], w[TILES][U];
 #pragma unroll
-    for (int u = 0; u < GEMV_U; ++u) {
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * 64);
-      b[u] = xp[(size_t)(s + u) * 64];
+      for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
+      b[u] = DIAG ? w[0][u] : xp[(size_t)(s + u) * SS * 64];
     }
 #pragma unroll
-    for (int u = 0; u < GEMV_U; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
                                                          __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
   }
-  for (; s < spw; ++s) {
-    u32x4_t b = xp[(size_t)s * 64];
+  if (s < spw) {  // tail: the remaining (< U) steps requested together as well (K = 11008: 43 steps per wave)
+    const int rem = spw - s;
+    u32x4_t b[U], w[TILES][U];
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-      u32x4_t w = __builtin_nontemporal_load(wp[t] + (size_t)s * 64);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w),
-                                                       __builtin_bit_cast(bf16x8_t, b), acc[t], 0, 0, 0);
+    for (int u = 0; u < U - 1; ++u) {
+      if (u < rem) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
+        b[u] = xp[(size_t)(s + u) * SS * 64];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) {
+      if (u < rem) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                           __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+      }
     }
   }
 
@@ -262,15 +278,35 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   }
 }
 
+// tuning knobs (dd_set_tuning): 0 = U (4/8/16), 1 = NT, 2 = ILV
+static int g_gemv_u = 8, g_gemv_nt = 1, g_gemv_ilv = 1, g_gemv_diag = 0;
+void ddk_set_tuning(int key, int value) {
+  if (key == 0) g_gemv_u = value;
+  else if (key == 1) g_gemv_nt = value;
+  else if (key == 2) g_gemv_ilv = value;
+  else if (key == 3) g_gemv_diag = value;
+}
+
+template <int EPI, int TILES>
+static void launch_gemv(const GemvArgs& a, hipStream_t st) {
+#define GV(U_, NT_, ILV_) k_gemv<EPI, TILES, U_, NT_, ILV_><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a)
+  const int u = g_gemv_u, nt = g_gemv_nt, il = g_gemv_ilv;
+  if (g_gemv_diag) { k_gemv<EPI, TILES, 8, 1, 3><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }  // diagnostic: no x-operand loads
+  if (u == 4) { if (nt) { if (il) GV(4, 1, 1); else GV(4, 1, 0); } else { if (il) GV(4, 0, 1); else GV(4, 0, 0); } }
+  else if (u == 16) { if (nt) { if (il) GV(16, 1, 1); else GV(16, 1, 0); } else { if (il) GV(16, 0, 1); else GV(16, 0, 0); } }
+  else { if (nt) { if (il) GV(8, 1, 1); else GV(8, 1, 0); } else { if (il) GV(8, 0, 1); else GV(8, 0, 0); } }
+#undef GV
+}
+
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv: K=%d must be a multiple of 256", a.S * 32);
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv: nb=%d", a.nb);
   DD_REQUIRE(!a.ssq_in || a.ssq_n >= 1, "gemv: ssq_n");
   switch (epi) {
-    case EPI_STORE: k_gemv<EPI_STORE, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
-    case EPI_RESID: k_gemv<EPI_RESID, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
-    case EPI_SILU: k_gemv<EPI_SILU, 2><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
-    case EPI_QKV: k_gemv<EPI_QKV, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    case EPI_STORE: launch_gemv<EPI_STORE, 1>(a, st); break;
+    case EPI_RESID: launch_gemv<EPI_RESID, 1>(a, st); break;
+    case EPI_SILU: launch_gemv<EPI_SILU, 2>(a, st); break;
+    case EPI_QKV: launch_gemv<EPI_QKV, 1>(a, st); break;
     default: DD_REQUIRE(false, "gemv: unknown epilogue %d", epi);
   }
   DD_CHECK_LAUNCH();

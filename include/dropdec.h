@@ -254,6 +254,11 @@ int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stre
 int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, double* bytes_per_launch_out,
                     void* stream);
 
+/* Kernel tuning knobs for the benchmark scripts: key 0 = GEMV weight tiles in flight per wave (4/8/16),
+ * 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves of a workgroup (0/1),
+ * 3 = timing-only diagnostic build without x-operand loads (results are wrong; never use for output). */
+int dd_set_tuning(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif
