@@ -123,7 +123,10 @@ def main() -> int:
         torch.cuda.set_device(0)
 
     from dropoutdecoding_amd import build
-    build.build()
+    if local == 0:
+        build.build()                      # one builder per node; the others wait (no concurrent writes of the .so)
+    if world > 1:
+        torch.distributed.barrier()
     from dropoutdecoding_amd import config as ddcfg
     from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
 

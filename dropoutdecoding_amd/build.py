@@ -19,12 +19,22 @@ HEADERS = ["dd_common.h", "dd_lm_kernels.h", os.path.join(ROOT, "include", "drop
 ARCH = "gfx950"
 
 
+def _src_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [x if os.path.isabs(x) else os.path.join(CSRC, x) for x in HEADERS]
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    """Content hash, not mtimes: the gpurun snapshot does not preserve modification times."""
+    stamp = LIB + ".srchash"
+    if not (os.path.exists(LIB) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(stamp).read().strip() != _src_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -44,7 +54,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd[cmd.index("-o") + 1] = tmp
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)                       # atomic: concurrent ranks never see a half-written library
+    with open(LIB + ".srchash", "w") as f:
+        f.write(_src_hash())
     return LIB
 
 

@@ -141,8 +141,13 @@ class DropoutVLM:
         eng = self.engine
         toks = eng.tokens()
         dropout = not self.original
+        ks = getattr(self, "kshard", None)             # dist.KShardDecoder: members sharded over ranks
         while len(toks) < n_new and not (eos and toks[-1] in eos):
-            if self.collect_diagnostics:
+            if ks is not None and dropout:
+                for _ in range(min(chunk, n_new - len(toks))):
+                    ks.decode_step()
+                toks = eng.tokens()
+            elif self.collect_diagnostics:
                 eng.decode_step(dropout=dropout)
                 if dropout:
                     self.masked_numbers = eng.last_step()["masked_numbers"].tolist()    # llava.py:338,661-662
