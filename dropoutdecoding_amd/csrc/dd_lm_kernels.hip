@@ -501,6 +501,13 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
 
 // ===============================================================================================
 // prefill
+// Prefill activations are stored in the SAME 16x32 operand-tile order as the weights: element (row m, col k) of a
+// [M][K] plane lives at u16 offset (((m/16)*S + k/32)*64 + ((k%32)/8)*16 + m%16)*8 + k%8, S = K/32, so every A
+// fragment of the prefill GEMM is one contiguous 1 KiB wave load (guide: fragment-shaped row-major loads cost 18-45 %).
+__device__ __forceinline__ size_t apack_off(int m, int k, int S) {
+  return ((((size_t)(m >> 4) * S + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (m & 15)) << 3) + (k & 7);
+}
+
 // ===============================================================================================
 // y = w * (x * rsqrt(mean(x^2) + eps)) in HF's op order, written as hi/lo bf16 planes (and optionally fp32)
 __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__ x, int d, const float* __restrict__ w,
@@ -515,15 +522,26 @@ __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
   __syncthreads();
   float rstd = 1.0f / sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)d + eps);
-  for (int i = threadIdx.x; i < d; i += 256) {
-    float y = w[i] * (xr[i] * rstd);
-    uint32_t h, l;
-    dd_split_hl(y, h, l);
-    if (hi) {
-      hi[(size_t)row * d + i] = (uint16_t)h;
-      lo[(size_t)row * d + i] = (uint16_t)l;
+  const int S = d >> 5;
+  for (int i8 = threadIdx.x * 8; i8 < d; i8 += 256 * 8) {   // 8 consecutive k per thread -> one 16-byte packed store
+    u32x4_t vh, vl;
+    uint32_t hh[8], ll[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = w[i8 + j] * (xr[i8 + j] * rstd);
+      dd_split_hl(y, hh[j], ll[j]);
+      if (normed) normed[(size_t)row * d + i8 + j] = y;
     }
-    if (normed) normed[(size_t)row * d + i] = y;
+    if (hi) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vh[j] = hh[2 * j] | (hh[2 * j + 1] << 16);
+        vl[j] = ll[2 * j] | (ll[2 * j + 1] << 16);
+      }
+      size_t o = apack_off(row, i8, S);
+      *(u32x4_t*)(hi + o) = vh;
+      *(u32x4_t*)(lo + o) = vl;
+    }
   }
 }
 int ddk_rmsnorm_split(const float* x, int M, int d, const float* w, float eps, uint16_t* hi, uint16_t* lo,
@@ -536,7 +554,8 @@ int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float e
   return ddk_rmsnorm_split(x, rows, d, w, eps, nullptr, nullptr, nullptr, out, st);
 }
 
-// C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64, operands straight from L2
+// C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64; both operands are pre-tiled so every
+// fragment is a contiguous 1 KiB wave load straight to VGPRs (L2-resident A, streamed W)
 #define GEMM_BM 128
 #define GEMM_BN_TILES 8
 
@@ -546,20 +565,20 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   const int wr = wave >> 1, wc = wave & 1;
   const int m_base = blockIdx.y * GEMM_BM + wr * 64;
   const int nt_base = blockIdx.x * GEMM_BN_TILES + wc * 4;
-  const int S = a.S, K = S * 32;
-  const int ar = lane & 15, ah = lane >> 4;
+  const int S = a.S;
   f32x4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const uint16_t* pa_hi[4];
-  const uint16_t* pa_lo[4];
+  const u32x4_t* pa_hi[4];
+  const u32x4_t* pa_lo[4];
+  const int m_tiles = (a.M + 15) >> 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int row = min(m_base + i * 16 + ar, a.M - 1);
-    pa_hi[i] = a.a_hi + (size_t)row * K + 8 * ah;
-    pa_lo[i] = a.a_lo + (size_t)row * K + 8 * ah;
+    int mt = min((m_base >> 4) + i, m_tiles - 1);
+    pa_hi[i] = (const u32x4_t*)a.a_hi + (size_t)mt * S * 64 + lane;
+    pa_lo[i] = (const u32x4_t*)a.a_lo + (size_t)mt * S * 64 + lane;
   }
   const u32x4_t* pw[4];
   bool wv[4];
@@ -568,15 +587,19 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     wv[j] = (nt_base + j) < a.n_tiles;
     pw[j] = a.W + ((size_t)(wv[j] ? nt_base + j : 0) * S) * 64 + lane;
   }
-  for (int ks = 0; ks < S; ++ks) {
-    u32x4_t ahi[4], alo[4], w[4];
+  // explicit two-stage register pipeline: the fragments of k-step s+1 are requested before the 32 MFMAs of step s
+  // issue, so the L2 latency of one step hides behind the matrix work of the other (S is even: K multiple of 256)
+  u32x4_t ahi0[4], alo0[4], w0[4], ahi1[4], alo1[4], w1[4];
+  auto load = [&](u32x4_t* ahi, u32x4_t* alo, u32x4_t* w, int ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ahi[i] = *(const u32x4_t*)(pa_hi[i] + (size_t)ks * 32);
-      alo[i] = *(const u32x4_t*)(pa_lo[i] + (size_t)ks * 32);
+      ahi[i] = pa_hi[i][(size_t)ks * 64];
+      alo[i] = pa_lo[i][(size_t)ks * 64];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = pw[j][(size_t)ks * 64];
+  };
+  auto compute = [&](const u32x4_t* ahi, const u32x4_t* alo, const u32x4_t* w) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -586,6 +609,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, alo[i]),
                                                             __builtin_bit_cast(bf16x8_t, w[j]), acc[i][j], 0, 0, 0);
       }
+  };
+  load(ahi0, alo0, w0, 0);
+  for (int ks = 0; ks < S; ks += 2) {
+    load(ahi1, alo1, w1, ks + 1);
+    compute(ahi0, alo0, w0);
+    if (ks + 2 < S) load(ahi0, alo0, w0, ks + 2);
+    compute(ahi1, alo1, w1);
   }
   // D[m][n]: m = 4*(lane>>4) + reg, n = lane & 15
   const int c = lane & 15;
@@ -613,8 +643,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
             dd_split_hl(act * u, h, l);
             int col = (nt >> 1) * 16 + c;
             if (ok) {
-              a.o_hi[(size_t)row * a.ld_planes + col] = (uint16_t)h;
-              a.o_lo[(size_t)row * a.ld_planes + col] = (uint16_t)l;
+              size_t o = apack_off(row, col, a.ld_planes >> 5);
+              a.o_hi[o] = (uint16_t)h;
+              a.o_lo[o] = (uint16_t)l;
             }
           }
         } else {  // EPI_QKV
@@ -712,14 +743,12 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
   acc.w += __shfl_xor(acc.w, 32);
   if (live && half == 0) {
     float inv = 1.0f / l_run;
+    uint32_t hh[4], ll[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t h, l;
-      dd_split_hl(acc[j] * inv, h, l);
-      size_t o = (size_t)t * q_dim + head * HEAD_DIM + dq * 4 + j;
-      o_hi[o] = (uint16_t)h;
-      o_lo[o] = (uint16_t)l;
-    }
+    for (int j = 0; j < 4; ++j) dd_split_hl(acc[j] * inv, hh[j], ll[j]);
+    size_t o = apack_off(t, head * HEAD_DIM + dq * 4, q_dim >> 5);      // 4 consecutive k: one 8-byte packed store
+    *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
+    *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
   }
 }
 
