@@ -146,6 +146,34 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   const u32x4_t* xp = a.xop + (size_t)s0 * 64 + lane;
   auto ldw = [](const u32x4_t* p) -> u32x4_t { return NT ? __builtin_nontemporal_load(p) : *p; };
 
+  // Everything the epilogue needs from memory is requested BEFORE the weight stream so its latency hides behind it:
+  // the folded RMSNorm's rstd (wave w assembles row w's sum of squares from the producer's slots), the residual
+  // input + next norm weight (EPI_RESID) and the rotary cos/sin (EPI_QKV).
+  if (a.ssq_in) {
+    float v = 0.f;
+    for (int i = lane; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)i * 8 + wave];
+    v = dd_wave_sum(v);
+    if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
+  }
+  float pre0 = 0.f, pre1 = 0.f;
+  {
+    const int em = threadIdx.x & 7, en = threadIdx.x >> 3;
+    if (threadIdx.x < 128 && em < a.nb) {
+      if (EPI == EPI_RESID) {
+        pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
+        pre1 = a.normw_next[tile0 * 16 + en];
+      } else if (EPI == EPI_QKV) {
+        if (tile0 < a.q_tiles + a.k_tiles) {
+          int ht = tile0 < a.q_tiles ? tile0 : tile0 - a.q_tiles;
+          int f = (ht & 7) * 8 + (en & 7);
+          int pos = a.state->pos;
+          pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
+          pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+        }
+      }
+    }
+  }
+
   int s = 0;
   for (; s + U <= spw; s += U) {
     u32x4_t b[U], w[TILES][U];
@@ -184,13 +212,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     }
   }
 
-  // rstd of the folded RMSNorm: wave w assembles row w's sum of squares from the producer's slots
-  if (a.ssq_in) {
-    float v = 0.f;
-    for (int i = lane; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)i * 8 + wave];
-    v = dd_wave_sum(v);
-    if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
-  }
 #pragma unroll
   for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
   __syncthreads();
@@ -224,9 +245,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     if (t < 128 && m < a.nb) {
       float y = tile_sum(0, n, m);
       int col = tile0 * 16 + n;
-      float xn = a.out[(size_t)m * a.ldo + col] + y;
+      float xn = pre0 + y;
       a.out[(size_t)m * a.ldo + col] = xn;
-      xop_store(a.xop_next, col, m, a.normw_next[col] * xn);
+      xop_store(a.xop_next, col, m, pre1 * xn);
       sq = xn * xn;
     }
     if (t < 128) ssq_sh[n * 8 + m] = sq;
@@ -262,8 +283,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
           bool is_q = nt < a.q_tiles;
           int ht = is_q ? nt : nt - a.q_tiles;
           int head = ht >> 3, f = (ht & 7) * 8 + (n & 7);
-          int pos = a.state->pos;
-          float c = a.rope_cos[(size_t)pos * ROPE_HALF + f], sn = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+          float c = pre0, sn = pre1;
           // q*cos + rotate_half(q)*sin, two rounded products then one add (HF apply_rotary_pos_emb)
           float o = (n < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
           int i = (n < 8) ? f : ROPE_HALF + f;

@@ -185,3 +185,65 @@ def test_properties_mid_size_synthetic(E):
     assert eng2.tokens() == c
     eng.close()
     eng2.close()
+
+
+def _rand_case(E, family, rcfg, T0, s0, L, probs, n_new, seed=3, wseed=21, std=0.05, max_seq=None):
+    from oracle.decode_ref import RefDecoder
+    w = random_weights(rcfg, wseed, std)
+    cfg = E.LMConfig(rcfg.vocab_size, rcfg.hidden_size, rcfg.intermediate_size, rcfg.num_layers, rcfg.num_heads,
+                     rcfg.num_kv_heads, rcfg.head_dim, rcfg.rms_eps, rcfg.rope_theta)
+    eng = E.DropoutEngine(cfg, family=family, max_seq=max_seq or (T0 + n_new + 8), max_visual=L, seed=seed)
+    eng.load_state_dict(w)
+    emb = torch.randn(T0, rcfg.hidden_size, generator=torch.Generator().manual_seed(seed)) * 0.8
+    ref = RefDecoder(family, rcfg, w, probs, seed=seed)
+    want = ref.generate(emb, s0, L, n_new)
+    eng.prefill(emb.cuda(), s0, L)
+    assert close(eng.logits(), ref.prefill_logits[-1].numpy())
+    for s in range(n_new - 1):
+        eng.decode_step(probs)
+        st, r = eng.last_step(), ref.records[s]
+        top2 = np.sort(r.logits)[-2:]
+        info = f"step {s}: oracle margin {top2[1] - top2[0]:.3g}"
+        np.testing.assert_array_equal(st["drop"], r.drop, err_msg=info)
+        assert st["member_argmax"].tolist() == r.member_argmax, info
+        assert st["winner"] == r.winner, info
+        assert close(eng.logits(), r.logits), info
+    assert eng.tokens() == want
+    eng.close()
+
+
+def test_two_packed_sweeps_K12(E):
+    """K > 8: members run as two packed sweeps (8 + 4); masks are cumulative across all 12 (LLaVA-1.5 rule)."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    _rand_case(E, FAMILY_LLAVA, rc, 40, 3, 30, [0.1 + 0.05 * i for i in range(12)], 6)
+
+
+def test_gqa_group4_long_context_many_key_tiles(E):
+    """Mistral-style GQA (8 q heads / 2 kv heads), theta 1e6, 300-token prefix: 5 key tiles per kv head, visual span
+    crossing tile boundaries."""
+    rc = RefCfg(512, 1024, 512, 2, 8, 2, 128, 1e-5, 1000000.0)
+    _rand_case(E, FAMILY_NEXT, rc, 300, 7, 250, [0.2, 0.5, 0.8], 5, std=0.03)
+
+
+def test_vocab_not_multiple_of_16_instructblip(E):
+    """Vicuna's V=32001 style: padded vocabulary rows must never win an argmax or leak into the scorer."""
+    rc = RefCfg(509, 256, 512, 2, 2, 2, 128, 1e-6, 10000.0)
+    _rand_case(E, FAMILY_IBLIP, rc, 40, 0, 32, [0.3, 0.5, 0.7], 6)
+
+
+def test_kv_capacity_and_state_errors(E):
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    cfg = E.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=64, max_visual=16)
+    eng.load_state_dict(random_weights(rc, 1, 0.05))
+    eng.prefill(torch.randn(60, 256).cuda(), 2, 16)
+    n = 0
+    with pytest.raises(Exception, match="KV cache full"):
+        for n in range(10):
+            eng.decode_step([0.3])
+    assert 1 <= n <= 4
+    with pytest.raises(ValueError):
+        eng.prefill(torch.randn(70, 256).cuda(), 2, 16)        # longer than the KV capacity
+    with pytest.raises(ValueError):
+        E.DropoutEngine(E.LMConfig(512, 200, 512, 2, 2, 2, 128), family=FAMILY_LLAVA)   # hidden not a multiple of 256
+    eng.close()

@@ -144,3 +144,45 @@ def test_kshard_phase_kernels_two_engines(built, split):
             np.testing.assert_array_equal(e.logits(), single.logits())
             np.testing.assert_allclose(e.kv_sums(), single.kv_sums(), rtol=0, atol=0)
             assert e.last_step()["winner"] == st["winner"]
+
+
+def test_llavanext_wrapper_with_hf_tiny_model(built):
+    """anyres front-end through HF's own get_image_features (tile split, CLIP, projector, unpad + newline packing)."""
+    from transformers import CLIPVisionConfig, LlavaNextConfig, LlavaNextForConditionalGeneration, MistralConfig
+    from dropoutdecoding_amd import config as ddc
+    from dropoutdecoding_amd.llavanext import CustomLlavaNextForConditionalGeneration
+    from dropoutdecoding_amd.vlm import lm_state_dict_from_hf
+    torch.manual_seed(1)
+    vc = CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+                          image_size=56, patch_size=14, projection_dim=16)
+    tc = MistralConfig(vocab_size=512, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                       num_key_value_heads=2, head_dim=128, max_position_embeddings=1024, sliding_window=None,
+                       tie_word_embeddings=False)
+    cfg = LlavaNextConfig(vision_config=vc, text_config=tc, image_token_index=511, vision_feature_layer=-2,
+                          vision_feature_select_strategy="default", image_grid_pinpoints=[[56, 112], [112, 56], [112, 112]])
+    hf = LlavaNextForConditionalGeneration(cfg).eval()
+    for n, p in hf.named_parameters():
+        if "language_model" in n or "lm_head" in n:
+            p.mul_(2.0)
+    sd = _ref_weights_from_engine_sd(lm_state_dict_from_hf(hf))
+    ddc.settings["voting_numbers"] = [0.1, 0.3, 0.5, 0.7]
+    ddc.settings["use_random"] = [False]
+    ddc._module_imported(506)
+    m = CustomLlavaNextForConditionalGeneration.from_hf_model(hf, max_new_tokens=16, max_visual=256)
+    pv = torch.randn(1, 5, 3, 56, 56, generator=torch.Generator().manual_seed(3))
+    sizes = torch.tensor([[100, 100]])
+    vis = m._visual_embeds(pixel_values=pv, image_sizes=sizes)
+    L = vis.shape[0]
+    assert L == 88                                                     # SURVEY appendix A: 100x100 image -> 88 visual tokens
+    ids = torch.tensor([[1, 17] + [511] * L + [45, 6, 7, 99]])
+    out = m.generate(input_ids=ids, pixel_values=pv, image_sizes=sizes, max_new_tokens=6, eos_token_id=[])
+    emb, start = m._merge(ids.cuda(), vis)
+    rc = RefCfg(512, 512, 512, 2, 4, 2, 128, tc.rms_norm_eps, float(LMtheta(tc)))
+    ref = RefDecoder(FAMILY_NEXT, rc, sd, [0.1, 0.3, 0.5, 0.7], seed=506)
+    assert out[0, ids.shape[1]:].tolist() == ref.generate(emb.cpu(), start, L, 6)
+    assert m.image_features[1].shape == (1, L, 10)                     # top-10 ids (llavanext.py:652)
+
+
+def LMtheta(tc):
+    rp = getattr(tc, "rope_parameters", None) or {}
+    return rp.get("rope_theta", getattr(tc, "rope_theta", 10000.0))
