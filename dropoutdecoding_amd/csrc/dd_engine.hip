@@ -302,9 +302,19 @@ __global__ void k_state_after_prefill(DDState* st, int T0, const int32_t* first_
     tokens[0] = first_tok[0];
   }
 }
-// pos rule: LLaVA-family llava.py:283 (sum(mask)-1 == T); InstructBLIP under transformers 5.x: cache position == T
-__global__ void k_step_begin(DDState* st) {
-  if (threadIdx.x == 0) st->pos = st->T;
+// pos rule: LLaVA-family llava.py:283 (sum(mask)-1 == T; the mask is rebuilt all-ones every step).  InstructBLIP:
+// transformers 5.x takes the position from the cache length (== T); under the reference's pinned 4.44,
+// prepare_inputs_for_generation derives it from the caller's 2-D mask, which still carries the zeros the last member
+// of the previous step left behind, so pos = T - #leaked zeros  (leak_mask == 2).
+__global__ __launch_bounds__(256) void k_step_begin(DDState* st, const uint8_t* leak_bits, int L, int mask_positions) {
+  __shared__ int cnt[4];
+  int c = 0;
+  if (mask_positions)
+    for (int l = threadIdx.x; l < L; l += 256) c += leak_bits[l] & 1;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) st->pos = st->T - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
 }
 __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int32_t* argmax_base,
                                                    const int32_t* member_tok, const float* base_logits,
@@ -461,7 +471,7 @@ extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rn
     return DD_ESTATE;
   }
   DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
-  k_step_begin<<<1, 64, 0, st>>>(h->state);
+  k_step_begin<<<1, 256, 0, st>>>(h->state, h->leak_bits, h->L, (h->cfg.leak_mask == 2 && h->have_leak) ? 1 : 0);
   DD_CHECK_LAUNCH();
   const uint8_t* base_bits = (h->cfg.leak_mask && h->have_leak) ? h->leak_bits : nullptr;
   h->bit0 = 0;

@@ -74,7 +74,8 @@ MISTRAL_7B = LMConfig(32064, 4096, 14336, 32, 32, 8, 128, 1e-5, 1000000.0)
 
 class DropoutEngine:
     def __init__(self, cfg: LMConfig, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
-                 seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None):
+                 seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
+                 iblip_positions: str = "cache"):
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
@@ -84,6 +85,8 @@ class DropoutEngine:
         fam = dict(_FAMILY[family])
         if family == FAMILY_NEXT and use_random:
             fam["mask_mode"] = MASK_NEXT_NO_OVERLAP           # settings['use_random'][0] (llavanext.py:547-550)
+        if family == FAMILY_IBLIP and iblip_positions == "mask":
+            fam["leak_mask"] = 2                                # transformers 4.44 position rule
         self.k_top = fam["k_top"]
         dev = torch.device(device or "cuda")
         self.device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)

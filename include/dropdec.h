@@ -147,7 +147,8 @@ typedef struct dd_lm_config {
   int32_t k_top;             /* 5 (LLaVA-1.5) or 10 (NeXT, InstructBLIP)    */
   int32_t mask_mode;         /* DD_MASK_*                                   */
   int32_t vote_on;           /* DD_VOTE_*                                   */
-  int32_t leak_mask;         /* InstructBLIP Q2: base pass sees last member's zeros */
+  int32_t leak_mask;         /* InstructBLIP Q2: 1 = the un-masked pass sees the last member's zeros (positions from the
+                                cache length, transformers 5.x); 2 = additionally position = T - #zeros (the 4.44 rule) */
   int32_t reserved[5];
 } dd_lm_config;
 

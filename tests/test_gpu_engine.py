@@ -247,3 +247,78 @@ def test_kv_capacity_and_state_errors(E):
     with pytest.raises(ValueError):
         E.DropoutEngine(E.LMConfig(512, 200, 512, 2, 2, 2, 128), family=FAMILY_LLAVA)   # hidden not a multiple of 256
     eng.close()
+
+
+def test_instructblip_positions_from_leaked_mask_444_rule(E, golden_dir):
+    """SURVEY Q2 switch: under transformers 4.44 the decode position is cumsum(mask)-1 of the leaked mask."""
+    g = _load(golden_dir, "g5_iblip_k3.npz")
+    v, d, f, nl, nh, nkv, hd = [int(x) for x in g["cfg"]]
+    rcfg = RefCfg(v, d, f, nl, nh, nkv, hd, float(g["rms_eps"]), float(g["rope_theta"]))
+    w = random_weights(rcfg, int(g["wseed"]), float(g["std"]))
+    probs = [0.3, 0.5, 0.7]
+    emb = torch.from_numpy(g["embeds"])
+    ref = RefDecoder(FAMILY_IBLIP, rcfg, w, probs, iblip_positions="mask")
+    want = ref.generate(emb, 0, 32, 8)
+    ref_cache = RefDecoder(FAMILY_IBLIP, rcfg, w, probs, iblip_positions="cache").generate(emb, 0, 32, 8)
+    eng = E.DropoutEngine(E.LMConfig(v, d, f, nl, nh, nkv, hd, float(g["rms_eps"]), float(g["rope_theta"])),
+                          family=FAMILY_IBLIP, max_seq=128, max_visual=32, iblip_positions="mask")
+    eng.load_state_dict(w)
+    eng.prefill(emb.cuda(), 0, 32)
+    got = eng.generate(8, mprobs=probs)
+    assert got == want
+    assert close(eng.logits(), ref.records[-1].logits)
+    eng.close()
+
+
+def test_full_size_llava15_7b_properties(E):
+    """BASELINE config size (LLaVA-1.5-7B shapes, 576 visual + 32 prompt tokens, K=8), synthetic weights.
+    The oracle cannot run at this size in seconds, so size-independent properties are checked instead:
+    replay determinism, members == un-masked pass when nothing is dropped (the vote is then unanimous and the
+    token equals stock greedy), masks obey the reference's invariants, K-sharded phases == the single call."""
+    eng = E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=704, max_visual=576, seed=5217)
+    eng.load_synthetic(1, 0.02)
+    emb = torch.randn(608, 4096, generator=torch.Generator().manual_seed(0)).cuda()
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    eng.prefill(emb, 5, 576)
+    u = eng.vision_uncert_dict()
+    epi = u["epis_uncert_per_token"][0]
+    assert np.isfinite(epi).all() and (epi > -1e-6).all()              # KL(p_l || mean p) >= 0
+    assert np.isfinite(u["alea_uncert_per_token"]).all() and (u["alea_uncert_per_token"] >= 0).all()
+    a = eng.generate(6, mprobs=probs)
+    st = eng.last_step()
+    nd = st["masked_numbers"]
+    assert (np.diff(nd) >= -int(st["keep"].sum())).all()               # cumulative masks (llava.py:344), modulo kept tokens
+    assert not (st["drop"] & st["keep"][None]).any()                   # kept tokens are never dropped (llava.py:660)
+    assert 0.03 * 576 < nd[0] < 0.2 * 576 and nd[-1] > nd[0]           # p in [0.1, mprob]
+    eng.rng.manual_seed(5217)
+    eng.prefill(emb, 5, 576)
+    assert eng.generate(6, mprobs=probs) == a                          # deterministic replay under a fixed seed
+    # nothing dropped -> every member reproduces the un-masked pass -> token == stock greedy
+    eng.prefill(emb, 5, 576)
+    ones = torch.ones(8, 576).cuda()
+    for _ in range(4):
+        eng.decode_step(probs, uniforms=ones)
+        s2 = eng.last_step()
+        assert s2["drop"].sum() == 0 and s2["winner"] == 0 and len(set(s2["member_argmax"].tolist())) == 1
+        assert close(eng.logits(), eng.base_logits(), 2e-4)
+    with_members = eng.tokens()
+    eng.prefill(emb, 5, 576)
+    assert eng.generate(5, dropout=False) == with_members
+    # phased (K-shard) API == single call, bit for bit
+    eng.rng.manual_seed(9)
+    eng.prefill(emb, 5, 576)
+    for _ in range(3):
+        eng.decode_step(probs)
+    ref_toks, ref_logits = eng.tokens(), eng.logits()
+    eng.rng.manual_seed(9)
+    eng.prefill(emb, 5, 576)
+    ids, rec = eng.new_xchg_buffers()
+    for _ in range(3):
+        eng.step_base(probs)
+        eng.step_members(0, 8)
+        eng.export_ids(0, 8, ids); eng.import_ids(ids)
+        eng.export_winner(0, 8, rec); eng.import_winner(rec)
+        eng.step_commit()
+    assert eng.tokens() == ref_toks
+    np.testing.assert_array_equal(eng.logits(), ref_logits)
+    eng.close()
