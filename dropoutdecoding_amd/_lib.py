@@ -17,7 +17,7 @@ SYMBOLS = [
     "dd_lm_prefill", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_set_next_token", "dd_lm_step_algorithmic_bytes",
-    "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning",
+    "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench",
 ]
 
 
@@ -97,6 +97,7 @@ def load() -> C.CDLL:
     lib.dd_lm_time_sweep.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     lib.dd_lm_time_gemv.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]
     lib.dd_set_tuning.argtypes = [C.c_int, C.c_int]
+    lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     _lib = lib
     return lib
 

@@ -255,6 +255,10 @@ int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stre
 int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, double* bytes_per_launch_out,
                     void* stream);
 
+/* Calibration for bench.py: streaming READ bandwidth (GB/s) this device delivers over buf_dev[bytes] (bytes >= 1 MiB;
+ * use a buffer much larger than the 256 MiB Infinity Cache), HIP events on `stream`. */
+int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks, float* gbs_out, void* stream);
+
 /* Kernel tuning knobs for the benchmark scripts: key 0 = GEMV weight tiles in flight per wave (4/8/16),
  * 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves of a workgroup (0/1),
  * 3 = timing-only diagnostic build without x-operand loads (results are wrong; never use for output). */
