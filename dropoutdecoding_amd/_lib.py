@@ -13,7 +13,7 @@ SYMBOLS = [
     "dd_rng_create", "dd_rng_destroy", "dd_rng_seed", "dd_rng_uniform",
     "dd_uncertainty_workspace_bytes", "dd_vision_uncertainty", "dd_overlap_keep", "dd_sample_masks", "dd_vote",
     "dd_argmax_rows",
-    "dd_lm_create", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_synthetic",
+    "dd_lm_create", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_tensor_fp8", "dd_lm_load_synthetic",
     "dd_lm_prefill", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_set_next_token", "dd_lm_step_algorithmic_bytes",
@@ -30,7 +30,7 @@ class LMConfigC(C.Structure):
                 ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
                 ("head_dim", C.c_int32), ("rms_eps", C.c_float), ("rope_theta", C.c_float),
                 ("max_seq", C.c_int32), ("max_visual", C.c_int32), ("k_top", C.c_int32), ("mask_mode", C.c_int32),
-                ("vote_on", C.c_int32), ("leak_mask", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("vote_on", C.c_int32), ("leak_mask", C.c_int32), ("weight_format", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 _lib = None
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     lib.dd_lm_device_bytes.restype = C.c_size_t
     lib.dd_lm_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     lib.dd_lm_load_synthetic.argtypes = [vp, C.c_uint32, C.c_float]
+    lib.dd_lm_load_tensor_fp8.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int]
     lib.dd_lm_prefill.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.dd_lm_decode_step.argtypes = [vp, C.POINTER(C.c_double), C.c_int, vp, vp, vp]
     lib.dd_lm_step_base.argtypes = [vp, C.POINTER(C.c_double), C.c_int, vp, vp, vp]

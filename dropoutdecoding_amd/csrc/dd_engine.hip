@@ -21,6 +21,7 @@ uint32_t* dd_rng_state_ptr(dd_rng* r);
 struct LayerW {
   u32x4_t *wqkv, *wo, *wgu, *wdown;
   float *norm1, *norm2;
+  float *s_qkv = nullptr, *s_o = nullptr, *s_gu = nullptr, *s_down = nullptr;   // fp8: per-row scales, packed order
 };
 
 struct dd_lm {
@@ -32,6 +33,9 @@ struct dd_lm {
   // weights
   std::vector<LayerW> lw;
   u32x4_t* lm_head = nullptr;
+  float* s_lm = nullptr;
+  int fp8 = 0;                 // weight storage: 0 bf16, 1 OCP e4m3fn + per-row scales
+  u32x4_t* deq_tmp = nullptr;  // fp8: bf16 tiles of ONE matrix for the prefill GEMM
   float* final_norm = nullptr;
   uint16_t* embed = nullptr;
   float *rope_cos = nullptr, *rope_sin = nullptr;
@@ -125,17 +129,34 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   h->S_d = h->d / 32, h->S_q = h->q_dim / 32, h->S_ff = h->dff / 32;
   h->q_tiles = h->q_dim / 16, h->k_tiles = h->kv_dim / 16, h->qkv_tiles = (h->q_dim + 2 * h->kv_dim) / 16;
   const int d = h->d, dff = h->dff, T = h->T_cap;
+  h->fp8 = c->weight_format == 1 ? 1 : 0;
+  DD_REQUIRE(c->weight_format == 0 || c->weight_format == 1, "dd_lm_create: unknown weight format %d", c->weight_format);
+  const int wdiv = h->fp8 ? 2 : 1;   // u32x4 units per tile row: S*64 (bf16) or (S/2)*64 (fp8)
   h->lw.resize(h->Lyr);
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
-    DA(w.wqkv, (size_t)h->qkv_tiles * h->S_d * 64);
-    DA(w.wo, (size_t)(d / 16) * h->S_q * 64);
-    DA(w.wgu, (size_t)(2 * dff / 16) * h->S_d * 64);
-    DA(w.wdown, (size_t)(d / 16) * h->S_ff * 64);
+    DA(w.wqkv, (size_t)h->qkv_tiles * h->S_d * 64 / wdiv);
+    DA(w.wo, (size_t)(d / 16) * h->S_q * 64 / wdiv);
+    DA(w.wgu, (size_t)(2 * dff / 16) * h->S_d * 64 / wdiv);
+    DA(w.wdown, (size_t)(d / 16) * h->S_ff * 64 / wdiv);
+    if (h->fp8) {
+      DA(w.s_qkv, (size_t)h->qkv_tiles * 16);
+      DA(w.s_o, (size_t)d);
+      DA(w.s_gu, (size_t)2 * dff);
+      DA(w.s_down, (size_t)d);
+    }
     DA(w.norm1, d);
     DA(w.norm2, d);
   }
-  DA(h->lm_head, (size_t)(h->Vpad / 16) * h->S_d * 64);
+  DA(h->lm_head, (size_t)(h->Vpad / 16) * h->S_d * 64 / wdiv);
+  if (h->fp8) {
+    DA(h->s_lm, (size_t)h->Vpad);
+    size_t mx = (size_t)h->qkv_tiles * h->S_d;
+    if ((size_t)(2 * dff / 16) * h->S_d > mx) mx = (size_t)(2 * dff / 16) * h->S_d;
+    if ((size_t)(d / 16) * h->S_ff > mx) mx = (size_t)(d / 16) * h->S_ff;
+    if ((size_t)(h->Vpad / 16) * h->S_d > mx) mx = (size_t)(h->Vpad / 16) * h->S_d;
+    DA(h->deq_tmp, mx * 64);
+  }
   DA(h->final_norm, d);
   DA(h->embed, (size_t)h->V * d);
   DA(h->rope_cos, (size_t)T * 64);
@@ -232,6 +253,8 @@ extern "C" int dd_lm_load_tensor(dd_lm* h, int id, int layer, const uint16_t* sr
   }
   DD_REQUIRE((size_t)rows * cols == (size_t)er * ec && (er == 1 || (rows == er && cols == ec)),
              "dd_lm_load_tensor: tensor %d expects %d x %d, got %d x %d", id, er, ec, rows, cols);
+  DD_REQUIRE(!h->fp8 || id == DD_T_EMBED || id == DD_T_ATTN_NORM || id == DD_T_MLP_NORM || id == DD_T_FINAL_NORM,
+             "dd_lm_load_tensor: this engine stores fp8 weights; load matrices with dd_lm_load_tensor_fp8");
   size_t n = (size_t)rows * cols;
   const uint16_t* dev = src;
   uint16_t* staging = nullptr;
@@ -268,9 +291,82 @@ extern "C" int dd_lm_load_tensor(dd_lm* h, int id, int layer, const uint16_t* sr
   return DD_OK;
 }
 
+extern "C" int dd_lm_load_tensor_fp8(dd_lm* h, int id, int layer, const uint8_t* q, const float* row_scale, int rows,
+                                     int cols, int on_device) {
+  DD_REQUIRE(h && q && row_scale, "dd_lm_load_tensor_fp8: null argument");
+  DD_REQUIRE(h->fp8, "dd_lm_load_tensor_fp8: the engine was created for bf16 weights (weight_format 0)");
+  bool per_layer = id != DD_T_LM_HEAD;
+  DD_REQUIRE(id == DD_T_LM_HEAD || (id >= DD_T_WQ && id <= DD_T_WDOWN && id != DD_T_MLP_NORM),
+             "dd_lm_load_tensor_fp8: tensor id %d is not a matrix", id);
+  DD_REQUIRE(!per_layer || (layer >= 0 && layer < h->Lyr), "dd_lm_load_tensor_fp8: layer %d out of range", layer);
+  const int d = h->d, dff = h->dff;
+  int er = 0, ec = 0;
+  switch (id) {
+    case DD_T_LM_HEAD: er = h->V, ec = d; break;
+    case DD_T_WQ: er = h->q_dim, ec = d; break;
+    case DD_T_WK: case DD_T_WV: er = h->kv_dim, ec = d; break;
+    case DD_T_WO: er = d, ec = h->q_dim; break;
+    case DD_T_WGATE: case DD_T_WUP: er = dff, ec = d; break;
+    case DD_T_WDOWN: er = d, ec = dff; break;
+  }
+  DD_REQUIRE(rows == er && cols == ec, "dd_lm_load_tensor_fp8: tensor %d expects %d x %d, got %d x %d", id, er, ec, rows, cols);
+  const uint8_t* dq = q;
+  const float* ds = row_scale;
+  uint8_t* sq = nullptr;
+  float* ss = nullptr;
+  if (!on_device) {
+    DD_HIP(hipMalloc((void**)&sq, (size_t)rows * cols));
+    DD_HIP(hipMalloc((void**)&ss, (size_t)rows * 4));
+    DD_HIP(hipMemcpy(sq, q, (size_t)rows * cols, hipMemcpyHostToDevice));
+    DD_HIP(hipMemcpy(ss, row_scale, (size_t)rows * 4, hipMemcpyHostToDevice));
+    dq = sq, ds = ss;
+  }
+  LayerW* w = per_layer ? &h->lw[layer] : nullptr;
+  int rc = DD_OK;
+  switch (id) {
+    case DD_T_WQ: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, w->wqkv, w->s_qkv, 0, 1, PACK_ROPE, h->q_tiles, nullptr); break;
+    case DD_T_WK: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, w->wqkv, w->s_qkv, h->q_tiles, 1, PACK_ROPE, h->k_tiles, nullptr); break;
+    case DD_T_WV: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, w->wqkv, w->s_qkv, h->q_tiles + h->k_tiles, 1, PACK_PLAIN, h->k_tiles, nullptr); break;
+    case DD_T_WO: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, w->wo, w->s_o, 0, 1, PACK_PLAIN, d / 16, nullptr); break;
+    case DD_T_WGATE: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, w->wgu, w->s_gu, 0, 2, PACK_PLAIN, dff / 16, nullptr); break;
+    case DD_T_WUP: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, w->wgu, w->s_gu, 1, 2, PACK_PLAIN, dff / 16, nullptr); break;
+    case DD_T_WDOWN: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, w->wdown, w->s_down, 0, 1, PACK_PLAIN, d / 16, nullptr); break;
+    case DD_T_LM_HEAD: rc = ddk_pack_weight_fp8(dq, ds, rows, cols, h->lm_head, h->s_lm, 0, 1, PACK_PLAIN, h->Vpad / 16, nullptr); break;
+  }
+  hipError_t e = hipDeviceSynchronize();
+  if (sq) (void)hipFree(sq);
+  if (ss) (void)hipFree(ss);
+  if (rc != DD_OK) return rc;
+  DD_HIP(e);
+  return DD_OK;
+}
+
 extern "C" int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std) {
   DD_REQUIRE(h, "dd_lm_load_synthetic: null handle");
   const int d = h->d, dff = h->dff;
+  if (h->fp8) {   // random finite e4m3 bytes (|q| <= 240, rms ~ 40) with a constant row scale that gives ~std
+    uint32_t s8 = seed * 2654435761u + 7;
+    const float sc = std / 40.0f;
+    for (int l = 0; l < h->Lyr; ++l) {
+      LayerW& w = h->lw[l];
+      RC(ddk_fill_synthetic_fp8((uint8_t*)w.wqkv, (size_t)h->qkv_tiles * h->S_d * 512, s8++, nullptr));
+      RC(ddk_fill_synthetic_fp8((uint8_t*)w.wo, (size_t)(d / 16) * h->S_q * 512, s8++, nullptr));
+      RC(ddk_fill_synthetic_fp8((uint8_t*)w.wgu, (size_t)(2 * dff / 16) * h->S_d * 512, s8++, nullptr));
+      RC(ddk_fill_synthetic_fp8((uint8_t*)w.wdown, (size_t)(d / 16) * h->S_ff * 512, s8++, nullptr));
+      RC(ddk_fill_const_f32(w.s_qkv, (size_t)h->qkv_tiles * 16, sc, nullptr));
+      RC(ddk_fill_const_f32(w.s_o, d, sc, nullptr));
+      RC(ddk_fill_const_f32(w.s_gu, (size_t)2 * dff, sc, nullptr));
+      RC(ddk_fill_const_f32(w.s_down, d, sc, nullptr));
+      RC(ddk_fill_const_f32(w.norm1, d, 1.0f, nullptr));
+      RC(ddk_fill_const_f32(w.norm2, d, 1.0f, nullptr));
+    }
+    RC(ddk_fill_synthetic_fp8((uint8_t*)h->lm_head, (size_t)(h->Vpad / 16) * h->S_d * 512, s8++, nullptr));
+    RC(ddk_fill_const_f32(h->s_lm, h->Vpad, sc, nullptr));
+    RC(ddk_fill_const_f32(h->final_norm, d, 1.0f, nullptr));
+    RC(ddk_fill_synthetic(h->embed, (size_t)h->V * d, s8++, 1.0f, nullptr));
+    DD_HIP(hipDeviceSynchronize());
+    return DD_OK;
+  }
   uint32_t s = seed * 2654435761u + 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
@@ -353,28 +449,42 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
              "dd_lm_prefill: visual span [%d, %d) does not fit the %d input positions (max_visual %d)", span_start,
              span_start + span_len, T0, h->Lmax);
   const int d = h->d, dff = h->dff, L = span_len;
+  // fp8 storage: the prefill GEMM runs on a bf16 expansion of ONE matrix at a time (exact), scales in its epilogue
+  auto wsel = [&](GemmArgs& g, u32x4_t* W, float* scale, int n_tiles, int S) -> int {
+    if (!h->fp8) {
+      g.W = W;
+      return DD_OK;
+    }
+    int rc = ddk_dequant_tiles(W, h->deq_tmp, n_tiles, S, st);
+    g.W = h->deq_tmp, g.wscale = scale;
+    return rc;
+  };
   DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)T0 * d * 4, hipMemcpyDeviceToDevice, st));
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
     RC(ddk_rmsnorm_split(h->px, T0, d, w.norm1, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st));
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.W = w.wqkv, g.n_tiles = h->qkv_tiles;
+    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.n_tiles = h->qkv_tiles;
+    RC(wsel(g, w.wqkv, w.s_qkv, h->qkv_tiles, h->S_d));
     g.qbuf = h->pq, g.kc = h->kc + (size_t)l * h->lsk, g.vc = h->vc + (size_t)l * h->lsv, g.T_cap = h->T_cap;
     g.q_tiles = h->q_tiles, g.k_tiles = h->k_tiles, g.q_dim = h->q_dim, g.kv_dim = h->kv_dim, g.pos0 = 0;
     g.rope_cos = h->rope_cos, g.rope_sin = h->rope_sin;
     RC(ddk_gemm(EPI_QKV, g, st));
     RC(ddk_attn_prefill(h->pq, g.kc, g.vc, T0, h->T_cap, h->H, h->Hkv, h->p1_hi, h->p1_lo, st));
     memset(&g, 0, sizeof(g));
-    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_q, g.W = w.wo, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
+    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_q, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
+    RC(wsel(g, w.wo, w.s_o, d / 16, h->S_q));
     RC(ddk_gemm(EPI_RESID, g, st));
     RC(ddk_rmsnorm_split(h->px, T0, d, w.norm2, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st));
     memset(&g, 0, sizeof(g));
-    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.W = w.wgu, g.n_tiles = 2 * dff / 16;
+    g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.n_tiles = 2 * dff / 16;
+    RC(wsel(g, w.wgu, w.s_gu, 2 * dff / 16, h->S_d));
     g.o_hi = h->p2_hi, g.o_lo = h->p2_lo, g.ld_planes = dff;
     RC(ddk_gemm(EPI_SILU, g, st));
     memset(&g, 0, sizeof(g));
-    g.a_hi = h->p2_hi, g.a_lo = h->p2_lo, g.M = T0, g.S = h->S_ff, g.W = w.wdown, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
+    g.a_hi = h->p2_hi, g.a_lo = h->p2_lo, g.M = T0, g.S = h->S_ff, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
+    RC(wsel(g, w.wdown, w.s_down, d / 16, h->S_ff));
     RC(ddk_gemm(EPI_RESID, g, st));
   }
   // lm_head over the visual span + the last position only (the reference projects all T0 positions,
@@ -388,7 +498,8 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq + (size_t)L * d, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = L + 1, g.S = h->S_d, g.W = h->lm_head, g.n_tiles = h->Vpad / 16;
+  g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = L + 1, g.S = h->S_d, g.n_tiles = h->Vpad / 16;
+  RC(wsel(g, h->lm_head, h->s_lm, h->Vpad / 16, h->S_d));
   g.out = h->image_logits, g.ldo = h->Vpad, g.n_valid = h->V;
   RC(ddk_gemm(EPI_STORE, g, st));
   RC(dd_vision_uncertainty(h->image_logits, L, h->V, h->Vpad, h->var, h->epi, h->alea, h->scalars, h->cfg.k_top,
@@ -418,6 +529,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     GemvArgs a;
     memset(&a, 0, sizeof(a));
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = nb, a.xop = h->xop_d;
+    a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.knew = knew, a.vnew = vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = h->state;
@@ -432,14 +544,17 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_q;
+    a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b;
     RC(ddk_gemv(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = nb, a.xop = h->xop_d;
+    a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.xop_next = h->xop_ff;
     RC(ddk_gemv(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_ff;
+    a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.ssq_out = h->ssq_a;
     RC(ddk_gemv(EPI_RESID, a, st));
@@ -448,6 +563,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
   GemvArgs a;
   memset(&a, 0, sizeof(a));
   a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = nb, a.xop = h->xop_d;
+  a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   a.out = logits_out, a.ldo = h->Vpad, a.n_valid = h->V;
   RC(ddk_gemv(EPI_STORE, a, st));
@@ -667,7 +783,7 @@ extern "C" double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K) {
   // members), 1 for the stock greedy step.  W_lm in bf16; kv_tok at the cache's storage width (fp32 here).
   double params = (double)h->Lyr * ((double)(h->q_dim + 2 * h->kv_dim) * h->d + (double)h->d * h->q_dim + 3.0 * h->d * h->dff) +
                   (double)h->V * h->d;
-  double w = params * 2.0;
+  double w = params * (h->fp8 ? 1.0 : 2.0);
   double kv_tok = (double)h->Lyr * 2 * h->kv_dim * 4.0;
   int sweeps = K > 0 ? 1 + (K + 7) / 8 : 1;
   return sweeps * (w + (double)h->T_host * kv_tok);
@@ -700,23 +816,23 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
     LayerW& w = h->lw[l % h->Lyr];
     GemvArgs a;
     memset(&a, 0, sizeof(a));
-    a.nb = nb, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.state = h->state;
+    a.nb = nb, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.state = h->state, a.fp8 = h->fp8;
     switch (which) {
       case 0:
-        a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.ssq_in = h->ssq_a, a.ssq_n = d / 16;
+        a.W = w.wqkv, a.wscale = w.s_qkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.ssq_in = h->ssq_a, a.ssq_n = d / 16;
         a.qbuf = h->qbuf, a.knew = h->knew, a.vnew = h->vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
         a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
         return ddk_gemv(EPI_QKV, a, st);
       case 1:
-        a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.out = h->xa, a.ldo = d;
+        a.W = w.wo, a.wscale = w.s_o, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.out = h->xa, a.ldo = d;
         a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b;
         return ddk_gemv(EPI_RESID, a, st);
       case 2:
-        a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.ssq_in = h->ssq_b, a.ssq_n = d / 16;
+        a.W = w.wgu, a.wscale = w.s_gu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.ssq_in = h->ssq_b, a.ssq_n = d / 16;
         a.xop_next = h->xop_ff;
         return ddk_gemv(EPI_SILU, a, st);
       default:
-        a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.out = h->xa, a.ldo = d;
+        a.W = w.wdown, a.wscale = w.s_down, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.out = h->xa, a.ldo = d;
         a.normw_next = w.norm1, a.xop_next = h->xop_d, a.ssq_out = h->ssq_a;
         return ddk_gemv(EPI_RESID, a, st);
     }
@@ -730,7 +846,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
   DD_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *mean_ms = ms / iters;
   double rows[4] = {(double)(h->q_dim + 2 * h->kv_dim) * d, (double)d * h->q_dim, 2.0 * dff * d, (double)d * dff};
-  *bytes_per_launch = rows[which] * 2.0;
+  *bytes_per_launch = rows[which] * (h->fp8 ? 1.0 : 2.0);
   return DD_OK;
 }
 

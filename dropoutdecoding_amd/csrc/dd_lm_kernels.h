@@ -42,8 +42,20 @@ int ddk_rope_table(float* cos_t, float* sin_t, int max_seq, const float* inv_fre
 #define EPI_SILU 2    // tile pair (gate, up): xop_next <- split(silu(g) * u)
 #define EPI_QKV 3     // rotary q/k + v scattered to qbuf / new-row KV scratch
 
+// FP8 weight storage (OCP e4m3fn, per-output-row fp32 scales): tile (nt, ks2) = 64 lanes x 16 bytes at
+// ((nt*S2 + ks2)*64 + lane), S2 = K/64; lane (h<<4)|r holds the 8 fp8 of W[row][ks2*64 + 8h..] followed by the 8 fp8
+// of W[row][ks2*64 + 32 + 8h..]: one 1 KiB wave load feeds TWO bf16 MFMA k-steps after an exact in-register
+// fp8 -> bf16 conversion (v_cvt_pk_f32_fp8 + v_perm).  Scales are stored in packed-row order and applied in the
+// epilogue: y[n] = scale[n] * sum_k q[n][k] x[k].
+int ddk_pack_weight_fp8(const uint8_t* src_dev, const float* row_scale_dev, int rows, int cols, u32x4_t* dst,
+                        float* dst_scale, int dst_tile0, int tile_stride, int pack_mode, int n_src_tiles, hipStream_t st);
+int ddk_dequant_tiles(const u32x4_t* src_fp8, u32x4_t* dst_bf16, int n_tiles, int S, hipStream_t st);
+int ddk_fill_synthetic_fp8(uint8_t* dst, size_t n, uint32_t seed, hipStream_t st);
+
 struct GemvArgs {
   const u32x4_t* W;
+  int fp8;              // 1: W holds fp8 tiles (S2 = S/2 per tile row), wscale required
+  const float* wscale;  // [tiles*16] per-row scales in packed-row order (fp8) or nullptr
   int S;                // K / 32
   int n_tiles;          // number of 16-row tiles (EPI_SILU: number of gate/up PAIRS)
   int nb;               // live rows (1..8)
@@ -100,6 +112,7 @@ struct GemmArgs {
   const uint16_t* a_lo;
   int M, S;
   const u32x4_t* W;
+  const float* wscale;   // per-column (output row of W) scales in packed-row order, or nullptr
   int n_tiles;           // 16-col tiles (EPI_SILU: gate/up tiles interleaved, n_tiles = 2 * d_ff/16)
   float* out;            // EPI_STORE [M][ldo] / EPI_RESID x[M][ldo]
   int ldo, n_valid;

@@ -48,6 +48,81 @@ int ddk_pack_weight(const uint16_t* src, int rows, int cols, u32x4_t* dst, int d
   return DD_OK;
 }
 
+// fp8 (e4m3fn) x16 -> two bf16x8 MFMA operands, exact (3 mantissa bits fit bf16's 7)
+__device__ __forceinline__ void fp8x16_to_bf16(u32x4_t w, u32x4_t& k0, u32x4_t& k1) {
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  uint32_t o[8];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    f2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[d], false);
+    f2_t b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[d], true);
+    o[2 * d] = __builtin_amdgcn_perm(__float_as_uint(a.y), __float_as_uint(a.x), 0x07060302u);
+    o[2 * d + 1] = __builtin_amdgcn_perm(__float_as_uint(b.y), __float_as_uint(b.x), 0x07060302u);
+  }
+  k0 = (u32x4_t){o[0], o[1], o[2], o[3]};
+  k1 = (u32x4_t){o[4], o[5], o[6], o[7]};
+}
+
+__global__ __launch_bounds__(256) void k_pack_weight_fp8(const uint8_t* __restrict__ src, const float* __restrict__ rs,
+                                                         int rows, int cols, u32x4_t* __restrict__ dst,
+                                                         float* __restrict__ dscale, int dst_tile0, int tile_stride,
+                                                         int pack_mode, int n_src_tiles) {
+  int S2 = cols >> 6;
+  size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)n_src_tiles * S2 * 64;
+  if (gid >= total) return;
+  int lane = (int)(gid & 63);
+  size_t q = gid >> 6;
+  int ks2 = (int)(q % S2);
+  int nt = (int)(q / S2);
+  int h = lane >> 4, r = lane & 15;
+  int row;
+  if (pack_mode == PACK_ROPE) {
+    int head = nt >> 3, tt = nt & 7;
+    row = head * HEAD_DIM + (r < 8 ? tt * 8 + r : ROPE_HALF + tt * 8 + (r - 8));
+  } else {
+    row = nt * 16 + r;
+  }
+  u32x4_t v = {0u, 0u, 0u, 0u};
+  if (row < rows) {
+    const uint8_t* p = src + (size_t)row * cols + (size_t)ks2 * 64 + 8 * h;
+    u32x2_t a = *(const u32x2_t*)p, b = *(const u32x2_t*)(p + 32);
+    v = (u32x4_t){a.x, a.y, b.x, b.y};
+  }
+  int dt = dst_tile0 + nt * tile_stride;
+  dst[((size_t)dt * S2 + ks2) * 64 + lane] = v;
+  if (ks2 == 0 && h == 0) dscale[(size_t)dt * 16 + r] = row < rows ? rs[row] : 0.f;
+}
+int ddk_pack_weight_fp8(const uint8_t* src, const float* rs, int rows, int cols, u32x4_t* dst, float* dscale,
+                        int dst_tile0, int tile_stride, int pack_mode, int n_src_tiles, hipStream_t st) {
+  size_t total = (size_t)n_src_tiles * (cols >> 6) * 64;
+  k_pack_weight_fp8<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, rs, rows, cols, dst, dscale, dst_tile0,
+                                                                     tile_stride, pack_mode, n_src_tiles);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+// fp8 tiles -> bf16 tiles of the plain layout (prefill GEMM operand), scales stay separate
+__global__ __launch_bounds__(256) void k_dequant_tiles(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst,
+                                                       size_t total, int S2) {
+  size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  int lane = (int)(gid & 63);
+  size_t q = gid >> 6;
+  int ks2 = (int)(q % S2);
+  size_t nt = q / S2;
+  u32x4_t k0, k1;
+  fp8x16_to_bf16(src[gid], k0, k1);
+  size_t o = ((nt * (size_t)(2 * S2) + 2 * ks2) * 64) + lane;
+  dst[o] = k0;
+  dst[o + 64] = k1;
+}
+int ddk_dequant_tiles(const u32x4_t* src, u32x4_t* dst, int n_tiles, int S, hipStream_t st) {
+  size_t total = (size_t)n_tiles * (S >> 1) * 64;
+  k_dequant_tiles<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, dst, total, S >> 1);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352du;
@@ -65,6 +140,20 @@ __global__ __launch_bounds__(256) void k_fill_synth(uint16_t* dst, size_t n, uin
   uint32_t h2 = hash32(h + 0x68bc21ebu);
   float u = ((h & 0xffff) + (h >> 16) + (h2 & 0xffff) + (h2 >> 16)) * (1.0f / 65536.0f) - 2.0f;  // var = 1/3
   dst[i] = (uint16_t)dd_bf16_rn(u * 1.7320508f * std);
+}
+// random finite e4m3fn bytes (0x7f / 0xff are NaN in the OCP encoding and are avoided)
+__global__ __launch_bounds__(256) void k_fill_synth_fp8(uint8_t* dst, size_t n, uint32_t seed) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h = hash32((uint32_t)i * 0x9e3779b9u + seed) ^ hash32((uint32_t)(i >> 32) + seed * 31u);
+  uint8_t b = (uint8_t)(h & 0xff);
+  if ((b & 0x7f) >= 0x78) b = (b & 0x80) | ((b & 0x3f) + 0x20);   // keep |value| <= 240, never NaN
+  dst[i] = b;
+}
+int ddk_fill_synthetic_fp8(uint8_t* dst, size_t n, uint32_t seed, hipStream_t st) {
+  k_fill_synth_fp8<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dst, n, seed);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 int ddk_fill_synthetic(uint16_t* dst, size_t n, uint32_t seed, float std, hipStream_t st) {
   k_fill_synth<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dst, n, seed, std);
@@ -124,7 +213,7 @@ __device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y) {
 // NT  = non-temporal weight loads (read-once stream, keeps L2/MALL for the x operand and the KV cache)
 // ILV = k-steps interleaved over the 8 waves (wave w takes steps w, w+8, ...: at any instant the workgroup reads
 //       8 consecutive KiB) instead of one contiguous chunk per wave
-template <int EPI, int TILES, int U, int NT, int ILV>
+template <int EPI, int TILES, int U, int NT, int ILV, int FP8 = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   __shared__ float red[TILES * GEMV_WAVES * 256];
   __shared__ float rstd_sh[8];
@@ -174,7 +263,45 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     }
   }
 
-  int s = 0;
+  if constexpr (FP8) {
+    // fp8 weights: one 1 KiB load = 64 k of a tile row = two MFMA k-steps; wave w takes 64-k steps w, w+8, ...
+    // (uneven tails allowed: K = 11008 has 172 such steps)
+    const int S2 = S >> 1;
+    const u32x4_t* wq[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) wq[t] = a.W + (size_t)(tile0 + t) * S2 * 64 + lane;
+    const u32x4_t* xq = a.xop + lane;
+    constexpr int UF = 4;   // fp8 loads in flight per tile = 8 bf16 k-steps
+    for (int s2 = wave; s2 < S2; s2 += GEMV_WAVES * UF) {
+      u32x4_t wf[TILES][UF], b0[UF], b1[UF];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) wf[t][u] = ldw(wq[t] + (size_t)ss * 64);
+          b0[u] = xq[(size_t)(2 * ss) * 64];
+          b1[u] = xq[(size_t)(2 * ss + 1) * 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            u32x4_t k0, k1;
+            fp8x16_to_bf16(wf[t][u], k0, k1);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0),
+                                                             __builtin_bit_cast(bf16x8_t, b0[u]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1),
+                                                             __builtin_bit_cast(bf16x8_t, b1[u]), acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  int s = FP8 ? spw : 0;
   for (; s + U <= spw; s += U) {
     u32x4_t b[U], w[TILES][U];
 #pragma unroll
@@ -226,6 +353,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       const float* r = &red[(tt * GEMV_WAVES + w) * 256];
       y += r[o] + r[o + 32];
     }
+    if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
     return y;
   };
 
@@ -310,6 +438,7 @@ void ddk_set_tuning(int key, int value) {
 template <int EPI, int TILES>
 static void launch_gemv(const GemvArgs& a, hipStream_t st) {
 #define GV(U_, NT_, ILV_) k_gemv<EPI, TILES, U_, NT_, ILV_><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a)
+  if (a.fp8) { k_gemv<EPI, TILES, 8, 1, 1, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }
   const int u = g_gemv_u, nt = g_gemv_nt, il = g_gemv_ilv;
   if (g_gemv_diag) { k_gemv<EPI, TILES, 8, 1, 3><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }  // diagnostic: no x-operand loads
   if (u == 4) { if (nt) { if (il) GV(4, 1, 1); else GV(4, 1, 0); } else { if (il) GV(4, 0, 1); else GV(4, 0, 0); } }
@@ -321,6 +450,7 @@ static void launch_gemv(const GemvArgs& a, hipStream_t st) {
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv: K=%d must be a multiple of 256", a.S * 32);
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv: nb=%d", a.nb);
+  DD_REQUIRE(!a.fp8 || a.wscale, "gemv: fp8 weights need row scales");
   DD_REQUIRE(!a.ssq_in || a.ssq_n >= 1, "gemv: ssq_n");
   switch (epi) {
     case EPI_STORE: launch_gemv<EPI_STORE, 1>(a, st); break;
@@ -649,6 +779,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
         const int row = m_base + i * 16 + 4 * (lane >> 4) + reg;
         const bool ok = row < a.M && wv[j];
         float y = acc[i][j][reg];
+        if (a.wscale) y *= a.wscale[(size_t)(wv[j] ? nt : 0) * 16 + c];
         if (EPI == EPI_STORE) {
           int col = nt * 16 + c;
           if (ok && col < a.n_valid) a.out[(size_t)row * a.ldo + col] = y;
@@ -658,6 +789,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
         } else if (EPI == EPI_SILU) {
           if ((j & 1) == 0) {
             float u = acc[i][j + 1][reg];
+            if (a.wscale) u *= a.wscale[(size_t)(nt + 1) * 16 + c];
             float act = y / (1.0f + expf(-y));
             uint32_t h, l;
             dd_split_hl(act * u, h, l);

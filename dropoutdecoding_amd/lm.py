@@ -72,10 +72,23 @@ VICUNA_7B = LMConfig(32001, 4096, 11008, 32, 32, 32, 128, 1e-6, 10000.0)
 MISTRAL_7B = LMConfig(32064, 4096, 14336, 32, 32, 8, 128, 1e-5, 1000000.0)
 
 
+def quantize_fp8(w: torch.Tensor):
+    """Per-output-row absmax quantisation to OCP fp8 e4m3fn: w ~= scale[:, None] * q.  Returns (q as uint8 [N, K],
+    scale fp32 [N]).  Build-defined (the reference has no fp8 path): BASELINE config 5."""
+    wf = w.float()
+    scale = wf.abs().amax(dim=1).clamp(min=1e-12) / 448.0
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale.float()
+
+
+def dequantize_fp8(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q_u8.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
 class DropoutEngine:
     def __init__(self, cfg: LMConfig, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
                  seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
-                 iblip_positions: str = "cache"):
+                 iblip_positions: str = "cache", weight_format: str = "bf16"):
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
@@ -93,7 +106,9 @@ class DropoutEngine:
         torch.cuda.set_device(self.device)
         c = _lib.LMConfigC(cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads,
                            cfg.num_kv_heads, cfg.head_dim, cfg.rms_eps, cfg.rope_theta, max_seq, max_visual,
-                           fam["k_top"], fam["mask_mode"], fam["vote_on"], fam["leak_mask"])
+                           fam["k_top"], fam["mask_mode"], fam["vote_on"], fam["leak_mask"],
+                           {"bf16": 0, "fp8": 1}[weight_format])
+        self.weight_format = weight_format
         self._h = C.c_void_p()
         _lib.check(self.lib.dd_lm_create(C.byref(c), C.byref(self._h)), "dd_lm_create")
         # the reference seeds torch's global generator at import (llava.py:16-20); under chair_test all three
@@ -111,15 +126,23 @@ class DropoutEngine:
         _lib.check(self.lib.dd_lm_load_tensor(self._h, tid, layer, t.view(torch.int16).data_ptr(), t.shape[0],
                                               t.shape[1], 1 if t.is_cuda else 0), f"dd_lm_load_tensor({tid},{layer})")
 
+    def _load_fp8(self, tid: int, layer: int, t: torch.Tensor) -> None:
+        q, s = quantize_fp8(t.detach())
+        q, s = q.contiguous(), s.contiguous()
+        _lib.check(self.lib.dd_lm_load_tensor_fp8(self._h, tid, layer, q.data_ptr(), s.data_ptr(), q.shape[0], q.shape[1],
+                                                  1 if q.is_cuda else 0), f"dd_lm_load_tensor_fp8({tid},{layer})")
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "") -> None:
-        """HF LlamaForCausalLM / MistralForCausalLM parameter names (optionally under `prefix`)."""
+        """HF LlamaForCausalLM / MistralForCausalLM parameter names (optionally under `prefix`).  An fp8 engine
+        quantises every matrix with `quantize_fp8` (per-row absmax / 448, OCP e4m3fn) on the way in."""
         g = lambda k: sd[prefix + k]
+        mat = self._load_fp8 if self.weight_format == "fp8" else self._load
         self._load(T_EMBED, 0, g("model.embed_tokens.weight"))
         self._load(T_FINAL_NORM, 0, g("model.norm.weight"))
-        self._load(T_LM_HEAD, 0, g("lm_head.weight"))
+        mat(T_LM_HEAD, 0, g("lm_head.weight"))
         for i in range(self.cfg.num_layers):
             for name, tid in _LAYER_TENSORS.items():
-                self._load(tid, i, g(f"model.layers.{i}.{name}"))
+                (self._load if tid in (T_ATTN_NORM, T_MLP_NORM) else mat)(tid, i, g(f"model.layers.{i}.{name}"))
 
     def load_synthetic(self, seed: int = 0, std: float = 0.02) -> None:
         _lib.check(self.lib.dd_lm_load_synthetic(self._h, seed, std), "dd_lm_load_synthetic")

@@ -149,7 +149,8 @@ typedef struct dd_lm_config {
   int32_t vote_on;           /* DD_VOTE_*                                   */
   int32_t leak_mask;         /* InstructBLIP Q2: 1 = the un-masked pass sees the last member's zeros (positions from the
                                 cache length, transformers 5.x); 2 = additionally position = T - #zeros (the 4.44 rule) */
-  int32_t reserved[5];
+  int32_t weight_format;     /* 0 = bf16 matrices, 1 = OCP fp8 e4m3fn matrices + per-output-row fp32 scales (BASELINE config 5) */
+  int32_t reserved[4];
 } dd_lm_config;
 
 typedef struct dd_lm dd_lm;
@@ -177,6 +178,13 @@ size_t dd_lm_device_bytes(const dd_lm* h);
  * for MFMA streaming. src may be a host or a device pointer (src_on_device).  Synchronous. */
 int dd_lm_load_tensor(dd_lm* h, int tensor_id, int layer, const uint16_t* src_bf16, int rows, int cols,
                       int src_on_device);
+/* fp8 engines (weight_format 1): one matrix as OCP e4m3fn bytes [rows][cols] plus row_scale[rows]; W = scale * q.
+ * Quantisation policy is the caller's (dropoutdecoding_amd.lm.quantize_fp8 uses per-row absmax / 448); the kernels
+ * expand fp8 -> bf16 exactly in registers and apply the scale in the epilogue.  Embedding and norm vectors still go
+ * through dd_lm_load_tensor. */
+int dd_lm_load_tensor_fp8(dd_lm* h, int tensor_id, int layer, const uint8_t* q_e4m3, const float* row_scale, int rows,
+                          int cols, int src_on_device);
+
 /* Fill every weight with a deterministic pseudo-random bf16 pattern of the given scale
  * (synthetic-weights benchmark mode; no host traffic). */
 int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std);

@@ -322,3 +322,65 @@ def test_full_size_llava15_7b_properties(E):
     assert eng.tokens() == ref_toks
     np.testing.assert_array_equal(eng.logits(), ref_logits)
     eng.close()
+
+
+def test_fp8_weight_storage_next_family(E):
+    """BASELINE config 5 style: matrices stored as OCP fp8 e4m3fn + per-row scales, expanded exactly to bf16 in
+    registers.  The oracle runs on the DEQUANTISED weights (scale * q in fp32), so the same tolerances apply."""
+    from dropoutdecoding_amd.lm import dequantize_fp8, quantize_fp8
+    rc = RefCfg(512, 512, 512, 2, 4, 2, 128, 1e-5, 1000000.0)
+    w = random_weights(rc, 33, 0.05)
+    wq = {}
+    for k, v in w.items():
+        if v.dim() == 2 and "embed_tokens" not in k:
+            q, s = quantize_fp8(v)
+            wq[k] = dequantize_fp8(q, s)
+        else:
+            wq[k] = v
+    probs = [0.2, 0.4, 0.6, 0.8]
+    eng = E.DropoutEngine(E.LMConfig(512, 512, 512, 2, 4, 2, 128, 1e-5, 1000000.0), family=FAMILY_NEXT, max_seq=160,
+                          max_visual=88, seed=4, weight_format="fp8")
+    eng.load_state_dict(w)
+    emb = torch.randn(100, 512, generator=torch.Generator().manual_seed(4)) * 0.8
+    ref = RefDecoder(FAMILY_NEXT, rc, wq, probs, seed=4)
+    want = ref.generate(emb, 6, 88, 10)
+    eng.prefill(emb.cuda(), 6, 88)
+    assert close(eng.logits(), ref.prefill_logits[-1].numpy())
+    np.testing.assert_allclose(eng.vision_uncert_dict()["epis_uncert_per_token"][0], ref.epi.numpy(), rtol=5e-3, atol=1e-6)
+    for s in range(9):
+        eng.decode_step(probs)
+        st, r = eng.last_step(), ref.records[s]
+        np.testing.assert_array_equal(st["drop"], r.drop, err_msg=f"step {s}")
+        assert st["member_argmax"].tolist() == r.member_argmax and st["winner"] == r.winner, s
+        assert close(eng.logits(), r.logits), s
+    assert eng.tokens() == want
+    with pytest.raises(ValueError):
+        eng._load(E.T_WQ, 0, w["model.layers.0.self_attn.q_proj.weight"])      # bf16 matrix into an fp8 engine
+    eng.close()
+
+
+def test_fp8_conversion_is_ocp_e4m3fn(E):
+    """Every finite e4m3fn byte through the kernel's fp8 -> bf16 expansion (a 256x256 identity-like probe)."""
+    from dropoutdecoding_amd.lm import dequantize_fp8
+    # one matrix row per byte value: W[n, k] = byte n at k == 0, zero elsewhere; x = e_0 picks it out through lm_head
+    V, d = 256, 256
+    rc = RefCfg(V, d, 256, 1, 2, 2, 128, 1e-5, 10000.0)
+    w = random_weights(rc, 1, 0.05)
+    eng = E.DropoutEngine(E.LMConfig(V, d, 256, 1, 2, 2, 128, 1e-5, 10000.0), family=FAMILY_LLAVA, max_seq=64, max_visual=8,
+                          weight_format="fp8")
+    eng.load_state_dict(w)
+    q = torch.zeros(V, d, dtype=torch.uint8)
+    q[:, 0] = torch.arange(256, dtype=torch.uint8)
+    q[127, 0] = 0
+    q[255, 0] = 0                                        # the two NaN encodings
+    scale = torch.ones(V)
+    import ctypes as C
+    from dropoutdecoding_amd import _lib
+    _lib.check(eng.lib.dd_lm_load_tensor_fp8(eng._h, E.T_LM_HEAD, 0, q.data_ptr(), scale.data_ptr(), V, d, 0), "load")
+    eng.prefill(torch.randn(10, d).cuda(), 1, 8)
+    # logits = lm_head @ hidden: column 0 of lm_head times hidden[0]; compare ratios to the torch decode of the bytes
+    hid = eng.hidden()
+    want = dequantize_fp8(q, scale)[:, 0].numpy() * hid[0]
+    got = eng.logits()
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-6 * np.abs(want).max())
+    eng.close()
