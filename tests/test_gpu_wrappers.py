@@ -186,3 +186,45 @@ def test_llavanext_wrapper_with_hf_tiny_model(built):
 def LMtheta(tc):
     rp = getattr(tc, "rope_parameters", None) or {}
     return rp.get("rope_theta", getattr(tc, "rope_theta", 10000.0))
+
+
+def test_instructblip_wrapper_with_hf_tiny_model(built):
+    """ViT + Q-Former + language_projection through the HF modules (reference models/instructblip.py:607-633), then
+    the engine with InstructBLIP semantics; returned ids = BOS(2) ‖ new ids."""
+    from transformers import (InstructBlipConfig, InstructBlipForConditionalGeneration, InstructBlipQFormerConfig,
+                              InstructBlipVisionConfig, LlamaConfig)
+    from dropoutdecoding_amd import config as ddc
+    from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration
+    from dropoutdecoding_amd.vlm import lm_state_dict_from_hf
+    torch.manual_seed(2)
+    vc = InstructBlipVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                  image_size=28, patch_size=14)
+    qc = InstructBlipQFormerConfig(vocab_size=100, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                                   intermediate_size=64, encoder_hidden_size=32, cross_attention_frequency=1)
+    tc = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                     num_key_value_heads=2, head_dim=128, max_position_embeddings=512, tie_word_embeddings=False)
+    cfg = InstructBlipConfig(vision_config=vc.to_dict(), qformer_config=qc.to_dict(), text_config=tc.to_dict(),
+                             num_query_tokens=32)
+    hf = InstructBlipForConditionalGeneration(cfg).eval()
+    for n, p in hf.named_parameters():
+        if "language_model" in n:
+            p.mul_(2.5)
+        if "language_projection" in n:
+            p.mul_(8.0)
+    sd = _ref_weights_from_engine_sd(lm_state_dict_from_hf(hf))
+    ddc.settings["voting_numbers"] = [0.3, 0.5, 0.7]
+    ddc._module_imported(5217)
+    m = CustomInstructBlipForConditionalGeneration.from_hf_model(hf, max_new_tokens=16)
+    pv = torch.randn(1, 3, 28, 28, generator=torch.Generator().manual_seed(3))
+    qids = torch.tensor([[3, 9, 27, 4]])
+    ids = torch.tensor([[1, 17, 45, 6, 7, 99]])
+    out = m.generate(pixel_values=pv, qformer_input_ids=qids, qformer_attention_mask=torch.ones_like(qids), input_ids=ids,
+                     attention_mask=torch.ones_like(ids), max_new_tokens=7, eos_token_id=[])
+    assert out.shape == (1, 8) and int(out[0, 0]) == 2
+    vis = m._visual_embeds(pixel_values=pv, qformer_input_ids=qids, qformer_attention_mask=torch.ones_like(qids))
+    assert vis.shape == (32, 256)
+    emb, start = m._merge(ids.cuda(), vis)
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, tc.rms_norm_eps, 10000.0)
+    ref = RefDecoder(FAMILY_IBLIP, rc, sd, [0.3, 0.5, 0.7])
+    assert out[0, 1:].tolist() == ref.generate(emb.cpu(), 0, 32, 7)
+    assert m.start_image_pos == [0] and m.end_image_pos == [31] and m.start_generation_pos == 38
