@@ -384,3 +384,38 @@ def test_fp8_conversion_is_ocp_e4m3fn(E):
     got = eng.logits()
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-6 * np.abs(want).max())
     eng.close()
+
+
+def test_mid_scale_llava_shapes_vs_oracle(E):
+    """SURVEY's mid-scale configuration (d=1024, 8 layers, the real V=32064, L=576 visual + 32 prompt tokens, K=8):
+    the largest size the oracle finishes in about a minute; exercises every multi-tile path (11 key tiles per head,
+    2004 vocabulary tiles, 576-token mask rows) against the reference-faithful CPU restatement."""
+    rc = RefCfg(32064, 1024, 2816, 8, 8, 8, 128, 1e-5, 10000.0)
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    w = random_weights(rc, 5, 0.03)
+    cfg = E.LMConfig(32064, 1024, 2816, 8, 8, 8, 128, 1e-5, 10000.0)
+    eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=640, max_visual=576, seed=5217)
+    eng.load_state_dict(w)
+    emb = torch.randn(608, 1024, generator=torch.Generator().manual_seed(9)) * 0.8
+    ref = RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=5217)
+    want = ref.generate(emb, 5, 576, 6)
+    eng.prefill(emb.cuda(), 5, 576)
+    assert close(eng.logits(), ref.prefill_logits[-1].numpy())
+    u = eng.vision_uncert_dict()
+    np.testing.assert_allclose(u["epis_uncert_per_token"][0], ref.epi.numpy(), rtol=5e-3, atol=1e-6)
+    assert set(map(tuple, np.sort(eng.topk()[1], 1))) == set(map(tuple, np.sort(ref.topk_ids.numpy(), 1)))
+    for s in range(5):
+        eng.decode_step(probs)
+        st, r = eng.last_step(), ref.records[s]
+        p = 0.1 + (np.array(probs)[:, None] - 0.1) * ((ref.epi.numpy() - ref.epi.numpy().min()) / np.ptp(ref.epi.numpy()))[None]
+        margin = np.abs(r.uniforms - p).min()
+        info = f"step {s}: min |r - p| = {margin:.2e}"
+        np.testing.assert_array_equal(st["keep"], r.keep, err_msg=info)
+        if margin > 1e-5:                                   # a uniform within 1e-5 of its threshold may legitimately flip
+            np.testing.assert_array_equal(st["drop"], r.drop, err_msg=info)
+            assert st["masked_numbers"].tolist() == r.masked_numbers, info
+        assert st["member_argmax"].tolist() == r.member_argmax, info
+        assert st["winner"] == r.winner, info
+        assert close(eng.logits(), r.logits), info
+    assert eng.tokens() == want
+    eng.close()
