@@ -65,6 +65,9 @@ struct dd_lm {
   bool have_leak = false;
   int bit0 = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // host-visible token mirror (pinned, device-mapped): the decode loop can watch for EOS without synchronising
+  int32_t* tok_host = nullptr;       // host pointer: [0] = count, [1..] = tokens
+  int32_t* tok_host_dev = nullptr;   // the same memory as seen from the device
 };
 
 template <typename T>
@@ -102,6 +105,7 @@ extern "C" int dd_lm_destroy(dd_lm* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->tok_host) (void)hipHostFree(h->tok_host);
   delete h;
   return DD_OK;
 }
@@ -227,6 +231,13 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   }
   (void)hipEventCreate(&h->ev0);
   (void)hipEventCreate(&h->ev1);
+  if (hipHostMalloc((void**)&h->tok_host, (MAX_NEW_TOKENS + 1) * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->tok_host_dev, h->tok_host, 0) != hipSuccess) {
+    dd_set_error("dd_lm_create: pinned token mirror allocation failed");
+    dd_lm_destroy(h);
+    return DD_EHIP;
+  }
+  h->tok_host[0] = 0;
   *out = h;
   return DD_OK;
 }
@@ -387,7 +398,8 @@ extern "C" int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std) {
 // -----------------------------------------------------------------------------------------------
 // small state kernels
 // -----------------------------------------------------------------------------------------------
-__global__ void k_state_after_prefill(DDState* st, int T0, const int32_t* first_tok, int32_t* tokens) {
+__global__ void k_state_after_prefill(DDState* st, int T0, const int32_t* first_tok, int32_t* tokens,
+                                      volatile int32_t* mirror) {
   if (threadIdx.x == 0) {
     st->T = T0;
     st->pos = T0;
@@ -396,6 +408,9 @@ __global__ void k_state_after_prefill(DDState* st, int T0, const int32_t* first_
     st->winner = 0;
     st->voted = first_tok[0];
     tokens[0] = first_tok[0];
+    mirror[1] = first_tok[0];
+    __threadfence_system();
+    mirror[0] = 1;
   }
 }
 // pos rule: LLaVA-family llava.py:283 (sum(mask)-1 == T; the mask is rebuilt all-ones every step).  InstructBLIP:
@@ -416,7 +431,8 @@ __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int
                                                    const int32_t* member_tok, const float* base_logits,
                                                    const float* member_logits, int Vpad, float* last_logits,
                                                    int32_t* tokens, const uint8_t* drop_bits, int L, uint8_t* leak_bits,
-                                                   int leak, const float* hidden_rows, int d, float* last_hidden) {
+                                                   int leak, const float* hidden_rows, int d, float* last_hidden,
+                                                   volatile int32_t* mirror) {
   int win = K > 0 ? st->winner : 0;
   const float* src = K > 0 ? member_logits + (size_t)win * Vpad : base_logits;
   for (int i = threadIdx.x; i < Vpad; i += 1024) last_logits[i] = src[i];
@@ -427,7 +443,12 @@ __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int
   if (threadIdx.x == 0) {
     int tok = K > 0 ? member_tok[win] : argmax_base[0];
     int n = st->n_tok;
-    if (n < MAX_NEW_TOKENS) tokens[n] = tok;
+    if (n < MAX_NEW_TOKENS) {
+      tokens[n] = tok;
+      mirror[1 + n] = tok;          // host-mapped: visible to a polling host thread without a stream sync
+      __threadfence_system();
+      mirror[0] = n + 1;
+    }
     st->n_tok = n + 1;
     st->cur_tok = tok;
     st->T = st->T + 1;
@@ -507,7 +528,8 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   DD_HIP(hipMemcpyAsync(h->last_logits, h->image_logits + (size_t)L * h->Vpad, (size_t)h->Vpad * 4,
                         hipMemcpyDeviceToDevice, st));
   RC(dd_argmax_rows(h->last_logits, 1, h->V, h->Vpad, h->argmax_base, st));
-  k_state_after_prefill<<<1, 64, 0, st>>>(h->state, T0, h->argmax_base, h->tokens);
+  h->tok_host[0] = 0;
+  k_state_after_prefill<<<1, 64, 0, st>>>(h->state, T0, h->argmax_base, h->tokens, h->tok_host_dev);
   DD_CHECK_LAUNCH();
   DD_HIP(hipMemsetAsync(h->leak_bits, 0, h->Lmax, st));
   h->T_host = T0, h->span_start = span_start, h->L = L, h->n_tok_host = 1, h->prefilled = true, h->have_leak = false;
@@ -637,7 +659,7 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
                    K > 0 ? 1 : 0, st));
   k_step_end<<<1, 1024, 0, st>>>(h->state, K, h->argmax_base, h->member_tok, h->base_logits, h->member_logits, h->Vpad,
                                  h->last_logits, h->tokens, h->drop_bits, h->L, h->leak_bits, h->cfg.leak_mask, h->hidden,
-                                 h->d, h->last_hidden);
+                                 h->d, h->last_hidden, h->tok_host_dev);
   DD_CHECK_LAUNCH();
   h->T_host += 1;
   h->n_tok_host += 1;
@@ -896,4 +918,17 @@ extern "C" int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, i
   (void)hipEventDestroy(e1);
   (void)hipFree(sink);
   return DD_OK;
+}
+
+// Non-blocking look at the tokens emitted so far (no stream synchronisation): the step kernels mirror every token into
+// pinned host memory.  Returns the number of tokens copied to dst (<= max_tokens).  Lets generate() stop enqueueing
+// steps as soon as an EOS shows up instead of discovering it a whole chunk later.
+extern "C" int dd_lm_peek_tokens(dd_lm* h, int32_t* dst, int max_tokens) {
+  if (!h || !dst || max_tokens <= 0) return 0;
+  volatile int32_t* m = h->tok_host;
+  int n = m[0];
+  if (n > max_tokens) n = max_tokens;
+  if (n > MAX_NEW_TOKENS) n = MAX_NEW_TOKENS;
+  for (int i = 0; i < n; ++i) dst[i] = m[1 + i];
+  return n;
 }

@@ -8,6 +8,7 @@ torch supplies device memory and the stream; the arithmetic is in libdropdec.so.
 from __future__ import annotations
 
 import ctypes as C
+import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -116,6 +117,8 @@ class DropoutEngine:
         self.rng = TorchCpuCompatRNG(fam["seed"] if seed is None else seed)
         self.L = 0
         self.masked_numbers: List[int] = []
+        self._peek_buf = np.zeros(8192, dtype=np.int32)
+        self._n_enqueued = 0
 
     # ---- weights ---------------------------------------------------------------------------
     def _load(self, tid: int, layer: int, t: torch.Tensor) -> None:
@@ -162,6 +165,7 @@ class DropoutEngine:
                    "dd_lm_prefill")
         self.L, self.T0 = span_len, e.shape[0]
         self._last_K = 0
+        self._n_enqueued = 1                       # the prefill's greedy token
 
     def _probs(self, mprobs):
         probs = list(settings["voting_numbers"] if mprobs is None else mprobs)   # read at every step (llava.py:340)
@@ -179,6 +183,7 @@ class DropoutEngine:
         _lib.check(self.lib.dd_lm_decode_step(self._h, arr, K, self.rng.handle, un.data_ptr() if un is not None else None,
                                               _stream()), "dd_lm_decode_step")
         self._last_K = K
+        self._n_enqueued += 1
 
     # phased form for K-sharding (see dist.py)
     def step_base(self, mprobs=None, uniforms=None) -> int:
@@ -195,6 +200,7 @@ class DropoutEngine:
 
     def step_commit(self) -> None:
         _lib.check(self.lib.dd_lm_step_commit(self._h, self._last_K, _stream()), "dd_lm_step_commit")
+        self._n_enqueued += 1
 
     # exchange records for K-sharding (dist.py); tensors are torch CUDA tensors owned by the caller
     def xchg_stride(self) -> int:
@@ -219,17 +225,32 @@ class DropoutEngine:
     def set_next_token(self, token: int) -> None:
         _lib.check(self.lib.dd_lm_set_next_token(self._h, int(token), _stream()), "dd_lm_set_next_token")
 
-    def generate(self, n_new: int, eos: Optional[int] = None, mprobs=None, dropout: bool = True, chunk: int = 16) -> List[int]:
+    def peek_tokens(self) -> List[int]:
+        """Tokens emitted so far WITHOUT synchronising (pinned host mirror written by the step kernels)."""
+        buf = self._peek_buf
+        n = self.lib.dd_lm_peek_tokens(self._h, buf.ctypes.data, buf.size)
+        return buf[:n].tolist()
+
+    def generate(self, n_new: int, eos=None, mprobs=None, dropout: bool = True, lookahead: int = 6, step_fn=None) -> List[int]:
         """Greedy loop of HF `_sample`: the prefill's token first, then ensemble steps until EOS or n_new.
-        Steps are enqueued `chunk` at a time; tokens past an EOS inside a chunk are discarded."""
-        toks = self.tokens()
-        while len(toks) < n_new and (eos is None or toks[-1] != eos):
-            for _ in range(min(chunk, n_new - len(toks))):
-                self.decode_step(mprobs, dropout=dropout)
-            toks = self.tokens()
-            if eos is not None and eos in toks:
-                toks = toks[:toks.index(eos) + 1]
+        Steps are enqueued without synchronising; the host watches the pinned token mirror and stops enqueueing as soon
+        as an EOS appears, so at most `lookahead` steps are wasted (their tokens are discarded)."""
+        eos_set = set() if eos is None else (set(eos) if isinstance(eos, (list, tuple, set)) else {int(eos)})
+        step = step_fn or (lambda: self.decode_step(mprobs, dropout=dropout))
+        enq = self._n_enqueued
+        while enq < n_new:
+            seen = self.peek_tokens()
+            if eos_set and any(t in eos_set for t in seen):
                 break
+            if enq - len(seen) >= lookahead:          # far enough ahead of the GPU: let it catch up
+                time.sleep(0.0002)
+                continue
+            step()
+            enq = self._n_enqueued
+        toks = self.tokens()
+        hit = [i for i, t in enumerate(toks) if t in eos_set]
+        if hit:
+            toks = toks[:hit[0] + 1]
         return toks[:n_new]
 
     # ---- read-backs (synchronise) -------------------------------------------------------------

@@ -139,23 +139,22 @@ class DropoutVLM:
 
     def _decode_loop(self, n_new: int, eos: List[int], chunk: int = 16) -> List[int]:
         eng = self.engine
-        toks = eng.tokens()
         dropout = not self.original
         ks = getattr(self, "kshard", None)             # dist.KShardDecoder: members sharded over ranks
+        if ks is None and not self.collect_diagnostics:
+            # steps are enqueued without host syncs; the pinned token mirror is watched for EOS (<= 6 wasted steps)
+            return eng.generate(n_new, eos=eos, dropout=dropout)
+        toks = eng.tokens()
         while len(toks) < n_new and not (eos and toks[-1] in eos):
             if ks is not None and dropout:
+                # every rank must issue the same collectives: fixed chunks, EOS checked on the synchronised tokens
                 for _ in range(min(chunk, n_new - len(toks))):
                     ks.decode_step()
-                toks = eng.tokens()
-            elif self.collect_diagnostics:
+            else:
                 eng.decode_step(dropout=dropout)
                 if dropout:
                     self.masked_numbers = eng.last_step()["masked_numbers"].tolist()    # llava.py:338,661-662
-                toks = eng.tokens()
-            else:
-                for _ in range(min(chunk, n_new - len(toks))):
-                    eng.decode_step(dropout=dropout)                                    # enqueued, no host sync
-                toks = eng.tokens()
+            toks = eng.tokens()
             hit = [i for i, t in enumerate(toks) if eos and t in eos]
             if hit:
                 toks = toks[:hit[0] + 1]

@@ -246,6 +246,10 @@ int dd_lm_xchg_import_winner(dd_lm* h, const float* rec_dev, void* stream);
 #define DD_GET_HIDDEN 17       /* fp32  [d]             final-normed hidden state behind DD_GET_LOGITS             */
 int dd_lm_get(dd_lm* h, int what, void* dst_host, size_t bytes, void* stream);
 
+/* Non-blocking: copy the tokens emitted so far (mirrored by the step kernels into pinned host memory) to dst and return
+ * how many; does not synchronise any stream. */
+int dd_lm_peek_tokens(dd_lm* h, int32_t* dst_host, int max_tokens);
+
 /* Force the next decode step's input token (default: the last emitted token). */
 int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream);
 
