@@ -124,7 +124,8 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -135,7 +136,7 @@ def main() -> int:
     from dropoutdecoding_amd import build
     if local == 0:
         build.build()                      # one builder per node; the others wait (no concurrent writes of the .so)
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
     from dropoutdecoding_amd import config as ddcfg
     from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
@@ -145,12 +146,12 @@ def main() -> int:
     model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
     model.original = args.original
     eng = model.engine
-    if args.mode == "kshard" and world > 1:
+    if args.mode == "kshard" and use_dist:
         from dropoutdecoding_amd.dist import KShardDecoder
         model.kshard = KShardDecoder(eng, rank, world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +170,7 @@ def main() -> int:
         one(img0 + args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -226,7 +227,7 @@ def main() -> int:
                 line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                         "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
     return 0
 
