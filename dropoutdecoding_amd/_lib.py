@@ -18,11 +18,18 @@ SYMBOLS = [
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_step_algorithmic_bytes",
     "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench",
+    "dd_vit_create", "dd_vit_destroy", "dd_vit_load_tensor", "dd_vit_forward",
 ]
 
 
 class DDError(RuntimeError):
     pass
+
+
+class VitConfigC(C.Structure):
+    _fields_ = [("image_size", C.c_int32), ("patch_size", C.c_int32), ("hidden_size", C.c_int32),
+                ("intermediate_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
+                ("proj_dim", C.c_int32), ("act", C.c_int32), ("ln_eps", C.c_float), ("reserved", C.c_int32 * 7)]
 
 
 class LMConfigC(C.Structure):
@@ -100,6 +107,10 @@ def load() -> C.CDLL:
     lib.dd_lm_time_sweep.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     lib.dd_lm_time_gemv.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]
     lib.dd_set_tuning.argtypes = [C.c_int, C.c_int]
+    lib.dd_vit_create.argtypes = [C.POINTER(VitConfigC), C.POINTER(vp)]
+    lib.dd_vit_destroy.argtypes = [vp]
+    lib.dd_vit_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    lib.dd_vit_forward.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     _lib = lib
     return lib

@@ -56,6 +56,13 @@ __device__ __forceinline__ void dd_split_hl(float x, uint32_t& hi, uint32_t& lo)
   lo = dd_bf16_rn(x - dd_bf16_to_f32(hi));
 }
 
+// Prefill activations are stored in the SAME 16x32 operand-tile order as the weights: element (row m, col k) of a
+// [M][K] plane lives at u16 offset (((m/16)*S + k/32)*64 + ((k%32)/8)*16 + m%16)*8 + k%8, S = K/32, so every A
+// fragment of the prefill GEMM is one contiguous 1 KiB wave load (guide: fragment-shaped row-major loads cost 18-45 %).
+__device__ __forceinline__ size_t apack_off(int m, int k, int S) {
+  return ((((size_t)(m >> 4) * S + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (m & 15)) << 3) + (k & 7);
+}
+
 __device__ __forceinline__ float dd_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -41,6 +41,8 @@ int ddk_rope_table(float* cos_t, float* sin_t, int max_seq, const float* inv_fre
 #define EPI_RESID 1   // x[m][n] += y; packs z = normw_next * x for the next GEMV; emits sum-of-squares slots
 #define EPI_SILU 2    // tile pair (gate, up): xop_next <- split(silu(g) * u)
 #define EPI_QKV 3     // rotary q/k + v scattered to qbuf / new-row KV scratch
+#define EPI_ACT 5     // (prefill GEMM only) y = act(y + bias) -> packed hi/lo planes; act 0 quick_gelu, 1 gelu(erf), 2 none
+#define EPI_QKV_VIT 6 // (prefill GEMM only) ViT q/k/v with bias: q*scale -> qbuf, k -> K^T tiles, v -> rows
 
 // FP8 weight storage (OCP e4m3fn, per-output-row fp32 scales): tile (nt, ks2) = 64 lanes x 16 bytes at
 // ((nt*S2 + ks2)*64 + lane), S2 = K/64; lane (h<<4)|r holds the 8 fp8 of W[row][ks2*64 + 8h..] followed by the 8 fp8
@@ -113,6 +115,10 @@ struct GemmArgs {
   int M, S;
   const u32x4_t* W;
   const float* wscale;   // per-column (output row of W) scales in packed-row order, or nullptr
+  const float* bias;     // per-column bias (natural order) added after the scale, or nullptr
+  int act;               // EPI_ACT: 0 quick_gelu, 1 gelu(erf), 2 identity
+  int vit_hidden, vit_head_dim;   // EPI_QKV_VIT
+  float vit_qscale;
   int n_tiles;           // 16-col tiles (EPI_SILU: gate/up tiles interleaved, n_tiles = 2 * d_ff/16)
   float* out;            // EPI_STORE [M][ldo] / EPI_RESID x[M][ldo]
   int ldo, n_valid;

@@ -652,13 +652,6 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
 
 // ===============================================================================================
 // prefill
-// Prefill activations are stored in the SAME 16x32 operand-tile order as the weights: element (row m, col k) of a
-// [M][K] plane lives at u16 offset (((m/16)*S + k/32)*64 + ((k%32)/8)*16 + m%16)*8 + k%8, S = K/32, so every A
-// fragment of the prefill GEMM is one contiguous 1 KiB wave load (guide: fragment-shaped row-major loads cost 18-45 %).
-__device__ __forceinline__ size_t apack_off(int m, int k, int S) {
-  return ((((size_t)(m >> 4) * S + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (m & 15)) << 3) + (k & 7);
-}
-
 // ===============================================================================================
 // y = w * (x * rsqrt(mean(x^2) + eps)) in HF's op order, written as hi/lo bf16 planes (and optionally fp32)
 __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__ x, int d, const float* __restrict__ w,
@@ -781,6 +774,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
         const bool ok = row < a.M && wv[j];
         float y = acc[i][j][reg];
         if (a.wscale) y *= a.wscale[(size_t)(wv[j] ? nt : 0) * 16 + c];
+        if (a.bias && EPI != EPI_SILU && EPI != EPI_QKV) y += a.bias[(wv[j] ? nt : 0) * 16 + c];
         if (EPI == EPI_STORE) {
           int col = nt * 16 + c;
           if (ok && col < a.n_valid) a.out[(size_t)row * a.ldo + col] = y;
@@ -799,6 +793,30 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
               size_t o = apack_off(row, col, a.ld_planes >> 5);
               a.o_hi[o] = (uint16_t)h;
               a.o_lo[o] = (uint16_t)l;
+            }
+          }
+        } else if (EPI == EPI_ACT) {
+          float v = y;
+          if (a.act == 0) v = y / (1.0f + expf(-1.702f * y));                        // quick_gelu: x * sigmoid(1.702 x)
+          else if (a.act == 1) v = 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));  // gelu (erf form)
+          uint32_t h, l;
+          dd_split_hl(v, h, l);
+          if (ok) {
+            size_t o = apack_off(row, nt * 16 + c, a.ld_planes >> 5);
+            a.o_hi[o] = (uint16_t)h;
+            a.o_lo[o] = (uint16_t)l;
+          }
+        } else if (EPI == EPI_QKV_VIT) {
+          if (ok) {
+            int col = nt * 16 + c, hd = a.vit_head_dim;
+            if (col < a.vit_hidden) {
+              a.qbuf[(size_t)row * a.vit_hidden + col] = y * a.vit_qscale;
+            } else if (col < 2 * a.vit_hidden) {
+              int cc = col - a.vit_hidden, head = cc / hd, idx = cc % hd;
+              a.kc[(((size_t)head * (hd >> 2) + (idx >> 2)) * a.T_cap + row) * 4 + (idx & 3)] = y;
+            } else {
+              int cc = col - 2 * a.vit_hidden, head = cc / hd, idx = cc % hd;
+              a.vc[((size_t)head * a.T_cap + row) * hd + idx] = y;
             }
           }
         } else {  // EPI_QKV
@@ -834,6 +852,8 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
     case EPI_RESID: k_gemm<EPI_RESID><<<grid, 256, 0, st>>>(a); break;
     case EPI_SILU: k_gemm<EPI_SILU><<<grid, 256, 0, st>>>(a); break;
     case EPI_QKV: k_gemm<EPI_QKV><<<grid, 256, 0, st>>>(a); break;
+    case EPI_ACT: k_gemm<EPI_ACT><<<grid, 256, 0, st>>>(a); break;
+    case EPI_QKV_VIT: k_gemm<EPI_QKV_VIT><<<grid, 256, 0, st>>>(a); break;
     default: DD_REQUIRE(false, "gemm: unknown epilogue %d", epi);
   }
   DD_CHECK_LAUNCH();

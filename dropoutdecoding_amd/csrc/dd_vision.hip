@@ -1,0 +1,372 @@
+// CLIP-style vision tower + LLaVA projector on own kernels (the vision front-end).
+// Replaces, for LLaVA-1.5 / LLaVA-NeXT tiles, what the reference runs through third-party modules at
+// models/llava.py:233-246 (vision_tower(pixel_values, output_hidden_states=True).hidden_states[-2][:, 1:] ->
+// multi_modal_projector) and models/llavanext.py:409-417.
+// Same numerics policy as the LM: bf16 weights, fp32 activations carried as bf16 hi/lo planes through the MFMA GEMM
+// (k_gemm, dd_lm_kernels.hip), fp32 LayerNorm / softmax / residual stream.
+#include <math.h>
+
+#include <vector>
+
+#include "dd_lm_kernels.h"
+
+// ---- tensor ids (HF CLIPVisionModel / LlavaMultiModalProjector parameter names) -----------------------------------
+// see include/dropdec.h
+
+struct VitLayer {
+  u32x4_t *wqkv, *wo, *wfc1, *wfc2;
+  float *bqkv, *bo, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
+};
+
+struct dd_vit {
+  dd_vit_config cfg;
+  int T, Tc, P, d, dff, H, hd, Kp, Sp, proj;   // tokens (patches+1), padded tokens, patches, hidden, mlp, heads, head dim, padded patch K
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+  std::vector<VitLayer> lw;
+  u32x4_t *wpatch = nullptr, *wp1 = nullptr, *wp2 = nullptr;
+  float *cls = nullptr, *pos = nullptr, *prew = nullptr, *preb = nullptr, *bp1 = nullptr, *bp2 = nullptr;
+  // scratch
+  float *x = nullptr, *q = nullptr, *kt = nullptr, *v = nullptr;
+  uint16_t *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
+};
+
+template <typename T>
+static int valloc(dd_vit* h, T** p, size_t n) {
+  void* q = nullptr;
+  size_t b = n * sizeof(T);
+  if (b == 0) b = 16;
+  if (hipMalloc(&q, b) != hipSuccess) {
+    dd_set_error("dd_vit: hipMalloc(%zu) failed", b);
+    return DD_ENOMEM;
+  }
+  (void)hipMemset(q, 0, b);
+  h->allocs.push_back(q);
+  h->bytes += b;
+  *p = (T*)q;
+  return DD_OK;
+}
+#define VA(ptr, n)                                   \
+  do {                                               \
+    int rc__ = valloc(h, &(ptr), (size_t)(n));       \
+    if (rc__ != DD_OK) {                             \
+      dd_vit_destroy(h);                             \
+      return rc__;                                   \
+    }                                                \
+  } while (0)
+#define RC(expr)                    \
+  do {                              \
+    int rc__ = (expr);              \
+    if (rc__ != DD_OK) return rc__; \
+  } while (0)
+
+extern "C" int dd_vit_destroy(dd_vit* h) {
+  if (!h) return DD_OK;
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return DD_OK;
+}
+
+extern "C" int dd_vit_create(const dd_vit_config* c, dd_vit** out) {
+  DD_REQUIRE(c && out, "dd_vit_create: null argument");
+  DD_REQUIRE(c->image_size % c->patch_size == 0, "dd_vit_create: image %d not a multiple of patch %d", c->image_size, c->patch_size);
+  DD_REQUIRE(c->hidden_size % 64 == 0 && c->intermediate_size % 64 == 0, "dd_vit_create: hidden/intermediate must be multiples of 64");
+  DD_REQUIRE(c->hidden_size % c->num_heads == 0, "dd_vit_create: heads");
+  int hd = c->hidden_size / c->num_heads;
+  DD_REQUIRE(hd == 64, "dd_vit_create: head_dim must be 64 (CLIP ViT-L/14), got %d", hd);
+  DD_REQUIRE(c->proj_dim == 0 || c->proj_dim % 64 == 0, "dd_vit_create: proj_dim must be a multiple of 64");
+  DD_REQUIRE(c->num_layers >= 1, "dd_vit_create: num_layers");
+  dd_vit* h = new dd_vit();
+  h->cfg = *c;
+  int g = c->image_size / c->patch_size;
+  h->P = g * g, h->T = h->P + 1, h->Tc = (h->T + 63) / 64 * 64;
+  h->d = c->hidden_size, h->dff = c->intermediate_size, h->H = c->num_heads, h->hd = hd, h->proj = c->proj_dim;
+  int kp = 3 * c->patch_size * c->patch_size;
+  h->Kp = (kp + 63) / 64 * 64, h->Sp = h->Kp / 32;
+  const int d = h->d, dff = h->dff;
+  h->lw.resize(c->num_layers);
+  for (auto& w : h->lw) {
+    VA(w.wqkv, (size_t)(3 * d / 16) * (d / 32) * 64);
+    VA(w.wo, (size_t)(d / 16) * (d / 32) * 64);
+    VA(w.wfc1, (size_t)(dff / 16) * (d / 32) * 64);
+    VA(w.wfc2, (size_t)(d / 16) * (dff / 32) * 64);
+    VA(w.bqkv, 3 * d); VA(w.bo, d); VA(w.bfc1, dff); VA(w.bfc2, d);
+    VA(w.ln1w, d); VA(w.ln1b, d); VA(w.ln2w, d); VA(w.ln2b, d);
+  }
+  VA(h->wpatch, (size_t)(d / 16) * h->Sp * 64);
+  VA(h->cls, d); VA(h->pos, (size_t)h->T * d); VA(h->prew, d); VA(h->preb, d);
+  if (h->proj) {
+    VA(h->wp1, (size_t)(h->proj / 16) * (d / 32) * 64);
+    VA(h->wp2, (size_t)(h->proj / 16) * (h->proj / 32) * 64);
+    VA(h->bp1, h->proj); VA(h->bp2, h->proj);
+  }
+  size_t wmax = (size_t)(dff > h->Kp ? dff : h->Kp);
+  if ((size_t)h->proj > wmax) wmax = h->proj;
+  VA(h->x, (size_t)h->Tc * d);
+  VA(h->q, (size_t)h->Tc * d);
+  VA(h->kt, (size_t)h->Tc * d);
+  VA(h->v, (size_t)h->Tc * d);
+  VA(h->a_hi, (size_t)h->Tc * (d > h->Kp ? d : h->Kp));
+  VA(h->a_lo, (size_t)h->Tc * (d > h->Kp ? d : h->Kp));
+  VA(h->b_hi, (size_t)h->Tc * wmax);
+  VA(h->b_lo, (size_t)h->Tc * wmax);
+  *out = h;
+  return DD_OK;
+}
+
+extern "C" int dd_vit_load_tensor(dd_vit* h, int id, int layer, const uint16_t* src, int rows, int cols, int on_device) {
+  DD_REQUIRE(h && src, "dd_vit_load_tensor: null argument");
+  DD_REQUIRE(id >= DD_VT_PATCH && id <= DD_VT_PROJ2_B, "dd_vit_load_tensor: unknown tensor id %d", id);
+  bool per_layer = id >= DD_VT_LN1_W && id <= DD_VT_FC2_B;
+  DD_REQUIRE(!per_layer || (layer >= 0 && layer < (int)h->lw.size()), "dd_vit_load_tensor: layer %d out of range", layer);
+  const int d = h->d, dff = h->dff;
+  size_t n = (size_t)rows * cols;
+  const uint16_t* dev = src;
+  uint16_t* staging = nullptr;
+  if (!on_device) {
+    DD_HIP(hipMalloc((void**)&staging, n * 2));
+    if (hipMemcpy(staging, src, n * 2, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(staging);
+      dd_set_error("dd_vit_load_tensor: H2D copy failed");
+      return DD_EHIP;
+    }
+    dev = staging;
+  }
+  VitLayer* w = per_layer ? &h->lw[layer] : nullptr;
+  int rc = DD_OK;
+  auto vec = [&](float* dst, int len) -> int {
+    if ((size_t)len != n) {
+      dd_set_error("dd_vit_load_tensor: tensor %d expects %d values, got %zu", id, len, n);
+      return DD_EINVAL;
+    }
+    return ddk_bf16_to_f32(dev, dst, len, nullptr);
+  };
+  auto mat = [&](u32x4_t* dst, int er, int ec, int tile0, int nt_total) -> int {
+    if (rows != er || cols != ec) {
+      dd_set_error("dd_vit_load_tensor: tensor %d expects %d x %d, got %d x %d", id, er, ec, rows, cols);
+      return DD_EINVAL;
+    }
+    (void)nt_total;
+    return ddk_pack_weight(dev, rows, cols, dst, tile0, 1, PACK_PLAIN, er / 16, nullptr);
+  };
+  switch (id) {
+    case DD_VT_PATCH: rc = mat(h->wpatch, d, h->Kp, 0, d / 16); break;   // conv weight flattened [d][3*p*p], zero-padded to Kp
+    case DD_VT_CLASS: rc = vec(h->cls, d); break;
+    case DD_VT_POS: rc = vec(h->pos, h->T * d); break;
+    case DD_VT_PRE_LN_W: rc = vec(h->prew, d); break;
+    case DD_VT_PRE_LN_B: rc = vec(h->preb, d); break;
+    case DD_VT_LN1_W: rc = vec(w->ln1w, d); break;
+    case DD_VT_LN1_B: rc = vec(w->ln1b, d); break;
+    case DD_VT_WQ: rc = mat(w->wqkv, d, d, 0, 3 * d / 16); break;
+    case DD_VT_WK: rc = mat(w->wqkv, d, d, d / 16, 3 * d / 16); break;
+    case DD_VT_WV: rc = mat(w->wqkv, d, d, 2 * d / 16, 3 * d / 16); break;
+    case DD_VT_BQ: rc = vec(w->bqkv, d); break;
+    case DD_VT_BK: rc = vec(w->bqkv + d, d); break;
+    case DD_VT_BV: rc = vec(w->bqkv + 2 * d, d); break;
+    case DD_VT_WO: rc = mat(w->wo, d, d, 0, d / 16); break;
+    case DD_VT_BO: rc = vec(w->bo, d); break;
+    case DD_VT_LN2_W: rc = vec(w->ln2w, d); break;
+    case DD_VT_LN2_B: rc = vec(w->ln2b, d); break;
+    case DD_VT_FC1_W: rc = mat(w->wfc1, dff, d, 0, dff / 16); break;
+    case DD_VT_FC1_B: rc = vec(w->bfc1, dff); break;
+    case DD_VT_FC2_W: rc = mat(w->wfc2, d, dff, 0, d / 16); break;
+    case DD_VT_FC2_B: rc = vec(w->bfc2, d); break;
+    case DD_VT_PROJ1_W: DD_REQUIRE(h->proj, "no projector configured"); rc = mat(h->wp1, h->proj, d, 0, h->proj / 16); break;
+    case DD_VT_PROJ1_B: DD_REQUIRE(h->proj, "no projector configured"); rc = vec(h->bp1, h->proj); break;
+    case DD_VT_PROJ2_W: DD_REQUIRE(h->proj, "no projector configured"); rc = mat(h->wp2, h->proj, h->proj, 0, h->proj / 16); break;
+    case DD_VT_PROJ2_B: DD_REQUIRE(h->proj, "no projector configured"); rc = vec(h->bp2, h->proj); break;
+  }
+  hipError_t e = hipDeviceSynchronize();
+  if (staging) (void)hipFree(staging);
+  if (rc != DD_OK) return rc;
+  DD_HIP(e);
+  return DD_OK;
+}
+
+// ---- kernels --------------------------------------------------------------------------------------------------------
+// pixels [3][H][W] fp32 -> im2col rows (one per patch, k = c*p*p + ky*p + kx, zero-padded to Kp) as packed hi/lo planes
+// with a row offset of 1 (row 0 is the class token, filled elsewhere)
+__global__ __launch_bounds__(256) void k_vit_patchify(const float* __restrict__ px, int img, int p, int Kp, uint16_t* hi,
+                                                      uint16_t* lo) {
+  int patch = blockIdx.x, g = img / p;
+  int py = patch / g, pxx = patch % g;
+  for (int k = threadIdx.x; k < Kp; k += 256) {
+    float v = 0.f;
+    if (k < 3 * p * p) {
+      int c = k / (p * p), r = k % (p * p), ky = r / p, kx = r % p;
+      v = px[((size_t)c * img + py * p + ky) * img + pxx * p + kx];
+    }
+    uint32_t h, l;
+    dd_split_hl(v, h, l);
+    size_t o = apack_off(patch + 1, k, Kp >> 5);
+    hi[o] = (uint16_t)h;
+    lo[o] = (uint16_t)l;
+  }
+}
+// x[0] = class_embedding + pos[0]; x[r] = patch_embed[r] + pos[r]
+__global__ __launch_bounds__(256) void k_vit_embed(float* x, const float* cls, const float* pos, int d) {
+  int row = blockIdx.x;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float v = row == 0 ? cls[i] : x[(size_t)row * d + i];
+    x[(size_t)row * d + i] = v + pos[(size_t)row * d + i];
+  }
+}
+// LayerNorm (biased variance, fp32): out_f32 (optional, may alias x) and/or packed hi/lo planes at row (row + row_off)
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, int d, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float eps, float* out_f32, uint16_t* hi,
+                                                   uint16_t* lo, int src_row0) {
+  __shared__ float sh[8];
+  int row = blockIdx.x;
+  const float* xr = x + (size_t)(row + src_row0) * d;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < d; i += 256) s += xr[i];
+  s = dd_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)d;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float t = xr[i] - mean;
+    v += t * t;
+  }
+  v = dd_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[4 + (threadIdx.x >> 6)] = v;
+  __syncthreads();
+  float rstd = 1.0f / sqrtf((sh[4] + sh[5] + sh[6] + sh[7]) / (float)d + eps);
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float y = w ? (xr[i] - mean) * rstd * w[i] + b[i] : xr[i];   // w == nullptr: plain split (projector input)
+    if (out_f32) out_f32[(size_t)row * d + i] = y;
+    if (hi) {
+      uint32_t h, l;
+      dd_split_hl(y, h, l);
+      size_t o = apack_off(row, i, d >> 5);
+      hi[o] = (uint16_t)h;
+      lo[o] = (uint16_t)l;
+    }
+  }
+}
+// bidirectional attention, head_dim 64, one wave per (head, query): keys on lanes from the transposed K, values with
+// 4 keys x 16 d-quads per wave instruction
+__global__ __launch_bounds__(256) void k_attn_vit(const float* __restrict__ q, const float* __restrict__ kt,
+                                                  const float* __restrict__ v, int T, int Tc, int d, uint16_t* o_hi,
+                                                  uint16_t* o_lo) {
+  __shared__ __align__(16) float q_sh[4][64];
+  __shared__ float p_sh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int head = blockIdx.x, t = blockIdx.y * 4 + wave;
+  const bool live = t < T;
+  const int tq = live ? t : T - 1;
+  q_sh[wave][lane] = q[(size_t)tq * d + head * 64 + lane];
+  __syncthreads();
+  const int kg = lane >> 4, dq = lane & 15;   // P.V: key group (4 keys per instruction), d-quad
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    int key = t0 + lane;
+    bool valid = key < T;
+    const float* kb = kt + ((size_t)head * 16 * Tc + (valid ? key : 0)) * 4;
+    float s = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < 16; ++d4) {
+      f32x4_t k4 = *(const f32x4_t*)(kb + (size_t)d4 * Tc * 4);
+      f32x4_t q4 = *(const f32x4_t*)&q_sh[wave][d4 * 4];
+      s += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+    }
+    if (!valid) s = -INFINITY;
+    float m_new = fmaxf(m_run, dd_wave_max(s));
+    float p = valid ? expf(s - m_new) : 0.f;
+    float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    l_run = l_run * corr + dd_wave_sum(p);
+    acc *= corr;
+    m_run = m_new;
+    p_sh[wave][lane] = p;
+    __builtin_amdgcn_wave_barrier();
+    int nkeys = min(64, T - t0);
+    const float* vb = v + ((size_t)head * Tc + t0) * 64 + dq * 4;
+    for (int k4i = 0; 4 * k4i < nkeys; ++k4i) {
+      int kk = 4 * k4i + kg;
+      if (kk < nkeys) acc += p_sh[wave][kk] * *(const f32x4_t*)(vb + (size_t)kk * 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o);
+    acc.y += __shfl_xor(acc.y, o);
+    acc.z += __shfl_xor(acc.z, o);
+    acc.w += __shfl_xor(acc.w, o);
+  }
+  if (live && kg == 0) {
+    float inv = 1.0f / l_run;
+    uint32_t hh[4], ll[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dd_split_hl(acc[j] * inv, hh[j], ll[j]);
+    size_t o = apack_off(t, head * 64 + dq * 4, d >> 5);
+    *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
+    *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
+  }
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------------
+extern "C" int dd_vit_forward(dd_vit* h, const float* pixels, int n_images, float* out, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && pixels && out && n_images >= 1, "dd_vit_forward: bad arguments");
+  const int d = h->d, dff = h->dff, T = h->T, P = h->P, img = h->cfg.image_size;
+  const int od = h->proj ? h->proj : d;
+  for (int im = 0; im < n_images; ++im) {
+    const float* px = pixels + (size_t)im * 3 * img * img;
+    float* o = out + (size_t)im * P * od;
+    k_vit_patchify<<<P, 256, 0, st>>>(px, img, h->cfg.patch_size, h->Kp, h->a_hi, h->a_lo);
+    DD_CHECK_LAUNCH();
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = h->Sp, g.W = h->wpatch, g.n_tiles = d / 16;
+    g.out = h->x, g.ldo = d, g.n_valid = d;                      // row 0 (class token) is overwritten next
+    RC(ddk_gemm(EPI_STORE, g, st));
+    k_vit_embed<<<T, 256, 0, st>>>(h->x, h->cls, h->pos, d);
+    DD_CHECK_LAUNCH();
+    k_layernorm<<<T, 256, 0, st>>>(h->x, d, h->prew, h->preb, h->cfg.ln_eps, h->x, nullptr, nullptr, 0);   // pre_layrnorm
+    DD_CHECK_LAUNCH();
+    for (auto& w : h->lw) {
+      k_layernorm<<<T, 256, 0, st>>>(h->x, d, w.ln1w, w.ln1b, h->cfg.ln_eps, nullptr, h->a_hi, h->a_lo, 0);
+      DD_CHECK_LAUNCH();
+      memset(&g, 0, sizeof(g));
+      g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = d / 32, g.W = w.wqkv, g.n_tiles = 3 * d / 16, g.bias = w.bqkv;
+      g.qbuf = h->q, g.kc = h->kt, g.vc = h->v, g.T_cap = h->Tc, g.vit_hidden = d, g.vit_head_dim = h->hd;
+      g.vit_qscale = 1.0f / sqrtf((float)h->hd);
+      RC(ddk_gemm(EPI_QKV_VIT, g, st));
+      k_attn_vit<<<dim3(h->H, (T + 3) / 4), 256, 0, st>>>(h->q, h->kt, h->v, T, h->Tc, d, h->a_hi, h->a_lo);
+      DD_CHECK_LAUNCH();
+      memset(&g, 0, sizeof(g));
+      g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = d / 32, g.W = w.wo, g.n_tiles = d / 16, g.bias = w.bo;
+      g.out = h->x, g.ldo = d;
+      RC(ddk_gemm(EPI_RESID, g, st));
+      k_layernorm<<<T, 256, 0, st>>>(h->x, d, w.ln2w, w.ln2b, h->cfg.ln_eps, nullptr, h->a_hi, h->a_lo, 0);
+      DD_CHECK_LAUNCH();
+      memset(&g, 0, sizeof(g));
+      g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = d / 32, g.W = w.wfc1, g.n_tiles = dff / 16, g.bias = w.bfc1;
+      g.act = h->cfg.act, g.o_hi = h->b_hi, g.o_lo = h->b_lo, g.ld_planes = dff;
+      RC(ddk_gemm(EPI_ACT, g, st));
+      memset(&g, 0, sizeof(g));
+      g.a_hi = h->b_hi, g.a_lo = h->b_lo, g.M = T, g.S = dff / 32, g.W = w.wfc2, g.n_tiles = d / 16, g.bias = w.bfc2;
+      g.out = h->x, g.ldo = d;
+      RC(ddk_gemm(EPI_RESID, g, st));
+    }
+    if (!h->proj) {   // raw features of the selected layer, class token dropped
+      DD_HIP(hipMemcpyAsync(o, h->x + d, (size_t)P * d * 4, hipMemcpyDeviceToDevice, st));
+      continue;
+    }
+    // projector: linear_1 -> GELU(erf) -> linear_2 on rows 1..P  (LlavaMultiModalProjector)
+    k_layernorm<<<P, 256, 0, st>>>(h->x, d, nullptr, nullptr, 0.f, nullptr, h->a_hi, h->a_lo, 1);
+    DD_CHECK_LAUNCH();
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = P, g.S = d / 32, g.W = h->wp1, g.n_tiles = h->proj / 16, g.bias = h->bp1;
+    g.act = 1, g.o_hi = h->b_hi, g.o_lo = h->b_lo, g.ld_planes = h->proj;
+    RC(ddk_gemm(EPI_ACT, g, st));
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->b_hi, g.a_lo = h->b_lo, g.M = P, g.S = h->proj / 32, g.W = h->wp2, g.n_tiles = h->proj / 16, g.bias = h->bp2;
+    g.out = o, g.ldo = h->proj, g.n_valid = h->proj;
+    RC(ddk_gemm(EPI_STORE, g, st));
+  }
+  return DD_OK;
+}

@@ -18,20 +18,41 @@ seed = 24                          # reference models/llava.py:16
 _config._module_imported(seed)
 
 
+class _Projector(torch.nn.Module):
+    """LlavaMultiModalProjector layout (linear_1 -> GELU -> linear_2) for the synthetic-weights model."""
+
+    def __init__(self, d_in: int, d_out: int):
+        super().__init__()
+        self.linear_1 = torch.nn.Linear(d_in, d_out)
+        self.act = torch.nn.GELU()
+        self.linear_2 = torch.nn.Linear(d_out, d_out)
+
+    def forward(self, x):
+        return self.linear_2(self.act(self.linear_1(x)))
+
+
 class CustomLlavaForConditionalGeneration(DropoutVLM):
     family = FAMILY_LLAVA
 
     def __init__(self, engine, embed_tokens, vision_tower, projector, image_token_index, vision_feature_layer=-2,
-                 vision_feature_select_strategy="default", eos_token_id=None, config=None):
+                 vision_feature_select_strategy="default", eos_token_id=None, config=None, native_vision: bool = True):
         super().__init__(engine, embed_tokens, image_token_index, eos_token_id, config)
         self.vision_tower, self.multi_modal_projector = vision_tower, projector
         self.vision_feature_layer = vision_feature_layer
         self.vision_feature_select_strategy = vision_feature_select_strategy
+        # CLIP tower + projector on the dd_vit_* kernels (vision.py); the HF modules stay available as
+        # `vision_tower` / `multi_modal_projector` for callers that poke at them, but are not on the path.
+        self.tower_hip = None
+        if native_vision and vision_feature_select_strategy == "default" and isinstance(vision_feature_layer, int):
+            from .vision import ClipTowerHIP
+            self.tower_hip = ClipTowerHIP.from_hf(vision_tower, projector, feature_layer=vision_feature_layer)
 
     # reference models/llava.py:229-250
     def _visual_embeds(self, pixel_values: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
         if pixel_values is None:
             raise ValueError("pixel_values is required (one image per prompt)")
+        if self.tower_hip is not None:
+            return self.tower_hip(pixel_values.to(self.device))[0]
         pv = pixel_values.to(self.device, dtype=next(self.vision_tower.parameters()).dtype)
         out = self.vision_tower(pv, output_hidden_states=True)
         feat = out.hidden_states[self.vision_feature_layer]
@@ -89,7 +110,6 @@ class CustomLlavaForConditionalGeneration(DropoutVLM):
         g = torch.Generator(device="cpu").manual_seed(seed)
         with torch.device(dev):
             vt = CLIPVisionModel(vc).to(vision_dtype).eval()
-            proj = torch.nn.Sequential(torch.nn.Linear(1024, lm_cfg.hidden_size), torch.nn.GELU(),
-                                       torch.nn.Linear(lm_cfg.hidden_size, lm_cfg.hidden_size)).to(vision_dtype).eval()
+            proj = _Projector(1024, lm_cfg.hidden_size).to(vision_dtype).eval()
         embed = (torch.randn(lm_cfg.vocab_size, 64, generator=g).repeat(1, lm_cfg.hidden_size // 64)).to(dev, torch.bfloat16)
         return cls(eng, embed, vt, proj, image_token_index, -2, "default", None, None)

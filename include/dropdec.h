@@ -267,6 +267,59 @@ int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stre
 int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, double* bytes_per_launch_out,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Vision front-end: CLIP-style ViT tower (+ optional LLaVA 2-layer projector) on own kernels.
+ * Replaces what the reference runs through third-party modules at models/llava.py:233-246
+ * (vision_tower(...).hidden_states[vision_feature_layer][:, 1:] -> multi_modal_projector) and, per tile,
+ * models/llavanext.py:409-417.  bf16 weights, fp32 activations (hi/lo bf16 planes through the MFMA GEMM).
+ * num_layers = how many encoder layers to RUN: vision_feature_layer = -2 on a 24-layer tower -> 23.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dd_vit_config {
+  int32_t image_size, patch_size;     /* 336, 14 */
+  int32_t hidden_size;                /* 1024 (multiple of 64; head_dim must be 64) */
+  int32_t intermediate_size;          /* 4096 */
+  int32_t num_layers;                 /* encoder layers to run */
+  int32_t num_heads;                  /* 16 */
+  int32_t proj_dim;                   /* 0 = return raw features [P][hidden]; else LLaVA projector output width */
+  int32_t act;                        /* MLP activation: 0 quick_gelu (CLIP), 1 gelu(erf) */
+  float ln_eps;                       /* 1e-5 */
+  int32_t reserved[7];
+} dd_vit_config;
+typedef struct dd_vit dd_vit;
+
+/* tensor ids for dd_vit_load_tensor (HF CLIPVisionModel / LlavaMultiModalProjector names) */
+#define DD_VT_PATCH 0      /* embeddings.patch_embedding.weight [hidden][3*p*p] flattened, zero-padded to a multiple of 64 columns */
+#define DD_VT_CLASS 1      /* embeddings.class_embedding [hidden]                      */
+#define DD_VT_POS 2        /* embeddings.position_embedding.weight [P+1][hidden]        */
+#define DD_VT_PRE_LN_W 3   /* pre_layrnorm.weight */
+#define DD_VT_PRE_LN_B 4
+#define DD_VT_LN1_W 5      /* encoder.layers.i.layer_norm1.weight */
+#define DD_VT_LN1_B 6
+#define DD_VT_WQ 7         /* self_attn.q_proj.weight [hidden][hidden] */
+#define DD_VT_WK 8
+#define DD_VT_WV 9
+#define DD_VT_BQ 10        /* self_attn.q_proj.bias */
+#define DD_VT_BK 11
+#define DD_VT_BV 12
+#define DD_VT_WO 13        /* self_attn.out_proj.weight */
+#define DD_VT_BO 14
+#define DD_VT_LN2_W 15
+#define DD_VT_LN2_B 16
+#define DD_VT_FC1_W 17     /* mlp.fc1.weight [intermediate][hidden] */
+#define DD_VT_FC1_B 18
+#define DD_VT_FC2_W 19     /* mlp.fc2.weight [hidden][intermediate] */
+#define DD_VT_FC2_B 20
+#define DD_VT_PROJ1_W 21   /* multi_modal_projector.linear_1.weight [proj][hidden] */
+#define DD_VT_PROJ1_B 22
+#define DD_VT_PROJ2_W 23   /* multi_modal_projector.linear_2.weight [proj][proj]   */
+#define DD_VT_PROJ2_B 24
+
+int dd_vit_create(const dd_vit_config* cfg, dd_vit** out);
+int dd_vit_destroy(dd_vit* h);
+int dd_vit_load_tensor(dd_vit* h, int tensor_id, int layer, const uint16_t* src_bf16, int rows, int cols, int src_on_device);
+/* pixels_dev [n_images][3][H][W] fp32 (already normalised) -> out_dev [n_images][P][proj_dim or hidden] fp32 */
+int dd_vit_forward(dd_vit* h, const float* pixels_dev, int n_images, float* out_dev, void* stream);
+
 /* Calibration for bench.py: streaming READ bandwidth (GB/s) this device delivers over buf_dev[bytes] (bytes >= 1 MiB;
  * use a buffer much larger than the 256 MiB Infinity Cache), HIP events on `stream`. */
 int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks, float* gbs_out, void* stream);

@@ -29,13 +29,15 @@ def test_llava_wrapper_generate_matches_oracle(built):
     from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
     from dropoutdecoding_amd.vlm import lm_state_dict_from_hf
     torch.manual_seed(0)
-    vc = CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+    vc = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
                           image_size=56, patch_size=14, projection_dim=16)
     tc = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
                      num_key_value_heads=2, head_dim=128, max_position_embeddings=512, tie_word_embeddings=False)
     cfg = LlavaConfig(vision_config=vc, text_config=tc, image_token_index=511, vision_feature_layer=-2,
                       vision_feature_select_strategy="default")
     hf = LlavaForConditionalGeneration(cfg).eval()
+    for p_ in hf.parameters():                               # bf16-valued weights on both sides (vision tower too)
+        p_.copy_(p_.to(torch.bfloat16).float())
     with torch.no_grad():
         for n, p in hf.named_parameters():
             if "language_model" in n or "lm_head" in n:
@@ -51,7 +53,11 @@ def test_llava_wrapper_generate_matches_oracle(built):
                       num_beams=1, pad_token_id=0, eos_token_id=[])
     assert out1.shape == (1, ids1.shape[1] + 8) and out1[0, :7].tolist() == ids1[0].tolist()
     # oracle on the same merged embeddings
+    assert m.tower_hip is not None                           # CLIP tower + projector on own kernels
     vis = m._visual_embeds(pixel_values=pv)
+    hs = m.vision_tower(pv.cuda(), output_hidden_states=True).hidden_states[-2][:, 1:]
+    vis_torch = m.multi_modal_projector(hs)[0]                # the third-party path the reference uses (llava.py:233-246)
+    assert float((vis - vis_torch).abs().max()) <= 1e-3 * float(vis_torch.abs().max())
     emb, start = m._merge(ids1.cuda(), vis)
     assert start == 2 and emb.shape[0] == 6 + 16
     rc = RefCfg(512, 256, 512, 2, 2, 2, 128, tc.rms_norm_eps, 10000.0)
