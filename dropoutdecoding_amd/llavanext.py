@@ -22,14 +22,34 @@ _config._module_imported(seed)
 class CustomLlavaNextForConditionalGeneration(DropoutVLM):
     family = FAMILY_NEXT
 
-    def __init__(self, engine, embed_tokens, hf_vision, image_token_index, eos_token_id=None, config=None):
+    def __init__(self, engine, embed_tokens, hf_vision, image_token_index, eos_token_id=None, config=None,
+                 native_vision: bool = True):
         super().__init__(engine, embed_tokens, image_token_index, eos_token_id, config)
         self._hf = hf_vision            # HF (Llava)NextModel stripped of its language model: tiles -> CLIP -> projector -> unpad/newline packing
+        # per-tile CLIP tower + projector on the dd_vit_* kernels; the anyres unpad / image_newline packing is index
+        # arithmetic on the resulting [tiles, 576, d] tensor and stays HF's pack_image_features
+        self.tower_hip = None
+        if (native_vision and config is not None and config.vision_feature_select_strategy == "default"
+                and isinstance(config.vision_feature_layer, int)):
+            from .vision import ClipTowerHIP
+            self.tower_hip = ClipTowerHIP.from_hf(hf_vision.vision_tower, hf_vision.multi_modal_projector,
+                                                  feature_layer=config.vision_feature_layer)
 
     # reference models/llavanext.py:388-443 (per-tile CLIP, projector, pack_image_features with image_newline)
     def _visual_embeds(self, pixel_values: Optional[torch.Tensor] = None, image_sizes: Optional[torch.Tensor] = None, **_):
         if pixel_values is None or image_sizes is None:
             raise ValueError("pixel_values and image_sizes are required")
+        if self.tower_hip is not None:
+            from transformers.models.llava_next.modeling_llava_next import image_size_to_num_patches
+            n_tiles = image_size_to_num_patches(image_size=image_sizes[0], grid_pinpoints=self.config.image_grid_pinpoints,
+                                                patch_size=self.config.vision_config.image_size)
+            pv = pixel_values.to(self.device)
+            tiles = pv[0][:n_tiles] if pv.dim() == 5 else pv[:n_tiles]
+            feats = self.tower_hip(tiles)                                  # [tiles, 576, d] fp32
+            packed, _ = self._hf.pack_image_features([feats], image_sizes.to(self.device),
+                                                     vision_feature_select_strategy="default",
+                                                     image_newline=self._hf.image_newline.float())
+            return torch.cat(list(packed), dim=0) if isinstance(packed, (list, tuple)) else packed
         dt = next(self._hf.vision_tower.parameters()).dtype
         out = self._hf.get_image_features(pixel_values.to(self.device, dt), image_sizes.to(self.device),
                                           vision_feature_layer=self.config.vision_feature_layer,

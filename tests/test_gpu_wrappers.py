@@ -159,7 +159,7 @@ def test_llavanext_wrapper_with_hf_tiny_model(built):
     from dropoutdecoding_amd.llavanext import CustomLlavaNextForConditionalGeneration
     from dropoutdecoding_amd.vlm import lm_state_dict_from_hf
     torch.manual_seed(1)
-    vc = CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+    vc = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
                           image_size=56, patch_size=14, projection_dim=16)
     tc = MistralConfig(vocab_size=512, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
                        num_key_value_heads=2, head_dim=128, max_position_embeddings=1024, sliding_window=None,
@@ -167,6 +167,8 @@ def test_llavanext_wrapper_with_hf_tiny_model(built):
     cfg = LlavaNextConfig(vision_config=vc, text_config=tc, image_token_index=511, vision_feature_layer=-2,
                           vision_feature_select_strategy="default", image_grid_pinpoints=[[56, 112], [112, 56], [112, 112]])
     hf = LlavaNextForConditionalGeneration(cfg).eval()
+    for p in hf.parameters():
+        p.copy_(p.to(torch.bfloat16).float())
     for n, p in hf.named_parameters():
         if "language_model" in n or "lm_head" in n:
             p.mul_(2.0)
@@ -177,7 +179,13 @@ def test_llavanext_wrapper_with_hf_tiny_model(built):
     m = CustomLlavaNextForConditionalGeneration.from_hf_model(hf, max_new_tokens=16, max_visual=256)
     pv = torch.randn(1, 5, 3, 56, 56, generator=torch.Generator().manual_seed(3))
     sizes = torch.tensor([[100, 100]])
+    assert m.tower_hip is not None
     vis = m._visual_embeds(pixel_values=pv, image_sizes=sizes)
+    hf_out = m._hf.get_image_features(pv.cuda(), sizes.cuda(), vision_feature_layer=-2, vision_feature_select_strategy="default")
+    hf_feats = hf_out.pooler_output if hasattr(hf_out, "pooler_output") else hf_out
+    hf_feats = torch.cat(list(hf_feats), 0) if isinstance(hf_feats, (list, tuple)) else hf_feats
+    assert vis.shape == hf_feats.shape
+    assert float((vis - hf_feats).abs().max()) <= 1e-3 * float(hf_feats.abs().max())    # own tower vs the HF modules
     L = vis.shape[0]
     assert L == 88                                                     # 100x100 image -> 88 visual tokens
     ids = torch.tensor([[1, 17] + [511] * L + [45, 6, 7, 99]])
