@@ -1,0 +1,142 @@
+"""Host-side logic of the drop-in wrappers on CPU (no GPU, no library calls): image-span bookkeeping for both
+processor layouts, error behaviour, return layouts, EOS handling, seed bookkeeping, fp8 quantiser round trip."""
+import numpy as np
+import pytest
+import torch
+
+from dropoutdecoding_amd import config as ddc
+from dropoutdecoding_amd.vlm import DropoutVLM, lm_state_dict_from_hf
+
+
+class StubEngine:
+    """Plays DropoutEngine for the wrapper: emits a scripted token sequence."""
+    device = torch.device("cpu")
+
+    def __init__(self, script):
+        self.script, self.n, self.calls = list(script), 0, []
+
+    def prefill(self, embeds, start, L):
+        self.calls.append(("prefill", tuple(embeds.shape), start, L))
+        self.n = 1
+
+    def generate(self, n_new, eos=None, dropout=True, **kw):
+        eos = set(eos or [])
+        out = []
+        for t in self.script[:n_new]:
+            out.append(t)
+            if t in eos:
+                break
+        self.calls.append(("generate", n_new, tuple(sorted(eos)), dropout))
+        return out
+
+    def tokens(self):
+        return self.script[:self.n]
+
+    def vision_uncert_dict(self):
+        return {"epis_uncert_per_token": np.zeros((1, 4), np.float32)}
+
+    def topk(self):
+        return np.zeros((4, 5), np.float32), np.zeros((4, 5), np.int32)
+
+
+class Wrap(DropoutVLM):
+    family = "llava-1.5"
+
+    def _visual_embeds(self, pixel_values=None, **_):
+        return torch.full((4, 8), 7.0)
+
+
+def make(script=(5, 6, 9, 3, 2)):
+    emb = torch.arange(20 * 8, dtype=torch.float32).reshape(20, 8)
+    return Wrap(StubEngine(script), emb, image_token_index=19, eos_token_id=9)
+
+
+def test_merge_single_placeholder_and_expanded_run():
+    m = make()
+    e1, s1 = m._merge(torch.tensor([[1, 19, 3]]), torch.full((4, 8), 7.0))
+    e2, s2 = m._merge(torch.tensor([[1, 19, 19, 19, 19, 3]]), torch.full((4, 8), 7.0))
+    assert s1 == s2 == 1 and e1.shape == e2.shape == (6, 8) and torch.equal(e1, e2)
+    assert torch.equal(e1[1:5], torch.full((4, 8), 7.0)) and torch.equal(e1[0], m.embed_tokens[1]) and torch.equal(e1[5], m.embed_tokens[3])
+
+
+@pytest.mark.parametrize("ids", [[[1, 2, 3]], [[1, 19, 19, 3]], [[19, 1, 19, 19, 19]]])
+def test_merge_rejects_wrong_image_token_counts(ids):
+    with pytest.raises(ValueError, match="number of image tokens"):
+        make()._merge(torch.tensor(ids), torch.full((4, 8), 7.0))       # reference llava.py:134-138
+
+
+def test_generate_surface_and_state():
+    m = make()
+    ids = torch.tensor([[1, 19, 3]])
+    out = m.generate(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values=torch.zeros(1), max_new_tokens=5,
+                     num_beams=1, pad_token_id=0)
+    assert out.tolist() == [[1, 19, 3, 5, 6, 9]]                      # stops on the model's EOS (9), prompt ids first
+    assert m.start_image_pos == [1] and m.end_image_pos == [4] and m.start_generation_pos == 6
+    assert m.engine.calls[0] == ("prefill", (6, 8), 1, 4)
+    assert m.image_features[1].shape == (1, 4, 5) and "epis_uncert_per_token" in m.vision_uncert_dict
+    out = m.generate(input_ids=ids, pixel_values=torch.zeros(1), max_new_tokens=4, eos_token_id=[])
+    assert out.tolist() == [[1, 19, 3, 5, 6, 9, 3]]                   # EOS ignored, exactly max_new_tokens
+    m.original = True
+    m.generate(input_ids=ids, pixel_values=torch.zeros(1), max_new_tokens=2)
+    assert m.engine.calls[-1][3] is False                            # --original: stock greedy steps
+
+
+def test_generate_rejects_what_the_reference_cannot_do():
+    m = make()
+    with pytest.raises(ValueError):
+        m.generate(input_ids=torch.tensor([[1, 19], [1, 19]]), pixel_values=torch.zeros(1))      # batch 2
+    with pytest.raises(ValueError):
+        m.generate(input_ids=torch.tensor([[1, 19]]), pixel_values=torch.zeros(1), num_beams=3)
+    with pytest.raises(ValueError):
+        m.generate(input_ids=torch.tensor([[1, 19]]), pixel_values=torch.zeros(1), do_sample=True)
+
+
+def test_instructblip_output_layout():
+    from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration as IB
+    emb = torch.arange(20 * 8, dtype=torch.float32).reshape(20, 8)
+    m = IB(StubEngine((5, 6, 9)), emb, hf_front=None, eos_token_id=9, config=None)
+    m._visual_embeds = lambda **kw: torch.full((4, 8), 7.0)
+    out = m.generate(input_ids=torch.tensor([[1, 3, 4]]), pixel_values=torch.zeros(1), max_new_tokens=8)
+    assert out.tolist() == [[2, 5, 6, 9]]                             # BOS(2) + new ids only (instructblip.py:686-695)
+    assert m.start_image_pos == [0] and m.end_image_pos == [3] and m.engine.calls[0] == ("prefill", (7, 8), 0, 4)
+
+
+def test_effective_seed_is_the_last_imported_module():
+    import importlib
+    import dropoutdecoding_amd.instructblip as a
+    import dropoutdecoding_amd.llava as b
+    import dropoutdecoding_amd.llavanext as c
+    for mod, seed in ((b, 24), (c, 506), (a, 5217)):                  # chair_test's import order (chair_test.py:9,12,19)
+        importlib.reload(mod)
+        assert ddc.effective_seed == seed == mod.seed
+    import models.config
+    assert models.config.settings is ddc.settings and ddc.settings["voting_numbers"]
+
+
+def test_lm_state_dict_layouts():
+    w = {k: torch.zeros(1) for k in ("language_model.model.embed_tokens.weight", "language_model.model.layers.0.mlp.up_proj.weight",
+                                     "language_model.lm_head.weight", "vision_tower.x")}
+
+    class M:
+        def state_dict(self):
+            return w
+    sd = lm_state_dict_from_hf(M())
+    assert set(sd) == {"model.embed_tokens.weight", "model.layers.0.mlp.up_proj.weight", "lm_head.weight"}
+    w2 = {"model.language_model.embed_tokens.weight": torch.ones(1), "model.language_model.norm.weight": torch.ones(1),
+          "model.vision_tower.y": torch.ones(1)}
+
+    class M2:
+        def state_dict(self):
+            return w2
+    sd2 = lm_state_dict_from_hf(M2())
+    assert set(sd2) == {"model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"}     # tied head filled in
+
+
+def test_fp8_quantiser_round_trip():
+    from dropoutdecoding_amd.lm import dequantize_fp8, quantize_fp8
+    w = torch.randn(32, 64, generator=torch.Generator().manual_seed(0)) * 0.05
+    q, s = quantize_fp8(w)
+    assert q.dtype == torch.uint8 and s.shape == (32,)
+    d = dequantize_fp8(q, s)
+    assert float((d - w).abs().max()) <= float(w.abs().max()) / 16 + 1e-9          # e4m3: 3 mantissa bits
+    assert float(d.abs().max(dim=1).values.sub(w.abs().max(dim=1).values).abs().max()) < 1e-6   # row maxima are exact
