@@ -860,75 +860,104 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
   return DD_OK;
 }
 
-// causal prefill attention, fp32 VALU, one wave per query row; keys lane-parallel from the transposed K cache
+// causal prefill attention, fp32 VALU; keys lane-parallel from the transposed K cache
+// Each wave owns QR = 4 consecutive query rows, so every K / V tile it loads (L2-resident) is reused 4 times:
+// the one-row-per-wave version was bound by L2 bandwidth (5.9 GB of tile re-reads per layer at T = 608).
+#define PF_QR 4
 template <int G>
 __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ qbuf, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int T, int T_cap, int n_heads,
                                                       uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo) {
-  __shared__ __align__(16) float q_sh[4][HEAD_DIM];
-  __shared__ float p_sh[4][ATT_SPLIT];
+  __shared__ __align__(16) float q_sh[4][PF_QR][HEAD_DIM];
+  __shared__ __align__(16) float p_sh[4][ATT_SPLIT][PF_QR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int head = blockIdx.x, kvh = head / G;
-  const int t = blockIdx.y * 4 + wave;
+  const int t_first = (blockIdx.y * 4 + wave) * PF_QR;          // rows t_first .. t_first + 3
   const int q_dim = n_heads * HEAD_DIM;
-  const bool live = t < T;
-  const int tq = live ? t : T - 1;
-  for (int i = lane; i < HEAD_DIM; i += 64) q_sh[wave][i] = qbuf[(size_t)tq * q_dim + head * HEAD_DIM + i];
-  __syncthreads();
+  if (t_first >= T) return;                                       // whole wave idle (no block-level barrier below)
+  const int t_last = min(t_first + PF_QR - 1, T - 1);
+  for (int i = lane; i < PF_QR * HEAD_DIM; i += 64) {
+    int r = i / HEAD_DIM, dd = i % HEAD_DIM;
+    q_sh[wave][r][dd] = qbuf[(size_t)min(t_first + r, T - 1) * q_dim + head * HEAD_DIM + dd];
+  }
+  __builtin_amdgcn_wave_barrier();
   const float scaling = 0.08838834764831845f;
   const int half = lane >> 5, dq = lane & 31;
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int t0 = 0; t0 <= tq; t0 += ATT_SPLIT) {
+  float m_run[PF_QR], l_run[PF_QR];
+  f32x4_t acc[PF_QR];
+#pragma unroll
+  for (int r = 0; r < PF_QR; ++r) {
+    m_run[r] = -INFINITY;
+    l_run[r] = 0.f;
+    acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int t0 = 0; t0 <= t_last; t0 += ATT_SPLIT) {
     int kt = t0 + lane;
-    bool valid = kt <= tq;
-    const float* kb = kc + ((size_t)kvh * 32 * T_cap + (valid ? kt : 0)) * 4;
-    float s = 0.f;
+    const float* kb = kc + ((size_t)kvh * 32 * T_cap + min(kt, t_last)) * 4;
+    float s[PF_QR];
+#pragma unroll
+    for (int r = 0; r < PF_QR; ++r) s[r] = 0.f;
 #pragma unroll 8
     for (int d4 = 0; d4 < 32; ++d4) {
       f32x4_t k4 = *(const f32x4_t*)(kb + (size_t)d4 * T_cap * 4);
-      f32x4_t q4 = *(const f32x4_t*)&q_sh[wave][d4 * 4];
-      s += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+#pragma unroll
+      for (int r = 0; r < PF_QR; ++r) {
+        f32x4_t q4 = *(const f32x4_t*)&q_sh[wave][r][d4 * 4];
+        s[r] += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+      }
     }
-    s = valid ? s * scaling : -INFINITY;
-    float m_new = fmaxf(m_run, dd_wave_max(s));
-    float p = valid ? expf(s - m_new) : 0.f;
-    float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
-    l_run = l_run * corr + dd_wave_sum(p);
-    acc *= corr;
-    m_run = m_new;
-    p_sh[wave][lane] = p;
+#pragma unroll
+    for (int r = 0; r < PF_QR; ++r) {
+      bool valid = kt <= min(t_first + r, T - 1);                 // causal: row t attends keys 0..t
+      float sv = valid ? s[r] * scaling : -INFINITY;
+      float m_new = fmaxf(m_run[r], dd_wave_max(sv));
+      float p = valid ? expf(sv - m_new) : 0.f;
+      float corr = (m_run[r] == -INFINITY) ? 0.f : expf(m_run[r] - m_new);
+      l_run[r] = l_run[r] * corr + dd_wave_sum(p);
+      acc[r] *= corr;
+      m_run[r] = m_new;
+      p_sh[wave][lane][r] = p;
+    }
     __builtin_amdgcn_wave_barrier();
-    int nkeys = min(ATT_SPLIT, tq + 1 - t0);
+    int nkeys = min(ATT_SPLIT, t_last + 1 - t0);
     const float* vb = vc + ((size_t)kvh * T_cap + t0) * HEAD_DIM + dq * 4;
     for (int kp = 0; 2 * kp < nkeys; ++kp) {
       int key = 2 * kp + half;
       if (key < nkeys) {
         f32x4_t v4 = *(const f32x4_t*)(vb + (size_t)key * HEAD_DIM);
-        acc += p_sh[wave][key] * v4;
+        f32x4_t p4 = *(const f32x4_t*)&p_sh[wave][key][0];
+        acc[0] += p4.x * v4;
+        acc[1] += p4.y * v4;
+        acc[2] += p4.z * v4;
+        acc[3] += p4.w * v4;
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  acc.x += __shfl_xor(acc.x, 32);
-  acc.y += __shfl_xor(acc.y, 32);
-  acc.z += __shfl_xor(acc.z, 32);
-  acc.w += __shfl_xor(acc.w, 32);
-  if (live && half == 0) {
-    float inv = 1.0f / l_run;
-    uint32_t hh[4], ll[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dd_split_hl(acc[j] * inv, hh[j], ll[j]);
-    size_t o = apack_off(t, head * HEAD_DIM + dq * 4, q_dim >> 5);      // 4 consecutive k: one 8-byte packed store
-    *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
-    *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
+  for (int r = 0; r < PF_QR; ++r) {
+    f32x4_t a = acc[r];
+    a.x += __shfl_xor(a.x, 32);
+    a.y += __shfl_xor(a.y, 32);
+    a.z += __shfl_xor(a.z, 32);
+    a.w += __shfl_xor(a.w, 32);
+    const int t = t_first + r;
+    if (t < T && half == 0) {
+      float inv = 1.0f / l_run[r];
+      uint32_t hh[4], ll[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dd_split_hl(a[j] * inv, hh[j], ll[j]);
+      size_t o = apack_off(t, head * HEAD_DIM + dq * 4, q_dim >> 5);      // 4 consecutive k: one 8-byte packed store
+      *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
+      *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
+    }
   }
 }
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, hipStream_t st) {
   int G = n_heads / n_kv;
-  dim3 grid(n_heads, (T + 3) / 4);
+  dim3 grid(n_heads, (T + 4 * PF_QR - 1) / (4 * PF_QR));
   if (G == 1) k_attn_prefill<1><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
   else if (G == 2) k_attn_prefill<2><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
   else if (G == 4) k_attn_prefill<4><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
