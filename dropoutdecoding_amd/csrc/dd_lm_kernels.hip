@@ -474,9 +474,14 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
 // 16-byte d-chunks, keys on lanes) AND of the V tile (16 keys, two per instruction) before anything else, so the
 // whole 64 KiB tile is in flight at once and the kernel pays one memory latency, not 64.  Scores are reduced over
 // the four waves through LDS, softmax statistics are per tile (flash-decoding), P.V partials are reduced the same way.
-template <int NBT, int G>
+// GH = q heads of the GQA group handled by one workgroup (blockIdx.z picks the slice): 32 rows per workgroup (8 members
+// x 4 heads) need 122 KiB of LDS and 156 VGPRs, i.e. one workgroup per CU; two slices of 16 rows run two per CU and
+// read the K/V tile twice through L2.
+template <int NBT, int G, int GH>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
-  constexpr int R = NBT * G;
+  constexpr int R = NBT * GH;        // rows of this workgroup
+  constexpr int RT = NBT * G;        // rows per kv head in the partial buffers
+  const int g0 = blockIdx.z * GH;
   extern __shared__ __align__(16) float att_sh[];
   float* q_sh = att_sh;                       // [R][128]
   float* s_part = q_sh + R * HEAD_DIM;        // [4][R][64]
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   }
   // 2. q rows (r = g*NBT + m) into LDS
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
-    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = r / NBT, m = r % NBT;
+    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT, m = r % NBT;
     q_sh[i] = (m < a.nb) ? a.qbuf[(size_t)m * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
   }
   __syncthreads();
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     float l = dd_wave_sum(p);
     p_sh[lane * R + r] = p;
     if (lane == 0) {
-      float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * R + r) * 2;
+      float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + g0 * NBT + r) * 2;
       ml[0] = mx;
       ml[1] = l;
     }
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 6. fixed-order sum over the four waves
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     float o = (o_part[i] + o_part[R * HEAD_DIM + i]) + (o_part[2 * R * HEAD_DIM + i] + o_part[3 * R * HEAD_DIM + i]);
-    a.part_o[((size_t)kvh * gridDim.y + split) * R * HEAD_DIM + i] = o;
+    a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
   }
 }
 
@@ -624,16 +629,17 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
 
 template <int NBT, int G>
 static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
-  constexpr int R = NBT * G;
+  constexpr int GH = (NBT * G > 16) ? 2 : G;     // at most 16 rows per workgroup
+  constexpr int R = NBT * GH;
   int splits = (a.T + ATT_SPLIT - 1) / ATT_SPLIT;
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_attn_partial<NBT, G><<<dim3(a.n_kv, splits), 256, smem, st>>>(a);
+  k_attn_partial<NBT, G, GH><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
   k_attn_combine<NBT, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
 }
