@@ -706,54 +706,55 @@ int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float e
 
 // C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64; both operands are pre-tiled so every
 // fragment is a contiguous 1 KiB wave load straight to VGPRs (L2-resident A, streamed W)
-#define GEMM_BM 128
-#define GEMM_BN_TILES 8
 
-template <int EPI>
+// MI x NJ = 16x16 MFMA tiles per wave (rows x cols); 4 waves as 2x2: block = (32*MI) rows x (32*NJ) cols.
+// 4x4 (128x128 block) for the LM prefill; 2x2 (64x64) when the grid would otherwise be too small to fill 256 CUs
+// (the ViT: M = 577, N = 1024).
+template <int EPI, int MI, int NJ>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m_base = blockIdx.y * GEMM_BM + wr * 64;
-  const int nt_base = blockIdx.x * GEMM_BN_TILES + wc * 4;
+  const int m_base = blockIdx.y * (32 * MI) + wr * (16 * MI);
+  const int nt_base = blockIdx.x * (2 * NJ) + wc * NJ;
   const int S = a.S;
-  f32x4_t acc[4][4];
+  f32x4_t acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const u32x4_t* pa_hi[4];
-  const u32x4_t* pa_lo[4];
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const u32x4_t* pa_hi[MI];
+  const u32x4_t* pa_lo[MI];
   const int m_tiles = (a.M + 15) >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     int mt = min((m_base >> 4) + i, m_tiles - 1);
     pa_hi[i] = (const u32x4_t*)a.a_hi + (size_t)mt * S * 64 + lane;
     pa_lo[i] = (const u32x4_t*)a.a_lo + (size_t)mt * S * 64 + lane;
   }
-  const u32x4_t* pw[4];
-  bool wv[4];
+  const u32x4_t* pw[NJ];
+  bool wv[NJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     wv[j] = (nt_base + j) < a.n_tiles;
     pw[j] = a.W + ((size_t)(wv[j] ? nt_base + j : 0) * S) * 64 + lane;
   }
   // explicit two-stage register pipeline: the fragments of k-step s+1 are requested before the 32 MFMAs of step s
   // issue, so the L2 latency of one step hides behind the matrix work of the other (S is even: K multiple of 256)
-  u32x4_t ahi0[4], alo0[4], w0[4], ahi1[4], alo1[4], w1[4];
+  u32x4_t ahi0[MI], alo0[MI], w0[NJ], ahi1[MI], alo1[MI], w1[NJ];
   auto load = [&](u32x4_t* ahi, u32x4_t* alo, u32x4_t* w, int ks) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       ahi[i] = pa_hi[i][(size_t)ks * 64];
       alo[i] = pa_lo[i][(size_t)ks * 64];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = pw[j][(size_t)ks * 64];
+    for (int j = 0; j < NJ; ++j) w[j] = pw[j][(size_t)ks * 64];
   };
   auto compute = [&](const u32x4_t* ahi, const u32x4_t* alo, const u32x4_t* w) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ahi[i]),
                                                             __builtin_bit_cast(bf16x8_t, w[j]), acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, alo[i]),
@@ -770,9 +771,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   // D[m][n]: m = 4*(lane>>4) + reg, n = lane & 15
   const int c = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int nt = nt_base + j;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
@@ -851,19 +852,27 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   }
 }
 
-int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
-  dim3 grid((a.n_tiles + GEMM_BN_TILES - 1) / GEMM_BN_TILES, (a.M + GEMM_BM - 1) / GEMM_BM);
+template <int MI, int NJ>
+static int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.n_tiles + 2 * NJ - 1) / (2 * NJ), (a.M + 32 * MI - 1) / (32 * MI));
   switch (epi) {
-    case EPI_STORE: k_gemm<EPI_STORE><<<grid, 256, 0, st>>>(a); break;
-    case EPI_RESID: k_gemm<EPI_RESID><<<grid, 256, 0, st>>>(a); break;
-    case EPI_SILU: k_gemm<EPI_SILU><<<grid, 256, 0, st>>>(a); break;
-    case EPI_QKV: k_gemm<EPI_QKV><<<grid, 256, 0, st>>>(a); break;
-    case EPI_ACT: k_gemm<EPI_ACT><<<grid, 256, 0, st>>>(a); break;
-    case EPI_QKV_VIT: k_gemm<EPI_QKV_VIT><<<grid, 256, 0, st>>>(a); break;
+    case EPI_STORE: k_gemm<EPI_STORE, MI, NJ><<<grid, 256, 0, st>>>(a); break;
+    case EPI_RESID: k_gemm<EPI_RESID, MI, NJ><<<grid, 256, 0, st>>>(a); break;
+    case EPI_SILU: k_gemm<EPI_SILU, MI, NJ><<<grid, 256, 0, st>>>(a); break;
+    case EPI_QKV: k_gemm<EPI_QKV, MI, NJ><<<grid, 256, 0, st>>>(a); break;
+    case EPI_ACT: k_gemm<EPI_ACT, MI, NJ><<<grid, 256, 0, st>>>(a); break;
+    case EPI_QKV_VIT: k_gemm<EPI_QKV_VIT, MI, NJ><<<grid, 256, 0, st>>>(a); break;
     default: DD_REQUIRE(false, "gemm: unknown epilogue %d", epi);
   }
   DD_CHECK_LAUNCH();
   return DD_OK;
+}
+
+int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
+  DD_REQUIRE(a.S >= 2 && (a.S & 1) == 0, "gemm: K=%d must be a multiple of 64", a.S * 32);
+  long big = (long)((a.n_tiles + 7) / 8) * ((a.M + 127) / 128);      // workgroups of the 128x128 tiling
+  if (big >= 150) return launch_gemm<4, 4>(epi, a, st);
+  return launch_gemm<2, 2>(epi, a, st);                              // 64x64 blocks: 4x the workgroups
 }
 
 // causal prefill attention, fp32 VALU; keys lane-parallel from the transposed K cache
