@@ -112,6 +112,8 @@ def load() -> C.CDLL:
     lib.dd_vit_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     lib.dd_vit_forward.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
+    if os.environ.get("DD_NO_GRAPH", "0") not in ("", "0"):
+        lib.dd_set_tuning(8, 0)          # launch every decode step kernel by kernel instead of replaying hipGraphs
     _lib = lib
     return lib
 

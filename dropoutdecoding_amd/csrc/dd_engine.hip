@@ -65,6 +65,13 @@ struct dd_lm {
   bool have_leak = false;
   int bit0 = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // hipGraph cache of whole decode steps (key: K, probabilities, key-tile count, rng)
+  struct GraphEntry {
+    unsigned long long key;
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs;
+  int steps_since_prefill = 0;
   // host-visible token mirror (pinned, device-mapped): the decode loop can watch for EOS without synchronising
   int32_t* tok_host = nullptr;       // host pointer: [0] = count, [1..] = tokens
   int32_t* tok_host_dev = nullptr;   // the same memory as seen from the device
@@ -106,6 +113,7 @@ extern "C" int dd_lm_destroy(dd_lm* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->tok_host) (void)hipHostFree(h->tok_host);
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   delete h;
   return DD_OK;
 }
@@ -534,6 +542,7 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   DD_HIP(hipMemsetAsync(h->leak_bits, 0, h->Lmax, st));
   h->T_host = T0, h->span_start = span_start, h->L = L, h->n_tok_host = 1, h->prefilled = true, h->have_leak = false;
   h->last_K = 0;
+  h->steps_since_prefill = 0;
   return DD_OK;
 }
 
@@ -559,7 +568,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
     t.qbuf = h->qbuf, t.kc = h->kc + (size_t)l * h->lsk, t.vc = h->vc + (size_t)l * h->lsv, t.T_cap = h->T_cap;
-    t.T = h->T_host, t.nb = nb, t.n_heads = h->H, t.n_kv = h->Hkv, t.drop_bits = bits;
+    t.T = h->T_host, t.state = h->state, t.nb = nb, t.n_heads = h->H, t.n_kv = h->Hkv, t.drop_bits = bits;
     t.bit0 = bits ? h->bit0 : 0;
     t.span_start = h->span_start, t.span_len = h->L, t.part_o = h->part_o, t.part_ml = h->part_ml;
     t.knew = knew, t.vnew = vnew, t.xop_out = h->xop_q;
@@ -609,9 +618,11 @@ extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rn
     return DD_ESTATE;
   }
   DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
-  k_step_begin<<<1, 256, 0, st>>>(h->state, h->leak_bits, h->L, (h->cfg.leak_mask == 2 && h->have_leak) ? 1 : 0);
+  // leak_bits are all zero until the first dropout step, so passing them unconditionally is equivalent and keeps the
+  // launch arguments identical from step to step (graph replay)
+  k_step_begin<<<1, 256, 0, st>>>(h->state, h->leak_bits, h->L, h->cfg.leak_mask == 2 ? 1 : 0);
   DD_CHECK_LAUNCH();
-  const uint8_t* base_bits = (h->cfg.leak_mask && h->have_leak) ? h->leak_bits : nullptr;
+  const uint8_t* base_bits = h->cfg.leak_mask ? h->leak_bits : nullptr;
   h->bit0 = 0;
   RC(lm_sweep(h, 1, base_bits, 0, h->base_logits, st));
   RC(dd_argmax_rows(h->base_logits, 1, h->V, h->Vpad, h->argmax_base, st));
@@ -667,10 +678,88 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
   return DD_OK;
 }
 
-extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
+static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
   RC(dd_lm_step_base(h, mprobs, K, rng, uniforms, stream));
   if (K > 0) RC(dd_lm_step_members(h, 0, K, stream));
   return dd_lm_step_commit(h, K, stream);
+}
+
+static int g_use_graph = 1;   // dd_set_tuning key 8
+void dd_engine_set_graph(int on) { g_use_graph = on; }
+
+// One whole ensemble step = ~340 kernel launches.  After the first (eager) step of a sequence the step is captured
+// into a hipGraph and replayed: every launch argument is step-invariant (lengths, positions, tokens and the vote live
+// in device memory), except the number of 64-key attention tiles, which is part of the cache key together with K, the
+// probabilities and the rng.  Host cost per step drops from ~3.4 ms of launches to one hipGraphLaunch.
+extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
+  DD_REQUIRE(h, "dd_lm_decode_step: null handle");
+  hipStream_t st = (hipStream_t)stream;
+  const bool graphable = g_use_graph && !uniforms && h->prefilled && h->steps_since_prefill >= 1 && st != nullptr;
+  if (!graphable) {
+    int rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
+    if (rc == DD_OK) h->steps_since_prefill++;
+    return rc;
+  }
+  if (!h->prefilled) {
+    dd_set_error("dd_lm_decode_step: decode before prefill");
+    return DD_ESTATE;
+  }
+  DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_step: bad K / mprobs");
+  if (h->T_host + 1 >= h->T_cap) {
+    dd_set_error("dd_lm_step: KV cache full (%d tokens)", h->T_cap);
+    return DD_ESTATE;
+  }
+  DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
+  unsigned long long key = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+  mix((unsigned long long)K);
+  for (int k = 0; k < K; ++k) {
+    unsigned long long bits;
+    memcpy(&bits, &mprobs[k], 8);
+    mix(bits);
+  }
+  mix((unsigned long long)((h->T_host + 63) / 64));
+  mix(((unsigned long long)h->L << 32) | (unsigned)h->span_start);   // launch arguments fixed by the last prefill
+  mix((unsigned long long)(uintptr_t)rng);
+  mix((unsigned long long)(uintptr_t)st);
+  for (auto& g : h->graphs)
+    if (g.key == key) {
+      DD_HIP(hipGraphLaunch(g.exec, st));
+      h->last_K = K, h->T_host += 1, h->n_tok_host += 1, h->steps_since_prefill++;
+      if (h->cfg.leak_mask && K > 0) h->have_leak = true;
+      return DD_OK;
+    }
+  // miss: capture this step, then launch it
+  const int sT = h->T_host, sN = h->n_tok_host, sK = h->last_K, sB = h->bit0;
+  const bool sL = h->have_leak;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    int rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
+    if (rc == DD_OK) h->steps_since_prefill++;
+    return rc;
+  }
+  int rc = decode_step_eager(h, mprobs, K, rng, nullptr, stream);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  hipGraphExec_t exec = nullptr;
+  if (rc == DD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    if (h->graphs.size() >= 6) {
+      (void)hipGraphExecDestroy(h->graphs.front().exec);
+      h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back({key, exec});
+    DD_HIP(hipGraphLaunch(exec, st));
+    h->steps_since_prefill++;
+    return DD_OK;          // host mirrors were advanced by the captured call
+  }
+  // capture failed: nothing was executed; restore the host mirrors and run the step eagerly
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  h->T_host = sT, h->n_tok_host = sN, h->last_K = sK, h->bit0 = sB, h->have_leak = sL;
+  rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
+  if (rc == DD_OK) h->steps_since_prefill++;
+  return rc;
 }
 
 extern "C" size_t dd_lm_xchg_stride(const dd_lm* h) {
@@ -875,8 +964,9 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE(key >= 0 && key <= 3, "dd_set_tuning: unknown key %d", key);
-  ddk_set_tuning(key, value);
+  DD_REQUIRE((key >= 0 && key <= 3) || key == 8, "dd_set_tuning: unknown key %d", key);
+  if (key == 8) dd_engine_set_graph(value);
+  else ddk_set_tuning(key, value);
   return DD_OK;
 }
 

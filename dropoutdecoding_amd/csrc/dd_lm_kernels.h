@@ -91,7 +91,8 @@ struct AttnDecodeArgs {
   const float* kc;       // this layer: [n_kv][32][T_cap][4]
   const float* vc;       // this layer: [n_kv][T_cap][128]
   int T_cap;
-  int T;                 // host copy of the prefix length (grid sizing)
+  int T;                 // host copy of the prefix length (grid sizing; also the length when `state` is null)
+  const DDState* state;  // when set, kernels read the prefix length from the device (graph replays keep advancing)
   int nb, n_heads, n_kv;
   const uint8_t* drop_bits;  // [span_len] bit (bit0 + m) = row m drops that visual token, or nullptr
   int bit0;

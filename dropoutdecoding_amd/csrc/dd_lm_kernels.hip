@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   float* o_part = p_sh + ATT_SPLIT * R;       // [4][R][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kvh = blockIdx.x, split = blockIdx.y;
-  const int T = a.T, t0 = split * ATT_SPLIT;
+  const int T = a.state ? a.state->T : a.T, t0 = split * ATT_SPLIT;
+  if (t0 >= T) return;   // cannot happen while ceil(T/64) matches the launch grid; guards a stale graph
   const int q_dim = a.n_heads * HEAD_DIM;
   const int nkeys = min(ATT_SPLIT, T - t0);
   const int half = lane >> 5, dq = lane & 31;

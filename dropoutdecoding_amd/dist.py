@@ -42,6 +42,13 @@ class KShardDecoder:
         self.ids, self.rec = engine.new_xchg_buffers()
 
     def decode_step(self, mprobs: Optional[Sequence[float]] = None, uniforms=None) -> None:
+        st = getattr(self.e, "torch_stream", None)
+        if st is None:
+            return self._decode_step(mprobs, uniforms)
+        with torch.cuda.stream(st):           # the collectives must run in order with the engine's kernels
+            return self._decode_step(mprobs, uniforms)
+
+    def _decode_step(self, mprobs: Optional[Sequence[float]] = None, uniforms=None) -> None:
         e = self.e
         K = e.step_base(mprobs, uniforms)
         if K == 0:

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .config import settings
 from .dropout import (MASK_IBLIP_QUANTILE, MASK_LLAVA_CUMULATIVE, MASK_NEXT_NO_OVERLAP, MASK_NEXT_RESET,
-                      TorchCpuCompatRNG, _stream)
+                      TorchCpuCompatRNG)
 
 FAMILY_LLAVA = "llava-1.5"
 FAMILY_NEXT = "llava-next"
@@ -115,10 +115,16 @@ class DropoutEngine:
         # the reference seeds torch's global generator at import (llava.py:16-20); under chair_test all three
         # modules are imported so 5217 is in force. Default here: the family's own module seed.
         self.rng = TorchCpuCompatRNG(fam["seed"] if seed is None else seed)
+        # the engine enqueues on its own (non-default) stream: decode steps can then be captured into hipGraphs, and
+        # torch work of the caller (next image's preprocessing) does not interleave with the dependent chain
+        self.torch_stream = torch.cuda.Stream(device=self.device)
         self.L = 0
         self.masked_numbers: List[int] = []
         self._peek_buf = np.zeros(8192, dtype=np.int32)
         self._n_enqueued = 0
+
+    def _s(self) -> int:
+        return self.torch_stream.cuda_stream
 
     # ---- weights ---------------------------------------------------------------------------
     def _load(self, tid: int, layer: int, t: torch.Tensor) -> None:
@@ -161,7 +167,9 @@ class DropoutEngine:
         e = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
         if e.shape[1] != self.cfg.hidden_size:
             raise ValueError(f"embeds have width {e.shape[1]}, model hidden size is {self.cfg.hidden_size}")
-        _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, _stream()),
+        self.torch_stream.wait_stream(torch.cuda.current_stream(self.device))   # embeds come from the caller's stream
+        e.record_stream(self.torch_stream)
+        _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, self._s()),
                    "dd_lm_prefill")
         self.L, self.T0 = span_len, e.shape[0]
         self._last_K = 0
@@ -180,8 +188,9 @@ class DropoutEngine:
         if uniforms is not None:
             un = uniforms.float().contiguous()
             self._keepalive = un
+            self.torch_stream.wait_stream(torch.cuda.current_stream(self.device))
         _lib.check(self.lib.dd_lm_decode_step(self._h, arr, K, self.rng.handle, un.data_ptr() if un is not None else None,
-                                              _stream()), "dd_lm_decode_step")
+                                              self._s()), "dd_lm_decode_step")
         self._last_K = K
         self._n_enqueued += 1
 
@@ -190,16 +199,18 @@ class DropoutEngine:
         probs, arr = self._probs(mprobs)
         un = uniforms.float().contiguous() if uniforms is not None else None
         self._keepalive = un
+        if un is not None:
+            self.torch_stream.wait_stream(torch.cuda.current_stream(self.device))
         _lib.check(self.lib.dd_lm_step_base(self._h, arr, len(probs), self.rng.handle,
-                                            un.data_ptr() if un is not None else None, _stream()), "dd_lm_step_base")
+                                            un.data_ptr() if un is not None else None, self._s()), "dd_lm_step_base")
         self._last_K = len(probs)
         return len(probs)
 
     def step_members(self, m_lo: int, m_hi: int) -> None:
-        _lib.check(self.lib.dd_lm_step_members(self._h, m_lo, m_hi, _stream()), "dd_lm_step_members")
+        _lib.check(self.lib.dd_lm_step_members(self._h, m_lo, m_hi, self._s()), "dd_lm_step_members")
 
     def step_commit(self) -> None:
-        _lib.check(self.lib.dd_lm_step_commit(self._h, self._last_K, _stream()), "dd_lm_step_commit")
+        _lib.check(self.lib.dd_lm_step_commit(self._h, self._last_K, self._s()), "dd_lm_step_commit")
         self._n_enqueued += 1
 
     # exchange records for K-sharding (dist.py); tensors are torch CUDA tensors owned by the caller
@@ -207,23 +218,23 @@ class DropoutEngine:
         return int(self.lib.dd_lm_xchg_stride(self._h))
 
     def export_ids(self, m_lo: int, m_hi: int, ids: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_export_ids(self._h, m_lo, m_hi, ids.data_ptr(), _stream()), "dd_lm_xchg_export_ids")
+        _lib.check(self.lib.dd_lm_xchg_export_ids(self._h, m_lo, m_hi, ids.data_ptr(), self._s()), "dd_lm_xchg_export_ids")
 
     def import_ids(self, ids: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_import_ids(self._h, ids.data_ptr(), _stream()), "dd_lm_xchg_import_ids")
+        _lib.check(self.lib.dd_lm_xchg_import_ids(self._h, ids.data_ptr(), self._s()), "dd_lm_xchg_import_ids")
 
     def export_winner(self, m_lo: int, m_hi: int, rec: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_export_winner(self._h, m_lo, m_hi, rec.data_ptr(), _stream()), "dd_lm_xchg_export_winner")
+        _lib.check(self.lib.dd_lm_xchg_export_winner(self._h, m_lo, m_hi, rec.data_ptr(), self._s()), "dd_lm_xchg_export_winner")
 
     def import_winner(self, rec: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_import_winner(self._h, rec.data_ptr(), _stream()), "dd_lm_xchg_import_winner")
+        _lib.check(self.lib.dd_lm_xchg_import_winner(self._h, rec.data_ptr(), self._s()), "dd_lm_xchg_import_winner")
 
     def new_xchg_buffers(self):
         return (torch.zeros(32, dtype=torch.int32, device=self.device),
                 torch.zeros(self.xchg_stride(), dtype=torch.float32, device=self.device))
 
     def set_next_token(self, token: int) -> None:
-        _lib.check(self.lib.dd_lm_set_next_token(self._h, int(token), _stream()), "dd_lm_set_next_token")
+        _lib.check(self.lib.dd_lm_set_next_token(self._h, int(token), self._s()), "dd_lm_set_next_token")
 
     def peek_tokens(self) -> List[int]:
         """Tokens emitted so far WITHOUT synchronising (pinned host mirror written by the step kernels)."""
@@ -256,11 +267,11 @@ class DropoutEngine:
     # ---- read-backs (synchronise) -------------------------------------------------------------
     def _get(self, what: int, n: int, dtype) -> np.ndarray:
         out = np.empty(n, dtype=dtype)
-        _lib.check(self.lib.dd_lm_get(self._h, what, out.ctypes.data, out.nbytes, _stream()), f"dd_lm_get({what})")
+        _lib.check(self.lib.dd_lm_get(self._h, what, out.ctypes.data, out.nbytes, self._s()), f"dd_lm_get({what})")
         return out
 
     def n_tokens(self) -> int:
-        torch.cuda.current_stream().synchronize()
+        self.torch_stream.synchronize()
         return self.T() - self.T0 + 1
 
     def T(self) -> int:
@@ -308,13 +319,13 @@ class DropoutEngine:
 
     def time_sweep(self, nb: int, iters: int) -> float:
         ms = C.c_float()
-        _lib.check(self.lib.dd_lm_time_sweep(self._h, nb, iters, C.byref(ms), _stream()), "dd_lm_time_sweep")
+        _lib.check(self.lib.dd_lm_time_sweep(self._h, nb, iters, C.byref(ms), self._s()), "dd_lm_time_sweep")
         return float(ms.value)
 
     def time_gemv(self, which: int, nb: int, iters: int):
         """(mean ms per launch, algorithmic bytes per launch) of one decode GEMV kind; 0 qkv, 1 o, 2 gate/up, 3 down."""
         ms, by = C.c_float(), C.c_double()
-        _lib.check(self.lib.dd_lm_time_gemv(self._h, which, nb, iters, C.byref(ms), C.byref(by), _stream()), "dd_lm_time_gemv")
+        _lib.check(self.lib.dd_lm_time_gemv(self._h, which, nb, iters, C.byref(ms), C.byref(by), self._s()), "dd_lm_time_gemv")
         return float(ms.value), float(by.value)
 
     def close(self) -> None:

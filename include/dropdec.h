@@ -326,7 +326,8 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
 
 /* Kernel tuning knobs for the benchmark scripts: key 0 = GEMV weight tiles in flight per wave (4/8/16),
  * 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves of a workgroup (0/1),
- * 3 = timing-only diagnostic build without x-operand loads (results are wrong; never use for output). */
+ * 3 = timing-only diagnostic build without x-operand loads (results are wrong; never use for output),
+ * 8 = replay decode steps from a hipGraph (default 1). */
 int dd_set_tuning(int key, int value);
 
 #ifdef __cplusplus

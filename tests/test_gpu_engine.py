@@ -313,6 +313,7 @@ def test_full_size_llava15_7b_properties(E):
     eng.rng.manual_seed(9)
     eng.prefill(emb, 5, 576)
     ids, rec = eng.new_xchg_buffers()
+    torch.cuda.synchronize()
     for _ in range(3):
         eng.step_base(probs)
         eng.step_members(0, 8)
@@ -419,3 +420,35 @@ def test_mid_scale_llava_shapes_vs_oracle(E):
         assert close(eng.logits(), r.logits), info
     assert eng.tokens() == want
     eng.close()
+
+
+def test_graph_replay_equals_eager_launches(E):
+    """Decode steps replayed from the hipGraph cache (the default) == the same steps launched kernel by kernel:
+    tokens, masks and logits bit for bit, across a 64-token attention-tile boundary (new graph) and a change of K."""
+    from dropoutdecoding_amd import _lib
+    L = _lib.load()
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    w = random_weights(rc, 17, 0.05)
+    emb = torch.randn(58, 256, generator=torch.Generator().manual_seed(3)).cuda()
+    outs = []
+    for graph in (0, 1):
+        L.dd_set_tuning(8, graph)
+        eng = E.DropoutEngine(E.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0), family=FAMILY_LLAVA, max_seq=160,
+                              max_visual=40, seed=11)
+        eng.load_state_dict(w)
+        eng.prefill(emb, 4, 40)
+        rec = []
+        for s in range(14):                                   # T: 58 -> 72 crosses the 64-key tile boundary
+            probs = [0.3, 0.5, 0.7] if s < 9 else [0.2, 0.4, 0.6, 0.8]
+            eng.decode_step(probs)
+            st = eng.last_step()
+            rec.append((st["drop"].copy(), st["member_argmax"].tolist(), st["winner"], eng.logits().copy()))
+        outs.append((eng.tokens(), rec, eng.kv_sums().copy()))
+        eng.close()
+    L.dd_set_tuning(8, 1)
+    assert outs[0][0] == outs[1][0]
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    for (d0, a0, w0, l0), (d1, a1, w1, l1) in zip(outs[0][1], outs[1][1]):
+        np.testing.assert_array_equal(d0, d1)
+        assert a0 == a1 and w0 == w1
+        np.testing.assert_array_equal(l0, l1)
