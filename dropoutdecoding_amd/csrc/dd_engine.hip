@@ -551,7 +551,7 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
 // -----------------------------------------------------------------------------------------------
 static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st) {
   const int d = h->d, dff = h->dff;
-  RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, st));
+  RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
@@ -561,7 +561,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     memset(&a, 0, sizeof(a));
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = nb, a.xop = h->xop_d;
     a.fp8 = h->fp8, a.wscale = w.s_qkv;
-    a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.knew = knew, a.vnew = vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = h->state;
     RC(ddk_gemv(EPI_QKV, a, st));
@@ -576,18 +576,18 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     memset(&a, 0, sizeof(a));
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_q;
     a.fp8 = h->fp8, a.wscale = w.s_o;
-    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b;
+    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     RC(ddk_gemv(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = nb, a.xop = h->xop_d;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
-    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.xop_next = h->xop_ff;
+    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.xop_next = h->xop_ff;
     RC(ddk_gemv(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_ff;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
-    a.xop_next = h->xop_d, a.ssq_out = h->ssq_a;
+    a.xop_next = h->xop_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
     RC(ddk_gemv(EPI_RESID, a, st));
     ssq_n = d / 16;
   }
@@ -595,7 +595,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
   memset(&a, 0, sizeof(a));
   a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = nb, a.xop = h->xop_d;
   a.fp8 = h->fp8, a.wscale = h->s_lm;
-  a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+  a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   a.out = logits_out, a.ldo = h->Vpad, a.n_valid = h->V;
   RC(ddk_gemv(EPI_STORE, a, st));
   return DD_OK;
@@ -930,21 +930,21 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
     a.nb = nb, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.state = h->state, a.fp8 = h->fp8;
     switch (which) {
       case 0:
-        a.W = w.wqkv, a.wscale = w.s_qkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.ssq_in = h->ssq_a, a.ssq_n = d / 16;
+        a.W = w.wqkv, a.wscale = w.s_qkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.ssq_in = h->ssq_a, a.ssq_n = d / 16, a.ssq_ld = d / 16;
         a.qbuf = h->qbuf, a.knew = h->knew, a.vnew = h->vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
         a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
         return ddk_gemv(EPI_QKV, a, st);
       case 1:
         a.W = w.wo, a.wscale = w.s_o, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.out = h->xa, a.ldo = d;
-        a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b;
+        a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
         return ddk_gemv(EPI_RESID, a, st);
       case 2:
-        a.W = w.wgu, a.wscale = w.s_gu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.ssq_in = h->ssq_b, a.ssq_n = d / 16;
+        a.W = w.wgu, a.wscale = w.s_gu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16;
         a.xop_next = h->xop_ff;
         return ddk_gemv(EPI_SILU, a, st);
       default:
         a.W = w.wdown, a.wscale = w.s_down, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.out = h->xa, a.ldo = d;
-        a.normw_next = w.norm1, a.xop_next = h->xop_d, a.ssq_out = h->ssq_a;
+        a.normw_next = w.norm1, a.xop_next = h->xop_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
         return ddk_gemv(EPI_RESID, a, st);
     }
   };
@@ -964,7 +964,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 3) || key == 8, "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4) || key == 8, "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
   else ddk_set_tuning(key, value);
   return DD_OK;

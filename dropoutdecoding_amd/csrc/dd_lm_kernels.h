@@ -62,8 +62,9 @@ struct GemvArgs {
   int n_tiles;          // number of 16-row tiles (EPI_SILU: number of gate/up PAIRS)
   int nb;               // live rows (1..8)
   const u32x4_t* xop;   // [S][64]
-  const float* ssq_in;  // [ssq_n][8] partial sums of squares of the un-normalised input, or nullptr
+  const float* ssq_in;  // [8][ssq_ld] partial sums of squares of the un-normalised input (ssq_n live per row), or nullptr
   int ssq_n;
+  int ssq_ld;           // row pitch of ssq_in / ssq_out (a multiple of 4: rows are read with 16-byte loads)
   float inv_k;          // 1 / K
   float eps;
   // epilogue
@@ -72,7 +73,7 @@ struct GemvArgs {
   int n_valid;          // EPI_STORE: columns >= n_valid are not written
   const float* normw_next;  // EPI_RESID: [N]
   u32x4_t* xop_next;    // EPI_RESID / EPI_SILU: packed operand for the next GEMV
-  float* ssq_out;       // EPI_RESID: [gridDim.x][8]
+  float* ssq_out;       // EPI_RESID: [8][ssq_ld], column blockIdx.x
   // EPI_QKV
   float* qbuf;          // [8][q_dim]
   float* knew;          // [8][kv_dim] rows of this pass, this layer
@@ -82,6 +83,7 @@ struct GemvArgs {
   const float* rope_cos; // [max_seq][64]
   const float* rope_sin;
   const DDState* state;
+  int diag;             // timing diagnostics only (dd_set_tuning key 3): 2 = no rstd prologue, 4 = no epilogue, 8 = no epilogue prefetch
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
 void ddk_set_tuning(int key, int value);
@@ -142,7 +144,7 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
 // ---- small glue -------------------------------------------------------------------------------
 // x[0..8)[d] <- embed[cur_tok] (all rows equal), xop <- split(normw * x), ssq slot 0
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
-                   float* ssq, hipStream_t st);
+                   float* ssq, int ssq_ld, hipStream_t st);
 int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st);
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
                   float* vc, size_t layer_stride_k, size_t layer_stride_v, int T_cap, const DDState* state,

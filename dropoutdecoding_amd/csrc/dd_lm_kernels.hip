@@ -214,7 +214,7 @@ __device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y) {
 // NT  = non-temporal weight loads (read-once stream, keeps L2/MALL for the x operand and the KV cache)
 // ILV = k-steps interleaved over the 8 waves (wave w takes steps w, w+8, ...: at any instant the workgroup reads
 //       8 consecutive KiB) instead of one contiguous chunk per wave
-template <int EPI, int TILES, int U, int NT, int ILV, int FP8 = 0>
+template <int EPI, int TILES, int U, int NT, int ILV, int FP8 = 0, int PIPE = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   __shared__ float red[TILES * GEMV_WAVES * 256];
   __shared__ float rstd_sh[8];
@@ -238,17 +238,18 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
 
   // Everything the epilogue needs from memory is requested BEFORE the weight stream so its latency hides behind it:
   // the folded RMSNorm's rstd (wave w assembles row w's sum of squares from the producer's slots), the residual
-  // input + next norm weight (EPI_RESID) and the rotary cos/sin (EPI_QKV).
-  if (a.ssq_in) {
-    float v = 0.f;
-    for (int i = lane; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)i * 8 + wave];
-    v = dd_wave_sum(v);
-    if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
-  }
+  // input + next norm weight (EPI_RESID) and the rotary cos/sin (EPI_QKV).  The sum-of-squares slots are only
+  // REQUESTED here; they are reduced after the first weight batch has been issued (loads return in order, so waiting
+  // on them does not wait on the weights behind them).
+  const bool has_ssq = a.ssq_in && !(a.diag & 2);
+  f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
+  // row `wave`'s slots are contiguous: one 16-byte load per lane covers 256 slots (every workgroup of the launch reads
+  // these same few lines, so the request count matters: strided 4-byte reads here cost ~2 us per launch)
+  if (has_ssq && 4 * lane < a.ssq_n) sv = *(const f32x4_t*)(a.ssq_in + (size_t)wave * a.ssq_ld + 4 * lane);
   float pre0 = 0.f, pre1 = 0.f;
   {
     const int em = threadIdx.x & 7, en = threadIdx.x >> 3;
-    if (threadIdx.x < 128 && em < a.nb) {
+    if (threadIdx.x < 128 && em < a.nb && !(a.diag & 8)) {
       if (EPI == EPI_RESID) {
         pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
         pre1 = a.normw_next[tile0 * 16 + en];
@@ -302,50 +303,119 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       }
     }
   }
-  int s = FP8 ? spw : 0;
-  for (; s + U <= spw; s += U) {
-    u32x4_t b[U], w[TILES][U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
-      b[u] = DIAG ? w[0][u] : xp[(size_t)(s + u) * SS * 64];
+  auto finish_rstd = [&]() {
+    if (has_ssq) {
+      const int i0 = 4 * lane;
+      float v = 0.f;
+      if (i0 < a.ssq_n) v += sv.x;
+      if (i0 + 1 < a.ssq_n) v += sv.y;
+      if (i0 + 2 < a.ssq_n) v += sv.z;
+      if (i0 + 3 < a.ssq_n) v += sv.w;
+      for (int i = lane + 256; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)wave * a.ssq_ld + i];
+      v = dd_wave_sum(v);
+      if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
     }
+  };
+  finish_rstd();
+  if constexpr (!FP8 && PIPE == 0) {
+    // batches: U steps requested together, then consumed; the other resident waves cover the drain
+    int s = 0;
+    for (; s + U <= spw; s += U) {
+      u32x4_t b[U], w[TILES][U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int t = 0; t < TILES; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                         __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
-  }
-  if (s < spw) {  // tail: the remaining (< U) steps requested together as well (K = 11008: 43 steps per wave)
-    const int rem = spw - s;
-    u32x4_t b[U], w[TILES][U];
-#pragma unroll
-    for (int u = 0; u < U - 1; ++u) {
-      if (u < rem) {
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
-        b[u] = xp[(size_t)(s + u) * SS * 64];
+        b[u] = DIAG ? w[0][u] : xp[(size_t)(s + u) * SS * 64];
       }
-    }
 #pragma unroll
-    for (int u = 0; u < U - 1; ++u) {
-      if (u < rem) {
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
                                                            __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+    }
+    if (s < spw) {  // tail: the remaining (< U) steps requested together as well (K = 11008: 43 steps per wave)
+      const int rem = spw - s;
+      u32x4_t b[U], w[TILES][U];
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        if (u < rem) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
+          b[u] = xp[(size_t)(s + u) * SS * 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        if (u < rem) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                             __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+        }
       }
     }
   }
+  if constexpr (!FP8 && PIPE == 1) {
+    // Ring of U requests per wave: slot u is consumed by its MFMA and immediately re-requested U steps ahead, so the
+    // wave always has ~U weight tiles in flight (no drain between batches).
+    const int n = spw;
+    u32x4_t b[U], w[TILES][U];
+    auto req = [&](int u, int step) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)step * SS * 64);
+      b[u] = xp[(size_t)step * SS * 64];
+    };
+    auto use = [&](int u) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                         __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < n) req(u, u);
+    int s = 0;
+    for (; s + 2 * U <= n; s += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        use(u);
+        req(u, s + U + u);
+        __builtin_amdgcn_sched_barrier(0);   // keep consume -> re-request order (otherwise the scheduler sinks all
+      }                                      // requests below the last MFMA, which is the batch order again)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u < n) use(u);
+      if (s + U + u < n) req(u, s + U + u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s + U + u < n) use(u);
+  }
 
+  if (a.diag & 4) {
+    if (acc[0].x == 1234.5f) a.out[0] = 0.f;
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
   __syncthreads();
 
   // D[n][c]: lane = (n>>2)*16 + c, reg = n&3.  y[m][n] = sum_w (D_w[n][m] + D_w[n][m+8])   (hi + lo columns)
   const int t = threadIdx.x;
+  if (a.diag & 32) {   // timing only: LDS reduce + arithmetic, no global stores
+    float y = 0.f;
+    if (t < 128) {
+      const float* r = &red[0];
+      int o = (((t >> 3) >> 2) * 16 + (t & 7)) * 4 + ((t >> 3) & 3);
+#pragma unroll
+      for (int w = 0; w < TILES * GEMV_WAVES; ++w) y += r[w * 256 + o] + r[w * 256 + o + 32];
+    }
+    if (y == 1234.5f) a.out[0] = y;
+    return;
+  }
   auto tile_sum = [&](int tt, int n, int m) -> float {
     float y = 0.f;
     int o = ((n >> 2) * 16 + m) * 4 + (n & 3);
@@ -384,7 +454,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     if (t < 8) {
       float v = 0.f;
       for (int i = 0; i < 16; ++i) v += ssq_sh[i * 8 + t];
-      a.ssq_out[(size_t)blockIdx.x * 8 + t] = v;
+      a.ssq_out[(size_t)t * a.ssq_ld + blockIdx.x] = v;
     }
   } else if (EPI == EPI_SILU) {
     if (t < 128) {
@@ -427,24 +497,25 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   }
 }
 
-// tuning knobs (dd_set_tuning): 0 = U (4/8/16), 1 = NT, 2 = ILV
-static int g_gemv_u = 8, g_gemv_nt = 1, g_gemv_ilv = 1, g_gemv_diag = 0;
+// tuning knobs (dd_set_tuning): 0 = U (4/8/16), 3 = timing diagnostics, 4 = ring (1) or batch (0) request order.
+// Keys 1 (non-temporal loads) and 2 (k-step interleave) are settled at 1 and kept only as accepted no-ops.
+static int g_gemv_u = 8, g_gemv_diag = 0, g_gemv_pipe = 0;
 void ddk_set_tuning(int key, int value) {
   if (key == 0) g_gemv_u = value;
-  else if (key == 1) g_gemv_nt = value;
-  else if (key == 2) g_gemv_ilv = value;
   else if (key == 3) g_gemv_diag = value;
+  else if (key == 4) g_gemv_pipe = value;
 }
 
 template <int EPI, int TILES>
-static void launch_gemv(const GemvArgs& a, hipStream_t st) {
-#define GV(U_, NT_, ILV_) k_gemv<EPI, TILES, U_, NT_, ILV_><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a)
+static void launch_gemv(const GemvArgs& a_, hipStream_t st) {
+  GemvArgs a = a_;
+  a.diag = g_gemv_diag & ~1;
+#define GV(U_, P_) k_gemv<EPI, TILES, U_, 1, 1, 0, P_><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a)
   if (a.fp8) { k_gemv<EPI, TILES, 8, 1, 1, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }
-  const int u = g_gemv_u, nt = g_gemv_nt, il = g_gemv_ilv;
-  if (g_gemv_diag) { k_gemv<EPI, TILES, 8, 1, 3><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }  // diagnostic: no x-operand loads
-  if (u == 4) { if (nt) { if (il) GV(4, 1, 1); else GV(4, 1, 0); } else { if (il) GV(4, 0, 1); else GV(4, 0, 0); } }
-  else if (u == 16) { if (nt) { if (il) GV(16, 1, 1); else GV(16, 1, 0); } else { if (il) GV(16, 0, 1); else GV(16, 0, 0); } }
-  else { if (nt) { if (il) GV(8, 1, 1); else GV(8, 1, 0); } else { if (il) GV(8, 0, 1); else GV(8, 0, 0); } }
+  if (g_gemv_diag & 1) { k_gemv<EPI, TILES, 8, 1, 3><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }  // diagnostic: no x-operand loads
+  const int u = g_gemv_u;
+  if (g_gemv_pipe) { if (u == 4) GV(4, 1); else if (u == 16) GV(16, 1); else GV(8, 1); }
+  else { if (u == 4) GV(4, 0); else if (u == 16) GV(16, 0); else GV(8, 0); }
 #undef GV
 }
 
@@ -987,7 +1058,7 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
 // ===============================================================================================
 __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict__ embed, int d, const DDState* state,
                                                      float* __restrict__ x, const float* __restrict__ normw,
-                                                     u32x4_t* __restrict__ xop, float* __restrict__ ssq) {
+                                                     u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld) {
   __shared__ float sh[16];
   int tok = state->cur_tok;
   float ss = 0.f;
@@ -1007,12 +1078,12 @@ __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict_
   if (threadIdx.x < 8) {
     float v = 0.f;
     for (int i = 0; i < 16; ++i) v += sh[i];
-    ssq[threadIdx.x] = v;
+    ssq[(size_t)threadIdx.x * ssq_ld] = v;
   }
 }
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
-                   float* ssq, hipStream_t st) {
-  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq);
+                   float* ssq, int ssq_ld, hipStream_t st) {
+  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

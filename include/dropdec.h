@@ -330,6 +330,13 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * 8 = replay decode steps from a hipGraph (default 1). */
 int dd_set_tuning(int key, int value);
 
+/* Measurement hook: stream `n_layers` x `n_phases` weight slabs the way one decode sweep does, either as one launch per
+ * phase (mode 0, `grid` workgroups of 512 threads), or as ONE resident kernel with a grid barrier per phase (mode 1), or
+ * the same with the next phase's first loads issued before the barrier (mode 2).  ms_out = mean time of one sweep.
+ * Nothing in the reference corresponds to it; tools/persist_probe.py uses it to size the persistent-sweep design. */
+int dd_persist_read_bench(const void* buf_dev, size_t layer_stride_bytes, const size_t* phase_bytes, int n_phases,
+                          int n_layers, int mode, int grid, int U, int iters, float* ms_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

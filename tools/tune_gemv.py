@@ -11,9 +11,9 @@ emb = torch.randn(672, 4096, device="cuda")
 eng.prefill(emb, 5, 576)
 L = _lib.load()
 rows = []
-for u, nt, il, dg in [(8, 1, 1, 0), (8, 1, 1, 1), (8, 1, 1, 0), (8, 1, 1, 1)]:
-    L.dd_set_tuning(0, u); L.dd_set_tuning(1, nt); L.dd_set_tuning(2, il); L.dd_set_tuning(3, dg)
-    r = {"U": u, "NT": nt, "ILV": il, "DIAG_nox": dg}
+for u, nt, il, dg in [(8, 0, 1, 0), (8, 0, 1, 64), (8, 0, 1, 32), (8, 0, 1, 0), (8, 0, 1, 64), (8, 0, 1, 32)]:
+    L.dd_set_tuning(0, u); L.dd_set_tuning(4, nt); L.dd_set_tuning(3, dg)
+    r = {"U": u, "RING": nt, "DIAG": dg}
     for which, name in ((0, "qkv"), (1, "o"), (2, "gateup"), (3, "down")):
         best = 0
         for _ in range(3):
@@ -21,6 +21,5 @@ for u, nt, il, dg in [(8, 1, 1, 0), (8, 1, 1, 1), (8, 1, 1, 0), (8, 1, 1, 1)]:
             best = max(best, by / ms / 1e6)
         r[name] = round(best)
     r["sweep8_ms"] = round(min(eng.time_sweep(8, 5) for _ in range(3)), 3)
-    r["sweep1_ms"] = round(min(eng.time_sweep(1, 5) for _ in range(3)), 3)
     rows.append(r)
     print(json.dumps(r), flush=True)
