@@ -7,6 +7,11 @@ settings = {}
 settings['voting_numbers'] = [0.3, 0.5, 0.7]
 settings['use_avg'] = False          # read by nobody in the reference either (models/llava.py:37-52 is never called)
 settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap" (models/llavanext.py:547-550)
+# Switches for code paths the reference carries but never enables.  Absent keys mean "off", so
+# a harness that replaces this dict with the reference's three keys keeps working.
+#   settings['first_step_ensemble'] = True   -> the `# if True:` toggle at models/llava.py:336-337 (read per generate())
+#   settings['mask_method'] = 'epis_no_overlap' -> models/llava.py:663-683 / instructblip.py:486-505 (read at model build)
+#   settings['use_avg'] = True               -> select_by_average, models/llava.py:37-52 (read at model build)
 
 # K = 8 is not reachable from the reference CLI (chair_test.py:163-175); BASELINE configs 3-5 use this list.
 VOTING_NUMBERS_K8 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
   }
 
   for (int k = 0; k < P.K; ++k) {
-    if (P.mode != DD_MASK_LLAVA_CUMULATIVE) {  // reset: llavanext.py:546, instructblip.py:121
+    if (P.mode != DD_MASK_LLAVA_CUMULATIVE && P.mode != DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) {  // reset: llavanext.py:546, instructblip.py:121
       for (int l = tid; l < L; l += MASK_THREADS) running[l] = 0;
     }
     float thr = 0.f;
@@ -532,6 +532,7 @@ __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
     __syncthreads();
     const float scale = P.scale[k];
     const float range = __fsub_rn(hi, lo);
+    const bool no_overlap = P.mode == DD_MASK_NEXT_NO_OVERLAP || P.mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP;
     int total = 0, cnt = 0;
     for (int base = 0; base < L; base += MASK_THREADS) {
       int l = base + tid;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
           d = r < p;  // llava.py:653 (NaN p when hi == lo: nothing dropped)
         }
         uint8_t run = running[l] | (d ? 1 : 0);                      // llava.py:654-657, in place
-        if (P.mode != DD_MASK_NEXT_NO_OVERLAP && P.keep[l]) run = 0;  // llava.py:660 keep-restore
+        if (!no_overlap && P.keep[l]) run = 0;  // llava.py:660 keep-restore
         running[l] = run;
         P.drop[(size_t)k * L + l] = run;
         dropped = run != 0;
@@ -582,8 +583,9 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
   DD_REQUIRE(epi && mprobs && drop && n_drop, "dd_sample_masks: null pointer");
   DD_REQUIRE(L >= 1 && L <= MASK_MAX_L, "dd_sample_masks: L=%d out of range (1..%d)", L, MASK_MAX_L);
   DD_REQUIRE(K >= 1 && K <= 64, "dd_sample_masks: K=%d out of range (1..64)", K);
-  DD_REQUIRE(mode >= 0 && mode <= 3, "dd_sample_masks: unknown mode %d", mode);
-  DD_REQUIRE(mode == DD_MASK_NEXT_NO_OVERLAP || keep, "dd_sample_masks: keep flags required for mode %d", mode);
+  DD_REQUIRE(mode >= 0 && mode <= 4, "dd_sample_masks: unknown mode %d", mode);
+  DD_REQUIRE(mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP || keep,
+             "dd_sample_masks: keep flags required for mode %d", mode);
   if (mode != DD_MASK_IBLIP_QUANTILE) {
     DD_REQUIRE(rng_mode == DD_RNG_INJECTED || rng_mode == DD_RNG_MT19937, "dd_sample_masks: unknown rng mode %d", rng_mode);
     DD_REQUIRE(rng_mode != DD_RNG_INJECTED || uniforms, "dd_sample_masks: injected rng needs uniforms");

@@ -132,7 +132,8 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   DD_REQUIRE((c->num_heads * 128) % 256 == 0, "dd_lm_create: num_heads*128 must be a multiple of 256");
   DD_REQUIRE(c->max_seq >= 2 && c->max_visual >= 1 && c->max_visual <= 8192, "dd_lm_create: bad max_seq/max_visual");
   DD_REQUIRE(c->k_top >= 1 && c->k_top <= DD_MAX_TOPK, "dd_lm_create: k_top out of range");
-  DD_REQUIRE(c->mask_mode >= 0 && c->mask_mode <= 3, "dd_lm_create: mask_mode");
+  DD_REQUIRE(c->mask_mode >= 0 && c->mask_mode <= 4, "dd_lm_create: mask_mode");
+  DD_REQUIRE(c->vote_on >= 0 && c->vote_on <= 2, "dd_lm_create: vote_on");
   dd_lm* h = new dd_lm();
   h->cfg = *c;
   h->d = c->hidden_size, h->dff = c->intermediate_size, h->V = c->vocab_size, h->Vpad = (c->vocab_size + 15) / 16 * 16;
@@ -187,7 +188,7 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   int max_splits = T / 64;
   DA(h->part_o, (size_t)h->Hkv * max_splits * 8 * G * 128);
   DA(h->part_ml, (size_t)h->Hkv * max_splits * 8 * G * 2);
-  DA(h->hidden, 8 * (size_t)d);
+  DA(h->hidden, (size_t)MAX_MEMBERS * d);
   DA(h->xop_d, (size_t)h->S_d * 64);
   DA(h->xop_q, (size_t)h->S_q * 64);
   DA(h->xop_ff, (size_t)h->S_ff * 64);
@@ -465,19 +466,39 @@ __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int
 __global__ void k_set_token(DDState* st, int tok) {
   if (threadIdx.x == 0) st->cur_tok = tok;
 }
+__global__ void k_set_winner(DDState* st, int winner, const int32_t* tok) {
+  if (threadIdx.x == 0) {
+    st->winner = winner;
+    st->voted = tok[winner];
+  }
+}
+// first-token ensemble: the winner's logits / hidden row become the sequence's, its argmax replaces the greedy token
+__global__ __launch_bounds__(1024) void k_first_token_from_member(DDState* st, const int32_t* member_tok,
+                                                                  const float* member_logits, int Vpad,
+                                                                  float* last_logits, int32_t* tokens,
+                                                                  const float* hidden_rows, int d, float* last_hidden,
+                                                                  volatile int32_t* mirror) {
+  const int win = st->winner;
+  for (int i = threadIdx.x; i < Vpad; i += 1024) last_logits[i] = member_logits[(size_t)win * Vpad + i];
+  for (int i = threadIdx.x; i < d; i += 1024) last_hidden[i] = hidden_rows[(size_t)win * d + i];
+  if (threadIdx.x == 0) {
+    int tok = member_tok[win];
+    tokens[0] = tok;
+    st->cur_tok = tok;
+    mirror[1] = tok;
+    __threadfence_system();
+    mirror[0] = 1;
+  }
+}
 
 // -----------------------------------------------------------------------------------------------
 // prefill
 // -----------------------------------------------------------------------------------------------
-extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_start, int span_len, void* stream_) {
-  hipStream_t st = (hipStream_t)stream_;
-  DD_REQUIRE(h && embeds, "dd_lm_prefill: null argument");
-  DD_REQUIRE(T0 >= 1 && T0 < h->T_cap, "dd_lm_prefill: T0=%d out of range (KV capacity %d)", T0, h->T_cap);
-  // reference llava.py:134-138 raises ValueError on an image-token / feature count mismatch; same contract here
-  DD_REQUIRE(span_len >= 1 && span_len <= h->Lmax && span_start >= 0 && span_start + span_len <= T0,
-             "dd_lm_prefill: visual span [%d, %d) does not fit the %d input positions (max_visual %d)", span_start,
-             span_start + span_len, T0, h->Lmax);
-  const int d = h->d, dff = h->dff, L = span_len;
+// all layers over the T0 prompt rows in h->px (overwritten in place), K/V written into the cache.  drop_plane/drop_bit:
+// the member's zero columns of the 2-D attention mask (first-token ensemble), or nullptr for the un-masked pass.
+static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_bit, int span_start, int span_len,
+                          hipStream_t st) {
+  const int d = h->d, dff = h->dff;
   // fp8 storage: the prefill GEMM runs on a bf16 expansion of ONE matrix at a time (exact), scales in its epilogue
   auto wsel = [&](GemmArgs& g, u32x4_t* W, float* scale, int n_tiles, int S) -> int {
     if (!h->fp8) {
@@ -488,7 +509,6 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
     g.W = h->deq_tmp, g.wscale = scale;
     return rc;
   };
-  DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)T0 * d * 4, hipMemcpyDeviceToDevice, st));
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
     RC(ddk_rmsnorm_split(h->px, T0, d, w.norm1, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st));
@@ -500,7 +520,8 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
     g.q_tiles = h->q_tiles, g.k_tiles = h->k_tiles, g.q_dim = h->q_dim, g.kv_dim = h->kv_dim, g.pos0 = 0;
     g.rope_cos = h->rope_cos, g.rope_sin = h->rope_sin;
     RC(ddk_gemm(EPI_QKV, g, st));
-    RC(ddk_attn_prefill(h->pq, g.kc, g.vc, T0, h->T_cap, h->H, h->Hkv, h->p1_hi, h->p1_lo, st));
+    RC(ddk_attn_prefill(h->pq, g.kc, g.vc, T0, h->T_cap, h->H, h->Hkv, h->p1_hi, h->p1_lo, drop_plane, drop_bit,
+                        span_start, span_len, st));
     memset(&g, 0, sizeof(g));
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_q, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
     RC(wsel(g, w.wo, w.s_o, d / 16, h->S_q));
@@ -516,6 +537,38 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
     RC(wsel(g, w.wdown, w.s_down, d / 16, h->S_ff));
     RC(ddk_gemm(EPI_RESID, g, st));
   }
+  return DD_OK;
+}
+
+// final norm + lm_head over `n_rows` rows of h->px selected by row_index (device) -> logits [n_rows][Vpad];
+// the normed rows stay in h->pq
+static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* logits, hipStream_t st) {
+  const int d = h->d;
+  RC(ddk_rmsnorm_split(h->px, n_rows, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, row_index, h->pq, st));
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = n_rows, g.S = h->S_d, g.n_tiles = h->Vpad / 16;
+  if (!h->fp8) {
+    g.W = h->lm_head;
+  } else {
+    RC(ddk_dequant_tiles(h->lm_head, h->deq_tmp, h->Vpad / 16, h->S_d, st));
+    g.W = h->deq_tmp, g.wscale = h->s_lm;
+  }
+  g.out = logits, g.ldo = h->Vpad, g.n_valid = h->V;
+  return ddk_gemm(EPI_STORE, g, st);
+}
+
+extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_start, int span_len, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && embeds, "dd_lm_prefill: null argument");
+  DD_REQUIRE(T0 >= 1 && T0 < h->T_cap, "dd_lm_prefill: T0=%d out of range (KV capacity %d)", T0, h->T_cap);
+  // reference llava.py:134-138 raises ValueError on an image-token / feature count mismatch; same contract here
+  DD_REQUIRE(span_len >= 1 && span_len <= h->Lmax && span_start >= 0 && span_start + span_len <= T0,
+             "dd_lm_prefill: visual span [%d, %d) does not fit the %d input positions (max_visual %d)", span_start,
+             span_start + span_len, T0, h->Lmax);
+  const int d = h->d, L = span_len;
+  DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)T0 * d * 4, hipMemcpyDeviceToDevice, st));
+  RC(prefill_layers(h, T0, nullptr, 0, span_start, span_len, st));
   // lm_head over the visual span + the last position only (the reference projects all T0 positions,
   // llava.py:294-305, but consumes just these: llava.py:311-314 and HF's greedy argmax)
   std::vector<int32_t> rows(L + 1);
@@ -523,14 +576,8 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   rows[L] = T0 - 1;
   DD_HIP(hipMemcpyAsync(h->row_index, rows.data(), (L + 1) * 4, hipMemcpyHostToDevice, st));
   DD_HIP(hipStreamSynchronize(st));  // rows is a host temporary
-  RC(ddk_rmsnorm_split(h->px, L + 1, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, h->row_index, h->pq, st));
+  RC(prefill_head(h, h->row_index, L + 1, h->image_logits, st));
   DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq + (size_t)L * d, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = L + 1, g.S = h->S_d, g.n_tiles = h->Vpad / 16;
-  RC(wsel(g, h->lm_head, h->s_lm, h->Vpad / 16, h->S_d));
-  g.out = h->image_logits, g.ldo = h->Vpad, g.n_valid = h->V;
-  RC(ddk_gemm(EPI_STORE, g, st));
   RC(dd_vision_uncertainty(h->image_logits, L, h->V, h->Vpad, h->var, h->epi, h->alea, h->scalars, h->cfg.k_top,
                            h->topk_vals, h->topk_ids, h->unc_ws, h->unc_ws_bytes, st));
   DD_HIP(hipMemcpyAsync(h->last_logits, h->image_logits + (size_t)L * h->Vpad, (size_t)h->Vpad * 4,
@@ -543,6 +590,65 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   h->T_host = T0, h->span_start = span_start, h->L = L, h->n_tok_host = 1, h->prefilled = true, h->have_leak = false;
   h->last_K = 0;
   h->steps_since_prefill = 0;
+  return DD_OK;
+}
+
+// the ensemble's vote (or mean) over the K member rows: sets state->winner / voted, member_tok[0] for the mean
+static int vote_members(dd_lm* h, int K, hipStream_t st) {
+  if (h->cfg.vote_on == DD_VOTE_AVERAGE) {
+    // select_by_average (llava.py:37-52): member 0's output with its last-token logits replaced by the fp32 mean
+    RC(ddk_mean_rows(h->member_logits, K, h->Vpad, h->V, st));
+    RC(dd_argmax_rows(h->member_logits, 1, h->V, h->Vpad, h->member_tok, st));
+    k_set_winner<<<1, 64, 0, st>>>(h->state, 0, h->member_tok);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
+  const int32_t* ids = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
+  return dd_vote(ids, K, &h->state->winner, st);
+}
+
+// Prefill with the ensemble also applied to the FIRST generated token — the reference's `# if True:` toggle at
+// models/llava.py:336-337 (the committed POPE numbers, max_new_tokens=1, were most likely produced
+// this way).  After the un-masked pass (uncertainty, top-k ids, keep set from its argmax) every member re-runs the
+// WHOLE prompt from an empty cache with its zero columns in the attention mask (llava.py:342-359 on the first forward:
+// `original_past_key_values` is the empty cache there); the vote picks the member whose logits and KV cache continue.
+// Members run last-to-first so the usual winner (member 0) is the one left in the cache; any other winner is re-run.
+extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int span_start, int span_len,
+                                      const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  RC(dd_lm_prefill(h, embeds, T0, span_start, span_len, stream_));
+  if (K == 0) return DD_OK;
+  DD_REQUIRE(K >= 1 && K <= MAX_MEMBERS && mprobs, "dd_lm_prefill_ensemble: K=%d out of range (1..%d)", K, MAX_MEMBERS);
+  DD_REQUIRE(span_start >= 1, "dd_lm_prefill_ensemble: the visual span must not start at position 0 (a fully masked "
+                              "first row has no defined attention; the reference toggle exists for LLaVA only)");
+  const int d = h->d, L = span_len;
+  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, L, h->cfg.k_top, h->keep, st));
+  int rng_mode = uniforms ? DD_RNG_INJECTED : DD_RNG_MT19937;
+  DD_REQUIRE(h->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || uniforms || rng, "dd_lm_prefill_ensemble: an rng or uniforms is required");
+  RC(dd_sample_masks_impl(h->epi, L, mprobs, K, h->keep, h->cfg.mask_mode, rng_mode, uniforms, dd_rng_state_ptr(rng),
+                          h->drop, h->n_drop, nullptr, h->drop_bits, st));
+  const int32_t* last_row = h->row_index + L;     // == T0 - 1 (set by dd_lm_prefill)
+  auto member_pass = [&](int k, bool head) -> int {
+    DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)T0 * d * 4, hipMemcpyDeviceToDevice, st));
+    RC(prefill_layers(h, T0, h->drop_bits + (size_t)(k >> 3) * L, k & 7, span_start, span_len, st));
+    if (!head) return DD_OK;
+    RC(prefill_head(h, last_row, 1, h->member_logits + (size_t)k * h->Vpad, st));
+    DD_HIP(hipMemcpyAsync(h->hidden + (size_t)k * d, h->pq, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
+    RC(dd_argmax_rows(h->member_logits + (size_t)k * h->Vpad, 1, h->V, h->Vpad, h->member_tok + k, st));
+    if (h->cfg.vote_on == DD_VOTE_HIDDEN) RC(dd_argmax_rows(h->hidden + (size_t)k * d, 1, d, d, h->member_vote + k, st));
+    return DD_OK;
+  };
+  for (int k = K - 1; k >= 0; --k) RC(member_pass(k, true));
+  RC(vote_members(h, K, st));
+  int32_t win[2] = {0, 0};
+  DD_HIP(hipMemcpyAsync(win, &h->state->winner, 8, hipMemcpyDeviceToHost, st));
+  DD_HIP(hipStreamSynchronize(st));
+  DD_REQUIRE(win[0] >= 0 && win[0] < K, "dd_lm_prefill_ensemble: vote returned member %d of %d", win[0], K);
+  if (win[0] != 0) RC(member_pass(win[0], false));   // leave the winner's K/V in the cache (llava.py:373)
+  k_first_token_from_member<<<1, 1024, 0, st>>>(h->state, h->member_tok, h->member_logits, h->Vpad, h->last_logits,
+                                                h->tokens, h->hidden, d, h->last_hidden, h->tok_host_dev);
+  DD_CHECK_LAUNCH();
+  h->last_K = K;
   return DD_OK;
 }
 
@@ -651,8 +757,9 @@ extern "C" int dd_lm_step_members(dd_lm* h, int m_lo, int m_hi, void* stream_) {
     RC(lm_sweep(h, nb, bits, g0, h->member_logits + (size_t)g0 * h->Vpad, st));
     RC(dd_argmax_rows(h->member_logits + (size_t)g0 * h->Vpad, nb, h->V, h->Vpad, h->member_tok + g0, st));
     if (h->cfg.vote_on == DD_VOTE_HIDDEN) {
-      RC(ddk_final_norm_rows(h->xa, nb, h->d, h->final_norm, h->cfg.rms_eps, h->hidden, st));
-      RC(dd_argmax_rows(h->hidden, nb, h->d, h->d, h->member_vote + g0, st));
+      float* hid = h->hidden + (size_t)g0 * h->d;
+      RC(ddk_final_norm_rows(h->xa, nb, h->d, h->final_norm, h->cfg.rms_eps, hid, st));
+      RC(dd_argmax_rows(hid, nb, h->d, h->d, h->member_vote + g0, st));
     }
     g0 = g1;
   }
@@ -662,10 +769,7 @@ extern "C" int dd_lm_step_members(dd_lm* h, int m_lo, int m_hi, void* stream_) {
 extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && h->prefilled && K == h->last_K, "dd_lm_step_commit: bad state (K=%d, expected %d)", K, h ? h->last_K : -1);
-  if (K > 0) {
-    const int32_t* ids = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
-    RC(dd_vote(ids, K, &h->state->winner, st));
-  }
+  if (K > 0) RC(vote_members(h, K, st));
   RC(ddk_commit_kv(h->knew, h->vnew, h->Lyr, MAX_MEMBERS, h->kv_dim, h->kc, h->vc, h->lsk, h->lsv, h->T_cap, h->state,
                    K > 0 ? 1 : 0, st));
   k_step_end<<<1, 1024, 0, st>>>(h->state, K, h->argmax_base, h->member_tok, h->base_logits, h->member_logits, h->Vpad,
@@ -806,6 +910,7 @@ __global__ __launch_bounds__(256) void k_xchg_winner(const DDState* st, int lo, 
 
 extern "C" int dd_lm_xchg_export_ids(dd_lm* h, int m_lo, int m_hi, int32_t* ids, void* stream_) {
   DD_REQUIRE(h && ids && h->last_K >= 1, "dd_lm_xchg_export_ids: bad state");
+  DD_REQUIRE(h->cfg.vote_on != DD_VOTE_AVERAGE, "dd_lm_xchg_*: the mean over members needs every member's logits on one rank");
   const int32_t* vote = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
   k_xchg_export_ids<<<1, 64, 0, (hipStream_t)stream_>>>(h->member_tok, vote, m_lo, m_hi, h->last_K, ids);
   DD_CHECK_LAUNCH();

@@ -139,7 +139,9 @@ struct GemmArgs {
 int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st);
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
-                     uint16_t* o_hi, uint16_t* o_lo, hipStream_t st);
+                     uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
+                     int span_len, hipStream_t st);
+int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st);
 
 // ---- small glue -------------------------------------------------------------------------------
 // x[0..8)[d] <- embed[cur_tok] (all rows equal), xop <- split(normw * x), ssq slot 0

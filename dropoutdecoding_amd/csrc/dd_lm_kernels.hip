@@ -954,7 +954,9 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
 template <int G>
 __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ qbuf, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int T, int T_cap, int n_heads,
-                                                      uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo) {
+                                                      uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
+                                                      const uint8_t* __restrict__ drop_plane, int drop_bit,
+                                                      int span_start, int span_len) {
   __shared__ __align__(16) float q_sh[4][PF_QR][HEAD_DIM];
   __shared__ __align__(16) float p_sh[4][ATT_SPLIT][PF_QR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -981,6 +983,10 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
   for (int t0 = 0; t0 <= t_last; t0 += ATT_SPLIT) {
     int kt = t0 + lane;
     const float* kb = kc + ((size_t)kvh * 32 * T_cap + min(kt, t_last)) * 4;
+    // a zero column of the member's 2-D attention mask (first-token ensemble: llava.py:336-359 run on the prompt)
+    bool key_dropped = false;
+    if (drop_plane && kt >= span_start && kt < span_start + span_len)
+      key_dropped = (drop_plane[kt - span_start] >> drop_bit) & 1;
     float s[PF_QR];
 #pragma unroll
     for (int r = 0; r < PF_QR; ++r) s[r] = 0.f;
@@ -995,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < PF_QR; ++r) {
-      bool valid = kt <= min(t_first + r, T - 1);                 // causal: row t attends keys 0..t
+      bool valid = kt <= min(t_first + r, T - 1) && !key_dropped;  // causal: row t attends keys 0..t
       float sv = valid ? s[r] * scaling : -INFINITY;
       float m_new = fmaxf(m_run[r], dd_wave_max(sv));
       float p = valid ? expf(sv - m_new) : 0.f;
@@ -1042,12 +1048,14 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
 }
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
-                     uint16_t* o_hi, uint16_t* o_lo, hipStream_t st) {
+                     uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
+                     int span_len, hipStream_t st) {
   int G = n_heads / n_kv;
   dim3 grid(n_heads, (T + 4 * PF_QR - 1) / (4 * PF_QR));
-  if (G == 1) k_attn_prefill<1><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
-  else if (G == 2) k_attn_prefill<2><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
-  else if (G == 4) k_attn_prefill<4><<<grid, 256, 0, st>>>(qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo);
+#define PF_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len
+  if (G == 1) k_attn_prefill<1><<<grid, 256, 0, st>>>(PF_ARGS);
+  else if (G == 2) k_attn_prefill<2><<<grid, 256, 0, st>>>(PF_ARGS);
+  else if (G == 4) k_attn_prefill<4><<<grid, 256, 0, st>>>(PF_ARGS);
   else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
   DD_CHECK_LAUNCH();
   return DD_OK;
@@ -1094,6 +1102,21 @@ __global__ void k_embed_tokens(const uint16_t* embed, int d, const int32_t* toke
 }
 int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st) {
   k_embed_tokens<<<n, 256, 0, st>>>(embed, d, tokens, x);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// rows[0][v] := (((r0 + r1) + r2) + ...) / K in fp32 — numpy's mean over axis 0 of a [K, V] float32 array
+// (reference llava.py:37-52, select_by_average)
+__global__ void k_mean_rows(float* rows, int K, int ld, int n) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = rows[i];
+  for (int k = 1; k < K; ++k) acc = __fadd_rn(acc, rows[(size_t)k * ld + i]);
+  rows[i] = __fdiv_rn(acc, (float)K);
+}
+int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st) {
+  k_mean_rows<<<(n + 255) / 256, 256, 0, st>>>(rows, K, ld, n);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

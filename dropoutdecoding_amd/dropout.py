@@ -15,6 +15,7 @@ import torch
 from . import _lib
 
 MASK_LLAVA_CUMULATIVE, MASK_NEXT_RESET, MASK_NEXT_NO_OVERLAP, MASK_IBLIP_QUANTILE = 0, 1, 2, 3
+MASK_LLAVA_CUMULATIVE_NO_OVERLAP = 4      # models/llava.py:663-683 (dormant "epis_no_overlap"), cumulative call site
 RNG_INJECTED, RNG_MT19937 = 0, 1
 
 

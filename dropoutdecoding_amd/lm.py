@@ -17,14 +17,15 @@ import torch
 
 from . import _lib
 from .config import settings
-from .dropout import (MASK_IBLIP_QUANTILE, MASK_LLAVA_CUMULATIVE, MASK_NEXT_NO_OVERLAP, MASK_NEXT_RESET,
+from .dropout import (MASK_IBLIP_QUANTILE, MASK_LLAVA_CUMULATIVE, MASK_LLAVA_CUMULATIVE_NO_OVERLAP, MASK_NEXT_NO_OVERLAP,
+                      MASK_NEXT_RESET,
                       TorchCpuCompatRNG)
 
 FAMILY_LLAVA = "llava-1.5"
 FAMILY_NEXT = "llava-next"
 FAMILY_IBLIP = "instructblip"
 
-VOTE_LOGITS, VOTE_HIDDEN = 0, 1
+VOTE_LOGITS, VOTE_HIDDEN, VOTE_AVERAGE = 0, 1, 2
 
 # per-family behaviour pinned by SURVEY.md 8(a) Q1-Q5 and tests/golden/g5_*
 _FAMILY = {
@@ -89,7 +90,8 @@ def dequantize_fp8(q_u8: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
 class DropoutEngine:
     def __init__(self, cfg: LMConfig, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
                  seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
-                 iblip_positions: str = "cache", weight_format: str = "bf16"):
+                 iblip_positions: str = "cache", weight_format: str = "bf16", mask_method: str = "epis",
+                 use_avg: bool = False):
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
@@ -99,6 +101,12 @@ class DropoutEngine:
         fam = dict(_FAMILY[family])
         if family == FAMILY_NEXT and use_random:
             fam["mask_mode"] = MASK_NEXT_NO_OVERLAP           # settings['use_random'][0] (llavanext.py:547-550)
+        if mask_method == "epis_no_overlap":                   # dormant variant (llava.py:663-683, instructblip.py:486-505)
+            fam["mask_mode"] = MASK_LLAVA_CUMULATIVE_NO_OVERLAP if family == FAMILY_LLAVA else MASK_NEXT_NO_OVERLAP
+        elif mask_method != "epis":
+            raise ValueError(f"mask_method {mask_method!r}: only 'epis' (the shipped call sites) and 'epis_no_overlap'")
+        if use_avg:
+            fam["vote_on"] = VOTE_AVERAGE                       # select_by_average, llava.py:37-52 (settings['use_avg'])
         if family == FAMILY_IBLIP and iblip_positions == "mask":
             fam["leak_mask"] = 2                                # transformers 4.44 position rule
         self.k_top = fam["k_top"]
@@ -161,7 +169,8 @@ class DropoutEngine:
         return int(self.lib.dd_lm_device_bytes(self._h))
 
     # ---- the path ---------------------------------------------------------------------------
-    def prefill(self, embeds: torch.Tensor, span_start: int, span_len: int) -> None:
+    def prefill(self, embeds: torch.Tensor, span_start: int, span_len: int, first_step_ensemble: bool = False,
+                mprobs: Optional[Sequence[float]] = None, uniforms: Optional[torch.Tensor] = None) -> None:
         if not embeds.is_cuda:
             raise ValueError("embeds must be on the GPU")
         e = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
@@ -169,10 +178,23 @@ class DropoutEngine:
             raise ValueError(f"embeds have width {e.shape[1]}, model hidden size is {self.cfg.hidden_size}")
         self.torch_stream.wait_stream(torch.cuda.current_stream(self.device))   # embeds come from the caller's stream
         e.record_stream(self.torch_stream)
-        _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, self._s()),
-                   "dd_lm_prefill")
+        K = 0
+        if first_step_ensemble:
+            # the reference's `# if True:` toggle (llava.py:336-337): the ensemble also picks the first token
+            probs, arr = self._probs(mprobs)
+            K = len(probs)
+            un = None
+            if uniforms is not None:
+                un = uniforms.float().contiguous()
+                un.record_stream(self.torch_stream)
+            _lib.check(self.lib.dd_lm_prefill_ensemble(self._h, e.data_ptr(), e.shape[0], span_start, span_len, arr, K,
+                                                       self.rng.handle, un.data_ptr() if un is not None else None,
+                                                       self._s()), "dd_lm_prefill_ensemble")
+        else:
+            _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, self._s()),
+                       "dd_lm_prefill")
         self.L, self.T0 = span_len, e.shape[0]
-        self._last_K = 0
+        self._last_K = K
         self._n_enqueued = 1                       # the prefill's greedy token
 
     def _probs(self, mprobs):

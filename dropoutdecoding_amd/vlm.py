@@ -128,7 +128,9 @@ class DropoutVLM:
         self.start_generation_pos = embeds.shape[0]
         self.masked_numbers = []
         eng = self.engine
-        eng.prefill(embeds, start, L)
+        # the `# if True:` toggle of llava.py:336-337; never for the stock greedy (`--original`) path
+        first = bool(settings.get("first_step_ensemble", False)) and not self.original
+        eng.prefill(embeds, start, L, first_step_ensemble=first)
         eos = self.eos_token_ids if eos_token_id is None else (
             list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
         toks = self._decode_loop(max_new_tokens, eos)
@@ -176,4 +178,5 @@ class DropoutVLM:
 def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens: int = 1024, prompt_tokens: int = 256,
                  use_random: bool = False, seed: Optional[int] = None) -> DropoutEngine:
     max_seq = max_visual + prompt_tokens + max_new_tokens + 8
-    return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random)
+    return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random,
+                         mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)))

@@ -43,6 +43,8 @@ extern "C" {
 #define DD_MASK_NEXT_RESET 1        /* models/llavanext.py:779-808, reset at :546                       */
 #define DD_MASK_NEXT_NO_OVERLAP 2   /* models/llavanext.py:809-829 ("epis_no_overlap", no keep-restore)  */
 #define DD_MASK_IBLIP_QUANTILE 3    /* models/instructblip.py:447-460, deterministic quantile, reset :121 */
+#define DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP 4 /* models/llava.py:663-683 ("epis_no_overlap") at the :344 call site:
+                                               * cumulative like mode 0, no keep-restore (dormant in the reference) */
 
 /* where the dropout uniforms come from (models/llava.py:650 `torch.rand_like`) */
 #define DD_RNG_INJECTED 0           /* caller supplies uniforms[K][L] (parity tests)                     */
@@ -51,6 +53,8 @@ extern "C" {
 /* what the ensemble votes on */
 #define DD_VOTE_LOGITS 0            /* models/llava.py:27, models/llavanext.py:31                         */
 #define DD_VOTE_HIDDEN 1            /* models/instructblip.py:125-137 (argmax over the final hidden state) */
+#define DD_VOTE_AVERAGE 2           /* models/llava.py:37-52 select_by_average (dormant): logits := fp32 mean over the
+                                     * members in list order, token = argmax(mean), member 0's KV is kept */
 
 int dd_version(void);
 const char* dd_last_error(void);
@@ -101,7 +105,7 @@ int dd_overlap_keep(const float* step_logits_dev, int V, const int32_t* topk_ids
  * per-family reset / cumulative / keep-restore behaviour of the calling loop
  * (llava.py:342-346, llavanext.py:544-551, instructblip.py:119-122).
  *   epi_dev [L] fp32; mprobs_host [K] doubles = settings['voting_numbers'] (models/config.py:2)
- *   keep_dev [L] u8 (from dd_overlap_keep); ignored for DD_MASK_NEXT_NO_OVERLAP
+ *   keep_dev [L] u8 (from dd_overlap_keep); ignored for the two *_NO_OVERLAP modes
  *   rng_mode DD_RNG_INJECTED: uniforms_dev [K][L] fp32;  DD_RNG_MT19937: rng != NULL, the
  *   stream advances by K*L draws (member-major), exactly like K rand_like(epi) calls
  *   drop_dev [K][L] u8: 1 = attention mask set to 0 for that member
@@ -193,6 +197,14 @@ int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std);
  * lm_head over the visual span + last position, top-k ids, uncertainty scorer.
  * Replaces the prefill branch of forward() (models/llava.py:285-314).  Resets the sequence. */
 int dd_lm_prefill(dd_lm* h, const float* embeds_dev, int T0, int span_start, int span_len, void* stream);
+
+/* Prefill with the ensemble ALSO applied to the first generated token: the reference's `# if True:` toggle at
+ * models/llava.py:336-337 (with it, the first forward runs llava.py:342-359 on the whole prompt: every member starts
+ * from the empty cache and masks its columns for all query rows).  Same arguments as dd_lm_prefill plus the step's
+ * (mprobs, K, rng | uniforms).  K == 0 is dd_lm_prefill.  Requires span_start >= 1.  Afterwards dd_lm_get(DD_GET_DROP,
+ * ..N_DROP, ..MEMBER_ARGMAX, ..WINNER) describe this first step. */
+int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds_dev, int T0, int span_start, int span_len, const double* mprobs,
+                           int K, dd_rng* rng, const float* uniforms_dev, void* stream);
 
 /* One ensemble decode step, enqueued on `stream` without host synchronisation:
  * embed(last token) -> un-masked pass -> argmax -> keep set -> K masks -> K masked members in

@@ -47,13 +47,17 @@ class StepRecord:
 class RefDecoder:
     def __init__(self, family: str, cfg: LMConfig, weights: Dict[str, torch.Tensor],
                  mprobs: Sequence[float], seed: int = 5217, use_random: bool = False,
-                 dropout: bool = True, iblip_positions: str = "cache"):
+                 dropout: bool = True, iblip_positions: str = "cache", mask_method: str = "epis",
+                 use_avg: bool = False, first_step_ensemble: bool = False):
         self.family, self.cfg, self.w = family, cfg, weights
         self.mprobs = list(mprobs)
         self.rng = TorchCpuMT19937(seed)
         self.use_random = use_random            # settings['use_random'][0], llavanext.py:547
         self.dropout = dropout                  # False = the `--original` path (stock greedy)
         self.iblip_positions = iblip_positions  # "cache" (transformers 5.x) | "mask" (4.44 cumsum rule), SURVEY Q2
+        self.mask_method = mask_method          # "epis" | "epis_no_overlap" (dormant: llava.py:663-683)
+        self.use_avg = use_avg                  # select_by_average instead of select_by_vote (dormant: llava.py:37-52)
+        self.first_step_ensemble = first_step_ensemble   # the `# if True:` toggle at llava.py:336-337
         self.cache = KVCache()
         self.dtype = weights["lm_head.weight"].dtype
         self.leaked = None                      # InstructBLIP: last member's drop flags (Q2)
@@ -72,6 +76,58 @@ class RefDecoder:
         self.epi = self.uncert["epis_uncert_per_token"][0]
         self.prefill_logits = logits
         return int(torch.argmax(logits[-1]))                            # HF greedy on the prefill logits (Q9)
+
+    def _mode(self) -> int:
+        if self.family == FAMILY_LLAVA:
+            return DR.MODE_LLAVA_CUMULATIVE_NO_OVERLAP if self.mask_method == "epis_no_overlap" else DR.MODE_LLAVA_CUMULATIVE
+        if self.mask_method == "epis_no_overlap":
+            return DR.MODE_NEXT_NO_OVERLAP
+        if self.family == FAMILY_NEXT:
+            return DR.MODE_NEXT_NO_OVERLAP if self.use_random else DR.MODE_NEXT_RESET
+        return DR.MODE_IBLIP_QUANTILE
+
+    def _select(self, member_logits, member_hid):
+        """-> (winner index, logits, ids).  Vote (llava.py:22-36 / instructblip.py:125-137) or mean (llava.py:37-52)."""
+        if self.use_avg:
+            ids = [int(torch.argmax(l)) for l in member_logits]
+            mean = torch.from_numpy(torch.stack(member_logits).numpy().mean(axis=0))     # numpy fp32 mean, llava.py:47
+            return 0, mean, ids
+        if self.family == FAMILY_IBLIP:
+            ids = [int(torch.argmax(h[-1])) for h in member_hid]
+        else:
+            ids = [int(torch.argmax(l)) for l in member_logits]
+        win, _ = DR.vote(ids)
+        return win, member_logits[win], ids
+
+    def prefill_first_step(self, embeds: torch.Tensor, span_start: int, span_len: int) -> int:
+        """prefill() followed by the ensemble on the FIRST token (llava.py:336 with `if True:`): each member re-runs the
+        whole prompt from an empty cache with its zero columns; the winner's logits and cache continue."""
+        self.prefill(embeds, span_start, span_len)
+        T0 = embeds.shape[0]
+        base_logits = self.prefill_logits[-1]
+        keep = DR.overlap_keep(base_logits, self.topk_ids)
+        K = len(self.mprobs)
+        mode = self._mode()
+        uniforms = None
+        if mode != DR.MODE_IBLIP_QUANTILE:
+            uniforms = torch.from_numpy(np.stack([self.rng.rand_f32(self.L) for _ in range(K)]))
+        drop = DR.sample_masks(self.epi, self.mprobs, keep, mode, uniforms)
+        member_logits, member_hid, member_cache = [], [], []
+        for k in range(K):
+            c = KVCache()
+            km = torch.ones(T0, dtype=torch.long)
+            km[span_start:span_start + span_len][drop[k]] = 0
+            hid = lm_hidden(self.cfg, self.w, embeds.to(self.dtype), torch.arange(T0), c, km)
+            member_hid.append(hid[-1:])
+            member_logits.append(lm_logits(self.cfg, self.w, hid[-1:])[0])
+            member_cache.append(c)
+        win, logits, ids = self._select(member_logits, member_hid)
+        self.cache = member_cache[win]
+        self.first_record = StepRecord(int(torch.argmax(base_logits)), keep.numpy().copy(),
+                                       None if uniforms is None else uniforms.numpy().copy(), drop.numpy().copy(),
+                                       [int(d.sum()) for d in drop], ids, win, int(torch.argmax(logits)),
+                                       logits.numpy().copy(), base_logits.numpy().copy(), {})
+        return int(torch.argmax(logits))
 
     def embed(self, token: int) -> torch.Tensor:
         return self.w["model.embed_tokens.weight"][token][None].to(self.dtype)
@@ -108,12 +164,7 @@ class RefDecoder:
         t0 = time.perf_counter()
         keep = DR.overlap_keep(base_logits, self.topk_ids)               # llava.py:603, 443-482
         K = len(self.mprobs)
-        if self.family == FAMILY_LLAVA:
-            mode = DR.MODE_LLAVA_CUMULATIVE
-        elif self.family == FAMILY_NEXT:
-            mode = DR.MODE_NEXT_NO_OVERLAP if self.use_random else DR.MODE_NEXT_RESET
-        else:
-            mode = DR.MODE_IBLIP_QUANTILE
+        mode = self._mode()
         uniforms = None
         if mode != DR.MODE_IBLIP_QUANTILE:
             # one rand_like(epi) per member, in list order (llava.py:650); contiguous stream
@@ -132,21 +183,12 @@ class RefDecoder:
             ph["lm"] += time.perf_counter() - t0
             member_cache.append(c)
         t0 = time.perf_counter()
+        member_logits = [lm_logits(self.cfg, self.w, h)[0] for h in member_hid]
+        # Q3: InstructBLIP votes on argmax over the flattened final hidden state (instructblip.py:125-137); LLaVA / NeXT on
+        # the logits argmax (llava.py:27, 361); `use_avg` takes the mean instead (llava.py:37-52)
+        win, logits, ids = self._select(member_logits, member_hid)
         if self.family == FAMILY_IBLIP:
-            # Q3: vote on argmax over the flattened final hidden state (instructblip.py:125-137)
-            ids = [int(torch.argmax(h[-1])) for h in member_hid]
-            win, _ = DR.vote(ids)
-            t1 = time.perf_counter()
-            logits = lm_logits(self.cfg, self.w, member_hid[win])[0]     # instructblip.py:138-140
-            ph["lm"] += time.perf_counter() - t1
             self.leaked = drop[K - 1].clone()
-        else:
-            t1 = time.perf_counter()
-            member_logits = [lm_logits(self.cfg, self.w, h)[0] for h in member_hid]
-            ph["lm"] += time.perf_counter() - t1
-            ids = [int(torch.argmax(l)) for l in member_logits]          # llava.py:27
-            win, _ = DR.vote(ids)                                        # llava.py:361
-            logits = member_logits[win]
         ph["vote"] += time.perf_counter() - t0
         self.cache = member_cache[win]                                   # llava.py:373
         tok = int(torch.argmax(logits))                                  # HF greedy
@@ -157,7 +199,7 @@ class RefDecoder:
 
     def generate(self, embeds: torch.Tensor, span_start: int, span_len: int, n_new: int,
                  eos: Optional[int] = None) -> List[int]:
-        tok = self.prefill(embeds, span_start, span_len)
+        tok = (self.prefill_first_step if (self.first_step_ensemble and self.dropout) else self.prefill)(embeds, span_start, span_len)
         out = [tok]
         self.records = []
         while len(out) < n_new and (eos is None or tok != eos):

@@ -17,6 +17,7 @@ MODE_LLAVA_CUMULATIVE = 0   # models/llava.py:342-346 — mask NOT reset between
 MODE_NEXT_RESET = 1         # models/llavanext.py:546-551 — reset before every member, keep-restore
 MODE_NEXT_NO_OVERLAP = 2    # models/llavanext.py:809-829 — reset, no keep-restore ("epis_no_overlap")
 MODE_IBLIP_QUANTILE = 3     # models/instructblip.py:447-460 — deterministic top-quantile, reset, keep-restore
+MODE_LLAVA_CUMULATIVE_NO_OVERLAP = 4   # models/llava.py:663-683 at the :344 call site — cumulative, no keep-restore
 
 
 def vision_uncertainty(logits: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -83,14 +84,14 @@ def sample_masks(epi: torch.Tensor, mprobs: Sequence[float], keep: torch.Tensor,
     out = torch.zeros(K, L, dtype=torch.bool)
     running = torch.zeros(L, dtype=torch.bool)       # the in-place-mutated mask, image span only
     for k, mprob in enumerate(mprobs):
-        if mode != MODE_LLAVA_CUMULATIVE:
+        if mode not in (MODE_LLAVA_CUMULATIVE, MODE_LLAVA_CUMULATIVE_NO_OVERLAP):
             running = torch.zeros(L, dtype=torch.bool)                  # llavanext.py:546, instructblip.py:121
         if mode == MODE_IBLIP_QUANTILE:
             drop = epi >= iblip_threshold(epi, mprob)                   # instructblip.py:450-453
         else:
             drop = uniforms[k] < drop_probability(epi, mprob)           # llava.py:650-653
         running = running | drop                                        # llava.py:654-657 (in place)
-        if mode != MODE_NEXT_NO_OVERLAP:
+        if mode not in (MODE_NEXT_NO_OVERLAP, MODE_LLAVA_CUMULATIVE_NO_OVERLAP):
             running = running & ~keep                                   # llava.py:660
         out[k] = running
     return out

@@ -125,7 +125,26 @@ def test_masks_golden(ops, golden_dir, fam, mode, rng_mode):
             assert (idx[k, len(want):] == -1).all()
 
 
-@pytest.mark.parametrize("fam,mode", MODES)
+@pytest.mark.parametrize("fam,mode", [("llava_no_overlap", DR.MODE_LLAVA_CUMULATIVE_NO_OVERLAP),
+                                      ("iblip_no_overlap", DR.MODE_NEXT_NO_OVERLAP)])
+@pytest.mark.parametrize("rng_mode", ["injected", "mt19937"])
+def test_masks_golden_dormant_no_overlap(ops, golden_dir, fam, mode, rng_mode):
+    """The reference's dormant `epis_no_overlap` call (llava.py:663-683 / instructblip.py:486-505) on the g3 inputs."""
+    g, g7 = _load(golden_dir, "g3_masks.npz"), _load(golden_dir, "g7_variants.npz")
+    for c in range(int(g7["n_cases"])):
+        epi = torch.from_numpy(g[f"c{c}_epi"]).cuda()
+        probs = [float(p) for p in g[f"c{c}_probs"]]
+        if rng_mode == "injected":
+            drop, nd = ops.sample_masks(epi, probs, None, mode, uniforms=torch.from_numpy(g[f"c{c}_uniforms"]).cuda())
+        else:
+            drop, nd = ops.sample_masks(epi, probs, None, mode, rng=ops.TorchCpuCompatRNG(int(g[f"c{c}_seed"])))
+        start, L = int(g[f"c{c}_start"]), epi.numel()
+        ref = g7[f"c{c}_{fam}_masks"][:, start:start + L] == 0
+        np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), ref, err_msg=f"case {c} {fam} {rng_mode}")
+        np.testing.assert_array_equal(nd.cpu().numpy(), ref.sum(1))
+
+
+@pytest.mark.parametrize("fam,mode", MODES + [("llava_no_overlap", DR.MODE_LLAVA_CUMULATIVE_NO_OVERLAP)])
 def test_masks_random_trials_vs_oracle(ops, fam, mode):
     rs = np.random.RandomState(hash(fam) % 1000)
     for trial in range(40):

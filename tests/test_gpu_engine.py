@@ -452,3 +452,69 @@ def test_graph_replay_equals_eager_launches(E):
         np.testing.assert_array_equal(d0, d1)
         assert a0 == a1 and w0 == w1
         np.testing.assert_array_equal(l0, l1)
+
+
+def _variant_case(E, family, rc, T0, s0, L, probs, n_new, seed=5, eng_kw=None, ref_kw=None, first=False, std=0.05):
+    """Engine vs oracle with the dormant variants switched on (same checks as _rand_case)."""
+    w = random_weights(rc, 23, std)
+    cfg = E.LMConfig(rc.vocab_size, rc.hidden_size, rc.intermediate_size, rc.num_layers, rc.num_heads, rc.num_kv_heads,
+                     rc.head_dim, rc.rms_eps, rc.rope_theta)
+    eng = E.DropoutEngine(cfg, family=family, max_seq=T0 + n_new + 8, max_visual=L, seed=seed, **(eng_kw or {}))
+    eng.load_state_dict(w)
+    emb = torch.randn(T0, rc.hidden_size, generator=torch.Generator().manual_seed(seed)) * 0.8
+    ref = RefDecoder(family, rc, w, probs, seed=seed, first_step_ensemble=first, **(ref_kw or {}))
+    want = ref.generate(emb, s0, L, n_new)
+    eng.prefill(emb.cuda(), s0, L, first_step_ensemble=first, mprobs=probs)
+    avg = bool((eng_kw or {}).get("use_avg"))
+    recs = ([ref.first_record] if first else []) + ref.records
+    for s, r in enumerate(recs):
+        if s > 0 or not first:
+            eng.decode_step(probs)
+        st = eng.last_step()
+        info = f"record {s}"
+        np.testing.assert_array_equal(st["drop"], r.drop, err_msg=info)
+        np.testing.assert_array_equal(st["masked_numbers"], r.masked_numbers, err_msg=info)
+        if not avg:                                    # the mean replaces member 0's row, so its argmax is the mean's
+            assert st["member_argmax"].tolist() == r.member_argmax, info
+        assert st["winner"] == r.winner, info
+        assert close(eng.logits(), r.logits), info
+        if first and s == 0:      # the masked prompt pass must really differ from the un-masked one
+            assert np.abs(r.logits - r.base_logits).max() > 1e-2 * np.abs(r.base_logits).max()
+            assert not close(eng.logits(), r.base_logits, 1e-3)
+    assert eng.tokens() == want
+    sums = eng.kv_sums()
+    eng.close()
+    return want, sums
+
+
+@pytest.mark.parametrize("family,K", [(FAMILY_LLAVA, 3), (FAMILY_NEXT, 4), (FAMILY_LLAVA, 8)])
+def test_first_token_ensemble_toggle(E, family, K):
+    """`# if True:` at llava.py:336 — the ensemble also picks the first token: every member re-runs
+    the whole prompt with its masked columns from an empty cache; the winner's cache continues (incl. a winner != 0)."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    probs = [0.1 + 0.1 * i for i in range(K)]
+    _variant_case(E, family, rc, 70, 3, 50, probs, 5, first=True)
+
+
+def test_first_token_ensemble_needs_a_text_token_before_the_span(E):
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    eng = E.DropoutEngine(E.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0), family=FAMILY_IBLIP, max_seq=64, max_visual=32)
+    eng.load_state_dict(random_weights(rc, 1, 0.05))
+    with pytest.raises(ValueError, match="position 0"):
+        eng.prefill(torch.randn(40, 256).cuda(), 0, 32, first_step_ensemble=True, mprobs=[0.3, 0.5])
+    eng.close()
+
+
+@pytest.mark.parametrize("family", [FAMILY_LLAVA, FAMILY_NEXT])
+def test_average_instead_of_vote(E, family):
+    """settings['use_avg'] / select_by_average (llava.py:37-52): logits := fp32 mean over members, member 0's cache."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    _variant_case(E, family, rc, 50, 2, 40, [0.2, 0.4, 0.6, 0.8, 0.9], 6, eng_kw=dict(use_avg=True), ref_kw=dict(use_avg=True))
+
+
+@pytest.mark.parametrize("family,s0", [(FAMILY_LLAVA, 4), (FAMILY_IBLIP, 0)])
+def test_epis_no_overlap_method(E, family, s0):
+    """The dormant `epis_no_overlap` branch (llava.py:663-683 cumulative, instructblip.py:486-505 reset + random)."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    _variant_case(E, family, rc, 48, s0, 32, [0.3, 0.5, 0.7], 6, eng_kw=dict(mask_method="epis_no_overlap"),
+                  ref_kw=dict(mask_method="epis_no_overlap"))

@@ -88,6 +88,16 @@ def test_llava_wrapper_generate_matches_oracle(built):
     m.engine.rng.manual_seed(5)
     o3 = m.generate(input_ids=ids1, pixel_values=pv, max_new_tokens=8, eos_token_id=eos)
     assert o3[0, 7:].tolist() == w3 and w3[-1] == eos and len(w3) <= 5
+    # POPE-style one-token answer with the ensemble on the first token (the `# if True:` toggle, llava.py:336-337)
+    ddc.settings["first_step_ensemble"] = True
+    try:
+        m.engine.rng.manual_seed(9)
+        o4 = m.generate(input_ids=ids1, pixel_values=pv, max_new_tokens=3, eos_token_id=[])
+    finally:
+        ddc.settings.pop("first_step_ensemble")
+    ref4 = RefDecoder(FAMILY_LLAVA, rc, sd, [0.3, 0.5, 0.7], seed=9, first_step_ensemble=True)
+    assert o4[0, 7:].tolist() == ref4.generate(emb.cpu(), start, 16, 3)
+    assert m.engine.last_step()["winner"] == ref4.records[-1].winner
 
 
 def test_instructblip_merge_and_output_format(built):

@@ -61,6 +61,40 @@ def test_g3_masks(golden_dir, fam, mode):
             np.testing.assert_array_equal(drop.sum(1).numpy(), g[f"c{c}_llava_masked_numbers"])
 
 
+@pytest.mark.parametrize("fam,mode", [("llava_no_overlap", DR.MODE_LLAVA_CUMULATIVE_NO_OVERLAP),
+                                      ("iblip_no_overlap", DR.MODE_NEXT_NO_OVERLAP)])
+def test_g7_dormant_no_overlap_masks(golden_dir, fam, mode):
+    """`epis_no_overlap` (llava.py:663-683 driven cumulatively; instructblip.py:486-505 with the reset): the reference's
+    own outputs on the g3 inputs."""
+    g, g7 = _load(golden_dir, "g3_masks.npz"), _load(golden_dir, "g7_variants.npz")
+    differs = False
+    for c in range(int(g7["n_cases"])):
+        epi = torch.from_numpy(g[f"c{c}_epi"])
+        probs = [float(p) for p in g[f"c{c}_probs"]]
+        keep = DR.overlap_keep(torch.from_numpy(g[f"c{c}_step_logits"]), torch.from_numpy(g[f"c{c}_topk_ids"]))
+        drop = DR.sample_masks(epi, probs, keep, mode, torch.from_numpy(g[f"c{c}_uniforms"]))
+        start, L = int(g[f"c{c}_start"]), epi.numel()
+        ref = g7[f"c{c}_{fam}_masks"]
+        np.testing.assert_array_equal(drop.numpy(), ref[:, start:start + L] == 0, err_msg=f"case {c} {fam}")
+        with_keep = DR.sample_masks(epi, probs, keep, DR.MODE_LLAVA_CUMULATIVE if "llava" in fam else DR.MODE_NEXT_RESET,
+                                    torch.from_numpy(g[f"c{c}_uniforms"]))
+        differs |= bool((with_keep != drop).any())
+    assert differs, "fixture must contain a case where the keep set matters"
+
+
+def test_g7_select_by_average(golden_dir):
+    """models/llava.py:37-52: numpy fp32 mean over the members, bit for bit."""
+    g7 = _load(golden_dir, "g7_variants.npz")
+    for a in range(int(g7["n_avg"])):
+        rows = torch.from_numpy(g7[f"avg{a}_rows"])
+        mean = torch.from_numpy(rows.numpy().mean(axis=0))
+        np.testing.assert_array_equal(mean.numpy(), g7[f"avg{a}_mean"])
+        seq = rows[0].clone()                                       # the order the HIP kernel uses: ((r0+r1)+r2)+... then / K
+        for k in range(1, rows.shape[0]):
+            seq = seq + rows[k]
+        np.testing.assert_array_equal((seq / np.float32(rows.shape[0])).numpy(), g7[f"avg{a}_mean"])
+
+
 def test_g3_uniforms_are_the_mt19937_stream(golden_dir):
     g = _load(golden_dir, "g3_masks.npz")
     for c in range(int(g["n_cases"])):
