@@ -13,7 +13,7 @@ SYMBOLS = [
     "dd_rng_create", "dd_rng_destroy", "dd_rng_seed", "dd_rng_uniform",
     "dd_uncertainty_workspace_bytes", "dd_vision_uncertainty", "dd_overlap_keep", "dd_sample_masks", "dd_vote",
     "dd_argmax_rows",
-    "dd_lm_create", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_tensor_fp8", "dd_lm_load_synthetic",
+    "dd_lm_create", "dd_lm_create_shared", "dd_lm_group_step", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_tensor_fp8", "dd_lm_load_synthetic",
     "dd_lm_prefill", "dd_lm_prefill_ensemble", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_step_algorithmic_bytes",
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     lib.dd_argmax_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.dd_lm_create.argtypes = [C.POINTER(LMConfigC), C.POINTER(vp)]
     lib.dd_lm_destroy.argtypes = [vp]
+    lib.dd_lm_create_shared.argtypes = [C.POINTER(LMConfigC), vp, C.POINTER(vp)]
+    lib.dd_lm_group_step.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(vp), vp]
     lib.dd_lm_device_bytes.argtypes = [vp]
     lib.dd_lm_device_bytes.restype = C.c_size_t
     lib.dd_lm_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]

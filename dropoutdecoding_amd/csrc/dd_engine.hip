@@ -30,6 +30,12 @@ struct dd_lm {
   int S_d, S_q, S_ff, qkv_tiles, q_tiles, k_tiles;
   std::vector<void*> allocs;
   size_t bytes = 0;
+  dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
+  float* grp_logits = nullptr; // [8][Vpad] base-pass logits of a group step (this handle is the group's first lane)
+  int32_t* grp_argmax = nullptr;
+  void** grp_tab = nullptr;    // 16 device pointers: where each sequence's base logits / argmax go
+  void* grp_tab_host[16] = {};
+  const float *commit_k = nullptr, *commit_v = nullptr;   // K == 0 group step: this lane's base row in the leader's scratch
   // weights
   std::vector<LayerW> lw;
   u32x4_t* lm_head = nullptr;
@@ -120,7 +126,7 @@ extern "C" int dd_lm_destroy(dd_lm* h) {
 
 extern "C" size_t dd_lm_device_bytes(const dd_lm* h) { return h ? h->bytes : 0; }
 
-extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
+static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DD_REQUIRE(c && out, "dd_lm_create: null argument");
   DD_REQUIRE(c->head_dim == 128, "dd_lm_create: head_dim must be 128 (got %d)", c->head_dim);
   DD_REQUIRE(c->hidden_size % 256 == 0 && c->intermediate_size % 256 == 0,
@@ -145,6 +151,21 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   h->fp8 = c->weight_format == 1 ? 1 : 0;
   DD_REQUIRE(c->weight_format == 0 || c->weight_format == 1, "dd_lm_create: unknown weight format %d", c->weight_format);
   const int wdiv = h->fp8 ? 2 : 1;   // u32x4 units per tile row: S*64 (bf16) or (S/2)*64 (fp8)
+  if (parent) {
+    // a lane: another sequence over the SAME weights (its own KV cache, state and scratch)
+    const dd_lm_config& pc = parent->cfg;
+    if (!(pc.vocab_size == c->vocab_size && pc.hidden_size == c->hidden_size && pc.intermediate_size == c->intermediate_size &&
+          pc.num_layers == c->num_layers && pc.num_heads == c->num_heads && pc.num_kv_heads == c->num_kv_heads &&
+          pc.weight_format == c->weight_format && pc.rope_theta == c->rope_theta && parent->wsrc == nullptr)) {
+      dd_set_error("dd_lm_create_shared: the lane's model dimensions differ from the weight owner's (or the owner is itself a lane)");
+      delete h;
+      return DD_EINVAL;
+    }
+    h->wsrc = parent;
+    h->lw = parent->lw;
+    h->lm_head = parent->lm_head, h->s_lm = parent->s_lm, h->deq_tmp = parent->deq_tmp;
+    h->final_norm = parent->final_norm, h->embed = parent->embed;
+  } else {
   h->lw.resize(h->Lyr);
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
@@ -172,6 +193,7 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   }
   DA(h->final_norm, d);
   DA(h->embed, (size_t)h->V * d);
+  }
   DA(h->rope_cos, (size_t)T * 64);
   DA(h->rope_sin, (size_t)T * 64);
   h->lsk = (size_t)h->Hkv * 32 * T * 4;
@@ -193,6 +215,9 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   DA(h->xop_q, (size_t)h->S_q * 64);
   DA(h->xop_ff, (size_t)h->S_ff * 64);
   DA(h->base_logits, h->Vpad);
+  DA(h->grp_logits, (size_t)8 * h->Vpad);
+  DA(h->grp_argmax, 8);
+  DA(h->grp_tab, 16);
   DA(h->member_logits, (size_t)MAX_MEMBERS * h->Vpad);
   DA(h->last_logits, h->Vpad);
   DA(h->last_hidden, d);
@@ -251,11 +276,22 @@ extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) {
   return DD_OK;
 }
 
+extern "C" int dd_lm_create(const dd_lm_config* c, dd_lm** out) { return lm_create_impl(c, nullptr, out); }
+
+// A further sequence ("lane") over the weights of `weights_from`: own KV cache, state, scratch and token mirror; the
+// weight owner must outlive it.  Lanes exist so that dd_lm_group_step can run the base passes of several sequences as
+// ONE sweep over the weights.
+extern "C" int dd_lm_create_shared(const dd_lm_config* c, dd_lm* weights_from, dd_lm** out) {
+  DD_REQUIRE(weights_from, "dd_lm_create_shared: null weight owner");
+  return lm_create_impl(c, weights_from, out);
+}
+
 // -----------------------------------------------------------------------------------------------
 // weights
 // -----------------------------------------------------------------------------------------------
 extern "C" int dd_lm_load_tensor(dd_lm* h, int id, int layer, const uint16_t* src, int rows, int cols, int on_device) {
   DD_REQUIRE(h && src, "dd_lm_load_tensor: null argument");
+  DD_REQUIRE(!h->wsrc, "dd_lm_load_tensor: this handle borrows its weights (dd_lm_create_shared); load into the owner");
   DD_REQUIRE(id >= DD_T_EMBED && id <= DD_T_LM_HEAD, "dd_lm_load_tensor: unknown tensor id %d", id);
   bool per_layer = !(id == DD_T_EMBED || id == DD_T_FINAL_NORM || id == DD_T_LM_HEAD);
   DD_REQUIRE(!per_layer || (layer >= 0 && layer < h->Lyr), "dd_lm_load_tensor: layer %d out of range", layer);
@@ -314,6 +350,7 @@ extern "C" int dd_lm_load_tensor(dd_lm* h, int id, int layer, const uint16_t* sr
 extern "C" int dd_lm_load_tensor_fp8(dd_lm* h, int id, int layer, const uint8_t* q, const float* row_scale, int rows,
                                      int cols, int on_device) {
   DD_REQUIRE(h && q && row_scale, "dd_lm_load_tensor_fp8: null argument");
+  DD_REQUIRE(!h->wsrc, "dd_lm_load_tensor_fp8: this handle borrows its weights (dd_lm_create_shared); load into the owner");
   DD_REQUIRE(h->fp8, "dd_lm_load_tensor_fp8: the engine was created for bf16 weights (weight_format 0)");
   bool per_layer = id != DD_T_LM_HEAD;
   DD_REQUIRE(id == DD_T_LM_HEAD || (id >= DD_T_WQ && id <= DD_T_WDOWN && id != DD_T_MLP_NORM),
@@ -362,6 +399,7 @@ extern "C" int dd_lm_load_tensor_fp8(dd_lm* h, int id, int layer, const uint8_t*
 }
 
 extern "C" int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std) {
+  DD_REQUIRE(h && !h->wsrc, "dd_lm_load_synthetic: null handle, or a handle that borrows its weights");
   DD_REQUIRE(h, "dd_lm_load_synthetic: null handle");
   const int d = h->d, dff = h->dff;
   if (h->fp8) {   // random finite e4m3 bytes (|q| <= 240, rms ~ 40) with a constant row scale that gives ~std
@@ -655,9 +693,19 @@ extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int
 // -----------------------------------------------------------------------------------------------
 // one packed sweep of nb rows through all layers + lm_head
 // -----------------------------------------------------------------------------------------------
-static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st) {
+// `lanes` (group step): row m of the pass is the base row of sequence lanes[m] — its own token, position, cache, span
+// and leak bits; scratch, weights and the per-layer new K/V rows are this handle's (the first lane of the group).
+static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st,
+                    dd_lm* const* lanes = nullptr) {
   const int d = h->d, dff = h->dff;
-  RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  if (lanes) {
+    EmbedLanes el;
+    memset(&el, 0, sizeof(el));
+    for (int m = 0; m < nb; ++m) el.state[m] = lanes[m]->state;
+    RC(ddk_embed_rows_lanes(h->embed, d, el, nb, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  } else {
+    RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  }
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
@@ -670,6 +718,8 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.knew = knew, a.vnew = vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = h->state;
+    if (lanes)
+      for (int m = 0; m < nb; ++m) a.state_rows[m] = lanes[m]->state;
     RC(ddk_gemv(EPI_QKV, a, st));
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
@@ -678,6 +728,16 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     t.bit0 = bits ? h->bit0 : 0;
     t.span_start = h->span_start, t.span_len = h->L, t.part_o = h->part_o, t.part_ml = h->part_ml;
     t.knew = knew, t.vnew = vnew, t.xop_out = h->xop_q;
+    if (lanes) {
+      t.n_lanes = nb, t.bit0 = 0, t.drop_bits = nullptr;
+      for (int m = 0; m < nb; ++m) {
+        dd_lm* q = lanes[m];
+        t.lane_kc[m] = q->kc + (size_t)l * q->lsk, t.lane_vc[m] = q->vc + (size_t)l * q->lsv, t.lane_state[m] = q->state;
+        t.lane_bits[m] = q->cfg.leak_mask ? q->leak_bits : nullptr;
+        t.lane_span_start[m] = q->span_start, t.lane_span_len[m] = q->L;
+        if (q->T_host > t.max_T) t.max_T = q->T_host;
+      }
+    }
     RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_q;
@@ -770,8 +830,8 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && h->prefilled && K == h->last_K, "dd_lm_step_commit: bad state (K=%d, expected %d)", K, h ? h->last_K : -1);
   if (K > 0) RC(vote_members(h, K, st));
-  RC(ddk_commit_kv(h->knew, h->vnew, h->Lyr, MAX_MEMBERS, h->kv_dim, h->kc, h->vc, h->lsk, h->lsv, h->T_cap, h->state,
-                   K > 0 ? 1 : 0, st));
+  RC(ddk_commit_kv(h->commit_k ? h->commit_k : h->knew, h->commit_v ? h->commit_v : h->vnew, h->Lyr, MAX_MEMBERS,
+                   h->kv_dim, h->kc, h->vc, h->lsk, h->lsv, h->T_cap, h->state, K > 0 ? 1 : 0, st));
   k_step_end<<<1, 1024, 0, st>>>(h->state, K, h->argmax_base, h->member_tok, h->base_logits, h->member_logits, h->Vpad,
                                  h->last_logits, h->tokens, h->drop_bits, h->L, h->leak_bits, h->cfg.leak_mask, h->hidden,
                                  h->d, h->last_hidden, h->tok_host_dev);
@@ -779,6 +839,84 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
   h->T_host += 1;
   h->n_tok_host += 1;
   if (h->cfg.leak_mask && K > 0) h->have_leak = true;
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// group step: one decode step for each of n sequences that share weights, with the n un-masked base passes packed into
+// ONE sweep (row m = sequence m).  Each sequence then samples its masks from ITS OWN rng stream and runs its K members
+// exactly as dd_lm_decode_step does, so every sequence's tokens, masks and logits are those of a run on its own.
+// Per step and sequence the weights are read 1/n + 1 times instead of twice.
+// -----------------------------------------------------------------------------------------------
+__global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, float* const* dst_logits,
+                               int32_t* const* dst_argmax) {
+  int m = blockIdx.x;
+  const float* src = grp_logits + (size_t)m * Vpad;
+  float* dst = dst_logits[m];
+  for (int i = threadIdx.x; i < Vpad; i += 256) dst[i] = src[i];
+  if (threadIdx.x == 0) dst_argmax[m][0] = grp_argmax[m];
+}
+
+extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(lanes && n >= 1 && n <= 8, "dd_lm_group_step: 1..8 sequences per group (got %d)", n);
+  DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_group_step: bad K / mprobs");
+  dd_lm* h0 = lanes[0];
+  DD_REQUIRE(h0, "dd_lm_group_step: null handle");
+  dd_lm* owner = h0->wsrc ? h0->wsrc : h0;
+  for (int m = 0; m < n; ++m) {
+    dd_lm* q = lanes[m];
+    DD_REQUIRE(q, "dd_lm_group_step: null handle");
+    DD_REQUIRE((q->wsrc ? q->wsrc : q) == owner, "dd_lm_group_step: sequence %d does not share the group's weights", m);
+    DD_REQUIRE(q->T_cap == h0->T_cap && q->Vpad == h0->Vpad, "dd_lm_group_step: sequence %d has a different KV capacity", m);
+    for (int j = 0; j < m; ++j) DD_REQUIRE(lanes[j] != q, "dd_lm_group_step: sequence listed twice");
+    if (!q->prefilled) {
+      dd_set_error("dd_lm_group_step: sequence %d: decode before prefill", m);
+      return DD_ESTATE;
+    }
+    if (q->T_host + 1 >= q->T_cap) {
+      dd_set_error("dd_lm_group_step: sequence %d: KV cache full (%d tokens)", m, q->T_cap);
+      return DD_ESTATE;
+    }
+    DD_REQUIRE(q->n_tok_host < MAX_NEW_TOKENS, "dd_lm_group_step: token buffer full");
+    DD_REQUIRE(K == 0 || q->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || (rngs && rngs[m]), "dd_lm_group_step: sequence %d needs an rng", m);
+  }
+  for (int m = 0; m < n; ++m) {
+    dd_lm* q = lanes[m];
+    k_step_begin<<<1, 256, 0, st>>>(q->state, q->leak_bits, q->L, q->cfg.leak_mask == 2 ? 1 : 0);
+    DD_CHECK_LAUNCH();
+  }
+  h0->bit0 = 0;
+  RC(lm_sweep(h0, n, nullptr, 0, h0->grp_logits, st, lanes));
+  RC(dd_argmax_rows(h0->grp_logits, n, h0->V, h0->Vpad, h0->grp_argmax, st));
+  // hand every sequence its base row (logits + argmax); pointer tables go through a small pinned staging area
+  {
+    for (int m = 0; m < 8; ++m) {
+      h0->grp_tab_host[m] = m < n ? (void*)lanes[m]->base_logits : nullptr;
+      h0->grp_tab_host[8 + m] = m < n ? (void*)lanes[m]->argmax_base : nullptr;
+    }
+    DD_HIP(hipMemcpyAsync(h0->grp_tab, h0->grp_tab_host, sizeof(h0->grp_tab_host), hipMemcpyHostToDevice, st));
+    k_scatter_base<<<n, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, (float* const*)h0->grp_tab,
+                                      (int32_t* const*)(h0->grp_tab + 8));
+    DD_CHECK_LAUNCH();
+  }
+  for (int m = 0; m < n; ++m) {
+    dd_lm* q = lanes[m];
+    q->last_K = K;
+    if (K > 0) {
+      RC(dd_overlap_keep_from_argmax(q->argmax_base, q->topk_ids, q->L, q->cfg.k_top, q->keep, st));
+      RC(dd_sample_masks_impl(q->epi, q->L, mprobs, K, q->keep, q->cfg.mask_mode, DD_RNG_MT19937, nullptr,
+                              dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits, st));
+      RC(dd_lm_step_members(q, 0, K, stream_));
+    } else {
+      // stock greedy: the base row's new K/V (in the leader's scratch, row m) is what gets appended
+      q->commit_k = h0->knew + (size_t)m * h0->kv_dim, q->commit_v = h0->vnew + (size_t)m * h0->kv_dim;
+    }
+    int rc = dd_lm_step_commit(q, K, stream_);
+    q->commit_k = q->commit_v = nullptr;
+    RC(rc);
+    q->steps_since_prefill++;
+  }
   return DD_OK;
 }
 

@@ -83,6 +83,7 @@ struct GemvArgs {
   const float* rope_cos; // [max_seq][64]
   const float* rope_sin;
   const DDState* state;
+  const DDState* state_rows[8];   // lanes: row m takes its position from state_rows[m] (null entries: `state`)
   int diag;             // timing diagnostics only (dd_set_tuning key 3): 2 = no rstd prologue, 4 = no epilogue, 8 = no epilogue prefetch
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
@@ -105,6 +106,15 @@ struct AttnDecodeArgs {
   const float* knew;     // [8][kv_dim] roped new keys of this layer (rows of this pass)
   const float* vnew;
   u32x4_t* xop_out;      // packed hi/lo operand for o_proj, [q_dim/32][64]
+  // lanes (n_lanes > 0): row m of the pass belongs to sequence m — its own cache, length, span and (un-shifted) bits.
+  // Used by the fused base pass of a group of sequences; kc/vc/state/drop_bits/span_* above are ignored then.
+  int n_lanes;
+  int max_T;             // host: largest prefix length among the lanes (grid sizing)
+  const float* lane_kc[8];
+  const float* lane_vc[8];
+  const DDState* lane_state[8];
+  const uint8_t* lane_bits[8];
+  int lane_span_start[8], lane_span_len[8];
 };
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
 
@@ -147,6 +157,11 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st);
 // x[0..8)[d] <- embed[cur_tok] (all rows equal), xop <- split(normw * x), ssq slot 0
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
                    float* ssq, int ssq_ld, hipStream_t st);
+struct EmbedLanes {
+  const DDState* state[8];
+};
+int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int nb, float* x, const float* normw,
+                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st);
 int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st);
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
                   float* vc, size_t layer_stride_k, size_t layer_stride_v, int T_cap, const DDState* state,

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
         if (tile0 < a.q_tiles + a.k_tiles) {
           int ht = tile0 < a.q_tiles ? tile0 : tile0 - a.q_tiles;
           int f = (ht & 7) * 8 + (en & 7);
-          int pos = a.state->pos;
+          const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+          int pos = sp->pos;
           pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
           pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
         }
@@ -548,11 +549,14 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
 // GH = q heads of the GQA group handled by one workgroup (blockIdx.z picks the slice): 32 rows per workgroup (8 members
 // x 4 heads) need 122 KiB of LDS and 156 VGPRs, i.e. one workgroup per CU; two slices of 16 rows run two per CU and
 // read the K/V tile twice through L2.
-template <int NBT, int G, int GH>
+// ML (lanes): NBT == 1 and GH == G; blockIdx.z is the ROW of the pass = the sequence whose cache this workgroup reads;
+// results go to the 8-rows-per-head layout the 8-row combine reads.
+template <int NBT, int G, int GH, int ML = 0>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
-  constexpr int RT = NBT * G;        // rows per kv head in the partial buffers
-  const int g0 = blockIdx.z * GH;
+  constexpr int RT = ML ? 8 * G : NBT * G;   // rows per kv head in the partial buffers
+  const int g0 = ML ? 0 : blockIdx.z * GH;
+  const int lane_row = ML ? blockIdx.z : 0;
   extern __shared__ __align__(16) float att_sh[];
   float* q_sh = att_sh;                       // [R][128]
   float* s_part = q_sh + R * HEAD_DIM;        // [4][R][64]
@@ -560,32 +564,36 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   float* o_part = p_sh + ATT_SPLIT * R;       // [4][R][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kvh = blockIdx.x, split = blockIdx.y;
-  const int T = a.state ? a.state->T : a.T, t0 = split * ATT_SPLIT;
-  if (t0 >= T) return;   // cannot happen while ceil(T/64) matches the launch grid; guards a stale graph
+  const int T = ML ? a.lane_state[lane_row]->T : (a.state ? a.state->T : a.T), t0 = split * ATT_SPLIT;
+  if (t0 >= T) return;   // shorter lane / stale graph: this tile does not exist (the combine skips it as well)
+  const float* kc_l = ML ? a.lane_kc[lane_row] : a.kc;
+  const float* vc_l = ML ? a.lane_vc[lane_row] : a.vc;
+  const uint8_t* bits_l = ML ? a.lane_bits[lane_row] : a.drop_bits;
+  const int span0 = ML ? a.lane_span_start[lane_row] : a.span_start, spanL = ML ? a.lane_span_len[lane_row] : a.span_len;
   const int q_dim = a.n_heads * HEAD_DIM;
   const int nkeys = min(ATT_SPLIT, T - t0);
   const int half = lane >> 5, dq = lane & 31;
 
   // 1. all K / V requests of this wave (addresses clamped to the last live key; dead keys get p = 0)
   const int kt = t0 + min(lane, nkeys - 1);
-  const float* kbase = a.kc + (((size_t)kvh * 32 + wave * 8) * a.T_cap + kt) * 4;
+  const float* kbase = kc_l + (((size_t)kvh * 32 + wave * 8) * a.T_cap + kt) * 4;
   f32x4_t k4[8], v4[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) k4[i] = *(const f32x4_t*)(kbase + (size_t)i * a.T_cap * 4);
-  const float* vbase = a.vc + ((size_t)kvh * a.T_cap + t0) * HEAD_DIM + dq * 4;
+  const float* vbase = vc_l + ((size_t)kvh * a.T_cap + t0) * HEAD_DIM + dq * 4;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     int key = min(wave * 16 + 2 * j + half, nkeys - 1);
     v4[j] = *(const f32x4_t*)(vbase + (size_t)key * HEAD_DIM);
   }
   uint32_t bits = 0;
-  if (a.drop_bits && lane < nkeys) {
+  if (bits_l && lane < nkeys) {
     int ka = t0 + lane;
-    if (ka >= a.span_start && ka < a.span_start + a.span_len) bits = a.drop_bits[ka - a.span_start];
+    if (ka >= span0 && ka < span0 + spanL) bits = bits_l[ka - span0];
   }
   // 2. q rows (r = g*NBT + m) into LDS
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
-    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT, m = r % NBT;
+    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT, m = ML ? lane_row : r % NBT;
     q_sh[i] = (m < a.nb) ? a.qbuf[(size_t)m * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
   }
   __syncthreads();
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 4. softmax statistics of the tile: wave w owns rows r = w, w+4, ...
   const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
   for (int r = wave; r < R; r += 4) {
-    int m = r % NBT;
+    int m = ML ? 0 : r % NBT;       // lanes: bit 0 of the sequence's own (leak) bits
     float sv = (s_part[(0 * R + r) * ATT_SPLIT + lane] + s_part[(1 * R + r) * ATT_SPLIT + lane]) +
                (s_part[(2 * R + r) * ATT_SPLIT + lane] + s_part[(3 * R + r) * ATT_SPLIT + lane]);
     sv *= scaling;
@@ -614,7 +622,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     float l = dd_wave_sum(p);
     p_sh[lane * R + r] = p;
     if (lane == 0) {
-      float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + g0 * NBT + r) * 2;
+      float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + (ML ? r * 8 + lane_row : g0 * NBT + r)) * 2;
       ml[0] = mx;
       ml[1] = l;
     }
@@ -644,14 +652,19 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 6. fixed-order sum over the four waves
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     float o = (o_part[i] + o_part[R * HEAD_DIM + i]) + (o_part[2 * R * HEAD_DIM + i] + o_part[3 * R * HEAD_DIM + i]);
-    a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
+    if (ML) {   // row r of this workgroup is q head g = r of the group: buffer row g * 8 + lane_row
+      int r = i / HEAD_DIM, dd = i % HEAD_DIM;
+      a.part_o[(((size_t)kvh * gridDim.y + split) * RT + r * 8 + lane_row) * HEAD_DIM + dd] = o;
+    } else {
+      a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
+    }
   }
 }
 
 // grid (n_heads, nb), block 128 (thread = d): merges the tiles of one (head, row), adds the row's own new key/value
 // (each ensemble member attends to the shared prefix + ITS OWN new token), packs hi/lo for o_proj.
 template <int NBT, int G>
-__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits) {
+__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits_grid) {
   constexpr int R = NBT * G;
   __shared__ float red[2];
   __shared__ float w_sh[ATT_MAX_SPLITS];
@@ -661,11 +674,14 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
   const float scaling = 0.08838834764831845f;
   const int r = g * NBT + m;
+  // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
+  // has the tiles of its own, possibly shorter, sequence
+  const int splits = a.n_lanes ? (a.lane_state[m]->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid;
   // every load of this block is issued here, before the first dependent use
   float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
   float kd = a.knew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
   float vd = a.vnew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
-  const float* mlb = a.part_ml + ((size_t)kvh * splits * R + r) * 2;
+  const float* mlb = a.part_ml + ((size_t)kvh * splits_grid * R + r) * 2;
   const size_t ml_stride = (size_t)R * 2;
   float ms0 = -INFINITY, ls0 = 0.f, ms1 = -INFINITY, ls1 = 0.f;   // two tiles per thread: up to 256 tiles
   if (d < splits) { ms0 = mlb[d * ml_stride]; ls0 = mlb[d * ml_stride + 1]; }
@@ -685,7 +701,7 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   float w_self = expf(s_self - M);
   float den = w_self + (den_sh[0] + den_sh[1]);
   float num = w_self * vd;
-  const float* po = a.part_o + ((size_t)kvh * splits * R + r) * HEAD_DIM + d;
+  const float* po = a.part_o + ((size_t)kvh * splits_grid * R + r) * HEAD_DIM + d;
   const size_t o_stride = (size_t)R * HEAD_DIM;
   int sp = 0;
   for (; sp + 8 <= splits; sp += 8) {
@@ -716,10 +732,30 @@ static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
   return DD_OK;
 }
 
+// fused base pass of up to 8 sequences: one single-query attention per row, each over its own cache
+template <int G>
+static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
+  constexpr int R = G;
+  int splits = (a.max_T + ATT_SPLIT - 1) / ATT_SPLIT;
+  DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
+  size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
+  k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
+  k_attn_combine<8, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
+  return DD_OK;
+}
+
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
   DD_REQUIRE(a.n_heads % a.n_kv == 0, "attn: heads %d not a multiple of kv heads %d", a.n_heads, a.n_kv);
   int G = a.n_heads / a.n_kv;
   DD_REQUIRE(G == 1 || G == 2 || G == 4, "attn: GQA group %d unsupported (1, 2, 4)", G);
+  if (a.n_lanes > 0) {
+    DD_REQUIRE(a.n_lanes <= 8 && a.nb == a.n_lanes, "attn: %d lanes for %d rows", a.n_lanes, a.nb);
+    if (G == 1) launch_attn_lanes<1>(a, st);
+    else if (G == 2) launch_attn_lanes<2>(a, st);
+    else launch_attn_lanes<4>(a, st);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   bool one = a.nb == 1;
   if (G == 1) one ? launch_attn<1, 1>(a, st) : launch_attn<8, 1>(a, st);
   else if (G == 2) one ? launch_attn<1, 2>(a, st) : launch_attn<8, 2>(a, st);
@@ -1092,6 +1128,43 @@ __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict_
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
                    float* ssq, int ssq_ld, hipStream_t st) {
   k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+// fused base pass of a group: row m embeds the current token of sequence m (rows >= nb are zero)
+__global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __restrict__ embed, int d, EmbedLanes lanes, int nb,
+                                                           float* __restrict__ x, const float* __restrict__ normw,
+                                                           u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld) {
+  __shared__ float sh[8][16];
+  int tok[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) tok[m] = m < nb ? lanes.state[m]->cur_tok : -1;
+  float ss[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < d; i += 1024) {
+    float w = normw[i];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float e = tok[m] >= 0 ? dd_bf16_to_f32(embed[(size_t)tok[m] * d + i]) : 0.f;
+      ss[m] += e * e;
+      x[(size_t)m * d + i] = e;
+      xop_store(xop, i, m, w * e);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    float v = dd_wave_sum(ss[m]);
+    if ((threadIdx.x & 63) == 0) sh[m][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float v = 0.f;
+    for (int i = 0; i < 16; ++i) v += sh[threadIdx.x][i];
+    ssq[(size_t)threadIdx.x * ssq_ld] = v;
+  }
+}
+int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int nb, float* x, const float* normw,
+                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st) {
+  k_embed_rows_lanes<<<1, 1024, 0, st>>>(embed, d, lanes, nb, x, normw, xop, ssq, ssq_ld);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -91,7 +91,7 @@ class DropoutEngine:
     def __init__(self, cfg: LMConfig, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
                  seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
                  iblip_positions: str = "cache", weight_format: str = "bf16", mask_method: str = "epis",
-                 use_avg: bool = False):
+                 use_avg: bool = False, share_weights_with: Optional["DropoutEngine"] = None):
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
@@ -119,13 +119,21 @@ class DropoutEngine:
                            {"bf16": 0, "fp8": 1}[weight_format])
         self.weight_format = weight_format
         self._h = C.c_void_p()
-        _lib.check(self.lib.dd_lm_create(C.byref(c), C.byref(self._h)), "dd_lm_create")
+        self.weight_owner = share_weights_with         # kept alive: a lane borrows the owner's weight memory
+        if share_weights_with is not None:
+            # a lane: another sequence (own KV cache, state, rng stream) over the same weights — see EngineGroup
+            if share_weights_with.weight_owner is not None:
+                share_weights_with = self.weight_owner = share_weights_with.weight_owner
+            _lib.check(self.lib.dd_lm_create_shared(C.byref(c), share_weights_with._h, C.byref(self._h)), "dd_lm_create_shared")
+        else:
+            _lib.check(self.lib.dd_lm_create(C.byref(c), C.byref(self._h)), "dd_lm_create")
         # the reference seeds torch's global generator at import (llava.py:16-20); under chair_test all three
         # modules are imported so 5217 is in force. Default here: the family's own module seed.
         self.rng = TorchCpuCompatRNG(fam["seed"] if seed is None else seed)
         # the engine enqueues on its own (non-default) stream: decode steps can then be captured into hipGraphs, and
         # torch work of the caller (next image's preprocessing) does not interleave with the dependent chain
-        self.torch_stream = torch.cuda.Stream(device=self.device)
+        self.torch_stream = (share_weights_with.torch_stream if share_weights_with is not None
+                             else torch.cuda.Stream(device=self.device))     # lanes of one owner share its stream
         self.L = 0
         self.masked_numbers: List[int] = []
         self._peek_buf = np.zeros(8192, dtype=np.int32)
@@ -360,3 +368,63 @@ class DropoutEngine:
             self.close()
         except Exception:
             pass
+
+
+class EngineGroup:
+    """Up to 8 sequences ("lanes") decoded together over ONE set of weights (dd_lm_group_step).
+
+    The reference decodes one image at a time and shards 500 images over processes, each with its own torch generator
+    (chair_test.py:270-346).  A lane is such a process: its own KV cache, state and rng stream.  Every lane's
+    tokens, masks and logits are bit-identical to decoding it alone; what changes is the cost — the un-masked base
+    passes of all lanes run as one sweep over the weights, so a token costs 1/n + 1 sweeps instead of 2.
+    """
+
+    def __init__(self, engines: Sequence[DropoutEngine]):
+        engines = list(engines)
+        if not 1 <= len(engines) <= 8:
+            raise ValueError("a group holds 1..8 sequences")
+        owner = engines[0].weight_owner or engines[0]
+        for e in engines:
+            if (e.weight_owner or e) is not owner:
+                raise ValueError("all sequences of a group must share one set of weights (share_weights_with=...)")
+        self.engines = engines
+        self.lib = engines[0].lib
+
+    def decode_step(self, mprobs: Optional[Sequence[float]] = None, dropout: bool = True,
+                    active: Optional[Sequence[int]] = None) -> None:
+        """One token for every (active) lane; enqueued without host sync."""
+        lanes = [self.engines[i] for i in (range(len(self.engines)) if active is None else active)]
+        if not lanes:
+            return
+        probs, arr = lanes[0]._probs(mprobs)
+        K = len(probs) if dropout else 0
+        hs = (C.c_void_p * len(lanes))(*[e._h for e in lanes])
+        rs = (C.c_void_p * len(lanes))(*[e.rng.handle for e in lanes])
+        _lib.check(self.lib.dd_lm_group_step(hs, len(lanes), arr, K, rs, lanes[0]._s()), "dd_lm_group_step")
+        for e in lanes:
+            e._last_K = K
+            e._n_enqueued += 1
+
+    def generate(self, n_new: int, eos=None, mprobs=None, dropout: bool = True, lookahead: int = 6) -> List[List[int]]:
+        """Greedy loops of all lanes in lockstep (each lane as DropoutEngine.generate): a lane stops at its EOS or at
+        n_new; the others go on with fewer rows in the fused base pass."""
+        eos_set = set() if eos is None else (set(eos) if isinstance(eos, (list, tuple, set)) else {int(eos)})
+        E = self.engines
+        while True:
+            seen = [e.peek_tokens() for e in E]
+            active = [i for i, e in enumerate(E)
+                      if e._n_enqueued < n_new and not (eos_set and any(t in eos_set for t in seen[i]))]
+            if not active:
+                break
+            if min(E[i]._n_enqueued - len(seen[i]) for i in active) >= lookahead:
+                time.sleep(0.0002)                      # far enough ahead of the GPU
+                continue
+            self.decode_step(mprobs, dropout=dropout, active=active)
+        out = []
+        for e in E:
+            toks = e.tokens()
+            hit = [i for i, t in enumerate(toks) if t in eos_set]
+            if hit:
+                toks = toks[:hit[0] + 1]
+            out.append(toks[:n_new])
+        return out

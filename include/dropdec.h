@@ -342,6 +342,19 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * 8 = replay decode steps from a hipGraph (default 1). */
 int dd_set_tuning(int key, int value);
 
+/* ---- several sequences over one set of weights -------------------------------------------------------------------------
+ * The reference decodes one image at a time (batch 1, chair_test.py:270-346) and, for 500 images, shards them over
+ * processes; every process has its own torch generator.  A "lane" is that: a further sequence with its own KV cache,
+ * state, token mirror and (caller-side) dd_rng, over the weights of an existing handle.  dd_lm_group_step advances n
+ * lanes by one token each; results per lane are bit-identical to dd_lm_decode_step on that lane alone, but the n
+ * un-masked base passes (models/llava.py:294-303 for each image) run as ONE sweep, so the weights are streamed
+ * 1/n + ceil(K/8) times per sequence and token instead of 1 + ceil(K/8) times.
+ *   dd_lm_create_shared: same cfg dimensions as the owner; max_seq must equal the owner's for lanes grouped together.
+ *   dd_lm_group_step: lanes[0..n), n <= 8, all prefilled; rngs[m] is lane m's stream (may be NULL for InstructBLIP's
+ *   deterministic masks or K == 0).  The owner may itself be one of the lanes. */
+int dd_lm_create_shared(const dd_lm_config* cfg, dd_lm* weights_from, dd_lm** out);
+int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream);
+
 /* Measurement hook: stream `n_layers` x `n_phases` weight slabs the way one decode sweep does, either as one launch per
  * phase (mode 0, `grid` workgroups of 512 threads), or as ONE resident kernel with a grid barrier per phase (mode 1), or
  * the same with the next phase's first loads issued before the barrier (mode 2).  ms_out = mean time of one sweep.

@@ -518,3 +518,94 @@ def test_epis_no_overlap_method(E, family, s0):
     rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
     _variant_case(E, family, rc, 48, s0, 32, [0.3, 0.5, 0.7], 6, eng_kw=dict(mask_method="epis_no_overlap"),
                   ref_kw=dict(mask_method="epis_no_overlap"))
+
+
+def _lane_setup(E, family, rc, shapes, seed=7, max_seq=160, **kw):
+    """engines[0] owns the weights; the others are lanes over them.  shapes: (T0, span_start, L) per sequence."""
+    w = random_weights(rc, 31, 0.05)
+    cfg = E.LMConfig(rc.vocab_size, rc.hidden_size, rc.intermediate_size, rc.num_layers, rc.num_heads, rc.num_kv_heads,
+                     rc.head_dim, rc.rms_eps, rc.rope_theta)
+    Lmax = max(s[2] for s in shapes)
+    engines = []
+    for i in range(len(shapes)):
+        e = E.DropoutEngine(cfg, family=family, max_seq=max_seq, max_visual=Lmax, seed=seed,
+                            share_weights_with=engines[0] if engines else None, **kw)
+        engines.append(e)
+    engines[0].load_state_dict(w)
+    embs = [torch.randn(T0, rc.hidden_size, generator=torch.Generator().manual_seed(100 + i)) * 0.8
+            for i, (T0, _, _) in enumerate(shapes)]
+    return w, engines, embs
+
+
+@pytest.mark.parametrize("family,shapes", [
+    (FAMILY_LLAVA, [(40, 3, 30), (70, 5, 50), (33, 1, 30), (66, 2, 60)]),       # lengths either side of a 64-key tile
+    (FAMILY_NEXT, [(90, 4, 80), (50, 4, 40)]),
+    (FAMILY_IBLIP, [(40, 0, 32), (45, 0, 32), (38, 0, 32)]),                    # leaked mask bits per lane
+])
+def test_group_step_each_lane_equals_the_oracle_and_a_solo_run(E, family, shapes):
+    """dd_lm_group_step: the base passes of all lanes are one sweep; every lane must still produce exactly what it
+    produces alone (bit-identical logits) and what the oracle produces (each lane = one reference process, own rng)."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    probs = [0.2, 0.4, 0.6, 0.8]
+    w, engines, embs = _lane_setup(E, family, rc, shapes)
+    for e, emb, (T0, s0, L) in zip(engines, embs, shapes):
+        e.prefill(emb.cuda(), s0, L)
+    grp = E.EngineGroup(engines)
+    n_steps = 6
+    recs = [[] for _ in engines]
+    for s in range(n_steps):
+        grp.decode_step(probs)
+        for i, e in enumerate(engines):
+            st = e.last_step()
+            recs[i].append((st["drop"].copy(), st["member_argmax"].tolist(), st["winner"], e.logits().copy(), e.base_logits().copy()))
+    toks = [e.tokens() for e in engines]
+    sums = [e.kv_sums().copy() for e in engines]
+    for i, ((T0, s0, L), emb) in enumerate(zip(shapes, embs)):
+        ref = RefDecoder(family, rc, w, probs, seed=7)
+        want = ref.generate(emb, s0, L, n_steps + 1)
+        assert toks[i] == want, f"lane {i}"
+        for s, r in enumerate(ref.records):
+            np.testing.assert_array_equal(recs[i][s][0], r.drop, err_msg=f"lane {i} step {s}")
+            assert recs[i][s][1] == r.member_argmax and recs[i][s][2] == r.winner
+            assert close(recs[i][s][3], r.logits) and close(recs[i][s][4], r.base_logits)
+    # solo runs on the same handles (each lane alone, eager + graph paths): bit-identical
+    for i, (e, emb, (T0, s0, L)) in enumerate(zip(engines, embs, shapes)):
+        e.rng.manual_seed(7)
+        e.prefill(emb.cuda(), s0, L)
+        for s in range(n_steps):
+            e.decode_step(probs)
+            np.testing.assert_array_equal(e.logits(), recs[i][s][3])
+            np.testing.assert_array_equal(e.base_logits(), recs[i][s][4])
+        assert e.tokens() == toks[i]
+        np.testing.assert_array_equal(e.kv_sums(), sums[i])
+    for e in reversed(engines):
+        e.close()
+
+
+def test_group_generate_with_uneven_stops_and_stock_greedy(E):
+    """Lanes stop at different times (EOS / n_new); the group goes on with fewer rows.  K = 0 (`--original`) in a group
+    appends each lane's base-row K/V."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    shapes = [(40, 3, 30), (52, 5, 40), (47, 2, 40)]
+    probs = [0.3, 0.5, 0.7]
+    w, engines, embs = _lane_setup(E, FAMILY_LLAVA, rc, shapes)
+    wants = [RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=7).generate(emb, s0, L, 10) for emb, (T0, s0, L) in zip(embs, shapes)]
+    eos = wants[1][3]                                        # lane 1 stops early on this id (others only if they emit it)
+    for e, emb, (T0, s0, L) in zip(engines, embs, shapes):
+        e.prefill(emb.cuda(), s0, L)
+    got = E.EngineGroup(engines).generate(10, eos=[eos], mprobs=probs)
+    for g, wnt in zip(got, wants):
+        cut = wnt[:wnt.index(eos) + 1] if eos in wnt else wnt
+        assert g == cut
+    assert len(got[1]) <= 4
+    # stock greedy
+    for e, emb, (T0, s0, L) in zip(engines, embs, shapes):
+        e.prefill(emb.cuda(), s0, L)
+    got0 = E.EngineGroup(engines).generate(8, dropout=False)
+    for g, emb, (T0, s0, L) in zip(got0, embs, shapes):
+        assert g == RefDecoder(FAMILY_LLAVA, rc, w, [], dropout=False).generate(emb, s0, L, 8)
+    with pytest.raises(ValueError):
+        other = E.DropoutEngine(E.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0), family=FAMILY_LLAVA, max_seq=160, max_visual=40)
+        E.EngineGroup([engines[0], other])
+    for e in reversed(engines):
+        e.close()
