@@ -119,6 +119,9 @@ def main() -> int:
     ap.add_argument("--mode", choices=["replicas", "kshard"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
+    ap.add_argument("--images-per-gpu", type=int, default=8,
+                    help="images decoded concurrently per GPU (lanes over one set of weights, 1..8); 1 = the reference's "
+                         "one-image-at-a-time loop")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,11 +158,23 @@ def main() -> int:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def one(i):
-        ids, px = synthetic_inputs(i, eng.cfg.vocab_size, model.image_token_index)
-        out = model.generate(input_ids=ids.cuda(), pixel_values=px.cuda(), max_new_tokens=args.n_new, eos_token_id=[])
-        assert out.shape[1] == ids.shape[1] + args.n_new
-        return out
+    B = 1 if args.mode == "kshard" else max(1, min(8, args.images_per_gpu))
+    lanes = [model] + [model.spawn_lane() for _ in range(B - 1)]
+    from dropoutdecoding_amd.vlm import generate_group
+
+    def one(i, n_lanes=B):
+        """one step = one batch of n_lanes images through generate(): CLIP + prefill each, then all decoded together"""
+        batch = []
+        for b in range(n_lanes):
+            ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
+            batch.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
+        if n_lanes == 1:
+            outs = [model.generate(**batch[0], max_new_tokens=args.n_new, eos_token_id=[])]
+        else:
+            outs = generate_group(lanes[:n_lanes], batch, max_new_tokens=args.n_new, eos_token_id=[])
+        for o, kw in zip(outs, batch):
+            assert o.shape[1] == kw["input_ids"].shape[1] + args.n_new
+        return outs
 
     img0 = rank * 10_000 if args.mode == "replicas" else 0
     for i in range(args.warmup):
@@ -170,12 +185,23 @@ def main() -> int:
         one(img0 + args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    single = None
+    if B > 1 and rank == 0:            # the same path one image at a time (the reference's loop), for the record
+        one(img0 + 900, 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one(img0 + 901, 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t1
+        single = {"value": round(args.n_new / t1, 2), "unit": "tokens/s", "ms_per_image": round(t1 * 1e3, 1)}
+    if use_dist:
+        torch.distributed.barrier()
     if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     streams = world if args.mode == "replicas" else 1
-    tokens = streams * args.steps * args.n_new
+    tokens = streams * args.steps * args.n_new * B
     value = tokens / dt
 
     # dominant kernel: the gate/up decode GEMV (44 % of the streamed bytes), HIP events on the launch stream
@@ -207,10 +233,13 @@ def main() -> int:
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "LLaVA-1.5-7B Dropout Decoding, 1 synthetic 336x336 image -> 576 visual tokens + 32-token prompt "
-                                   f"(prefill 608), {args.n_new} decoded tokens per image (EOS ignored), K={K_eff} voting_numbers={probs if K_eff else []}, "
-                                   "random-init weights of the real shapes (bf16 weights, fp32 activations/KV)",
-                       "mode": args.mode, "images_per_step_per_gpu": 1, "n_new": args.n_new, "K": K_eff,
+            "config": {"workload": f"LLaVA-1.5-7B Dropout Decoding, {B} synthetic 336x336 image(s) per step and GPU -> each 576 visual tokens + "
+                                   f"32-token prompt (prefill 608), {args.n_new} decoded tokens per image (EOS ignored), K={K_eff} voting_numbers={probs if K_eff else []}, "
+                                   "random-init weights of the real shapes (bf16 weights, fp32 activations/KV)"
+                                   + (f"; the {B} images are {B} independent sequences (own KV cache and rng stream, results identical to "
+                                      "decoding each alone) whose un-masked passes share one sweep over the weights" if B > 1 else ""),
+                       "mode": args.mode, "images_per_step_per_gpu": B, "n_new": args.n_new, "K": K_eff,
+                       "one_image_at_a_time": single,
                        "prefill_included": True, "device_bytes": eng.device_bytes},
             "roofline": {"bound": "hbm", "kernel": "k_gemv<EPI_SILU,2> (gate/up decode GEMV)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

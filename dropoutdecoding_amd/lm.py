@@ -98,6 +98,9 @@ class DropoutEngine:
             raise _lib.DDError("DropoutEngine needs a GPU (MI355X); there is no CPU fallback for the product path")
         self.lib = _lib.load()
         self.cfg, self.family = cfg, family
+        # remembered so that a lane over these weights can be created with the same behaviour (DropoutVLM.spawn_lane)
+        self.max_seq, self.max_visual, self.use_random, self.iblip_positions = max_seq, max_visual, use_random, iblip_positions
+        self.mask_method, self.use_avg = mask_method, use_avg
         fam = dict(_FAMILY[family])
         if family == FAMILY_NEXT and use_random:
             fam["mask_mode"] = MASK_NEXT_NO_OVERLAP           # settings['use_random'][0] (llavanext.py:547-550)
@@ -129,7 +132,8 @@ class DropoutEngine:
             _lib.check(self.lib.dd_lm_create(C.byref(c), C.byref(self._h)), "dd_lm_create")
         # the reference seeds torch's global generator at import (llava.py:16-20); under chair_test all three
         # modules are imported so 5217 is in force. Default here: the family's own module seed.
-        self.rng = TorchCpuCompatRNG(fam["seed"] if seed is None else seed)
+        self.seed = fam["seed"] if seed is None else seed
+        self.rng = TorchCpuCompatRNG(self.seed)
         # the engine enqueues on its own (non-default) stream: decode steps can then be captured into hipGraphs, and
         # torch work of the caller (next image's preprocessing) does not interleave with the dependent chain
         self.torch_stream = (share_weights_with.torch_stream if share_weights_with is not None

@@ -106,10 +106,8 @@ class DropoutVLM:
         return merged, start
 
     # ---- the boundary -------------------------------------------------------------------------
-    @torch.no_grad()
-    def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
-                 max_new_tokens: Optional[int] = None, max_length: Optional[int] = None, num_beams: int = 1,
-                 pad_token_id: Optional[int] = None, eos_token_id=None, do_sample: bool = False, **inputs) -> torch.LongTensor:
+    def _prepare(self, input_ids, max_new_tokens, max_length, num_beams, eos_token_id, do_sample, inputs):
+        """Everything of generate() up to and including the prefill; -> (input_ids on device, n_new, eos ids)."""
         if input_ids is None or input_ids.shape[0] != 1:
             raise ValueError("Dropout Decoding runs batch size 1 with exactly one image per prompt "
                              "(reference models/llava.py:75-76)")
@@ -127,17 +125,42 @@ class DropoutVLM:
         self.start_image_pos, self.end_image_pos = [start], [start + L - 1]
         self.start_generation_pos = embeds.shape[0]
         self.masked_numbers = []
-        eng = self.engine
         # the `# if True:` toggle of llava.py:336-337; never for the stock greedy (`--original`) path
         first = bool(settings.get("first_step_ensemble", False)) and not self.original
-        eng.prefill(embeds, start, L, first_step_ensemble=first)
+        self.engine.prefill(embeds, start, L, first_step_ensemble=first)
         eos = self.eos_token_ids if eos_token_id is None else (
             list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
-        toks = self._decode_loop(max_new_tokens, eos)
+        return input_ids, max_new_tokens, eos
+
+    def _finalize(self, input_ids: torch.Tensor, toks: List[int]) -> torch.LongTensor:
         self.is_first_generation = False
         self._publish_prefill_diagnostics()
         new = torch.tensor([toks], dtype=torch.long, device=input_ids.device)
         return self._format_output(input_ids, new)
+
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 max_new_tokens: Optional[int] = None, max_length: Optional[int] = None, num_beams: int = 1,
+                 pad_token_id: Optional[int] = None, eos_token_id=None, do_sample: bool = False, **inputs) -> torch.LongTensor:
+        input_ids, max_new_tokens, eos = self._prepare(input_ids, max_new_tokens, max_length, num_beams, eos_token_id,
+                                                       do_sample, inputs)
+        toks = self._decode_loop(max_new_tokens, eos)
+        return self._finalize(input_ids, toks)
+
+    # ---- several images at once (lanes) ---------------------------------------------------------
+    def spawn_lane(self) -> "DropoutVLM":
+        """A further sequence over the SAME weights: a shallow copy of this wrapper with its own engine (KV cache, state,
+        rng stream seeded like a fresh process) that borrows this engine's weights.  See generate_group()."""
+        import copy
+        eng = self.engine
+        lane = copy.copy(self)
+        lane.engine = DropoutEngine(eng.cfg, family=eng.family, max_seq=eng.max_seq, max_visual=eng.max_visual,
+                                    seed=eng.seed, use_random=eng.use_random, iblip_positions=eng.iblip_positions,
+                                    weight_format=eng.weight_format, mask_method=eng.mask_method, use_avg=eng.use_avg,
+                                    share_weights_with=eng)
+        lane.start_image_pos, lane.end_image_pos, lane.masked_numbers, lane.logits_mask_prob = [], [], [], []
+        return lane
+
 
     def _decode_loop(self, n_new: int, eos: List[int], chunk: int = 16) -> List[int]:
         eng = self.engine
@@ -180,3 +203,33 @@ def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens:
     max_seq = max_visual + prompt_tokens + max_new_tokens + 8
     return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random,
                          mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)))
+
+
+@torch.no_grad()
+def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens: Optional[int] = None, eos_token_id=None,
+                   num_beams: int = 1, do_sample: bool = False, pad_token_id: Optional[int] = None) -> List[torch.LongTensor]:
+    """`generate()` for up to 8 images at once: models[i] (a wrapper and its spawn_lane() copies) decodes inputs[i].
+
+    Each image is decoded exactly as `models[i].generate(**inputs[i])` would (same tokens, masks, logits; its own rng
+    stream, like one process of the reference's sharded 500-image runs), but all sequences advance together and their
+    un-masked passes share one sweep over the weights (EngineGroup) — the throughput mode for CHAIR-style jobs."""
+    from .lm import EngineGroup
+    if len(models) != len(inputs) or not 1 <= len(models) <= 8:
+        raise ValueError("generate_group: one model lane per input, 1..8 of them")
+    prepared = []
+    for m, kw in zip(models, inputs):
+        kw = dict(kw)
+        kw.pop("attention_mask", None)
+        ids = kw.pop("input_ids", None)
+        mnt = kw.pop("max_new_tokens", max_new_tokens)
+        prepared.append(m._prepare(ids, mnt, kw.pop("max_length", None), num_beams, kw.pop("eos_token_id", eos_token_id),
+                                   do_sample, kw))
+    n_new = {p[1] for p in prepared}
+    eos = prepared[0][2]
+    if len(n_new) != 1 or any(p[2] != eos for p in prepared):
+        raise ValueError("generate_group: all images of a group share max_new_tokens and eos_token_id")
+    dropout = {not m.original for m in models}
+    if len(dropout) != 1:
+        raise ValueError("generate_group: `original` must be the same for all lanes")
+    toks = EngineGroup([m.engine for m in models]).generate(n_new.pop(), eos=eos, dropout=dropout.pop())
+    return [m._finalize(p[0], t) for m, p, t in zip(models, prepared, toks)]

@@ -259,3 +259,48 @@ def test_instructblip_wrapper_with_hf_tiny_model(built):
     ref = RefDecoder(FAMILY_IBLIP, rc, sd, [0.3, 0.5, 0.7])
     assert out[0, 1:].tolist() == ref.generate(emb.cpu(), 0, 32, 7)
     assert m.start_image_pos == [0] and m.end_image_pos == [31] and m.start_generation_pos == 38
+
+
+def test_generate_group_three_images_at_once(built):
+    """spawn_lane() + generate_group(): three images decoded together over one set of weights; each equals its own solo
+    generate() and the oracle started from a fresh rng stream (one reference process per lane)."""
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+    from dropoutdecoding_amd import config as ddc
+    from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
+    from dropoutdecoding_amd.vlm import generate_group, lm_state_dict_from_hf
+    torch.manual_seed(0)
+    vc = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                          image_size=56, patch_size=14, projection_dim=16)
+    tc = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                     num_key_value_heads=2, head_dim=128, max_position_embeddings=512, tie_word_embeddings=False)
+    cfg = LlavaConfig(vision_config=vc, text_config=tc, image_token_index=511, vision_feature_layer=-2,
+                      vision_feature_select_strategy="default")
+    hf = LlavaForConditionalGeneration(cfg).eval()
+    for p_ in hf.parameters():
+        p_.copy_(p_.to(torch.bfloat16).float())
+    for n, p in hf.named_parameters():
+        if "language_model" in n or "lm_head" in n:
+            p.mul_(2.5)
+    sd = _ref_weights_from_engine_sd(lm_state_dict_from_hf(hf))
+    ddc.settings["voting_numbers"] = [0.3, 0.5, 0.7]
+    ddc._module_imported(24)
+    m0 = CustomLlavaForConditionalGeneration.from_hf_model(hf, max_new_tokens=16)
+    lanes = [m0, m0.spawn_lane(), m0.spawn_lane()]
+    assert lanes[1].engine is not m0.engine and lanes[1].engine.weight_owner is m0.engine
+    prompts = [torch.tensor([[1, 17, 511, 45, 6, 7, 99]]), torch.tensor([[1, 511, 8, 9]]), torch.tensor([[1, 3, 4, 5, 511, 77]])]
+    pvs = [torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(10 + i)) for i in range(3)]
+    outs = generate_group(lanes, [dict(input_ids=p, pixel_values=v, attention_mask=torch.ones_like(p)) for p, v in zip(prompts, pvs)],
+                          max_new_tokens=7, eos_token_id=[])
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, tc.rms_norm_eps, 10000.0)
+    for i, (m, p, v, o) in enumerate(zip(lanes, prompts, pvs, outs)):
+        assert o.shape == (1, p.shape[1] + 7) and o[0, :p.shape[1]].tolist() == p[0].tolist()
+        emb, start = m._merge(p.cuda(), m._visual_embeds(pixel_values=v))
+        want = RefDecoder(FAMILY_LLAVA, rc, sd, [0.3, 0.5, 0.7], seed=24).generate(emb.cpu(), start, 16, 7)
+        assert o[0, p.shape[1]:].tolist() == want, f"lane {i}"
+        assert m.start_image_pos == [start] and m.image_features[1].shape == (1, 16, 5)
+    # and the same image through the solo path of a fresh lane
+    solo = m0.spawn_lane()
+    o1 = solo.generate(input_ids=prompts[1], pixel_values=pvs[1], max_new_tokens=7, eos_token_id=[])
+    assert o1.tolist() == outs[1].tolist()
+    with pytest.raises(ValueError):
+        generate_group(lanes, [dict(input_ids=prompts[0], pixel_values=pvs[0])] * 2)
