@@ -33,8 +33,6 @@ struct dd_lm {
   dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
   float* grp_logits = nullptr; // [8][Vpad] base-pass logits of a group step (this handle is the group's first lane)
   int32_t* grp_argmax = nullptr;
-  void** grp_tab = nullptr;    // 16 device pointers: where each sequence's base logits / argmax go
-  void* grp_tab_host[16] = {};
   const float *commit_k = nullptr, *commit_v = nullptr;   // K == 0 group step: this lane's base row in the leader's scratch
   // weights
   std::vector<LayerW> lw;
@@ -217,7 +215,6 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->base_logits, h->Vpad);
   DA(h->grp_logits, (size_t)8 * h->Vpad);
   DA(h->grp_argmax, 8);
-  DA(h->grp_tab, 16);
   DA(h->member_logits, (size_t)MAX_MEMBERS * h->Vpad);
   DA(h->last_logits, h->Vpad);
   DA(h->last_hidden, d);
@@ -848,16 +845,19 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
 // exactly as dd_lm_decode_step does, so every sequence's tokens, masks and logits are those of a run on its own.
 // Per step and sequence the weights are read 1/n + 1 times instead of twice.
 // -----------------------------------------------------------------------------------------------
-__global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, float* const* dst_logits,
-                               int32_t* const* dst_argmax) {
+struct ScatterTab {
+  float* logits[8];
+  int32_t* argmax[8];
+};
+__global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, ScatterTab tab) {
   int m = blockIdx.x;
   const float* src = grp_logits + (size_t)m * Vpad;
-  float* dst = dst_logits[m];
+  float* dst = tab.logits[m];
   for (int i = threadIdx.x; i < Vpad; i += 256) dst[i] = src[i];
-  if (threadIdx.x == 0) dst_argmax[m][0] = grp_argmax[m];
+  if (threadIdx.x == 0) tab.argmax[m][0] = grp_argmax[m];
 }
 
-extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
+static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(lanes && n >= 1 && n <= 8, "dd_lm_group_step: 1..8 sequences per group (got %d)", n);
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_group_step: bad K / mprobs");
@@ -889,15 +889,12 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   h0->bit0 = 0;
   RC(lm_sweep(h0, n, nullptr, 0, h0->grp_logits, st, lanes));
   RC(dd_argmax_rows(h0->grp_logits, n, h0->V, h0->Vpad, h0->grp_argmax, st));
-  // hand every sequence its base row (logits + argmax); pointer tables go through a small pinned staging area
+  // hand every sequence its base row (logits + argmax)
   {
-    for (int m = 0; m < 8; ++m) {
-      h0->grp_tab_host[m] = m < n ? (void*)lanes[m]->base_logits : nullptr;
-      h0->grp_tab_host[8 + m] = m < n ? (void*)lanes[m]->argmax_base : nullptr;
-    }
-    DD_HIP(hipMemcpyAsync(h0->grp_tab, h0->grp_tab_host, sizeof(h0->grp_tab_host), hipMemcpyHostToDevice, st));
-    k_scatter_base<<<n, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, (float* const*)h0->grp_tab,
-                                      (int32_t* const*)(h0->grp_tab + 8));
+    ScatterTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int m = 0; m < n; ++m) tab.logits[m] = lanes[m]->base_logits, tab.argmax[m] = lanes[m]->argmax_base;
+    k_scatter_base<<<n, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
     DD_CHECK_LAUNCH();
   }
   for (int m = 0; m < n; ++m) {
@@ -931,7 +928,8 @@ void dd_engine_set_graph(int on) { g_use_graph = on; }
 
 // One whole ensemble step = ~340 kernel launches.  After the first (eager) step of a sequence the step is captured
 // into a hipGraph and replayed: every launch argument is step-invariant (lengths, positions, tokens and the vote live
-// in device memory), except the number of 64-key attention tiles, which is part of the cache key together with K, the
+// in device memory), except the number of 64-key attention tiles the launch is shaped for (rounded up to 4, so it changes
+// every 256 tokens), which is part of the cache key together with K, the
 // probabilities and the rng.  Host cost per step drops from ~3.4 ms of launches to one hipGraphLaunch.
 extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
   DD_REQUIRE(h, "dd_lm_decode_step: null handle");
@@ -960,7 +958,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
     memcpy(&bits, &mprobs[k], 8);
     mix(bits);
   }
-  mix((unsigned long long)((h->T_host + 63) / 64));
+  mix((unsigned long long)ddk_attn_grid_tiles(h->T_host, h->T_cap));
   mix(((unsigned long long)h->L << 32) | (unsigned)h->span_start);   // launch arguments fixed by the last prefill
   mix((unsigned long long)(uintptr_t)rng);
   mix((unsigned long long)(uintptr_t)st);
@@ -1002,6 +1000,85 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
   if (rc == DD_OK) h->steps_since_prefill++;
   return rc;
+}
+
+// Replays the whole group step (n + 1 sweeps, ~1600 launches) from a hipGraph when nothing but device-side state has
+// changed since it was captured; the cache lives in the first lane.
+extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= 8 && lanes[0] && (K == 0 || mprobs);
+  for (int m = 0; graphable && m < n; ++m)
+    graphable = lanes[m] && lanes[m]->prefilled && lanes[m]->steps_since_prefill >= 1 &&
+                lanes[m]->T_host + 1 < lanes[m]->T_cap && lanes[m]->n_tok_host < MAX_NEW_TOKENS;
+  if (!graphable) return group_step_eager(lanes, n, mprobs, K, rngs, stream_);
+  dd_lm* h0 = lanes[0];
+  unsigned long long key = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+  mix(0x67726f7570ull + (unsigned long long)n);
+  mix((unsigned long long)K);
+  for (int k = 0; k < K; ++k) {
+    unsigned long long bits;
+    memcpy(&bits, &mprobs[k], 8);
+    mix(bits);
+  }
+  int max_T = 0;
+  for (int m = 0; m < n; ++m) {
+    dd_lm* q = lanes[m];
+    mix((unsigned long long)(uintptr_t)q);
+    mix((unsigned long long)(uintptr_t)(rngs ? rngs[m] : nullptr));
+    mix((unsigned long long)ddk_attn_grid_tiles(q->T_host, q->T_cap));
+    mix(((unsigned long long)q->L << 32) | (unsigned)q->span_start);
+    if (q->T_host > max_T) max_T = q->T_host;
+  }
+  mix((unsigned long long)ddk_attn_grid_tiles(max_T, h0->T_cap));
+  mix((unsigned long long)(uintptr_t)st);
+  auto advance = [&]() {
+    for (int m = 0; m < n; ++m) {
+      dd_lm* q = lanes[m];
+      q->last_K = K, q->T_host += 1, q->n_tok_host += 1, q->steps_since_prefill++;
+      if (q->cfg.leak_mask && K > 0) q->have_leak = true;
+    }
+  };
+  for (auto& g : h0->graphs)
+    if (g.key == key) {
+      DD_HIP(hipGraphLaunch(g.exec, st));
+      advance();
+      return DD_OK;
+    }
+  struct Saved {
+    int T, N, K, S;
+    bool leak;
+  } sv[8];
+  for (int m = 0; m < n; ++m)
+    sv[m] = {lanes[m]->T_host, lanes[m]->n_tok_host, lanes[m]->last_K, lanes[m]->steps_since_prefill, lanes[m]->have_leak};
+  auto restore = [&]() {
+    for (int m = 0; m < n; ++m) {
+      dd_lm* q = lanes[m];
+      q->T_host = sv[m].T, q->n_tok_host = sv[m].N, q->last_K = sv[m].K, q->steps_since_prefill = sv[m].S, q->have_leak = sv[m].leak;
+    }
+  };
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return group_step_eager(lanes, n, mprobs, K, rngs, stream_);
+  }
+  int rc = group_step_eager(lanes, n, mprobs, K, rngs, stream_);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  hipGraphExec_t exec = nullptr;
+  if (rc == DD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    if (h0->graphs.size() >= 6) {
+      (void)hipGraphExecDestroy(h0->graphs.front().exec);
+      h0->graphs.erase(h0->graphs.begin());
+    }
+    h0->graphs.push_back({key, exec});
+    DD_HIP(hipGraphLaunch(exec, st));
+    return DD_OK;          // host mirrors were advanced by the captured call
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  restore();               // nothing was executed
+  return group_step_eager(lanes, n, mprobs, K, rngs, stream_);
 }
 
 extern "C" size_t dd_lm_xchg_stride(const dd_lm* h) {

@@ -117,6 +117,7 @@ struct AttnDecodeArgs {
   int lane_span_start[8], lane_span_len[8];
 };
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+int ddk_attn_grid_tiles(int T, int T_cap);   // tiles the decode attention is launched with for a prefix of T keys
 
 // ---- prefill (M rows) -------------------------------------------------------------------------
 int ddk_rmsnorm_split(const float* x, int M, int d, const float* w, float eps, uint16_t* hi, uint16_t* lo,

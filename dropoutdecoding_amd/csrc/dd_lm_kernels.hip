@@ -676,7 +676,8 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   const int r = g * NBT + m;
   // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
   // has the tiles of its own, possibly shorter, sequence
-  const int splits = a.n_lanes ? (a.lane_state[m]->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid;
+  const int splits = a.n_lanes ? (a.lane_state[m]->T + ATT_SPLIT - 1) / ATT_SPLIT
+                               : (a.state ? (a.state->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid);
   // every load of this block is issued here, before the first dependent use
   float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
   float kd = a.knew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
@@ -715,11 +716,20 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
 }
 
+// Key tiles the partial kernel is LAUNCHED with: the live count rounded up to a multiple of 4 (workgroups of tiles past
+// the sequence end return at once), so that the launch shape — and with it a captured hipGraph — stays valid for 256
+// more tokens instead of 64.  The combine takes the live count from the device-side length.
+int ddk_attn_grid_tiles(int T, int T_cap) {
+  int tiles = (T + ATT_SPLIT - 1) / ATT_SPLIT;
+  int up = (tiles + 3) / 4 * 4, cap = T_cap / ATT_SPLIT;
+  return up < cap ? up : (cap > tiles ? cap : tiles);
+}
+
 template <int NBT, int G>
 static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
   constexpr int GH = (NBT * G > 16) ? 2 : G;     // at most 16 rows per workgroup
   constexpr int R = NBT * GH;
-  int splits = (a.T + ATT_SPLIT - 1) / ATT_SPLIT;
+  int splits = ddk_attn_grid_tiles(a.T, a.T_cap);
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
   static bool attr = false;
@@ -736,7 +746,7 @@ static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
 template <int G>
 static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   constexpr int R = G;
-  int splits = (a.max_T + ATT_SPLIT - 1) / ATT_SPLIT;
+  int splits = ddk_attn_grid_tiles(a.max_T, a.T_cap);
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
   k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
