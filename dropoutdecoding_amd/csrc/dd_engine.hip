@@ -199,19 +199,19 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->kc, h->lsk * h->Lyr);
   DA(h->vc, h->lsv * h->Lyr);
   // decode scratch
-  DA(h->xa, 8 * (size_t)d);
-  DA(h->qbuf, 8 * (size_t)h->q_dim);
+  DA(h->xa, 16 * (size_t)d);                 // 16 rows: a member pass of two sequences (dd_lm_group_step)
+  DA(h->qbuf, 16 * (size_t)h->q_dim);
   DA(h->knew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
   DA(h->vnew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
-  DA(h->ssq_a, (size_t)(d / 16) * 8);
-  DA(h->ssq_b, (size_t)(d / 16) * 8);
+  DA(h->ssq_a, (size_t)(d / 16) * 16);
+  DA(h->ssq_b, (size_t)(d / 16) * 16);
   int max_splits = T / 64;
-  DA(h->part_o, (size_t)h->Hkv * max_splits * 8 * G * 128);
-  DA(h->part_ml, (size_t)h->Hkv * max_splits * 8 * G * 2);
+  DA(h->part_o, (size_t)h->Hkv * max_splits * 16 * G * 128);
+  DA(h->part_ml, (size_t)h->Hkv * max_splits * 16 * G * 2);
   DA(h->hidden, (size_t)MAX_MEMBERS * d);
-  DA(h->xop_d, (size_t)h->S_d * 64);
-  DA(h->xop_q, (size_t)h->S_q * 64);
-  DA(h->xop_ff, (size_t)h->S_ff * 64);
+  DA(h->xop_d, (size_t)h->S_d * 64 * 2);     // two operand planes (rows 0-7 / 8-15)
+  DA(h->xop_q, (size_t)h->S_q * 64 * 2);
+  DA(h->xop_ff, (size_t)h->S_ff * 64 * 2);
   DA(h->base_logits, h->Vpad);
   DA(h->grp_logits, (size_t)8 * h->Vpad);
   DA(h->grp_argmax, 8);
@@ -699,7 +699,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     EmbedLanes el;
     memset(&el, 0, sizeof(el));
     for (int m = 0; m < nb; ++m) el.state[m] = lanes[m]->state;
-    RC(ddk_embed_rows_lanes(h->embed, d, el, nb, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+    RC(ddk_embed_rows_lanes(h->embed, d, el, 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   } else {
     RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   }
@@ -840,6 +840,86 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
 }
 
 // -----------------------------------------------------------------------------------------------
+// one 16-row sweep: the K members of sequence A (rows 0..K-1) and of sequence B (rows 8..8+K-1) against ONE pass over the
+// weights.  Scratch is `h`'s (the group's first lane); logits, new K/V rows and hidden rows land in A's and B's own
+// buffers, so that vote and commit run per sequence exactly as after lm_sweep.
+// -----------------------------------------------------------------------------------------------
+static int g_use_graph = 1;    // dd_set_tuning key 8
+static int g_pair_sweeps = 1;  // dd_set_tuning key 9: 16-row member sweeps (two sequences) in dd_lm_group_step
+void dd_engine_set_graph(int on) { g_use_graph = on; }
+void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
+
+static int lm_sweep_pair(dd_lm* h, dd_lm* A, dd_lm* B, int K, hipStream_t st) {
+  const int d = h->d, dff = h->dff;
+  EmbedLanes el;
+  memset(&el, 0, sizeof(el));
+  for (int m = 0; m < K; ++m) el.state[m] = A->state, el.state[8 + m] = B->state;
+  RC(ddk_embed_rows_lanes(h->embed, d, el, 16, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  int ssq_n = 1;
+  for (int l = 0; l < h->Lyr; ++l) {
+    LayerW& w = h->lw[l];
+    float* knewA = A->knew + (size_t)l * MAX_MEMBERS * A->kv_dim;
+    float* vnewA = A->vnew + (size_t)l * MAX_MEMBERS * A->kv_dim;
+    float* knewB = B->knew + (size_t)l * MAX_MEMBERS * B->kv_dim;
+    float* vnewB = B->vnew + (size_t)l * MAX_MEMBERS * B->kv_dim;
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d;
+    a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.qbuf = h->qbuf, a.knew = knewA, a.vnew = vnewA, a.knew2 = knewB, a.vnew2 = vnewB;
+    a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
+    a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = A->state;
+    for (int m = 0; m < 8; ++m) a.state_rows[m] = A->state, a.state_rows[8 + m] = B->state;
+    RC(ddk_gemv16(EPI_QKV, a, st));
+    AttnDecodeArgs t;
+    memset(&t, 0, sizeof(t));
+    t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0;
+    t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
+    t.knew = knewA, t.vnew = vnewA, t.knew2 = knewB, t.vnew2 = vnewB;
+    t.n_lanes = 2, t.lane_groups = 2;
+    dd_lm* qs[2] = {A, B};
+    for (int g = 0; g < 2; ++g) {
+      dd_lm* q = qs[g];
+      t.lane_kc[g] = q->kc + (size_t)l * q->lsk, t.lane_vc[g] = q->vc + (size_t)l * q->lsv, t.lane_state[g] = q->state;
+      t.lane_bits[g] = q->drop_bits, t.lane_span_start[g] = q->span_start, t.lane_span_len[g] = q->L;
+      if (q->T_host > t.max_T) t.max_T = q->T_host;
+    }
+    RC(ddk_attn_decode(t, st));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q;
+    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
+    RC(ddk_gemv16(EPI_RESID, a, st));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d;
+    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.xop_next = h->xop_ff, a.S_next = h->S_ff;
+    RC(ddk_gemv16(EPI_SILU, a, st));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff;
+    a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
+    a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
+    RC(ddk_gemv16(EPI_RESID, a, st));
+    ssq_n = d / 16;
+  }
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d;
+  a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+  a.out = A->member_logits, a.out2 = B->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
+  RC(ddk_gemv16(EPI_STORE, a, st));
+  dd_lm* qs[2] = {A, B};
+  for (int g = 0; g < 2; ++g) {
+    dd_lm* q = qs[g];
+    RC(dd_argmax_rows(q->member_logits, K, q->V, q->Vpad, q->member_tok, st));
+    if (q->cfg.vote_on == DD_VOTE_HIDDEN) {
+      RC(ddk_final_norm_rows(h->xa + (size_t)g * 8 * d, K, d, h->final_norm, h->cfg.rms_eps, q->hidden, st));
+      RC(dd_argmax_rows(q->hidden, K, d, d, q->member_vote, st));
+    }
+  }
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
 // group step: one decode step for each of n sequences that share weights, with the n un-masked base passes packed into
 // ONE sweep (row m = sequence m).  Each sequence then samples its masks from ITS OWN rng stream and runs its K members
 // exactly as dd_lm_decode_step does, so every sequence's tokens, masks and logits are those of a run on its own.
@@ -897,6 +977,8 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     k_scatter_base<<<n, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
     DD_CHECK_LAUNCH();
   }
+  // masks of every sequence first (each from its own rng stream), then the members: two sequences per 16-row sweep where
+  // possible (bf16 weights, K <= 8), the 8-row sweep otherwise
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
     q->last_K = K;
@@ -904,6 +986,21 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
       RC(dd_overlap_keep_from_argmax(q->argmax_base, q->topk_ids, q->L, q->cfg.k_top, q->keep, st));
       RC(dd_sample_masks_impl(q->epi, q->L, mprobs, K, q->keep, q->cfg.mask_mode, DD_RNG_MT19937, nullptr,
                               dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits, st));
+    }
+  }
+  const bool pairs = g_pair_sweeps && K > 0 && K <= 8 && !h0->fp8;
+  for (int m = 0; m < n; ++m) {
+    dd_lm* q = lanes[m];
+    if (K > 0) {
+      if (pairs && m + 1 < n) {
+        RC(lm_sweep_pair(h0, q, lanes[m + 1], K, st));
+        for (int j = 0; j < 2; ++j) {
+          RC(dd_lm_step_commit(lanes[m + j], K, stream_));
+          lanes[m + j]->steps_since_prefill++;
+        }
+        ++m;
+        continue;
+      }
       RC(dd_lm_step_members(q, 0, K, stream_));
     } else {
       // stock greedy: the base row's new K/V (in the leader's scratch, row m) is what gets appended
@@ -923,8 +1020,7 @@ static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng,
   return dd_lm_step_commit(h, K, stream);
 }
 
-static int g_use_graph = 1;   // dd_set_tuning key 8
-void dd_engine_set_graph(int on) { g_use_graph = on; }
+
 
 // One whole ensemble step = ~340 kernel launches.  After the first (eager) step of a sequence the step is captured
 // into a hipGraph and replayed: every launch argument is step-invariant (lengths, positions, tokens and the vote live
@@ -1284,8 +1380,9 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 4) || key == 8, "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4) || key == 8 || key == 9, "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
+  else if (key == 9) dd_engine_set_pairs(value);
   else ddk_set_tuning(key, value);
   return DD_OK;
 }

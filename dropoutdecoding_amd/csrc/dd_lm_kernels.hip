@@ -537,6 +537,216 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
 }
 
 // ===============================================================================================
+// decode GEMV, 16 rows: two groups of 8 rows (e.g. the members of two sequences) against ONE pass over the weights.
+// Same tiles, same k order and the same fixed-order reduction per output as k_gemv, so a row's result does not depend
+// on which of the two kernels computed it; the second group's B operand is a second plane of the packed operand and
+// costs a second MFMA per tile step (the kernel is HBM-bound, the MFMA pipe is idle either way).
+// ===============================================================================================
+__device__ __forceinline__ void xop_store16(u32x4_t* xop, int k, int m, float y, int S) {
+  xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y);
+}
+
+template <int EPI, int TILES>
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv16(GemvArgs a) {
+  constexpr int U = 4;
+  __shared__ float red[TILES * 2 * GEMV_WAVES * 256];
+  __shared__ float rstd_sh[16];
+  __shared__ float ssq_sh[16 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S, spw = S / GEMV_WAVES;
+  const int tile0 = blockIdx.x * TILES;
+  f32x4_t acc[TILES][2];
+  const u32x4_t* wp[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    acc[t][0] = acc[t][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    wp[t] = a.W + ((size_t)(tile0 + t) * S + wave) * 64 + lane;
+  }
+  const u32x4_t* xp0 = a.xop + (size_t)wave * 64 + lane;
+  const u32x4_t* xp1 = xp0 + (size_t)S * 64;
+
+  // folded RMSNorm: wave w assembles rows w and w + 8
+  f32x4_t sv0 = {0.f, 0.f, 0.f, 0.f}, sv1 = {0.f, 0.f, 0.f, 0.f};
+  if (a.ssq_in && 4 * lane < a.ssq_n) {
+    sv0 = *(const f32x4_t*)(a.ssq_in + (size_t)wave * a.ssq_ld + 4 * lane);
+    sv1 = *(const f32x4_t*)(a.ssq_in + (size_t)(wave + 8) * a.ssq_ld + 4 * lane);
+  }
+  // epilogue thread t < 256: group t >> 7, row m = 8 * group + (t & 7), column n = (t & 127) >> 3
+  const int et = threadIdx.x, em = ((et >> 7) << 3) + (et & 7), en = (et & 127) >> 3;
+  const bool erow = et < 256 && (et & 7) < a.nb;
+  float pre0 = 0.f, pre1 = 0.f;
+  if (erow) {
+    if (EPI == EPI_RESID) {
+      pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
+      pre1 = a.normw_next[tile0 * 16 + en];
+    } else if (EPI == EPI_QKV) {
+      if (tile0 < a.q_tiles + a.k_tiles) {
+        int ht = tile0 < a.q_tiles ? tile0 : tile0 - a.q_tiles;
+        int f = (ht & 7) * 8 + (en & 7);
+        const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+        int pos = sp->pos;
+        pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
+        pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+      }
+    }
+  }
+  if (a.ssq_in) {
+    const int i0 = 4 * lane;
+    float v0 = 0.f, v1 = 0.f;
+    if (i0 < a.ssq_n) v0 += sv0.x, v1 += sv1.x;
+    if (i0 + 1 < a.ssq_n) v0 += sv0.y, v1 += sv1.y;
+    if (i0 + 2 < a.ssq_n) v0 += sv0.z, v1 += sv1.z;
+    if (i0 + 3 < a.ssq_n) v0 += sv0.w, v1 += sv1.w;
+    for (int i = lane + 256; i < a.ssq_n; i += 64) {
+      v0 += a.ssq_in[(size_t)wave * a.ssq_ld + i];
+      v1 += a.ssq_in[(size_t)(wave + 8) * a.ssq_ld + i];
+    }
+    v0 = dd_wave_sum(v0);
+    v1 = dd_wave_sum(v1);
+    if (lane == 0) {
+      rstd_sh[wave] = 1.0f / sqrtf(v0 * a.inv_k + a.eps);
+      rstd_sh[wave + 8] = 1.0f / sqrtf(v1 * a.inv_k + a.eps);
+    }
+  }
+
+  int s = 0;
+  for (; s + U <= spw; s += U) {
+    u32x4_t b0[U], b1[U], w[TILES][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * GEMV_WAVES * 64);
+      b0[u] = xp0[(size_t)(s + u) * GEMV_WAVES * 64];
+      b1[u] = xp1[(size_t)(s + u) * GEMV_WAVES * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                            __builtin_bit_cast(bf16x8_t, b0[u]), acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                            __builtin_bit_cast(bf16x8_t, b1[u]), acc[t][1], 0, 0, 0);
+      }
+  }
+  if (s < spw) {
+    const int rem = spw - s;
+    u32x4_t b0[U], b1[U], w[TILES][U];
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * GEMV_WAVES * 64);
+        b0[u] = xp0[(size_t)(s + u) * GEMV_WAVES * 64];
+        b1[u] = xp1[(size_t)(s + u) * GEMV_WAVES * 64];
+      }
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                              __builtin_bit_cast(bf16x8_t, b0[u]), acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                              __builtin_bit_cast(bf16x8_t, b1[u]), acc[t][1], 0, 0, 0);
+        }
+      }
+  }
+
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) *(f32x4_t*)&red[((t * 2 + g) * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t][g];
+  __syncthreads();
+
+  const int eg = et >> 7, ml = et & 7;       // group and row within the group of this epilogue thread
+  auto tile_sum = [&](int tt, int n) -> float {
+    float y = 0.f;
+    int o = ((n >> 2) * 16 + ml) * 4 + (n & 3);
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; ++w) {
+      const float* r = &red[((tt * 2 + eg) * GEMV_WAVES + w) * 256];
+      y += r[o] + r[o + 32];
+    }
+    return y;
+  };
+
+  if (EPI == EPI_STORE) {
+    if (erow) {
+      float y = tile_sum(0, en);
+      if (a.ssq_in) y *= rstd_sh[em];
+      int col = tile0 * 16 + en;
+      float* row = (eg && a.out2) ? a.out2 + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
+      if (col < a.n_valid) row[col] = y;
+    }
+  } else if (EPI == EPI_RESID) {
+    float sq = 0.f;
+    if (erow) {
+      float y = tile_sum(0, en);
+      int col = tile0 * 16 + en;
+      float xn = pre0 + y;
+      a.out[(size_t)em * a.ldo + col] = xn;
+      xop_store16(a.xop_next, col, em, pre1 * xn, a.S_next);
+      sq = xn * xn;
+    }
+    if (et < 256) ssq_sh[en * 16 + em] = sq;
+    __syncthreads();
+    if (et < 16) {
+      float v = 0.f;
+      for (int i = 0; i < 16; ++i) v += ssq_sh[i * 16 + et];
+      a.ssq_out[(size_t)et * a.ssq_ld + blockIdx.x] = v;
+    }
+  } else if (EPI == EPI_SILU) {
+    if (erow) {
+      float g = tile_sum(0, en), u = tile_sum(TILES - 1, en);
+      if (a.ssq_in) {
+        g *= rstd_sh[em];
+        u *= rstd_sh[em];
+      }
+      float act = g / (1.0f + expf(-g));  // silu
+      xop_store16(a.xop_next, blockIdx.x * 16 + en, em, act * u, a.S_next);
+    }
+  } else {  // EPI_QKV
+    if (erow) {
+      float y = tile_sum(0, en);
+      if (a.ssq_in) y *= rstd_sh[em];
+      int nt = tile0;
+      float* kn = (eg && a.knew2) ? a.knew2 + (size_t)ml * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
+      float* vn = (eg && a.vnew2) ? a.vnew2 + (size_t)ml * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+      if (nt < a.q_tiles + a.k_tiles) {
+        float yp = tile_sum(0, en ^ 8);
+        if (a.ssq_in) yp *= rstd_sh[em];
+        bool is_q = nt < a.q_tiles;
+        int ht = is_q ? nt : nt - a.q_tiles;
+        int head = ht >> 3, f = (ht & 7) * 8 + (en & 7);
+        float c = pre0, sn = pre1;
+        float o = (en < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
+        int i = (en < 8) ? f : ROPE_HALF + f;
+        if (is_q) a.qbuf[(size_t)em * a.q_dim + head * HEAD_DIM + i] = o;
+        else kn[head * HEAD_DIM + i] = o;
+      } else {
+        int col = (nt - a.q_tiles - a.k_tiles) * 16 + en;
+        vn[col] = y;
+      }
+    }
+  }
+}
+
+int ddk_gemv16(int epi, const GemvArgs& a, hipStream_t st) {
+  DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv16: K=%d must be a multiple of 256", a.S * 32);
+  DD_REQUIRE(a.nb >= 1 && a.nb <= 8 && !a.fp8, "gemv16: nb=%d rows per group, bf16 weights only", a.nb);
+  switch (epi) {
+    case EPI_STORE: k_gemv16<EPI_STORE, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    case EPI_RESID: k_gemv16<EPI_RESID, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    case EPI_SILU: k_gemv16<EPI_SILU, 2><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    case EPI_QKV: k_gemv16<EPI_QKV, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
+    default: DD_REQUIRE(false, "gemv16: unknown epilogue %d", epi);
+  }
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// ===============================================================================================
 // decode attention: partial (one wave per kv head x 64-key split) + combine
 // ===============================================================================================
 #define ATT_SPLIT 64
@@ -549,14 +759,22 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
 // GH = q heads of the GQA group handled by one workgroup (blockIdx.z picks the slice): 32 rows per workgroup (8 members
 // x 4 heads) need 122 KiB of LDS and 156 VGPRs, i.e. one workgroup per CU; two slices of 16 rows run two per CU and
 // read the K/V tile twice through L2.
-// ML (lanes): NBT == 1 and GH == G; blockIdx.z is the ROW of the pass = the sequence whose cache this workgroup reads;
-// results go to the 8-rows-per-head layout the 8-row combine reads.
+// ML == 1 (lanes): NBT == 1 and GH == G; blockIdx.z is the ROW of the pass = the sequence whose cache this workgroup
+// reads; results go to the 8-rows-per-head layout the 8-row combine reads.
+// ML == 2 (two groups): NBT == 8; blockIdx.z = group * (G / GH) + GQA slice; group g's 8 rows (members of sequence g) read
+// that sequence's cache and drop bits; results go to a 16-rows-per-head layout (row = 8 * group + member).
 template <int NBT, int G, int GH, int ML = 0>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
-  constexpr int RT = ML ? 8 * G : NBT * G;   // rows per kv head in the partial buffers
-  const int g0 = ML ? 0 : blockIdx.z * GH;
-  const int lane_row = ML ? blockIdx.z : 0;
+  constexpr int RT = ML == 1 ? 8 * G : (ML == 2 ? 16 * G : NBT * G);   // rows per kv head in the partial buffers
+  const int g0 = ML == 1 ? 0 : (ML == 2 ? (blockIdx.z % (G / GH)) * GH : blockIdx.z * GH);
+  const int lane_row = ML == 1 ? blockIdx.z : (ML == 2 ? blockIdx.z / (G / GH) : 0);
+  // partial-buffer row of this workgroup's row r (= local head r / NBT, member r % NBT)
+  auto buf_row = [&](int r) -> int {
+    if (ML == 1) return r * 8 + lane_row;
+    if (ML == 2) return (g0 + r / NBT) * 16 + lane_row * 8 + r % NBT;
+    return g0 * NBT + r;
+  };
   extern __shared__ __align__(16) float att_sh[];
   float* q_sh = att_sh;                       // [R][128]
   float* s_part = q_sh + R * HEAD_DIM;        // [4][R][64]
@@ -593,8 +811,10 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   }
   // 2. q rows (r = g*NBT + m) into LDS
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
-    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT, m = ML ? lane_row : r % NBT;
-    q_sh[i] = (m < a.nb) ? a.qbuf[(size_t)m * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
+    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT;
+    int m = ML == 1 ? lane_row : r % NBT;                 // row within its group (live if < nb)
+    int qrow = ML == 2 ? lane_row * 8 + m : m;            // row of the pass
+    q_sh[i] = (m < a.nb) ? a.qbuf[(size_t)qrow * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
   }
   __syncthreads();
   // 3. partial scores over this wave's 32 d values
@@ -612,7 +832,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 4. softmax statistics of the tile: wave w owns rows r = w, w+4, ...
   const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
   for (int r = wave; r < R; r += 4) {
-    int m = ML ? 0 : r % NBT;       // lanes: bit 0 of the sequence's own (leak) bits
+    int m = ML == 1 ? 0 : r % NBT;  // lanes: bit 0 of the sequence's own (leak) bits; groups: the member's bit
     float sv = (s_part[(0 * R + r) * ATT_SPLIT + lane] + s_part[(1 * R + r) * ATT_SPLIT + lane]) +
                (s_part[(2 * R + r) * ATT_SPLIT + lane] + s_part[(3 * R + r) * ATT_SPLIT + lane]);
     sv *= scaling;
@@ -622,7 +842,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     float l = dd_wave_sum(p);
     p_sh[lane * R + r] = p;
     if (lane == 0) {
-      float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + (ML ? r * 8 + lane_row : g0 * NBT + r)) * 2;
+      float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * 2;
       ml[0] = mx;
       ml[1] = l;
     }
@@ -652,9 +872,9 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 6. fixed-order sum over the four waves
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     float o = (o_part[i] + o_part[R * HEAD_DIM + i]) + (o_part[2 * R * HEAD_DIM + i] + o_part[3 * R * HEAD_DIM + i]);
-    if (ML) {   // row r of this workgroup is q head g = r of the group: buffer row g * 8 + lane_row
+    if (ML) {
       int r = i / HEAD_DIM, dd = i % HEAD_DIM;
-      a.part_o[(((size_t)kvh * gridDim.y + split) * RT + r * 8 + lane_row) * HEAD_DIM + dd] = o;
+      a.part_o[(((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * HEAD_DIM + dd] = o;
     } else {
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
     }
@@ -676,12 +896,15 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   const int r = g * NBT + m;
   // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
   // has the tiles of its own, possibly shorter, sequence
-  const int splits = a.n_lanes ? (a.lane_state[m]->T + ATT_SPLIT - 1) / ATT_SPLIT
+  const int splits = a.n_lanes ? (a.lane_state[a.lane_groups == 2 ? m >> 3 : m]->T + ATT_SPLIT - 1) / ATT_SPLIT
                                : (a.state ? (a.state->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid);
+  const bool second = NBT == 16 && m >= 8;            // row of the second group (16-row passes)
+  const float* knew_r = (second && a.knew2) ? a.knew2 + (size_t)(m - 8) * kv_dim : a.knew + (size_t)m * kv_dim;
+  const float* vnew_r = (second && a.vnew2) ? a.vnew2 + (size_t)(m - 8) * kv_dim : a.vnew + (size_t)m * kv_dim;
   // every load of this block is issued here, before the first dependent use
   float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
-  float kd = a.knew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
-  float vd = a.vnew[(size_t)m * kv_dim + kvh * HEAD_DIM + d];
+  float kd = knew_r[kvh * HEAD_DIM + d];
+  float vd = vnew_r[kvh * HEAD_DIM + d];
   const float* mlb = a.part_ml + ((size_t)kvh * splits_grid * R + r) * 2;
   const size_t ml_stride = (size_t)R * 2;
   float ms0 = -INFINITY, ls0 = 0.f, ms1 = -INFINITY, ls1 = 0.f;   // two tiles per thread: up to 256 tiles
@@ -713,7 +936,8 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
     for (int u = 0; u < 8; ++u) num += w_sh[sp + u] * o[u];
   }
   for (; sp < splits; ++sp) num += w_sh[sp] * po[(size_t)sp * o_stride];
-  xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
+  if (NBT == 16) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5);
+  else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
 }
 
 // Key tiles the partial kernel is LAUNCHED with: the live count rounded up to a multiple of 4 (workgroups of tiles past
@@ -754,10 +978,36 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   return DD_OK;
 }
 
+// 16-row pass: members of two sequences (8 rows each), every group over its own cache
+template <int G>
+static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
+  constexpr int GH = (8 * G > 16) ? 2 : G;
+  constexpr int R = 8 * GH;
+  int splits = ddk_attn_grid_tiles(a.max_T, a.T_cap);
+  DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
+  size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<8, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  k_attn_partial<8, G, GH, 2><<<dim3(a.n_kv, splits, 2 * (G / GH)), 256, smem, st>>>(a);
+  k_attn_combine<16, G><<<dim3(a.n_heads, 16), HEAD_DIM, 0, st>>>(a, splits);
+  return DD_OK;
+}
+
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
   DD_REQUIRE(a.n_heads % a.n_kv == 0, "attn: heads %d not a multiple of kv heads %d", a.n_heads, a.n_kv);
   int G = a.n_heads / a.n_kv;
   DD_REQUIRE(G == 1 || G == 2 || G == 4, "attn: GQA group %d unsupported (1, 2, 4)", G);
+  if (a.n_lanes > 0 && a.lane_groups == 2) {
+    DD_REQUIRE(a.n_lanes == 2 && a.nb >= 1 && a.nb <= 8, "attn: a 16-row pass takes two sequences of up to 8 members");
+    if (G == 1) launch_attn_groups<1>(a, st);
+    else if (G == 2) launch_attn_groups<2>(a, st);
+    else launch_attn_groups<4>(a, st);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   if (a.n_lanes > 0) {
     DD_REQUIRE(a.n_lanes <= 8 && a.nb == a.n_lanes, "attn: %d lanes for %d rows", a.n_lanes, a.nb);
     if (G == 1) launch_attn_lanes<1>(a, st);
@@ -1141,40 +1391,46 @@ int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x,
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-// fused base pass of a group: row m embeds the current token of sequence m (rows >= nb are zero)
-__global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __restrict__ embed, int d, EmbedLanes lanes, int nb,
+// row m embeds the current token of sequence lanes.state[m] (null: a zero row).  ROWS = 8: fused base pass of a group;
+// ROWS = 16: member pass of two sequences (rows 0-7 / 8-15), second operand plane for rows 8..15.
+template <int ROWS>
+__global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __restrict__ embed, int d, EmbedLanes lanes,
                                                            float* __restrict__ x, const float* __restrict__ normw,
                                                            u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld) {
-  __shared__ float sh[8][16];
-  int tok[8];
+  __shared__ float sh[ROWS][16];
+  int tok[ROWS];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) tok[m] = m < nb ? lanes.state[m]->cur_tok : -1;
-  float ss[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < ROWS; ++m) tok[m] = lanes.state[m] ? lanes.state[m]->cur_tok : -1;
+  float ss[ROWS];
+#pragma unroll
+  for (int m = 0; m < ROWS; ++m) ss[m] = 0.f;
   for (int i = threadIdx.x; i < d; i += 1024) {
     float w = normw[i];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < ROWS; ++m) {
       float e = tok[m] >= 0 ? dd_bf16_to_f32(embed[(size_t)tok[m] * d + i]) : 0.f;
       ss[m] += e * e;
       x[(size_t)m * d + i] = e;
-      xop_store(xop, i, m, w * e);
+      if (ROWS == 16) xop_store16(xop, i, m, w * e, d >> 5);
+      else xop_store(xop, i, m, w * e);
     }
   }
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
+  for (int m = 0; m < ROWS; ++m) {
     float v = dd_wave_sum(ss[m]);
     if ((threadIdx.x & 63) == 0) sh[m][threadIdx.x >> 6] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x < ROWS) {
     float v = 0.f;
     for (int i = 0; i < 16; ++i) v += sh[threadIdx.x][i];
     ssq[(size_t)threadIdx.x * ssq_ld] = v;
   }
 }
-int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int nb, float* x, const float* normw,
+int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
                          u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st) {
-  k_embed_rows_lanes<<<1, 1024, 0, st>>>(embed, d, lanes, nb, x, normw, xop, ssq, ssq_ld);
+  if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
+  else k_embed_rows_lanes<8><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
