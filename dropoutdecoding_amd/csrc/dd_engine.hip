@@ -1336,8 +1336,14 @@ extern "C" int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms, voi
 extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms, double* bytes_per_launch,
                                void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && nb >= 1 && nb <= 8 && iters >= 1,
-             "dd_lm_time_gemv: bad arguments");
+  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16) && iters >= 1,
+             "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 = the two-group kernel)");
+  const bool wide = nb == 16 && !h->fp8;
+  if (nb == 16) nb = 8;
+  auto gemv = [&](int epi, GemvArgs& a) -> int {
+    a.S_next = epi == EPI_SILU ? h->S_ff : h->S_d;
+    return wide ? ddk_gemv16(epi, a, st) : ddk_gemv(epi, a, st);
+  };
   const int d = h->d, dff = h->dff;
   auto launch = [&](int l) -> int {
     LayerW& w = h->lw[l % h->Lyr];
@@ -1349,19 +1355,19 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
         a.W = w.wqkv, a.wscale = w.s_qkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.ssq_in = h->ssq_a, a.ssq_n = d / 16, a.ssq_ld = d / 16;
         a.qbuf = h->qbuf, a.knew = h->knew, a.vnew = h->vnew, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
         a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
-        return ddk_gemv(EPI_QKV, a, st);
+        return gemv(EPI_QKV, a);
       case 1:
         a.W = w.wo, a.wscale = w.s_o, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.out = h->xa, a.ldo = d;
         a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
-        return ddk_gemv(EPI_RESID, a, st);
+        return gemv(EPI_RESID, a);
       case 2:
         a.W = w.wgu, a.wscale = w.s_gu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16;
         a.xop_next = h->xop_ff;
-        return ddk_gemv(EPI_SILU, a, st);
+        return gemv(EPI_SILU, a);
       default:
         a.W = w.wdown, a.wscale = w.s_down, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.out = h->xa, a.ldo = d;
         a.normw_next = w.norm1, a.xop_next = h->xop_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
-        return ddk_gemv(EPI_RESID, a, st);
+        return gemv(EPI_RESID, a);
     }
   };
   for (int i = 0; i < h->Lyr; ++i) RC(launch(i));  // warm (also evicts)

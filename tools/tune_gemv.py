@@ -11,15 +11,14 @@ emb = torch.randn(672, 4096, device="cuda")
 eng.prefill(emb, 5, 576)
 L = _lib.load()
 rows = []
-for u, nt, il, dg in [(8, 0, 1, 0), (8, 0, 1, 64), (8, 0, 1, 32), (8, 0, 1, 0), (8, 0, 1, 64), (8, 0, 1, 32)]:
-    L.dd_set_tuning(0, u); L.dd_set_tuning(4, nt); L.dd_set_tuning(3, dg)
-    r = {"U": u, "RING": nt, "DIAG": dg}
+for nb, dg in [(8, 0), (16, 0), (1, 0)]:
+    L.dd_set_tuning(3, dg)
+    r = {"rows": nb, "DIAG": dg}
     for which, name in ((0, "qkv"), (1, "o"), (2, "gateup"), (3, "down")):
-        best = 0
+        best = 1e9
         for _ in range(3):
-            ms, by = eng.time_gemv(which, 8, 96)
-            best = max(best, by / ms / 1e6)
-        r[name] = round(best)
-    r["sweep8_ms"] = round(min(eng.time_sweep(8, 5) for _ in range(3)), 3)
-    rows.append(r)
+            ms, by = eng.time_gemv(which, nb, 96)
+            best = min(best, ms)
+        r[name + "_us"] = round(best * 1e3, 2)
     print(json.dumps(r), flush=True)
+L.dd_set_tuning(3, 0)
