@@ -209,9 +209,9 @@ def main() -> int:
     K_eff = 0 if args.original else len(probs)
     rows8 = min(max(K_eff, 1), 8)
     wide = B > 1 and 1 <= K_eff <= 8
-    dom_rows = 16 if wide else rows8
-    dom_name = "k_gemv16<EPI_SILU,2> (gate/up decode GEMV, 16 rows = the members of two sequences)" if wide \
-        else "k_gemv<EPI_SILU,2> (gate/up decode GEMV)"
+    dom_rows = (32 if B >= 4 else 16) if wide else rows8
+    dom_name = (f"k_gemv_groups<EPI_SILU,2,{dom_rows // 8}> (gate/up decode GEMV, {dom_rows} rows = the members of "
+                f"{dom_rows // 8} sequences)") if wide else "k_gemv<EPI_SILU,2> (gate/up decode GEMV)"
     ms, by = eng.time_gemv(2, dom_rows, 96)
     achieved = by / (ms * 1e-3) / 1e9
     sweep_ms = eng.time_sweep(rows8, 5)
@@ -230,7 +230,7 @@ def main() -> int:
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
         for name, v in pm["kernels"].items():
-            if name.startswith("void k_gemv16<2, 2" if wide else "void k_gemv<2, 2"):
+            if name.startswith(f"void k_gemv_groups<2, 2, {dom_rows // 8}" if wide else "void k_gemv<2, 2"):
                 traffic = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
     except Exception:
         pass

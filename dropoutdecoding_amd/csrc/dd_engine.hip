@@ -199,19 +199,19 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->kc, h->lsk * h->Lyr);
   DA(h->vc, h->lsv * h->Lyr);
   // decode scratch
-  DA(h->xa, 16 * (size_t)d);                 // 16 rows: a member pass of two sequences (dd_lm_group_step)
-  DA(h->qbuf, 16 * (size_t)h->q_dim);
+  DA(h->xa, 32 * (size_t)d);                 // up to 32 rows: a member pass of four sequences (dd_lm_group_step)
+  DA(h->qbuf, 32 * (size_t)h->q_dim);
   DA(h->knew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
   DA(h->vnew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
-  DA(h->ssq_a, (size_t)(d / 16) * 16);
-  DA(h->ssq_b, (size_t)(d / 16) * 16);
+  DA(h->ssq_a, (size_t)(d / 16) * 32);
+  DA(h->ssq_b, (size_t)(d / 16) * 32);
   int max_splits = T / 64;
-  DA(h->part_o, (size_t)h->Hkv * max_splits * 16 * G * 128);
-  DA(h->part_ml, (size_t)h->Hkv * max_splits * 16 * G * 2);
+  DA(h->part_o, (size_t)h->Hkv * max_splits * 32 * G * 128);
+  DA(h->part_ml, (size_t)h->Hkv * max_splits * 32 * G * 2);
   DA(h->hidden, (size_t)MAX_MEMBERS * d);
-  DA(h->xop_d, (size_t)h->S_d * 64 * 2);     // two operand planes (rows 0-7 / 8-15)
-  DA(h->xop_q, (size_t)h->S_q * 64 * 2);
-  DA(h->xop_ff, (size_t)h->S_ff * 64 * 2);
+  DA(h->xop_d, (size_t)h->S_d * 64 * 4);     // four operand planes (8 rows each)
+  DA(h->xop_q, (size_t)h->S_q * 64 * 4);
+  DA(h->xop_ff, (size_t)h->S_ff * 64 * 4);
   DA(h->base_logits, h->Vpad);
   DA(h->grp_logits, (size_t)8 * h->Vpad);
   DA(h->grp_argmax, 8);
@@ -840,75 +840,73 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
 }
 
 // -----------------------------------------------------------------------------------------------
-// one 16-row sweep: the K members of sequence A (rows 0..K-1) and of sequence B (rows 8..8+K-1) against ONE pass over the
-// weights.  Scratch is `h`'s (the group's first lane); logits, new K/V rows and hidden rows land in A's and B's own
+// one multi-group sweep: the K members of ng = 2 or 4 sequences (group g = rows 8g..8g+K-1) against ONE pass over the
+// weights.  Scratch is `h`'s (the group's first lane); logits, new K/V rows and hidden rows land in each sequence's own
 // buffers, so that vote and commit run per sequence exactly as after lm_sweep.
 // -----------------------------------------------------------------------------------------------
 static int g_use_graph = 1;    // dd_set_tuning key 8
-static int g_pair_sweeps = 1;  // dd_set_tuning key 9: 16-row member sweeps (two sequences) in dd_lm_group_step
+static int g_pair_sweeps = 4;  // dd_set_tuning key 9: sequences per member sweep in dd_lm_group_step (0/1: one, 2, 4)
 void dd_engine_set_graph(int on) { g_use_graph = on; }
 void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
 
-static int lm_sweep_pair(dd_lm* h, dd_lm* A, dd_lm* B, int K, hipStream_t st) {
+static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st) {
   const int d = h->d, dff = h->dff;
   EmbedLanes el;
   memset(&el, 0, sizeof(el));
-  for (int m = 0; m < K; ++m) el.state[m] = A->state, el.state[8 + m] = B->state;
-  RC(ddk_embed_rows_lanes(h->embed, d, el, 16, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  for (int g = 0; g < ng; ++g)
+    for (int m = 0; m < K; ++m) el.state[8 * g + m] = qs[g]->state;
+  RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * ng, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
-    float* knewA = A->knew + (size_t)l * MAX_MEMBERS * A->kv_dim;
-    float* vnewA = A->vnew + (size_t)l * MAX_MEMBERS * A->kv_dim;
-    float* knewB = B->knew + (size_t)l * MAX_MEMBERS * B->kv_dim;
-    float* vnewB = B->vnew + (size_t)l * MAX_MEMBERS * B->kv_dim;
     GemvArgs a;
     memset(&a, 0, sizeof(a));
-    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d;
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
-    a.qbuf = h->qbuf, a.knew = knewA, a.vnew = vnewA, a.knew2 = knewB, a.vnew2 = vnewB;
-    a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
-    a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = A->state;
-    for (int m = 0; m < 8; ++m) a.state_rows[m] = A->state, a.state_rows[8 + m] = B->state;
-    RC(ddk_gemv16(EPI_QKV, a, st));
+    a.qbuf = h->qbuf, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
+    a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = qs[0]->state;
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
     t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0;
     t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
-    t.knew = knewA, t.vnew = vnewA, t.knew2 = knewB, t.vnew2 = vnewB;
-    t.n_lanes = 2, t.lane_groups = 2;
-    dd_lm* qs[2] = {A, B};
-    for (int g = 0; g < 2; ++g) {
+    t.n_lanes = ng, t.lane_groups = ng;
+    for (int g = 0; g < ng; ++g) {
       dd_lm* q = qs[g];
+      float* kn = q->knew + (size_t)l * MAX_MEMBERS * q->kv_dim;
+      float* vn = q->vnew + (size_t)l * MAX_MEMBERS * q->kv_dim;
+      a.knew_g[g] = kn, a.vnew_g[g] = vn, t.knew_g[g] = kn, t.vnew_g[g] = vn;
+      for (int m = 0; m < 8; ++m) a.state_rows[8 * g + m] = q->state;
       t.lane_kc[g] = q->kc + (size_t)l * q->lsk, t.lane_vc[g] = q->vc + (size_t)l * q->lsv, t.lane_state[g] = q->state;
       t.lane_bits[g] = q->drop_bits, t.lane_span_start[g] = q->span_start, t.lane_span_len[g] = q->L;
       if (q->T_host > t.max_T) t.max_T = q->T_host;
     }
+    a.knew = a.knew_g[0], a.vnew = a.vnew_g[0], t.knew = t.knew_g[0], t.vnew = t.vnew_g[0];
+    RC(ddk_gemv_groups(EPI_QKV, a, st));
     RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
-    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q;
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = ng;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
-    RC(ddk_gemv16(EPI_RESID, a, st));
+    RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
-    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d;
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
-    RC(ddk_gemv16(EPI_SILU, a, st));
+    RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
-    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff;
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = ng;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
-    RC(ddk_gemv16(EPI_RESID, a, st));
+    RC(ddk_gemv_groups(EPI_RESID, a, st));
     ssq_n = d / 16;
   }
   GemvArgs a;
   memset(&a, 0, sizeof(a));
-  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d;
+  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
-  a.out = A->member_logits, a.out2 = B->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
-  RC(ddk_gemv16(EPI_STORE, a, st));
-  dd_lm* qs[2] = {A, B};
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < ng; ++g) a.out_g[g] = qs[g]->member_logits;
+  a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
+  RC(ddk_gemv_groups(EPI_STORE, a, st));
+  for (int g = 0; g < ng; ++g) {
     dd_lm* q = qs[g];
     RC(dd_argmax_rows(q->member_logits, K, q->V, q->Vpad, q->member_tok, st));
     if (q->cfg.vote_on == DD_VOTE_HIDDEN) {
@@ -988,17 +986,19 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
                               dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits, st));
     }
   }
-  const bool pairs = g_pair_sweeps && K > 0 && K <= 8 && !h0->fp8;
+  const bool multi = g_pair_sweeps && K > 0 && K <= 8 && !h0->fp8;
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
     if (K > 0) {
-      if (pairs && m + 1 < n) {
-        RC(lm_sweep_pair(h0, q, lanes[m + 1], K, st));
-        for (int j = 0; j < 2; ++j) {
+      const int left = n - m;
+      const int ng = !multi ? 1 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1));
+      if (ng > 1) {
+        RC(lm_sweep_groups(h0, lanes + m, ng, K, st));
+        for (int j = 0; j < ng; ++j) {
           RC(dd_lm_step_commit(lanes[m + j], K, stream_));
           lanes[m + j]->steps_since_prefill++;
         }
-        ++m;
+        m += ng - 1;
         continue;
       }
       RC(dd_lm_step_members(q, 0, K, stream_));
@@ -1336,13 +1336,15 @@ extern "C" int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms, voi
 extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms, double* bytes_per_launch,
                                void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16) && iters >= 1,
-             "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 = the two-group kernel)");
-  const bool wide = nb == 16 && !h->fp8;
-  if (nb == 16) nb = 8;
+  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16 || nb == 32) && iters >= 1,
+             "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 / 32 = the two- / four-group kernel)");
+  const int ngroups = (nb >= 16 && !h->fp8) ? nb / 8 : 0;
+  const bool wide = ngroups > 0;
+  if (nb >= 16) nb = 8;
   auto gemv = [&](int epi, GemvArgs& a) -> int {
     a.S_next = epi == EPI_SILU ? h->S_ff : h->S_d;
-    return wide ? ddk_gemv16(epi, a, st) : ddk_gemv(epi, a, st);
+    a.n_groups = ngroups;
+    return wide ? ddk_gemv_groups(epi, a, st) : ddk_gemv(epi, a, st);
   };
   const int d = h->d, dff = h->dff;
   auto launch = [&](int l) -> int {

@@ -83,17 +83,19 @@ struct GemvArgs {
   const float* rope_cos; // [max_seq][64]
   const float* rope_sin;
   const DDState* state;
-  const DDState* state_rows[16];  // lanes: row m takes its position from state_rows[m] (null entries: `state`)
-  // 16-row passes (ddk_gemv16): rows 8..15 are a second group of 8 — its operand plane follows the first one in `xop`
-  // (and in xop_next: plane stride S_next * 64 u32x4), its logits / new K/V rows may live in another sequence's buffers
-  float* out2;          // EPI_STORE rows 8..15 (null: out + 8 * ldo)
-  float* knew2;         // EPI_QKV rows 8..15 (null: knew + 8 * kv_dim)
-  float* vnew2;
+  const DDState* state_rows[32];  // lanes: row m takes its position from state_rows[m] (null entries: `state`)
+  // multi-group passes (ddk_gemv_groups): rows 8g..8g+7 are group g (2 or 4 groups) — group g's operand plane is plane g
+  // of `xop` (and of xop_next: plane stride S_next * 64 u32x4); its logits / new K/V rows may live in another sequence's
+  // buffers
+  int n_groups;
+  float* out_g[4];      // EPI_STORE rows of group g (null: out + 8 g * ldo)
+  float* knew_g[4];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
+  float* vnew_g[4];
   int S_next;           // K / 32 of the GEMV that consumes xop_next
   int diag;             // timing diagnostics only (dd_set_tuning key 3): 2 = no rstd prologue, 4 = no epilogue, 8 = no epilogue prefetch
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
-int ddk_gemv16(int epi, const GemvArgs& a, hipStream_t st);   // the same for two groups of up to 8 rows (bf16 weights)
+int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2 or 4) groups of up to 8 rows (bf16 weights)
 void ddk_set_tuning(int key, int value);
 
 struct AttnDecodeArgs {
@@ -116,10 +118,10 @@ struct AttnDecodeArgs {
   // lanes (n_lanes > 0): row m of the pass belongs to sequence m — its own cache, length, span and (un-shifted) bits.
   // Used by the fused base pass of a group of sequences; kc/vc/state/drop_bits/span_* above are ignored then.
   int n_lanes;
-  int lane_groups;       // 0: lane m = row m (fused base pass).  2: a 16-row pass of TWO sequences — rows 0-7 are members of
-                         // lane 0, rows 8-15 of lane 1 (each group reads its own cache with its own drop bits, bit = row & 7)
-  const float* knew2;    // lane_groups == 2: new K/V rows of the second group (rows 8..15)
-  const float* vnew2;
+  int lane_groups;       // 0: lane m = row m (fused base pass).  2 / 4: a 16- / 32-row pass of that many sequences — rows
+                         // 8g..8g+7 are members of lane g (each group reads its own cache with its own drop bits, bit = row & 7)
+  const float* knew_g[4];  // lane_groups > 0: new K/V rows of group g
+  const float* vnew_g[4];
   int max_T;             // host: largest prefix length among the lanes (grid sizing)
   const float* lane_kc[8];
   const float* lane_vc[8];
@@ -170,10 +172,10 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st);
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
                    float* ssq, int ssq_ld, hipStream_t st);
 struct EmbedLanes {
-  const DDState* state[16];   // row m embeds the current token of this sequence (null: row unused)
+  const DDState* state[32];   // row m embeds the current token of this sequence (null: row unused)
 };
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
-                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st);   // rows = 8 or 16
+                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st);   // rows = 8, 16 or 32
 int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st);
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
                   float* vc, size_t layer_stride_k, size_t layer_stride_v, int T_cap, const DDState* state,

@@ -537,43 +537,45 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
 }
 
 // ===============================================================================================
-// decode GEMV, 16 rows: two groups of 8 rows (e.g. the members of two sequences) against ONE pass over the weights.
+// decode GEMV, NG groups of 8 rows (NG = 2 or 4; e.g. the members of NG sequences) against ONE pass over the weights.
 // Same tiles, same k order and the same fixed-order reduction per output as k_gemv, so a row's result does not depend
-// on which of the two kernels computed it; the second group's B operand is a second plane of the packed operand and
-// costs a second MFMA per tile step (the kernel is HBM-bound, the MFMA pipe is idle either way).
+// on which of the kernels computed it; group g's B operand is plane g of the packed operand and costs one more MFMA per
+// tile step (the kernel is HBM-bound; even 4 planes keep the MFMA pipe under half busy).
 // ===============================================================================================
 __device__ __forceinline__ void xop_store16(u32x4_t* xop, int k, int m, float y, int S) {
-  xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y);
+  xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y);   // plane = group of the row
 }
 
-template <int EPI, int TILES>
-__global__ __launch_bounds__(GEMV_THREADS) void k_gemv16(GemvArgs a) {
-  constexpr int U = 4;
-  __shared__ float red[TILES * 2 * GEMV_WAVES * 256];
-  __shared__ float rstd_sh[16];
-  __shared__ float ssq_sh[16 * 16];
+template <int EPI, int TILES, int NG, int U = 4>
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
+  extern __shared__ float gg_sh[];
+  float* red = gg_sh;                                   // [TILES * NG * 8 waves][256]
+  float* rstd_sh = red + TILES * NG * GEMV_WAVES * 256;  // [8 * NG]
+  float* ssq_sh = rstd_sh + 8 * NG;                     // [16][8 * NG]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = a.S, spw = S / GEMV_WAVES;
   const int tile0 = blockIdx.x * TILES;
-  f32x4_t acc[TILES][2];
+  f32x4_t acc[TILES][NG];
   const u32x4_t* wp[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
-    acc[t][0] = acc[t][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[t][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     wp[t] = a.W + ((size_t)(tile0 + t) * S + wave) * 64 + lane;
   }
-  const u32x4_t* xp0 = a.xop + (size_t)wave * 64 + lane;
-  const u32x4_t* xp1 = xp0 + (size_t)S * 64;
+  const u32x4_t* xp = a.xop + (size_t)wave * 64 + lane;      // plane g: + g * S * 64
+  const size_t xplane = (size_t)S * 64;
 
-  // folded RMSNorm: wave w assembles rows w and w + 8
-  f32x4_t sv0 = {0.f, 0.f, 0.f, 0.f}, sv1 = {0.f, 0.f, 0.f, 0.f};
-  if (a.ssq_in && 4 * lane < a.ssq_n) {
-    sv0 = *(const f32x4_t*)(a.ssq_in + (size_t)wave * a.ssq_ld + 4 * lane);
-    sv1 = *(const f32x4_t*)(a.ssq_in + (size_t)(wave + 8) * a.ssq_ld + 4 * lane);
+  // folded RMSNorm: wave w assembles rows w, w + 8, ...
+  f32x4_t sv[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    sv[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (a.ssq_in && 4 * lane < a.ssq_n) sv[g] = *(const f32x4_t*)(a.ssq_in + (size_t)(wave + 8 * g) * a.ssq_ld + 4 * lane);
   }
-  // epilogue thread t < 256: group t >> 7, row m = 8 * group + (t & 7), column n = (t & 127) >> 3
-  const int et = threadIdx.x, em = ((et >> 7) << 3) + (et & 7), en = (et & 127) >> 3;
-  const bool erow = et < 256 && (et & 7) < a.nb;
+  // epilogue thread t < 128 * NG: group t >> 7, row m = 8 * group + (t & 7), column n = (t & 127) >> 3
+  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
+  const bool erow = et < 128 * NG && ml < a.nb;
   float pre0 = 0.f, pre1 = 0.f;
   if (erow) {
     if (EPI == EPI_RESID) {
@@ -592,80 +594,73 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv16(GemvArgs a) {
   }
   if (a.ssq_in) {
     const int i0 = 4 * lane;
-    float v0 = 0.f, v1 = 0.f;
-    if (i0 < a.ssq_n) v0 += sv0.x, v1 += sv1.x;
-    if (i0 + 1 < a.ssq_n) v0 += sv0.y, v1 += sv1.y;
-    if (i0 + 2 < a.ssq_n) v0 += sv0.z, v1 += sv1.z;
-    if (i0 + 3 < a.ssq_n) v0 += sv0.w, v1 += sv1.w;
-    for (int i = lane + 256; i < a.ssq_n; i += 64) {
-      v0 += a.ssq_in[(size_t)wave * a.ssq_ld + i];
-      v1 += a.ssq_in[(size_t)(wave + 8) * a.ssq_ld + i];
-    }
-    v0 = dd_wave_sum(v0);
-    v1 = dd_wave_sum(v1);
-    if (lane == 0) {
-      rstd_sh[wave] = 1.0f / sqrtf(v0 * a.inv_k + a.eps);
-      rstd_sh[wave + 8] = 1.0f / sqrtf(v1 * a.inv_k + a.eps);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float v = 0.f;
+      if (i0 < a.ssq_n) v += sv[g].x;
+      if (i0 + 1 < a.ssq_n) v += sv[g].y;
+      if (i0 + 2 < a.ssq_n) v += sv[g].z;
+      if (i0 + 3 < a.ssq_n) v += sv[g].w;
+      for (int i = lane + 256; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)(wave + 8 * g) * a.ssq_ld + i];
+      v = dd_wave_sum(v);
+      if (lane == 0) rstd_sh[wave + 8 * g] = 1.0f / sqrtf(v * a.inv_k + a.eps);
     }
   }
 
   int s = 0;
   for (; s + U <= spw; s += U) {
-    u32x4_t b0[U], b1[U], w[TILES][U];
+    u32x4_t b[U][NG], w[TILES][U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * GEMV_WAVES * 64);
-      b0[u] = xp0[(size_t)(s + u) * GEMV_WAVES * 64];
-      b1[u] = xp1[(size_t)(s + u) * GEMV_WAVES * 64];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) b[u][g] = xp[(size_t)(s + u) * GEMV_WAVES * 64 + g * xplane];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                            __builtin_bit_cast(bf16x8_t, b0[u]), acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                            __builtin_bit_cast(bf16x8_t, b1[u]), acc[t][1], 0, 0, 0);
-      }
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                              __builtin_bit_cast(bf16x8_t, b[u][g]), acc[t][g], 0, 0, 0);
   }
   if (s < spw) {
     const int rem = spw - s;
-    u32x4_t b0[U], b1[U], w[TILES][U];
+    u32x4_t b[U][NG], w[TILES][U];
 #pragma unroll
     for (int u = 0; u < U - 1; ++u)
       if (u < rem) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * GEMV_WAVES * 64);
-        b0[u] = xp0[(size_t)(s + u) * GEMV_WAVES * 64];
-        b1[u] = xp1[(size_t)(s + u) * GEMV_WAVES * 64];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b[u][g] = xp[(size_t)(s + u) * GEMV_WAVES * 64 + g * xplane];
       }
 #pragma unroll
     for (int u = 0; u < U - 1; ++u)
       if (u < rem) {
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                              __builtin_bit_cast(bf16x8_t, b0[u]), acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                              __builtin_bit_cast(bf16x8_t, b1[u]), acc[t][1], 0, 0, 0);
-        }
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
+                                                                __builtin_bit_cast(bf16x8_t, b[u][g]), acc[t][g], 0, 0, 0);
       }
   }
 
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) *(f32x4_t*)&red[((t * 2 + g) * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t][g];
+    for (int g = 0; g < NG; ++g) *(f32x4_t*)&red[((t * NG + g) * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t][g];
   __syncthreads();
 
-  const int eg = et >> 7, ml = et & 7;       // group and row within the group of this epilogue thread
   auto tile_sum = [&](int tt, int n) -> float {
     float y = 0.f;
     int o = ((n >> 2) * 16 + ml) * 4 + (n & 3);
 #pragma unroll
     for (int w = 0; w < GEMV_WAVES; ++w) {
-      const float* r = &red[((tt * 2 + eg) * GEMV_WAVES + w) * 256];
+      const float* r = &red[((tt * NG + eg) * GEMV_WAVES + w) * 256];
       y += r[o] + r[o + 32];
     }
     return y;
@@ -676,7 +671,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv16(GemvArgs a) {
       float y = tile_sum(0, en);
       if (a.ssq_in) y *= rstd_sh[em];
       int col = tile0 * 16 + en;
-      float* row = (eg && a.out2) ? a.out2 + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
+      float* row = a.out_g[eg] ? a.out_g[eg] + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
       if (col < a.n_valid) row[col] = y;
     }
   } else if (EPI == EPI_RESID) {
@@ -689,11 +684,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv16(GemvArgs a) {
       xop_store16(a.xop_next, col, em, pre1 * xn, a.S_next);
       sq = xn * xn;
     }
-    if (et < 256) ssq_sh[en * 16 + em] = sq;
+    if (et < 128 * NG) ssq_sh[en * (8 * NG) + em] = sq;
     __syncthreads();
-    if (et < 16) {
+    if (et < 8 * NG) {
       float v = 0.f;
-      for (int i = 0; i < 16; ++i) v += ssq_sh[i * 16 + et];
+      for (int i = 0; i < 16; ++i) v += ssq_sh[i * (8 * NG) + et];
       a.ssq_out[(size_t)et * a.ssq_ld + blockIdx.x] = v;
     }
   } else if (EPI == EPI_SILU) {
@@ -711,8 +706,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv16(GemvArgs a) {
       float y = tile_sum(0, en);
       if (a.ssq_in) y *= rstd_sh[em];
       int nt = tile0;
-      float* kn = (eg && a.knew2) ? a.knew2 + (size_t)ml * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
-      float* vn = (eg && a.vnew2) ? a.vnew2 + (size_t)ml * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+      float* kn = a.knew_g[eg] ? a.knew_g[eg] + (size_t)ml * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
+      float* vn = a.vnew_g[eg] ? a.vnew_g[eg] + (size_t)ml * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
       if (nt < a.q_tiles + a.k_tiles) {
         float yp = tile_sum(0, en ^ 8);
         if (a.ssq_in) yp *= rstd_sh[em];
@@ -732,16 +727,35 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv16(GemvArgs a) {
   }
 }
 
-int ddk_gemv16(int epi, const GemvArgs& a, hipStream_t st) {
-  DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv16: K=%d must be a multiple of 256", a.S * 32);
-  DD_REQUIRE(a.nb >= 1 && a.nb <= 8 && !a.fp8, "gemv16: nb=%d rows per group, bf16 weights only", a.nb);
-  switch (epi) {
-    case EPI_STORE: k_gemv16<EPI_STORE, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
-    case EPI_RESID: k_gemv16<EPI_RESID, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
-    case EPI_SILU: k_gemv16<EPI_SILU, 2><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
-    case EPI_QKV: k_gemv16<EPI_QKV, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); break;
-    default: DD_REQUIRE(false, "gemv16: unknown epilogue %d", epi);
+template <int EPI, int TILES, int NG>
+static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
+  size_t smem = (size_t)(TILES * NG * GEMV_WAVES * 256 + 8 * NG + 16 * 8 * NG) * sizeof(float);
+  // weight tiles requested per wave before the first MFMA: 4, except the two-tile (gate/up) kernel with four operand
+  // planes, where 2 keeps the register file at two workgroups per CU (measured: 49 vs 53 us)
+  constexpr int U = (TILES == 2 && NG == 4) ? 2 : 4;
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
   }
+  k_gemv_groups<EPI, TILES, NG, U><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
+  return DD_OK;
+}
+
+int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
+  DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv_groups: K=%d must be a multiple of 256", a.S * 32);
+  DD_REQUIRE(a.nb >= 1 && a.nb <= 8 && !a.fp8, "gemv_groups: nb=%d rows per group, bf16 weights only", a.nb);
+  DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4, "gemv_groups: %d groups (2 or 4)", a.n_groups);
+  int rc = DD_OK;
+  const bool two = a.n_groups == 2;
+  switch (epi) {
+    case EPI_STORE: rc = two ? launch_gemv_groups<EPI_STORE, 1, 2>(a, st) : launch_gemv_groups<EPI_STORE, 1, 4>(a, st); break;
+    case EPI_RESID: rc = two ? launch_gemv_groups<EPI_RESID, 1, 2>(a, st) : launch_gemv_groups<EPI_RESID, 1, 4>(a, st); break;
+    case EPI_SILU: rc = two ? launch_gemv_groups<EPI_SILU, 2, 2>(a, st) : launch_gemv_groups<EPI_SILU, 2, 4>(a, st); break;
+    case EPI_QKV: rc = two ? launch_gemv_groups<EPI_QKV, 1, 2>(a, st) : launch_gemv_groups<EPI_QKV, 1, 4>(a, st); break;
+    default: DD_REQUIRE(false, "gemv_groups: unknown epilogue %d", epi);
+  }
+  if (rc != DD_OK) return rc;
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -761,18 +775,18 @@ int ddk_gemv16(int epi, const GemvArgs& a, hipStream_t st) {
 // read the K/V tile twice through L2.
 // ML == 1 (lanes): NBT == 1 and GH == G; blockIdx.z is the ROW of the pass = the sequence whose cache this workgroup
 // reads; results go to the 8-rows-per-head layout the 8-row combine reads.
-// ML == 2 (two groups): NBT == 8; blockIdx.z = group * (G / GH) + GQA slice; group g's 8 rows (members of sequence g) read
-// that sequence's cache and drop bits; results go to a 16-rows-per-head layout (row = 8 * group + member).
+// ML == 2 (groups): NBT == 8; blockIdx.z = group * (G / GH) + GQA slice; group g's 8 rows (members of sequence g) read
+// that sequence's cache and drop bits; results go to an (8 * a.lane_groups)-rows-per-head layout (row = 8 * group + member).
 template <int NBT, int G, int GH, int ML = 0>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
-  constexpr int RT = ML == 1 ? 8 * G : (ML == 2 ? 16 * G : NBT * G);   // rows per kv head in the partial buffers
+  const int RT = ML == 1 ? 8 * G : (ML == 2 ? 8 * a.lane_groups * G : NBT * G);   // rows per kv head in the partial buffers
   const int g0 = ML == 1 ? 0 : (ML == 2 ? (blockIdx.z % (G / GH)) * GH : blockIdx.z * GH);
   const int lane_row = ML == 1 ? blockIdx.z : (ML == 2 ? blockIdx.z / (G / GH) : 0);
   // partial-buffer row of this workgroup's row r (= local head r / NBT, member r % NBT)
   auto buf_row = [&](int r) -> int {
     if (ML == 1) return r * 8 + lane_row;
-    if (ML == 2) return (g0 + r / NBT) * 16 + lane_row * 8 + r % NBT;
+    if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + r % NBT;
     return g0 * NBT + r;
   };
   extern __shared__ __align__(16) float att_sh[];
@@ -896,11 +910,11 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   const int r = g * NBT + m;
   // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
   // has the tiles of its own, possibly shorter, sequence
-  const int splits = a.n_lanes ? (a.lane_state[a.lane_groups == 2 ? m >> 3 : m]->T + ATT_SPLIT - 1) / ATT_SPLIT
+  const int splits = a.n_lanes ? (a.lane_state[a.lane_groups ? m >> 3 : m]->T + ATT_SPLIT - 1) / ATT_SPLIT
                                : (a.state ? (a.state->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid);
-  const bool second = NBT == 16 && m >= 8;            // row of the second group (16-row passes)
-  const float* knew_r = (second && a.knew2) ? a.knew2 + (size_t)(m - 8) * kv_dim : a.knew + (size_t)m * kv_dim;
-  const float* vnew_r = (second && a.vnew2) ? a.vnew2 + (size_t)(m - 8) * kv_dim : a.vnew + (size_t)m * kv_dim;
+  const int grp = NBT > 8 ? m >> 3 : 0;               // group of the row (multi-group passes)
+  const float* knew_r = (NBT > 8 && a.knew_g[grp]) ? a.knew_g[grp] + (size_t)(m & 7) * kv_dim : a.knew + (size_t)m * kv_dim;
+  const float* vnew_r = (NBT > 8 && a.vnew_g[grp]) ? a.vnew_g[grp] + (size_t)(m & 7) * kv_dim : a.vnew + (size_t)m * kv_dim;
   // every load of this block is issued here, before the first dependent use
   float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
   float kd = knew_r[kvh * HEAD_DIM + d];
@@ -936,7 +950,7 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
     for (int u = 0; u < 8; ++u) num += w_sh[sp + u] * o[u];
   }
   for (; sp < splits; ++sp) num += w_sh[sp] * po[(size_t)sp * o_stride];
-  if (NBT == 16) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5);
+  if (NBT > 8) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5);
   else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
 }
 
@@ -978,8 +992,8 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   return DD_OK;
 }
 
-// 16-row pass: members of two sequences (8 rows each), every group over its own cache
-template <int G>
+// multi-group pass: members of NG sequences (8 rows each), every group over its own cache
+template <int G, int NG>
 static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
   constexpr int GH = (8 * G > 16) ? 2 : G;
   constexpr int R = 8 * GH;
@@ -991,8 +1005,8 @@ static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<8, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_attn_partial<8, G, GH, 2><<<dim3(a.n_kv, splits, 2 * (G / GH)), 256, smem, st>>>(a);
-  k_attn_combine<16, G><<<dim3(a.n_heads, 16), HEAD_DIM, 0, st>>>(a, splits);
+  k_attn_partial<8, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH)), 256, smem, st>>>(a);
+  k_attn_combine<8 * NG, G><<<dim3(a.n_heads, 8 * NG), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
 }
 
@@ -1000,11 +1014,18 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
   DD_REQUIRE(a.n_heads % a.n_kv == 0, "attn: heads %d not a multiple of kv heads %d", a.n_heads, a.n_kv);
   int G = a.n_heads / a.n_kv;
   DD_REQUIRE(G == 1 || G == 2 || G == 4, "attn: GQA group %d unsupported (1, 2, 4)", G);
-  if (a.n_lanes > 0 && a.lane_groups == 2) {
-    DD_REQUIRE(a.n_lanes == 2 && a.nb >= 1 && a.nb <= 8, "attn: a 16-row pass takes two sequences of up to 8 members");
-    if (G == 1) launch_attn_groups<1>(a, st);
-    else if (G == 2) launch_attn_groups<2>(a, st);
-    else launch_attn_groups<4>(a, st);
+  if (a.n_lanes > 0 && a.lane_groups) {
+    DD_REQUIRE((a.lane_groups == 2 || a.lane_groups == 4) && a.n_lanes == a.lane_groups && a.nb >= 1 && a.nb <= 8,
+               "attn: a multi-group pass takes 2 or 4 sequences of up to 8 members");
+    if (a.lane_groups == 2) {
+      if (G == 1) launch_attn_groups<1, 2>(a, st);
+      else if (G == 2) launch_attn_groups<2, 2>(a, st);
+      else launch_attn_groups<4, 2>(a, st);
+    } else {
+      if (G == 1) launch_attn_groups<1, 4>(a, st);
+      else if (G == 2) launch_attn_groups<2, 4>(a, st);
+      else launch_attn_groups<4, 4>(a, st);
+    }
     DD_CHECK_LAUNCH();
     return DD_OK;
   }
@@ -1411,7 +1432,7 @@ __global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __res
       float e = tok[m] >= 0 ? dd_bf16_to_f32(embed[(size_t)tok[m] * d + i]) : 0.f;
       ss[m] += e * e;
       x[(size_t)m * d + i] = e;
-      if (ROWS == 16) xop_store16(xop, i, m, w * e, d >> 5);
+      if (ROWS > 8) xop_store16(xop, i, m, w * e, d >> 5);
       else xop_store(xop, i, m, w * e);
     }
   }
@@ -1429,7 +1450,8 @@ __global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __res
 }
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
                          u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st) {
-  if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
+  if (rows == 32) k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
+  else if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
   else k_embed_rows_lanes<8><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
   DD_CHECK_LAUNCH();
   return DD_OK;
