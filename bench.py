@@ -177,12 +177,34 @@ def main() -> int:
         return outs
 
     img0 = rank * 10_000 if args.mode == "replicas" else 0
-    for i in range(args.warmup):
-        one(img0 + i)
+    pipe = None
+    if B > 1:
+        # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
+        from dropoutdecoding_amd.vlm import GroupPipeline
+        pipe = GroupPipeline(model, lanes=B)
+
+    def batch_inputs(i):
+        out = []
+        for b in range(B):
+            ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
+            out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
+        return out
+
+    def run_steps(first, n):
+        if pipe is None:
+            for i in range(n):
+                one(first + i)
+            return
+        done = 0
+        for outs in pipe.run((batch_inputs(first + i) for i in range(n)), max_new_tokens=args.n_new, eos_token_id=[]):
+            assert len(outs) == B and all(o.shape[1] == 32 + args.n_new for o in outs)
+            done += 1
+        assert done == n
+
+    run_steps(img0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        one(img0 + args.warmup + i)
+    run_steps(img0 + args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     single = None
@@ -246,7 +268,8 @@ def main() -> int:
                                    f"32-token prompt (prefill 608), {args.n_new} decoded tokens per image (EOS ignored), K={K_eff} voting_numbers={probs if K_eff else []}, "
                                    "random-init weights of the real shapes (bf16 weights, fp32 activations/KV)"
                                    + (f"; the {B} images are {B} independent sequences (own KV cache and rng stream, results identical to "
-                                      "decoding each alone) whose un-masked passes share one sweep over the weights" if B > 1 else ""),
+                                      "decoding each alone) whose un-masked passes share one sweep over the weights and whose member passes run four sequences "
+                                      "per sweep; the next batch's CLIP + prefill overlap the current batch's decode on a second stream" if B > 1 else ""),
                        "mode": args.mode, "images_per_step_per_gpu": B, "n_new": args.n_new, "K": K_eff,
                        "one_image_at_a_time": single,
                        "prefill_included": True, "device_bytes": eng.device_bytes},

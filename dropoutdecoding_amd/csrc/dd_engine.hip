@@ -498,6 +498,12 @@ __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int
     st->T = st->T + 1;
   }
 }
+// rows of the prompt that go through lm_head: the visual span, then the last position
+__global__ void k_prefill_rows(int32_t* rows, int span_start, int L, int T0) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < L) rows[i] = span_start + i;
+  else if (i == L) rows[L] = T0 - 1;
+}
 __global__ void k_set_token(DDState* st, int tok) {
   if (threadIdx.x == 0) st->cur_tok = tok;
 }
@@ -606,11 +612,8 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   RC(prefill_layers(h, T0, nullptr, 0, span_start, span_len, st));
   // lm_head over the visual span + the last position only (the reference projects all T0 positions,
   // llava.py:294-305, but consumes just these: llava.py:311-314 and HF's greedy argmax)
-  std::vector<int32_t> rows(L + 1);
-  for (int i = 0; i < L; ++i) rows[i] = span_start + i;
-  rows[L] = T0 - 1;
-  DD_HIP(hipMemcpyAsync(h->row_index, rows.data(), (L + 1) * 4, hipMemcpyHostToDevice, st));
-  DD_HIP(hipStreamSynchronize(st));  // rows is a host temporary
+  k_prefill_rows<<<(L + 1 + 255) / 256, 256, 0, st>>>(h->row_index, span_start, L, T0);   // no host data: prefill stays asynchronous
+  DD_CHECK_LAUNCH();
   RC(prefill_head(h, h->row_index, L + 1, h->image_logits, st));
   DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq + (size_t)L * d, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
   RC(dd_vision_uncertainty(h->image_logits, L, h->V, h->Vpad, h->var, h->epi, h->alea, h->scalars, h->cfg.k_top,

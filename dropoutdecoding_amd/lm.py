@@ -182,14 +182,19 @@ class DropoutEngine:
 
     # ---- the path ---------------------------------------------------------------------------
     def prefill(self, embeds: torch.Tensor, span_start: int, span_len: int, first_step_ensemble: bool = False,
-                mprobs: Optional[Sequence[float]] = None, uniforms: Optional[torch.Tensor] = None) -> None:
+                mprobs: Optional[Sequence[float]] = None, uniforms: Optional[torch.Tensor] = None,
+                stream: Optional[torch.cuda.Stream] = None) -> None:
+        """`stream`: run this prefill on another stream than the engine's (GroupPipeline overlaps the next batch's prefill
+        with the current batch's decode); the caller orders the engine's stream after it (event) before decoding."""
         if not embeds.is_cuda:
             raise ValueError("embeds must be on the GPU")
         e = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
         if e.shape[1] != self.cfg.hidden_size:
             raise ValueError(f"embeds have width {e.shape[1]}, model hidden size is {self.cfg.hidden_size}")
-        self.torch_stream.wait_stream(torch.cuda.current_stream(self.device))   # embeds come from the caller's stream
-        e.record_stream(self.torch_stream)
+        pstream = stream if stream is not None else self.torch_stream
+        pstream.wait_stream(torch.cuda.current_stream(self.device))   # embeds come from the caller's stream
+        e.record_stream(pstream)
+        ps = pstream.cuda_stream
         K = 0
         if first_step_ensemble:
             # the reference's `# if True:` toggle (llava.py:336-337): the ensemble also picks the first token
@@ -198,12 +203,12 @@ class DropoutEngine:
             un = None
             if uniforms is not None:
                 un = uniforms.float().contiguous()
-                un.record_stream(self.torch_stream)
+                un.record_stream(pstream)
             _lib.check(self.lib.dd_lm_prefill_ensemble(self._h, e.data_ptr(), e.shape[0], span_start, span_len, arr, K,
                                                        self.rng.handle, un.data_ptr() if un is not None else None,
-                                                       self._s()), "dd_lm_prefill_ensemble")
+                                                       ps), "dd_lm_prefill_ensemble")
         else:
-            _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, self._s()),
+            _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, ps),
                        "dd_lm_prefill")
         self.L, self.T0 = span_len, e.shape[0]
         self._last_K = K
@@ -409,9 +414,12 @@ class EngineGroup:
             e._last_K = K
             e._n_enqueued += 1
 
-    def generate(self, n_new: int, eos=None, mprobs=None, dropout: bool = True, lookahead: int = 6) -> List[List[int]]:
+    def generate(self, n_new: int, eos=None, mprobs=None, dropout: bool = True, lookahead: int = 6,
+                 idle=None) -> List[List[int]]:
         """Greedy loops of all lanes in lockstep (each lane as DropoutEngine.generate): a lane stops at its EOS or at
-        n_new; the others go on with fewer rows in the fused base pass."""
+        n_new; the others go on with fewer rows in the fused base pass.  `idle()` (optional) is called while the GPU has
+        `lookahead` steps queued; it does one unit of other host work (e.g. enqueue the next image's prefill on another
+        stream) and returns False when it has nothing left."""
         eos_set = set() if eos is None else (set(eos) if isinstance(eos, (list, tuple, set)) else {int(eos)})
         E = self.engines
         while True:
@@ -421,7 +429,8 @@ class EngineGroup:
             if not active:
                 break
             if min(E[i]._n_enqueued - len(seen[i]) for i in active) >= lookahead:
-                time.sleep(0.0002)                      # far enough ahead of the GPU
+                if idle is None or not idle():
+                    time.sleep(0.0002)                  # far enough ahead of the GPU
                 continue
             self.decode_step(mprobs, dropout=dropout, active=active)
         out = []

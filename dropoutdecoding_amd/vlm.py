@@ -106,7 +106,7 @@ class DropoutVLM:
         return merged, start
 
     # ---- the boundary -------------------------------------------------------------------------
-    def _prepare(self, input_ids, max_new_tokens, max_length, num_beams, eos_token_id, do_sample, inputs):
+    def _prepare(self, input_ids, max_new_tokens, max_length, num_beams, eos_token_id, do_sample, inputs, stream=None):
         """Everything of generate() up to and including the prefill; -> (input_ids on device, n_new, eos ids)."""
         if input_ids is None or input_ids.shape[0] != 1:
             raise ValueError("Dropout Decoding runs batch size 1 with exactly one image per prompt "
@@ -127,7 +127,7 @@ class DropoutVLM:
         self.masked_numbers = []
         # the `# if True:` toggle of llava.py:336-337; never for the stock greedy (`--original`) path
         first = bool(settings.get("first_step_ensemble", False)) and not self.original
-        self.engine.prefill(embeds, start, L, first_step_ensemble=first)
+        self.engine.prefill(embeds, start, L, first_step_ensemble=first, stream=stream)
         eos = self.eos_token_ids if eos_token_id is None else (
             list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
         return input_ids, max_new_tokens, eos
@@ -233,3 +233,62 @@ def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens:
         raise ValueError("generate_group: `original` must be the same for all lanes")
     toks = EngineGroup([m.engine for m in models]).generate(n_new.pop(), eos=eos, dropout=dropout.pop())
     return [m._finalize(p[0], t) for m, p, t in zip(models, prepared, toks)]
+
+
+class GroupPipeline:
+    """Caption a long list of images in batches of up to 8: while one set of lanes decodes, the vision tower and the
+    prefill of the NEXT batch are enqueued on a second stream (the decode step is HBM-bound, the prefill MFMA-bound, so
+    they overlap) — the 500-image CHAIR job of the reference's SLURM launchers on one GPU.
+
+    Each image is still decoded exactly as `generate()` would decode it on a lane of its own (see generate_group)."""
+
+    def __init__(self, model: DropoutVLM, lanes: int = 8):
+        if not 1 <= lanes <= 8:
+            raise ValueError("1..8 lanes per set")
+        self.sets = [[model] + [model.spawn_lane() for _ in range(lanes - 1)], [model.spawn_lane() for _ in range(lanes)]]
+        self.pre_stream = torch.cuda.Stream(device=model.device)
+
+    def _stage(self, lanes, batch, kw):
+        """-> per-image closures that each enqueue one image's front-end + prefill on the second stream"""
+        state = {"prepared": [], "todo": list(zip(lanes, batch)), "event": None, "lanes": lanes[:len(batch)]}
+
+        def unit() -> bool:
+            if not state["todo"]:
+                return False
+            m, inp = state["todo"].pop(0)
+            inp = dict(inp)
+            inp.pop("attention_mask", None)
+            with torch.cuda.stream(self.pre_stream):
+                state["prepared"].append(m._prepare(inp.pop("input_ids", None), inp.pop("max_new_tokens", kw["max_new_tokens"]),
+                                                    inp.pop("max_length", None), 1, inp.pop("eos_token_id", kw["eos_token_id"]),
+                                                    False, inp, stream=self.pre_stream))
+                if not state["todo"]:
+                    state["event"] = torch.cuda.Event()
+                    state["event"].record(self.pre_stream)
+            return True
+        state["unit"] = unit
+        return state
+
+    @torch.no_grad()
+    def run(self, batches, max_new_tokens: int, eos_token_id=None):
+        """batches: iterable of lists of generate() keyword dicts (up to `lanes` each); yields the list of output id tensors
+        of each batch, in order."""
+        from .lm import EngineGroup
+        kw = {"max_new_tokens": max_new_tokens, "eos_token_id": eos_token_id}
+        it = iter(batches)
+        first = next(it, None)
+        cur = self._stage(self.sets[0], first, kw) if first is not None else None
+        k = 0
+        while cur is not None:
+            while cur["unit"]():                       # whatever the previous decode loop did not get to
+                pass
+            lanes, prepared = cur["lanes"], cur["prepared"]
+            lanes[0].engine.torch_stream.wait_event(cur["event"])
+            nb = next(it, None)
+            k += 1
+            nxt = self._stage(self.sets[k % 2], nb, kw) if nb is not None else None
+            dropout = not lanes[0].original
+            toks = EngineGroup([m.engine for m in lanes]).generate(
+                prepared[0][1], eos=prepared[0][2], dropout=dropout, idle=(nxt["unit"] if nxt is not None else None))
+            yield [m._finalize(p[0], t) for m, p, t in zip(lanes, prepared, toks)]
+            cur = nxt

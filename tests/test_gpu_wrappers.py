@@ -304,3 +304,17 @@ def test_generate_group_three_images_at_once(built):
     assert o1.tolist() == outs[1].tolist()
     with pytest.raises(ValueError):
         generate_group(lanes, [dict(input_ids=prompts[0], pixel_values=pvs[0])] * 2)
+    # GroupPipeline: batches back to back, the next batch's vision tower + prefill overlapped with the current decode.
+    # Lane b of set s sees batches s, s+2, ... and its rng stream continues across them — like one reference process.
+    from dropoutdecoding_amd.vlm import GroupPipeline
+    m1 = CustomLlavaForConditionalGeneration.from_hf_model(hf, max_new_tokens=16)
+    pipe = GroupPipeline(m1, lanes=2)
+    imgs = [(prompts[i % 3], torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(40 + i))) for i in range(6)]
+    batches = [[dict(input_ids=p, pixel_values=v) for p, v in imgs[2 * b:2 * b + 2]] for b in range(3)]
+    got = [o for outs in pipe.run(batches, max_new_tokens=6, eos_token_id=[]) for o in outs]
+    assert len(got) == 6
+    for lane_imgs in ([0, 4], [1, 5], [2], [3]):            # (set 0, lane 0), (set 0, lane 1), (set 1, lane 0), (set 1, lane 1)
+        solo = m1.spawn_lane()
+        for i in lane_imgs:
+            want = solo.generate(input_ids=imgs[i][0], pixel_values=imgs[i][1], max_new_tokens=6, eos_token_id=[])
+            assert got[i].tolist() == want.tolist(), f"image {i}"
