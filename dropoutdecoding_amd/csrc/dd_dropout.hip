@@ -307,7 +307,9 @@ int dd_overlap_keep_from_argmax(const int32_t* argmax_dev, const int32_t* topk_i
 // ----------------------------------------------------------------------------------------------
 struct dd_rng {
   uint32_t* state;  // device, 625 words
+  unsigned long long serial;   // never reused: captured decode steps are keyed on it, not on the address
 };
+static unsigned long long g_rng_serial = 0;
 
 #define MT_N 624
 #define MT_M 397
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(1024) void k_mt_uniform(uint32_t* st, float* out, i
 extern "C" int dd_rng_create(uint32_t seed, dd_rng** out) {
   DD_REQUIRE(out, "dd_rng_create: null out");
   dd_rng* r = new dd_rng();
+  r->serial = ++g_rng_serial;
   hipError_t e = hipMalloc((void**)&r->state, (MT_N + 1) * sizeof(uint32_t));
   if (e != hipSuccess) {
     delete r;
@@ -418,6 +421,7 @@ extern "C" int dd_rng_uniform(dd_rng* r, float* out, int n, void* stream_) {
   return DD_OK;
 }
 uint32_t* dd_rng_state_ptr(dd_rng* r) { return r ? r->state : nullptr; }
+unsigned long long dd_rng_serial(dd_rng* r) { return r ? r->serial : 0ull; }
 
 // ----------------------------------------------------------------------------------------------
 // Mask sampler: one workgroup, all K members of a step (get_image_attention_mask "epis")

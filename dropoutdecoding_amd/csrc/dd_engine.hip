@@ -14,6 +14,8 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
                          int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
                          int32_t* idx, uint8_t* drop_bits, hipStream_t st);
 uint32_t* dd_rng_state_ptr(dd_rng* r);
+unsigned long long dd_rng_serial(dd_rng* r);
+static unsigned long long g_lm_serial = 0;   // handles are identified in graph keys by a serial that is never reused
 
 #define MAX_MEMBERS 16
 #define MAX_NEW_TOKENS 8192
@@ -30,6 +32,7 @@ struct dd_lm {
   int S_d, S_q, S_ff, qkv_tiles, q_tiles, k_tiles;
   std::vector<void*> allocs;
   size_t bytes = 0;
+  unsigned long long serial = 0;
   dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
   float* grp_logits = nullptr; // [8][Vpad] base-pass logits of a group step (this handle is the group's first lane)
   int32_t* grp_argmax = nullptr;
@@ -139,6 +142,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DD_REQUIRE(c->mask_mode >= 0 && c->mask_mode <= 4, "dd_lm_create: mask_mode");
   DD_REQUIRE(c->vote_on >= 0 && c->vote_on <= 2, "dd_lm_create: vote_on");
   dd_lm* h = new dd_lm();
+  h->serial = ++g_lm_serial;
   h->cfg = *c;
   h->d = c->hidden_size, h->dff = c->intermediate_size, h->V = c->vocab_size, h->Vpad = (c->vocab_size + 15) / 16 * 16;
   h->H = c->num_heads, h->Hkv = c->num_kv_heads, h->q_dim = h->H * 128, h->kv_dim = h->Hkv * 128;
@@ -1059,7 +1063,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   }
   mix((unsigned long long)ddk_attn_grid_tiles(h->T_host, h->T_cap));
   mix(((unsigned long long)h->L << 32) | (unsigned)h->span_start);   // launch arguments fixed by the last prefill
-  mix((unsigned long long)(uintptr_t)rng);
+  mix(dd_rng_serial(rng));
   mix((unsigned long long)(uintptr_t)st);
   for (auto& g : h->graphs)
     if (g.key == key) {
@@ -1123,8 +1127,8 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   int max_T = 0;
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
-    mix((unsigned long long)(uintptr_t)q);
-    mix((unsigned long long)(uintptr_t)(rngs ? rngs[m] : nullptr));
+    mix(q->serial);
+    mix(dd_rng_serial(rngs ? rngs[m] : nullptr));
     mix((unsigned long long)ddk_attn_grid_tiles(q->T_host, q->T_cap));
     mix(((unsigned long long)q->L << 32) | (unsigned)q->span_start);
     if (q->T_host > max_T) max_T = q->T_host;

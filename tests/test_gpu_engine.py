@@ -609,3 +609,63 @@ def test_group_generate_with_uneven_stops_and_stock_greedy(E):
         E.EngineGroup([engines[0], other])
     for e in reversed(engines):
         e.close()
+
+
+def test_full_size_lanes_equal_solo_runs_bitwise(E):
+    """BASELINE size (LLaVA-1.5-7B shapes, K = 8): 6 lanes decoded as a group (fused base pass, one 4-sequence and one
+    2-sequence member sweep: the full-length k loops and the K = 11008 tail of k_gemv_groups) == each lane alone,
+    bit for bit — logits, masks, tokens, KV checksums."""
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    shapes = [(608, 5, 576), (640, 9, 576), (600, 1, 576), (615, 20, 576), (609, 5, 576), (700, 60, 576)]   # tiles 10 / 11
+    engs = []
+    for i in range(len(shapes)):
+        engs.append(E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=768, max_visual=576, seed=5217,
+                                    share_weights_with=engs[0] if engs else None))
+    engs[0].load_synthetic(1, 0.02)
+    embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(50 + i)).cuda() for i, (T0, _, _) in enumerate(shapes)]
+    for e, x, (T0, s0, L) in zip(engs, embs, shapes):
+        e.prefill(x, s0, L)
+    grp = E.EngineGroup(engs)
+    n_steps, rec = 3, [[] for _ in engs]
+    for s in range(n_steps):
+        grp.decode_step(probs)
+        for i, e in enumerate(engs):
+            st = e.last_step()
+            rec[i].append((st["drop"].copy(), st["member_argmax"].tolist(), st["winner"], e.logits().copy(), e.base_logits().copy()))
+    toks = [e.tokens() for e in engs]
+    sums = [e.kv_sums().copy() for e in engs]
+    assert len({tuple(t) for t in toks}) > 1                          # the lanes really decode different things
+    for i, (e, x, (T0, s0, L)) in enumerate(zip(engs, embs, shapes)):
+        e.rng.manual_seed(5217)
+        e.prefill(x, s0, L)
+        for s in range(n_steps):
+            e.decode_step(probs)
+            st = e.last_step()
+            np.testing.assert_array_equal(st["drop"], rec[i][s][0], err_msg=f"lane {i} step {s}")
+            assert st["member_argmax"].tolist() == rec[i][s][1] and st["winner"] == rec[i][s][2]
+            np.testing.assert_array_equal(e.logits(), rec[i][s][3], err_msg=f"lane {i} step {s}")
+            np.testing.assert_array_equal(e.base_logits(), rec[i][s][4], err_msg=f"lane {i} step {s}")
+        assert e.tokens() == toks[i]
+        np.testing.assert_array_equal(e.kv_sums(), sums[i])
+    for e in reversed(engs):
+        e.close()
+
+
+def test_lanes_mid_scale_against_the_oracle(E):
+    """d = 1024, d_ff = 2816 (K = 2816: 11 k-steps per wave, main loop + tail of the grouped GEMV), GQA 2, 4 layers, V = 4099:
+    five lanes (one 4-sequence sweep + one plain 8-row sweep) against the oracle, one fresh rng stream per lane."""
+    rc = RefCfg(4099, 1024, 2816, 4, 8, 4, 128, 1e-5, 10000.0)
+    probs = [0.1, 0.3, 0.5, 0.7, 0.9]
+    shapes = [(90, 4, 80), (70, 2, 64), (130, 10, 100), (66, 1, 60), (100, 3, 90)]
+    w, engines, embs = _lane_setup(E, FAMILY_LLAVA, rc, shapes, max_seq=192)
+    for e, emb, (T0, s0, L) in zip(engines, embs, shapes):
+        e.prefill(emb.cuda(), s0, L)
+    toks = E.EngineGroup(engines).generate(5, mprobs=probs)
+    for i, (emb, (T0, s0, L)) in enumerate(zip(embs, shapes)):
+        ref = RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=7)
+        assert toks[i] == ref.generate(emb, s0, L, 5), f"lane {i}"
+        st = engines[i].last_step()
+        np.testing.assert_array_equal(st["drop"], ref.records[-1].drop)
+        assert close(engines[i].logits(), ref.records[-1].logits)
+    for e in reversed(engines):
+        e.close()
