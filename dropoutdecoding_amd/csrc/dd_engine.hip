@@ -34,7 +34,7 @@ struct dd_lm {
   size_t bytes = 0;
   unsigned long long serial = 0;
   dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
-  float* grp_logits = nullptr; // [8][Vpad] base-pass logits of a group step (this handle is the group's first lane)
+  float* grp_logits = nullptr; // [16][Vpad] base-pass logits of a group step (this handle is the group's first lane)
   int32_t* grp_argmax = nullptr;
   const float *commit_k = nullptr, *commit_v = nullptr;   // K == 0 group step: this lane's base row in the leader's scratch
   // weights
@@ -217,8 +217,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->xop_q, (size_t)h->S_q * 64 * 4);
   DA(h->xop_ff, (size_t)h->S_ff * 64 * 4);
   DA(h->base_logits, h->Vpad);
-  DA(h->grp_logits, (size_t)8 * h->Vpad);
-  DA(h->grp_argmax, 8);
+  DA(h->grp_logits, (size_t)16 * h->Vpad);
+  DA(h->grp_argmax, 16);
   DA(h->member_logits, (size_t)MAX_MEMBERS * h->Vpad);
   DA(h->last_logits, h->Vpad);
   DA(h->last_hidden, d);
@@ -702,11 +702,18 @@ extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int
 static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st,
                     dd_lm* const* lanes = nullptr) {
   const int d = h->d, dff = h->dff;
+  // more than 8 lanes: the base rows fill two operand planes (rows 0-7 / 8-15) and go through the grouped GEMV
+  const bool wide = lanes && nb > 8;
+  auto gemv = [&](int epi, GemvArgs& a) -> int {
+    if (!wide) return ddk_gemv(epi, a, st);
+    a.n_groups = 2, a.nb = 8;
+    return ddk_gemv_groups(epi, a, st);
+  };
   if (lanes) {
     EmbedLanes el;
     memset(&el, 0, sizeof(el));
     for (int m = 0; m < nb; ++m) el.state[m] = lanes[m]->state;
-    RC(ddk_embed_rows_lanes(h->embed, d, el, 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+    RC(ddk_embed_rows_lanes(h->embed, d, el, wide ? 16 : 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   } else {
     RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   }
@@ -724,7 +731,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = h->state;
     if (lanes)
       for (int m = 0; m < nb; ++m) a.state_rows[m] = lanes[m]->state;
-    RC(ddk_gemv(EPI_QKV, a, st));
+    RC(gemv(EPI_QKV, a));
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
     t.qbuf = h->qbuf, t.kc = h->kc + (size_t)l * h->lsk, t.vc = h->vc + (size_t)l * h->lsv, t.T_cap = h->T_cap;
@@ -746,19 +753,19 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     memset(&a, 0, sizeof(a));
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_q;
     a.fp8 = h->fp8, a.wscale = w.s_o;
-    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
-    RC(ddk_gemv(EPI_RESID, a, st));
+    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
+    RC(gemv(EPI_RESID, a));
     memset(&a, 0, sizeof(a));
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = nb, a.xop = h->xop_d;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
-    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.xop_next = h->xop_ff;
-    RC(ddk_gemv(EPI_SILU, a, st));
+    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.xop_next = h->xop_ff, a.S_next = h->S_ff;
+    RC(gemv(EPI_SILU, a));
     memset(&a, 0, sizeof(a));
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_ff;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
-    a.xop_next = h->xop_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
-    RC(ddk_gemv(EPI_RESID, a, st));
+    a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
+    RC(gemv(EPI_RESID, a));
     ssq_n = d / 16;
   }
   GemvArgs a;
@@ -767,7 +774,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   a.out = logits_out, a.ldo = h->Vpad, a.n_valid = h->V;
-  RC(ddk_gemv(EPI_STORE, a, st));
+  RC(gemv(EPI_STORE, a));
   return DD_OK;
 }
 
@@ -931,8 +938,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
 // Per step and sequence the weights are read 1/n + 1 times instead of twice.
 // -----------------------------------------------------------------------------------------------
 struct ScatterTab {
-  float* logits[8];
-  int32_t* argmax[8];
+  float* logits[16];
+  int32_t* argmax[16];
 };
 __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, ScatterTab tab) {
   int m = blockIdx.x;
@@ -944,10 +951,11 @@ __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argma
 
 static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  DD_REQUIRE(lanes && n >= 1 && n <= 8, "dd_lm_group_step: 1..8 sequences per group (got %d)", n);
+  DD_REQUIRE(lanes && n >= 1 && n <= 16, "dd_lm_group_step: 1..16 sequences per group (got %d)", n);
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_group_step: bad K / mprobs");
   dd_lm* h0 = lanes[0];
   DD_REQUIRE(h0, "dd_lm_group_step: null handle");
+  DD_REQUIRE(n <= 8 || !h0->fp8, "dd_lm_group_step: more than 8 sequences need bf16 weights (the grouped GEMV has no fp8 path)");
   dd_lm* owner = h0->wsrc ? h0->wsrc : h0;
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
@@ -1109,7 +1117,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
 // changed since it was captured; the cache lives in the first lane.
 extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= 8 && lanes[0] && (K == 0 || mprobs);
+  bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= 16 && lanes[0] && (K == 0 || mprobs);
   for (int m = 0; graphable && m < n; ++m)
     graphable = lanes[m] && lanes[m]->prefilled && lanes[m]->steps_since_prefill >= 1 &&
                 lanes[m]->T_host + 1 < lanes[m]->T_cap && lanes[m]->n_tok_host < MAX_NEW_TOKENS;
@@ -1151,7 +1159,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   struct Saved {
     int T, N, K, S;
     bool leak;
-  } sv[8];
+  } sv[16];
   for (int m = 0; m < n; ++m)
     sv[m] = {lanes[m]->T_host, lanes[m]->n_tok_host, lanes[m]->last_K, lanes[m]->steps_since_prefill, lanes[m]->have_leak};
   auto restore = [&]() {

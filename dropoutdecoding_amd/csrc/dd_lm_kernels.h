@@ -118,16 +118,16 @@ struct AttnDecodeArgs {
   // lanes (n_lanes > 0): row m of the pass belongs to sequence m — its own cache, length, span and (un-shifted) bits.
   // Used by the fused base pass of a group of sequences; kc/vc/state/drop_bits/span_* above are ignored then.
   int n_lanes;
-  int lane_groups;       // 0: lane m = row m (fused base pass).  2 / 4: a 16- / 32-row pass of that many sequences — rows
+  int lane_groups;       // 0: lane m = row m (fused base pass of up to 16 sequences).  2 / 4: a 16- / 32-row pass of that many sequences — rows
                          // 8g..8g+7 are members of lane g (each group reads its own cache with its own drop bits, bit = row & 7)
   const float* knew_g[4];  // lane_groups > 0: new K/V rows of group g
   const float* vnew_g[4];
   int max_T;             // host: largest prefix length among the lanes (grid sizing)
-  const float* lane_kc[8];
-  const float* lane_vc[8];
-  const DDState* lane_state[8];
-  const uint8_t* lane_bits[8];
-  int lane_span_start[8], lane_span_len[8];
+  const float* lane_kc[16];
+  const float* lane_vc[16];
+  const DDState* lane_state[16];
+  const uint8_t* lane_bits[16];
+  int lane_span_start[16], lane_span_len[16];
 };
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
 int ddk_attn_grid_tiles(int T, int T_cap);   // tiles the decode attention is launched with for a prefix of T keys

@@ -780,12 +780,13 @@ int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
 template <int NBT, int G, int GH, int ML = 0>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
-  const int RT = ML == 1 ? 8 * G : (ML == 2 ? 8 * a.lane_groups * G : NBT * G);   // rows per kv head in the partial buffers
+  const int lane_rows = a.n_lanes > 8 ? 16 : 8;   // ML == 1: rows per q head in the buffers (what the combine is built for)
+  const int RT = ML == 1 ? lane_rows * G : (ML == 2 ? 8 * a.lane_groups * G : NBT * G);   // rows per kv head in the partial buffers
   const int g0 = ML == 1 ? 0 : (ML == 2 ? (blockIdx.z % (G / GH)) * GH : blockIdx.z * GH);
   const int lane_row = ML == 1 ? blockIdx.z : (ML == 2 ? blockIdx.z / (G / GH) : 0);
   // partial-buffer row of this workgroup's row r (= local head r / NBT, member r % NBT)
   auto buf_row = [&](int r) -> int {
-    if (ML == 1) return r * 8 + lane_row;
+    if (ML == 1) return r * lane_rows + lane_row;
     if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + r % NBT;
     return g0 * NBT + r;
   };
@@ -988,7 +989,8 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
   k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
-  k_attn_combine<8, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
+  if (a.n_lanes > 8) k_attn_combine<16, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
+  else k_attn_combine<8, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
 }
 
@@ -1030,7 +1032,7 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
     return DD_OK;
   }
   if (a.n_lanes > 0) {
-    DD_REQUIRE(a.n_lanes <= 8 && a.nb == a.n_lanes, "attn: %d lanes for %d rows", a.n_lanes, a.nb);
+    DD_REQUIRE(a.n_lanes <= 16 && a.nb == a.n_lanes, "attn: %d lanes for %d rows", a.n_lanes, a.nb);
     if (G == 1) launch_attn_lanes<1>(a, st);
     else if (G == 2) launch_attn_lanes<2>(a, st);
     else launch_attn_lanes<4>(a, st);
