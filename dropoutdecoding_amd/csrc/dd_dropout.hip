@@ -251,6 +251,35 @@ __global__ __launch_bounds__(1024) void k_argmax_rows(const float* __restrict__ 
   if (threadIdx.x == 0) out[blockIdx.x] = a.i;
 }
 
+// rows of up to 4 sequences (their K member logits) in one launch: grid (R, n)
+struct ArgmaxLanes {
+  const float* x[4];
+  int32_t* out[4];
+};
+__global__ __launch_bounds__(1024) void k_argmax_rows_lanes(ArgmaxLanes t, int V, int ld) {
+  __shared__ ArgMax sh[16];
+  const float* r = t.x[blockIdx.y] + (size_t)blockIdx.x * ld;
+  ArgMax a = {-INFINITY, 0x7fffffff};
+  for (int v = threadIdx.x; v < V; v += 1024) {
+    float xv = r[v];
+    if (better(xv, v, a.v, a.i)) {
+      a.v = xv;
+      a.i = v;
+    }
+  }
+  a = block_argmax(a, sh);
+  if (threadIdx.x == 0) t.out[blockIdx.y][blockIdx.x] = a.i;
+}
+int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, int n, int R, int V, int ld, hipStream_t st) {
+  DD_REQUIRE(x && out && n >= 1 && n <= 4 && R >= 1, "dd_argmax_rows_lanes: bad arguments");
+  ArgmaxLanes t;
+  memset(&t, 0, sizeof(t));
+  for (int i = 0; i < n; ++i) t.x[i] = x[i], t.out[i] = out[i];
+  k_argmax_rows_lanes<<<dim3(R, n), 1024, 0, st>>>(t, V, ld);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 extern "C" int dd_argmax_rows(const float* x, int R, int V, int ld, int32_t* out, void* stream_) {
   DD_REQUIRE(x && out && R >= 1 && V >= 1 && ld >= V, "dd_argmax_rows: bad arguments");
   k_argmax_rows<<<R, 1024, 0, (hipStream_t)stream_>>>(x, V, ld, out);
@@ -468,8 +497,7 @@ __device__ int block_exclusive_scan_flag(bool flag, int* sh /*>=17*/, int* total
   return off + within;
 }
 
-__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned char* smem) {
   float* e = (float*)smem;                       // [Lp]
   float* u = e + MASK_MAX_L;                     // [Lp] uniforms of the current member, or sort buffer
   uint8_t* running = (uint8_t*)(u + MASK_MAX_L);  // [L]
@@ -581,6 +609,82 @@ __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
   }
 }
 
+__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  sample_masks_body(P, smem);
+}
+
+// Group step: the keep set (models/llava.py:443-482 from the base argmax already on the device) and the K masks of up to
+// 16 sequences in ONE launch, one workgroup per sequence, each from its own mt19937 state.
+struct MaskLanes {
+  MaskParams common;                 // K, mode, rng_mode, scale[], q[]; per-sequence fields below override the rest
+  int n, k_top;
+  const float* epi[16];
+  int L[16];
+  uint8_t* keep[16];
+  const int32_t* argmax[16];
+  const int32_t* topk[16];
+  uint32_t* rng_state[16];
+  uint8_t* drop[16];
+  int32_t* n_drop[16];
+  uint8_t* drop_bits[16];
+};
+__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks_lanes(MaskLanes M) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int m = blockIdx.x;
+  const int L = M.L[m], k = M.k_top;
+  const int tok = M.argmax[m][0];
+  for (int l = threadIdx.x; l < L; l += MASK_THREADS) {
+    bool hit = false;
+    for (int j = 0; j < k; ++j) hit |= (M.topk[m][(size_t)l * k + j] == tok);
+    M.keep[m][l] = hit ? 1 : 0;
+  }
+  __syncthreads();                   // keep[] is read back by this same workgroup
+  MaskParams P = M.common;
+  P.epi = M.epi[m], P.L = L, P.keep = M.keep[m], P.uniforms = nullptr, P.rng_state = M.rng_state[m];
+  P.drop = M.drop[m], P.n_drop = M.n_drop[m], P.idx = nullptr, P.drop_bits = M.drop_bits[m];
+  sample_masks_body(P, smem);
+}
+
+struct MaskLaneArgs {                // host-side description of one sequence for dd_sample_masks_lanes
+  const float* epi;
+  int L;
+  uint8_t* keep;
+  const int32_t* argmax;
+  const int32_t* topk;
+  uint32_t* rng_state;
+  uint8_t* drop;
+  int32_t* n_drop;
+  uint8_t* drop_bits;
+};
+int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st) {
+  DD_REQUIRE(lanes && n >= 1 && n <= 16 && K >= 1 && K <= 64 && mode >= 0 && mode <= 4, "dd_sample_masks_lanes: bad arguments");
+  MaskLanes M;
+  memset(&M, 0, sizeof(M));
+  M.common.K = K, M.common.mode = mode, M.common.rng_mode = mode == DD_MASK_IBLIP_QUANTILE ? DD_RNG_INJECTED : DD_RNG_MT19937;
+  for (int k = 0; k < K; ++k) {
+    M.common.scale[k] = (float)(mprobs[k] - 0.1);
+    M.common.q[k] = (float)(1.0 - mprobs[k]);
+  }
+  M.n = n, M.k_top = k_top;
+  for (int m = 0; m < n; ++m) {
+    DD_REQUIRE(lanes[m].L >= 1 && lanes[m].L <= MASK_MAX_L, "dd_sample_masks_lanes: L out of range");
+    DD_REQUIRE(mode == DD_MASK_IBLIP_QUANTILE || lanes[m].rng_state, "dd_sample_masks_lanes: sequence %d needs an rng", m);
+    M.epi[m] = lanes[m].epi, M.L[m] = lanes[m].L, M.keep[m] = lanes[m].keep, M.argmax[m] = lanes[m].argmax;
+    M.topk[m] = lanes[m].topk, M.rng_state[m] = lanes[m].rng_state, M.drop[m] = lanes[m].drop, M.n_drop[m] = lanes[m].n_drop;
+    M.drop_bits[m] = lanes[m].drop_bits;
+  }
+  size_t smem = (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  k_sample_masks_lanes<<<n, MASK_THREADS, smem, st>>>(M);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
                          int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
                          int32_t* idx, uint8_t* drop_bits, hipStream_t st) {
@@ -642,6 +746,39 @@ __global__ void k_vote(const int32_t* __restrict__ ids, int K, int32_t* __restri
   }
   out2[0] = best_k;        // first member whose argmax is the majority id
   out2[1] = ids[best_k];
+}
+
+// the votes of up to 4 sequences in one launch (block = sequence)
+struct VoteLanes {
+  const int32_t* ids[4];
+  int32_t* out2[4];
+};
+__global__ void k_vote_lanes(VoteLanes t, int K) {
+  if (threadIdx.x != 0) return;
+  const int32_t* ids = t.ids[blockIdx.x];
+  int best_k = 0, best_c = 0;
+  for (int k = 0; k < K; ++k) {
+    bool first = true;
+    for (int j = 0; j < k; ++j) first &= (ids[j] != ids[k]);
+    if (!first) continue;
+    int c = 0;
+    for (int j = 0; j < K; ++j) c += (ids[j] == ids[k]);
+    if (c > best_c) {
+      best_c = c;
+      best_k = k;
+    }
+  }
+  t.out2[blockIdx.x][0] = best_k;
+  t.out2[blockIdx.x][1] = ids[best_k];
+}
+int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, int n, int K, hipStream_t st) {
+  DD_REQUIRE(ids && out2 && n >= 1 && n <= 4 && K >= 1 && K <= 4096, "dd_vote_lanes: bad arguments");
+  VoteLanes t;
+  memset(&t, 0, sizeof(t));
+  for (int i = 0; i < n; ++i) t.ids[i] = ids[i], t.out2[i] = out2[i];
+  k_vote_lanes<<<n, 64, 0, st>>>(t, K);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 
 extern "C" int dd_vote(const int32_t* ids, int K, int32_t* out2, void* stream_) {

@@ -15,6 +15,20 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
                          int32_t* idx, uint8_t* drop_bits, hipStream_t st);
 uint32_t* dd_rng_state_ptr(dd_rng* r);
 unsigned long long dd_rng_serial(dd_rng* r);
+struct MaskLaneArgs {
+  const float* epi;
+  int L;
+  uint8_t* keep;
+  const int32_t* argmax;
+  const int32_t* topk;
+  uint32_t* rng_state;
+  uint8_t* drop;
+  int32_t* n_drop;
+  uint8_t* drop_bits;
+};
+int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st);
+int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, int n, int R, int V, int ld, hipStream_t st);
+int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, int n, int K, hipStream_t st);
 static unsigned long long g_lm_serial = 0;   // handles are identified in graph keys by a serial that is never reused
 
 #define MAX_MEMBERS 16
@@ -508,6 +522,58 @@ __global__ void k_prefill_rows(int32_t* rows, int span_start, int L, int T0) {
   if (i < L) rows[i] = span_start + i;
   else if (i == L) rows[L] = T0 - 1;
 }
+// ---- the same two kernels for several sequences at once (group step): block = sequence
+struct StepBeginLanes {
+  DDState* st[16];
+  const uint8_t* leak_bits[16];
+  int L[16], mask_positions[16];
+};
+__global__ __launch_bounds__(256) void k_step_begin_lanes(StepBeginLanes t) {
+  __shared__ int cnt[4];
+  const int q = blockIdx.x;
+  int c = 0;
+  if (t.mask_positions[q])
+    for (int l = threadIdx.x; l < t.L[q]; l += 256) c += t.leak_bits[q][l] & 1;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) t.st[q]->pos = t.st[q]->T - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+}
+struct StepEndLanes {
+  DDState* st[4];
+  const int32_t* member_tok[4];
+  const float* member_logits[4];
+  float* last_logits[4];
+  int32_t* tokens[4];
+  const uint8_t* drop_bits[4];
+  uint8_t* leak_bits[4];
+  volatile int32_t* mirror[4];
+  int L[4], leak[4];
+};
+__global__ __launch_bounds__(1024) void k_step_end_lanes(StepEndLanes t, int K, int Vpad) {
+  const int q = blockIdx.x;
+  DDState* st = t.st[q];
+  const int win = st->winner;
+  const float* src = t.member_logits[q] + (size_t)win * Vpad;
+  for (int i = threadIdx.x; i < Vpad; i += 1024) t.last_logits[q][i] = src[i];
+  if (t.leak[q])
+    for (int l = threadIdx.x; l < t.L[q]; l += 1024)
+      t.leak_bits[q][l] = (t.drop_bits[q][(size_t)((K - 1) >> 3) * t.L[q] + l] >> ((K - 1) & 7)) & 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tok = t.member_tok[q][win];
+    int n = st->n_tok;
+    if (n < MAX_NEW_TOKENS) {
+      t.tokens[q][n] = tok;
+      t.mirror[q][1 + n] = tok;
+      __threadfence_system();
+      t.mirror[q][0] = n + 1;
+    }
+    st->n_tok = n + 1;
+    st->cur_tok = tok;
+    st->T = st->T + 1;
+  }
+}
 __global__ void k_set_token(DDState* st, int tok) {
   if (threadIdx.x == 0) st->cur_tok = tok;
 }
@@ -920,13 +986,57 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   for (int g = 0; g < ng; ++g) a.out_g[g] = qs[g]->member_logits;
   a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
   RC(ddk_gemv_groups(EPI_STORE, a, st));
+  return DD_OK;
+}
+
+// what follows a multi-group sweep: member argmax, vote, winner's K/V appended, token emitted — for the ng sequences of
+// the sweep with ONE launch per stage (dd_lm_step_commit's work, block = sequence)
+static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st) {
+  const int d = h->d;
+  const float* lg[4];
+  int32_t* tk[4];
+  for (int g = 0; g < ng; ++g) lg[g] = qs[g]->member_logits, tk[g] = qs[g]->member_tok;
+  RC(dd_argmax_rows_lanes(lg, tk, ng, K, h->V, h->Vpad, st));
+  bool plain_vote = true;
   for (int g = 0; g < ng; ++g) {
     dd_lm* q = qs[g];
-    RC(dd_argmax_rows(q->member_logits, K, q->V, q->Vpad, q->member_tok, st));
-    if (q->cfg.vote_on == DD_VOTE_HIDDEN) {
+    if (q->cfg.vote_on == DD_VOTE_HIDDEN) {    // InstructBLIP: argmax over the final-normed hidden state (instructblip.py:125-137)
       RC(ddk_final_norm_rows(h->xa + (size_t)g * 8 * d, K, d, h->final_norm, h->cfg.rms_eps, q->hidden, st));
       RC(dd_argmax_rows(q->hidden, K, d, d, q->member_vote, st));
     }
+    plain_vote &= q->cfg.vote_on != DD_VOTE_AVERAGE;
+  }
+  if (!plain_vote) {                            // select_by_average: per sequence, as dd_lm_step_commit does it
+    for (int g = 0; g < ng; ++g) {
+      RC(dd_lm_step_commit(qs[g], K, st));
+      qs[g]->steps_since_prefill++;
+    }
+    return DD_OK;
+  }
+  const int32_t* ids[4];
+  int32_t* out2[4];
+  CommitLanes cl;
+  StepEndLanes el;
+  memset(&cl, 0, sizeof(cl));
+  memset(&el, 0, sizeof(el));
+  cl.lsk = h->lsk, cl.lsv = h->lsv;
+  for (int g = 0; g < ng; ++g) {
+    dd_lm* q = qs[g];
+    ids[g] = q->cfg.vote_on == DD_VOTE_HIDDEN ? q->member_vote : q->member_tok;
+    out2[g] = &q->state->winner;
+    cl.knew[g] = q->knew, cl.vnew[g] = q->vnew, cl.kc[g] = q->kc, cl.vc[g] = q->vc, cl.state[g] = q->state;
+    el.st[g] = q->state, el.member_tok[g] = q->member_tok, el.member_logits[g] = q->member_logits;
+    el.last_logits[g] = q->last_logits, el.tokens[g] = q->tokens, el.drop_bits[g] = q->drop_bits, el.leak_bits[g] = q->leak_bits;
+    el.mirror[g] = q->tok_host_dev, el.L[g] = q->L, el.leak[g] = q->cfg.leak_mask ? 1 : 0;
+  }
+  RC(dd_vote_lanes(ids, out2, ng, K, st));
+  RC(ddk_commit_kv_lanes(cl, ng, h->Lyr, MAX_MEMBERS, h->kv_dim, h->T_cap, st));
+  k_step_end_lanes<<<ng, 1024, 0, st>>>(el, K, h->Vpad);
+  DD_CHECK_LAUNCH();
+  for (int g = 0; g < ng; ++g) {
+    dd_lm* q = qs[g];
+    q->T_host += 1, q->n_tok_host += 1, q->steps_since_prefill++;
+    if (q->cfg.leak_mask) q->have_leak = true;
   }
   return DD_OK;
 }
@@ -974,9 +1084,14 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     DD_REQUIRE(q->n_tok_host < MAX_NEW_TOKENS, "dd_lm_group_step: token buffer full");
     DD_REQUIRE(K == 0 || q->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || (rngs && rngs[m]), "dd_lm_group_step: sequence %d needs an rng", m);
   }
-  for (int m = 0; m < n; ++m) {
-    dd_lm* q = lanes[m];
-    k_step_begin<<<1, 256, 0, st>>>(q->state, q->leak_bits, q->L, q->cfg.leak_mask == 2 ? 1 : 0);
+  {
+    StepBeginLanes t;
+    memset(&t, 0, sizeof(t));
+    for (int m = 0; m < n; ++m) {
+      dd_lm* q = lanes[m];
+      t.st[m] = q->state, t.leak_bits[m] = q->leak_bits, t.L[m] = q->L, t.mask_positions[m] = q->cfg.leak_mask == 2 ? 1 : 0;
+    }
+    k_step_begin_lanes<<<n, 256, 0, st>>>(t);
     DD_CHECK_LAUNCH();
   }
   h0->bit0 = 0;
@@ -992,10 +1107,22 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   }
   // masks of every sequence first (each from its own rng stream), then the members: two sequences per 16-row sweep where
   // possible (bf16 weights, K <= 8), the 8-row sweep otherwise
+  bool same_rule = true;
   for (int m = 0; m < n; ++m) {
-    dd_lm* q = lanes[m];
-    q->last_K = K;
-    if (K > 0) {
+    lanes[m]->last_K = K;
+    same_rule &= lanes[m]->cfg.mask_mode == h0->cfg.mask_mode && lanes[m]->cfg.k_top == h0->cfg.k_top;
+  }
+  if (K > 0 && same_rule) {          // keep sets + masks of all sequences: one launch, one workgroup per sequence
+    MaskLaneArgs ml[16];
+    for (int m = 0; m < n; ++m) {
+      dd_lm* q = lanes[m];
+      ml[m] = {q->epi, q->L, q->keep, q->argmax_base, q->topk_ids, dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop,
+               q->drop_bits};
+    }
+    RC(dd_sample_masks_lanes(ml, n, h0->cfg.k_top, mprobs, K, h0->cfg.mask_mode, st));
+  } else if (K > 0) {
+    for (int m = 0; m < n; ++m) {
+      dd_lm* q = lanes[m];
       RC(dd_overlap_keep_from_argmax(q->argmax_base, q->topk_ids, q->L, q->cfg.k_top, q->keep, st));
       RC(dd_sample_masks_impl(q->epi, q->L, mprobs, K, q->keep, q->cfg.mask_mode, DD_RNG_MT19937, nullptr,
                               dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits, st));
@@ -1009,10 +1136,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
       const int ng = !multi ? 1 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1));
       if (ng > 1) {
         RC(lm_sweep_groups(h0, lanes + m, ng, K, st));
-        for (int j = 0; j < ng; ++j) {
-          RC(dd_lm_step_commit(lanes[m + j], K, stream_));
-          lanes[m + j]->steps_since_prefill++;
-        }
+        RC(group_finish(h0, lanes + m, ng, K, st));
         m += ng - 1;
         continue;
       }

@@ -177,6 +177,15 @@ struct EmbedLanes {
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
                          u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st);   // rows = 8, 16 or 32
 int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st);
+struct CommitLanes {       // winners of up to 4 sequences appended to their caches in one launch
+  const float* knew[4];
+  const float* vnew[4];
+  float* kc[4];
+  float* vc[4];
+  const DDState* state[4];
+  size_t lsk, lsv;
+};
+int ddk_commit_kv_lanes(const CommitLanes& t, int n, int n_layers, int rows_per_layer, int kv_dim, int T_cap, hipStream_t st);
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
                   float* vc, size_t layer_stride_k, size_t layer_stride_v, int T_cap, const DDState* state,
                   int use_winner, hipStream_t st);

@@ -1502,6 +1502,26 @@ __global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ kne
     vl[((size_t)kvh * T_cap + T) * HEAD_DIM + idx] = vr[i];
   }
 }
+// the same for up to 4 sequences in one launch: grid (layers, sequences)
+__global__ __launch_bounds__(256) void k_commit_kv_lanes(CommitLanes t, int rows_per_layer, int kv_dim, int T_cap) {
+  const int layer = blockIdx.x, q = blockIdx.y;
+  const DDState* state = t.state[q];
+  const int row = state->winner, T = state->T;
+  const float* kr = t.knew[q] + ((size_t)layer * rows_per_layer + row) * kv_dim;
+  const float* vr = t.vnew[q] + ((size_t)layer * rows_per_layer + row) * kv_dim;
+  float* kl = t.kc[q] + (size_t)layer * t.lsk;
+  float* vl = t.vc[q] + (size_t)layer * t.lsv;
+  for (int i = threadIdx.x; i < kv_dim; i += 256) {
+    int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
+    kl[(((size_t)kvh * 32 + (idx >> 2)) * T_cap + T) * 4 + (idx & 3)] = kr[i];
+    vl[((size_t)kvh * T_cap + T) * HEAD_DIM + idx] = vr[i];
+  }
+}
+int ddk_commit_kv_lanes(const CommitLanes& t, int n, int n_layers, int rows_per_layer, int kv_dim, int T_cap, hipStream_t st) {
+  k_commit_kv_lanes<<<dim3(n_layers, n), 256, 0, st>>>(t, rows_per_layer, kv_dim, T_cap);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
                   float* vc, size_t lsk, size_t lsv, int T_cap, const DDState* state, int use_winner, hipStream_t st) {
   k_commit_kv<<<n_layers, 256, 0, st>>>(knew, vnew, rows_per_layer, kv_dim, kc, vc, lsk, lsv, T_cap, state, use_winner);
