@@ -15,7 +15,7 @@ class StubEngine:
     def __init__(self, script):
         self.script, self.n, self.calls = list(script), 0, []
 
-    def prefill(self, embeds, start, L, first_step_ensemble=False):
+    def prefill(self, embeds, start, L, first_step_ensemble=False, stream=None):
         self.calls.append(("prefill", tuple(embeds.shape), start, L))
         self.n = 1
 
