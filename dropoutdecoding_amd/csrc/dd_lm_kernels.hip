@@ -782,12 +782,17 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
   const int lane_rows = a.n_lanes > 8 ? 16 : 8;   // ML == 1: rows per q head in the buffers (what the combine is built for)
   const int RT = ML == 1 ? lane_rows * G : (ML == 2 ? 8 * a.lane_groups * G : NBT * G);   // rows per kv head in the partial buffers
-  const int g0 = ML == 1 ? 0 : (ML == 2 ? (blockIdx.z % (G / GH)) * GH : blockIdx.z * GH);
-  const int lane_row = ML == 1 ? blockIdx.z : (ML == 2 ? blockIdx.z / (G / GH) : 0);
+  // ML == 2 with NBT < 8: the 8 members of a group are split over 8 / NBT workgroups (member offset mo); each re-reads
+  // the K/V tile through L2 but carries 1 / (8 / NBT) of the LDS and VALU work, which is what bounds the 8-row variant
+  constexpr int MSPLIT = ML == 2 ? 8 / NBT : 1;
+  const int zz = ML == 2 ? blockIdx.z % ((G / GH) * MSPLIT) : 0;
+  const int g0 = ML == 1 ? 0 : (ML == 2 ? (zz / MSPLIT) * GH : blockIdx.z * GH);
+  const int mo = ML == 2 ? (zz % MSPLIT) * NBT : 0;
+  const int lane_row = ML == 1 ? blockIdx.z : (ML == 2 ? blockIdx.z / ((G / GH) * MSPLIT) : 0);
   // partial-buffer row of this workgroup's row r (= local head r / NBT, member r % NBT)
   auto buf_row = [&](int r) -> int {
     if (ML == 1) return r * lane_rows + lane_row;
-    if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + r % NBT;
+    if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + mo + r % NBT;
     return g0 * NBT + r;
   };
   extern __shared__ __align__(16) float att_sh[];
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 2. q rows (r = g*NBT + m) into LDS
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT;
-    int m = ML == 1 ? lane_row : r % NBT;                 // row within its group (live if < nb)
+    int m = ML == 1 ? lane_row : mo + r % NBT;            // row within its group (live if < nb)
     int qrow = ML == 2 ? lane_row * 8 + m : m;            // row of the pass
     q_sh[i] = (m < a.nb) ? a.qbuf[(size_t)qrow * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
   }
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 4. softmax statistics of the tile: wave w owns rows r = w, w+4, ...
   const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
   for (int r = wave; r < R; r += 4) {
-    int m = ML == 1 ? 0 : r % NBT;  // lanes: bit 0 of the sequence's own (leak) bits; groups: the member's bit
+    int m = ML == 1 ? 0 : mo + r % NBT;  // lanes: bit 0 of the sequence's own (leak) bits; groups: the member's bit
     float sv = (s_part[(0 * R + r) * ATT_SPLIT + lane] + s_part[(1 * R + r) * ATT_SPLIT + lane]) +
                (s_part[(2 * R + r) * ATT_SPLIT + lane] + s_part[(3 * R + r) * ATT_SPLIT + lane]);
     sv *= scaling;
@@ -995,21 +1000,31 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
 }
 
 // multi-group pass: members of NG sequences (8 rows each), every group over its own cache
-template <int G, int NG>
-static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
-  constexpr int GH = (8 * G > 16) ? 2 : G;
-  constexpr int R = 8 * GH;
+static int g_attn_msplit = 1;   // workgroups per group of 8 members in the grouped decode attention (1, 2 or 4; dd_set_tuning key 10)
+void ddk_set_attn_split(int v) { g_attn_msplit = v; }
+
+template <int G, int NG, int NBT>
+static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
+  constexpr int GH = (NBT * G > 16) ? 2 : G;
+  constexpr int R = NBT * GH;
   int splits = ddk_attn_grid_tiles(a.max_T, a.T_cap);
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<8, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_attn_partial<8, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH)), 256, smem, st>>>(a);
+  k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
   k_attn_combine<8 * NG, G><<<dim3(a.n_heads, 8 * NG), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
+}
+// multi-group pass: members of NG sequences (8 rows each), every group over its own cache
+template <int G, int NG>
+static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
+  if (g_attn_msplit == 4) return launch_attn_groups_n<G, NG, 2>(a, st);
+  if (g_attn_msplit == 2) return launch_attn_groups_n<G, NG, 4>(a, st);
+  return launch_attn_groups_n<G, NG, 8>(a, st);
 }
 
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {

@@ -339,7 +339,10 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
 /* Kernel tuning knobs for the benchmark scripts: key 0 = GEMV weight tiles in flight per wave (4/8/16),
  * 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves of a workgroup (0/1),
  * 3 = timing-only diagnostic build without x-operand loads (results are wrong; never use for output),
- * 8 = replay decode steps from a hipGraph (default 1). */
+ * 4 = ring (1) or batch (0, default) request order in the 8-row GEMV,
+ * 8 = replay decode steps from a hipGraph (default 1), 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4;
+ * default 4), 10 = workgroups per group of 8 members in the grouped decode attention (1, 2, 4; default 1).
+ * Keys 1 and 2 are accepted and ignored (settled: non-temporal weight loads, interleaved k-steps). */
 int dd_set_tuning(int key, int value);
 
 /* ---- several sequences over one set of weights -------------------------------------------------------------------------

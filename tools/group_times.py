@@ -7,6 +7,9 @@ from dropoutdecoding_amd.config import VOTING_NUMBERS_K8
 
 torch.cuda.set_device(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+from dropoutdecoding_amd import _lib
+if len(sys.argv) > 2:
+    _lib.load().dd_set_tuning(10, int(sys.argv[2]))
 engs = []
 for i in range(B):
     engs.append(lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_visual=576,
