@@ -19,4 +19,16 @@ for name, cfg, fam, L, T0 in (("llava-next-mistral-7b", lm.MISTRAL_7B, lm.FAMILY
     print(json.dumps({"model": name, "prefill_ms": round((t2 - t1) * 1e3, 1), "decode_ms_per_step": round((t3 - t2) / 127 * 1e3, 3),
                       "tokens_per_s_incl_prefill": round(128 / (t3 - t1), 1), "masked_numbers": st["masked_numbers"].tolist(),
                       "sweep8_ms": round(eng.time_sweep(8, 3), 3), "device_GB": round(eng.device_bytes / 1e9, 2)}), flush=True)
-    eng.close(); del eng; torch.cuda.empty_cache()
+    # the same shapes as 8 lanes over these weights (fused base pass + grouped member sweeps)
+    B = 8
+    lanes = [eng] + [lm.DropoutEngine(cfg, family=fam, max_seq=T0 + 140, max_visual=L, share_weights_with=eng) for _ in range(B - 1)]
+    for i, e in enumerate(lanes):
+        e.prefill(torch.randn(T0, 4096, device="cuda"), 0 if fam == lm.FAMILY_IBLIP else 5, L)
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    lm.EngineGroup(lanes).generate(128, mprobs=probs); torch.cuda.synchronize(); t5 = time.perf_counter()
+    print(json.dumps({"model": name, "lanes": B, "group_step_ms": round((t5 - t4) / 127 * 1e3, 3),
+                      "ms_per_image_token": round((t5 - t4) / 127 / B * 1e3, 3),
+                      "decode_tokens_per_s": round(B * 127 / (t5 - t4), 1)}), flush=True)
+    for e in reversed(lanes):
+        e.close()
+    del eng, lanes; torch.cuda.empty_cache()
