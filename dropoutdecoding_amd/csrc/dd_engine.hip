@@ -942,6 +942,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     GemvArgs a;
     memset(&a, 0, sizeof(a));
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
+    a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = qs[0]->state;
@@ -965,15 +966,18 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = ng;
+    a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
+    a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
     RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = ng;
+    a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
@@ -982,6 +986,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   GemvArgs a;
   memset(&a, 0, sizeof(a));
   a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
+  a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   for (int g = 0; g < ng; ++g) a.out_g[g] = qs[g]->member_logits;
   a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
@@ -1065,7 +1070,6 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_group_step: bad K / mprobs");
   dd_lm* h0 = lanes[0];
   DD_REQUIRE(h0, "dd_lm_group_step: null handle");
-  DD_REQUIRE(n <= 8 || !h0->fp8, "dd_lm_group_step: more than 8 sequences need bf16 weights (the grouped GEMV has no fp8 path)");
   dd_lm* owner = h0->wsrc ? h0->wsrc : h0;
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
@@ -1128,7 +1132,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
                               dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits, st));
     }
   }
-  const bool multi = g_pair_sweeps && K > 0 && K <= 8 && !h0->fp8;
+  const bool multi = g_pair_sweeps && K > 0 && K <= 8;
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
     if (K > 0) {
@@ -1477,7 +1481,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16 || nb == 32) && iters >= 1,
              "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 / 32 = the two- / four-group kernel)");
-  const int ngroups = (nb >= 16 && !h->fp8) ? nb / 8 : 0;
+  const int ngroups = nb >= 16 ? nb / 8 : 0;
   const bool wide = ngroups > 0;
   if (nb >= 16) nb = 8;
   auto gemv = [&](int epi, GemvArgs& a) -> int {

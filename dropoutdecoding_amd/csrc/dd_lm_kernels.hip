@@ -546,7 +546,7 @@ __device__ __forceinline__ void xop_store16(u32x4_t* xop, int k, int m, float y,
   xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y);   // plane = group of the row
 }
 
-template <int EPI, int TILES, int NG, int U = 4>
+template <int EPI, int TILES, int NG, int U = 4, int FP8 = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
   extern __shared__ float gg_sh[];
   float* red = gg_sh;                                   // [TILES * NG * 8 waves][256]
@@ -607,7 +607,51 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
     }
   }
 
-  int s = 0;
+  if constexpr (FP8) {
+    // fp8 weights: one 1 KiB load = 64 k of a tile row = two MFMA k-steps, expanded exactly to bf16 in registers ONCE and
+    // used for all NG operand planes; wave w takes 64-k steps w, w+8, ... (same order as k_gemv's fp8 path)
+    const int S2 = S >> 1;
+    const u32x4_t* wq[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) wq[t] = a.W + (size_t)(tile0 + t) * S2 * 64 + lane;
+    const u32x4_t* xq = a.xop + lane;
+    constexpr int UF = 2;
+    for (int s2 = wave; s2 < S2; s2 += GEMV_WAVES * UF) {
+      u32x4_t wf[TILES][UF], b0[UF][NG], b1[UF][NG];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) wf[t][u] = __builtin_nontemporal_load(wq[t] + (size_t)ss * 64);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            b0[u][g] = xq[(size_t)(2 * ss) * 64 + g * xplane];
+            b1[u][g] = xq[(size_t)(2 * ss + 1) * 64 + g * xplane];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            u32x4_t k0, k1;
+            fp8x16_to_bf16(wf[t][u], k0, k1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0),
+                                                                  __builtin_bit_cast(bf16x8_t, b0[u][g]), acc[t][g], 0, 0, 0);
+              acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1),
+                                                                  __builtin_bit_cast(bf16x8_t, b1[u][g]), acc[t][g], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  int s = FP8 ? spw : 0;
   for (; s + U <= spw; s += U) {
     u32x4_t b[U][NG], w[TILES][U];
 #pragma unroll
@@ -663,6 +707,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
       const float* r = &red[((tt * NG + eg) * GEMV_WAVES + w) * 256];
       y += r[o] + r[o + 32];
     }
+    if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
     return y;
   };
 
@@ -727,24 +772,29 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
   }
 }
 
-template <int EPI, int TILES, int NG>
-static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
+template <int EPI, int TILES, int NG, int FP8>
+static int launch_gemv_groups_f(const GemvArgs& a, hipStream_t st) {
   size_t smem = (size_t)(TILES * NG * GEMV_WAVES * 256 + 8 * NG + 16 * 8 * NG) * sizeof(float);
   // weight tiles requested per wave before the first MFMA: 4, except the two-tile (gate/up) kernel with four operand
   // planes, where 2 keeps the register file at two workgroups per CU (measured: 49 vs 53 us)
   constexpr int U = (TILES == 2 && NG == 4) ? 2 : 4;
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_gemv_groups<EPI, TILES, NG, U><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
+  k_gemv_groups<EPI, TILES, NG, U, FP8><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
   return DD_OK;
+}
+template <int EPI, int TILES, int NG>
+static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
+  return a.fp8 ? launch_gemv_groups_f<EPI, TILES, NG, 1>(a, st) : launch_gemv_groups_f<EPI, TILES, NG, 0>(a, st);
 }
 
 int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv_groups: K=%d must be a multiple of 256", a.S * 32);
-  DD_REQUIRE(a.nb >= 1 && a.nb <= 8 && !a.fp8, "gemv_groups: nb=%d rows per group, bf16 weights only", a.nb);
+  DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv_groups: nb=%d rows per group", a.nb);
+  DD_REQUIRE(!a.fp8 || a.wscale, "gemv_groups: fp8 weights need row scales");
   DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4, "gemv_groups: %d groups (2 or 4)", a.n_groups);
   int rc = DD_OK;
   const bool two = a.n_groups == 2;

@@ -670,3 +670,60 @@ def test_lanes_mid_scale_against_the_oracle(E):
         assert close(engines[i].logits(), ref.records[-1].logits)
     for e in reversed(engines):
         e.close()
+
+
+def test_fp8_lanes_grouped_sweeps(E):
+    """fp8 weight storage through the grouped GEMV (tiles expanded once, used for every operand plane): 11 lanes (fused
+    16-row base pass, 4 + 4 + 2 + 1 member sweeps) against the oracle on the dequantised weights, and a mid-size shape
+    whose k loops run full length bit for bit against solo runs."""
+    from dropoutdecoding_amd.lm import dequantize_fp8, quantize_fp8
+    rc = RefCfg(512, 512, 512, 2, 4, 2, 128, 1e-5, 1000000.0)
+    w = random_weights(rc, 33, 0.05)
+    wq = {k: (dequantize_fp8(*quantize_fp8(v)) if v.dim() == 2 and "embed_tokens" not in k else v) for k, v in w.items()}
+    probs = [0.2, 0.4, 0.6, 0.8]
+    shapes = [(60 + 5 * i, 3 + i % 4, 40) for i in range(11)]
+    cfg = E.LMConfig(512, 512, 512, 2, 4, 2, 128, 1e-5, 1000000.0)
+    engs = []
+    for i in range(len(shapes)):
+        engs.append(E.DropoutEngine(cfg, family=FAMILY_NEXT, max_seq=192, max_visual=40, seed=4, weight_format="fp8",
+                                    share_weights_with=engs[0] if engs else None))
+    engs[0].load_state_dict(w)
+    embs = [torch.randn(T0, 512, generator=torch.Generator().manual_seed(70 + i)) * 0.8 for i, (T0, _, _) in enumerate(shapes)]
+    for e, x, (T0, s0, L) in zip(engs, embs, shapes):
+        e.prefill(x.cuda(), s0, L)
+    toks = E.EngineGroup(engs).generate(6, mprobs=probs)
+    for i, (x, (T0, s0, L)) in enumerate(zip(embs, shapes)):
+        ref = RefDecoder(FAMILY_NEXT, rc, wq, probs, seed=4)
+        assert toks[i] == ref.generate(x, s0, L, 6), f"lane {i}"
+        assert close(engs[i].logits(), ref.records[-1].logits)
+    for e in reversed(engs):
+        e.close()
+    # full-length k loops: d = 2048, d_ff = 5632 (22 64-k steps per wave + tail), 5 lanes, synthetic fp8 weights
+    big = E.LMConfig(4099, 2048, 5632, 2, 16, 16, 128, 1e-5, 10000.0)
+    shapes = [(70, 3, 60), (80, 5, 64), (66, 1, 60), (90, 9, 70), (75, 2, 64)]
+    engs = []
+    for i in range(len(shapes)):
+        engs.append(E.DropoutEngine(big, family=FAMILY_LLAVA, max_seq=128, max_visual=70, seed=9, weight_format="fp8",
+                                    share_weights_with=engs[0] if engs else None))
+    engs[0].load_synthetic(3, 0.03)
+    embs = [torch.randn(T0, 2048, generator=torch.Generator().manual_seed(90 + i)).cuda() for i, (T0, _, _) in enumerate(shapes)]
+    for e, x, (T0, s0, L) in zip(engs, embs, shapes):
+        e.prefill(x, s0, L)
+    grp = E.EngineGroup(engs)
+    rec = [[] for _ in engs]
+    for s in range(3):
+        grp.decode_step(probs)
+        for i, e in enumerate(engs):
+            rec[i].append((e.last_step()["drop"].copy(), e.logits().copy(), e.base_logits().copy()))
+    toks = [e.tokens() for e in engs]
+    for i, (e, x, (T0, s0, L)) in enumerate(zip(engs, embs, shapes)):
+        e.rng.manual_seed(9)
+        e.prefill(x, s0, L)
+        for s in range(3):
+            e.decode_step(probs)
+            np.testing.assert_array_equal(e.last_step()["drop"], rec[i][s][0])
+            np.testing.assert_array_equal(e.logits(), rec[i][s][1], err_msg=f"lane {i} step {s}")
+            np.testing.assert_array_equal(e.base_logits(), rec[i][s][2], err_msg=f"lane {i} step {s}")
+        assert e.tokens() == toks[i]
+    for e in reversed(engs):
+        e.close()

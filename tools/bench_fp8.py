@@ -20,4 +20,15 @@ for name, cfg, fam, L, T0 in (("llava-1.5-7b", lm.LLAVA15_7B, lm.FAMILY_LLAVA, 5
             ms, by = eng.time_gemv(which, 8, 64)
             r[nm + "_GBs"] = round(by / ms / 1e6)
         print(json.dumps(r), flush=True)
-        eng.close(); del eng; torch.cuda.empty_cache()
+        B = 8                                  # the same as 8 lanes over these weights
+        lanes = [eng] + [lm.DropoutEngine(cfg, family=fam, max_seq=T0 + 140, max_visual=L, weight_format=fmt, share_weights_with=eng)
+                         for _ in range(B - 1)]
+        for e in lanes:
+            e.prefill(torch.randn(T0, 4096, device="cuda"), 5, L)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        lm.EngineGroup(lanes).generate(64, mprobs=probs); torch.cuda.synchronize(); t5 = time.perf_counter()
+        print(json.dumps({"model": name, "weights": fmt, "lanes": B, "group_step_ms": round((t5 - t4) / 63 * 1e3, 3),
+                          "ms_per_image_token": round((t5 - t4) / 63 / B * 1e3, 3)}), flush=True)
+        for e in reversed(lanes):
+            e.close()
+        del eng, lanes; torch.cuda.empty_cache()
