@@ -11,8 +11,8 @@ emb = torch.randn(672, 4096, device="cuda")
 eng.prefill(emb, 5, 576)
 L = _lib.load()
 rows = []
-for nb, dg in [(8, 8), (16, 8), (32, 8)]:
-    L.dd_set_tuning(0, dg)
+for nb, dg in [(8, 0), (16, 0), (32, 0)]:
+    L.dd_set_tuning(3, dg)
     r = {"rows": nb, "U": dg if dg != 8 else 4}
     for which, name in ((0, "qkv"), (1, "o"), (2, "gateup"), (3, "down")):
         best = 1e9
@@ -21,4 +21,4 @@ for nb, dg in [(8, 8), (16, 8), (32, 8)]:
             best = min(best, ms)
         r[name + "_us"] = round(best * 1e3, 2)
     print(json.dumps(r), flush=True)
-L.dd_set_tuning(0, 8)
+L.dd_set_tuning(3, 0)
