@@ -785,9 +785,10 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
 template <int EPI, int TILES, int NG, int FP8>
 static int launch_gemv_groups_f(const GemvArgs& a, hipStream_t st) {
   size_t smem = (size_t)(TILES * NG * GEMV_WAVES * 256 + 8 * NG + 16 * 8 * NG) * sizeof(float);
-  // weight tiles requested per wave before the first MFMA: 4, except the two-tile (gate/up) kernel with four operand
-  // planes, where 2 keeps the register file at two workgroups per CU (measured: 49 vs 53 us)
-  constexpr int U = (TILES == 2 && NG == 4) ? 2 : 4;
+  // weight tiles requested per wave before the first MFMA: 4; 2 for the two-tile kernels with four operand planes (keeps
+  // the register file at two workgroups per CU: gate/up 49 vs 53 us); 8 for o_proj / down (one workgroup per CU anyway:
+  // 32.0 vs 33.0 us)
+  constexpr int U = (TILES == 2 && NG == 4) ? 2 : (EPI == EPI_RESID ? 8 : 4);
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
