@@ -129,27 +129,52 @@ def load_sampled_ids(path: str) -> List[int]:
 
 
 # ---- the caption loop (chair_test.py:270-372) ---------------------------------------------------------------------------
-def caption_images(model, processor, items: Iterable, model_name: str, log: CaptionLog, load_image: Callable,
-                   max_new_tokens: int = 512, num_beams: int = 1, device="cuda", on_caption: Optional[Callable] = None) -> int:
-    """items: (image_id, image_path) pairs.  Builds the inputs the way the reference does for each family, calls
-    `model.generate(**inputs, max_new_tokens, num_beams, pad_token_id=eos)`, decodes, strips, filters, appends."""
+def _caption_inputs(processor, model_name: str, image, device):
     prompt = CHAIR_PROMPTS[model_name]
+    if model_name == "instructblip":
+        inputs = processor(images=image, text=prompt, return_tensors="pt")     # chair_test.py:289-292
+    else:
+        inputs = processor(prompt, image, return_tensors="pt")                  # chair_test.py:294
+    return inputs.to(device) if hasattr(inputs, "to") else inputs
+
+
+def caption_images(model, processor, items: Iterable, model_name: str, log: CaptionLog, load_image: Callable,
+                   max_new_tokens: int = 512, num_beams: int = 1, device="cuda", on_caption: Optional[Callable] = None,
+                   pipeline=None, lanes: int = 8) -> int:
+    """items: (image_id, image_path) pairs.  Builds the inputs the way the reference does for each family, calls
+    `model.generate(**inputs, max_new_tokens, num_beams, pad_token_id=eos)`, decodes, strips, filters, appends.
+
+    pipeline: a `dropoutdecoding_amd.vlm.GroupPipeline` over `model` — the images are then captioned `lanes` at a time
+    (same captions per image as its own lane's generate(); rows are appended in input order)."""
     n = 0
-    for image_id, path in items:
-        image = load_image(path)
-        if model_name == "instructblip":
-            inputs = processor(images=image, text=prompt, return_tensors="pt")     # chair_test.py:289-292
-        else:
-            inputs = processor(prompt, image, return_tensors="pt")                  # chair_test.py:294
-        inputs = inputs.to(device) if hasattr(inputs, "to") else inputs
-        output_ids = model.generate(**inputs, max_new_tokens=max_new_tokens, num_beams=num_beams,
-                                    pad_token_id=processor.tokenizer.eos_token_id)  # chair_test.py:337-342
+
+    def finish(image_id, output_ids):
+        nonlocal n
         text = processor.batch_decode(output_ids, skip_special_tokens=True)[0]
         caption = filter_unk_sentences(strip_prompt_echo(model_name, text))
         log.append(image_id, caption)
         if on_caption:
             on_caption(image_id, caption)
         n += 1
+
+    if pipeline is None:
+        for image_id, path in items:
+            inputs = _caption_inputs(processor, model_name, load_image(path), device)
+            finish(image_id, model.generate(**inputs, max_new_tokens=max_new_tokens, num_beams=num_beams,
+                                            pad_token_id=processor.tokenizer.eos_token_id))  # chair_test.py:337-342
+        return n
+    if num_beams != 1:
+        raise ValueError("the grouped path is greedy (num_beams=1), like the dropout-decoding path itself")
+    items = list(items)
+    ids_of = [[i for i, _ in items[b:b + lanes]] for b in range(0, len(items), lanes)]
+
+    def batches():
+        for b in range(0, len(items), lanes):
+            yield [dict(_caption_inputs(processor, model_name, load_image(path), device)) for _, path in items[b:b + lanes]]
+    for ids, outs in zip(ids_of, pipeline.run(batches(), max_new_tokens=max_new_tokens,
+                                              eos_token_id=getattr(model, "eos_token_ids", None) or None)):
+        for image_id, out in zip(ids, outs):
+            finish(image_id, out)
     return n
 
 
@@ -239,6 +264,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--use-random", type=_bool, default=False)
     p.add_argument("--avg", type=_bool, default=False)
     p.add_argument("--max-new-tokens", type=int, default=512)
+    p.add_argument("--lanes", type=int, default=1,
+                   help="images captioned concurrently on the GPU (1 = the reference's one-at-a-time loop; up to 16)")
     return p
 
 
@@ -265,9 +292,13 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     name = args.method + datetime.now().strftime("%m%d%H%M") + ".json"
     log = CaptionLog(os.path.join(args.output_dir, name))
     items = [(image_id_from_coco_filename(files[i]), os.path.join(args.coco_data_dir, "val2014", files[i])) for i in ids]
+    pipe = None
+    if args.lanes > 1:
+        from .vlm import GroupPipeline
+        pipe = GroupPipeline(model, lanes=args.lanes)
     n = caption_images(model, processor, items, args.model, log, lambda p: Image.open(p).convert("RGB"),
                        max_new_tokens=args.max_new_tokens, num_beams=args.num_beams or 1,
-                       on_caption=lambda i, c: print(c))
+                       on_caption=lambda i, c: print(c), pipeline=pipe, lanes=max(1, args.lanes))
     print("the result is saved into", args.output_dir, name, f"({n} captions)")
     return 0
 

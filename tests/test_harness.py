@@ -157,6 +157,28 @@ def test_caption_loop_calls_generate_like_the_reference(tmp_path):
     assert proc2.calls[0] == ((), {"images": "p", "text": "Describe the image."})
 
 
+class _FakePipeline:
+    def __init__(self, texts):
+        self.texts, self.batches = list(texts), []
+
+    def run(self, batches, max_new_tokens, eos_token_id=None):
+        for b in batches:
+            self.batches.append((len(b), max_new_tokens))
+            yield [self.texts.pop(0) for _ in b]
+
+
+def test_caption_loop_through_a_lane_pipeline(tmp_path):
+    proc = _FakeProcessor()
+    pipe = _FakePipeline([f"USER: x ASSISTANT: caption {i}." for i in range(5)])
+    log = H.CaptionLog(str(tmp_path / "g.json"))
+    n = H.caption_images(_FakeModel([]), proc, [(100 + i, f"/img/{i}.jpg") for i in range(5)], "llava-1.5", log,
+                         load_image=lambda p: p, device="cpu", pipeline=pipe, lanes=2, max_new_tokens=64)
+    assert n == 5 and pipe.batches == [(2, 64), (2, 64), (1, 64)]
+    assert H.read_caption_log(log.path) == [{"image_id": 100 + i, "caption": f"caption {i}."} for i in range(5)]
+    with pytest.raises(ValueError):
+        H.caption_images(_FakeModel([]), proc, [(1, "p")], "llava-1.5", log, load_image=lambda p: p, pipeline=pipe, num_beams=3)
+
+
 def test_pope_loop(tmp_path):
     proc = _FakeProcessor()
     model = _FakeModel(["USER:  \nIs there a cat? ASSISTANT: Yes", "q ASSISTANT: No"])
