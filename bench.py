@@ -248,12 +248,13 @@ def main() -> int:
 
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run
     # separately as the MI355X guide prescribes; FETCH_SIZE doubled for gfx950): bench.py itself cannot collect PMCs.
-    traffic = None
+    traffic = mfma_util = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
         for name, v in pm["kernels"].items():
             if name.startswith(f"void k_gemv_groups<2, 2, {dom_rows // 8}" if wide else "void k_gemv<2, 2"):
                 traffic = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+                mfma_util = v.get("mfma_util")
     except Exception:
         pass
 
@@ -276,6 +277,7 @@ def main() -> int:
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_summary.json (bytes per launch, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                         "mfma_util": mfma_util,     # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), same PMC summary
                          "bytes_per_launch": by, "ms_per_launch": round(ms, 5),
                          "other_gemv_GBs": kinds,
                          "packed_sweep_8_rows": {"ms": round(sweep_ms, 4), "algorithmic_bytes": sweep_bytes,
