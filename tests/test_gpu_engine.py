@@ -727,3 +727,30 @@ def test_fp8_lanes_grouped_sweeps(E):
         assert e.tokens() == toks[i]
     for e in reversed(engs):
         e.close()
+
+
+def test_long_generation_across_attention_launch_buckets(E):
+    """300 tokens per lane starting at 200 / 240 / 250 / 490 keys: the grouped step is re-captured whenever a lane's key-tile
+    bucket (4 tiles = 256 keys) changes, lanes cross at different steps.  Tokens against the oracle, logits bit for bit
+    against solo runs (which cross the same buckets through dd_lm_decode_step's own graph cache)."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    probs = [0.2, 0.5, 0.8]
+    shapes = [(200, 3, 150), (240, 5, 200), (250, 1, 240), (490, 7, 400)]
+    w, engines, embs = _lane_setup(E, FAMILY_LLAVA, rc, shapes, max_seq=832)
+    n_new = 300
+    for e, emb, (T0, s0, L) in zip(engines, embs, shapes):
+        e.prefill(emb.cuda(), s0, L)
+    toks = E.EngineGroup(engines).generate(n_new, mprobs=probs)
+    finals = [e.logits().copy() for e in engines]
+    sums = [e.kv_sums().copy() for e in engines]
+    for i, (e, emb, (T0, s0, L)) in enumerate(zip(engines, embs, shapes)):
+        assert len(toks[i]) == n_new
+        if i in (0, 3):                                  # the oracle is slow at these lengths: two lanes are enough
+            assert toks[i] == RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=7).generate(emb, s0, L, n_new), f"lane {i}"
+        e.rng.manual_seed(7)
+        e.prefill(emb.cuda(), s0, L)
+        assert e.generate(n_new, mprobs=probs) == toks[i], f"lane {i} solo"
+        np.testing.assert_array_equal(e.logits(), finals[i])
+        np.testing.assert_array_equal(e.kv_sums(), sums[i])
+    for e in reversed(engines):
+        e.close()
