@@ -12,6 +12,9 @@ settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap
 #   settings['first_step_ensemble'] = True   -> the `# if True:` toggle at models/llava.py:336-337 (read per generate())
 #   settings['mask_method'] = 'epis_no_overlap' -> models/llava.py:663-683 / instructblip.py:486-505 (read at model build)
 #   settings['use_avg'] = True               -> select_by_average, models/llava.py:37-52 (read at model build)
+# Not in the reference at all (its harness re-runs the whole prompt for every question):
+#   settings['reuse_image_prefix'] = True    -> consecutive prompts over the SAME image keep the image prefix's K/V,
+#                                               uncertainty and top-k ids and prefill only the new text (LLaVA families)
 
 # K = 8 is not reachable from the reference CLI (chair_test.py:163-175); BASELINE configs 3-5 use this list.
 VOTING_NUMBERS_K8 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]

@@ -574,6 +574,14 @@ __global__ __launch_bounds__(1024) void k_step_end_lanes(StepEndLanes t, int K, 
     st->T = st->T + 1;
   }
 }
+__global__ void k_state_truncate(DDState* st, int T) {
+  if (threadIdx.x == 0) {
+    st->T = T;
+    st->pos = T;
+    st->n_tok = 0;
+    st->winner = 0;
+  }
+}
 __global__ void k_set_token(DDState* st, int tok) {
   if (threadIdx.x == 0) st->cur_tok = tok;
 }
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(1024) void k_first_token_from_member(DDState* st, c
 // all layers over the T0 prompt rows in h->px (overwritten in place), K/V written into the cache.  drop_plane/drop_bit:
 // the member's zero columns of the 2-D attention mask (first-token ensemble), or nullptr for the un-masked pass.
 static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_bit, int span_start, int span_len,
-                          hipStream_t st) {
+                          hipStream_t st, int pos0 = 0) {
   const int d = h->d, dff = h->dff;
   // fp8 storage: the prefill GEMM runs on a bf16 expansion of ONE matrix at a time (exact), scales in its epilogue
   auto wsel = [&](GemmArgs& g, u32x4_t* W, float* scale, int n_tiles, int S) -> int {
@@ -628,11 +636,11 @@ static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.n_tiles = h->qkv_tiles;
     RC(wsel(g, w.wqkv, w.s_qkv, h->qkv_tiles, h->S_d));
     g.qbuf = h->pq, g.kc = h->kc + (size_t)l * h->lsk, g.vc = h->vc + (size_t)l * h->lsv, g.T_cap = h->T_cap;
-    g.q_tiles = h->q_tiles, g.k_tiles = h->k_tiles, g.q_dim = h->q_dim, g.kv_dim = h->kv_dim, g.pos0 = 0;
+    g.q_tiles = h->q_tiles, g.k_tiles = h->k_tiles, g.q_dim = h->q_dim, g.kv_dim = h->kv_dim, g.pos0 = pos0;
     g.rope_cos = h->rope_cos, g.rope_sin = h->rope_sin;
     RC(ddk_gemm(EPI_QKV, g, st));
     RC(ddk_attn_prefill(h->pq, g.kc, g.vc, T0, h->T_cap, h->H, h->Hkv, h->p1_hi, h->p1_lo, drop_plane, drop_bit,
-                        span_start, span_len, st));
+                        span_start, span_len, pos0, st));
     memset(&g, 0, sizeof(g));
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_q, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
     RC(wsel(g, w.wo, w.s_o, d / 16, h->S_q));
@@ -698,6 +706,49 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   h->T_host = T0, h->span_start = span_start, h->L = L, h->n_tok_host = 1, h->prefilled = true, h->have_leak = false;
   h->last_K = 0;
   h->steps_since_prefill = 0;
+  return DD_OK;
+}
+
+// Cut the sequence back to its first T_keep positions (T_keep >= end of the visual span): everything the prefill derived
+// from the image — uncertainty, top-k ids, image logits — stays valid because attention is causal.  Used with
+// dd_lm_prefill_extend to answer several questions about ONE image (pope_test/pope_test.py asks 6 per image) without
+// re-running the 576 visual positions: the reference re-runs the whole prompt each time (pope_test.py:228-232); the K/V
+// rows it recomputes for the shared prefix are the ones already in the cache.
+extern "C" int dd_lm_truncate(dd_lm* h, int T_keep, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && h->prefilled, "dd_lm_truncate: no prefilled sequence");
+  DD_REQUIRE(T_keep >= h->span_start + h->L && T_keep >= 1 && T_keep <= h->T_host,
+             "dd_lm_truncate: T_keep=%d outside [%d, %d] (end of the visual span .. current length)", T_keep,
+             h->span_start + h->L, h->T_host);
+  k_state_truncate<<<1, 64, 0, st>>>(h->state, T_keep);
+  DD_CHECK_LAUNCH();
+  DD_HIP(hipMemsetAsync(h->leak_bits, 0, h->Lmax, st));
+  h->tok_host[0] = 0;
+  h->T_host = T_keep, h->n_tok_host = 0, h->have_leak = false, h->last_K = 0, h->steps_since_prefill = 0;
+  return DD_OK;
+}
+
+// Append n more PROMPT positions (fp32 embeddings [n][d]) to a prefilled (or truncated) sequence: a chunked prefill over
+// the rows at positions T .. T+n-1 against the cache, then the greedy first token from the last row exactly as
+// dd_lm_prefill emits it.  Row for row the arithmetic is that of a full prefill of the longer prompt.
+extern "C" int dd_lm_prefill_extend(dd_lm* h, const float* embeds, int n, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && embeds && h->prefilled, "dd_lm_prefill_extend: null argument or no prefilled sequence");
+  DD_REQUIRE(h->n_tok_host <= 1, "dd_lm_prefill_extend: the sequence has already generated tokens (dd_lm_truncate first)");
+  DD_REQUIRE(n >= 1 && h->T_host + n < h->T_cap, "dd_lm_prefill_extend: %d more positions do not fit (length %d, capacity %d)",
+             n, h->T_host, h->T_cap);
+  const int d = h->d, pos0 = h->T_host;
+  DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)n * d * 4, hipMemcpyDeviceToDevice, st));
+  RC(prefill_layers(h, n, nullptr, 0, h->span_start, h->L, st, pos0));
+  k_prefill_rows<<<1, 256, 0, st>>>(h->row_index, 0, 0, n);          // row_index[0] = n - 1: the last new row
+  DD_CHECK_LAUNCH();
+  RC(prefill_head(h, h->row_index, 1, h->last_logits, st));
+  DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
+  RC(dd_argmax_rows(h->last_logits, 1, h->V, h->Vpad, h->argmax_base, st));
+  h->tok_host[0] = 0;
+  k_state_after_prefill<<<1, 64, 0, st>>>(h->state, pos0 + n, h->argmax_base, h->tokens, h->tok_host_dev);
+  DD_CHECK_LAUNCH();
+  h->T_host = pos0 + n, h->n_tok_host = 1, h->have_leak = false, h->last_K = 0, h->steps_since_prefill = 0;
   return DD_OK;
 }
 

@@ -165,7 +165,7 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st);
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, hipStream_t st);
+                     int span_len, int q0, hipStream_t st);   // q0 = position of query row 0 (chunked prefill)
 int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st);
 
 // ---- small glue -------------------------------------------------------------------------------

@@ -1361,18 +1361,23 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
                                                       const float* __restrict__ vc, int T, int T_cap, int n_heads,
                                                       uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
                                                       const uint8_t* __restrict__ drop_plane, int drop_bit,
-                                                      int span_start, int span_len) {
+                                                      int span_start, int span_len, int q0) {
+  // q0: position of query row 0 (chunked prefill: rows q0 .. q0 + T - 1 attend to keys 0 .. their own position; the keys
+  // before q0 are already in the cache).  T = number of query rows of this call.
   __shared__ __align__(16) float q_sh[4][PF_QR][HEAD_DIM];
   __shared__ __align__(16) float p_sh[4][ATT_SPLIT][PF_QR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int head = blockIdx.x, kvh = head / G;
-  const int t_first = (blockIdx.y * 4 + wave) * PF_QR;          // rows t_first .. t_first + 3
+  // groups of PF_QR rows are aligned to ABSOLUTE positions (a multiple of PF_QR), so a row is processed with the same
+  // three neighbours whether it arrives in a full prefill or in a later chunk: the two give bit-identical outputs
+  const int t_first = (blockIdx.y * 4 + wave) * PF_QR - (q0 & (PF_QR - 1));   // local rows t_first .. t_first + 3 (may start < 0)
   const int q_dim = n_heads * HEAD_DIM;
   if (t_first >= T) return;                                       // whole wave idle (no block-level barrier below)
   const int t_last = min(t_first + PF_QR - 1, T - 1);
+  const int p_last = q0 + t_last;                                 // last key position this wave needs
   for (int i = lane; i < PF_QR * HEAD_DIM; i += 64) {
     int r = i / HEAD_DIM, dd = i % HEAD_DIM;
-    q_sh[wave][r][dd] = qbuf[(size_t)min(t_first + r, T - 1) * q_dim + head * HEAD_DIM + dd];
+    q_sh[wave][r][dd] = qbuf[(size_t)max(0, min(t_first + r, T - 1)) * q_dim + head * HEAD_DIM + dd];
   }
   __builtin_amdgcn_wave_barrier();
   const float scaling = 0.08838834764831845f;
@@ -1385,9 +1390,9 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
     l_run[r] = 0.f;
     acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
-  for (int t0 = 0; t0 <= t_last; t0 += ATT_SPLIT) {
+  for (int t0 = 0; t0 <= p_last; t0 += ATT_SPLIT) {
     int kt = t0 + lane;
-    const float* kb = kc + ((size_t)kvh * 32 * T_cap + min(kt, t_last)) * 4;
+    const float* kb = kc + ((size_t)kvh * 32 * T_cap + min(kt, p_last)) * 4;
     // a zero column of the member's 2-D attention mask (first-token ensemble: llava.py:336-359 run on the prompt)
     bool key_dropped = false;
     if (drop_plane && kt >= span_start && kt < span_start + span_len)
@@ -1406,7 +1411,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < PF_QR; ++r) {
-      bool valid = kt <= min(t_first + r, T - 1) && !key_dropped;  // causal: row t attends keys 0..t
+      bool valid = kt <= q0 + max(0, min(t_first + r, T - 1)) && !key_dropped;  // causal: the row at position p attends keys 0..p
       float sv = valid ? s[r] * scaling : -INFINITY;
       float m_new = fmaxf(m_run[r], dd_wave_max(sv));
       float p = valid ? expf(sv - m_new) : 0.f;
@@ -1417,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
       p_sh[wave][lane][r] = p;
     }
     __builtin_amdgcn_wave_barrier();
-    int nkeys = min(ATT_SPLIT, t_last + 1 - t0);
+    int nkeys = min(ATT_SPLIT, p_last + 1 - t0);
     const float* vb = vc + ((size_t)kvh * T_cap + t0) * HEAD_DIM + dq * 4;
     for (int kp = 0; 2 * kp < nkeys; ++kp) {
       int key = 2 * kp + half;
@@ -1440,7 +1445,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
     a.z += __shfl_xor(a.z, 32);
     a.w += __shfl_xor(a.w, 32);
     const int t = t_first + r;
-    if (t < T && half == 0) {
+    if (t >= 0 && t < T && half == 0) {
       float inv = 1.0f / l_run[r];
       uint32_t hh[4], ll[4];
 #pragma unroll
@@ -1454,10 +1459,10 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, hipStream_t st) {
+                     int span_len, int q0, hipStream_t st) {
   int G = n_heads / n_kv;
-  dim3 grid(n_heads, (T + 4 * PF_QR - 1) / (4 * PF_QR));
-#define PF_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len
+  dim3 grid(n_heads, (T + (q0 & (PF_QR - 1)) + 4 * PF_QR - 1) / (4 * PF_QR));
+#define PF_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0
   if (G == 1) k_attn_prefill<1><<<grid, 256, 0, st>>>(PF_ARGS);
   else if (G == 2) k_attn_prefill<2><<<grid, 256, 0, st>>>(PF_ARGS);
   else if (G == 4) k_attn_prefill<4><<<grid, 256, 0, st>>>(PF_ARGS);

@@ -228,9 +228,13 @@ def write_pope_answers(path: str, rows: Sequence[Dict]) -> None:
 
 
 def answer_pope(model, processor, questions: Sequence[Dict], model_name: str, image_root: str, load_image: Callable,
-                number: Optional[int] = None, device="cuda") -> List[Dict]:
-    """pope_test.py:215-241: one generated token per question."""
+                number: Optional[int] = None, device="cuda", reuse_image_prefix: bool = False) -> List[Dict]:
+    """pope_test.py:215-241: one generated token per question.  reuse_image_prefix: POPE asks several questions per image
+    back to back; with it the image prefix (vision tower, its prefill, uncertainty) is computed once per image and only
+    the question text is prefilled for the others — same answers (settings['reuse_image_prefix'], LLaVA families)."""
     rows = []
+    if reuse_image_prefix:
+        settings["reuse_image_prefix"] = True
     for q in questions[:number] if number is not None else questions:
         image = load_image(os.path.join(image_root, q["image"]))
         inputs = processor(text=pope_prompt(model_name, q["text"]), images=image, return_tensors="pt")

@@ -33,6 +33,7 @@ class _Projector(torch.nn.Module):
 
 class CustomLlavaForConditionalGeneration(DropoutVLM):
     family = FAMILY_LLAVA
+    supports_prefix_reuse = True        # visual tokens depend on the image only
 
     def __init__(self, engine, embed_tokens, vision_tower, projector, image_token_index, vision_feature_layer=-2,
                  vision_feature_select_strategy="default", eos_token_id=None, config=None, native_vision: bool = True):

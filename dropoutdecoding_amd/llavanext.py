@@ -21,6 +21,7 @@ _config._module_imported(seed)
 
 class CustomLlavaNextForConditionalGeneration(DropoutVLM):
     family = FAMILY_NEXT
+    supports_prefix_reuse = True        # visual tokens depend on the image only
 
     def __init__(self, engine, embed_tokens, hf_vision, image_token_index, eos_token_id=None, config=None,
                  native_vision: bool = True):

@@ -214,6 +214,31 @@ class DropoutEngine:
         self._last_K = K
         self._n_enqueued = 1                       # the prefill's greedy token
 
+    def truncate(self, T_keep: int, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Cut the sequence back to its first T_keep positions (>= end of the visual span); see prefill_extend."""
+        pstream = stream if stream is not None else self.torch_stream
+        if stream is not None:
+            pstream.wait_stream(self.torch_stream)
+        _lib.check(self.lib.dd_lm_truncate(self._h, int(T_keep), pstream.cuda_stream), "dd_lm_truncate")
+        self.T0 = int(T_keep)
+        self._last_K = 0
+        self._n_enqueued = 0
+
+    def prefill_extend(self, embeds: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Append more PROMPT positions to a prefilled / truncated sequence (chunked prefill against the cache) and emit
+        the greedy first token, as a full prefill of the longer prompt would.  With truncate(): several questions about
+        one image (POPE asks 6) without re-running the visual positions."""
+        e = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
+        if not e.is_cuda or e.shape[1] != self.cfg.hidden_size:
+            raise ValueError("embeds must be [n, hidden] on the GPU")
+        pstream = stream if stream is not None else self.torch_stream
+        pstream.wait_stream(torch.cuda.current_stream(self.device))
+        e.record_stream(pstream)
+        _lib.check(self.lib.dd_lm_prefill_extend(self._h, e.data_ptr(), e.shape[0], pstream.cuda_stream), "dd_lm_prefill_extend")
+        self.T0 += e.shape[0]
+        self._last_K = 0
+        self._n_enqueued = 1
+
     def _probs(self, mprobs):
         probs = list(settings["voting_numbers"] if mprobs is None else mprobs)   # read at every step (llava.py:340)
         return probs, (C.c_double * max(len(probs), 1))(*[float(p) for p in probs])

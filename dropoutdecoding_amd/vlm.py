@@ -45,6 +45,7 @@ class DropoutVLM:
 
     family: str = ""
     original: bool = False              # True = stock greedy decode (`--original`), no ensemble
+    supports_prefix_reuse: bool = False  # visual tokens depend on the image only (LLaVA families; not InstructBLIP's Q-Former)
 
     def __init__(self, engine: DropoutEngine, embed_tokens: torch.Tensor, image_token_index: int,
                  eos_token_id=None, config=None):
@@ -116,6 +117,13 @@ class DropoutVLM:
         if max_new_tokens is None:
             max_new_tokens = 20 if max_length is None else max(1, max_length - input_ids.shape[1])
         input_ids = input_ids.to(self.device)
+        # the `# if True:` toggle of llava.py:336-337; never for the stock greedy (`--original`) path
+        first = bool(settings.get("first_step_ensemble", False)) and not self.original
+        if (self.supports_prefix_reuse and bool(settings.get("reuse_image_prefix", False)) and not first
+                and self._try_reuse_prefix(input_ids, inputs, stream)):
+            eos = self.eos_token_ids if eos_token_id is None else (
+                list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
+            return input_ids, max_new_tokens, eos
         visual = self._visual_embeds(**inputs)
         embeds, start = self._merge(input_ids, visual)
         L = visual.shape[0]
@@ -125,12 +133,46 @@ class DropoutVLM:
         self.start_image_pos, self.end_image_pos = [start], [start + L - 1]
         self.start_generation_pos = embeds.shape[0]
         self.masked_numbers = []
-        # the `# if True:` toggle of llava.py:336-337; never for the stock greedy (`--original`) path
-        first = bool(settings.get("first_step_ensemble", False)) and not self.original
         self.engine.prefill(embeds, start, L, first_step_ensemble=first, stream=stream)
+        self._prefix = None
+        if self.supports_prefix_reuse and not first:
+            ids = input_ids[0]
+            n_ph = int((ids == self.image_token_index).sum())
+            self._prefix = {"ids": ids[:start + n_ph].clone(), "n_ph": n_ph, "start": start, "L": L,
+                            "inputs": {k: v.detach().clone() for k, v in inputs.items() if torch.is_tensor(v)}}
         eos = self.eos_token_ids if eos_token_id is None else (
             list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
         return input_ids, max_new_tokens, eos
+
+    def _try_reuse_prefix(self, input_ids: torch.Tensor, inputs: dict, stream) -> bool:
+        """settings['reuse_image_prefix']: the previous prompt on this object had the same image and the same ids up to
+        the image — keep its first start+L positions (K/V, uncertainty, top-k ids) and prefill only the new tail.  What
+        the reference recomputes for the shared prefix (pope_test.py:228-232 re-runs the whole prompt for each of the 6
+        questions about an image) is identical to what is kept."""
+        p = getattr(self, "_prefix", None)
+        if p is None:
+            return False
+        ids = input_ids[0]
+        k = p["ids"].numel()
+        if ids.numel() <= k or not torch.equal(ids[:k], p["ids"].to(ids.device)):
+            return False
+        for name, v in p["inputs"].items():
+            w = inputs.get(name)
+            if not torch.is_tensor(w) or w.shape != v.shape or not torch.equal(w.to(v.device), v):
+                return False
+        tail = ids[k:]
+        if (tail == self.image_token_index).any():
+            return False
+        emb = torch.nn.functional.embedding(tail, self.embed_tokens).float()
+        P = p["start"] + p["L"]
+        self.engine.truncate(P, stream=stream)
+        self.engine.prefill_extend(emb, stream=stream)
+        self.is_first_generation = True
+        self.logits_mask_prob = []
+        self.start_image_pos, self.end_image_pos = [p["start"]], [P - 1]
+        self.start_generation_pos = P + tail.numel()
+        self.masked_numbers = []
+        return True
 
     def _finalize(self, input_ids: torch.Tensor, toks: List[int]) -> torch.LongTensor:
         self.is_first_generation = False
@@ -159,6 +201,7 @@ class DropoutVLM:
                                     weight_format=eng.weight_format, mask_method=eng.mask_method, use_avg=eng.use_avg,
                                     share_weights_with=eng)
         lane.start_image_pos, lane.end_image_pos, lane.masked_numbers, lane.logits_mask_prob = [], [], [], []
+        lane._prefix = None
         return lane
 
 

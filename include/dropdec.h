@@ -198,6 +198,14 @@ int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std);
  * Replaces the prefill branch of forward() (models/llava.py:285-314).  Resets the sequence. */
 int dd_lm_prefill(dd_lm* h, const float* embeds_dev, int T0, int span_start, int span_len, void* stream);
 
+/* Prefix reuse (several prompts over one image, e.g. the 6 POPE questions per image, pope_test/pope_test.py:215-241).
+ * dd_lm_truncate cuts the sequence back to its first T_keep positions (>= end of the visual span; the image-derived
+ * uncertainty / top-k stay valid: attention is causal); dd_lm_prefill_extend appends n more prompt positions (fp32
+ * embeddings [n][d], device) with a chunked prefill against the cache and emits the greedy first token like
+ * dd_lm_prefill.  prefill(P) + extend(tail) == prefill(P ‖ tail) row for row. */
+int dd_lm_truncate(dd_lm* h, int T_keep, void* stream);
+int dd_lm_prefill_extend(dd_lm* h, const float* embeds_dev, int n, void* stream);
+
 /* Prefill with the ensemble ALSO applied to the first generated token: the reference's `# if True:` toggle at
  * models/llava.py:336-337 (with it, the first forward runs llava.py:342-359 on the whole prompt: every member starts
  * from the empty cache and masks its columns for all query rows).  Same arguments as dd_lm_prefill plus the step's

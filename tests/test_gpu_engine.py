@@ -754,3 +754,50 @@ def test_long_generation_across_attention_launch_buckets(E):
         np.testing.assert_array_equal(e.kv_sums(), sums[i])
     for e in reversed(engines):
         e.close()
+
+
+@pytest.mark.parametrize("family,s0", [(FAMILY_LLAVA, 4), (FAMILY_NEXT, 2)])
+def test_truncate_and_extend_equal_a_full_prefill(E, family, s0):
+    """dd_lm_truncate + dd_lm_prefill_extend (several questions about one image): prefill(prefix) then extend(tail) gives
+    bit for bit the logits, first token, KV cache and following ensemble steps of prefill(prefix ‖ tail); a second tail
+    after truncating back reuses the same prefix; the oracle decodes the full prompts."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    w = random_weights(rc, 41, 0.05)
+    cfg = E.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    probs = [0.3, 0.5, 0.7]
+    L, P = 70, s0 + 70                                       # the prefix ends with the visual span (crosses a 64-key tile)
+    g = torch.Generator().manual_seed(12)
+    prefix = torch.randn(P, 256, generator=g) * 0.8
+    tails = [torch.randn(n, 256, generator=g) * 0.8 for n in (9, 1, 23)]
+    full = E.DropoutEngine(cfg, family=family, max_seq=192, max_visual=L, seed=3)
+    part = E.DropoutEngine(cfg, family=family, max_seq=192, max_visual=L, seed=3)
+    full.load_state_dict(w)
+    part.load_state_dict(w)
+    part.prefill(prefix.cuda(), s0, L)
+    epi0 = part.vision_uncert_dict()["epis_uncert_per_token"].copy()
+    ref_rng = None
+    for ti, tail in enumerate(tails):
+        prompt = torch.cat([prefix, tail], 0)
+        full.prefill(prompt.cuda(), s0, L)
+        part.truncate(P)
+        part.prefill_extend(tail.cuda())
+        np.testing.assert_array_equal(part.logits(), full.logits(), err_msg=f"tail {ti}")
+        np.testing.assert_array_equal(part.vision_uncert_dict()["epis_uncert_per_token"], epi0)
+        ref = RefDecoder(family, rc, w, probs, seed=3)
+        if ref_rng is not None:
+            ref.rng = ref_rng                                 # the stream continues across prompts, as on the engines
+        want = ref.generate(prompt, s0, L, 5)
+        ref_rng = ref.rng
+        for s in range(4):
+            full.decode_step(probs)
+            part.decode_step(probs)
+            np.testing.assert_array_equal(part.last_step()["drop"], full.last_step()["drop"])
+            np.testing.assert_array_equal(part.logits(), full.logits(), err_msg=f"tail {ti} step {s}")
+        assert part.tokens() == full.tokens() == want
+        np.testing.assert_array_equal(part.kv_sums(), full.kv_sums())
+    with pytest.raises(ValueError):
+        part.truncate(P - 1)                                  # would cut into the visual span
+    with pytest.raises(ValueError):
+        part.prefill_extend(tails[0].cuda())                  # tokens already generated: truncate first
+    full.close()
+    part.close()

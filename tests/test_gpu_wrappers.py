@@ -88,6 +88,26 @@ def test_llava_wrapper_generate_matches_oracle(built):
     m.engine.rng.manual_seed(5)
     o3 = m.generate(input_ids=ids1, pixel_values=pv, max_new_tokens=8, eos_token_id=eos)
     assert o3[0, 7:].tolist() == w3 and w3[-1] == eos and len(w3) <= 5
+    # several questions about one image (POPE): with settings['reuse_image_prefix'] the second prompt keeps the image
+    # prefix of the first and prefills only its own text — same ids out as without it
+    qs = [torch.tensor([[1, 17, 511, 45, 6, 7, 99]]), torch.tensor([[1, 17, 511, 88, 3]]), torch.tensor([[1, 17, 511, 9, 9, 9, 12, 40]])]
+    m.engine.rng.manual_seed(11)
+    plain = [m.generate(input_ids=q, pixel_values=pv, max_new_tokens=4, eos_token_id=[]) for q in qs]
+    ddc.settings["reuse_image_prefix"] = True
+    try:
+        m.engine.rng.manual_seed(11)
+        calls = {"n": 0}
+        orig_vis = m._visual_embeds
+        m._visual_embeds = lambda **kw: (calls.__setitem__("n", calls["n"] + 1), orig_vis(**kw))[1]
+        reused = [m.generate(input_ids=q, pixel_values=pv, max_new_tokens=4, eos_token_id=[]) for q in qs]
+        other = m.generate(input_ids=qs[1], pixel_values=pv + 0.5, max_new_tokens=4, eos_token_id=[])     # another image
+        m._visual_embeds = orig_vis
+    finally:
+        ddc.settings.pop("reuse_image_prefix")
+    assert [r.tolist() for r in reused] == [p_.tolist() for p_ in plain]
+    assert calls["n"] == 1       # vision tower: never for the three questions (the prefix of the last plain call is still
+                                 # cached: same image), once for the new image
+    assert other.shape == (1, 5 + 4) and m.start_generation_pos == 2 + 16 + 2
     # POPE-style one-token answer with the ensemble on the first token (the `# if True:` toggle, llava.py:336-337)
     ddc.settings["first_step_ensemble"] = True
     try:
