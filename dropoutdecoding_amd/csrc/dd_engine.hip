@@ -50,6 +50,8 @@ struct dd_lm {
   dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
   float* grp_logits = nullptr; // [16][Vpad] base-pass logits of a group step (this handle is the group's first lane)
   int32_t* grp_argmax = nullptr;
+  DDState* chunk_states = nullptr;   // [32] positions of the rows of a short prompt chunk (dd_lm_prefill_extend)
+  float *chunk_k = nullptr, *chunk_v = nullptr;   // [32][kv_dim] roped K / V rows of the chunk, one layer at a time
   const float *commit_k = nullptr, *commit_v = nullptr;   // K == 0 group step: this lane's base row in the leader's scratch
   // weights
   std::vector<LayerW> lw;
@@ -233,6 +235,9 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->base_logits, h->Vpad);
   DA(h->grp_logits, (size_t)16 * h->Vpad);
   DA(h->grp_argmax, 16);
+  DA(h->chunk_states, 32);
+  DA(h->chunk_k, (size_t)32 * h->kv_dim);
+  DA(h->chunk_v, (size_t)32 * h->kv_dim);
   DA(h->member_logits, (size_t)MAX_MEMBERS * h->Vpad);
   DA(h->last_logits, h->Vpad);
   DA(h->last_hidden, d);
@@ -661,9 +666,10 @@ static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_
 
 // final norm + lm_head over `n_rows` rows of h->px selected by row_index (device) -> logits [n_rows][Vpad];
 // the normed rows stay in h->pq
-static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* logits, hipStream_t st) {
+static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* logits, hipStream_t st,
+                        const float* src = nullptr) {
   const int d = h->d;
-  RC(ddk_rmsnorm_split(h->px, n_rows, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, row_index, h->pq, st));
+  RC(ddk_rmsnorm_split(src ? src : h->px, n_rows, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, row_index, h->pq, st));
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = n_rows, g.S = h->S_d, g.n_tiles = h->Vpad / 16;
@@ -728,6 +734,79 @@ extern "C" int dd_lm_truncate(dd_lm* h, int T_keep, void* stream_) {
   return DD_OK;
 }
 
+// Short chunks (n <= 32 rows: a question's text after a cached image prefix) go through the DECODE kernels: the prefill
+// GEMM is built for hundreds of rows and streams the weights at under 1 TB/s when it has a dozen, the 8 / 16 / 32-row
+// GEMVs stream them at 4-5 TB/s.  Rows carry their own positions (RoPE in the QKV epilogue), the chunk's K/V rows are
+// scattered into the cache before the causal chunk attention (k_attn_prefill with q0), which hands its rows to o_proj
+// as packed operand planes.  Same arithmetic as the decode path, i.e. within fp32 rounding of the GEMM path, not
+// bit-identical to it.
+static int g_extend_rows = 1;   // dd_set_tuning key 11: chunks of <= 32 rows through the decode GEMVs (0: always the GEMM path)
+void dd_engine_set_extend_rows(int on) { g_extend_rows = on; }
+
+static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t st) {
+  const int d = h->d, dff = h->dff, pos0 = h->T_host;
+  const int cap = n <= 8 ? 8 : (n <= 16 ? 16 : 32), ng = cap / 8;
+  auto gemv = [&](int epi, GemvArgs& a) -> int {
+    a.nb = cap == 8 ? n : 8;
+    if (cap == 8) return ddk_gemv(epi, a, st);
+    a.n_groups = ng;
+    return ddk_gemv_groups(epi, a, st);
+  };
+  RC(ddk_chunk_positions(h->chunk_states, h->state, n, st));
+  RC(ddk_pack_embed_rows(embeds, n, cap, d, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  int ssq_n = 1;
+  for (int l = 0; l < h->Lyr; ++l) {
+    LayerW& w = h->lw[l];
+    float* kc = h->kc + (size_t)l * h->lsk;
+    float* vc = h->vc + (size_t)l * h->lsv;
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.fp8 = h->fp8, a.wscale = w.s_qkv;
+    a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.qbuf = h->qbuf, a.knew = h->chunk_k, a.vnew = h->chunk_v, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
+    a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = h->chunk_states;
+    for (int m = 0; m < cap; ++m) a.state_rows[m] = h->chunk_states + (m < n ? m : 0);
+    RC(gemv(EPI_QKV, a));
+    RC(ddk_scatter_kv_rows(h->chunk_k, h->chunk_v, n, h->kv_dim, kc, vc, h->T_cap, h->state, st));
+    // causal attention of the chunk rows: row i = a single-query decode attention over the cache up to position
+    // pos0 + i - 1 (prefix + the chunk rows ahead of it, just scattered) plus its own new key — the fused-base-pass
+    // kernel with every "lane" pointing at this one cache; 16 rows per launch
+    for (int r0 = 0; r0 < n; r0 += 16) {
+      const int nr = n - r0 < 16 ? n - r0 : 16;
+      AttnDecodeArgs t;
+      memset(&t, 0, sizeof(t));
+      t.qbuf = h->qbuf + (size_t)r0 * h->q_dim, t.T_cap = h->T_cap, t.nb = nr, t.n_heads = h->H, t.n_kv = h->Hkv;
+      t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q + (size_t)(r0 / 8) * h->S_q * 64;
+      t.knew = h->chunk_k + (size_t)r0 * h->kv_dim, t.vnew = h->chunk_v + (size_t)r0 * h->kv_dim;
+      t.n_lanes = nr, t.max_T = pos0 + n;
+      for (int m = 0; m < nr; ++m) {
+        t.lane_kc[m] = kc, t.lane_vc[m] = vc, t.lane_state[m] = h->chunk_states + r0 + m;
+        t.lane_span_start[m] = h->span_start, t.lane_span_len[m] = h->L;
+      }
+      RC(ddk_attn_decode(t, st));
+    }
+    memset(&a, 0, sizeof(a));
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.fp8 = h->fp8, a.wscale = w.s_o;
+    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
+    RC(gemv(EPI_RESID, a));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.fp8 = h->fp8, a.wscale = w.s_gu;
+    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.xop_next = h->xop_ff, a.S_next = h->S_ff;
+    RC(gemv(EPI_SILU, a));
+    memset(&a, 0, sizeof(a));
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.fp8 = h->fp8, a.wscale = w.s_down;
+    a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
+    a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
+    RC(gemv(EPI_RESID, a));
+    ssq_n = d / 16;
+  }
+  // last row -> final norm -> lm_head (one row through the prefill head: its hidden state stays in h->pq)
+  k_prefill_rows<<<1, 256, 0, st>>>(h->row_index, 0, 0, n);
+  DD_CHECK_LAUNCH();
+  return prefill_head(h, h->row_index, 1, h->last_logits, st, h->xa);
+}
+
 // Append n more PROMPT positions (fp32 embeddings [n][d]) to a prefilled (or truncated) sequence: a chunked prefill over
 // the rows at positions T .. T+n-1 against the cache, then the greedy first token from the last row exactly as
 // dd_lm_prefill emits it.  Row for row the arithmetic is that of a full prefill of the longer prompt.
@@ -738,11 +817,15 @@ extern "C" int dd_lm_prefill_extend(dd_lm* h, const float* embeds, int n, void* 
   DD_REQUIRE(n >= 1 && h->T_host + n < h->T_cap, "dd_lm_prefill_extend: %d more positions do not fit (length %d, capacity %d)",
              n, h->T_host, h->T_cap);
   const int d = h->d, pos0 = h->T_host;
-  DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)n * d * 4, hipMemcpyDeviceToDevice, st));
-  RC(prefill_layers(h, n, nullptr, 0, h->span_start, h->L, st, pos0));
-  k_prefill_rows<<<1, 256, 0, st>>>(h->row_index, 0, 0, n);          // row_index[0] = n - 1: the last new row
-  DD_CHECK_LAUNCH();
-  RC(prefill_head(h, h->row_index, 1, h->last_logits, st));
+  if (n <= 32 && g_extend_rows) {
+    RC(prefill_extend_rows(h, embeds, n, st));
+  } else {
+    DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)n * d * 4, hipMemcpyDeviceToDevice, st));
+    RC(prefill_layers(h, n, nullptr, 0, h->span_start, h->L, st, pos0));
+    k_prefill_rows<<<1, 256, 0, st>>>(h->row_index, 0, 0, n);          // row_index[0] = n - 1: the last new row
+    DD_CHECK_LAUNCH();
+    RC(prefill_head(h, h->row_index, 1, h->last_logits, st));
+  }
   DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
   RC(dd_argmax_rows(h->last_logits, 1, h->V, h->Vpad, h->argmax_base, st));
   h->tok_host[0] = 0;
@@ -1582,9 +1665,10 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 4) || (key >= 8 && key <= 10), "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4) || (key >= 8 && key <= 11), "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 10) ddk_set_attn_split(value);
+  else if (key == 11) dd_engine_set_extend_rows(value);
   else if (key == 9) dd_engine_set_pairs(value);
   else ddk_set_tuning(key, value);
   return DD_OK;

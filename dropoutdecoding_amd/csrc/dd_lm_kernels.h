@@ -165,7 +165,13 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st);
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, int q0, hipStream_t st);   // q0 = position of query row 0 (chunked prefill)
+                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out = nullptr);   // q0 = position of query row 0
+// xop_out: write the rows as packed decode-GEMV operand planes (row-major [32 rows]) instead of the GEMM's A planes
+int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x, const float* normw, u32x4_t* xop, float* ssq,
+                        int ssq_ld, hipStream_t st);
+int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t st);
+int ddk_scatter_kv_rows(const float* kr, const float* vr, int n, int kv_dim, float* kc, float* vc, int T_cap, const DDState* base,
+                        hipStream_t st);
 int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st);
 
 // ---- small glue -------------------------------------------------------------------------------

@@ -1356,12 +1356,12 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
 // Each wave owns QR = 4 consecutive query rows, so every K / V tile it loads (L2-resident) is reused 4 times:
 // the one-row-per-wave version was bound by L2 bandwidth (5.9 GB of tile re-reads per layer at T = 608).
 #define PF_QR 4
-template <int G>
+template <int G, int XOP = 0>
 __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ qbuf, const float* __restrict__ kc,
                                                       const float* __restrict__ vc, int T, int T_cap, int n_heads,
                                                       uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
                                                       const uint8_t* __restrict__ drop_plane, int drop_bit,
-                                                      int span_start, int span_len, int q0) {
+                                                      int span_start, int span_len, int q0, u32x4_t* __restrict__ xop_out) {
   // q0: position of query row 0 (chunked prefill: rows q0 .. q0 + T - 1 attend to keys 0 .. their own position; the keys
   // before q0 are already in the cache).  T = number of query rows of this call.
   __shared__ __align__(16) float q_sh[4][PF_QR][HEAD_DIM];
@@ -1448,6 +1448,11 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
     if (t >= 0 && t < T && half == 0) {
       float inv = 1.0f / l_run[r];
       uint32_t hh[4], ll[4];
+      if (XOP) {                  // rows feed the decode GEMV next (short chunks): its packed operand planes instead
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xop_store16(xop_out, head * HEAD_DIM + dq * 4 + j, t, a[j] * inv, q_dim >> 5);
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) dd_split_hl(a[j] * inv, hh[j], ll[j]);
       size_t o = apack_off(t, head * HEAD_DIM + dq * 4, q_dim >> 5);      // 4 consecutive k: one 8-byte packed store
@@ -1459,10 +1464,18 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, int q0, hipStream_t st) {
+                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out) {
   int G = n_heads / n_kv;
   dim3 grid(n_heads, (T + (q0 & (PF_QR - 1)) + 4 * PF_QR - 1) / (4 * PF_QR));
-#define PF_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0
+#define PF_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, xop_out
+  if (xop_out) {
+    if (G == 1) k_attn_prefill<1, 1><<<grid, 256, 0, st>>>(PF_ARGS);
+    else if (G == 2) k_attn_prefill<2, 1><<<grid, 256, 0, st>>>(PF_ARGS);
+    else if (G == 4) k_attn_prefill<4, 1><<<grid, 256, 0, st>>>(PF_ARGS);
+    else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   if (G == 1) k_attn_prefill<1><<<grid, 256, 0, st>>>(PF_ARGS);
   else if (G == 2) k_attn_prefill<2><<<grid, 256, 0, st>>>(PF_ARGS);
   else if (G == 4) k_attn_prefill<4><<<grid, 256, 0, st>>>(PF_ARGS);
@@ -1546,6 +1559,78 @@ int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, 
   if (rows == 32) k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
   else if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
   else k_embed_rows_lanes<8><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+// short prompt chunks through the decode GEMVs: n (<= ROWS) rows of fp32 embeddings become the residual rows x[ROWS][d]
+// (rows >= n zero), the packed operand planes of the first GEMV (w_norm * x) and the per-row sums of squares
+template <int ROWS>
+__global__ __launch_bounds__(1024) void k_pack_embed_rows(const float* __restrict__ rows, int n, int d, float* __restrict__ x,
+                                                          const float* __restrict__ normw, u32x4_t* __restrict__ xop,
+                                                          float* __restrict__ ssq, int ssq_ld) {
+  __shared__ float sh[ROWS][16];
+  float ss[ROWS];
+#pragma unroll
+  for (int m = 0; m < ROWS; ++m) ss[m] = 0.f;
+  for (int i = threadIdx.x; i < d; i += 1024) {
+    float w = normw[i];
+#pragma unroll
+    for (int m = 0; m < ROWS; ++m) {
+      float e = m < n ? rows[(size_t)m * d + i] : 0.f;
+      ss[m] += e * e;
+      x[(size_t)m * d + i] = e;
+      if (ROWS > 8) xop_store16(xop, i, m, w * e, d >> 5);
+      else xop_store(xop, i, m, w * e);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < ROWS; ++m) {
+    float v = dd_wave_sum(ss[m]);
+    if ((threadIdx.x & 63) == 0) sh[m][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < ROWS) {
+    float v = 0.f;
+    for (int i = 0; i < 16; ++i) v += sh[threadIdx.x][i];
+    ssq[(size_t)threadIdx.x * ssq_ld] = v;
+  }
+}
+int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x, const float* normw, u32x4_t* xop, float* ssq,
+                        int ssq_ld, hipStream_t st) {
+  if (rows_cap == 32) k_pack_embed_rows<32><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld);
+  else if (rows_cap == 16) k_pack_embed_rows<16><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld);
+  else k_pack_embed_rows<8><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+// position of chunk row i = base->T + i (device-side, like every other length on the decode path)
+__global__ void k_chunk_positions(DDState* rows, const DDState* base, int n) {
+  int i = threadIdx.x;
+  if (i < n) {
+    rows[i] = *base;
+    rows[i].pos = base->T + i;
+    rows[i].T = base->T + i;      // keys before row i: the prefix and the chunk rows ahead of it (its own key comes as a new row)
+  }
+}
+// the chunk's roped K rows / V rows [n][kv_dim] into the cache at positions base->T + i
+__global__ __launch_bounds__(256) void k_scatter_kv_rows(const float* __restrict__ kr, const float* __restrict__ vr, int kv_dim,
+                                                         float* __restrict__ kc, float* __restrict__ vc, int T_cap,
+                                                         const DDState* base) {
+  const int row = blockIdx.x, T = base->T + row;
+  for (int i = threadIdx.x; i < kv_dim; i += 256) {
+    int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
+    kc[(((size_t)kvh * 32 + (idx >> 2)) * T_cap + T) * 4 + (idx & 3)] = kr[(size_t)row * kv_dim + i];
+    vc[((size_t)kvh * T_cap + T) * HEAD_DIM + idx] = vr[(size_t)row * kv_dim + i];
+  }
+}
+int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t st) {
+  k_chunk_positions<<<1, 64, 0, st>>>(rows, base, n);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int ddk_scatter_kv_rows(const float* kr, const float* vr, int n, int kv_dim, float* kc, float* vc, int T_cap, const DDState* base,
+                        hipStream_t st) {
+  k_scatter_kv_rows<<<n, 256, 0, st>>>(kr, vr, kv_dim, kc, vc, T_cap, base);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -26,3 +26,17 @@ for reuse in (False, True, False, True):
             outs.append(int(model.generate(input_ids=q, pixel_values=imgs[i], max_new_tokens=1, eos_token_id=[])[0, -1]))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"reuse_image_prefix={reuse}: {n_img * per / dt:.1f} questions/s ({dt / (n_img * per) * 1e3:.1f} ms per question), answers {outs[:8]}")
+
+# where a reused question's time goes
+eng = model.engine
+ddcfg.settings["reuse_image_prefix"] = True
+model.generate(input_ids=qs[0][0], pixel_values=imgs[0], max_new_tokens=1, eos_token_id=[])
+tail = torch.randn(12, 4096, device="cuda")
+for name, fn in (("truncate+extend (12 rows)", lambda: (eng.truncate(581), eng.prefill_extend(tail))),
+                 ("whole generate() of a reused question", lambda: model.generate(input_ids=qs[0][1], pixel_values=imgs[0], max_new_tokens=1, eos_token_id=[]))):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
