@@ -807,3 +807,27 @@ def test_truncate_and_extend_equal_a_full_prefill(E, family, s0, rows_path):
     _lib.load().dd_set_tuning(11, 1)
     full.close()
     part.close()
+
+
+@pytest.mark.parametrize("kw,K", [(dict(), 12), (dict(use_avg=True), 4), (dict(mask_method="epis_no_overlap"), 3)])
+def test_group_step_side_paths(E, kw, K):
+    """Group steps off the main road: K > 8 (members fall back to per-sequence packed sweeps), select_by_average (commit per
+    sequence), the no-overlap mask rule in the batched mask kernel — each lane against the oracle and a solo run."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    probs = [0.1 + 0.06 * i for i in range(K)]
+    shapes = [(40, 3, 30), (52, 5, 40), (47, 2, 40)]
+    w, engines, embs = _lane_setup(E, FAMILY_LLAVA, rc, shapes, **kw)
+    for e, emb, (T0, s0, L) in zip(engines, embs, shapes):
+        e.prefill(emb.cuda(), s0, L)
+    toks = E.EngineGroup(engines).generate(5, mprobs=probs)
+    finals = [e.logits().copy() for e in engines]
+    for i, (e, emb, (T0, s0, L)) in enumerate(zip(engines, embs, shapes)):
+        ref = RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=7, **kw)
+        assert toks[i] == ref.generate(emb, s0, L, 5), f"lane {i}"
+        assert close(finals[i], ref.records[-1].logits)
+        e.rng.manual_seed(7)
+        e.prefill(emb.cuda(), s0, L)
+        assert e.generate(5, mprobs=probs) == toks[i]
+        np.testing.assert_array_equal(e.logits(), finals[i])
+    for e in reversed(engines):
+        e.close()
