@@ -1462,6 +1462,167 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
   }
 }
 
+
+// -----------------------------------------------------------------------------------------------
+// prefill attention on the matrix cores.  fp32-grade through bf16 MFMA: every operand is split x = hi + lo (bf16 each) and
+// a product a.b is taken as a_hi.b_hi + a_lo.b_hi + a_hi.b_lo (the lo.lo term is below fp32 rounding).
+//   S^T = K . Q^T   (A = K tile [16 keys x 32 d], B = Q^T [32 d x 16 queries]):  D lane l = query l & 15, keys 4 (l >> 4) + r
+//   O^T = V^T . P^T (A = V^T [16 d x 32 key slots], B = P^T [32 key slots x 16 queries])
+// A wave owns 16 queries (columns of every D), so the online-softmax statistics and the rescale of O^T are per LANE; the
+// 32 key slots of a PV step are ordered so that the 8 probabilities a lane group already holds (4 keys of each of the two
+// S^T tiles) ARE its B operand — no transpose.  K and V tiles of 32 keys are staged in LDS once per workgroup (4 waves =
+// 64 queries).  Query groups are aligned to absolute positions, extra (masked) key steps add exact zeros, so a row's
+// output does not depend on the call it arrives in (chunked prefill).
+// -----------------------------------------------------------------------------------------------
+#define FA_KEYS 32
+#define FA_LD 132            // padded row pitch (floats) of the staged K / V tiles: keeps the V^T reads conflict-free
+__device__ __forceinline__ void fa_split8(const float* v, u32x4_t& hi, u32x4_t& lo) {
+  uint32_t h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dd_split_hl(v[j], h[j], l[j]);
+  hi = (u32x4_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+  lo = (u32x4_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+}
+#define FA_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), C, 0, 0, 0)
+
+template <int G>
+__global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restrict__ qbuf, const float* __restrict__ kc,
+                                                           const float* __restrict__ vc, int T, int T_cap, int n_heads,
+                                                           uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
+                                                           const uint8_t* __restrict__ drop_plane, int drop_bit,
+                                                           int span_start, int span_len, int q0) {
+  __shared__ __align__(16) float Ksh[FA_KEYS * FA_LD];
+  __shared__ __align__(16) float Vsh[FA_KEYS * FA_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x, kvh = head / G;
+  const int q_dim = n_heads * HEAD_DIM;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int shift = q0 & 15;
+  const int blk_first = blockIdx.y * 64 - shift;             // local row of the workgroup's first query (may be < 0)
+  const int t_q = blk_first + wave * 16 + c16;                // this lane's query (local row), same for its 4 lane groups
+  const bool q_live = t_q >= 0 && t_q < T;
+  const int pos_q = q0 + max(0, min(t_q, T - 1));             // its absolute position
+  const int blk_last = min(blk_first + 63, T - 1);
+  if (blk_last < 0) return;
+  const int p_max = q0 + blk_last;                            // last key any query of the workgroup attends to
+  const int wave_pmax = q0 + min(blk_first + wave * 16 + 15, T - 1);   // ... of this wave
+  const bool wave_live = blk_first + wave * 16 < T && blk_first + wave * 16 + 15 >= 0;
+
+  // Q^T operands of the lane: B[k = d 8 g4 .. +8][j = query c16], four 32-d steps, hi and lo
+  u32x4_t qh[4], ql[4];
+  {
+    const float* qr = qbuf + (size_t)max(0, min(t_q, T - 1)) * q_dim + head * HEAD_DIM;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
+      *(f32x4_t*)&v[0] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8);
+      *(f32x4_t*)&v[4] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8 + 4);
+      fa_split8(v, qh[ks], ql[ks]);
+    }
+  }
+  f32x4_t acc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float scaling = 0.08838834764831845f;
+
+  for (int t0 = 0; t0 <= p_max; t0 += FA_KEYS) {
+    __syncthreads();                                          // the previous tiles are no longer being read
+    // stage K (from the transposed cache [d/4][T_cap][4]) and V ([T_cap][128]) of keys t0 .. t0+31, clamped to p_max
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int k = tid & 31, c = (tid >> 5) + 8 * j;               // 32 keys x 32 d-chunks of 4
+      int key = min(t0 + k, p_max);
+      f32x4_t v = *(const f32x4_t*)(kc + (((size_t)kvh * 32 + c) * T_cap + key) * 4);
+      *(f32x4_t*)&Ksh[k * FA_LD + c * 4] = v;
+      int d4 = tid & 31, kk = (tid >> 5) + 8 * j;             // 32 keys x 32 float4 of a V row
+      int key2 = min(t0 + kk, p_max);
+      f32x4_t w = *(const f32x4_t*)(vc + ((size_t)kvh * T_cap + key2) * HEAD_DIM + d4 * 4);
+      *(f32x4_t*)&Vsh[kk * FA_LD + d4 * 4] = w;
+    }
+    __syncthreads();
+    if (!wave_live || t0 > wave_pmax) continue;               // nothing for this wave in these keys (barriers above stay matched)
+
+    // S^T for the two 16-key tiles
+    float sv[8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+      const float* kr = &Ksh[(kt * 16 + c16) * FA_LD + g4 * 8];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float v[8];
+        *(f32x4_t*)&v[0] = *(const f32x4_t*)(kr + ks * 32);
+        *(f32x4_t*)&v[4] = *(const f32x4_t*)(kr + ks * 32 + 4);
+        u32x4_t kh, kl;
+        fa_split8(v, kh, kl);
+        sacc = FA_MFMA(kh, qh[ks], sacc);
+        sacc = FA_MFMA(kl, qh[ks], sacc);
+        sacc = FA_MFMA(kh, ql[ks], sacc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = t0 + kt * 16 + g4 * 4 + r;
+        bool ok = key <= pos_q;
+        if (ok && drop_plane && key >= span_start && key < span_start + span_len) ok = !((drop_plane[key - span_start] >> drop_bit) & 1);
+        sv[kt * 4 + r] = ok ? sacc[r] * scaling : -INFINITY;
+      }
+    }
+    // online softmax of this lane's query over the 32 keys (8 in this lane, the rest in lanes ^16, ^32)
+    float mx = sv[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sv[j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    float p[8], ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      p[j] = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - m_new);
+      ps += p[j];
+    }
+    ps += __shfl_xor(ps, 16);
+    ps += __shfl_xor(ps, 32);
+    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    l_run = l_run * corr + ps;
+    m_run = m_new;
+    u32x4_t ph, pl;
+    fa_split8(p, ph, pl);
+    // O^T += V^T . P^T: lane group g4 holds key slots {4 g4 + j, 16 + 4 g4 + j}, j < 4, of this step
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      float v[8];
+      const float* vr = &Vsh[dt * 16 + c16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = vr[(4 * g4 + j) * FA_LD];
+        v[4 + j] = vr[(16 + 4 * g4 + j) * FA_LD];
+      }
+      u32x4_t vh, vl;
+      fa_split8(v, vh, vl);
+      f32x4_t a = acc[dt] * corr;
+      a = FA_MFMA(vh, ph, a);
+      a = FA_MFMA(vl, ph, a);
+      a = FA_MFMA(vh, pl, a);
+      acc[dt] = a;
+    }
+  }
+  if (!q_live) return;
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) {
+    uint32_t hh[4], ll[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dd_split_hl(acc[dt][r] * inv, hh[r], ll[r]);
+    size_t o = apack_off(t_q, head * HEAD_DIM + dt * 16 + g4 * 4, q_dim >> 5);   // 4 consecutive k: one 8-byte packed store
+    *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
+    *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
+  }
+}
+
+static int g_prefill_mfma = 1;   // dd_set_tuning key 12: prefill attention on the matrix cores (0: the VALU kernel)
+void ddk_set_prefill_mfma(int on) { g_prefill_mfma = on; }
+
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
                      int span_len, int q0, hipStream_t st, u32x4_t* xop_out) {
@@ -1473,6 +1634,17 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
     else if (G == 2) k_attn_prefill<2, 1><<<grid, 256, 0, st>>>(PF_ARGS);
     else if (G == 4) k_attn_prefill<4, 1><<<grid, 256, 0, st>>>(PF_ARGS);
     else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
+  if (g_prefill_mfma) {
+    dim3 g2(n_heads, (T + (q0 & 15) + 63) / 64);
+#define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0
+    if (G == 1) k_attn_prefill_mfma<1><<<g2, 256, 0, st>>>(FA_ARGS);
+    else if (G == 2) k_attn_prefill_mfma<2><<<g2, 256, 0, st>>>(FA_ARGS);
+    else if (G == 4) k_attn_prefill_mfma<4><<<g2, 256, 0, st>>>(FA_ARGS);
+    else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
+#undef FA_ARGS
     DD_CHECK_LAUNCH();
     return DD_OK;
   }
