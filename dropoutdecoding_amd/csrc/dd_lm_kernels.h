@@ -99,6 +99,9 @@ int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same f
 void ddk_set_tuning(int key, int value);
 void ddk_set_attn_split(int v);
 void ddk_set_prefill_mfma(int on);
+int ddk_prefill_mfma_enabled();
+int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
+                      hipStream_t st);   // CLIP tower attention (head_dim 64, bidirectional) on the matrix cores
 
 struct AttnDecodeArgs {
   const float* qbuf;     // [8][q_dim] roped

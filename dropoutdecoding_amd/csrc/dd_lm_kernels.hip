@@ -1475,7 +1475,6 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const float* __restrict__ 
 // output does not depend on the call it arrives in (chunked prefill).
 // -----------------------------------------------------------------------------------------------
 #define FA_KEYS 32
-#define FA_LD 132            // padded row pitch (floats) of the staged K / V tiles: keeps the V^T reads conflict-free
 __device__ __forceinline__ void fa_split8(const float* v, u32x4_t& hi, u32x4_t& lo) {
   uint32_t h[8], l[8];
 #pragma unroll
@@ -1485,17 +1484,20 @@ __device__ __forceinline__ void fa_split8(const float* v, u32x4_t& hi, u32x4_t& 
 }
 #define FA_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), C, 0, 0, 0)
 
-template <int G>
+// HD = head dimension (128: the LM; 64: the CLIP tower, bidirectional, q pre-scaled)
+template <int G, int HD = 128>
 __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restrict__ qbuf, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, int T, int T_cap, int n_heads,
                                                            uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
                                                            const uint8_t* __restrict__ drop_plane, int drop_bit,
-                                                           int span_start, int span_len, int q0) {
-  __shared__ __align__(16) float Ksh[FA_KEYS * FA_LD];
-  __shared__ __align__(16) float Vsh[FA_KEYS * FA_LD];
+                                                           int span_start, int span_len, int q0, int causal, float scaling) {
+  constexpr int LD = HD + 4;   // padded row pitch (floats) of the staged K / V tiles: keeps the V^T reads conflict-free
+  constexpr int KS = HD / 32, DT = HD / 16, C4 = HD / 4;
+  __shared__ __align__(16) float Ksh[FA_KEYS * LD];
+  __shared__ __align__(16) float Vsh[FA_KEYS * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int head = blockIdx.x, kvh = head / G;
-  const int q_dim = n_heads * HEAD_DIM;
+  const int q_dim = n_heads * HD;
   const int c16 = lane & 15, g4 = lane >> 4;
   const int shift = q0 & 15;
   const int blk_first = blockIdx.y * 64 - shift;             // local row of the workgroup's first query (may be < 0)
@@ -1504,41 +1506,37 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
   const int pos_q = q0 + max(0, min(t_q, T - 1));             // its absolute position
   const int blk_last = min(blk_first + 63, T - 1);
   if (blk_last < 0) return;
-  const int p_max = q0 + blk_last;                            // last key any query of the workgroup attends to
-  const int wave_pmax = q0 + min(blk_first + wave * 16 + 15, T - 1);   // ... of this wave
+  const int p_max = causal ? q0 + blk_last : T - 1;           // last key any query of the workgroup attends to
+  const int wave_pmax = causal ? q0 + min(blk_first + wave * 16 + 15, T - 1) : T - 1;   // ... of this wave
   const bool wave_live = blk_first + wave * 16 < T && blk_first + wave * 16 + 15 >= 0;
 
   // Q^T operands of the lane: B[k = d 8 g4 .. +8][j = query c16], four 32-d steps, hi and lo
-  u32x4_t qh[4], ql[4];
+  u32x4_t qh[KS], ql[KS];
   {
-    const float* qr = qbuf + (size_t)max(0, min(t_q, T - 1)) * q_dim + head * HEAD_DIM;
+    const float* qr = qbuf + (size_t)max(0, min(t_q, T - 1)) * q_dim + head * HD;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       float v[8];
       *(f32x4_t*)&v[0] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8);
       *(f32x4_t*)&v[4] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8 + 4);
       fa_split8(v, qh[ks], ql[ks]);
     }
   }
-  f32x4_t acc[8];
+  f32x4_t acc[DT];
 #pragma unroll
-  for (int dt = 0; dt < 8; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  const float scaling = 0.08838834764831845f;
 
   for (int t0 = 0; t0 <= p_max; t0 += FA_KEYS) {
     __syncthreads();                                          // the previous tiles are no longer being read
     // stage K (from the transposed cache [d/4][T_cap][4]) and V ([T_cap][128]) of keys t0 .. t0+31, clamped to p_max
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int k = tid & 31, c = (tid >> 5) + 8 * j;               // 32 keys x 32 d-chunks of 4
-      int key = min(t0 + k, p_max);
-      f32x4_t v = *(const f32x4_t*)(kc + (((size_t)kvh * 32 + c) * T_cap + key) * 4);
-      *(f32x4_t*)&Ksh[k * FA_LD + c * 4] = v;
-      int d4 = tid & 31, kk = (tid >> 5) + 8 * j;             // 32 keys x 32 float4 of a V row
-      int key2 = min(t0 + kk, p_max);
-      f32x4_t w = *(const f32x4_t*)(vc + ((size_t)kvh * T_cap + key2) * HEAD_DIM + d4 * 4);
-      *(f32x4_t*)&Vsh[kk * FA_LD + d4 * 4] = w;
+    for (int i = tid; i < FA_KEYS * C4; i += 256) {
+      int kk = i & 31, c = i >> 5;                            // K: 32 keys x C4 d-chunks of 4 (keys contiguous in the cache)
+      int key = min(t0 + kk, p_max);
+      *(f32x4_t*)&Ksh[kk * LD + c * 4] = *(const f32x4_t*)(kc + (((size_t)kvh * C4 + c) * T_cap + key) * 4);
+      int d4 = i % C4, k2 = i / C4;                            // V: 32 keys x C4 float4 of a row
+      int key2 = min(t0 + k2, p_max);
+      *(f32x4_t*)&Vsh[k2 * LD + d4 * 4] = *(const f32x4_t*)(vc + ((size_t)kvh * T_cap + key2) * HD + d4 * 4);
     }
     __syncthreads();
     if (!wave_live || t0 > wave_pmax) continue;               // nothing for this wave in these keys (barriers above stay matched)
@@ -1548,9 +1546,9 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
-      const float* kr = &Ksh[(kt * 16 + c16) * FA_LD + g4 * 8];
+      const float* kr = &Ksh[(kt * 16 + c16) * LD + g4 * 8];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         float v[8];
         *(f32x4_t*)&v[0] = *(const f32x4_t*)(kr + ks * 32);
         *(f32x4_t*)&v[4] = *(const f32x4_t*)(kr + ks * 32 + 4);
@@ -1563,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = t0 + kt * 16 + g4 * 4 + r;
-        bool ok = key <= pos_q;
+        bool ok = causal ? key <= pos_q : key < T;
         if (ok && drop_plane && key >= span_start && key < span_start + span_len) ok = !((drop_plane[key - span_start] >> drop_bit) & 1);
         sv[kt * 4 + r] = ok ? sacc[r] * scaling : -INFINITY;
       }
@@ -1590,13 +1588,13 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
     fa_split8(p, ph, pl);
     // O^T += V^T . P^T: lane group g4 holds key slots {4 g4 + j, 16 + 4 g4 + j}, j < 4, of this step
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
+    for (int dt = 0; dt < DT; ++dt) {
       float v[8];
       const float* vr = &Vsh[dt * 16 + c16];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = vr[(4 * g4 + j) * FA_LD];
-        v[4 + j] = vr[(16 + 4 * g4 + j) * FA_LD];
+        v[j] = vr[(4 * g4 + j) * LD];
+        v[4 + j] = vr[(16 + 4 * g4 + j) * LD];
       }
       u32x4_t vh, vl;
       fa_split8(v, vh, vl);
@@ -1610,18 +1608,28 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
   if (!q_live) return;
   const float inv = 1.0f / l_run;
 #pragma unroll
-  for (int dt = 0; dt < 8; ++dt) {
+  for (int dt = 0; dt < DT; ++dt) {
     uint32_t hh[4], ll[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) dd_split_hl(acc[dt][r] * inv, hh[r], ll[r]);
-    size_t o = apack_off(t_q, head * HEAD_DIM + dt * 16 + g4 * 4, q_dim >> 5);   // 4 consecutive k: one 8-byte packed store
+    size_t o = apack_off(t_q, head * HD + dt * 16 + g4 * 4, q_dim >> 5);   // 4 consecutive k: one 8-byte packed store
     *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
     *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
   }
 }
 
+// bidirectional attention of the CLIP tower (head_dim 64, q pre-scaled by the QKV epilogue), same kernel
+int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
+                      hipStream_t st) {
+  k_attn_prefill_mfma<1, 64><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0,
+                                                                          0, 1.0f);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int ddk_prefill_mfma_enabled();
 static int g_prefill_mfma = 1;   // dd_set_tuning key 12: prefill attention on the matrix cores (0: the VALU kernel)
 void ddk_set_prefill_mfma(int on) { g_prefill_mfma = on; }
+int ddk_prefill_mfma_enabled() { return g_prefill_mfma; }
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
@@ -1639,7 +1647,7 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
   }
   if (g_prefill_mfma) {
     dim3 g2(n_heads, (T + (q0 & 15) + 63) / 64);
-#define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0
+#define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f
     if (G == 1) k_attn_prefill_mfma<1><<<g2, 256, 0, st>>>(FA_ARGS);
     else if (G == 2) k_attn_prefill_mfma<2><<<g2, 256, 0, st>>>(FA_ARGS);
     else if (G == 4) k_attn_prefill_mfma<4><<<g2, 256, 0, st>>>(FA_ARGS);

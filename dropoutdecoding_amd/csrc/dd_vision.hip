@@ -335,8 +335,12 @@ extern "C" int dd_vit_forward(dd_vit* h, const float* pixels, int n_images, floa
       g.qbuf = h->q, g.kc = h->kt, g.vc = h->v, g.T_cap = h->Tc, g.vit_hidden = d, g.vit_head_dim = h->hd;
       g.vit_qscale = 1.0f / sqrtf((float)h->hd);
       RC(ddk_gemm(EPI_QKV_VIT, g, st));
-      k_attn_vit<<<dim3(h->H, (T + 3) / 4), 256, 0, st>>>(h->q, h->kt, h->v, T, h->Tc, d, h->a_hi, h->a_lo);
-      DD_CHECK_LAUNCH();
+      if (h->hd == 64 && ddk_prefill_mfma_enabled()) {
+        RC(ddk_attn_vit_mfma(h->q, h->kt, h->v, T, h->Tc, h->H, h->a_hi, h->a_lo, st));
+      } else {
+        k_attn_vit<<<dim3(h->H, (T + 3) / 4), 256, 0, st>>>(h->q, h->kt, h->v, T, h->Tc, d, h->a_hi, h->a_lo);
+        DD_CHECK_LAUNCH();
+      }
       memset(&g, 0, sizeof(g));
       g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = d / 32, g.W = w.wo, g.n_tiles = d / 16, g.bias = w.bo;
       g.out = h->x, g.ldo = d;
