@@ -119,6 +119,9 @@ def load() -> C.CDLL:
     lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     lib.dd_persist_read_bench.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.POINTER(C.c_float), vp]
+    for kv in filter(None, os.environ.get("DD_TUNE", "").split(",")):     # e.g. DD_TUNE="13=0,12=0" (dd_set_tuning keys)
+        k, v = kv.split("=")
+        lib.dd_set_tuning(int(k), int(v))
     if os.environ.get("DD_NO_GRAPH", "0") not in ("", "0"):
         lib.dd_set_tuning(8, 0)          # launch every decode step kernel by kernel instead of replaying hipGraphs
     _lib = lib
