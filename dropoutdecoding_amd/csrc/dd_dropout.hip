@@ -432,7 +432,7 @@ extern "C" int dd_rng_create(uint32_t seed, dd_rng** out) {
 }
 extern "C" int dd_rng_destroy(dd_rng* r) {
   if (!r) return DD_OK;
-  hipFree(r->state);
+  (void)hipFree(r->state);
   delete r;
   return DD_OK;
 }

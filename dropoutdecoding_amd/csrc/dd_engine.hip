@@ -110,7 +110,7 @@ static int dalloc(dd_lm* h, T** p, size_t n) {
     dd_set_error("hipMalloc(%zu bytes) -> %s", b, hipGetErrorString(e));
     return DD_ENOMEM;
   }
-  hipMemset(q, 0, b);
+  (void)hipMemset(q, 0, b);
   h->allocs.push_back(q);
   h->bytes += b;
   *p = (T*)q;
