@@ -119,7 +119,7 @@ def main() -> int:
     ap.add_argument("--mode", choices=["replicas", "kshard"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
-    ap.add_argument("--images-per-gpu", type=int, default=16,
+    ap.add_argument("--images-per-gpu", type=int, default=32,
                     help="images decoded concurrently per GPU (lanes over one set of weights, 1..16); 1 = the reference's "
                          "one-image-at-a-time loop")
     args = ap.parse_args()
@@ -158,7 +158,7 @@ def main() -> int:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    B = 1 if args.mode == "kshard" else max(1, min(16, args.images_per_gpu))
+    B = 1 if args.mode == "kshard" else max(1, min(32, args.images_per_gpu))
     lanes = [model] + [model.spawn_lane() for _ in range(B - 1)]
     from dropoutdecoding_amd.vlm import generate_group
 

@@ -619,15 +619,15 @@ __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
 struct MaskLanes {
   MaskParams common;                 // K, mode, rng_mode, scale[], q[]; per-sequence fields below override the rest
   int n, k_top;
-  const float* epi[16];
-  int L[16];
-  uint8_t* keep[16];
-  const int32_t* argmax[16];
-  const int32_t* topk[16];
-  uint32_t* rng_state[16];
-  uint8_t* drop[16];
-  int32_t* n_drop[16];
-  uint8_t* drop_bits[16];
+  const float* epi[32];
+  int L[32];
+  uint8_t* keep[32];
+  const int32_t* argmax[32];
+  const int32_t* topk[32];
+  uint32_t* rng_state[32];
+  uint8_t* drop[32];
+  int32_t* n_drop[32];
+  uint8_t* drop_bits[32];
 };
 __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks_lanes(MaskLanes M) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -658,7 +658,7 @@ struct MaskLaneArgs {                // host-side description of one sequence fo
   uint8_t* drop_bits;
 };
 int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st) {
-  DD_REQUIRE(lanes && n >= 1 && n <= 16 && K >= 1 && K <= 64 && mode >= 0 && mode <= 4, "dd_sample_masks_lanes: bad arguments");
+  DD_REQUIRE(lanes && n >= 1 && n <= 32 && K >= 1 && K <= 64 && mode >= 0 && mode <= 4, "dd_sample_masks_lanes: bad arguments");
   MaskLanes M;
   memset(&M, 0, sizeof(M));
   M.common.K = K, M.common.mode = mode, M.common.rng_mode = mode == DD_MASK_IBLIP_QUANTILE ? DD_RNG_INJECTED : DD_RNG_MT19937;

@@ -32,6 +32,7 @@ int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, int n, int K,
 static unsigned long long g_lm_serial = 0;   // handles are identified in graph keys by a serial that is never reused
 
 #define MAX_MEMBERS 16
+#define KV_ROWS 32        // new K/V rows kept per layer: 16 members, or the base rows of up to 32 lanes (group step)
 #define MAX_NEW_TOKENS 8192
 
 struct LayerW {
@@ -48,7 +49,7 @@ struct dd_lm {
   size_t bytes = 0;
   unsigned long long serial = 0;
   dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
-  float* grp_logits = nullptr; // [16][Vpad] base-pass logits of a group step (this handle is the group's first lane)
+  float* grp_logits = nullptr; // [32][Vpad] base-pass logits of a group step (this handle is the group's first lane)
   int32_t* grp_argmax = nullptr;
   DDState* chunk_states = nullptr;   // [32] positions of the rows of a short prompt chunk (dd_lm_prefill_extend)
   float *chunk_k = nullptr, *chunk_v = nullptr;   // [32][kv_dim] roped K / V rows of the chunk, one layer at a time
@@ -221,8 +222,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   // decode scratch
   DA(h->xa, 32 * (size_t)d);                 // up to 32 rows: a member pass of four sequences (dd_lm_group_step)
   DA(h->qbuf, 32 * (size_t)h->q_dim);
-  DA(h->knew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
-  DA(h->vnew, (size_t)h->Lyr * MAX_MEMBERS * h->kv_dim);
+  DA(h->knew, (size_t)h->Lyr * KV_ROWS * h->kv_dim);
+  DA(h->vnew, (size_t)h->Lyr * KV_ROWS * h->kv_dim);
   DA(h->ssq_a, (size_t)(d / 16) * 32);
   DA(h->ssq_b, (size_t)(d / 16) * 32);
   int max_splits = T / 64;
@@ -233,8 +234,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->xop_q, (size_t)h->S_q * 64 * 4);
   DA(h->xop_ff, (size_t)h->S_ff * 64 * 4);
   DA(h->base_logits, h->Vpad);
-  DA(h->grp_logits, (size_t)16 * h->Vpad);
-  DA(h->grp_argmax, 16);
+  DA(h->grp_logits, (size_t)32 * h->Vpad);
+  DA(h->grp_argmax, 32);
   DA(h->chunk_states, 32);
   DA(h->chunk_k, (size_t)32 * h->kv_dim);
   DA(h->chunk_v, (size_t)32 * h->kv_dim);
@@ -529,9 +530,9 @@ __global__ void k_prefill_rows(int32_t* rows, int span_start, int L, int T0) {
 }
 // ---- the same two kernels for several sequences at once (group step): block = sequence
 struct StepBeginLanes {
-  DDState* st[16];
-  const uint8_t* leak_bits[16];
-  int L[16], mask_positions[16];
+  DDState* st[32];
+  const uint8_t* leak_bits[32];
+  int L[32], mask_positions[32];
 };
 __global__ __launch_bounds__(256) void k_step_begin_lanes(StepBeginLanes t) {
   __shared__ int cnt[4];
@@ -902,26 +903,27 @@ extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int
 static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st,
                     dd_lm* const* lanes = nullptr) {
   const int d = h->d, dff = h->dff;
-  // more than 8 lanes: the base rows fill two operand planes (rows 0-7 / 8-15) and go through the grouped GEMV
+  // more than 8 lanes: the base rows fill two (up to 16 lanes) or four operand planes and go through the grouped GEMV
   const bool wide = lanes && nb > 8;
+  const int lane_groups = nb > 16 ? 4 : 2;
   auto gemv = [&](int epi, GemvArgs& a) -> int {
     if (!wide) return ddk_gemv(epi, a, st);
-    a.n_groups = 2, a.nb = 8;
+    a.n_groups = lane_groups, a.nb = 8;
     return ddk_gemv_groups(epi, a, st);
   };
   if (lanes) {
     EmbedLanes el;
     memset(&el, 0, sizeof(el));
     for (int m = 0; m < nb; ++m) el.state[m] = lanes[m]->state;
-    RC(ddk_embed_rows_lanes(h->embed, d, el, wide ? 16 : 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+    RC(ddk_embed_rows_lanes(h->embed, d, el, wide ? 8 * lane_groups : 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   } else {
     RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   }
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
-    float* knew = h->knew + ((size_t)l * MAX_MEMBERS + row0) * h->kv_dim;
-    float* vnew = h->vnew + ((size_t)l * MAX_MEMBERS + row0) * h->kv_dim;
+    float* knew = h->knew + ((size_t)l * KV_ROWS + row0) * h->kv_dim;
+    float* vnew = h->vnew + ((size_t)l * KV_ROWS + row0) * h->kv_dim;
     GemvArgs a;
     memset(&a, 0, sizeof(a));
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = nb, a.xop = h->xop_d;
@@ -940,16 +942,25 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     t.span_start = h->span_start, t.span_len = h->L, t.part_o = h->part_o, t.part_ml = h->part_ml;
     t.knew = knew, t.vnew = vnew, t.xop_out = h->xop_q;
     if (lanes) {
-      t.n_lanes = nb, t.bit0 = 0, t.drop_bits = nullptr;
-      for (int m = 0; m < nb; ++m) {
-        dd_lm* q = lanes[m];
-        t.lane_kc[m] = q->kc + (size_t)l * q->lsk, t.lane_vc[m] = q->vc + (size_t)l * q->lsv, t.lane_state[m] = q->state;
-        t.lane_bits[m] = q->cfg.leak_mask ? q->leak_bits : nullptr;
-        t.lane_span_start[m] = q->span_start, t.lane_span_len[m] = q->L;
-        if (q->T_host > t.max_T) t.max_T = q->T_host;
+      // one single-query attention per lane over its own cache, 16 rows per launch
+      for (int r0 = 0; r0 < nb; r0 += 16) {
+        const int nr = nb - r0 < 16 ? nb - r0 : 16;
+        AttnDecodeArgs u = t;
+        u.qbuf = h->qbuf + (size_t)r0 * h->q_dim, u.nb = nr, u.n_lanes = nr, u.bit0 = 0, u.drop_bits = nullptr, u.max_T = 0;
+        u.knew = knew + (size_t)r0 * h->kv_dim, u.vnew = vnew + (size_t)r0 * h->kv_dim;
+        u.xop_out = h->xop_q + (size_t)(r0 / 8) * h->S_q * 64;
+        for (int m = 0; m < nr; ++m) {
+          dd_lm* q = lanes[r0 + m];
+          u.lane_kc[m] = q->kc + (size_t)l * q->lsk, u.lane_vc[m] = q->vc + (size_t)l * q->lsv, u.lane_state[m] = q->state;
+          u.lane_bits[m] = q->cfg.leak_mask ? q->leak_bits : nullptr;
+          u.lane_span_start[m] = q->span_start, u.lane_span_len[m] = q->L;
+          if (q->T_host > u.max_T) u.max_T = q->T_host;
+        }
+        RC(ddk_attn_decode(u, st));
       }
+    } else {
+      RC(ddk_attn_decode(t, st));
     }
-    RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_q;
     a.fp8 = h->fp8, a.wscale = w.s_o;
@@ -1041,7 +1052,7 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && h->prefilled && K == h->last_K, "dd_lm_step_commit: bad state (K=%d, expected %d)", K, h ? h->last_K : -1);
   if (K > 0) RC(vote_members(h, K, st));
-  RC(ddk_commit_kv(h->commit_k ? h->commit_k : h->knew, h->commit_v ? h->commit_v : h->vnew, h->Lyr, MAX_MEMBERS,
+  RC(ddk_commit_kv(h->commit_k ? h->commit_k : h->knew, h->commit_v ? h->commit_v : h->vnew, h->Lyr, KV_ROWS,
                    h->kv_dim, h->kc, h->vc, h->lsk, h->lsv, h->T_cap, h->state, K > 0 ? 1 : 0, st));
   k_step_end<<<1, 1024, 0, st>>>(h->state, K, h->argmax_base, h->member_tok, h->base_logits, h->member_logits, h->Vpad,
                                  h->last_logits, h->tokens, h->drop_bits, h->L, h->leak_bits, h->cfg.leak_mask, h->hidden,
@@ -1087,8 +1098,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     t.n_lanes = ng, t.lane_groups = ng;
     for (int g = 0; g < ng; ++g) {
       dd_lm* q = qs[g];
-      float* kn = q->knew + (size_t)l * MAX_MEMBERS * q->kv_dim;
-      float* vn = q->vnew + (size_t)l * MAX_MEMBERS * q->kv_dim;
+      float* kn = q->knew + (size_t)l * KV_ROWS * q->kv_dim;
+      float* vn = q->vnew + (size_t)l * KV_ROWS * q->kv_dim;
       a.knew_g[g] = kn, a.vnew_g[g] = vn, t.knew_g[g] = kn, t.vnew_g[g] = vn;
       for (int m = 0; m < 8; ++m) a.state_rows[8 * g + m] = q->state;
       t.lane_kc[g] = q->kc + (size_t)l * q->lsk, t.lane_vc[g] = q->vc + (size_t)l * q->lsv, t.lane_state[g] = q->state;
@@ -1169,7 +1180,7 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
     el.mirror[g] = q->tok_host_dev, el.L[g] = q->L, el.leak[g] = q->cfg.leak_mask ? 1 : 0;
   }
   RC(dd_vote_lanes(ids, out2, ng, K, st));
-  RC(ddk_commit_kv_lanes(cl, ng, h->Lyr, MAX_MEMBERS, h->kv_dim, h->T_cap, st));
+  RC(ddk_commit_kv_lanes(cl, ng, h->Lyr, KV_ROWS, h->kv_dim, h->T_cap, st));
   k_step_end_lanes<<<ng, 1024, 0, st>>>(el, K, h->Vpad);
   DD_CHECK_LAUNCH();
   for (int g = 0; g < ng; ++g) {
@@ -1187,8 +1198,8 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
 // Per step and sequence the weights are read 1/n + 1 times instead of twice.
 // -----------------------------------------------------------------------------------------------
 struct ScatterTab {
-  float* logits[16];
-  int32_t* argmax[16];
+  float* logits[32];
+  int32_t* argmax[32];
 };
 __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, ScatterTab tab) {
   int m = blockIdx.x;
@@ -1200,7 +1211,7 @@ __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argma
 
 static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  DD_REQUIRE(lanes && n >= 1 && n <= 16, "dd_lm_group_step: 1..16 sequences per group (got %d)", n);
+  DD_REQUIRE(lanes && n >= 1 && n <= 32, "dd_lm_group_step: 1..32 sequences per group (got %d)", n);
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_group_step: bad K / mprobs");
   dd_lm* h0 = lanes[0];
   DD_REQUIRE(h0, "dd_lm_group_step: null handle");
@@ -1251,7 +1262,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     same_rule &= lanes[m]->cfg.mask_mode == h0->cfg.mask_mode && lanes[m]->cfg.k_top == h0->cfg.k_top;
   }
   if (K > 0 && same_rule) {          // keep sets + masks of all sequences: one launch, one workgroup per sequence
-    MaskLaneArgs ml[16];
+    MaskLaneArgs ml[32];
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
       ml[m] = {q->epi, q->L, q->keep, q->argmax_base, q->topk_ids, dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop,
@@ -1379,7 +1390,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
 // changed since it was captured; the cache lives in the first lane.
 extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= 16 && lanes[0] && (K == 0 || mprobs);
+  bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= 32 && lanes[0] && (K == 0 || mprobs);
   for (int m = 0; graphable && m < n; ++m)
     graphable = lanes[m] && lanes[m]->prefilled && lanes[m]->steps_since_prefill >= 1 &&
                 lanes[m]->T_host + 1 < lanes[m]->T_cap && lanes[m]->n_tok_host < MAX_NEW_TOKENS;
@@ -1421,7 +1432,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   struct Saved {
     int T, N, K, S;
     bool leak;
-  } sv[16];
+  } sv[32];
   for (int m = 0; m < n; ++m)
     sv[m] = {lanes[m]->T_host, lanes[m]->n_tok_host, lanes[m]->last_K, lanes[m]->steps_since_prefill, lanes[m]->have_leak};
   auto restore = [&]() {
@@ -1513,7 +1524,7 @@ extern "C" int dd_lm_xchg_import_ids(dd_lm* h, const int32_t* ids, void* stream_
 static int xchg_winner(dd_lm* h, int lo, int hi, float* rec, int import, hipStream_t st) {
   size_t total = dd_lm_xchg_stride(h);
   k_xchg_winner<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(h->state, lo, hi, h->member_logits, h->knew, h->vnew,
-                                                                h->Vpad, h->kv_dim, h->Lyr, MAX_MEMBERS, rec, import);
+                                                                h->Vpad, h->kv_dim, h->Lyr, KV_ROWS, rec, import);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

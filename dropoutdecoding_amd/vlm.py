@@ -251,14 +251,14 @@ def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens:
 @torch.no_grad()
 def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens: Optional[int] = None, eos_token_id=None,
                    num_beams: int = 1, do_sample: bool = False, pad_token_id: Optional[int] = None) -> List[torch.LongTensor]:
-    """`generate()` for up to 16 images at once: models[i] (a wrapper and its spawn_lane() copies) decodes inputs[i].
+    """`generate()` for up to 32 images at once: models[i] (a wrapper and its spawn_lane() copies) decodes inputs[i].
 
     Each image is decoded exactly as `models[i].generate(**inputs[i])` would (same tokens, masks, logits; its own rng
     stream, like one process of the reference's sharded 500-image runs), but all sequences advance together and their
     un-masked passes share one sweep over the weights (EngineGroup) — the throughput mode for CHAIR-style jobs."""
     from .lm import EngineGroup
-    if len(models) != len(inputs) or not 1 <= len(models) <= 16:
-        raise ValueError("generate_group: one model lane per input, 1..16 of them")
+    if len(models) != len(inputs) or not 1 <= len(models) <= 32:
+        raise ValueError("generate_group: one model lane per input, 1..32 of them")
     prepared = []
     for m, kw in zip(models, inputs):
         kw = dict(kw)
@@ -279,15 +279,15 @@ def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens:
 
 
 class GroupPipeline:
-    """Caption a long list of images in batches of up to 16: while one set of lanes decodes, the vision tower and the
+    """Caption a long list of images in batches of up to 32: while one set of lanes decodes, the vision tower and the
     prefill of the NEXT batch are enqueued on a second stream (the decode step is HBM-bound, the prefill MFMA-bound, so
     they overlap) — the 500-image CHAIR job of the reference's SLURM launchers on one GPU.
 
     Each image is still decoded exactly as `generate()` would decode it on a lane of its own (see generate_group)."""
 
     def __init__(self, model: DropoutVLM, lanes: int = 8):
-        if not 1 <= lanes <= 16:
-            raise ValueError("1..16 lanes per set")
+        if not 1 <= lanes <= 32:
+            raise ValueError("1..32 lanes per set")
         self.sets = [[model] + [model.spawn_lane() for _ in range(lanes - 1)], [model.spawn_lane() for _ in range(lanes)]]
         self.pre_stream = torch.cuda.Stream(device=model.device)
 

@@ -540,6 +540,7 @@ def _lane_setup(E, family, rc, shapes, seed=7, max_seq=160, **kw):
 @pytest.mark.parametrize("family,shapes", [
     (FAMILY_LLAVA, [(40, 3, 30), (70, 5, 50), (33, 1, 30), (66, 2, 60)]),       # lengths either side of a 64-key tile
     (FAMILY_LLAVA, [(34 + 3 * i, 1 + i % 3, 30) for i in range(11)]),           # > 8 lanes: base rows in two operand planes
+    (FAMILY_LLAVA, [(34 + 2 * i, 1 + i % 3, 30) for i in range(21)]),           # > 16 lanes: four planes, two attention launches
     (FAMILY_NEXT, [(90, 4, 80), (50, 4, 40)]),
     (FAMILY_IBLIP, [(40, 0, 32), (45, 0, 32), (38, 0, 32)]),                    # leaked mask bits per lane
 ])
