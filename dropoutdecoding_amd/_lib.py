@@ -16,7 +16,7 @@ SYMBOLS = [
     "dd_lm_create", "dd_lm_create_shared", "dd_lm_group_step", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_tensor_fp8", "dd_lm_load_synthetic",
     "dd_lm_prefill", "dd_lm_prefill_ensemble", "dd_lm_truncate", "dd_lm_prefill_extend", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
-    "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_step_algorithmic_bytes",
+    "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_set_eos", "dd_lm_step_algorithmic_bytes",
     "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench", "dd_persist_read_bench",
     "dd_vit_create", "dd_vit_destroy", "dd_vit_load_tensor", "dd_vit_forward",
 ]
@@ -105,6 +105,7 @@ def load() -> C.CDLL:
     lib.dd_lm_xchg_import_winner.argtypes = [vp, vp, vp]
     lib.dd_lm_get.argtypes = [vp, C.c_int, vp, C.c_size_t, vp]
     lib.dd_lm_set_next_token.argtypes = [vp, C.c_int32, vp]
+    lib.dd_lm_set_eos.argtypes = [vp, C.POINTER(C.c_int32), C.c_int, vp]
     lib.dd_lm_peek_tokens.argtypes = [vp, vp, C.c_int]
     lib.dd_lm_peek_tokens.restype = C.c_int
     lib.dd_lm_step_algorithmic_bytes.argtypes = [vp, C.c_int]

@@ -236,8 +236,12 @@ extern "C" int dd_vision_uncertainty(const float* logits, int L, int V, int ld, 
 // ----------------------------------------------------------------------------------------------
 // argmax over rows; keep set (get_overlap_image_tokens, reference models/llava.py:443-482)
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_argmax_rows(const float* __restrict__ x, int V, int ld, int32_t* out) {
+// `gate` (engine-internal launches): non-null and non-zero = the sequence has emitted its EOS; the wasted look-ahead step
+// leaves every persistent buffer as the EOS step left it (dd_lm_kernels.h DDState::done)
+__global__ __launch_bounds__(1024) void k_argmax_rows(const float* __restrict__ x, int V, int ld, int32_t* out,
+                                                      const int32_t* __restrict__ gate) {
   __shared__ ArgMax sh[16];
+  if (gate && *gate) return;
   const float* r = x + (size_t)blockIdx.x * ld;
   ArgMax a = {-INFINITY, 0x7fffffff};
   for (int v = threadIdx.x; v < V; v += 1024) {
@@ -255,9 +259,11 @@ __global__ __launch_bounds__(1024) void k_argmax_rows(const float* __restrict__ 
 struct ArgmaxLanes {
   const float* x[4];
   int32_t* out[4];
+  const int32_t* gate[4];
 };
 __global__ __launch_bounds__(1024) void k_argmax_rows_lanes(ArgmaxLanes t, int V, int ld) {
   __shared__ ArgMax sh[16];
+  if (t.gate[blockIdx.y] && *t.gate[blockIdx.y]) return;
   const float* r = t.x[blockIdx.y] + (size_t)blockIdx.x * ld;
   ArgMax a = {-INFINITY, 0x7fffffff};
   for (int v = threadIdx.x; v < V; v += 1024) {
@@ -270,11 +276,12 @@ __global__ __launch_bounds__(1024) void k_argmax_rows_lanes(ArgmaxLanes t, int V
   a = block_argmax(a, sh);
   if (threadIdx.x == 0) t.out[blockIdx.y][blockIdx.x] = a.i;
 }
-int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, int n, int R, int V, int ld, hipStream_t st) {
+int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, const int32_t* const* gates, int n, int R, int V, int ld,
+                         hipStream_t st) {
   DD_REQUIRE(x && out && n >= 1 && n <= 4 && R >= 1, "dd_argmax_rows_lanes: bad arguments");
   ArgmaxLanes t;
   memset(&t, 0, sizeof(t));
-  for (int i = 0; i < n; ++i) t.x[i] = x[i], t.out[i] = out[i];
+  for (int i = 0; i < n; ++i) t.x[i] = x[i], t.out[i] = out[i], t.gate[i] = gates ? gates[i] : nullptr;
   k_argmax_rows_lanes<<<dim3(R, n), 1024, 0, st>>>(t, V, ld);
   DD_CHECK_LAUNCH();
   return DD_OK;
@@ -282,7 +289,12 @@ int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, int n, int 
 
 extern "C" int dd_argmax_rows(const float* x, int R, int V, int ld, int32_t* out, void* stream_) {
   DD_REQUIRE(x && out && R >= 1 && V >= 1 && ld >= V, "dd_argmax_rows: bad arguments");
-  k_argmax_rows<<<R, 1024, 0, (hipStream_t)stream_>>>(x, V, ld, out);
+  k_argmax_rows<<<R, 1024, 0, (hipStream_t)stream_>>>(x, V, ld, out, nullptr);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int dd_argmax_rows_gated(const float* x, int R, int V, int ld, int32_t* out, const int32_t* gate, hipStream_t st) {
+  k_argmax_rows<<<R, 1024, 0, st>>>(x, V, ld, out, gate);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -290,8 +302,10 @@ extern "C" int dd_argmax_rows(const float* x, int R, int V, int ld, int32_t* out
 __global__ __launch_bounds__(1024) void k_overlap_keep(const float* __restrict__ x, int V,
                                                        const int32_t* __restrict__ topk, int L, int k,
                                                        uint8_t* __restrict__ keep, int32_t* __restrict__ argmax_out,
-                                                       const int32_t* __restrict__ argmax_in) {
+                                                       const int32_t* __restrict__ argmax_in,
+                                                       const int32_t* __restrict__ gate) {
   __shared__ ArgMax sh[16];
+  if (gate && *gate) return;
   int tok;
   if (argmax_in) {
     tok = argmax_in[0];
@@ -318,15 +332,15 @@ __global__ __launch_bounds__(1024) void k_overlap_keep(const float* __restrict__
 extern "C" int dd_overlap_keep(const float* step_logits, int V, const int32_t* topk_ids, int L, int k, uint8_t* keep,
                                int32_t* argmax_out, void* stream_) {
   DD_REQUIRE(step_logits && topk_ids && keep && V >= 1 && L >= 1 && k >= 1, "dd_overlap_keep: bad arguments");
-  k_overlap_keep<<<1, 1024, 0, (hipStream_t)stream_>>>(step_logits, V, topk_ids, L, k, keep, argmax_out, nullptr);
+  k_overlap_keep<<<1, 1024, 0, (hipStream_t)stream_>>>(step_logits, V, topk_ids, L, k, keep, argmax_out, nullptr, nullptr);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 
 // internal variant used by the engine: argmax already on the device
 int dd_overlap_keep_from_argmax(const int32_t* argmax_dev, const int32_t* topk_ids, int L, int k, uint8_t* keep,
-                                hipStream_t st) {
-  k_overlap_keep<<<1, 1024, 0, st>>>(nullptr, 0, topk_ids, L, k, keep, nullptr, argmax_dev);
+                                const int32_t* gate, hipStream_t st) {
+  k_overlap_keep<<<1, 1024, 0, st>>>(nullptr, 0, topk_ids, L, k, keep, nullptr, argmax_dev, gate);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -468,6 +482,7 @@ struct MaskParams {
   int32_t* n_drop;        // [K]
   int32_t* idx;           // [K][L] or nullptr
   uint8_t* drop_bits;     // optional [ceil(K/8)][L]: bit (k&7) of plane k>>3 = member k dropped (engine layout)
+  const int32_t* gate;    // optional: *gate != 0 -> the whole launch is a no-op (no draws: the rng stream stays put)
   float scale[64];        // f32(mprob - 0.1)   (reference llava.py:646: python double, rounded when it meets fp32)
   float q[64];            // f32(1 - mprob)     (reference instructblip.py:450)
 };
@@ -611,6 +626,7 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
 
 __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (P.gate && *P.gate) return;          // sequence finished (EOS): draw nothing, write nothing
   sample_masks_body(P, smem);
 }
 
@@ -628,10 +644,12 @@ struct MaskLanes {
   uint8_t* drop[32];
   int32_t* n_drop[32];
   uint8_t* drop_bits[32];
+  const int32_t* gate[32];
 };
 __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks_lanes(MaskLanes M) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int m = blockIdx.x;
+  if (M.gate[m] && *M.gate[m]) return;    // this sequence finished (EOS): its stream and masks stay as they are
   const int L = M.L[m], k = M.k_top;
   const int tok = M.argmax[m][0];
   for (int l = threadIdx.x; l < L; l += MASK_THREADS) {
@@ -656,6 +674,7 @@ struct MaskLaneArgs {                // host-side description of one sequence fo
   uint8_t* drop;
   int32_t* n_drop;
   uint8_t* drop_bits;
+  const int32_t* gate;
 };
 int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st) {
   DD_REQUIRE(lanes && n >= 1 && n <= 32 && K >= 1 && K <= 64 && mode >= 0 && mode <= 4, "dd_sample_masks_lanes: bad arguments");
@@ -672,7 +691,7 @@ int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const dou
     DD_REQUIRE(mode == DD_MASK_IBLIP_QUANTILE || lanes[m].rng_state, "dd_sample_masks_lanes: sequence %d needs an rng", m);
     M.epi[m] = lanes[m].epi, M.L[m] = lanes[m].L, M.keep[m] = lanes[m].keep, M.argmax[m] = lanes[m].argmax;
     M.topk[m] = lanes[m].topk, M.rng_state[m] = lanes[m].rng_state, M.drop[m] = lanes[m].drop, M.n_drop[m] = lanes[m].n_drop;
-    M.drop_bits[m] = lanes[m].drop_bits;
+    M.drop_bits[m] = lanes[m].drop_bits, M.gate[m] = lanes[m].gate;
   }
   size_t smem = (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4;
   static bool attr_set = false;
@@ -687,7 +706,7 @@ int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const dou
 
 int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
                          int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
-                         int32_t* idx, uint8_t* drop_bits, hipStream_t st) {
+                         int32_t* idx, uint8_t* drop_bits, const int32_t* gate, hipStream_t st) {
   DD_REQUIRE(epi && mprobs && drop && n_drop, "dd_sample_masks: null pointer");
   DD_REQUIRE(L >= 1 && L <= MASK_MAX_L, "dd_sample_masks: L=%d out of range (1..%d)", L, MASK_MAX_L);
   DD_REQUIRE(K >= 1 && K <= 64, "dd_sample_masks: K=%d out of range (1..64)", K);
@@ -704,7 +723,7 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
   MaskParams P;
   memset(&P, 0, sizeof(P));
   P.epi = epi, P.L = L, P.K = K, P.mode = mode, P.rng_mode = rng_mode, P.keep = keep, P.uniforms = uniforms;
-  P.rng_state = rng_state, P.drop = drop, P.n_drop = n_drop, P.idx = idx, P.drop_bits = drop_bits;
+  P.rng_state = rng_state, P.drop = drop, P.n_drop = n_drop, P.idx = idx, P.drop_bits = drop_bits, P.gate = gate;
   for (int k = 0; k < K; ++k) {
     P.scale[k] = (float)(mprobs[k] - 0.1);  // double subtraction, then one rounding to fp32
     P.q[k] = (float)(1.0 - mprobs[k]);
@@ -724,14 +743,15 @@ extern "C" int dd_sample_masks(const float* epi, int L, const double* mprobs, in
                                int rng_mode, const float* uniforms, dd_rng* rng, uint8_t* drop, int32_t* n_drop,
                                int32_t* idx, void* stream_) {
   return dd_sample_masks_impl(epi, L, mprobs, K, keep, mode, rng_mode, uniforms, rng ? rng->state : nullptr, drop,
-                              n_drop, idx, nullptr, (hipStream_t)stream_);
+                              n_drop, idx, nullptr, nullptr, (hipStream_t)stream_);
 }
 
 // ----------------------------------------------------------------------------------------------
 // vote (select_by_vote, reference models/llava.py:22-36)
 // ----------------------------------------------------------------------------------------------
-__global__ void k_vote(const int32_t* __restrict__ ids, int K, int32_t* __restrict__ out2) {
+__global__ void k_vote(const int32_t* __restrict__ ids, int K, int32_t* __restrict__ out2, const int32_t* __restrict__ gate) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (gate && *gate) return;
   int best_k = 0, best_c = 0;
   for (int k = 0; k < K; ++k) {
     bool first = true;
@@ -752,9 +772,11 @@ __global__ void k_vote(const int32_t* __restrict__ ids, int K, int32_t* __restri
 struct VoteLanes {
   const int32_t* ids[4];
   int32_t* out2[4];
+  const int32_t* gate[4];
 };
 __global__ void k_vote_lanes(VoteLanes t, int K) {
   if (threadIdx.x != 0) return;
+  if (t.gate[blockIdx.x] && *t.gate[blockIdx.x]) return;
   const int32_t* ids = t.ids[blockIdx.x];
   int best_k = 0, best_c = 0;
   for (int k = 0; k < K; ++k) {
@@ -771,11 +793,11 @@ __global__ void k_vote_lanes(VoteLanes t, int K) {
   t.out2[blockIdx.x][0] = best_k;
   t.out2[blockIdx.x][1] = ids[best_k];
 }
-int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, int n, int K, hipStream_t st) {
+int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, const int32_t* const* gates, int n, int K, hipStream_t st) {
   DD_REQUIRE(ids && out2 && n >= 1 && n <= 4 && K >= 1 && K <= 4096, "dd_vote_lanes: bad arguments");
   VoteLanes t;
   memset(&t, 0, sizeof(t));
-  for (int i = 0; i < n; ++i) t.ids[i] = ids[i], t.out2[i] = out2[i];
+  for (int i = 0; i < n; ++i) t.ids[i] = ids[i], t.out2[i] = out2[i], t.gate[i] = gates ? gates[i] : nullptr;
   k_vote_lanes<<<n, 64, 0, st>>>(t, K);
   DD_CHECK_LAUNCH();
   return DD_OK;
@@ -783,7 +805,12 @@ int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, int n, int K,
 
 extern "C" int dd_vote(const int32_t* ids, int K, int32_t* out2, void* stream_) {
   DD_REQUIRE(ids && out2 && K >= 1 && K <= 4096, "dd_vote: bad arguments");
-  k_vote<<<1, 64, 0, (hipStream_t)stream_>>>(ids, K, out2);
+  k_vote<<<1, 64, 0, (hipStream_t)stream_>>>(ids, K, out2, nullptr);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int dd_vote_gated(const int32_t* ids, int K, int32_t* out2, const int32_t* gate, hipStream_t st) {
+  k_vote<<<1, 64, 0, st>>>(ids, K, out2, gate);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

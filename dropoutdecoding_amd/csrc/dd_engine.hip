@@ -8,11 +8,15 @@
 
 #include "dd_lm_kernels.h"
 
+// `gate` arguments: &state->done of the sequence — a finished sequence's look-ahead steps leave rng, masks, keep set, argmax
+// and vote untouched (HF stops at EOS; here the stop is device-side because steps are enqueued ahead)
 int dd_overlap_keep_from_argmax(const int32_t* argmax_dev, const int32_t* topk_ids, int L, int k, uint8_t* keep,
-                                hipStream_t st);
+                                const int32_t* gate, hipStream_t st);
 int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
                          int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
-                         int32_t* idx, uint8_t* drop_bits, hipStream_t st);
+                         int32_t* idx, uint8_t* drop_bits, const int32_t* gate, hipStream_t st);
+int dd_argmax_rows_gated(const float* x, int R, int V, int ld, int32_t* out, const int32_t* gate, hipStream_t st);
+int dd_vote_gated(const int32_t* ids, int K, int32_t* out2, const int32_t* gate, hipStream_t st);
 uint32_t* dd_rng_state_ptr(dd_rng* r);
 unsigned long long dd_rng_serial(dd_rng* r);
 struct MaskLaneArgs {
@@ -25,10 +29,12 @@ struct MaskLaneArgs {
   uint8_t* drop;
   int32_t* n_drop;
   uint8_t* drop_bits;
+  const int32_t* gate;
 };
 int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st);
-int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, int n, int R, int V, int ld, hipStream_t st);
-int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, int n, int K, hipStream_t st);
+int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, const int32_t* const* gates, int n, int R, int V, int ld,
+                         hipStream_t st);
+int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, const int32_t* const* gates, int n, int K, hipStream_t st);
 static unsigned long long g_lm_serial = 0;   // handles are identified in graph keys by a serial that is never reused
 
 #define MAX_MEMBERS 16
@@ -475,6 +481,7 @@ __global__ void k_state_after_prefill(DDState* st, int T0, const int32_t* first_
     st->cur_tok = first_tok[0];
     st->winner = 0;
     st->voted = first_tok[0];
+    st->done = dd_is_eos(st, first_tok[0]) ? 1 : 0;   // the eos list itself survives prefills (dd_lm_set_eos)
     tokens[0] = first_tok[0];
     mirror[1] = first_tok[0];
     __threadfence_system();
@@ -501,6 +508,7 @@ __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int
                                                    int32_t* tokens, const uint8_t* drop_bits, int L, uint8_t* leak_bits,
                                                    int leak, const float* hidden_rows, int d, float* last_hidden,
                                                    volatile int32_t* mirror) {
+  if (st->done) return;          // the sequence ended at an EOS: this enqueued-ahead step emits and advances nothing
   int win = K > 0 ? st->winner : 0;
   const float* src = K > 0 ? member_logits + (size_t)win * Vpad : base_logits;
   for (int i = threadIdx.x; i < Vpad; i += 1024) last_logits[i] = src[i];
@@ -520,6 +528,7 @@ __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int
     st->n_tok = n + 1;
     st->cur_tok = tok;
     st->T = st->T + 1;
+    if (dd_is_eos(st, tok)) st->done = 1;
   }
 }
 // rows of the prompt that go through lm_head: the visual span, then the last position
@@ -559,6 +568,7 @@ struct StepEndLanes {
 __global__ __launch_bounds__(1024) void k_step_end_lanes(StepEndLanes t, int K, int Vpad) {
   const int q = blockIdx.x;
   DDState* st = t.st[q];
+  if (st->done) return;
   const int win = st->winner;
   const float* src = t.member_logits[q] + (size_t)win * Vpad;
   for (int i = threadIdx.x; i < Vpad; i += 1024) t.last_logits[q][i] = src[i];
@@ -578,6 +588,7 @@ __global__ __launch_bounds__(1024) void k_step_end_lanes(StepEndLanes t, int K, 
     st->n_tok = n + 1;
     st->cur_tok = tok;
     st->T = st->T + 1;
+    if (dd_is_eos(st, tok)) st->done = 1;
   }
 }
 __global__ void k_state_truncate(DDState* st, int T) {
@@ -586,13 +597,24 @@ __global__ void k_state_truncate(DDState* st, int T) {
     st->pos = T;
     st->n_tok = 0;
     st->winner = 0;
+    st->done = 0;
+  }
+}
+struct EosList {
+  int32_t n, ids[DD_MAX_EOS];
+};
+__global__ void k_set_eos(DDState* st, EosList e) {
+  if (threadIdx.x == 0) {
+    st->n_eos = e.n;
+    for (int i = 0; i < DD_MAX_EOS; ++i) st->eos[i] = e.ids[i];
+    st->done = (st->n_tok > 0 && dd_is_eos(st, st->cur_tok)) ? 1 : 0;   // the last emitted token may already be one
   }
 }
 __global__ void k_set_token(DDState* st, int tok) {
   if (threadIdx.x == 0) st->cur_tok = tok;
 }
 __global__ void k_set_winner(DDState* st, int winner, const int32_t* tok) {
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !st->done) {
     st->winner = winner;
     st->voted = tok[winner];
   }
@@ -610,6 +632,7 @@ __global__ __launch_bounds__(1024) void k_first_token_from_member(DDState* st, c
     int tok = member_tok[win];
     tokens[0] = tok;
     st->cur_tok = tok;
+    st->done = dd_is_eos(st, tok) ? 1 : 0;
     mirror[1] = tok;
     __threadfence_system();
     mirror[0] = 1;
@@ -840,14 +863,14 @@ extern "C" int dd_lm_prefill_extend(dd_lm* h, const float* embeds, int n, void* 
 static int vote_members(dd_lm* h, int K, hipStream_t st) {
   if (h->cfg.vote_on == DD_VOTE_AVERAGE) {
     // select_by_average (llava.py:37-52): member 0's output with its last-token logits replaced by the fp32 mean
-    RC(ddk_mean_rows(h->member_logits, K, h->Vpad, h->V, st));
-    RC(dd_argmax_rows(h->member_logits, 1, h->V, h->Vpad, h->member_tok, st));
+    RC(ddk_mean_rows(h->member_logits, K, h->Vpad, h->V, &h->state->done, st));
+    RC(dd_argmax_rows_gated(h->member_logits, 1, h->V, h->Vpad, h->member_tok, &h->state->done, st));
     k_set_winner<<<1, 64, 0, st>>>(h->state, 0, h->member_tok);
     DD_CHECK_LAUNCH();
     return DD_OK;
   }
   const int32_t* ids = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
-  return dd_vote(ids, K, &h->state->winner, st);
+  return dd_vote_gated(ids, K, &h->state->winner, &h->state->done, st);
 }
 
 // Prefill with the ensemble also applied to the FIRST generated token — the reference's `# if True:` toggle at
@@ -865,11 +888,11 @@ extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int
   DD_REQUIRE(span_start >= 1, "dd_lm_prefill_ensemble: the visual span must not start at position 0 (a fully masked "
                               "first row has no defined attention; the reference toggle exists for LLaVA only)");
   const int d = h->d, L = span_len;
-  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, L, h->cfg.k_top, h->keep, st));
+  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, L, h->cfg.k_top, h->keep, nullptr, st));
   int rng_mode = uniforms ? DD_RNG_INJECTED : DD_RNG_MT19937;
   DD_REQUIRE(h->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || uniforms || rng, "dd_lm_prefill_ensemble: an rng or uniforms is required");
   RC(dd_sample_masks_impl(h->epi, L, mprobs, K, h->keep, h->cfg.mask_mode, rng_mode, uniforms, dd_rng_state_ptr(rng),
-                          h->drop, h->n_drop, nullptr, h->drop_bits, st));
+                          h->drop, h->n_drop, nullptr, h->drop_bits, nullptr, st));
   const int32_t* last_row = h->row_index + L;     // == T0 - 1 (set by dd_lm_prefill)
   auto member_pass = [&](int k, bool head) -> int {
     DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)T0 * d * 4, hipMemcpyDeviceToDevice, st));
@@ -985,7 +1008,8 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   a.out = logits_out, a.ldo = h->Vpad, a.n_valid = h->V;
-  RC(gemv(EPI_STORE, a));
+  if (!lanes) a.state = h->state;      // a finished sequence keeps the logits of its EOS step (the group's fused base rows go
+  RC(gemv(EPI_STORE, a));              // to scratch and are handed out by k_scatter_base, which checks per sequence)
   return DD_OK;
 }
 
@@ -1013,14 +1037,15 @@ extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rn
   const uint8_t* base_bits = h->cfg.leak_mask ? h->leak_bits : nullptr;
   h->bit0 = 0;
   RC(lm_sweep(h, 1, base_bits, 0, h->base_logits, st));
-  RC(dd_argmax_rows(h->base_logits, 1, h->V, h->Vpad, h->argmax_base, st));
+  const int32_t* gate = &h->state->done;
+  RC(dd_argmax_rows_gated(h->base_logits, 1, h->V, h->Vpad, h->argmax_base, gate, st));
   h->last_K = K;
   if (K == 0) return DD_OK;
-  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, st));
+  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, gate, st));
   int rng_mode = uniforms ? DD_RNG_INJECTED : DD_RNG_MT19937;
   DD_REQUIRE(h->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || uniforms || rng, "dd_lm_step: an rng or uniforms is required");
   RC(dd_sample_masks_impl(h->epi, h->L, mprobs, K, h->keep, h->cfg.mask_mode, rng_mode, uniforms,
-                          dd_rng_state_ptr(rng), h->drop, h->n_drop, nullptr, h->drop_bits, st));
+                          dd_rng_state_ptr(rng), h->drop, h->n_drop, nullptr, h->drop_bits, gate, st));
   return DD_OK;
 }
 
@@ -1037,11 +1062,11 @@ extern "C" int dd_lm_step_members(dd_lm* h, int m_lo, int m_hi, void* stream_) {
     const uint8_t* bits = h->drop_bits + (size_t)(g0 >> 3) * h->L;
     h->bit0 = g0 & 7;
     RC(lm_sweep(h, nb, bits, g0, h->member_logits + (size_t)g0 * h->Vpad, st));
-    RC(dd_argmax_rows(h->member_logits + (size_t)g0 * h->Vpad, nb, h->V, h->Vpad, h->member_tok + g0, st));
+    RC(dd_argmax_rows_gated(h->member_logits + (size_t)g0 * h->Vpad, nb, h->V, h->Vpad, h->member_tok + g0, &h->state->done, st));
     if (h->cfg.vote_on == DD_VOTE_HIDDEN) {
       float* hid = h->hidden + (size_t)g0 * h->d;
       RC(ddk_final_norm_rows(h->xa, nb, h->d, h->final_norm, h->cfg.rms_eps, hid, st));
-      RC(dd_argmax_rows(hid, nb, h->d, h->d, h->member_vote + g0, st));
+      RC(dd_argmax_rows_gated(hid, nb, h->d, h->d, h->member_vote + g0, &h->state->done, st));
     }
     g0 = g1;
   }
@@ -1133,7 +1158,10 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
-  for (int g = 0; g < ng; ++g) a.out_g[g] = qs[g]->member_logits;
+  for (int g = 0; g < ng; ++g) {
+    a.out_g[g] = qs[g]->member_logits;
+    for (int m = 0; m < 8; ++m) a.state_rows[8 * g + m] = qs[g]->state;
+  }
   a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
   RC(ddk_gemv_groups(EPI_STORE, a, st));
   return DD_OK;
@@ -1145,14 +1173,15 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
   const int d = h->d;
   const float* lg[4];
   int32_t* tk[4];
-  for (int g = 0; g < ng; ++g) lg[g] = qs[g]->member_logits, tk[g] = qs[g]->member_tok;
-  RC(dd_argmax_rows_lanes(lg, tk, ng, K, h->V, h->Vpad, st));
+  const int32_t* gates[4];
+  for (int g = 0; g < ng; ++g) lg[g] = qs[g]->member_logits, tk[g] = qs[g]->member_tok, gates[g] = &qs[g]->state->done;
+  RC(dd_argmax_rows_lanes(lg, tk, gates, ng, K, h->V, h->Vpad, st));
   bool plain_vote = true;
   for (int g = 0; g < ng; ++g) {
     dd_lm* q = qs[g];
     if (q->cfg.vote_on == DD_VOTE_HIDDEN) {    // InstructBLIP: argmax over the final-normed hidden state (instructblip.py:125-137)
       RC(ddk_final_norm_rows(h->xa + (size_t)g * 8 * d, K, d, h->final_norm, h->cfg.rms_eps, q->hidden, st));
-      RC(dd_argmax_rows(q->hidden, K, d, d, q->member_vote, st));
+      RC(dd_argmax_rows_gated(q->hidden, K, d, d, q->member_vote, &q->state->done, st));
     }
     plain_vote &= q->cfg.vote_on != DD_VOTE_AVERAGE;
   }
@@ -1179,7 +1208,7 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
     el.last_logits[g] = q->last_logits, el.tokens[g] = q->tokens, el.drop_bits[g] = q->drop_bits, el.leak_bits[g] = q->leak_bits;
     el.mirror[g] = q->tok_host_dev, el.L[g] = q->L, el.leak[g] = q->cfg.leak_mask ? 1 : 0;
   }
-  RC(dd_vote_lanes(ids, out2, ng, K, st));
+  RC(dd_vote_lanes(ids, out2, gates, ng, K, st));
   RC(ddk_commit_kv_lanes(cl, ng, h->Lyr, KV_ROWS, h->kv_dim, h->T_cap, st));
   k_step_end_lanes<<<ng, 1024, 0, st>>>(el, K, h->Vpad);
   DD_CHECK_LAUNCH();
@@ -1200,9 +1229,11 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
 struct ScatterTab {
   float* logits[32];
   int32_t* argmax[32];
+  const DDState* st[32];
 };
 __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, ScatterTab tab) {
   int m = blockIdx.x;
+  if (tab.st[m]->done) return;
   const float* src = grp_logits + (size_t)m * Vpad;
   float* dst = tab.logits[m];
   for (int i = threadIdx.x; i < Vpad; i += 256) dst[i] = src[i];
@@ -1250,7 +1281,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   {
     ScatterTab tab;
     memset(&tab, 0, sizeof(tab));
-    for (int m = 0; m < n; ++m) tab.logits[m] = lanes[m]->base_logits, tab.argmax[m] = lanes[m]->argmax_base;
+    for (int m = 0; m < n; ++m) tab.logits[m] = lanes[m]->base_logits, tab.argmax[m] = lanes[m]->argmax_base, tab.st[m] = lanes[m]->state;
     k_scatter_base<<<n, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
     DD_CHECK_LAUNCH();
   }
@@ -1266,15 +1297,16 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
       ml[m] = {q->epi, q->L, q->keep, q->argmax_base, q->topk_ids, dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop,
-               q->drop_bits};
+               q->drop_bits, &q->state->done};
     }
     RC(dd_sample_masks_lanes(ml, n, h0->cfg.k_top, mprobs, K, h0->cfg.mask_mode, st));
   } else if (K > 0) {
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
-      RC(dd_overlap_keep_from_argmax(q->argmax_base, q->topk_ids, q->L, q->cfg.k_top, q->keep, st));
+      RC(dd_overlap_keep_from_argmax(q->argmax_base, q->topk_ids, q->L, q->cfg.k_top, q->keep, &q->state->done, st));
       RC(dd_sample_masks_impl(q->epi, q->L, mprobs, K, q->keep, q->cfg.mask_mode, DD_RNG_MT19937, nullptr,
-                              dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits, st));
+                              dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits,
+                              &q->state->done, st));
     }
   }
   const bool multi = g_pair_sweeps && K > 0 && K <= 8;
@@ -1531,12 +1563,27 @@ static int xchg_winner(dd_lm* h, int lo, int hi, float* rec, int import, hipStre
 extern "C" int dd_lm_xchg_export_winner(dd_lm* h, int m_lo, int m_hi, float* rec, void* stream_) {
   DD_REQUIRE(h && rec && h->last_K >= 1, "dd_lm_xchg_export_winner: bad state");
   const int32_t* ids = h->cfg.vote_on == DD_VOTE_HIDDEN ? h->member_vote : h->member_tok;
-  RC(dd_vote(ids, h->last_K, &h->state->winner, stream_));
+  RC(dd_vote_gated(ids, h->last_K, &h->state->winner, &h->state->done, (hipStream_t)stream_));
   return xchg_winner(h, m_lo, m_hi, rec, 0, (hipStream_t)stream_);
 }
 extern "C" int dd_lm_xchg_import_winner(dd_lm* h, const float* rec, void* stream_) {
   DD_REQUIRE(h && rec && h->last_K >= 1, "dd_lm_xchg_import_winner: bad state");
   return xchg_winner(h, 0, 0, (float*)rec, 1, (hipStream_t)stream_);
+}
+
+// HF's greedy loop ends a sequence at the first EOS id (chair_test.py:341-346 relies on it).  The ids live in the
+// sequence's device state: the step that emits one marks the sequence done, and steps enqueued beyond it change nothing
+// that persists — in particular they draw nothing from the rng stream, which the reference continues into the next image
+// (models/llava.py:16-20, :650).  The list survives prefills; n = 0 clears it.
+extern "C" int dd_lm_set_eos(dd_lm* h, const int32_t* eos_ids_host, int n, void* stream_) {
+  DD_REQUIRE(h && n >= 0 && n <= DD_MAX_EOS && (n == 0 || eos_ids_host), "dd_lm_set_eos: 0..%d ids", DD_MAX_EOS);
+  EosList e;
+  memset(&e, 0, sizeof(e));
+  e.n = n;
+  for (int i = 0; i < n; ++i) e.ids[i] = eos_ids_host[i];
+  k_set_eos<<<1, 64, 0, (hipStream_t)stream_>>>(h->state, e);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 
 extern "C" int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream_) {
@@ -1553,6 +1600,12 @@ extern "C" int dd_lm_get(dd_lm* h, int what, void* dst, size_t bytes, void* stre
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && dst, "dd_lm_get: null argument");
   DD_HIP(hipStreamSynchronize(st));
+  if (h->prefilled) {
+    // the host mirrors count ENQUEUED steps; steps enqueued beyond an EOS did not advance the sequence (DDState::done)
+    DDState ds;
+    DD_HIP(hipMemcpy(&ds, h->state, sizeof(ds), hipMemcpyDeviceToHost));
+    h->T_host = ds.T, h->n_tok_host = ds.n_tok < MAX_NEW_TOKENS ? ds.n_tok : MAX_NEW_TOKENS;
+  }
   const void* src = nullptr;
   size_t avail = 0;
   const int K = h->last_K, L = h->L;

@@ -11,8 +11,19 @@ struct DDState {
   int32_t cur_tok;  // input token of the step being decoded
   int32_t winner;   // last vote: member index
   int32_t voted;    // last vote: id
-  int32_t pad[2];
+  // HF's greedy loop stops at EOS; steps are enqueued ahead of the host's knowledge of the tokens, so the
+  // stop lives here: the step that emits an EOS id sets `done`, and every later enqueued step of the sequence is a no-op
+  // for everything that persists (rng stream, masks, vote, KV append, tokens, lengths) until the next prefill.
+  int32_t done;
+  int32_t n_eos;
+  int32_t eos[8];
 };
+#define DD_MAX_EOS 8
+__host__ __device__ inline bool dd_is_eos(const DDState* st, int tok) {
+  bool hit = false;
+  for (int i = 0; i < DD_MAX_EOS; ++i) hit |= (i < st->n_eos && st->eos[i] == tok);
+  return hit;
+}
 
 // ---- weight layout ------------------------------------------------------------------------
 // W[N][K] bf16 (HF: out_features x in_features) is stored as 16x32 MFMA operand tiles:
@@ -176,7 +187,7 @@ int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x,
 int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t st);
 int ddk_scatter_kv_rows(const float* kr, const float* vr, int n, int kv_dim, float* kc, float* vc, int T_cap, const DDState* base,
                         hipStream_t st);
-int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st);
+int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStream_t st);
 
 // ---- small glue -------------------------------------------------------------------------------
 // x[0..8)[d] <- embed[cur_tok] (all rows equal), xop <- split(normw * x), ssq slot 0

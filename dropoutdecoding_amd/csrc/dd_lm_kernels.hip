@@ -262,6 +262,10 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
           pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
           pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
         }
+      } else if (EPI == EPI_STORE) {
+        // logits of a sequence that already emitted its EOS are not overwritten by look-ahead steps (DDState::done)
+        const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+        if (sp && sp->done) pre0 = 1.f;
       }
     }
   }
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
         float y = tile_sum(0, n, m);
         if (a.ssq_in) y *= rstd_sh[m];
         int col = tile0 * 16 + n;
-        if (col < a.n_valid) a.out[(size_t)m * a.ldo + col] = y;
+        if (col < a.n_valid && pre0 == 0.f) a.out[(size_t)m * a.ldo + col] = y;
       }
     }
   } else if (EPI == EPI_RESID) {
@@ -597,6 +601,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
           rope_s[tt] = a.rope_sin[(size_t)pos * ROPE_HALF + f];
         }
       }
+    } else if (EPI == EPI_STORE) {
+      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+      if (sp && sp->done) pre0 = 1.f;    // finished sequence: its logits stay as the EOS step left them
     }
   }
   if (a.ssq_in) {
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
       if (a.ssq_in) y *= rstd_sh[em];
       int col = tile0 * 16 + en;
       float* row = a.out_g[eg] ? a.out_g[eg] + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
-      if (col < a.n_valid) row[col] = y;
+      if (col < a.n_valid && pre0 == 0.f) row[col] = y;
     }
   } else if (EPI == EPI_RESID) {
     float sq = 0.f;
@@ -1827,15 +1834,15 @@ int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n,
 
 // rows[0][v] := (((r0 + r1) + r2) + ...) / K in fp32 — numpy's mean over axis 0 of a [K, V] float32 array
 // (reference llava.py:37-52, select_by_average)
-__global__ void k_mean_rows(float* rows, int K, int ld, int n) {
+__global__ void k_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || (gate && *gate)) return;
   float acc = rows[i];
   for (int k = 1; k < K; ++k) acc = __fadd_rn(acc, rows[(size_t)k * ld + i]);
   rows[i] = __fdiv_rn(acc, (float)K);
 }
-int ddk_mean_rows(float* rows, int K, int ld, int n, hipStream_t st) {
-  k_mean_rows<<<(n + 255) / 256, 256, 0, st>>>(rows, K, ld, n);
+int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStream_t st) {
+  k_mean_rows<<<(n + 255) / 256, 256, 0, st>>>(rows, K, ld, n, gate);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -1845,6 +1852,7 @@ __global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ kne
                                                    int rows_per_layer, int kv_dim, float* __restrict__ kc,
                                                    float* __restrict__ vc, size_t lsk, size_t lsv, int T_cap,
                                                    const DDState* state, int use_winner) {
+  if (state->done) return;       // finished at EOS: a look-ahead step appends nothing
   int layer = blockIdx.x;
   int row = use_winner ? state->winner : 0;
   int T = state->T;
@@ -1862,6 +1870,7 @@ __global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ kne
 __global__ __launch_bounds__(256) void k_commit_kv_lanes(CommitLanes t, int rows_per_layer, int kv_dim, int T_cap) {
   const int layer = blockIdx.x, q = blockIdx.y;
   const DDState* state = t.state[q];
+  if (state->done) return;
   const int row = state->winner, T = state->T;
   const float* kr = t.knew[q] + ((size_t)layer * rows_per_layer + row) * kv_dim;
   const float* vr = t.vnew[q] + ((size_t)layer * rows_per_layer + row) * kv_dim;

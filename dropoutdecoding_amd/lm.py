@@ -74,6 +74,14 @@ VICUNA_7B = LMConfig(32001, 4096, 11008, 32, 32, 32, 128, 1e-6, 10000.0)
 MISTRAL_7B = LMConfig(32064, 4096, 14336, 32, 32, 8, 128, 1e-5, 1000000.0)
 
 
+def _eos_ids(eos) -> tuple:
+    if eos is None:
+        return ()
+    if isinstance(eos, (list, tuple, set, frozenset)):
+        return tuple(sorted({int(t) for t in eos}))
+    return (int(eos),)
+
+
 def quantize_fp8(w: torch.Tensor):
     """Per-output-row absmax quantisation to OCP fp8 e4m3fn: w ~= scale[:, None] * q.  Returns (q as uint8 [N, K],
     scale fp32 [N]).  Build-defined (the reference has no fp8 path): BASELINE config 5."""
@@ -142,6 +150,7 @@ class DropoutEngine:
         self.masked_numbers: List[int] = []
         self._peek_buf = np.zeros(8192, dtype=np.int32)
         self._n_enqueued = 0
+        self._eos_dev: Optional[tuple] = None        # eos ids currently held in the sequence's device state
 
     def _s(self) -> int:
         return self.torch_stream.cuda_stream
@@ -297,6 +306,19 @@ class DropoutEngine:
         return (torch.zeros(32, dtype=torch.int32, device=self.device),
                 torch.zeros(self.xchg_stride(), dtype=torch.float32, device=self.device))
 
+    def set_eos(self, eos) -> None:
+        """EOS ids of HF's greedy loop, kept in the sequence's DEVICE state: the step that emits one ends
+        the sequence there, and steps already enqueued beyond it are no-ops — they draw nothing from the rng stream, so
+        the next image continues the stream exactly where the reference's would (models/llava.py:16-20, :650)."""
+        ids = _eos_ids(eos)
+        if self._eos_dev == ids:
+            return
+        if len(ids) > 8:
+            raise ValueError("at most 8 eos ids")
+        arr = (C.c_int32 * max(len(ids), 1))(*ids)
+        _lib.check(self.lib.dd_lm_set_eos(self._h, arr, len(ids), self._s()), "dd_lm_set_eos")
+        self._eos_dev = ids
+
     def set_next_token(self, token: int) -> None:
         _lib.check(self.lib.dd_lm_set_next_token(self._h, int(token), self._s()), "dd_lm_set_next_token")
 
@@ -309,8 +331,11 @@ class DropoutEngine:
     def generate(self, n_new: int, eos=None, mprobs=None, dropout: bool = True, lookahead: int = 6, step_fn=None) -> List[int]:
         """Greedy loop of HF `_sample`: the prefill's token first, then ensemble steps until EOS or n_new.
         Steps are enqueued without synchronising; the host watches the pinned token mirror and stops enqueueing as soon
-        as an EOS appears, so at most `lookahead` steps are wasted (their tokens are discarded)."""
-        eos_set = set() if eos is None else (set(eos) if isinstance(eos, (list, tuple, set)) else {int(eos)})
+        as an EOS appears.  The stop itself is device-side (set_eos): up to `lookahead` steps enqueued beyond the EOS
+        step run as no-ops that neither emit tokens nor consume the rng stream, so results do not depend on host
+        timing."""
+        eos_set = set(_eos_ids(eos))
+        self._sync_eos(eos_set)
         step = step_fn or (lambda: self.decode_step(mprobs, dropout=dropout))
         enq = self._n_enqueued
         while enq < n_new:
@@ -322,11 +347,14 @@ class DropoutEngine:
                 continue
             step()
             enq = self._n_enqueued
-        toks = self.tokens()
-        hit = [i for i, t in enumerate(toks) if t in eos_set]
-        if hit:
-            toks = toks[:hit[0] + 1]
+        toks = self.tokens()              # the device stopped at the EOS step; nothing to cut off
+        self._n_enqueued = len(toks)
         return toks[:n_new]
+
+    def _sync_eos(self, eos_set) -> None:
+        """The device-side eos list must be the loop's: set it before the first step is enqueued.  If the prefill's greedy
+        token (emitted before the list was known) already is an EOS, the loop below enqueues nothing, so no flag is needed."""
+        self.set_eos(sorted(eos_set))
 
     # ---- read-backs (synchronise) -------------------------------------------------------------
     def _get(self, what: int, n: int, dtype) -> np.ndarray:
@@ -445,8 +473,10 @@ class EngineGroup:
         n_new; the others go on with fewer rows in the fused base pass.  `idle()` (optional) is called while the GPU has
         `lookahead` steps queued; it does one unit of other host work (e.g. enqueue the next image's prefill on another
         stream) and returns False when it has nothing left."""
-        eos_set = set() if eos is None else (set(eos) if isinstance(eos, (list, tuple, set)) else {int(eos)})
+        eos_set = set(_eos_ids(eos))
         E = self.engines
+        for e in E:
+            e._sync_eos(eos_set)
         while True:
             seen = [e.peek_tokens() for e in E]
             active = [i for i, e in enumerate(E)
@@ -460,9 +490,7 @@ class EngineGroup:
             self.decode_step(mprobs, dropout=dropout, active=active)
         out = []
         for e in E:
-            toks = e.tokens()
-            hit = [i for i, t in enumerate(toks) if t in eos_set]
-            if hit:
-                toks = toks[:hit[0] + 1]
+            toks = e.tokens()             # each lane stopped at its own EOS step on the device
+            e._n_enqueued = len(toks)
             out.append(toks[:n_new])
         return out

@@ -210,8 +210,10 @@ class DropoutVLM:
         dropout = not self.original
         ks = getattr(self, "kshard", None)             # dist.KShardDecoder: members sharded over ranks
         if ks is None and not self.collect_diagnostics:
-            # steps are enqueued without host syncs; the pinned token mirror is watched for EOS (<= 6 wasted steps)
+            # steps are enqueued without host syncs; the pinned token mirror is watched for EOS (look-ahead steps past
+            # it are device-side no-ops: no tokens, no rng draws)
             return eng.generate(n_new, eos=eos, dropout=dropout)
+        eng.set_eos(eos)            # K-shard chunks run past an EOS on every rank: the stop is device-side there too
         toks = eng.tokens()
         while len(toks) < n_new and not (eos and toks[-1] in eos):
             if ks is not None and dropout:

@@ -270,6 +270,17 @@ int dd_lm_get(dd_lm* h, int what, void* dst_host, size_t bytes, void* stream);
  * how many; does not synchronise any stream. */
 int dd_lm_peek_tokens(dd_lm* h, int32_t* dst_host, int max_tokens);
 
+/* End of sequence, device-side.  HF's greedy loop (third-party GenerationMixin._sample, the caller of the reference's
+ * forward(); chair_test/chair_test.py:341-346) stops at the first EOS id, and the reference's global rng stream then
+ * continues into the next image (models/llava.py:16-20, :650).  Decode steps are enqueued here without host
+ * synchronisation, possibly several beyond the step that will emit the EOS, so the stop has to live on the device: the
+ * step that emits one of these ids marks the sequence finished, and every later enqueued step of that sequence is a no-op
+ * for all persistent state — it draws nothing from the rng, leaves masks / keep set / vote / logits / tokens / KV length as
+ * the EOS step left them — until the next dd_lm_prefill / dd_lm_truncate.  eos_ids_host: up to 8 ids (host memory);
+ * n = 0 clears the list (never stop).  The list survives prefills.  dd_lm_get re-reads the committed length, so host-side
+ * bookkeeping of enqueued steps never leaks into results. */
+int dd_lm_set_eos(dd_lm* h, const int32_t* eos_ids_host, int n, void* stream);
+
 /* Force the next decode step's input token (default: the last emitted token). */
 int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream);
 
