@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libdropdec.so")
 SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_engine.hip", "dd_vision.hip", "dd_persist.hip"]
-HEADERS = ["dd_common.h", "dd_lm_kernels.h", os.path.join(ROOT, "include", "dropdec.h")]
+HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_gemv_slices.h", os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
 
 

@@ -74,6 +74,8 @@ struct dd_lm {
   size_t lsk = 0, lsv = 0;
   // decode scratch
   float *xa, *qbuf, *knew, *vnew, *ssq_a, *ssq_b, *part_o, *part_ml, *hidden;
+  float* gemv_part = nullptr;   // partial sums of the slice-resident 16 / 32-row GEMVs (dd_gemv_slices.h)
+  size_t gemv_part_floats = 0;
   u32x4_t *xop_d, *xop_q, *xop_ff;
   float *base_logits, *member_logits, *last_logits, *last_hidden;
   int32_t *argmax_base, *member_tok, *member_vote, *tokens;
@@ -236,6 +238,13 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->part_o, (size_t)h->Hkv * max_splits * 32 * G * 128);
   DA(h->part_ml, (size_t)h->Hkv * max_splits * 32 * G * 2);
   DA(h->hidden, (size_t)MAX_MEMBERS * d);
+  {
+    // slice partials: 8 slices x tiles x 4 planes x 128 floats for qkv / o / down, 4 slice pairs for gate/up
+    size_t t8 = (size_t)h->qkv_tiles > (size_t)d / 16 ? (size_t)h->qkv_tiles : (size_t)d / 16;
+    size_t nfl = 8 * t8 * 4 * 128, gu = (size_t)4 * (2 * dff / 16) * 4 * 128;
+    h->gemv_part_floats = h->fp8 ? 0 : (nfl > gu ? nfl : gu);
+    if (h->gemv_part_floats) DA(h->gemv_part, h->gemv_part_floats + 64);   // + rstd of the 32 operand rows
+  }
   DA(h->xop_d, (size_t)h->S_d * 64 * 4);     // four operand planes (8 rows each)
   DA(h->xop_q, (size_t)h->S_q * 64 * 4);
   DA(h->xop_ff, (size_t)h->S_ff * 64 * 4);
@@ -774,6 +783,7 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
     a.nb = cap == 8 ? n : 8;
     if (cap == 8) return ddk_gemv(epi, a, st);
     a.n_groups = ng;
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     return ddk_gemv_groups(epi, a, st);
   };
   RC(ddk_chunk_positions(h->chunk_states, h->state, n, st));
@@ -932,6 +942,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
   auto gemv = [&](int epi, GemvArgs& a) -> int {
     if (!wide) return ddk_gemv(epi, a, st);
     a.n_groups = lane_groups, a.nb = 8;
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     return ddk_gemv_groups(epi, a, st);
   };
   if (lanes) {
@@ -1132,24 +1143,28 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
       if (q->T_host > t.max_T) t.max_T = q->T_host;
     }
     a.knew = a.knew_g[0], a.vnew = a.vnew_g[0], t.knew = t.knew_g[0], t.vnew = t.vnew_g[0];
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_QKV, a, st));
     RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = ng;
     a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = ng;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     ssq_n = d / 16;
   }
@@ -1163,7 +1178,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     for (int m = 0; m < 8; ++m) a.state_rows[8 * g + m] = qs[g]->state;
   }
   a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
-  RC(ddk_gemv_groups(EPI_STORE, a, st));
+  a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
+    RC(ddk_gemv_groups(EPI_STORE, a, st));
   return DD_OK;
 }
 
@@ -1685,6 +1701,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
   auto gemv = [&](int epi, GemvArgs& a) -> int {
     a.S_next = epi == EPI_SILU ? h->S_ff : h->S_d;
     a.n_groups = ngroups;
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     return wide ? ddk_gemv_groups(epi, a, st) : ddk_gemv(epi, a, st);
   };
   const int d = h->d, dff = h->dff;
@@ -1729,12 +1746,13 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 4) || (key >= 8 && key <= 12), "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4) || (key >= 8 && key <= 13), "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 10) ddk_set_attn_split(value);
   else if (key == 11) dd_engine_set_extend_rows(value);
   else if (key == 12) ddk_set_prefill_mfma(value);
   else if (key == 9) dd_engine_set_pairs(value);
+  else if (key == 13) ddk_set_gemv_slices(value);
   else ddk_set_tuning(key, value);
   return DD_OK;
 }

@@ -1,0 +1,267 @@
+// Slice-resident decode GEMV for 16 / 32 rows (NG = 2 / 4 operand planes of 8 rows each), bf16 weights.
+//
+// Why: with several operand planes the K-split-over-waves kernel (k_gemv_groups) reads NG KiB of packed operand from L2
+// for every KiB of weights it streams from HBM, once per workgroup — 2-4x the weight bytes per launch — and the CU's
+// L2 -> L1 path, not HBM, sets its time (measured with tools/gemv_lab: dropping those reads takes the 32-row gate/up
+// GEMV from 45 to 34 us, o_proj from 16 to 8, down from 42 to 18).
+//
+// How: K is cut into the SAME 8 interleaved slices k_gemv uses (slice q = k-steps q, q+8, ...; k_gemv's wave q).  A
+// workgroup takes ONE slice of all NG operand planes into LDS (read once from L2) and its 8 waves each own whole weight
+// tiles over that slice: a wave streams its tiles' k-steps straight to registers through a ring of U requests and takes the
+// B operands from LDS (ds_read_b128, conflict-free, lgkmcnt — so the weight queue depth is not tied to operand registers).
+// The slice's accumulators are the ones wave q of k_gemv would hold for that tile: same k order, same MFMA chain.  They
+// are written out as partial sums (hi + lo columns folded: D[m] + D[m+8], the first add of k_gemv's reduction) and a
+// finishing kernel (k_gemv_finish in dd_lm_kernels.hip) adds the slices in k_gemv's order — pairs of waves first:
+// y = sum_p ((hi+lo)(2p) + (hi+lo)(2p+1)) — and runs the epilogue: the arithmetic of k_gemv / k_gemv_groups bit for bit.
+// CH = 2: a workgroup holds a PAIR of slices (2q, 2q+1) and adds the pair itself — half the partial-sum traffic, one
+// workgroup per CU (128 KiB of operands at four planes).
+//
+// Long K (slice larger than the LDS chunk): the slice is staged in chunks of CS k-steps; the next chunk's operand pieces
+// are requested into registers at the START of the current chunk (they return ahead of the weight requests issued after
+// them) and committed to LDS between two barriers, so the weight ring never drains.  Then every wave owns exactly one
+// tile group (its accumulators live across the chunks).
+#pragma once
+#include "dd_common.h"
+
+struct SliceArgs {
+  const u32x4_t* W;     // packed weight tiles [n_tiles][S][64]
+  const u32x4_t* xop;   // NG operand planes [NG][S][64]
+  float* part;          // partial sums [8 / CH][n_tiles][NG][128]
+  int S;                // K / 32
+  int n_groups;         // tile groups of TW tiles
+  int G;                // workgroups per slice (grid = 8 * G)
+  // folded RMSNorm of the operand rows: workgroup 0 assembles rstd(row) from the producer's sum-of-squares slots while the
+  // others stream, so that the finishing kernel starts with one 4-byte load instead of a reduction (ssq_in null: no norm)
+  const float* ssq_in;
+  int ssq_n, ssq_ld;
+  float inv_k, eps;
+  float* rstd_out;      // [8 * NG]
+};
+
+// rstd(row) = 1 / sqrt(mean(x^2) + eps) from per-workgroup partial sums of squares; wave w of the calling workgroup
+// (8 waves) assembles rows w, w + 8, ...  ONE definition for every kernel that needs it: the sum order is part of the result.
+template <int NG>
+__device__ __forceinline__ void dd_rows_rstd(const float* ssq_in, int ssq_n, int ssq_ld, float inv_k, float eps, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4_t sv[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    sv[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (4 * lane < ssq_n) sv[g] = *(const f32x4_t*)(ssq_in + (size_t)(wave + 8 * g) * ssq_ld + 4 * lane);
+  }
+  const int i0 = 4 * lane;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float v = 0.f;
+    if (i0 < ssq_n) v += sv[g].x;
+    if (i0 + 1 < ssq_n) v += sv[g].y;
+    if (i0 + 2 < ssq_n) v += sv[g].z;
+    if (i0 + 3 < ssq_n) v += sv[g].w;
+    for (int i = lane + 256; i < ssq_n; i += 64) v += ssq_in[(size_t)(wave + 8 * g) * ssq_ld + i];
+    v = dd_wave_sum(v);
+    if (lane == 0) out[wave + 8 * g] = 1.0f / sqrtf(v * inv_k + eps);
+  }
+}
+
+// 128 floats per (slice, tile, plane): element (n = output row of the tile, m = row of the plane) at
+// ((n >> 2) * 8 + m) * 4 + (n & 3)
+__device__ __forceinline__ int dd_part_index(int n, int m) { return (((n >> 2) * 8 + m) << 2) + (n & 3); }
+
+// grid = (8 / CH) * G workgroups of 512 threads; dynamic LDS = CH * min(SPW, CS) * NG KiB
+template <int TW, int NG, int U, int SPW, int CS, int CH = 1>
+__global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
+  constexpr int NCH = (SPW + CS - 1) / CS;             // LDS chunks per slice
+  constexpr int PW = (CH * CS * NG + 7) / 8;           // operand pieces (1 KiB) per wave and chunk
+  static_assert(SPW % U == 0 || NCH > 1 || SPW < U, "ring depth must divide the slice");
+  static_assert(CH == 1 || NCH == 1, "slice pairs only when a whole slice fits the LDS chunk");
+  extern __shared__ __align__(16) u32x4_t xs[];        // [CH][CS][NG][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NQ = 8 / CH;                           // slice sets
+  const int qs = blockIdx.x % NQ, j = blockIdx.x / NQ;
+  const int q = qs * CH;                               // first slice of this workgroup
+  const size_t xplane = (size_t)a.S * 64;
+  const int n_tiles = a.n_groups * TW;
+  if (blockIdx.x == 0 && a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+
+  u32x4_t xv[PW];
+  auto stage_issue = [&](int c0, int n) {              // chunk = slice steps c0 .. c0+n-1: piece p = (slice, step, plane)
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      int p = wave + 8 * i;
+      int pc = p < CH * n * NG ? p : 0;
+      int ch = pc / (n * NG), r = pc % (n * NG);
+      xv[i] = a.xop[(size_t)(q + ch + 8 * (c0 + r / NG)) * 64 + (r % NG) * xplane + lane];
+    }
+  };
+  auto stage_commit = [&](int n) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      int p = wave + 8 * i;
+      if (p < CH * n * NG) xs[(size_t)p * 64 + lane] = xv[i];
+    }
+  };
+  auto fold = [&](f32x4_t v) -> f32x4_t {              // D[n][m] + D[n][m + 8]: hi + lo column of row m (lanes c < 8 of 16)
+    v.x += __shfl_down(v.x, 8);
+    v.y += __shfl_down(v.y, 8);
+    v.z += __shfl_down(v.z, 8);
+    v.w += __shfl_down(v.w, 8);
+    return v;
+  };
+  auto store_partials = [&](int g, f32x4_t (&sum)[TW][NG]) {     // sum: already folded
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int h = 0; h < NG; ++h)
+        if ((lane & 8) == 0) {
+          const int l32 = (lane >> 4) * 8 + (lane & 7);
+          *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + (size_t)g * TW + t) * NG + h) << 7) + l32 * 4] = sum[t][h];
+        }
+  };
+  auto mfma = [](u32x4_t w, u32x4_t b, f32x4_t c) -> f32x4_t {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  };
+  const size_t wstep = 8 * 64;                         // one slice step = 8 k-steps of the tile row
+
+  if constexpr (NCH == 1) {
+    // ---- whole slice (or slice pair) resident: a wave walks its tile groups g = j + G * (wave + 8 i); per group it streams
+    // CH * SPW steps (slice q, then slice q + 1); the request ring runs on across slice and group boundaries
+    constexpr int NS = CH * SPW;                       // steps per group
+    constexpr int UU = SPW < U ? SPW : U;
+    constexpr int NB = NS / UU;
+    static_assert(SPW % UU == 0, "ring depth must divide the slice");
+    int g = j + a.G * wave;
+    const bool any = g < a.n_groups;
+    // weight address of step s (0 .. NS-1) of a group: slice q + s / SPW, slice step s % SPW
+    auto woff = [&](int s) -> size_t { return (size_t)(s / SPW) * 64 + (size_t)(s % SPW) * wstep; };
+    u32x4_t w[TW][UU];
+    if (any) {
+#pragma unroll
+      for (int u = 0; u < UU; ++u)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+          w[t][u] = __builtin_nontemporal_load(a.W + ((size_t)(g * TW + t) * a.S + q) * 64 + lane + woff(u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_issue(0, SPW);
+    stage_commit(SPW);
+    __syncthreads();
+    if (!any) return;
+    while (true) {
+      const int gn = g + a.G * 8;
+      const bool has_next = gn < a.n_groups;
+      const u32x4_t* wp[TW];
+      const u32x4_t* wn[TW];
+#pragma unroll
+      for (int t = 0; t < TW; ++t) {
+        wp[t] = a.W + ((size_t)(g * TW + t) * a.S + q) * 64 + lane;
+        wn[t] = a.W + ((size_t)((has_next ? gn : g) * TW + t) * a.S + q) * 64 + lane;
+      }
+      f32x4_t acc[TW][NG], sum[TW][NG];
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int h = 0; h < NG; ++h) acc[t][h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      auto block = [&](int blk, bool request_next_group) {
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+          const int s = blk * UU + u;
+          u32x4_t b[NG];
+#pragma unroll
+          for (int h = 0; h < NG; ++h) b[h] = xs[(size_t)(s * NG + h) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < TW; ++t) {
+#pragma unroll
+            for (int h = 0; h < NG; ++h) acc[t][h] = mfma(w[t][u], b[h], acc[t][h]);
+            if (blk + 1 < NB) w[t][u] = __builtin_nontemporal_load(wp[t] + woff(s + UU));
+            else if (request_next_group) w[t][u] = __builtin_nontemporal_load(wn[t] + woff(u));
+          }
+          __builtin_amdgcn_sched_barrier(0);           // keep consume -> re-request order
+        }
+        if ((blk + 1) * UU % SPW == 0) {               // a slice's chain is complete: fold it into the group's sum
+          const int ch = (blk + 1) * UU / SPW - 1;
+#pragma unroll
+          for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int h = 0; h < NG; ++h) {
+              f32x4_t f = fold(acc[t][h]);
+              if (ch == 0) sum[t][h] = f;
+              else sum[t][h] = sum[t][h] + f;          // (hi+lo)(2p) + (hi+lo)(2p+1)
+              acc[t][h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+      };
+      if (has_next) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) block(blk, true);
+      } else {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) block(blk, false);
+      }
+      store_partials(g, sum);
+      if (!has_next) break;
+      g = gn;
+    }
+  } else {
+    // ---- chunked slice: one tile group per wave, accumulators live across the chunks
+    static_assert(CS % U == 0, "chunk must be a whole number of ring blocks");
+    const int g = j + a.G * wave;
+    const bool live = g < a.n_groups;
+    const int gg = live ? g : 0;
+    const u32x4_t* wp[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) wp[t] = a.W + ((size_t)(gg * TW + t) * a.S + q) * 64 + lane;
+    stage_issue(0, CS);
+    u32x4_t w[TW][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TW; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)u * wstep);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_commit(CS);
+    __syncthreads();
+    f32x4_t acc[TW][NG];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int h = 0; h < NG; ++h) acc[t][h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int c0 = k * CS;
+      const int n = (SPW - c0) < CS ? (SPW - c0) : CS;               // steps of this chunk (compile-time after unrolling)
+      const int n_next = (SPW - c0 - CS) < CS ? (SPW - c0 - CS) : CS;
+      if (k + 1 < NCH) stage_issue(c0 + CS, n_next);                  // requested ahead of the ring's later requests
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cc = 0; cc < CS; ++cc) {
+        if (cc < n) {
+          const int c = c0 + cc, u = c % U;
+          u32x4_t b[NG];
+#pragma unroll
+          for (int h = 0; h < NG; ++h) b[h] = xs[(size_t)(cc * NG + h) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < TW; ++t) {
+#pragma unroll
+            for (int h = 0; h < NG; ++h) acc[t][h] = mfma(w[t][u], b[h], acc[t][h]);
+            if (c + U < SPW) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(c + U) * wstep);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (k + 1 < NCH) {
+        __syncthreads();                 // every wave has read this chunk
+        stage_commit(n_next);
+        __syncthreads();
+      }
+    }
+    if (live) {
+      f32x4_t sum[TW][NG];
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int h = 0; h < NG; ++h) sum[t][h] = fold(acc[t][h]);
+      store_partials(g, sum);
+    }
+  }
+}

@@ -103,11 +103,14 @@ struct GemvArgs {
   float* knew_g[4];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
   float* vnew_g[4];
   int S_next;           // K / 32 of the GEMV that consumes xop_next
+  float* part;          // scratch for the slice-resident path (dd_gemv_slices.h): partial sums, or nullptr (then k_gemv_groups runs)
+  size_t part_floats;   // capacity; 64 more floats behind it hold rstd of the operand rows
   int diag;             // timing diagnostics only (dd_set_tuning key 3): 2 = no rstd prologue, 4 = no epilogue, 8 = no epilogue prefetch
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
 int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2 or 4) groups of up to 8 rows (bf16 weights)
 void ddk_set_tuning(int key, int value);
+void ddk_set_gemv_slices(int on);
 void ddk_set_attn_split(int v);
 void ddk_set_prefill_mfma(int on);
 int ddk_prefill_mfma_enabled();

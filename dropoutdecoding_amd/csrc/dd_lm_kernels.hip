@@ -8,6 +8,7 @@
 //   - prefill GEMM: the same packed weights as the MFMA B operand, activations as hi/lo bf16 planes.
 // Reference anchors: the third-party LM forward the reference calls at models/llava.py:294-303,350-359.
 #include "dd_lm_kernels.h"
+#include "dd_gemv_slices.h"
 
 #define ROPE_HALF 64
 #define HEAD_DIM 128
@@ -209,6 +210,11 @@ __device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y) {
 // ===============================================================================================
 #define GEMV_WAVES 8
 #define GEMV_THREADS (GEMV_WAVES * 64)
+#define RC_(...)                     \
+  do {                               \
+    int rc__ = (__VA_ARGS__);        \
+    if (rc__ != DD_OK) return rc__;  \
+  } while (0)
 
 // U   = weight tiles requested per wave before the first MFMA consumes one (loads in flight)
 // NT  = non-temporal weight loads (read-once stream, keeps L2/MALL for the x operand and the KV cache)
@@ -421,13 +427,15 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     if (y == 1234.5f) a.out[0] = y;
     return;
   }
+  // fixed order: (hi + lo) per wave, waves added in pairs, pairs in sequence — the order the slice-resident kernels
+  // reproduce from partial sums (dd_gemv_slices.h): y = sum_p ((hi+lo)(2p) + (hi+lo)(2p+1))
   auto tile_sum = [&](int tt, int n, int m) -> float {
     float y = 0.f;
     int o = ((n >> 2) * 16 + m) * 4 + (n & 3);
 #pragma unroll
-    for (int w = 0; w < GEMV_WAVES; ++w) {
+    for (int w = 0; w < GEMV_WAVES; w += 2) {
       const float* r = &red[(tt * GEMV_WAVES + w) * 256];
-      y += r[o] + r[o + 32];
+      y += (r[o] + r[o + 32]) + (r[256 + o] + r[256 + o + 32]);
     }
     if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
     return y;
@@ -550,6 +558,121 @@ __device__ __forceinline__ void xop_store16(u32x4_t* xop, int k, int m, float y,
   xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y);   // plane = group of the row
 }
 
+// What the epilogue needs from memory, requested before the weight stream (k_gemv_groups) or before the partial sums
+// (k_gemv_finish): residual + next norm weight (EPI_RESID), rotary cos/sin (EPI_QKV), the finished flag (EPI_STORE).
+// Epilogue thread t < 128 * NG: group t >> 7, row m = 8 * group + (t & 7), column n = (t & 127) >> 3.
+template <int TILES>
+struct GroupsPre {
+  float pre0, pre1;
+  float rope_c[TILES], rope_s[TILES];
+};
+template <int EPI, int TILES, int NG>
+__device__ __forceinline__ void groups_prefetch(const GemvArgs& a, int tile0, GroupsPre<TILES>& p) {
+  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
+  const bool erow = et < 128 * NG && ml < a.nb;
+  p.pre0 = p.pre1 = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < TILES; ++tt) p.rope_c[tt] = p.rope_s[tt] = 0.f;
+  if (erow) {
+    if (EPI == EPI_RESID) {
+      p.pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
+      p.pre1 = a.normw_next[tile0 * 16 + en];
+    } else if (EPI == EPI_QKV) {
+      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+      const int pos = sp->pos;
+#pragma unroll
+      for (int tt = 0; tt < TILES; ++tt) {     // one (cos, sin) pair per tile of the workgroup (q_tiles, k_tiles are even)
+        const int nt = tile0 + tt;
+        if (nt < a.q_tiles + a.k_tiles) {
+          int ht = nt < a.q_tiles ? nt : nt - a.q_tiles;
+          int f = (ht & 7) * 8 + (en & 7);
+          p.rope_c[tt] = a.rope_cos[(size_t)pos * ROPE_HALF + f];
+          p.rope_s[tt] = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+        }
+      }
+    } else if (EPI == EPI_STORE) {
+      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+      if (sp && sp->done) p.pre0 = 1.f;    // finished sequence: its logits stay as the EOS step left them
+    }
+  }
+}
+// folded RMSNorm: wave w assembles rstd of rows w, w + 8, ... from the producer's sum-of-squares slots
+template <int NG>
+__device__ __forceinline__ void groups_rstd(const GemvArgs& a, float* rstd_sh) {
+  if (a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, rstd_sh);
+}
+// everything after the reduction; tile_sum(tt, n) = this thread's (group, row) sum for output row n of tile tt.
+// wg = index of the workgroup's tile set (k_gemv_groups: blockIdx.x); rstd_sh must be visible (barrier before the call).
+template <int EPI, int TILES, int NG, typename TS>
+__device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const GroupsPre<TILES>& p, const float* rstd_sh,
+                                                float* ssq_sh, TS tile_sum) {
+  const int tile0 = wg * TILES;
+  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
+  const bool erow = et < 128 * NG && ml < a.nb;
+  if (EPI == EPI_STORE) {
+    if (erow) {
+      float y = tile_sum(0, en);
+      if (a.ssq_in) y *= rstd_sh[em];
+      int col = tile0 * 16 + en;
+      float* row = a.out_g[eg] ? a.out_g[eg] + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
+      if (col < a.n_valid && p.pre0 == 0.f) row[col] = y;
+    }
+  } else if (EPI == EPI_RESID) {
+    float sq = 0.f;
+    if (erow) {
+      float y = tile_sum(0, en);
+      int col = tile0 * 16 + en;
+      float xn = p.pre0 + y;
+      a.out[(size_t)em * a.ldo + col] = xn;
+      xop_store16(a.xop_next, col, em, p.pre1 * xn, a.S_next);
+      sq = xn * xn;
+    }
+    if (et < 128 * NG) ssq_sh[en * (8 * NG) + em] = sq;
+    __syncthreads();
+    if (et < 8 * NG) {
+      float v = 0.f;
+      for (int i = 0; i < 16; ++i) v += ssq_sh[i * (8 * NG) + et];
+      a.ssq_out[(size_t)et * a.ssq_ld + wg] = v;
+    }
+  } else if (EPI == EPI_SILU) {
+    if (erow) {
+      float g = tile_sum(0, en), u = tile_sum(TILES - 1, en);
+      if (a.ssq_in) {
+        g *= rstd_sh[em];
+        u *= rstd_sh[em];
+      }
+      float act = g / (1.0f + expf(-g));  // silu
+      xop_store16(a.xop_next, wg * 16 + en, em, act * u, a.S_next);
+    }
+  } else {  // EPI_QKV
+    if (erow) {
+      float* kn = a.knew_g[eg] ? a.knew_g[eg] + (size_t)ml * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
+      float* vn = a.vnew_g[eg] ? a.vnew_g[eg] + (size_t)ml * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+#pragma unroll
+      for (int tt = 0; tt < TILES; ++tt) {
+        float y = tile_sum(tt, en);
+        if (a.ssq_in) y *= rstd_sh[em];
+        const int nt = tile0 + tt;
+        if (nt < a.q_tiles + a.k_tiles) {
+          float yp = tile_sum(tt, en ^ 8);
+          if (a.ssq_in) yp *= rstd_sh[em];
+          bool is_q = nt < a.q_tiles;
+          int ht = is_q ? nt : nt - a.q_tiles;
+          int head = ht >> 3, f = (ht & 7) * 8 + (en & 7);
+          float c = p.rope_c[tt], sn = p.rope_s[tt];
+          float o = (en < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
+          int i = (en < 8) ? f : ROPE_HALF + f;
+          if (is_q) a.qbuf[(size_t)em * a.q_dim + head * HEAD_DIM + i] = o;
+          else kn[head * HEAD_DIM + i] = o;
+        } else {
+          int col = (nt - a.q_tiles - a.k_tiles) * 16 + en;
+          vn[col] = y;
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, int TILES, int NG, int U = 4, int FP8 = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
   extern __shared__ float gg_sh[];
@@ -569,57 +692,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
   }
   const u32x4_t* xp = a.xop + (size_t)wave * 64 + lane;      // plane g: + g * S * 64
   const size_t xplane = (size_t)S * 64;
-
-  // folded RMSNorm: wave w assembles rows w, w + 8, ...
-  f32x4_t sv[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    sv[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (a.ssq_in && 4 * lane < a.ssq_n) sv[g] = *(const f32x4_t*)(a.ssq_in + (size_t)(wave + 8 * g) * a.ssq_ld + 4 * lane);
-  }
-  // epilogue thread t < 128 * NG: group t >> 7, row m = 8 * group + (t & 7), column n = (t & 127) >> 3
-  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
-  const bool erow = et < 128 * NG && ml < a.nb;
-  float pre0 = 0.f, pre1 = 0.f;
-  float rope_c[TILES], rope_s[TILES];
-#pragma unroll
-  for (int tt = 0; tt < TILES; ++tt) rope_c[tt] = rope_s[tt] = 0.f;
-  if (erow) {
-    if (EPI == EPI_RESID) {
-      pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
-      pre1 = a.normw_next[tile0 * 16 + en];
-    } else if (EPI == EPI_QKV) {
-      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
-      const int pos = sp->pos;
-#pragma unroll
-      for (int tt = 0; tt < TILES; ++tt) {     // one (cos, sin) pair per tile of the workgroup (q_tiles, k_tiles are even)
-        const int nt = tile0 + tt;
-        if (nt < a.q_tiles + a.k_tiles) {
-          int ht = nt < a.q_tiles ? nt : nt - a.q_tiles;
-          int f = (ht & 7) * 8 + (en & 7);
-          rope_c[tt] = a.rope_cos[(size_t)pos * ROPE_HALF + f];
-          rope_s[tt] = a.rope_sin[(size_t)pos * ROPE_HALF + f];
-        }
-      }
-    } else if (EPI == EPI_STORE) {
-      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
-      if (sp && sp->done) pre0 = 1.f;    // finished sequence: its logits stay as the EOS step left them
-    }
-  }
-  if (a.ssq_in) {
-    const int i0 = 4 * lane;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      float v = 0.f;
-      if (i0 < a.ssq_n) v += sv[g].x;
-      if (i0 + 1 < a.ssq_n) v += sv[g].y;
-      if (i0 + 2 < a.ssq_n) v += sv[g].z;
-      if (i0 + 3 < a.ssq_n) v += sv[g].w;
-      for (int i = lane + 256; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)(wave + 8 * g) * a.ssq_ld + i];
-      v = dd_wave_sum(v);
-      if (lane == 0) rstd_sh[wave + 8 * g] = 1.0f / sqrtf(v * a.inv_k + a.eps);
-    }
-  }
+  GroupsPre<TILES> pre;
+  groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
+  groups_rstd<NG>(a, rstd_sh);
 
   if constexpr (FP8) {
     // fp8 weights: one 1 KiB load = 64 k of a tile row = two MFMA k-steps, expanded exactly to bf16 in registers ONCE and
@@ -713,80 +788,59 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
     for (int g = 0; g < NG; ++g) *(f32x4_t*)&red[((t * NG + g) * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t][g];
   __syncthreads();
 
-  auto tile_sum = [&](int tt, int n) -> float {
+  const int eg = threadIdx.x >> 7, ml = threadIdx.x & 7;
+  auto tile_sum = [&](int tt, int n) -> float {     // the order of k_gemv's tile_sum: (hi + lo) per wave, waves in pairs
     float y = 0.f;
     int o = ((n >> 2) * 16 + ml) * 4 + (n & 3);
 #pragma unroll
-    for (int w = 0; w < GEMV_WAVES; ++w) {
+    for (int w = 0; w < GEMV_WAVES; w += 2) {
       const float* r = &red[((tt * NG + eg) * GEMV_WAVES + w) * 256];
-      y += r[o] + r[o + 32];
+      y += (r[o] + r[o + 32]) + (r[256 + o] + r[256 + o + 32]);
     }
     if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
     return y;
   };
+  groups_epilogue<EPI, TILES, NG>(a, blockIdx.x, pre, rstd_sh, ssq_sh, tile_sum);
+}
 
-  if (EPI == EPI_STORE) {
-    if (erow) {
-      float y = tile_sum(0, en);
-      if (a.ssq_in) y *= rstd_sh[em];
-      int col = tile0 * 16 + en;
-      float* row = a.out_g[eg] ? a.out_g[eg] + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
-      if (col < a.n_valid && pre0 == 0.f) row[col] = y;
-    }
-  } else if (EPI == EPI_RESID) {
-    float sq = 0.f;
-    if (erow) {
-      float y = tile_sum(0, en);
-      int col = tile0 * 16 + en;
-      float xn = pre0 + y;
-      a.out[(size_t)em * a.ldo + col] = xn;
-      xop_store16(a.xop_next, col, em, pre1 * xn, a.S_next);
-      sq = xn * xn;
-    }
-    if (et < 128 * NG) ssq_sh[en * (8 * NG) + em] = sq;
-    __syncthreads();
-    if (et < 8 * NG) {
-      float v = 0.f;
-      for (int i = 0; i < 16; ++i) v += ssq_sh[i * (8 * NG) + et];
-      a.ssq_out[(size_t)et * a.ssq_ld + blockIdx.x] = v;
-    }
-  } else if (EPI == EPI_SILU) {
-    if (erow) {
-      float g = tile_sum(0, en), u = tile_sum(TILES - 1, en);
-      if (a.ssq_in) {
-        g *= rstd_sh[em];
-        u *= rstd_sh[em];
-      }
-      float act = g / (1.0f + expf(-g));  // silu
-      xop_store16(a.xop_next, blockIdx.x * 16 + en, em, act * u, a.S_next);
-    }
-  } else {  // EPI_QKV
-    if (erow) {
-      float* kn = a.knew_g[eg] ? a.knew_g[eg] + (size_t)ml * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
-      float* vn = a.vnew_g[eg] ? a.vnew_g[eg] + (size_t)ml * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+// Second half of the slice-resident GEMV (dd_gemv_slices.h): adds the slices' partial sums in k_gemv's order and runs
+// k_gemv_groups' epilogue for ONE tile set per workgroup (128 * NG threads).  Everything it needs from memory — the
+// partial sums, rstd (assembled by the first kernel), residual / norm weight / rotary terms — is requested up front.
+// part: [NP][n_tiles_total][NG][128], NP = 8 (single slices) or 4 (slice pairs already added by the producer).
+template <int EPI, int TILES, int NG, int NP>
+__global__ __launch_bounds__(128 * NG) void k_gemv_finish(GemvArgs a, const float* __restrict__ part, const float* __restrict__ rstd_g,
+                                                          int n_sets) {
+  __shared__ float ssq_sh[16 * 8 * NG];
+  __shared__ float y_sh[EPI == EPI_QKV ? TILES * NG * 128 : 1];
+  const int wg = blockIdx.x, tile0 = wg * TILES;
+  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, en = (et & 127) >> 3;
+  const size_t ps = ((size_t)n_sets * TILES * NG) << 7;
+  float v[TILES][NP];
 #pragma unroll
-      for (int tt = 0; tt < TILES; ++tt) {
-        float y = tile_sum(tt, en);
-        if (a.ssq_in) y *= rstd_sh[em];
-        const int nt = tile0 + tt;
-        if (nt < a.q_tiles + a.k_tiles) {
-          float yp = tile_sum(tt, en ^ 8);
-          if (a.ssq_in) yp *= rstd_sh[em];
-          bool is_q = nt < a.q_tiles;
-          int ht = is_q ? nt : nt - a.q_tiles;
-          int head = ht >> 3, f = (ht & 7) * 8 + (en & 7);
-          float c = rope_c[tt], sn = rope_s[tt];
-          float o = (en < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
-          int i = (en < 8) ? f : ROPE_HALF + f;
-          if (is_q) a.qbuf[(size_t)em * a.q_dim + head * HEAD_DIM + i] = o;
-          else kn[head * HEAD_DIM + i] = o;
-        } else {
-          int col = (nt - a.q_tiles - a.k_tiles) * 16 + en;
-          vn[col] = y;
-        }
-      }
-    }
+  for (int tt = 0; tt < TILES; ++tt) {
+    const float* p0 = part + (((size_t)(tile0 + tt) * NG + eg) << 7) + dd_part_index(en, ml);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) v[tt][q] = p0[(size_t)q * ps];
   }
+  GroupsPre<TILES> pre;
+  groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
+  float y_own[TILES];
+#pragma unroll
+  for (int tt = 0; tt < TILES; ++tt) {
+    float y = 0.f;
+    if (NP == 8) {
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) y += v[tt][q] + v[tt][q + 1];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) y += v[tt][q];
+    }
+    y_own[tt] = y;
+    if (EPI == EPI_QKV) y_sh[(tt * NG + eg) * 128 + en * 8 + ml] = y;    // the rotary partner (n ^ 8) reads it from here
+  }
+  if (EPI == EPI_QKV) __syncthreads();
+  auto tile_sum = [&](int tt, int n) -> float { return (EPI == EPI_QKV && n != en) ? y_sh[(tt * NG + eg) * 128 + n * 8 + ml] : y_own[tt]; };
+  groups_epilogue<EPI, TILES, NG>(a, wg, pre, rstd_g, ssq_sh, tile_sum);
 }
 
 template <int EPI, int TILES, int NG, int FP8>
@@ -809,11 +863,76 @@ static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
   return a.fp8 ? launch_gemv_groups_f<EPI, TILES, NG, 1>(a, st) : launch_gemv_groups_f<EPI, TILES, NG, 0>(a, st);
 }
 
+// ---- slice-resident path (dd_gemv_slices.h + k_gemv_finish): bf16 weights, the per-layer matrices at the shapes the 7B
+// families have (K = 4096: 16 k-steps per slice; K = 11008 / 14336: 43 / 56, staged in chunks of 16).  Anything else runs
+// through k_gemv_groups; both produce the same bits.
+static int g_gemv_slices = 1;     // dd_set_tuning key 13
+void ddk_set_gemv_slices(int on) { g_gemv_slices = on; }
+#define SLICES_UNSUPPORTED 1
+
+template <int TW, int NG, int U, int SPW, int CS, int CH>
+static int launch_slices_k(const SliceArgs& sa, hipStream_t st) {
+  constexpr size_t smem = (size_t)CH * (SPW < CS ? SPW : CS) * NG * 1024;
+  static bool attr = false;
+  if (!attr) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  k_gemv_slices<TW, NG, U, SPW, CS, CH><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  return DD_OK;
+}
+template <int EPI, int TILES, int NG, int NP>
+static void launch_finish(const GemvArgs& a, int n_sets, hipStream_t st) {
+  k_gemv_finish<EPI, TILES, NG, NP><<<n_sets, 128 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
+}
+template <int NG>
+static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
+  const int spw = a.S / GEMV_WAVES;
+  const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;      // 16-row weight tiles
+  if (epi == EPI_STORE || !(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
+  SliceArgs sa;
+  sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S;
+  sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
+  sa.rstd_out = a.part + a.part_floats;                              // 32 floats behind the partial sums
+  const size_t need8 = (size_t)8 * nt * NG * 128, need4 = need8 / 2;
+  if (epi == EPI_QKV) {
+    if (spw != 16 || (nt & 1) || a.part_floats < need8) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt / 2;
+    sa.G = sa.n_groups >= 256 ? (sa.n_groups + 15) / 16 : (sa.n_groups + 7) / 8;     // two tile pairs per wave when there are enough
+    RC_(launch_slices_k<2, NG, 8, 16, 16, 1>(sa, st));
+    launch_finish<EPI_QKV, 1, NG, 8>(a, nt, st);
+  } else if (epi == EPI_RESID) {
+    // o_proj at two planes: the wave-split kernel is as fast (10.3 vs 11.2 us measured), one launch instead of two
+    if (a.part_floats < need8 || (spw == 16 && NG == 2)) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    sa.G = (nt + 7) / 8;                                             // one tile per wave
+    if (spw == 16) RC_(launch_slices_k<1, NG, 8, 16, 16, 1>(sa, st));
+    else if (spw == 43) RC_(launch_slices_k<1, NG, 8, 43, 16, 1>(sa, st));
+    else RC_(launch_slices_k<1, NG, 8, 56, 16, 1>(sa, st));
+    launch_finish<EPI_RESID, 1, NG, 8>(a, nt, st);
+  } else {  // EPI_SILU: slice pairs, one workgroup per CU
+    if (spw != 16 || a.part_floats < need4) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    sa.G = 64;
+    RC_(launch_slices_k<1, NG, 8, 16, 16, 2>(sa, st));
+    launch_finish<EPI_SILU, 2, NG, 4>(a, a.n_tiles, st);
+  }
+  return DD_OK;
+}
+
 int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv_groups: K=%d must be a multiple of 256", a.S * 32);
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv_groups: nb=%d rows per group", a.nb);
   DD_REQUIRE(!a.fp8 || a.wscale, "gemv_groups: fp8 weights need row scales");
   DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4, "gemv_groups: %d groups (2 or 4)", a.n_groups);
+  if (g_gemv_slices && !a.fp8 && a.part) {
+    int rs = a.n_groups == 2 ? try_slices<2>(epi, a, st) : try_slices<4>(epi, a, st);
+    if (rs != SLICES_UNSUPPORTED) {
+      if (rs != DD_OK) return rs;
+      DD_CHECK_LAUNCH();
+      return DD_OK;
+    }
+  }
   int rc = DD_OK;
   const bool two = a.n_groups == 2;
   switch (epi) {
