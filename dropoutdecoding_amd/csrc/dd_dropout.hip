@@ -483,6 +483,8 @@ struct MaskParams {
   int32_t* idx;           // [K][L] or nullptr
   uint8_t* drop_bits;     // optional [ceil(K/8)][L]: bit (k&7) of plane k>>3 = member k dropped (engine layout)
   const int32_t* gate;    // optional: *gate != 0 -> the whole launch is a no-op (no draws: the rng stream stays put)
+  const uint32_t* rng_in; // optional: read the mt19937 state from here instead of rng_state and do NOT write it back (a re-run
+                          // of the draws a speculative launch already made: the stream has advanced by exactly these draws)
   float scale[64];        // f32(mprob - 0.1)   (reference llava.py:646: python double, rounded when it meets fp32)
   float q[64];            // f32(1 - mprob)     (reference instructblip.py:450)
 };
@@ -527,8 +529,9 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
     running[l] = 0;
   }
   if (P.rng_mode == DD_RNG_MT19937) {
-    for (int i = tid; i < MT_N; i += MASK_THREADS) mt[i] = P.rng_state[i];
-    if (tid == 0) idx_sh = (int)P.rng_state[MT_N];
+    const uint32_t* src = P.rng_in ? P.rng_in : P.rng_state;
+    for (int i = tid; i < MT_N; i += MASK_THREADS) mt[i] = src[i];
+    if (tid == 0) idx_sh = (int)src[MT_N];
   }
   __syncthreads();
   float lo = 0.f, hi = 0.f;
@@ -596,7 +599,7 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
           d = r < p;  // llava.py:653 (NaN p when hi == lo: nothing dropped)
         }
         uint8_t run = running[l] | (d ? 1 : 0);                      // llava.py:654-657, in place
-        if (!no_overlap && P.keep[l]) run = 0;  // llava.py:660 keep-restore
+        if (!no_overlap && P.keep && P.keep[l]) run = 0;  // llava.py:660 keep-restore (keep null: an empty keep set)
         running[l] = run;
         P.drop[(size_t)k * L + l] = run;
         dropped = run != 0;
@@ -618,7 +621,7 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
     }
     __syncthreads();
   }
-  if (P.rng_mode == DD_RNG_MT19937) {
+  if (P.rng_mode == DD_RNG_MT19937 && !P.rng_in) {
     for (int i = tid; i < MT_N; i += MASK_THREADS) P.rng_state[i] = mt[i];
     if (tid == 0) P.rng_state[MT_N] = (uint32_t)idx_sh;
   }
@@ -706,12 +709,13 @@ int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const dou
 
 int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
                          int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
-                         int32_t* idx, uint8_t* drop_bits, const int32_t* gate, hipStream_t st) {
+                         int32_t* idx, uint8_t* drop_bits, const int32_t* gate, hipStream_t st, const uint32_t* rng_in,
+                         bool empty_keep) {
   DD_REQUIRE(epi && mprobs && drop && n_drop, "dd_sample_masks: null pointer");
   DD_REQUIRE(L >= 1 && L <= MASK_MAX_L, "dd_sample_masks: L=%d out of range (1..%d)", L, MASK_MAX_L);
   DD_REQUIRE(K >= 1 && K <= 64, "dd_sample_masks: K=%d out of range (1..64)", K);
   DD_REQUIRE(mode >= 0 && mode <= 4, "dd_sample_masks: unknown mode %d", mode);
-  DD_REQUIRE(mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP || keep,
+  DD_REQUIRE(mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP || keep || empty_keep,
              "dd_sample_masks: keep flags required for mode %d", mode);
   if (mode != DD_MASK_IBLIP_QUANTILE) {
     DD_REQUIRE(rng_mode == DD_RNG_INJECTED || rng_mode == DD_RNG_MT19937, "dd_sample_masks: unknown rng mode %d", rng_mode);
@@ -723,7 +727,8 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
   MaskParams P;
   memset(&P, 0, sizeof(P));
   P.epi = epi, P.L = L, P.K = K, P.mode = mode, P.rng_mode = rng_mode, P.keep = keep, P.uniforms = uniforms;
-  P.rng_state = rng_state, P.drop = drop, P.n_drop = n_drop, P.idx = idx, P.drop_bits = drop_bits, P.gate = gate;
+  P.rng_state = rng_state, P.drop = drop, P.n_drop = n_drop, P.idx = idx, P.drop_bits = drop_bits, P.gate = gate, P.rng_in = rng_in;
+  if (empty_keep) P.keep = nullptr;
   for (int k = 0; k < K; ++k) {
     P.scale[k] = (float)(mprobs[k] - 0.1);  // double subtraction, then one rounding to fp32
     P.q[k] = (float)(1.0 - mprobs[k]);
@@ -743,7 +748,45 @@ extern "C" int dd_sample_masks(const float* epi, int L, const double* mprobs, in
                                int rng_mode, const float* uniforms, dd_rng* rng, uint8_t* drop, int32_t* n_drop,
                                int32_t* idx, void* stream_) {
   return dd_sample_masks_impl(epi, L, mprobs, K, keep, mode, rng_mode, uniforms, rng ? rng->state : nullptr, drop,
-                              n_drop, idx, nullptr, nullptr, (hipStream_t)stream_);
+                              n_drop, idx, nullptr, nullptr, (hipStream_t)stream_, nullptr, false);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Speculative single-sequence step (dd_engine.hip): the K members ran in the same sweep as the un-masked row with masks
+// sampled for an EMPTY keep set.  That is the reference's result exactly when no member dropped a token of the real keep
+// set (models/llava.py:660 would have restored it).  ok_out = 1: the speculative masks and member rows stand (also when the
+// sequence is finished: nothing to redo); 0: the members must be re-run with the real keep set.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_spec_check(const uint8_t* __restrict__ keep, const uint8_t* __restrict__ drop_bits, int L,
+                                                     int K, const int32_t* __restrict__ done, int32_t* __restrict__ ok_out,
+                                                     int keep_matters) {
+  __shared__ int hit;
+  if (threadIdx.x == 0) hit = 0;
+  __syncthreads();
+  int h = 0;
+  if (keep_matters && !*done) {
+    const unsigned mask = (1u << K) - 1u;
+    for (int l = threadIdx.x; l < L; l += 1024) h |= (keep[l] && (drop_bits[l] & mask)) ? 1 : 0;
+  }
+  if (h) hit = 1;                       // benign race: every writer stores 1
+  __syncthreads();
+  if (threadIdx.x == 0) ok_out[0] = hit ? 0 : 1;
+}
+int dd_spec_check(const uint8_t* keep, const uint8_t* drop_bits, int L, int K, const int32_t* done, int32_t* ok_out,
+                  int keep_matters, hipStream_t st) {
+  k_spec_check<<<1, 1024, 0, st>>>(keep, drop_bits, L, K, done, ok_out, keep_matters);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+__global__ void k_copy_row_gated(const float* __restrict__ src, float* __restrict__ dst, int n, const int32_t* __restrict__ gate) {
+  if (gate && *gate) return;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+int dd_copy_row_gated(const float* src, float* dst, int n, const int32_t* gate, hipStream_t st) {
+  k_copy_row_gated<<<(n + 255) / 256, 256, 0, st>>>(src, dst, n, gate);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -14,7 +14,11 @@ int dd_overlap_keep_from_argmax(const int32_t* argmax_dev, const int32_t* topk_i
                                 const int32_t* gate, hipStream_t st);
 int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, const uint8_t* keep, int mode,
                          int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
-                         int32_t* idx, uint8_t* drop_bits, const int32_t* gate, hipStream_t st);
+                         int32_t* idx, uint8_t* drop_bits, const int32_t* gate, hipStream_t st, const uint32_t* rng_in = nullptr,
+                         bool empty_keep = false);
+int dd_spec_check(const uint8_t* keep, const uint8_t* drop_bits, int L, int K, const int32_t* done, int32_t* ok_out,
+                  int keep_matters, hipStream_t st);
+int dd_copy_row_gated(const float* src, float* dst, int n, const int32_t* gate, hipStream_t st);
 int dd_argmax_rows_gated(const float* x, int R, int V, int ld, int32_t* out, const int32_t* gate, hipStream_t st);
 int dd_vote_gated(const int32_t* ids, int K, int32_t* out2, const int32_t* gate, hipStream_t st);
 uint32_t* dd_rng_state_ptr(dd_rng* r);
@@ -74,6 +78,8 @@ struct dd_lm {
   size_t lsk = 0, lsv = 0;
   // decode scratch
   float *xa, *qbuf, *knew, *vnew, *ssq_a, *ssq_b, *part_o, *part_ml, *hidden;
+  int32_t* spec_ok = nullptr;   // speculative step: 1 = the members of the combined sweep stand, 0 = re-run them (device flag)
+  uint32_t* rng_backup = nullptr;   // mt19937 state before the speculative draws (the re-run repeats exactly these)
   float* gemv_part = nullptr;   // partial sums of the slice-resident 16 / 32-row GEMVs (dd_gemv_slices.h)
   size_t gemv_part_floats = 0;
   u32x4_t *xop_d, *xop_q, *xop_ff;
@@ -238,6 +244,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->part_o, (size_t)h->Hkv * max_splits * 32 * G * 128);
   DA(h->part_ml, (size_t)h->Hkv * max_splits * 32 * G * 2);
   DA(h->hidden, (size_t)MAX_MEMBERS * d);
+  DA(h->spec_ok, 4);
+  DA(h->rng_backup, 640);
   {
     // slice partials: 8 slices x tiles x 4 planes x 128 floats for qkv / o / down, 4 slice pairs for gate/up
     size_t t8 = (size_t)h->qkv_tiles > (size_t)d / 16 ? (size_t)h->qkv_tiles : (size_t)d / 16;
@@ -934,12 +942,13 @@ extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int
 // `lanes` (group step): row m of the pass is the base row of sequence lanes[m] — its own token, position, cache, span
 // and leak bits; scratch, weights and the per-layer new K/V rows are this handle's (the first lane of the group).
 static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st,
-                    dd_lm* const* lanes = nullptr) {
+                    dd_lm* const* lanes = nullptr, const int32_t* skip_if = nullptr) {
   const int d = h->d, dff = h->dff;
   // more than 8 lanes: the base rows fill two (up to 16 lanes) or four operand planes and go through the grouped GEMV
   const bool wide = lanes && nb > 8;
   const int lane_groups = nb > 16 ? 4 : 2;
   auto gemv = [&](int epi, GemvArgs& a) -> int {
+    a.skip_if = skip_if;
     if (!wide) return ddk_gemv(epi, a, st);
     a.n_groups = lane_groups, a.nb = 8;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
@@ -951,7 +960,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     for (int m = 0; m < nb; ++m) el.state[m] = lanes[m]->state;
     RC(ddk_embed_rows_lanes(h->embed, d, el, wide ? 8 * lane_groups : 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
   } else {
-    RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+    RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, skip_if));
   }
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
@@ -974,7 +983,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     t.T = h->T_host, t.state = h->state, t.nb = nb, t.n_heads = h->H, t.n_kv = h->Hkv, t.drop_bits = bits;
     t.bit0 = bits ? h->bit0 : 0;
     t.span_start = h->span_start, t.span_len = h->L, t.part_o = h->part_o, t.part_ml = h->part_ml;
-    t.knew = knew, t.vnew = vnew, t.xop_out = h->xop_q;
+    t.knew = knew, t.vnew = vnew, t.xop_out = h->xop_q, t.skip_if = skip_if;
     if (lanes) {
       // one single-query attention per lane over its own cache, 16 rows per launch
       for (int r0 = 0; r0 < nb; r0 += 16) {
@@ -1350,7 +1359,131 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   return DD_OK;
 }
 
+// -----------------------------------------------------------------------------------------------
+// Speculative single-sequence step: ONE sweep over the weights for the un-masked row AND the K members.
+// The members' masks depend on the un-masked pass only through the keep set (models/llava.py:603, 660: the tokens whose
+// top-k ids contain the base argmax are restored to 1).  The masks are sampled for an EMPTY keep set before the sweep (same
+// draws, same order), the K members ride in rows 0..K-1 and the un-masked row in row 8 of a 16-row pass (two operand planes:
+// the kernels of the lanes path, rows bit-identical to the 8-row kernels), and afterwards the real keep set is compared with
+// what the members dropped: if no kept token was dropped by any member the speculative masks ARE the reference's masks and
+// the step is complete after one sweep; otherwise the masks are re-sampled from the saved rng state with the real keep set
+// and the members re-run (the classic second sweep) — its kernels are enqueued either way and return at once when the
+// device-side flag says the speculation held.  Results are those of the two-sweep step in every case.
+// -----------------------------------------------------------------------------------------------
+static int g_speculate = 1;   // dd_set_tuning key 14
+void dd_engine_set_speculate(int on) { g_speculate = on; }
+
+static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
+  const int d = h->d, dff = h->dff;
+  EmbedLanes el;
+  memset(&el, 0, sizeof(el));
+  for (int m = 0; m < K; ++m) el.state[m] = h->state;
+  el.state[8] = h->state;                                     // row 8: the un-masked row
+  RC(ddk_embed_rows_lanes(h->embed, d, el, 16, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  int ssq_n = 1;
+  auto common = [&](GemvArgs& a) {
+    a.nb = K, a.n_groups = 2, a.fp8 = h->fp8, a.state = h->state;
+    a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
+  };
+  for (int l = 0; l < h->Lyr; ++l) {
+    LayerW& w = h->lw[l];
+    float* kn = h->knew + (size_t)l * KV_ROWS * h->kv_dim;
+    float* vn = h->vnew + (size_t)l * KV_ROWS * h->kv_dim;
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    common(a);
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.wscale = w.s_qkv;
+    a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.qbuf = h->qbuf, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
+    a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin;
+    a.knew_g[0] = kn, a.vnew_g[0] = vn, a.knew_g[1] = kn + (size_t)8 * h->kv_dim, a.vnew_g[1] = vn + (size_t)8 * h->kv_dim;
+    a.knew = kn, a.vnew = vn;
+    RC(ddk_gemv_groups(EPI_QKV, a, st));
+    AttnDecodeArgs t;
+    memset(&t, 0, sizeof(t));
+    t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0;
+    t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
+    t.n_lanes = 2, t.lane_groups = 2, t.max_T = h->T_host;
+    for (int g = 0; g < 2; ++g) {
+      t.knew_g[g] = a.knew_g[g], t.vnew_g[g] = a.vnew_g[g];
+      t.lane_kc[g] = h->kc + (size_t)l * h->lsk, t.lane_vc[g] = h->vc + (size_t)l * h->lsv, t.lane_state[g] = h->state;
+      t.lane_span_start[g] = h->span_start, t.lane_span_len[g] = h->L;
+    }
+    t.lane_bits[0] = h->drop_bits;                              // members: bit m of plane 0
+    t.lane_bits[1] = h->cfg.leak_mask ? h->leak_bits : nullptr;  // un-masked row: InstructBLIP's leaked zeros (bit 0) or nothing
+    t.knew = t.knew_g[0], t.vnew = t.vnew_g[0];
+    RC(ddk_attn_decode(t, st));
+    memset(&a, 0, sizeof(a));
+    common(a);
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.wscale = w.s_o;
+    a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
+    RC(ddk_gemv_groups(EPI_RESID, a, st));
+    memset(&a, 0, sizeof(a));
+    common(a);
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.wscale = w.s_gu;
+    a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+    a.xop_next = h->xop_ff, a.S_next = h->S_ff;
+    RC(ddk_gemv_groups(EPI_SILU, a, st));
+    memset(&a, 0, sizeof(a));
+    common(a);
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.wscale = w.s_down;
+    a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
+    a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
+    RC(ddk_gemv_groups(EPI_RESID, a, st));
+    ssq_n = d / 16;
+  }
+  GemvArgs a;
+  memset(&a, 0, sizeof(a));
+  common(a);
+  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.xop = h->xop_d, a.wscale = h->s_lm;
+  a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
+  a.out_g[0] = h->member_logits, a.out_g[1] = h->grp_logits;   // row 0 of the second group = the un-masked row's logits
+  a.out = h->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
+  RC(ddk_gemv_groups(EPI_STORE, a, st));
+  return DD_OK;
+}
+
+static int decode_step_spec(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, hipStream_t st) {
+  const int32_t* gate = &h->state->done;
+  k_step_begin<<<1, 256, 0, st>>>(h->state, h->leak_bits, h->L, h->cfg.leak_mask == 2 ? 1 : 0);
+  DD_CHECK_LAUNCH();
+  const int mode = h->cfg.mask_mode;
+  const int rng_mode = uniforms ? DD_RNG_INJECTED : DD_RNG_MT19937;
+  const bool draws = mode != DD_MASK_IBLIP_QUANTILE && !uniforms;
+  DD_REQUIRE(mode == DD_MASK_IBLIP_QUANTILE || uniforms || rng, "dd_lm_step: an rng or uniforms is required");
+  uint32_t* rs = dd_rng_state_ptr(rng);
+  if (draws) DD_HIP(hipMemcpyAsync(h->rng_backup, rs, 625 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  // 1. masks for an empty keep set (the stream advances by the step's K * L draws here, once)
+  RC(dd_sample_masks_impl(h->epi, h->L, mprobs, K, nullptr, mode, rng_mode, uniforms, rs, h->drop, h->n_drop, nullptr,
+                          h->drop_bits, gate, st, nullptr, true));
+  // 2. the combined sweep
+  h->bit0 = 0;
+  RC(lm_sweep_spec(h, K, st));
+  RC(dd_copy_row_gated(h->grp_logits, h->base_logits, h->Vpad, gate, st));
+  RC(dd_argmax_rows_gated(h->base_logits, 1, h->V, h->Vpad, h->argmax_base, gate, st));
+  // 3. the real keep set; did any member drop one of its tokens?
+  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, gate, st));
+  const int keep_matters = (mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) ? 0 : 1;
+  RC(dd_spec_check(h->keep, h->drop_bits, h->L, K, gate, h->spec_ok, keep_matters, st));
+  // 4. fallback (returns at once when the speculation held): the reference's masks from the same draws, members re-run
+  if (keep_matters) {
+    RC(dd_sample_masks_impl(h->epi, h->L, mprobs, K, h->keep, mode, rng_mode, uniforms, rs, h->drop, h->n_drop, nullptr,
+                            h->drop_bits, h->spec_ok, st, draws ? h->rng_backup : nullptr, false));
+    RC(lm_sweep(h, K, h->drop_bits, 0, h->member_logits, st, nullptr, h->spec_ok));
+  }
+  // 5. member argmax (+ InstructBLIP's hidden-state argmax), vote, commit — as after dd_lm_step_members
+  RC(dd_argmax_rows_gated(h->member_logits, K, h->V, h->Vpad, h->member_tok, gate, st));
+  if (h->cfg.vote_on == DD_VOTE_HIDDEN) {
+    RC(ddk_final_norm_rows(h->xa, K, h->d, h->final_norm, h->cfg.rms_eps, h->hidden, st));
+    RC(dd_argmax_rows_gated(h->hidden, K, h->d, h->d, h->member_vote, gate, st));
+  }
+  h->last_K = K;
+  return dd_lm_step_commit(h, K, st);
+}
+
 static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
+  if (g_speculate && K >= 1 && K <= 8 && h && h->prefilled && mprobs && h->T_host + 1 < h->T_cap && h->n_tok_host < MAX_NEW_TOKENS)
+    return decode_step_spec(h, mprobs, K, rng, uniforms, (hipStream_t)stream);
   RC(dd_lm_step_base(h, mprobs, K, rng, uniforms, stream));
   if (K > 0) RC(dd_lm_step_members(h, 0, K, stream));
   return dd_lm_step_commit(h, K, stream);
@@ -1394,6 +1527,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   mix(((unsigned long long)h->L << 32) | (unsigned)h->span_start);   // launch arguments fixed by the last prefill
   mix(dd_rng_serial(rng));
   mix((unsigned long long)(uintptr_t)st);
+  mix((unsigned long long)g_speculate);
   for (auto& g : h->graphs)
     if (g.key == key) {
       DD_HIP(hipGraphLaunch(g.exec, st));
@@ -1642,6 +1776,7 @@ extern "C" int dd_lm_get(dd_lm* h, int what, void* dst, size_t bytes, void* stre
     case DD_GET_KEEP: src = h->keep, avail = (size_t)L; break;
     case DD_GET_SEQ_LEN: src = &h->state->T, avail = 4; break;
     case DD_GET_HIDDEN: src = h->last_hidden, avail = (size_t)h->d * 4; break;
+    case DD_GET_SPEC_OK: src = h->spec_ok, avail = 4; break;
     case DD_GET_IMAGE_LOGITS: {
       DD_REQUIRE(bytes <= (size_t)L * h->V * 4, "dd_lm_get: image logits: at most %zu bytes", (size_t)L * h->V * 4);
       size_t rows = bytes / ((size_t)h->V * 4);
@@ -1746,13 +1881,14 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 4) || (key >= 8 && key <= 13), "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4) || (key >= 8 && key <= 14), "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 10) ddk_set_attn_split(value);
   else if (key == 11) dd_engine_set_extend_rows(value);
   else if (key == 12) ddk_set_prefill_mfma(value);
   else if (key == 9) dd_engine_set_pairs(value);
   else if (key == 13) ddk_set_gemv_slices(value);
+  else if (key == 14) dd_engine_set_speculate(value);
   else ddk_set_tuning(key, value);
   return DD_OK;
 }

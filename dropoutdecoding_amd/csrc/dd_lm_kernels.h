@@ -103,6 +103,7 @@ struct GemvArgs {
   float* knew_g[4];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
   float* vnew_g[4];
   int S_next;           // K / 32 of the GEMV that consumes xop_next
+  const int32_t* skip_if;   // optional (k_gemv): *skip_if != 0 -> the launch returns at once (fallback sweep of a speculative step)
   float* part;          // scratch for the slice-resident path (dd_gemv_slices.h): partial sums, or nullptr (then k_gemv_groups runs)
   size_t part_floats;   // capacity; 64 more floats behind it hold rstd of the operand rows
   int diag;             // timing diagnostics only (dd_set_tuning key 3): 2 = no rstd prologue, 4 = no epilogue, 8 = no epilogue prefetch
@@ -134,6 +135,7 @@ struct AttnDecodeArgs {
   const float* knew;     // [8][kv_dim] roped new keys of this layer (rows of this pass)
   const float* vnew;
   u32x4_t* xop_out;      // packed hi/lo operand for o_proj, [q_dim/32][64]
+  const int32_t* skip_if;  // optional: *skip_if != 0 -> both kernels return at once (fallback sweep of a speculative step)
   // lanes (n_lanes > 0): row m of the pass belongs to sequence m — its own cache, length, span and (un-shifted) bits.
   // Used by the fused base pass of a group of sequences; kc/vc/state/drop_bits/span_* above are ignored then.
   int n_lanes;
@@ -195,7 +197,7 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStr
 // ---- small glue -------------------------------------------------------------------------------
 // x[0..8)[d] <- embed[cur_tok] (all rows equal), xop <- split(normw * x), ssq slot 0
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
-                   float* ssq, int ssq_ld, hipStream_t st);
+                   float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if = nullptr);
 struct EmbedLanes {
   const DDState* state[32];   // row m embeds the current token of this sequence (null: row unused)
 };

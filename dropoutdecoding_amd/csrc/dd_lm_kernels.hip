@@ -225,6 +225,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   __shared__ float red[TILES * GEMV_WAVES * 256];
   __shared__ float rstd_sh[8];
   __shared__ float ssq_sh[8 * 16];
+  if (a.skip_if && *a.skip_if) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = a.S, spw = S / GEMV_WAVES;
   constexpr bool DIAG = (ILV == 3);          // timing-only build: x operand := the weight tile (no L2 x traffic)
@@ -997,6 +998,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   float* s_part = q_sh + R * HEAD_DIM;        // [4][R][64]
   float* p_sh = s_part + 4 * R * ATT_SPLIT;   // [64][R]
   float* o_part = p_sh + ATT_SPLIT * R;       // [4][R][128]
+  if (a.skip_if && *a.skip_if) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kvh = blockIdx.x, split = blockIdx.y;
   const int T = ML ? a.lane_state[lane_row]->T : (a.state ? a.state->T : a.T), t0 = split * ATT_SPLIT;
@@ -1106,6 +1108,7 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   __shared__ float red[2];
   __shared__ float w_sh[ATT_MAX_SPLITS];
   __shared__ float mx_sh[2], den_sh[2];
+  if (a.skip_if && *a.skip_if) return;
   const int head = blockIdx.x, m = blockIdx.y, d = threadIdx.x, kvh = head / G, g = head % G;
   const int lane = d & 63, wv = d >> 6;
   const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
@@ -1795,8 +1798,10 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
 // ===============================================================================================
 __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict__ embed, int d, const DDState* state,
                                                      float* __restrict__ x, const float* __restrict__ normw,
-                                                     u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld) {
+                                                     u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld,
+                                                     const int32_t* __restrict__ skip_if) {
   __shared__ float sh[16];
+  if (skip_if && *skip_if) return;
   int tok = state->cur_tok;
   float ss = 0.f;
   for (int i = threadIdx.x; i < d; i += 1024) {
@@ -1819,8 +1824,8 @@ __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict_
   }
 }
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
-                   float* ssq, int ssq_ld, hipStream_t st) {
-  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld);
+                   float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if) {
+  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld, skip_if);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

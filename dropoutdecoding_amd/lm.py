@@ -36,7 +36,7 @@ _FAMILY = {
 
 (GET_TOKENS, GET_LOGITS, GET_EPI, GET_ALEA, GET_VAR, GET_UNCERT_SCALARS, GET_TOPK_IDS, GET_TOPK_VALS, GET_DROP,
  GET_N_DROP, GET_MEMBER_ARGMAX, GET_WINNER, GET_BASE_LOGITS, GET_IMAGE_LOGITS, GET_KEEP, GET_KV_SUMS, GET_SEQ_LEN,
- GET_HIDDEN) = range(18)
+ GET_HIDDEN, GET_SPEC_OK) = range(19)
 
 (T_EMBED, T_ATTN_NORM, T_WQ, T_WK, T_WV, T_WO, T_MLP_NORM, T_WGATE, T_WUP, T_WDOWN, T_FINAL_NORM, T_LM_HEAD) = range(12)
 
@@ -402,6 +402,10 @@ class DropoutEngine:
         return {"drop": self._get(GET_DROP, K * self.L, np.uint8).reshape(K, self.L).astype(bool),
                 "masked_numbers": self._get(GET_N_DROP, K, np.int32), "keep": self._get(GET_KEEP, self.L, np.uint8).astype(bool),
                 "member_argmax": self._get(GET_MEMBER_ARGMAX, K, np.int32), "winner": int(w[0]), "voted": int(w[1])}
+
+    def spec_ok(self) -> int:
+        """1: the last single-sequence step finished in one sweep (speculative masks stood); 0: the members were re-run."""
+        return int(self._get(GET_SPEC_OK, 1, np.int32)[0])
 
     def kv_sums(self) -> np.ndarray:
         return self._get(GET_KV_SUMS, self.cfg.num_layers * 2, np.float64).reshape(-1, 2)

@@ -214,6 +214,11 @@ int dd_lm_prefill_extend(dd_lm* h, const float* embeds_dev, int n, void* stream)
 int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds_dev, int T0, int span_start, int span_len, const double* mprobs,
                            int K, dd_rng* rng, const float* uniforms_dev, void* stream);
 
+/* Single-sequence steps with 1 <= K <= 8 run SPECULATIVELY (dd_set_tuning key 14, default on): the K members share ONE
+ * sweep over the weights with the un-masked pass, their masks sampled for an empty keep set from the same draws; when the
+ * real keep set (models/llava.py:603, 660) would have restored a token some member dropped, the masks are re-sampled from
+ * the saved rng state and the members re-run.  Every result (tokens, masks, logits, KV rows, rng stream) is that of the
+ * two-sweep step, bit for bit; DD_GET_SPEC_OK tells which way the last step went. */
 /* One ensemble decode step, enqueued on `stream` without host synchronisation:
  * embed(last token) -> un-masked pass -> argmax -> keep set -> K masks -> K masked members in
  * one packed sweep -> vote -> winner's logits/argmax + KV row committed.
@@ -264,6 +269,8 @@ int dd_lm_xchg_import_winner(dd_lm* h, const float* rec_dev, void* stream);
 #define DD_GET_KV_SUMS 15      /* fp64  [layers][2]     sum of K and of V entries over the committed cache         */
 #define DD_GET_SEQ_LEN 16      /* int32 [1]             committed KV length                                        */
 #define DD_GET_HIDDEN 17       /* fp32  [d]             final-normed hidden state behind DD_GET_LOGITS             */
+#define DD_GET_SPEC_OK 18      /* int32 [1]             last single-sequence step: 1 = the members' masks sampled for an empty keep set
+                                                        stood (one sweep), 0 = they were re-sampled and the members re-run       */
 int dd_lm_get(dd_lm* h, int what, void* dst_host, size_t bytes, void* stream);
 
 /* Non-blocking: copy the tokens emitted so far (mirrored by the step kernels into pinned host memory) to dst and return
@@ -360,7 +367,9 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * 3 = timing-only diagnostic build without x-operand loads (results are wrong; never use for output),
  * 4 = ring (1) or batch (0, default) request order in the 8-row GEMV,
  * 8 = replay decode steps from a hipGraph (default 1), 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4;
- * default 4), 10 = workgroups per group of 8 members in the grouped decode attention (1, 2, 4; default 1).
+ * default 4), 10 = workgroups per group of 8 members in the grouped decode attention (1, 2, 4; default 1),
+ * 13 = slice-resident 16 / 32-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits), 14 = speculative
+ * single-sequence steps (default 1; 0: always two sweeps, same results).
  * Keys 1 and 2 are accepted and ignored (settled: non-temporal weight loads, interleaved k-steps). */
 int dd_set_tuning(int key, int value);
 
