@@ -1828,8 +1828,14 @@ extern "C" int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms, voi
 extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms, double* bytes_per_launch,
                                void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
+  const bool stream_only = which >= 8;      // 8 + kind: the slice-resident path's streaming kernel alone (no finishing kernel)
+  if (stream_only) which -= 8;
   DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16 || nb == 32) && iters >= 1,
              "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 / 32 = the two- / four-group kernel)");
+  struct Restore {
+    ~Restore() { ddk_set_slices_only(0); }
+  } restore_;
+  ddk_set_slices_only(stream_only ? 1 : 0);
   const int ngroups = nb >= 16 ? nb / 8 : 0;
   const bool wide = ngroups > 0;
   if (nb >= 16) nb = 8;

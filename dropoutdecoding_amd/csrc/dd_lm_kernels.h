@@ -112,6 +112,7 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
 int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2 or 4) groups of up to 8 rows (bf16 weights)
 void ddk_set_tuning(int key, int value);
 void ddk_set_gemv_slices(int on);
+void ddk_set_slices_only(int on);
 void ddk_set_attn_split(int v);
 void ddk_set_prefill_mfma(int on);
 int ddk_prefill_mfma_enabled();

@@ -868,7 +868,9 @@ static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
 // families have (K = 4096: 16 k-steps per slice; K = 11008 / 14336: 43 / 56, staged in chunks of 16).  Anything else runs
 // through k_gemv_groups; both produce the same bits.
 static int g_gemv_slices = 1;     // dd_set_tuning key 13
+static int g_slices_only = 0;     // dd_lm_time_gemv: launch the streaming kernel without its finishing kernel (timing only)
 void ddk_set_gemv_slices(int on) { g_gemv_slices = on; }
+void ddk_set_slices_only(int on) { g_slices_only = on; }
 #define SLICES_UNSUPPORTED 1
 
 template <int TW, int NG, int U, int SPW, int CS, int CH>
@@ -884,6 +886,7 @@ static int launch_slices_k(const SliceArgs& sa, hipStream_t st) {
 }
 template <int EPI, int TILES, int NG, int NP>
 static void launch_finish(const GemvArgs& a, int n_sets, hipStream_t st) {
+  if (g_slices_only) return;
   k_gemv_finish<EPI, TILES, NG, NP><<<n_sets, 128 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
 }
 template <int NG>

@@ -300,7 +300,10 @@ double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K);
 int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stream);
 
 /* Time one decode GEMV kind in isolation (HIP events on `stream`), cycling over the layers' weights so every
- * launch streams bytes that are not cache-resident. which: 0 qkv, 1 o_proj, 2 gate/up, 3 down_proj.
+ * launch streams bytes that are not cache-resident. which: 0 qkv, 1 o_proj, 2 gate/up, 3 down_proj; nb = rows (1..8, or
+ * 16 / 32 = the two- / four-plane kernels of the lanes path: k_gemv_slices + k_gemv_finish, or k_gemv_groups).
+ * which + 8: the slice-resident path's STREAMING kernel alone (k_gemv_slices without its finishing kernel) — the kernel
+ * whose duration rocprofv3's kernel trace reports under that name.
  * bytes_per_launch_out = algorithmic (bf16 weight) bytes of one launch. */
 int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, double* bytes_per_launch_out,
                     void* stream);

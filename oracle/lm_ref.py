@@ -94,6 +94,12 @@ def rope_cos_sin(cfg: LMConfig, positions: torch.Tensor, dtype) -> Tuple[torch.T
     return emb.cos().to(dtype), emb.sin().to(dtype)
 
 
+def _lin(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear without bias, as HF calls it (F.linear on the contiguous [out, in] weight: the batch-1 GEMV then streams
+    the weight rows at memory speed — `x @ w.T` in bf16 went through a several-times slower path on the bench host)."""
+    return torch.nn.functional.linear(x, w)
+
+
 def _rotate_half(x: torch.Tensor) -> torch.Tensor:
     h = x.shape[-1] // 2
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
@@ -141,9 +147,9 @@ def lm_hidden(cfg: LMConfig, w: Dict[str, torch.Tensor], x: torch.Tensor, positi
         p = f"model.layers.{i}."
         r = h
         hn = rms_norm(h, w[p + "input_layernorm.weight"], cfg.rms_eps)
-        q = (hn @ w[p + "self_attn.q_proj.weight"].T).view(T_new, cfg.num_heads, cfg.head_dim).transpose(0, 1)
-        k = (hn @ w[p + "self_attn.k_proj.weight"].T).view(T_new, cfg.num_kv_heads, cfg.head_dim).transpose(0, 1)
-        v = (hn @ w[p + "self_attn.v_proj.weight"].T).view(T_new, cfg.num_kv_heads, cfg.head_dim).transpose(0, 1)
+        q = _lin(hn, w[p + "self_attn.q_proj.weight"]).view(T_new, cfg.num_heads, cfg.head_dim).transpose(0, 1)
+        k = _lin(hn, w[p + "self_attn.k_proj.weight"]).view(T_new, cfg.num_kv_heads, cfg.head_dim).transpose(0, 1)
+        v = _lin(hn, w[p + "self_attn.v_proj.weight"]).view(T_new, cfg.num_kv_heads, cfg.head_dim).transpose(0, 1)
         q = q * cos[None] + _rotate_half(q) * sin[None]
         k = k * cos[None] + _rotate_half(k) * sin[None]
         if first:
@@ -157,14 +163,14 @@ def lm_hidden(cfg: LMConfig, w: Dict[str, torch.Tensor], x: torch.Tensor, positi
         att = (q @ kk.transpose(1, 2)) * (cfg.head_dim ** -0.5) + add[None]
         att = torch.softmax(att, dim=-1, dtype=torch.float32).to(dt)
         o = (att @ vv).transpose(0, 1).reshape(T_new, cfg.q_dim)
-        h = r + o @ w[p + "self_attn.o_proj.weight"].T
+        h = r + _lin(o, w[p + "self_attn.o_proj.weight"])
         r = h
         hn = rms_norm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-        g = hn @ w[p + "mlp.gate_proj.weight"].T
-        u = hn @ w[p + "mlp.up_proj.weight"].T
-        h = r + (torch.nn.functional.silu(g) * u) @ w[p + "mlp.down_proj.weight"].T
+        g = _lin(hn, w[p + "mlp.gate_proj.weight"])
+        u = _lin(hn, w[p + "mlp.up_proj.weight"])
+        h = r + _lin(torch.nn.functional.silu(g) * u, w[p + "mlp.down_proj.weight"])
     return rms_norm(h, w["model.norm.weight"], cfg.rms_eps)
 
 
 def lm_logits(cfg: LMConfig, w: Dict[str, torch.Tensor], hidden: torch.Tensor) -> torch.Tensor:
-    return (hidden @ w["lm_head.weight"].T).float()
+    return _lin(hidden, w["lm_head.weight"]).float()
