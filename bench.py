@@ -75,6 +75,17 @@ def cpu_baseline(K: int, budget_s: float = 20.0):
     from oracle.decode_ref import FAMILY_LLAVA, RefDecoder
     from oracle.lm_ref import KVCache, LMConfig
     host = _host_info()
+    try:
+        # glibc hands every > 128 KiB tensor a fresh mmap and unmaps it on free: the (1 + K) KV-cache copies per token then
+        # cost page faults + TLB shoot-downs across all threads (seconds per token on a 128-core host).  Keep big blocks on
+        # the heap instead — what a CPU deployment gets from tcmalloc / jemalloc.
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)      # M_MMAP_THRESHOLD
+        libc.mallopt(-1, 1 << 31 - 1)  # M_TRIM_THRESHOLD
+        host["malloc"] = "glibc, M_MMAP_THRESHOLD=1GiB (large tensors reuse heap memory)"
+    except Exception:
+        host["malloc"] = "glibc defaults"
     torch.set_num_threads(max(1, int(host["physical_cores"])))
     torch.manual_seed(0)
     cores = torch.get_num_threads()
@@ -330,7 +341,7 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": f"LLaVA-1.5-7B Dropout Decoding, {B} synthetic 336x336 image(s) per step and GPU -> each 576 visual tokens + "
                                    f"32-token prompt (prefill 608), {args.n_new} decoded tokens per image (EOS ignored), K={K_eff} voting_numbers={probs if K_eff else []}, "
-                                   "random-init weights of the real shapes (bf16 weights, fp32 activations/KV)"
+                                   "random-init weights of the real shapes (bf16 weights, fp32 activations, fp16 KV cache = the reference's cache width)"
                                    + (f"; the {B} images are {B} independent sequences (own KV cache and rng stream, results identical to "
                                       "decoding each alone) whose un-masked passes share one sweep over the weights and whose member passes run four sequences "
                                       "per sweep; the next batch's CLIP + prefill overlap the current batch's decode on a second stream" if B > 1 else ""),

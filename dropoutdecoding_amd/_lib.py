@@ -37,7 +37,8 @@ class LMConfigC(C.Structure):
                 ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
                 ("head_dim", C.c_int32), ("rms_eps", C.c_float), ("rope_theta", C.c_float),
                 ("max_seq", C.c_int32), ("max_visual", C.c_int32), ("k_top", C.c_int32), ("mask_mode", C.c_int32),
-                ("vote_on", C.c_int32), ("leak_mask", C.c_int32), ("weight_format", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("vote_on", C.c_int32), ("leak_mask", C.c_int32), ("weight_format", C.c_int32), ("kv_format", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 _lib = None

@@ -16,6 +16,14 @@ settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap
 #   settings['reuse_image_prefix'] = True    -> consecutive prompts over the SAME image keep the image prefix's K/V,
 #                                               uncertainty and top-k ids and prefill only the new text (LLaVA families)
 
+# Storage formats, read when a model is built (from_pretrained / from_hf_model / from_synthetic):
+#   settings['kv_cache'] = 'fp16' (default) | 'fp32'  -> KV cache width.  fp16 is what the reference keeps (it loads every model
+#                                               with torch_dtype=float16, chair_test.py:189-213); K/V are rounded when they enter
+#                                               the cache, the attention arithmetic stays fp32.  Goldens + 24-step oracle runs:
+#                                               tokens / masks / votes exact, logits <= 1.7e-4 of max|logit| (tests/test_gpu_kv_fp16.py)
+#   settings['weight_format'] = 'bf16' (default) | 'fp8' -> LM matrices stored as OCP fp8 e4m3fn + per-row scales (BASELINE config 5:
+#                                               "fp8 MFMA weights"); quantised on load by lm.quantize_fp8
+
 # K = 8 is not reachable from the reference CLI (chair_test.py:163-175); BASELINE configs 3-5 use this list.
 VOTING_NUMBERS_K8 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
 VOTING_NUMBERS_K4 = [0.1, 0.3, 0.5, 0.7]   # chair_test.py:170

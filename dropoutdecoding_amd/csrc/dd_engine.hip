@@ -3,6 +3,7 @@
 // sweep -> vote -> commit) on one HIP stream with no host synchronisation.
 // Replaces the reference's decode branch of forward(): models/llava.py:254-376 (see include/dropdec.h).
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -69,6 +70,7 @@ struct dd_lm {
   u32x4_t* lm_head = nullptr;
   float* s_lm = nullptr;
   int fp8 = 0;                 // weight storage: 0 bf16, 1 OCP e4m3fn + per-row scales
+  int kv16 = 0;                // KV cache storage: 0 fp32, 1 fp16 (the reference's cache width; layouts in dd_lm_kernels.h)
   u32x4_t* deq_tmp = nullptr;  // fp8: bf16 tiles of ONE matrix for the prefill GEMM
   float* final_norm = nullptr;
   uint16_t* embed = nullptr;
@@ -182,6 +184,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   h->q_tiles = h->q_dim / 16, h->k_tiles = h->kv_dim / 16, h->qkv_tiles = (h->q_dim + 2 * h->kv_dim) / 16;
   const int d = h->d, dff = h->dff, T = h->T_cap;
   h->fp8 = c->weight_format == 1 ? 1 : 0;
+  h->kv16 = c->kv_format == 1 ? 1 : 0;
+  DD_REQUIRE(c->kv_format == 0 || c->kv_format == 1, "dd_lm_create: unknown KV cache format %d", c->kv_format);
   DD_REQUIRE(c->weight_format == 0 || c->weight_format == 1, "dd_lm_create: unknown weight format %d", c->weight_format);
   const int wdiv = h->fp8 ? 2 : 1;   // u32x4 units per tile row: S*64 (bf16) or (S/2)*64 (fp8)
   if (parent) {
@@ -229,8 +233,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   }
   DA(h->rope_cos, (size_t)T * 64);
   DA(h->rope_sin, (size_t)T * 64);
-  h->lsk = (size_t)h->Hkv * 32 * T * 4;
-  h->lsv = (size_t)h->Hkv * T * 128;
+  h->lsk = (size_t)h->Hkv * 32 * T * 4 / (h->kv16 ? 2 : 1);     // layer strides in floats of the storage (fp16: half)
+  h->lsv = (size_t)h->Hkv * T * 128 / (h->kv16 ? 2 : 1);
   DA(h->kc, h->lsk * h->Lyr);
   DA(h->vc, h->lsv * h->Lyr);
   // decode scratch
@@ -682,11 +686,11 @@ static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.n_tiles = h->qkv_tiles;
     RC(wsel(g, w.wqkv, w.s_qkv, h->qkv_tiles, h->S_d));
     g.qbuf = h->pq, g.kc = h->kc + (size_t)l * h->lsk, g.vc = h->vc + (size_t)l * h->lsv, g.T_cap = h->T_cap;
-    g.q_tiles = h->q_tiles, g.k_tiles = h->k_tiles, g.q_dim = h->q_dim, g.kv_dim = h->kv_dim, g.pos0 = pos0;
+    g.q_tiles = h->q_tiles, g.k_tiles = h->k_tiles, g.q_dim = h->q_dim, g.kv_dim = h->kv_dim, g.pos0 = pos0, g.kv16 = h->kv16;
     g.rope_cos = h->rope_cos, g.rope_sin = h->rope_sin;
     RC(ddk_gemm(EPI_QKV, g, st));
     RC(ddk_attn_prefill(h->pq, g.kc, g.vc, T0, h->T_cap, h->H, h->Hkv, h->p1_hi, h->p1_lo, drop_plane, drop_bit,
-                        span_start, span_len, pos0, st));
+                        span_start, span_len, pos0, st, nullptr, h->kv16));
     memset(&g, 0, sizeof(g));
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_q, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
     RC(wsel(g, w.wo, w.s_o, d / 16, h->S_q));
@@ -809,7 +813,7 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = h->chunk_states;
     for (int m = 0; m < cap; ++m) a.state_rows[m] = h->chunk_states + (m < n ? m : 0);
     RC(gemv(EPI_QKV, a));
-    RC(ddk_scatter_kv_rows(h->chunk_k, h->chunk_v, n, h->kv_dim, kc, vc, h->T_cap, h->state, st));
+    RC(ddk_scatter_kv_rows(h->chunk_k, h->chunk_v, n, h->kv_dim, kc, vc, h->T_cap, h->state, st, h->kv16));
     // causal attention of the chunk rows: row i = a single-query decode attention over the cache up to position
     // pos0 + i - 1 (prefix + the chunk rows ahead of it, just scattered) plus its own new key — the fused-base-pass
     // kernel with every "lane" pointing at this one cache; 16 rows per launch
@@ -817,7 +821,7 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
       const int nr = n - r0 < 16 ? n - r0 : 16;
       AttnDecodeArgs t;
       memset(&t, 0, sizeof(t));
-      t.qbuf = h->qbuf + (size_t)r0 * h->q_dim, t.T_cap = h->T_cap, t.nb = nr, t.n_heads = h->H, t.n_kv = h->Hkv;
+      t.qbuf = h->qbuf + (size_t)r0 * h->q_dim, t.T_cap = h->T_cap, t.nb = nr, t.n_heads = h->H, t.n_kv = h->Hkv, t.kv16 = h->kv16;
       t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q + (size_t)(r0 / 8) * h->S_q * 64;
       t.knew = h->chunk_k + (size_t)r0 * h->kv_dim, t.vnew = h->chunk_v + (size_t)r0 * h->kv_dim;
       t.n_lanes = nr, t.max_T = pos0 + n;
@@ -979,7 +983,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     RC(gemv(EPI_QKV, a));
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
-    t.qbuf = h->qbuf, t.kc = h->kc + (size_t)l * h->lsk, t.vc = h->vc + (size_t)l * h->lsv, t.T_cap = h->T_cap;
+    t.qbuf = h->qbuf, t.kc = h->kc + (size_t)l * h->lsk, t.vc = h->vc + (size_t)l * h->lsv, t.T_cap = h->T_cap, t.kv16 = h->kv16;
     t.T = h->T_host, t.state = h->state, t.nb = nb, t.n_heads = h->H, t.n_kv = h->Hkv, t.drop_bits = bits;
     t.bit0 = bits ? h->bit0 : 0;
     t.span_start = h->span_start, t.span_len = h->L, t.part_o = h->part_o, t.part_ml = h->part_ml;
@@ -1098,7 +1102,7 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
   DD_REQUIRE(h && h->prefilled && K == h->last_K, "dd_lm_step_commit: bad state (K=%d, expected %d)", K, h ? h->last_K : -1);
   if (K > 0) RC(vote_members(h, K, st));
   RC(ddk_commit_kv(h->commit_k ? h->commit_k : h->knew, h->commit_v ? h->commit_v : h->vnew, h->Lyr, KV_ROWS,
-                   h->kv_dim, h->kc, h->vc, h->lsk, h->lsv, h->T_cap, h->state, K > 0 ? 1 : 0, st));
+                   h->kv_dim, h->kc, h->vc, h->lsk, h->lsv, h->T_cap, h->state, K > 0 ? 1 : 0, st, h->kv16));
   k_step_end<<<1, 1024, 0, st>>>(h->state, K, h->argmax_base, h->member_tok, h->base_logits, h->member_logits, h->Vpad,
                                  h->last_logits, h->tokens, h->drop_bits, h->L, h->leak_bits, h->cfg.leak_mask, h->hidden,
                                  h->d, h->last_hidden, h->tok_host_dev);
@@ -1138,7 +1142,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = qs[0]->state;
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
-    t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0;
+    t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0, t.kv16 = h->kv16;
     t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
     t.n_lanes = ng, t.lane_groups = ng;
     for (int g = 0; g < ng; ++g) {
@@ -1223,7 +1227,7 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
   StepEndLanes el;
   memset(&cl, 0, sizeof(cl));
   memset(&el, 0, sizeof(el));
-  cl.lsk = h->lsk, cl.lsv = h->lsv;
+  cl.lsk = h->lsk, cl.lsv = h->lsv, cl.kv16 = h->kv16;
   for (int g = 0; g < ng; ++g) {
     dd_lm* q = qs[g];
     ids[g] = q->cfg.vote_on == DD_VOTE_HIDDEN ? q->member_vote : q->member_tok;
@@ -1276,7 +1280,8 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     dd_lm* q = lanes[m];
     DD_REQUIRE(q, "dd_lm_group_step: null handle");
     DD_REQUIRE((q->wsrc ? q->wsrc : q) == owner, "dd_lm_group_step: sequence %d does not share the group's weights", m);
-    DD_REQUIRE(q->T_cap == h0->T_cap && q->Vpad == h0->Vpad, "dd_lm_group_step: sequence %d has a different KV capacity", m);
+    DD_REQUIRE(q->T_cap == h0->T_cap && q->Vpad == h0->Vpad && q->kv16 == h0->kv16,
+               "dd_lm_group_step: sequence %d has a different KV capacity or cache format", m);
     for (int j = 0; j < m; ++j) DD_REQUIRE(lanes[j] != q, "dd_lm_group_step: sequence listed twice");
     if (!q->prefilled) {
       dd_set_error("dd_lm_group_step: sequence %d: decode before prefill", m);
@@ -1401,7 +1406,7 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
     RC(ddk_gemv_groups(EPI_QKV, a, st));
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
-    t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0;
+    t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0, t.kv16 = h->kv16;
     t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
     t.n_lanes = 2, t.lane_groups = 2, t.max_T = h->T_host;
     for (int g = 0; g < 2; ++g) {
@@ -1576,7 +1581,10 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   for (int m = 0; graphable && m < n; ++m)
     graphable = lanes[m] && lanes[m]->prefilled && lanes[m]->steps_since_prefill >= 1 &&
                 lanes[m]->T_host + 1 < lanes[m]->T_cap && lanes[m]->n_tok_host < MAX_NEW_TOKENS;
-  if (!graphable) return group_step_eager(lanes, n, mprobs, K, rngs, stream_);
+  if (!graphable) {
+    if (getenv("DD_DEBUG")) fprintf(stderr, "[dropdec] group step not graphable (eager)\n");
+    return group_step_eager(lanes, n, mprobs, K, rngs, stream_);
+  }
   dd_lm* h0 = lanes[0];
   unsigned long long key = 1469598103934665603ull;
   auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
@@ -1611,6 +1619,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
       advance();
       return DD_OK;
     }
+  if (getenv("DD_DEBUG")) fprintf(stderr, "[dropdec] group step graph miss: capturing (cache holds %zu)\n", h0->graphs.size());
   struct Saved {
     int T, N, K, S;
     bool leak;
@@ -1641,6 +1650,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
     DD_HIP(hipGraphLaunch(exec, st));
     return DD_OK;          // host mirrors were advanced by the captured call
   }
+  if (getenv("DD_DEBUG")) fprintf(stderr, "[dropdec] group step capture failed: rc=%d end_capture=%s graph=%p (%s)\n", rc, hipGetErrorString(e), (void*)graph, dd_last_error());
   if (graph) (void)hipGraphDestroy(graph);
   (void)hipGetLastError();
   restore();               // nothing was executed
@@ -1785,7 +1795,7 @@ extern "C" int dd_lm_get(dd_lm* h, int what, void* dst, size_t bytes, void* stre
       return DD_OK;
     }
     case DD_GET_KV_SUMS:
-      RC(ddk_kv_sums(h->kc, h->vc, h->Lyr, h->lsk, h->lsv, h->Hkv, h->T_cap, h->T_host, h->kv_sums, st));
+      RC(ddk_kv_sums(h->kc, h->vc, h->Lyr, h->lsk, h->lsv, h->Hkv, h->T_cap, h->T_host, h->kv_sums, st, h->kv16));
       DD_HIP(hipStreamSynchronize(st));
       src = h->kv_sums, avail = (size_t)h->Lyr * 16;
       break;
@@ -1803,7 +1813,7 @@ extern "C" double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K) {
   double params = (double)h->Lyr * ((double)(h->q_dim + 2 * h->kv_dim) * h->d + (double)h->d * h->q_dim + 3.0 * h->d * h->dff) +
                   (double)h->V * h->d;
   double w = params * (h->fp8 ? 1.0 : 2.0);
-  double kv_tok = (double)h->Lyr * 2 * h->kv_dim * 4.0;
+  double kv_tok = (double)h->Lyr * 2 * h->kv_dim * (h->kv16 ? 2.0 : 4.0);
   int sweeps = K > 0 ? 1 + (K + 7) / 8 : 1;
   return sweeps * (w + (double)h->T_host * kv_tok);
 }

@@ -25,6 +25,36 @@ __host__ __device__ inline bool dd_is_eos(const DDState* st, int tok) {
   return hit;
 }
 
+// ---- KV cache layouts -------------------------------------------------------------------------
+// fp32 (kv16 = 0):  K [kv_head][d/4][T_cap][4]  (keys on lanes: a wave's 16-byte loads of one d-chunk are 1 KiB contiguous),
+//                   V [kv_head][T_cap][128]
+// fp16 (kv16 = 1, the width the reference keeps its cache in — chair_test/chair_test.py:189-213 loads every model with
+//                   torch_dtype=float16):  K [kv_head][d/8][T_cap][8] halves (16 bytes per key and chunk),
+//                   V [kv_head][T_cap/2][32][2][4] halves: a 16-byte load = 4 consecutive d of keys 2p and 2p + 1, so the lane ->
+//                   (key, d) map of the P.V loop is the fp32 kernel's with two keys per load.
+// Pointers stay `float*` in the interfaces; layer strides are in floats of the actual storage (half the element count for
+// fp16).  Element offsets (in elements of the storage type) of key t, dimension d of kv head `kvh`:
+__host__ __device__ inline size_t dd_k32(int kvh, int d, int t, int Tc) { return (((size_t)kvh * 32 + (d >> 2)) * Tc + t) * 4 + (d & 3); }
+__host__ __device__ inline size_t dd_v32(int kvh, int d, int t, int Tc) { return ((size_t)kvh * Tc + t) * 128 + d; }
+__host__ __device__ inline size_t dd_k16(int kvh, int d, int t, int Tc) { return (((size_t)kvh * 16 + (d >> 3)) * Tc + t) * 8 + (d & 7); }
+__host__ __device__ inline size_t dd_v16(int kvh, int d, int t, int Tc) {
+  return (size_t)kvh * Tc * 128 + ((size_t)(t >> 1) * 32 + (d >> 2)) * 8 + (t & 1) * 4 + (d & 3);
+}
+typedef _Float16 dd_half;
+__device__ __forceinline__ void dd_kv_store(float* kc, float* vc, int kv16, int kvh, int d, int t, int Tc, bool is_k, float v) {
+  if (kv16) {
+    if (is_k) ((dd_half*)kc)[dd_k16(kvh, d, t, Tc)] = (dd_half)v;      // round to nearest even, as a cast to torch.float16 does
+    else ((dd_half*)vc)[dd_v16(kvh, d, t, Tc)] = (dd_half)v;
+  } else {
+    if (is_k) kc[dd_k32(kvh, d, t, Tc)] = v;
+    else vc[dd_v32(kvh, d, t, Tc)] = v;
+  }
+}
+__device__ __forceinline__ float dd_kv_load(const float* kc, const float* vc, int kv16, int kvh, int d, int t, int Tc, bool is_k) {
+  if (kv16) return is_k ? (float)((const dd_half*)kc)[dd_k16(kvh, d, t, Tc)] : (float)((const dd_half*)vc)[dd_v16(kvh, d, t, Tc)];
+  return is_k ? kc[dd_k32(kvh, d, t, Tc)] : vc[dd_v32(kvh, d, t, Tc)];
+}
+
 // ---- weight layout ------------------------------------------------------------------------
 // W[N][K] bf16 (HF: out_features x in_features) is stored as 16x32 MFMA operand tiles:
 //   tile (nt, ks) = 64 lanes x 16 bytes at ((nt * S + ks) * 64 + lane), S = K/32,
@@ -124,6 +154,7 @@ struct AttnDecodeArgs {
   const float* kc;       // this layer: [n_kv][32][T_cap][4]
   const float* vc;       // this layer: [n_kv][T_cap][128]
   int T_cap;
+  int kv16;              // 1: the cache holds fp16 (layouts above); the rows' own new K/V (knew / vnew) are fp32 either way
   int T;                 // host copy of the prefix length (grid sizing; also the length when `state` is null)
   const DDState* state;  // when set, kernels read the prefix length from the device (graph replays keep advancing)
   int nb, n_heads, n_kv;
@@ -179,6 +210,7 @@ struct GemmArgs {
   float* kc;             // layer K cache
   float* vc;
   int T_cap, q_tiles, k_tiles, q_dim, kv_dim, pos0;
+  int kv16;              // EPI_QKV: the cache holds fp16
   const float* rope_cos;
   const float* rope_sin;
 };
@@ -186,13 +218,13 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st);
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out = nullptr);   // q0 = position of query row 0
+                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out = nullptr, int kv16 = 0);   // q0 = position of query row 0
 // xop_out: write the rows as packed decode-GEMV operand planes (row-major [32 rows]) instead of the GEMM's A planes
 int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x, const float* normw, u32x4_t* xop, float* ssq,
                         int ssq_ld, hipStream_t st);
 int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t st);
 int ddk_scatter_kv_rows(const float* kr, const float* vr, int n, int kv_dim, float* kc, float* vc, int T_cap, const DDState* base,
-                        hipStream_t st);
+                        hipStream_t st, int kv16 = 0);
 int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStream_t st);
 
 // ---- small glue -------------------------------------------------------------------------------
@@ -212,11 +244,12 @@ struct CommitLanes {       // winners of up to 4 sequences appended to their cac
   float* vc[4];
   const DDState* state[4];
   size_t lsk, lsv;
+  int kv16;
 };
 int ddk_commit_kv_lanes(const CommitLanes& t, int n, int n_layers, int rows_per_layer, int kv_dim, int T_cap, hipStream_t st);
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
                   float* vc, size_t layer_stride_k, size_t layer_stride_v, int T_cap, const DDState* state,
-                  int use_winner, hipStream_t st);
+                  int use_winner, hipStream_t st, int kv16 = 0);
 int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float eps, float* out, hipStream_t st);
 int ddk_kv_sums(const float* kc, const float* vc, int n_layers, size_t lsk, size_t lsv, int n_kv, int T_cap, int T,
-                double* out, hipStream_t st);
+                double* out, hipStream_t st, int kv16 = 0);

@@ -978,7 +978,8 @@ int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
 // reads; results go to the 8-rows-per-head layout the 8-row combine reads.
 // ML == 2 (groups): NBT == 8; blockIdx.z = group * (G / GH) + GQA slice; group g's 8 rows (members of sequence g) read
 // that sequence's cache and drop bits; results go to an (8 * a.lane_groups)-rows-per-head layout (row = 8 * group + member).
-template <int NBT, int G, int GH, int ML = 0>
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int NBT, int G, int GH, int ML = 0, int KV16 = 0>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
   const int lane_rows = a.n_lanes > 8 ? 16 : 8;   // ML == 1: rows per q head in the buffers (what the combine is built for)
@@ -1016,15 +1017,31 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 
   // 1. all K / V requests of this wave (addresses clamped to the last live key; dead keys get p = 0)
   const int kt = t0 + min(lane, nkeys - 1);
-  const float* kbase = kc_l + (((size_t)kvh * 32 + wave * 8) * a.T_cap + kt) * 4;
-  f32x4_t k4[8], v4[8];
+  f32x4_t k4[KV16 ? 1 : 8], v4[KV16 ? 1 : 8];
+  u32x4_t k8[KV16 ? 4 : 1], v8[KV16 ? 4 : 1];
+  if constexpr (!KV16) {
+    const float* kbase = kc_l + (((size_t)kvh * 32 + wave * 8) * a.T_cap + kt) * 4;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) k4[i] = *(const f32x4_t*)(kbase + (size_t)i * a.T_cap * 4);
-  const float* vbase = vc_l + ((size_t)kvh * a.T_cap + t0) * HEAD_DIM + dq * 4;
+    for (int i = 0; i < 8; ++i) k4[i] = *(const f32x4_t*)(kbase + (size_t)i * a.T_cap * 4);
+    const float* vbase = vc_l + ((size_t)kvh * a.T_cap + t0) * HEAD_DIM + dq * 4;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int key = min(wave * 16 + 2 * j + half, nkeys - 1);
-    v4[j] = *(const f32x4_t*)(vbase + (size_t)key * HEAD_DIM);
+    for (int j = 0; j < 8; ++j) {
+      int key = min(wave * 16 + 2 * j + half, nkeys - 1);
+      v4[j] = *(const f32x4_t*)(vbase + (size_t)key * HEAD_DIM);
+    }
+  } else {
+    // fp16 cache: K [d/8][T_cap][8] — this wave's 32 d are 4 chunks of 16 bytes per key; V pair-interleaved — one 16-byte
+    // load = 4 d (dq) of keys 2p, 2p + 1; the wave's 16 keys are 8 pairs, two pairs (half 0 / 1) per instruction
+    const dd_half* kbase = (const dd_half*)kc_l + (((size_t)kvh * 16 + wave * 4) * a.T_cap + kt) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k8[i] = *(const u32x4_t*)(kbase + (size_t)i * a.T_cap * 8);
+    const dd_half* vbase = (const dd_half*)vc_l + (size_t)kvh * a.T_cap * HEAD_DIM + ((size_t)(t0 >> 1) * 32 + dq) * 8;
+    const int last_pair = (nkeys - 1) >> 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int pr = min(wave * 8 + 2 * j + half, last_pair);
+      v8[j] = *(const u32x4_t*)(vbase + (size_t)pr * 32 * 8);
+    }
   }
   uint32_t bits = 0;
   if (bits_l && lane < nkeys) {
@@ -1043,10 +1060,21 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float sp = 0.f;
+    if constexpr (!KV16) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
-      sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
+      for (int i = 0; i < 8; ++i) {
+        f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
+        sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f16x8_t kh = __builtin_bit_cast(f16x8_t, k8[i]);
+        f32x4_t qa = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 4 + i) * 8];
+        f32x4_t qb = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 4 + i) * 8 + 4];
+        sp += qa.x * (float)kh[0] + qa.y * (float)kh[1] + qa.z * (float)kh[2] + qa.w * (float)kh[3];
+        sp += qb.x * (float)kh[4] + qb.y * (float)kh[5] + qb.z * (float)kh[6] + qb.w * (float)kh[7];
+      }
     }
     s_part[(wave * R + r) * ATT_SPLIT + lane] = sp;
   }
@@ -1074,12 +1102,26 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   f32x4_t acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  if constexpr (!KV16) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int key = wave * 16 + 2 * j + half;
-    const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
+    for (int j = 0; j < 8; ++j) {
+      int key = wave * 16 + 2 * j + half;
+      const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
+      for (int r = 0; r < R; ++r) acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key0 = 2 * (wave * 8 + 2 * j + half);        // keys 2p, 2p + 1 of this lane's pair
+      const f16x8_t vh = __builtin_bit_cast(f16x8_t, v8[j]);
+      const f32x4_t va = {(float)vh[0], (float)vh[1], (float)vh[2], (float)vh[3]};
+      const f32x4_t vb = {(float)vh[4], (float)vh[5], (float)vh[6], (float)vh[7]};
+      const float* pa = &p_sh[key0 * R];
+      const float* pb = &p_sh[(key0 + 1) * R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] += pa[r] * va + pb[r] * vb;   // p = 0 for dead / dropped keys
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1184,7 +1226,16 @@ static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_attn_partial<NBT, G, GH><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
+  if (a.kv16) {
+    static bool attr16 = false;
+    if (!attr16 && smem > 48 * 1024) {
+      DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr16 = true;
+    }
+    k_attn_partial<NBT, G, GH, 0, 1><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
+  } else {
+    k_attn_partial<NBT, G, GH><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
+  }
   k_attn_combine<NBT, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
 }
@@ -1196,7 +1247,8 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   int splits = ddk_attn_grid_tiles(a.max_T, a.T_cap);
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
-  k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
+  if (a.kv16) k_attn_partial<1, G, G, 1, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
+  else k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
   if (a.n_lanes > 8) k_attn_combine<16, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   else k_attn_combine<8, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
@@ -1218,7 +1270,16 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
+  if (a.kv16) {
+    static bool attr16 = false;
+    if (!attr16 && smem > 48 * 1024) {
+      DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr16 = true;
+    }
+    k_attn_partial<NBT, G, GH, 2, 1><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
+  } else {
+    k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
+  }
   k_attn_combine<8 * NG, G><<<dim3(a.n_heads, 8 * NG), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
 }
@@ -1447,13 +1508,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
             int idx = (c < 8) ? f : ROPE_HALF + f;
             if (ok) {
               if (is_q) a.qbuf[(size_t)row * a.q_dim + head * HEAD_DIM + idx] = o;
-              else a.kc[(((size_t)head * 32 + (idx >> 2)) * a.T_cap + pos) * 4 + (idx & 3)] = o;
+              else dd_kv_store(a.kc, a.vc, a.kv16, head, idx, pos, a.T_cap, true, o);
             }
           } else if (ok) {
             int col = (nt - a.q_tiles - a.k_tiles) * 16 + c;
             int kvh = col / HEAD_DIM, idx = col % HEAD_DIM;
             int pos = a.pos0 + row;
-            a.vc[((size_t)kvh * a.T_cap + pos) * HEAD_DIM + idx] = y;
+            dd_kv_store(a.kc, a.vc, a.kv16, kvh, idx, pos, a.T_cap, false, y);
           }
         }
       }
@@ -1617,7 +1678,7 @@ __device__ __forceinline__ void fa_split8(const float* v, u32x4_t& hi, u32x4_t& 
 #define FA_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), C, 0, 0, 0)
 
 // HD = head dimension (128: the LM; 64: the CLIP tower, bidirectional, q pre-scaled)
-template <int G, int HD = 128>
+template <int G, int HD = 128, int KV16 = 0>
 __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restrict__ qbuf, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, int T, int T_cap, int n_heads,
                                                            uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
@@ -1662,13 +1723,32 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
   for (int t0 = 0; t0 <= p_max; t0 += FA_KEYS) {
     __syncthreads();                                          // the previous tiles are no longer being read
     // stage K (from the transposed cache [d/4][T_cap][4]) and V ([T_cap][128]) of keys t0 .. t0+31, clamped to p_max
-    for (int i = tid; i < FA_KEYS * C4; i += 256) {
-      int kk = i & 31, c = i >> 5;                            // K: 32 keys x C4 d-chunks of 4 (keys contiguous in the cache)
-      int key = min(t0 + kk, p_max);
-      *(f32x4_t*)&Ksh[kk * LD + c * 4] = *(const f32x4_t*)(kc + (((size_t)kvh * C4 + c) * T_cap + key) * 4);
-      int d4 = i % C4, k2 = i / C4;                            // V: 32 keys x C4 float4 of a row
-      int key2 = min(t0 + k2, p_max);
-      *(f32x4_t*)&Vsh[k2 * LD + d4 * 4] = *(const f32x4_t*)(vc + ((size_t)kvh * T_cap + key2) * HD + d4 * 4);
+    if constexpr (!KV16) {
+      for (int i = tid; i < FA_KEYS * C4; i += 256) {
+        int kk = i & 31, c = i >> 5;                            // K: 32 keys x C4 d-chunks of 4 (keys contiguous in the cache)
+        int key = min(t0 + kk, p_max);
+        *(f32x4_t*)&Ksh[kk * LD + c * 4] = *(const f32x4_t*)(kc + (((size_t)kvh * C4 + c) * T_cap + key) * 4);
+        int d4 = i % C4, k2 = i / C4;                            // V: 32 keys x C4 float4 of a row
+        int key2 = min(t0 + k2, p_max);
+        *(f32x4_t*)&Vsh[k2 * LD + d4 * 4] = *(const f32x4_t*)(vc + ((size_t)kvh * T_cap + key2) * HD + d4 * 4);
+      }
+    } else {
+      // fp16 cache (dd_lm_kernels.h layouts): K chunks of 8 d, V pairs of keys x 4 d; expanded to fp32 in the staged tiles
+      constexpr int C8 = HD / 8;
+      for (int i = tid; i < FA_KEYS * C8; i += 256) {
+        int kk = i & 31, c = i >> 5;
+        int key = min(t0 + kk, p_max);
+        const f16x8_t kh = *(const f16x8_t*)((const dd_half*)kc + (((size_t)kvh * C8 + c) * T_cap + key) * 8);
+        *(f32x4_t*)&Ksh[kk * LD + c * 8] = (f32x4_t){(float)kh[0], (float)kh[1], (float)kh[2], (float)kh[3]};
+        *(f32x4_t*)&Ksh[kk * LD + c * 8 + 4] = (f32x4_t){(float)kh[4], (float)kh[5], (float)kh[6], (float)kh[7]};
+      }
+      for (int i = tid; i < (FA_KEYS / 2) * C4; i += 256) {
+        int d4 = i % C4, pr = i / C4;                          // pair pr = keys t0 + 2 pr, t0 + 2 pr + 1 (t0 is even)
+        int pair = min((t0 >> 1) + pr, p_max >> 1);
+        const f16x8_t vh = *(const f16x8_t*)((const dd_half*)vc + (size_t)kvh * T_cap * HD + ((size_t)pair * C4 + d4) * 8);
+        *(f32x4_t*)&Vsh[(2 * pr) * LD + d4 * 4] = (f32x4_t){(float)vh[0], (float)vh[1], (float)vh[2], (float)vh[3]};
+        *(f32x4_t*)&Vsh[(2 * pr + 1) * LD + d4 * 4] = (f32x4_t){(float)vh[4], (float)vh[5], (float)vh[6], (float)vh[7]};
+      }
     }
     __syncthreads();
     if (!wave_live || t0 > wave_pmax) continue;               // nothing for this wave in these keys (barriers above stay matched)
@@ -1765,8 +1845,9 @@ int ddk_prefill_mfma_enabled() { return g_prefill_mfma; }
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out) {
+                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out, int kv16) {
   int G = n_heads / n_kv;
+  DD_REQUIRE(!kv16 || (g_prefill_mfma && !xop_out), "attn_prefill: the fp16 KV cache is read by the matrix-core prefill attention only");
   dim3 grid(n_heads, (T + (q0 & (PF_QR - 1)) + 4 * PF_QR - 1) / (4 * PF_QR));
 #define PF_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, xop_out
   if (xop_out) {
@@ -1780,7 +1861,12 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
   if (g_prefill_mfma) {
     dim3 g2(n_heads, (T + (q0 & 15) + 63) / 64);
 #define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f
-    if (G == 1) k_attn_prefill_mfma<1><<<g2, 256, 0, st>>>(FA_ARGS);
+    if (kv16) {
+      if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
+      else if (G == 2) k_attn_prefill_mfma<2, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
+      else if (G == 4) k_attn_prefill_mfma<4, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
+      else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
+    } else if (G == 1) k_attn_prefill_mfma<1><<<g2, 256, 0, st>>>(FA_ARGS);
     else if (G == 2) k_attn_prefill_mfma<2><<<g2, 256, 0, st>>>(FA_ARGS);
     else if (G == 4) k_attn_prefill_mfma<4><<<g2, 256, 0, st>>>(FA_ARGS);
     else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
@@ -1929,12 +2015,12 @@ __global__ void k_chunk_positions(DDState* rows, const DDState* base, int n) {
 // the chunk's roped K rows / V rows [n][kv_dim] into the cache at positions base->T + i
 __global__ __launch_bounds__(256) void k_scatter_kv_rows(const float* __restrict__ kr, const float* __restrict__ vr, int kv_dim,
                                                          float* __restrict__ kc, float* __restrict__ vc, int T_cap,
-                                                         const DDState* base) {
+                                                         const DDState* base, int kv16) {
   const int row = blockIdx.x, T = base->T + row;
   for (int i = threadIdx.x; i < kv_dim; i += 256) {
     int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
-    kc[(((size_t)kvh * 32 + (idx >> 2)) * T_cap + T) * 4 + (idx & 3)] = kr[(size_t)row * kv_dim + i];
-    vc[((size_t)kvh * T_cap + T) * HEAD_DIM + idx] = vr[(size_t)row * kv_dim + i];
+    dd_kv_store(kc, vc, kv16, kvh, idx, T, T_cap, true, kr[(size_t)row * kv_dim + i]);
+    dd_kv_store(kc, vc, kv16, kvh, idx, T, T_cap, false, vr[(size_t)row * kv_dim + i]);
   }
 }
 int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t st) {
@@ -1943,8 +2029,8 @@ int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t s
   return DD_OK;
 }
 int ddk_scatter_kv_rows(const float* kr, const float* vr, int n, int kv_dim, float* kc, float* vc, int T_cap, const DDState* base,
-                        hipStream_t st) {
-  k_scatter_kv_rows<<<n, 256, 0, st>>>(kr, vr, kv_dim, kc, vc, T_cap, base);
+                        hipStream_t st, int kv16) {
+  k_scatter_kv_rows<<<n, 256, 0, st>>>(kr, vr, kv_dim, kc, vc, T_cap, base, kv16);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -1978,7 +2064,7 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStr
 __global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ knew, const float* __restrict__ vnew,
                                                    int rows_per_layer, int kv_dim, float* __restrict__ kc,
                                                    float* __restrict__ vc, size_t lsk, size_t lsv, int T_cap,
-                                                   const DDState* state, int use_winner) {
+                                                   const DDState* state, int use_winner, int kv16) {
   if (state->done) return;       // finished at EOS: a look-ahead step appends nothing
   int layer = blockIdx.x;
   int row = use_winner ? state->winner : 0;
@@ -1989,8 +2075,8 @@ __global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ kne
   float* vl = vc + (size_t)layer * lsv;
   for (int i = threadIdx.x; i < kv_dim; i += 256) {
     int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
-    kl[(((size_t)kvh * 32 + (idx >> 2)) * T_cap + T) * 4 + (idx & 3)] = kr[i];
-    vl[((size_t)kvh * T_cap + T) * HEAD_DIM + idx] = vr[i];
+    dd_kv_store(kl, vl, kv16, kvh, idx, T, T_cap, true, kr[i]);
+    dd_kv_store(kl, vl, kv16, kvh, idx, T, T_cap, false, vr[i]);
   }
 }
 // the same for up to 4 sequences in one launch: grid (layers, sequences)
@@ -2005,8 +2091,8 @@ __global__ __launch_bounds__(256) void k_commit_kv_lanes(CommitLanes t, int rows
   float* vl = t.vc[q] + (size_t)layer * t.lsv;
   for (int i = threadIdx.x; i < kv_dim; i += 256) {
     int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
-    kl[(((size_t)kvh * 32 + (idx >> 2)) * T_cap + T) * 4 + (idx & 3)] = kr[i];
-    vl[((size_t)kvh * T_cap + T) * HEAD_DIM + idx] = vr[i];
+    dd_kv_store(kl, vl, t.kv16, kvh, idx, T, T_cap, true, kr[i]);
+    dd_kv_store(kl, vl, t.kv16, kvh, idx, T, T_cap, false, vr[i]);
   }
 }
 int ddk_commit_kv_lanes(const CommitLanes& t, int n, int n_layers, int rows_per_layer, int kv_dim, int T_cap, hipStream_t st) {
@@ -2015,14 +2101,14 @@ int ddk_commit_kv_lanes(const CommitLanes& t, int n, int n_layers, int rows_per_
   return DD_OK;
 }
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
-                  float* vc, size_t lsk, size_t lsv, int T_cap, const DDState* state, int use_winner, hipStream_t st) {
-  k_commit_kv<<<n_layers, 256, 0, st>>>(knew, vnew, rows_per_layer, kv_dim, kc, vc, lsk, lsv, T_cap, state, use_winner);
+                  float* vc, size_t lsk, size_t lsv, int T_cap, const DDState* state, int use_winner, hipStream_t st, int kv16) {
+  k_commit_kv<<<n_layers, 256, 0, st>>>(knew, vnew, rows_per_layer, kv_dim, kc, vc, lsk, lsv, T_cap, state, use_winner, kv16);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 
 __global__ __launch_bounds__(256) void k_kv_sums(const float* kc, const float* vc, size_t lsk, size_t lsv, int n_kv,
-                                                 int T_cap, int T, double* out) {
+                                                 int T_cap, int T, double* out, int kv16) {
   __shared__ double sh[4];
   int layer = blockIdx.x, which = blockIdx.y;
   double acc = 0;
@@ -2031,8 +2117,7 @@ __global__ __launch_bounds__(256) void k_kv_sums(const float* kc, const float* v
     int t = (int)(i % T);
     size_t r = i / T;  // kvh*128 + idx
     int kvh = (int)(r / HEAD_DIM), idx = (int)(r % HEAD_DIM);
-    float v = which == 0 ? kc[(size_t)layer * lsk + (((size_t)kvh * 32 + (idx >> 2)) * T_cap + t) * 4 + (idx & 3)]
-                         : vc[(size_t)layer * lsv + ((size_t)kvh * T_cap + t) * HEAD_DIM + idx];
+    float v = dd_kv_load(kc + (size_t)layer * lsk, vc + (size_t)layer * lsv, kv16, kvh, idx, t, T_cap, which == 0);
     acc += (double)v;
   }
   acc = dd_wave_sum_d(acc);
@@ -2041,8 +2126,8 @@ __global__ __launch_bounds__(256) void k_kv_sums(const float* kc, const float* v
   if (threadIdx.x == 0) out[layer * 2 + which] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 int ddk_kv_sums(const float* kc, const float* vc, int n_layers, size_t lsk, size_t lsv, int n_kv, int T_cap, int T,
-                double* out, hipStream_t st) {
-  k_kv_sums<<<dim3(n_layers, 2), 256, 0, st>>>(kc, vc, lsk, lsv, n_kv, T_cap, T, out);
+                double* out, hipStream_t st, int kv16) {
+  k_kv_sums<<<dim3(n_layers, 2), 256, 0, st>>>(kc, vc, lsk, lsv, n_kv, T_cap, T, out, kv16);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -99,7 +99,7 @@ class DropoutEngine:
     def __init__(self, cfg: LMConfig, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
                  seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
                  iblip_positions: str = "cache", weight_format: str = "bf16", mask_method: str = "epis",
-                 use_avg: bool = False, share_weights_with: Optional["DropoutEngine"] = None):
+                 use_avg: bool = False, share_weights_with: Optional["DropoutEngine"] = None, kv_format: str = "fp32"):
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
@@ -109,6 +109,9 @@ class DropoutEngine:
         # remembered so that a lane over these weights can be created with the same behaviour (DropoutVLM.spawn_lane)
         self.max_seq, self.max_visual, self.use_random, self.iblip_positions = max_seq, max_visual, use_random, iblip_positions
         self.mask_method, self.use_avg = mask_method, use_avg
+        if kv_format not in ("fp32", "fp16"):
+            raise ValueError(f"kv_format {kv_format!r}: 'fp32' or 'fp16' (the reference's cache width)")
+        self.kv_format = kv_format
         fam = dict(_FAMILY[family])
         if family == FAMILY_NEXT and use_random:
             fam["mask_mode"] = MASK_NEXT_NO_OVERLAP           # settings['use_random'][0] (llavanext.py:547-550)
@@ -127,7 +130,7 @@ class DropoutEngine:
         c = _lib.LMConfigC(cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads,
                            cfg.num_kv_heads, cfg.head_dim, cfg.rms_eps, cfg.rope_theta, max_seq, max_visual,
                            fam["k_top"], fam["mask_mode"], fam["vote_on"], fam["leak_mask"],
-                           {"bf16": 0, "fp8": 1}[weight_format])
+                           {"bf16": 0, "fp8": 1}[weight_format], {"fp32": 0, "fp16": 1}[kv_format])
         self.weight_format = weight_format
         self._h = C.c_void_p()
         self.weight_owner = share_weights_with         # kept alive: a lane borrows the owner's weight memory

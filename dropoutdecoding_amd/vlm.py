@@ -199,7 +199,7 @@ class DropoutVLM:
         lane.engine = DropoutEngine(eng.cfg, family=eng.family, max_seq=eng.max_seq, max_visual=eng.max_visual,
                                     seed=eng.seed, use_random=eng.use_random, iblip_positions=eng.iblip_positions,
                                     weight_format=eng.weight_format, mask_method=eng.mask_method, use_avg=eng.use_avg,
-                                    share_weights_with=eng)
+                                    share_weights_with=eng, kv_format=eng.kv_format)
         lane.start_image_pos, lane.end_image_pos, lane.masked_numbers, lane.logits_mask_prob = [], [], [], []
         lane._prefix = None
         return lane
@@ -247,7 +247,8 @@ def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens:
                  use_random: bool = False, seed: Optional[int] = None) -> DropoutEngine:
     max_seq = max_visual + prompt_tokens + max_new_tokens + 8
     return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random,
-                         mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)))
+                         mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)),
+                         weight_format=settings.get("weight_format", "bf16"), kv_format=settings.get("kv_cache", "fp16"))
 
 
 @torch.no_grad()

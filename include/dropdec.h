@@ -154,7 +154,10 @@ typedef struct dd_lm_config {
   int32_t leak_mask;         /* InstructBLIP Q2: 1 = the un-masked pass sees the last member's zeros (positions from the
                                 cache length, transformers 5.x); 2 = additionally position = T - #zeros (the 4.44 rule) */
   int32_t weight_format;     /* 0 = bf16 matrices, 1 = OCP fp8 e4m3fn matrices + per-output-row fp32 scales (BASELINE config 5) */
-  int32_t reserved[4];
+  int32_t kv_format;         /* KV cache storage: 0 = fp32 (default), 1 = fp16 — the width the reference keeps its cache in
+                                (chair_test/chair_test.py:189-213: torch_dtype=float16): half the attention bytes; K/V are
+                                rounded to nearest-even when they enter the cache, attention arithmetic stays fp32 */
+  int32_t reserved[3];
 } dd_lm_config;
 
 typedef struct dd_lm dd_lm;
