@@ -812,36 +812,43 @@ template <int EPI, int TILES, int NG, int NP>
 __global__ __launch_bounds__(128 * NG) void k_gemv_finish(GemvArgs a, const float* __restrict__ part, const float* __restrict__ rstd_g,
                                                           int n_sets) {
   __shared__ float ssq_sh[16 * 8 * NG];
-  __shared__ float y_sh[EPI == EPI_QKV ? TILES * NG * 128 : 1];
+  __shared__ float rstd_sh[8 * NG];
   const int wg = blockIdx.x, tile0 = wg * TILES;
   const int et = threadIdx.x, eg = et >> 7, ml = et & 7, en = (et & 127) >> 3;
   const size_t ps = ((size_t)n_sets * TILES * NG) << 7;
-  float v[TILES][NP];
+  // one batch of requests: the thread's partial sums (and, for rotary tiles, its partner column's: n ^ 8), rstd, the
+  // epilogue's operands — a single memory round trip before the arithmetic
+  constexpr int NV = EPI == EPI_QKV ? 2 : 1;
+  float v[TILES][NV][NP];
 #pragma unroll
-  for (int tt = 0; tt < TILES; ++tt) {
-    const float* p0 = part + (((size_t)(tile0 + tt) * NG + eg) << 7) + dd_part_index(en, ml);
+  for (int tt = 0; tt < TILES; ++tt)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) v[tt][q] = p0[(size_t)q * ps];
-  }
+    for (int x = 0; x < NV; ++x) {
+      const float* p0 = part + (((size_t)(tile0 + tt) * NG + eg) << 7) + dd_part_index(x ? en ^ 8 : en, ml);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) v[tt][x][q] = p0[(size_t)q * ps];
+    }
+  if (a.ssq_in && et < 8 * NG) rstd_sh[et] = rstd_g[et];
   GroupsPre<TILES> pre;
   groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
-  float y_own[TILES];
+  float y_own[TILES][NV];
 #pragma unroll
-  for (int tt = 0; tt < TILES; ++tt) {
-    float y = 0.f;
-    if (NP == 8) {
+  for (int tt = 0; tt < TILES; ++tt)
 #pragma unroll
-      for (int q = 0; q < 8; q += 2) y += v[tt][q] + v[tt][q + 1];
-    } else {
+    for (int x = 0; x < NV; ++x) {
+      float y = 0.f;
+      if (NP == 8) {
 #pragma unroll
-      for (int q = 0; q < NP; ++q) y += v[tt][q];
+        for (int q = 0; q < 8; q += 2) y += v[tt][x][q] + v[tt][x][q + 1];
+      } else {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) y += v[tt][x][q];
+      }
+      y_own[tt][x] = y;
     }
-    y_own[tt] = y;
-    if (EPI == EPI_QKV) y_sh[(tt * NG + eg) * 128 + en * 8 + ml] = y;    // the rotary partner (n ^ 8) reads it from here
-  }
-  if (EPI == EPI_QKV) __syncthreads();
-  auto tile_sum = [&](int tt, int n) -> float { return (EPI == EPI_QKV && n != en) ? y_sh[(tt * NG + eg) * 128 + n * 8 + ml] : y_own[tt]; };
-  groups_epilogue<EPI, TILES, NG>(a, wg, pre, rstd_g, ssq_sh, tile_sum);
+  __syncthreads();                                   // rstd_sh
+  auto tile_sum = [&](int tt, int n) -> float { return (NV == 2 && n != en) ? y_own[tt][NV - 1] : y_own[tt][0]; };
+  groups_epilogue<EPI, TILES, NG>(a, wg, pre, rstd_sh, ssq_sh, tile_sum);
 }
 
 template <int EPI, int TILES, int NG, int FP8>
@@ -906,8 +913,9 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
     RC_(launch_slices_k<2, NG, 8, 16, 16, 1>(sa, st));
     launch_finish<EPI_QKV, 1, NG, 8>(a, nt, st);
   } else if (epi == EPI_RESID) {
-    // o_proj at two planes: the wave-split kernel is as fast (10.3 vs 11.2 us measured), one launch instead of two
-    if (a.part_floats < need8 || (spw == 16 && NG == 2)) return SLICES_UNSUPPORTED;
+    // K = 4096 (o_proj): the wave-split kernel in one launch is as fast as slices + finish (13.5 vs 14.2 us at four planes,
+    // 10.3 vs 11.2 at two: 33 MB of weights do not amortise a second launch); the long-K matrix (down) gains 30 %
+    if (a.part_floats < need8 || spw == 16) return SLICES_UNSUPPORTED;
     sa.n_groups = nt;
     sa.G = (nt + 7) / 8;                                             // one tile per wave
     if (spw == 16) RC_(launch_slices_k<1, NG, 8, 16, 16, 1>(sa, st));
