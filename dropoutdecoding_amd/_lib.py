@@ -17,7 +17,7 @@ SYMBOLS = [
     "dd_lm_prefill", "dd_lm_prefill_ensemble", "dd_lm_truncate", "dd_lm_prefill_extend", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_set_eos", "dd_lm_step_algorithmic_bytes",
-    "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench", "dd_persist_read_bench",
+    "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench",
     "dd_vit_create", "dd_vit_destroy", "dd_vit_load_tensor", "dd_vit_forward",
 ]
 
@@ -119,11 +119,6 @@ def load() -> C.CDLL:
     lib.dd_vit_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     lib.dd_vit_forward.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
-    lib.dd_persist_read_bench.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                          C.c_int, C.POINTER(C.c_float), vp]
-    for kv in filter(None, os.environ.get("DD_TUNE", "").split(",")):     # e.g. DD_TUNE="13=0,12=0" (dd_set_tuning keys)
-        k, v = kv.split("=")
-        lib.dd_set_tuning(int(k), int(v))
     if os.environ.get("DD_NO_GRAPH", "0") not in ("", "0"):
         lib.dd_set_tuning(8, 0)          # launch every decode step kernel by kernel instead of replaying hipGraphs
     _lib = lib

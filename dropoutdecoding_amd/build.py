@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libdropdec.so")
-SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_engine.hip", "dd_vision.hip", "dd_persist.hip"]
+SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_engine.hip", "dd_vision.hip"]
 HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_gemv_slices.h", os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
 

@@ -42,7 +42,7 @@ int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, const int32
 int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, const int32_t* const* gates, int n, int K, hipStream_t st);
 static unsigned long long g_lm_serial = 0;   // handles are identified in graph keys by a serial that is never reused
 
-#define MAX_MEMBERS 16
+#define MAX_MEMBERS DD_MAX_MEMBERS
 #define KV_ROWS 32        // new K/V rows kept per layer: 16 members, or the base rows of up to 32 lanes (group step)
 #define MAX_NEW_TOKENS 8192
 
@@ -171,6 +171,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DD_REQUIRE(G == 1 || G == 2 || G == 4, "dd_lm_create: GQA group %d unsupported", G);
   DD_REQUIRE((c->num_heads * 128) % 256 == 0, "dd_lm_create: num_heads*128 must be a multiple of 256");
   DD_REQUIRE(c->max_seq >= 2 && c->max_visual >= 1 && c->max_visual <= 8192, "dd_lm_create: bad max_seq/max_visual");
+  DD_REQUIRE(c->max_seq <= 160 * 64, "dd_lm_create: max_seq %d exceeds the decode attention's %d key tiles of 64", c->max_seq, 160);
   DD_REQUIRE(c->k_top >= 1 && c->k_top <= DD_MAX_TOPK, "dd_lm_create: k_top out of range");
   DD_REQUIRE(c->mask_mode >= 0 && c->mask_mode <= 4, "dd_lm_create: mask_mode");
   DD_REQUIRE(c->vote_on >= 0 && c->vote_on <= 2, "dd_lm_create: vote_on");
@@ -1897,7 +1898,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 4) || (key >= 8 && key <= 14), "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4 && key != 3) || (key >= 8 && key <= 14), "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 10) ddk_set_attn_split(value);
   else if (key == 11) dd_engine_set_extend_rows(value);

@@ -136,7 +136,6 @@ struct GemvArgs {
   const int32_t* skip_if;   // optional (k_gemv): *skip_if != 0 -> the launch returns at once (fallback sweep of a speculative step)
   float* part;          // scratch for the slice-resident path (dd_gemv_slices.h): partial sums, or nullptr (then k_gemv_groups runs)
   size_t part_floats;   // capacity; 64 more floats behind it hold rstd of the operand rows
-  int diag;             // timing diagnostics only (dd_set_tuning key 3): 2 = no rstd prologue, 4 = no epilogue, 8 = no epilogue prefetch
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
 int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2 or 4) groups of up to 8 rows (bf16 weights)

@@ -228,7 +228,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   if (a.skip_if && *a.skip_if) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = a.S, spw = S / GEMV_WAVES;
-  constexpr bool DIAG = (ILV == 3);          // timing-only build: x operand := the weight tile (no L2 x traffic)
   const int s0 = ILV ? wave : wave * spw;
   constexpr int SS = ILV ? GEMV_WAVES : 1;   // step stride of this wave
   const int tile0 = blockIdx.x * TILES;
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   // input + next norm weight (EPI_RESID) and the rotary cos/sin (EPI_QKV).  The sum-of-squares slots are only
   // REQUESTED here; they are reduced after the first weight batch has been issued (loads return in order, so waiting
   // on them does not wait on the weights behind them).
-  const bool has_ssq = a.ssq_in && !(a.diag & 2);
+  const bool has_ssq = a.ssq_in != nullptr;
   f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
   // row `wave`'s slots are contiguous: one 16-byte load per lane covers 256 slots (every workgroup of the launch reads
   // these same few lines, so the request count matters: strided 4-byte reads here cost ~2 us per launch)
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   float pre0 = 0.f, pre1 = 0.f;
   {
     const int em = threadIdx.x & 7, en = threadIdx.x >> 3;
-    if (threadIdx.x < 128 && em < a.nb && !(a.diag & 8)) {
+    if (threadIdx.x < 128 && em < a.nb) {
       if (EPI == EPI_RESID) {
         pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
         pre1 = a.normw_next[tile0 * 16 + en];
@@ -338,7 +337,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
-        b[u] = DIAG ? w[0][u] : xp[(size_t)(s + u) * SS * 64];
+        b[u] = xp[(size_t)(s + u) * SS * 64];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -407,27 +406,12 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       if (s + U + u < n) use(u);
   }
 
-  if (a.diag & 4) {
-    if (acc[0].x == 1234.5f) a.out[0] = 0.f;
-    return;
-  }
 #pragma unroll
   for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
   __syncthreads();
 
   // D[n][c]: lane = (n>>2)*16 + c, reg = n&3.  y[m][n] = sum_w (D_w[n][m] + D_w[n][m+8])   (hi + lo columns)
   const int t = threadIdx.x;
-  if (a.diag & 32) {   // timing only: LDS reduce + arithmetic, no global stores
-    float y = 0.f;
-    if (t < 128) {
-      const float* r = &red[0];
-      int o = (((t >> 3) >> 2) * 16 + (t & 7)) * 4 + ((t >> 3) & 3);
-#pragma unroll
-      for (int w = 0; w < TILES * GEMV_WAVES; ++w) y += r[w * 256 + o] + r[w * 256 + o + 32];
-    }
-    if (y == 1234.5f) a.out[0] = y;
-    return;
-  }
   // fixed order: (hi + lo) per wave, waves added in pairs, pairs in sequence — the order the slice-resident kernels
   // reproduce from partial sums (dd_gemv_slices.h): y = sum_p ((hi+lo)(2p) + (hi+lo)(2p+1))
   auto tile_sum = [&](int tt, int n, int m) -> float {
@@ -511,22 +495,19 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   }
 }
 
-// tuning knobs (dd_set_tuning): 0 = U (4/8/16), 3 = timing diagnostics, 4 = ring (1) or batch (0) request order.
+// tuning knobs (dd_set_tuning): 0 = U (4/8/16), 4 = ring (1) or batch (0) request order.
 // Keys 1 (non-temporal loads) and 2 (k-step interleave) are settled at 1 and kept only as accepted no-ops.
-static int g_gemv_u = 8, g_gemv_diag = 0, g_gemv_pipe = 0;
+static int g_gemv_u = 8, g_gemv_pipe = 0;
 void ddk_set_tuning(int key, int value) {
   if (key == 0) g_gemv_u = value;
-  else if (key == 3) g_gemv_diag = value;
   else if (key == 4) g_gemv_pipe = value;
 }
 
 template <int EPI, int TILES>
 static void launch_gemv(const GemvArgs& a_, hipStream_t st) {
-  GemvArgs a = a_;
-  a.diag = g_gemv_diag & ~1;
+  const GemvArgs& a = a_;
 #define GV(U_, P_) k_gemv<EPI, TILES, U_, 1, 1, 0, P_><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a)
   if (a.fp8) { k_gemv<EPI, TILES, 8, 1, 1, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }
-  if (g_gemv_diag & 1) { k_gemv<EPI, TILES, 8, 1, 3><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }  // diagnostic: no x-operand loads
   const int u = g_gemv_u;
   if (g_gemv_pipe) { if (u == 4) GV(4, 1); else if (u == 16) GV(16, 1); else GV(8, 1); }
   else { if (u == 4) GV(4, 0); else if (u == 16) GV(16, 0); else GV(8, 0); }
@@ -1303,33 +1284,37 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
   DD_REQUIRE(a.n_heads % a.n_kv == 0, "attn: heads %d not a multiple of kv heads %d", a.n_heads, a.n_kv);
   int G = a.n_heads / a.n_kv;
   DD_REQUIRE(G == 1 || G == 2 || G == 4, "attn: GQA group %d unsupported (1, 2, 4)", G);
+  int rc = DD_OK;                    // a launcher that refuses (too many key tiles, attribute failure) launches nothing
   if (a.n_lanes > 0 && a.lane_groups) {
     DD_REQUIRE((a.lane_groups == 2 || a.lane_groups == 4) && a.n_lanes == a.lane_groups && a.nb >= 1 && a.nb <= 8,
                "attn: a multi-group pass takes 2 or 4 sequences of up to 8 members");
     if (a.lane_groups == 2) {
-      if (G == 1) launch_attn_groups<1, 2>(a, st);
-      else if (G == 2) launch_attn_groups<2, 2>(a, st);
-      else launch_attn_groups<4, 2>(a, st);
+      if (G == 1) rc = launch_attn_groups<1, 2>(a, st);
+      else if (G == 2) rc = launch_attn_groups<2, 2>(a, st);
+      else rc = launch_attn_groups<4, 2>(a, st);
     } else {
-      if (G == 1) launch_attn_groups<1, 4>(a, st);
-      else if (G == 2) launch_attn_groups<2, 4>(a, st);
-      else launch_attn_groups<4, 4>(a, st);
+      if (G == 1) rc = launch_attn_groups<1, 4>(a, st);
+      else if (G == 2) rc = launch_attn_groups<2, 4>(a, st);
+      else rc = launch_attn_groups<4, 4>(a, st);
     }
+    if (rc != DD_OK) return rc;
     DD_CHECK_LAUNCH();
     return DD_OK;
   }
   if (a.n_lanes > 0) {
     DD_REQUIRE(a.n_lanes <= 16 && a.nb == a.n_lanes, "attn: %d lanes for %d rows", a.n_lanes, a.nb);
-    if (G == 1) launch_attn_lanes<1>(a, st);
-    else if (G == 2) launch_attn_lanes<2>(a, st);
-    else launch_attn_lanes<4>(a, st);
+    if (G == 1) rc = launch_attn_lanes<1>(a, st);
+    else if (G == 2) rc = launch_attn_lanes<2>(a, st);
+    else rc = launch_attn_lanes<4>(a, st);
+    if (rc != DD_OK) return rc;
     DD_CHECK_LAUNCH();
     return DD_OK;
   }
   bool one = a.nb == 1;
-  if (G == 1) one ? launch_attn<1, 1>(a, st) : launch_attn<8, 1>(a, st);
-  else if (G == 2) one ? launch_attn<1, 2>(a, st) : launch_attn<8, 2>(a, st);
-  else one ? launch_attn<1, 4>(a, st) : launch_attn<8, 4>(a, st);
+  if (G == 1) rc = one ? launch_attn<1, 1>(a, st) : launch_attn<8, 1>(a, st);
+  else if (G == 2) rc = one ? launch_attn<1, 2>(a, st) : launch_attn<8, 2>(a, st);
+  else rc = one ? launch_attn<1, 4>(a, st) : launch_attn<8, 4>(a, st);
+  if (rc != DD_OK) return rc;
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

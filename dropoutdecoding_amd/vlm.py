@@ -323,6 +323,8 @@ class GroupPipeline:
         kw = {"max_new_tokens": max_new_tokens, "eos_token_id": eos_token_id}
         it = iter(batches)
         first = next(it, None)
+        while first is not None and len(first) == 0:           # empty batches (a trailing [] of a batching generator) are skipped
+            first = next(it, None)
         cur = self._stage(self.sets[0], first, kw) if first is not None else None
         k = 0
         while cur is not None:
@@ -331,6 +333,10 @@ class GroupPipeline:
             lanes, prepared = cur["lanes"], cur["prepared"]
             lanes[0].engine.torch_stream.wait_event(cur["event"])
             nb = next(it, None)
+            while nb is not None and len(nb) == 0:
+                nb = next(it, None)
+            if nb is not None and len(nb) > len(self.sets[0]):
+                raise ValueError(f"a batch of {len(nb)} images for {len(self.sets[0])} lanes")
             k += 1
             nxt = self._stage(self.sets[k % 2], nb, kw) if nb is not None else None
             dropout = not lanes[0].original

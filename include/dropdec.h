@@ -36,6 +36,8 @@ extern "C" {
 #define DD_ESTATE (-4)     /* call sequence error (e.g. decode before prefill) */
 
 #define DD_MAX_MEMBERS_PER_PASS 8   /* ensemble members packed into one weight sweep */
+#define DD_MAX_MEMBERS 16           /* K = len(settings['voting_numbers']) per decode step: 1..16 (two packed sweeps); the
+                                     * reference accepts any list length (models/llava.py:340) but ships 3 and 4, BASELINE uses 8 */
 #define DD_MAX_TOPK 16
 
 /* mask-sampler modes: which family's get_image_attention_mask() semantics to follow */
@@ -370,7 +372,6 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
 
 /* Kernel tuning knobs for the benchmark scripts: key 0 = GEMV weight tiles in flight per wave (4/8/16),
  * 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves of a workgroup (0/1),
- * 3 = timing-only diagnostic build without x-operand loads (results are wrong; never use for output),
  * 4 = ring (1) or batch (0, default) request order in the 8-row GEMV,
  * 8 = replay decode steps from a hipGraph (default 1), 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4;
  * default 4), 10 = workgroups per group of 8 members in the grouped decode attention (1, 2, 4; default 1),
@@ -391,13 +392,6 @@ int dd_set_tuning(int key, int value);
  *   deterministic masks or K == 0).  The owner may itself be one of the lanes. */
 int dd_lm_create_shared(const dd_lm_config* cfg, dd_lm* weights_from, dd_lm** out);
 int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream);
-
-/* Measurement hook: stream `n_layers` x `n_phases` weight slabs the way one decode sweep does, either as one launch per
- * phase (mode 0, `grid` workgroups of 512 threads), or as ONE resident kernel with a grid barrier per phase (mode 1), or
- * the same with the next phase's first loads issued before the barrier (mode 2).  ms_out = mean time of one sweep.
- * Nothing in the reference corresponds to it; tools/persist_probe.py uses it to size the persistent-sweep design. */
-int dd_persist_read_bench(const void* buf_dev, size_t layer_stride_bytes, const size_t* phase_bytes, int n_phases,
-                          int n_layers, int mode, int grid, int U, int iters, float* ms_out, void* stream);
 
 #ifdef __cplusplus
 }

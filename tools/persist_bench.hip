@@ -1,3 +1,5 @@
+// Measurement code of round 1 (persistent-sweep sizing): NOT part of libdropdec.so any more.
+// Kept as a record; to run it, compile it next to the library sources and bind dd_persist_read_bench by hand.
 // Persistent-sweep experiments (measurement hooks, not part of the reference's surface).
 //
 // Question this file answers with numbers: the decode sweep is ~170 dependent kernel launches whose weight streams each
