@@ -21,8 +21,13 @@ settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap
 #                                               with torch_dtype=float16, chair_test.py:189-213); K/V are rounded when they enter
 #                                               the cache, the attention arithmetic stays fp32.  Goldens + 24-step oracle runs:
 #                                               tokens / masks / votes exact, logits <= 1.7e-4 of max|logit| (tests/test_gpu_kv_fp16.py)
-#   settings['weight_format'] = 'bf16' (default) | 'fp8' -> LM matrices stored as OCP fp8 e4m3fn + per-row scales (BASELINE config 5:
-#                                               "fp8 MFMA weights"); quantised on load by lm.quantize_fp8
+#   settings['weight_format'] = 'auto' (default) | 'fp16' | 'bf16' | 'fp8' -> storage of the LM matrices.  'auto': fp16 when the
+#                                               checkpoint's LM tensors are float16 (from_pretrained loads with torch_dtype=float16
+#                                               like the reference), else bf16.  'fp16': fp16-native checkpoints stay exact, products
+#                                               on the f16 MFMA (vs the fp32 oracle on an fp16-valued checkpoint: logits 2e-6, tokens
+#                                               and masks exact); 'bf16' rounds them to bf16 (3 mantissa bits less: logits move by
+#                                               5e-3, masks and tokens drift — tests/test_gpu_fp16_weights.py);
+#                                               'fp8': OCP e4m3fn + per-row scales (BASELINE config 5), quantised by lm.quantize_fp8
 
 # K = 8 is not reachable from the reference CLI (chair_test.py:163-175); BASELINE configs 3-5 use this list.
 VOTING_NUMBERS_K8 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]

@@ -38,6 +38,7 @@ void dd_set_error(const char* fmt, ...);
   } while (0)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 dd_f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
@@ -55,12 +56,43 @@ __device__ __forceinline__ void dd_split_hl(float x, uint32_t& hi, uint32_t& lo)
   hi = dd_bf16_rn(x);
   lo = dd_bf16_rn(x - dd_bf16_to_f32(hi));
 }
+// The same for engines that keep fp16 weights (weight_format 2: fp16-native checkpoints stay exact — the reference loads
+// every model with torch_dtype=float16, chair_test/chair_test.py:189-213): operands of the f16 MFMA.  hi + lo carries
+// ~22 mantissa bits; |x| beyond fp16's range saturates (the reference's own fp16 activations live in that range).
+typedef _Float16 dd_f16;
+__device__ __forceinline__ uint32_t dd_f16_bits(float x) {
+  dd_f16 h = (dd_f16)fminf(fmaxf(x, -65504.f), 65504.f);
+  return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float dd_f16_to_f32(uint32_t b) { return (float)__builtin_bit_cast(dd_f16, (unsigned short)b); }
+__device__ __forceinline__ void dd_split_hl_f16(float x, uint32_t& hi, uint32_t& lo) {
+  hi = dd_f16_bits(x);
+  lo = dd_f16_bits(x - dd_f16_to_f32(hi));
+}
+// wf: the engine's 16-bit weight type (0 bf16, 1 fp16); activations are split in the same type
+__device__ __forceinline__ void dd_split(float x, uint32_t& hi, uint32_t& lo, int wf) {
+  // x becomes an opaque register value first: hipcc's default -ffp-contract=fast may otherwise fuse the multiplication that
+  // produced x with the `x - hi` below into an fma in one kernel and not in another (it did, once `wf` was a template
+  // constant in some kernels and a run-time value in others), and the same value must split identically everywhere —
+  // rows are bit-identical across the 8 / 16 / 32-row kernels only if their operands are
+  asm volatile("" : "+v"(x));
+  if (wf) dd_split_hl_f16(x, hi, lo);
+  else dd_split_hl(x, hi, lo);
+}
+__device__ __forceinline__ float dd_w16_to_f32(uint32_t b, int wf) { return wf ? dd_f16_to_f32(b) : dd_bf16_to_f32(b); }
 
 // Prefill activations are stored in the SAME 16x32 operand-tile order as the weights: element (row m, col k) of a
 // [M][K] plane lives at u16 offset (((m/16)*S + k/32)*64 + ((k%32)/8)*16 + m%16)*8 + k%8, S = K/32, so every A
 // fragment of the prefill GEMM is one contiguous 1 KiB wave load (guide: fragment-shaped row-major loads cost 18-45 %).
 __device__ __forceinline__ size_t apack_off(int m, int k, int S) {
   return ((((size_t)(m >> 4) * S + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (m & 15)) << 3) + (k & 7);
+}
+
+// 16x16x32 MFMA on 16-bit operand tiles of the engine's weight type
+template <int WF>
+__device__ __forceinline__ f32x4_t dd_mfma16(u32x4_t a, u32x4_t b, f32x4_t c) {
+  if constexpr (WF) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dd_f16x8_t, a), __builtin_bit_cast(dd_f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float dd_wave_max(float v) {

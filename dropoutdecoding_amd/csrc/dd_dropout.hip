@@ -80,7 +80,7 @@ __device__ float block_max_f(float v, float* sh) {
 //   pass A: per row softmax statistics (max, sum exp) + top-k ids        (llava.py:722, 428-441)
 //   pass B: partial column sums of p over row chunks, B2 combine -> p_avg (llava.py:732)
 //   pass C: per row epi / alea / var                                      (llava.py:728,735-739)
-// HBM-bound: 3 reads of the [L][V] fp32 logits; rows are streamed with 16-byte loads.
+// HBM-bound: 3 reads of the [L][V] fp32 logits (pass A keeps its row in LDS: k_row_stats_topk_lds).
 // ----------------------------------------------------------------------------------------------
 #define UNC_THREADS 512
 #define UNC_LSPLIT 8
@@ -104,6 +104,55 @@ __global__ __launch_bounds__(UNC_THREADS) void k_row_stats_topk(const float* __r
     row_sum[blockIdx.x] = (float)s;
   }
   // top-k by repeated "next in (value desc, index asc) order" selection; the row is L2-resident
+  float pv = INFINITY;
+  int pi = -1;
+  for (int j = 0; j < k_top; ++j) {
+    ArgMax a = {-INFINITY, 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += UNC_THREADS) {
+      float xv = x[v];
+      bool after = (xv < pv) || (xv == pv && v > pi);
+      if (after && better(xv, v, a.v, a.i)) {
+        a.v = xv;
+        a.i = v;
+      }
+    }
+    a = block_argmax(a, sh_am);
+    pv = a.v;
+    pi = a.i;
+    if (threadIdx.x == 0) {
+      if (topk_vals) topk_vals[(size_t)blockIdx.x * k_top + j] = a.v;
+      if (topk_ids) topk_ids[(size_t)blockIdx.x * k_top + j] = a.i;
+    }
+  }
+}
+
+// The same pass with the row held in LDS: one workgroup reads its row from memory ONCE (16-byte loads; 125 KiB at V = 32064
+// fit the CU's 160 KiB) and takes max, sum-exp and the k_top selection sweeps from LDS — the [L][V] logits are read once
+// here instead of 2 + k_top times.  Same arithmetic, same order: results identical to k_row_stats_topk.
+__global__ __launch_bounds__(UNC_THREADS) void k_row_stats_topk_lds(const float* __restrict__ logits, int V, int ld,
+                                                                    float* __restrict__ row_max, float* __restrict__ row_sum,
+                                                                    int k_top, float* __restrict__ topk_vals,
+                                                                    int32_t* __restrict__ topk_ids) {
+  extern __shared__ __align__(16) float row_sh[];
+  __shared__ ArgMax sh_am[16];
+  __shared__ double sh_d[16];
+  __shared__ float sh_f[16];
+  const float* xg = logits + (size_t)blockIdx.x * ld;
+  const int V4 = V >> 2;
+  for (int i = threadIdx.x; i < V4; i += UNC_THREADS) *(f32x4_t*)&row_sh[4 * i] = *(const f32x4_t*)(xg + 4 * i);
+  for (int v = 4 * V4 + threadIdx.x; v < V; v += UNC_THREADS) row_sh[v] = xg[v];
+  __syncthreads();
+  const float* x = row_sh;
+  float m = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += UNC_THREADS) m = fmaxf(m, x[v]);
+  m = block_max_f(m, sh_f);
+  double s = 0;
+  for (int v = threadIdx.x; v < V; v += UNC_THREADS) s += (double)expf(x[v] - m);
+  s = block_sum_d(s, sh_d);
+  if (threadIdx.x == 0) {
+    row_max[blockIdx.x] = m;
+    row_sum[blockIdx.x] = (float)s;
+  }
   float pv = INFINITY;
   int pi = -1;
   for (int j = 0; j < k_top; ++j) {
@@ -218,7 +267,17 @@ extern "C" int dd_vision_uncertainty(const float* logits, int L, int V, int ld, 
   float* row_sum = (float*)(base + a);
   float* p_avg = (float*)(base + 2 * a);
   double* partial = (double*)(base + 2 * a + p);
-  k_row_stats_topk<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, row_max, row_sum, k_top, topk_vals, topk_ids);
+  const size_t row_bytes = (size_t)V * sizeof(float);
+  if (row_bytes <= 150 * 1024 && (ld & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
+    static bool attr = false;
+    if (!attr) {
+      DD_HIP(hipFuncSetAttribute((const void*)k_row_stats_topk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr = true;
+    }
+    k_row_stats_topk_lds<<<L, UNC_THREADS, row_bytes, st>>>(logits, V, ld, row_max, row_sum, k_top, topk_vals, topk_ids);
+  } else {
+    k_row_stats_topk<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, row_max, row_sum, k_top, topk_vals, topk_ids);
+  }
   DD_CHECK_LAUNCH();
   k_col_partial<<<dim3((V + 255) / 256, UNC_LSPLIT), 256, 0, st>>>(logits, L, V, ld, row_max, row_sum, partial);
   DD_CHECK_LAUNCH();

@@ -70,6 +70,7 @@ struct dd_lm {
   u32x4_t* lm_head = nullptr;
   float* s_lm = nullptr;
   int fp8 = 0;                 // weight storage: 0 bf16, 1 OCP e4m3fn + per-row scales
+  int wf = 0;                  // 16-bit weight / operand type: 0 bf16, 1 fp16 (weight_format 2: fp16 checkpoints stay exact)
   int kv16 = 0;                // KV cache storage: 0 fp32, 1 fp16 (the reference's cache width; layouts in dd_lm_kernels.h)
   u32x4_t* deq_tmp = nullptr;  // fp8: bf16 tiles of ONE matrix for the prefill GEMM
   float* final_norm = nullptr;
@@ -185,9 +186,10 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   h->q_tiles = h->q_dim / 16, h->k_tiles = h->kv_dim / 16, h->qkv_tiles = (h->q_dim + 2 * h->kv_dim) / 16;
   const int d = h->d, dff = h->dff, T = h->T_cap;
   h->fp8 = c->weight_format == 1 ? 1 : 0;
+  h->wf = c->weight_format == 2 ? 1 : 0;
   h->kv16 = c->kv_format == 1 ? 1 : 0;
   DD_REQUIRE(c->kv_format == 0 || c->kv_format == 1, "dd_lm_create: unknown KV cache format %d", c->kv_format);
-  DD_REQUIRE(c->weight_format == 0 || c->weight_format == 1, "dd_lm_create: unknown weight format %d", c->weight_format);
+  DD_REQUIRE(c->weight_format >= 0 && c->weight_format <= 2, "dd_lm_create: unknown weight format %d", c->weight_format);
   const int wdiv = h->fp8 ? 2 : 1;   // u32x4 units per tile row: S*64 (bf16) or (S/2)*64 (fp8)
   if (parent) {
     // a lane: another sequence over the SAME weights (its own KV cache, state and scratch)
@@ -377,9 +379,9 @@ extern "C" int dd_lm_load_tensor(dd_lm* h, int id, int layer, const uint16_t* sr
   LayerW* w = per_layer ? &h->lw[layer] : nullptr;
   switch (id) {
     case DD_T_EMBED: rc = hipMemcpy(h->embed, dev, n * 2, hipMemcpyDeviceToDevice) == hipSuccess ? DD_OK : DD_EHIP; break;
-    case DD_T_ATTN_NORM: rc = ddk_bf16_to_f32(dev, w->norm1, d, nullptr); break;
-    case DD_T_MLP_NORM: rc = ddk_bf16_to_f32(dev, w->norm2, d, nullptr); break;
-    case DD_T_FINAL_NORM: rc = ddk_bf16_to_f32(dev, h->final_norm, d, nullptr); break;
+    case DD_T_ATTN_NORM: rc = ddk_bf16_to_f32(dev, w->norm1, d, nullptr, h->wf); break;
+    case DD_T_MLP_NORM: rc = ddk_bf16_to_f32(dev, w->norm2, d, nullptr, h->wf); break;
+    case DD_T_FINAL_NORM: rc = ddk_bf16_to_f32(dev, h->final_norm, d, nullptr, h->wf); break;
     case DD_T_WQ: rc = ddk_pack_weight(dev, rows, cols, w->wqkv, 0, 1, PACK_ROPE, h->q_tiles, nullptr); break;
     case DD_T_WK: rc = ddk_pack_weight(dev, rows, cols, w->wqkv, h->q_tiles, 1, PACK_ROPE, h->k_tiles, nullptr); break;
     case DD_T_WV: rc = ddk_pack_weight(dev, rows, cols, w->wqkv, h->q_tiles + h->k_tiles, 1, PACK_PLAIN, h->k_tiles, nullptr); break;
@@ -477,16 +479,16 @@ extern "C" int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std) {
   uint32_t s = seed * 2654435761u + 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
-    RC(ddk_fill_synthetic((uint16_t*)w.wqkv, (size_t)h->qkv_tiles * h->S_d * 512, s++, std, nullptr));
-    RC(ddk_fill_synthetic((uint16_t*)w.wo, (size_t)(d / 16) * h->S_q * 512, s++, std, nullptr));
-    RC(ddk_fill_synthetic((uint16_t*)w.wgu, (size_t)(2 * dff / 16) * h->S_d * 512, s++, std, nullptr));
-    RC(ddk_fill_synthetic((uint16_t*)w.wdown, (size_t)(d / 16) * h->S_ff * 512, s++, std, nullptr));
+    RC(ddk_fill_synthetic((uint16_t*)w.wqkv, (size_t)h->qkv_tiles * h->S_d * 512, s++, std, nullptr, h->wf));
+    RC(ddk_fill_synthetic((uint16_t*)w.wo, (size_t)(d / 16) * h->S_q * 512, s++, std, nullptr, h->wf));
+    RC(ddk_fill_synthetic((uint16_t*)w.wgu, (size_t)(2 * dff / 16) * h->S_d * 512, s++, std, nullptr, h->wf));
+    RC(ddk_fill_synthetic((uint16_t*)w.wdown, (size_t)(d / 16) * h->S_ff * 512, s++, std, nullptr, h->wf));
     RC(ddk_fill_const_f32(w.norm1, d, 1.0f, nullptr));
     RC(ddk_fill_const_f32(w.norm2, d, 1.0f, nullptr));
   }
-  RC(ddk_fill_synthetic((uint16_t*)h->lm_head, (size_t)(h->Vpad / 16) * h->S_d * 512, s++, std, nullptr));
+  RC(ddk_fill_synthetic((uint16_t*)h->lm_head, (size_t)(h->Vpad / 16) * h->S_d * 512, s++, std, nullptr, h->wf));
   RC(ddk_fill_const_f32(h->final_norm, d, 1.0f, nullptr));
-  RC(ddk_fill_synthetic(h->embed, (size_t)h->V * d, s++, 1.0f, nullptr));
+  RC(ddk_fill_synthetic(h->embed, (size_t)h->V * d, s++, 1.0f, nullptr, h->wf));
   DD_HIP(hipDeviceSynchronize());
   return DD_OK;
 }
@@ -681,9 +683,10 @@ static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_
   };
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
-    RC(ddk_rmsnorm_split(h->px, T0, d, w.norm1, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st));
+    RC(ddk_rmsnorm_split(h->px, T0, d, w.norm1, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st, h->wf));
     GemmArgs g;
     memset(&g, 0, sizeof(g));
+    g.wf = h->wf;
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.n_tiles = h->qkv_tiles;
     RC(wsel(g, w.wqkv, w.s_qkv, h->qkv_tiles, h->S_d));
     g.qbuf = h->pq, g.kc = h->kc + (size_t)l * h->lsk, g.vc = h->vc + (size_t)l * h->lsv, g.T_cap = h->T_cap;
@@ -691,18 +694,21 @@ static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_
     g.rope_cos = h->rope_cos, g.rope_sin = h->rope_sin;
     RC(ddk_gemm(EPI_QKV, g, st));
     RC(ddk_attn_prefill(h->pq, g.kc, g.vc, T0, h->T_cap, h->H, h->Hkv, h->p1_hi, h->p1_lo, drop_plane, drop_bit,
-                        span_start, span_len, pos0, st, nullptr, h->kv16));
+                        span_start, span_len, pos0, st, nullptr, h->kv16, h->wf));
     memset(&g, 0, sizeof(g));
+    g.wf = h->wf;
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_q, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
     RC(wsel(g, w.wo, w.s_o, d / 16, h->S_q));
     RC(ddk_gemm(EPI_RESID, g, st));
-    RC(ddk_rmsnorm_split(h->px, T0, d, w.norm2, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st));
+    RC(ddk_rmsnorm_split(h->px, T0, d, w.norm2, h->cfg.rms_eps, h->p1_hi, h->p1_lo, nullptr, nullptr, st, h->wf));
     memset(&g, 0, sizeof(g));
+    g.wf = h->wf;
     g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = T0, g.S = h->S_d, g.n_tiles = 2 * dff / 16;
     RC(wsel(g, w.wgu, w.s_gu, 2 * dff / 16, h->S_d));
     g.o_hi = h->p2_hi, g.o_lo = h->p2_lo, g.ld_planes = dff;
     RC(ddk_gemm(EPI_SILU, g, st));
     memset(&g, 0, sizeof(g));
+    g.wf = h->wf;
     g.a_hi = h->p2_hi, g.a_lo = h->p2_lo, g.M = T0, g.S = h->S_ff, g.n_tiles = d / 16, g.out = h->px, g.ldo = d;
     RC(wsel(g, w.wdown, w.s_down, d / 16, h->S_ff));
     RC(ddk_gemm(EPI_RESID, g, st));
@@ -715,9 +721,10 @@ static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_
 static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* logits, hipStream_t st,
                         const float* src = nullptr) {
   const int d = h->d;
-  RC(ddk_rmsnorm_split(src ? src : h->px, n_rows, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, row_index, h->pq, st));
+  RC(ddk_rmsnorm_split(src ? src : h->px, n_rows, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, row_index, h->pq, st, h->wf));
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.wf = h->wf;
   g.a_hi = h->p1_hi, g.a_lo = h->p1_lo, g.M = n_rows, g.S = h->S_d, g.n_tiles = h->Vpad / 16;
   if (!h->fp8) {
     g.W = h->lm_head;
@@ -800,7 +807,7 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
     return ddk_gemv_groups(epi, a, st);
   };
   RC(ddk_chunk_positions(h->chunk_states, h->state, n, st));
-  RC(ddk_pack_embed_rows(embeds, n, cap, d, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  RC(ddk_pack_embed_rows(embeds, n, cap, d, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
@@ -808,6 +815,7 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
     float* vc = h->vc + (size_t)l * h->lsv;
     GemvArgs a;
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.knew = h->chunk_k, a.vnew = h->chunk_v, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
@@ -822,6 +830,7 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
       const int nr = n - r0 < 16 ? n - r0 : 16;
       AttnDecodeArgs t;
       memset(&t, 0, sizeof(t));
+      t.wf = h->wf;
       t.qbuf = h->qbuf + (size_t)r0 * h->q_dim, t.T_cap = h->T_cap, t.nb = nr, t.n_heads = h->H, t.n_kv = h->Hkv, t.kv16 = h->kv16;
       t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q + (size_t)(r0 / 8) * h->S_q * 64;
       t.knew = h->chunk_k + (size_t)r0 * h->kv_dim, t.vnew = h->chunk_v + (size_t)r0 * h->kv_dim;
@@ -833,15 +842,18 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
       RC(ddk_attn_decode(t, st));
     }
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     RC(gemv(EPI_RESID, a));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
     RC(gemv(EPI_SILU, a));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
@@ -963,9 +975,9 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     EmbedLanes el;
     memset(&el, 0, sizeof(el));
     for (int m = 0; m < nb; ++m) el.state[m] = lanes[m]->state;
-    RC(ddk_embed_rows_lanes(h->embed, d, el, wide ? 8 * lane_groups : 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+    RC(ddk_embed_rows_lanes(h->embed, d, el, wide ? 8 * lane_groups : 8, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
   } else {
-    RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, skip_if));
+    RC(ddk_embed_rows(h->embed, d, h->state, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, skip_if, h->wf));
   }
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
@@ -974,6 +986,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     float* vnew = h->vnew + ((size_t)l * KV_ROWS + row0) * h->kv_dim;
     GemvArgs a;
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = nb, a.xop = h->xop_d;
     a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
@@ -984,6 +997,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
     RC(gemv(EPI_QKV, a));
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
+    t.wf = h->wf;
     t.qbuf = h->qbuf, t.kc = h->kc + (size_t)l * h->lsk, t.vc = h->vc + (size_t)l * h->lsv, t.T_cap = h->T_cap, t.kv16 = h->kv16;
     t.T = h->T_host, t.state = h->state, t.nb = nb, t.n_heads = h->H, t.n_kv = h->Hkv, t.drop_bits = bits;
     t.bit0 = bits ? h->bit0 : 0;
@@ -1010,16 +1024,19 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
       RC(ddk_attn_decode(t, st));
     }
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_q;
     a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     RC(gemv(EPI_RESID, a));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = nb, a.xop = h->xop_d;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.xop_next = h->xop_ff, a.S_next = h->S_ff;
     RC(gemv(EPI_SILU, a));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = nb, a.xop = h->xop_ff;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
@@ -1029,6 +1046,7 @@ static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logi
   }
   GemvArgs a;
   memset(&a, 0, sizeof(a));
+  a.wf = h->wf;
   a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = nb, a.xop = h->xop_d;
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
@@ -1130,12 +1148,13 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   memset(&el, 0, sizeof(el));
   for (int g = 0; g < ng; ++g)
     for (int m = 0; m < K; ++m) el.state[8 * g + m] = qs[g]->state;
-  RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * ng, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * ng, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
     GemvArgs a;
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
     a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
@@ -1143,6 +1162,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.q_dim = h->q_dim, a.kv_dim = h->kv_dim, a.rope_cos = h->rope_cos, a.rope_sin = h->rope_sin, a.state = qs[0]->state;
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
+    t.wf = h->wf;
     t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0, t.kv16 = h->kv16;
     t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
     t.n_lanes = ng, t.lane_groups = ng;
@@ -1161,12 +1181,14 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     RC(ddk_gemv_groups(EPI_QKV, a, st));
     RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = ng;
     a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
@@ -1174,6 +1196,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = ng;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
@@ -1184,6 +1207,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   }
   GemvArgs a;
   memset(&a, 0, sizeof(a));
+  a.wf = h->wf;
   a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
@@ -1385,10 +1409,10 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
   memset(&el, 0, sizeof(el));
   for (int m = 0; m < K; ++m) el.state[m] = h->state;
   el.state[8] = h->state;                                     // row 8: the un-masked row
-  RC(ddk_embed_rows_lanes(h->embed, d, el, 16, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st));
+  RC(ddk_embed_rows_lanes(h->embed, d, el, 16, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
   int ssq_n = 1;
   auto common = [&](GemvArgs& a) {
-    a.nb = K, a.n_groups = 2, a.fp8 = h->fp8, a.state = h->state;
+    a.nb = K, a.n_groups = 2, a.fp8 = h->fp8, a.state = h->state, a.wf = h->wf;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
   };
   for (int l = 0; l < h->Lyr; ++l) {
@@ -1397,6 +1421,7 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
     float* vn = h->vnew + (size_t)l * KV_ROWS * h->kv_dim;
     GemvArgs a;
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     common(a);
     a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.xop = h->xop_d, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
@@ -1407,6 +1432,7 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
     RC(ddk_gemv_groups(EPI_QKV, a, st));
     AttnDecodeArgs t;
     memset(&t, 0, sizeof(t));
+    t.wf = h->wf;
     t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0, t.kv16 = h->kv16;
     t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
     t.n_lanes = 2, t.lane_groups = 2, t.max_T = h->T_host;
@@ -1420,17 +1446,20 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
     t.knew = t.knew_g[0], t.vnew = t.vnew_g[0];
     RC(ddk_attn_decode(t, st));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     common(a);
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.xop = h->xop_q, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     common(a);
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.xop = h->xop_d, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
     RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     common(a);
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.xop = h->xop_ff, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
@@ -1440,6 +1469,7 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
   }
   GemvArgs a;
   memset(&a, 0, sizeof(a));
+  a.wf = h->wf;
   common(a);
   a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.xop = h->xop_d, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
@@ -1861,6 +1891,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
     LayerW& w = h->lw[l % h->Lyr];
     GemvArgs a;
     memset(&a, 0, sizeof(a));
+    a.wf = h->wf;
     a.nb = nb, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps, a.state = h->state, a.fp8 = h->fp8;
     switch (which) {
       case 0:

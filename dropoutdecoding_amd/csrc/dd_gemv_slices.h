@@ -68,7 +68,7 @@ __device__ __forceinline__ void dd_rows_rstd(const float* ssq_in, int ssq_n, int
 __device__ __forceinline__ int dd_part_index(int n, int m) { return (((n >> 2) * 8 + m) << 2) + (n & 3); }
 
 // grid = (8 / CH) * G workgroups of 512 threads; dynamic LDS = CH * min(SPW, CS) * NG KiB
-template <int TW, int NG, int U, int SPW, int CS, int CH = 1>
+template <int TW, int NG, int U, int SPW, int CS, int CH = 1, int WF = 0>
 __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
   constexpr int NCH = (SPW + CS - 1) / CS;             // LDS chunks per slice
   constexpr int PW = (CH * CS * NG + 7) / 8;           // operand pieces (1 KiB) per wave and chunk
@@ -117,9 +117,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
           *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + (size_t)g * TW + t) * NG + h) << 7) + l32 * 4] = sum[t][h];
         }
   };
-  auto mfma = [](u32x4_t w, u32x4_t b, f32x4_t c) -> f32x4_t {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-  };
+  auto mfma = [](u32x4_t w, u32x4_t b, f32x4_t c) -> f32x4_t { return dd_mfma16<WF>(w, b, c); };
   const size_t wstep = 8 * 64;                         // one slice step = 8 k-steps of the tile row
 
   if constexpr (NCH == 1) {

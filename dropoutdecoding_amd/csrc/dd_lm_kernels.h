@@ -67,9 +67,9 @@ __device__ __forceinline__ float dd_kv_load(const float* kc, const float* vc, in
 
 int ddk_pack_weight(const uint16_t* src_dev, int rows, int cols, u32x4_t* dst, int dst_tile0, int tile_stride,
                     int pack_mode, int n_src_tiles, hipStream_t st);
-int ddk_fill_synthetic(uint16_t* dst_bf16, size_t n, uint32_t seed, float std, hipStream_t st);
+int ddk_fill_synthetic(uint16_t* dst_bf16, size_t n, uint32_t seed, float std, hipStream_t st, int wf = 0);   // wf 1: fp16 bits
 int ddk_fill_const_f32(float* dst, size_t n, float v, hipStream_t st);
-int ddk_bf16_to_f32(const uint16_t* src, float* dst, int n, hipStream_t st);
+int ddk_bf16_to_f32(const uint16_t* src, float* dst, int n, hipStream_t st, int wf = 0);
 int ddk_rope_table(float* cos_t, float* sin_t, int max_seq, const float* inv_freq_dev, hipStream_t st);
 
 // ---- decode (NB <= 8 rows against one weight sweep) ------------------------------------------
@@ -133,6 +133,7 @@ struct GemvArgs {
   float* knew_g[4];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
   float* vnew_g[4];
   int S_next;           // K / 32 of the GEMV that consumes xop_next
+  int wf;                   // 16-bit type of W and of the packed operands: 0 bf16, 1 fp16 (engines created with weight_format 2)
   const int32_t* skip_if;   // optional (k_gemv): *skip_if != 0 -> the launch returns at once (fallback sweep of a speculative step)
   float* part;          // scratch for the slice-resident path (dd_gemv_slices.h): partial sums, or nullptr (then k_gemv_groups runs)
   size_t part_floats;   // capacity; 64 more floats behind it hold rstd of the operand rows
@@ -166,6 +167,7 @@ struct AttnDecodeArgs {
   const float* knew;     // [8][kv_dim] roped new keys of this layer (rows of this pass)
   const float* vnew;
   u32x4_t* xop_out;      // packed hi/lo operand for o_proj, [q_dim/32][64]
+  int wf;                  // 16-bit type of the packed operand written for o_proj (0 bf16, 1 fp16)
   const int32_t* skip_if;  // optional: *skip_if != 0 -> both kernels return at once (fallback sweep of a speculative step)
   // lanes (n_lanes > 0): row m of the pass belongs to sequence m — its own cache, length, span and (un-shifted) bits.
   // Used by the fused base pass of a group of sequences; kc/vc/state/drop_bits/span_* above are ignored then.
@@ -186,7 +188,7 @@ int ddk_attn_grid_tiles(int T, int T_cap);   // tiles the decode attention is la
 
 // ---- prefill (M rows) -------------------------------------------------------------------------
 int ddk_rmsnorm_split(const float* x, int M, int d, const float* w, float eps, uint16_t* hi, uint16_t* lo,
-                      const int32_t* row_index, float* normed_out, hipStream_t st);
+                      const int32_t* row_index, float* normed_out, hipStream_t st, int wf = 0);
 
 struct GemmArgs {
   const uint16_t* a_hi;  // [M][K] bf16
@@ -210,6 +212,7 @@ struct GemmArgs {
   float* vc;
   int T_cap, q_tiles, k_tiles, q_dim, kv_dim, pos0;
   int kv16;              // EPI_QKV: the cache holds fp16
+  int wf;                // 16-bit type of W, the A planes and the planes written by the epilogue (0 bf16, 1 fp16)
   const float* rope_cos;
   const float* rope_sin;
 };
@@ -217,10 +220,10 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st);
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out = nullptr, int kv16 = 0);   // q0 = position of query row 0
+                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out = nullptr, int kv16 = 0, int wf = 0);   // q0 = position of query row 0
 // xop_out: write the rows as packed decode-GEMV operand planes (row-major [32 rows]) instead of the GEMM's A planes
 int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x, const float* normw, u32x4_t* xop, float* ssq,
-                        int ssq_ld, hipStream_t st);
+                        int ssq_ld, hipStream_t st, int wf = 0);
 int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t st);
 int ddk_scatter_kv_rows(const float* kr, const float* vr, int n, int kv_dim, float* kc, float* vc, int T_cap, const DDState* base,
                         hipStream_t st, int kv16 = 0);
@@ -229,13 +232,13 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStr
 // ---- small glue -------------------------------------------------------------------------------
 // x[0..8)[d] <- embed[cur_tok] (all rows equal), xop <- split(normw * x), ssq slot 0
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
-                   float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if = nullptr);
+                   float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if = nullptr, int wf = 0);
 struct EmbedLanes {
   const DDState* state[32];   // row m embeds the current token of this sequence (null: row unused)
 };
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
-                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st);   // rows = 8, 16 or 32
-int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st);
+                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf = 0);   // rows = 8, 16 or 32
+int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st, int wf = 0);
 struct CommitLanes {       // winners of up to 4 sequences appended to their caches in one launch
   const float* knew[4];
   const float* vnew[4];

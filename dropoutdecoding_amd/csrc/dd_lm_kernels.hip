@@ -135,13 +135,13 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 }
 
 // deterministic pseudo-random bf16 fill (sum of 4 uniforms ~ normal), synthetic-weights bench mode
-__global__ __launch_bounds__(256) void k_fill_synth(uint16_t* dst, size_t n, uint32_t seed, float std) {
+__global__ __launch_bounds__(256) void k_fill_synth(uint16_t* dst, size_t n, uint32_t seed, float std, int wf) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t h = hash32((uint32_t)i * 0x9e3779b9u + seed) ^ hash32((uint32_t)(i >> 32) + seed * 31u);
   uint32_t h2 = hash32(h + 0x68bc21ebu);
   float u = ((h & 0xffff) + (h >> 16) + (h2 & 0xffff) + (h2 >> 16)) * (1.0f / 65536.0f) - 2.0f;  // var = 1/3
-  dst[i] = (uint16_t)dd_bf16_rn(u * 1.7320508f * std);
+  dst[i] = (uint16_t)(wf ? dd_f16_bits(u * 1.7320508f * std) : dd_bf16_rn(u * 1.7320508f * std));
 }
 // random finite e4m3fn bytes (0x7f / 0xff are NaN in the OCP encoding and are avoided)
 __global__ __launch_bounds__(256) void k_fill_synth_fp8(uint8_t* dst, size_t n, uint32_t seed) {
@@ -157,8 +157,8 @@ int ddk_fill_synthetic_fp8(uint8_t* dst, size_t n, uint32_t seed, hipStream_t st
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-int ddk_fill_synthetic(uint16_t* dst, size_t n, uint32_t seed, float std, hipStream_t st) {
-  k_fill_synth<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dst, n, seed, std);
+int ddk_fill_synthetic(uint16_t* dst, size_t n, uint32_t seed, float std, hipStream_t st, int wf) {
+  k_fill_synth<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dst, n, seed, std, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -171,12 +171,12 @@ int ddk_fill_const_f32(float* dst, size_t n, float v, hipStream_t st) {
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-__global__ void k_bf16_to_f32(const uint16_t* src, float* dst, int n) {
+__global__ void k_bf16_to_f32(const uint16_t* src, float* dst, int n, int wf) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = dd_bf16_to_f32(src[i]);
+  if (i < n) dst[i] = dd_w16_to_f32(src[i], wf);
 }
-int ddk_bf16_to_f32(const uint16_t* src, float* dst, int n, hipStream_t st) {
-  k_bf16_to_f32<<<(n + 255) / 256, 256, 0, st>>>(src, dst, n);
+int ddk_bf16_to_f32(const uint16_t* src, float* dst, int n, hipStream_t st, int wf) {
+  k_bf16_to_f32<<<(n + 255) / 256, 256, 0, st>>>(src, dst, n, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -195,9 +195,9 @@ int ddk_rope_table(float* c, float* s, int max_seq, const float* inv_freq, hipSt
 }
 
 // write the hi/lo split of value y for (row m, k index k) into a packed decode operand
-__device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y) {
+__device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y, int wf = 0) {
   uint32_t hi, lo;
-  dd_split_hl(y, hi, lo);
+  dd_split(y, hi, lo, wf);
   uint16_t* p = (uint16_t*)xop;
   int ks = k >> 5, h = (k >> 3) & 3, j = k & 7;
   size_t base = ((size_t)ks * 64 + h * 16) * 8 + j;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y) {
 // NT  = non-temporal weight loads (read-once stream, keeps L2/MALL for the x operand and the KV cache)
 // ILV = k-steps interleaved over the 8 waves (wave w takes steps w, w+8, ...: at any instant the workgroup reads
 //       8 consecutive KiB) instead of one contiguous chunk per wave
-template <int EPI, int TILES, int U, int NT, int ILV, int FP8 = 0, int PIPE = 0>
+template <int EPI, int TILES, int U, int NT, int ILV, int FP8 = 0, int PIPE = 0, int WF = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   __shared__ float red[TILES * GEMV_WAVES * 256];
   __shared__ float rstd_sh[8];
@@ -343,8 +343,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                           __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+          acc[t] = dd_mfma16<WF>(w[t][u], b[u], acc[t]);
     }
     if (s < spw) {  // tail: the remaining (< U) steps requested together as well (K = 11008: 43 steps per wave)
       const int rem = spw - s;
@@ -362,8 +361,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
         if (u < rem) {
 #pragma unroll
           for (int t = 0; t < TILES; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                             __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+            acc[t] = dd_mfma16<WF>(w[t][u], b[u], acc[t]);
         }
       }
     }
@@ -381,8 +379,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
     auto use = [&](int u) {
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                         __builtin_bit_cast(bf16x8_t, b[u]), acc[t], 0, 0, 0);
+        acc[t] = dd_mfma16<WF>(w[t][u], b[u], acc[t]);
     };
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -444,7 +441,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       int col = tile0 * 16 + n;
       float xn = pre0 + y;
       a.out[(size_t)m * a.ldo + col] = xn;
-      xop_store(a.xop_next, col, m, pre1 * xn);
+      xop_store(a.xop_next, col, m, pre1 * xn, WF);
       sq = xn * xn;
     }
     if (t < 128) ssq_sh[n * 8 + m] = sq;
@@ -464,7 +461,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
           u *= rstd_sh[m];
         }
         float act = g / (1.0f + expf(-g));  // silu
-        xop_store(a.xop_next, blockIdx.x * 16 + n, m, act * u);
+        xop_store(a.xop_next, blockIdx.x * 16 + n, m, act * u, WF);
       }
     }
   } else {  // EPI_QKV
@@ -506,7 +503,11 @@ void ddk_set_tuning(int key, int value) {
 template <int EPI, int TILES>
 static void launch_gemv(const GemvArgs& a_, hipStream_t st) {
   const GemvArgs& a = a_;
-#define GV(U_, P_) k_gemv<EPI, TILES, U_, 1, 1, 0, P_><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a)
+#define GV(U_, P_)                                                                             \
+  do {                                                                                         \
+    if (a.wf) k_gemv<EPI, TILES, U_, 1, 1, 0, P_, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a);   \
+    else k_gemv<EPI, TILES, U_, 1, 1, 0, P_, 0><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a);        \
+  } while (0)
   if (a.fp8) { k_gemv<EPI, TILES, 8, 1, 1, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }
   const int u = g_gemv_u;
   if (g_gemv_pipe) { if (u == 4) GV(4, 1); else if (u == 16) GV(16, 1); else GV(8, 1); }
@@ -536,8 +537,8 @@ int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
 // on which of the kernels computed it; group g's B operand is plane g of the packed operand and costs one more MFMA per
 // tile step (the kernel is HBM-bound; even 4 planes keep the MFMA pipe under half busy).
 // ===============================================================================================
-__device__ __forceinline__ void xop_store16(u32x4_t* xop, int k, int m, float y, int S) {
-  xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y);   // plane = group of the row
+__device__ __forceinline__ void xop_store16(u32x4_t* xop, int k, int m, float y, int S, int wf = 0) {
+  xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y, wf);   // plane = group of the row
 }
 
 // What the epilogue needs from memory, requested before the weight stream (k_gemv_groups) or before the partial sums
@@ -606,7 +607,7 @@ __device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const
       int col = tile0 * 16 + en;
       float xn = p.pre0 + y;
       a.out[(size_t)em * a.ldo + col] = xn;
-      xop_store16(a.xop_next, col, em, p.pre1 * xn, a.S_next);
+      xop_store16(a.xop_next, col, em, p.pre1 * xn, a.S_next, a.wf);
       sq = xn * xn;
     }
     if (et < 128 * NG) ssq_sh[en * (8 * NG) + em] = sq;
@@ -624,7 +625,7 @@ __device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const
         u *= rstd_sh[em];
       }
       float act = g / (1.0f + expf(-g));  // silu
-      xop_store16(a.xop_next, wg * 16 + en, em, act * u, a.S_next);
+      xop_store16(a.xop_next, wg * 16 + en, em, act * u, a.S_next, a.wf);
     }
   } else {  // EPI_QKV
     if (erow) {
@@ -655,7 +656,7 @@ __device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const
   }
 }
 
-template <int EPI, int TILES, int NG, int U = 4, int FP8 = 0>
+template <int EPI, int TILES, int NG, int U = 4, int FP8 = 0, int WF = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
   extern __shared__ float gg_sh[];
   float* red = gg_sh;                                   // [TILES * NG * 8 waves][256]
@@ -738,8 +739,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
       for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-          acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                              __builtin_bit_cast(bf16x8_t, b[u][g]), acc[t][g], 0, 0, 0);
+          acc[t][g] = dd_mfma16<WF>(w[t][u], b[u][g], acc[t][g]);
   }
   if (s < spw) {
     const int rem = spw - s;
@@ -759,8 +759,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
         for (int t = 0; t < TILES; ++t)
 #pragma unroll
           for (int g = 0; g < NG; ++g)
-            acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[t][u]),
-                                                                __builtin_bit_cast(bf16x8_t, b[u][g]), acc[t][g], 0, 0, 0);
+            acc[t][g] = dd_mfma16<WF>(w[t][u], b[u][g], acc[t][g]);
       }
   }
 
@@ -841,10 +840,12 @@ static int launch_gemv_groups_f(const GemvArgs& a, hipStream_t st) {
   constexpr int U = (TILES == 2 && NG == 4) ? 2 : (EPI == EPI_RESID ? 8 : 4);
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, FP8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!FP8) DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_gemv_groups<EPI, TILES, NG, U, FP8><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
+  if (!FP8 && a.wf) k_gemv_groups<EPI, TILES, NG, U, 0, 1><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
+  else k_gemv_groups<EPI, TILES, NG, U, FP8, 0><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
   return DD_OK;
 }
 template <int EPI, int TILES, int NG>
@@ -862,14 +863,16 @@ void ddk_set_slices_only(int on) { g_slices_only = on; }
 #define SLICES_UNSUPPORTED 1
 
 template <int TW, int NG, int U, int SPW, int CS, int CH>
-static int launch_slices_k(const SliceArgs& sa, hipStream_t st) {
+static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)CH * (SPW < CS ? SPW : CS) * NG * 1024;
   static bool attr = false;
   if (!attr) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  k_gemv_slices<TW, NG, U, SPW, CS, CH><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 template <int EPI, int TILES, int NG, int NP>
@@ -891,7 +894,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
     if (spw != 16 || (nt & 1) || a.part_floats < need8) return SLICES_UNSUPPORTED;
     sa.n_groups = nt / 2;
     sa.G = sa.n_groups >= 256 ? (sa.n_groups + 15) / 16 : (sa.n_groups + 7) / 8;     // two tile pairs per wave when there are enough
-    RC_(launch_slices_k<2, NG, 8, 16, 16, 1>(sa, st));
+    RC_(launch_slices_k<2, NG, 8, 16, 16, 1>(sa, a.wf, st));
     launch_finish<EPI_QKV, 1, NG, 8>(a, nt, st);
   } else if (epi == EPI_RESID) {
     // K = 4096 (o_proj): the wave-split kernel in one launch is as fast as slices + finish (13.5 vs 14.2 us at four planes,
@@ -899,15 +902,15 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
     if (a.part_floats < need8 || spw == 16) return SLICES_UNSUPPORTED;
     sa.n_groups = nt;
     sa.G = (nt + 7) / 8;                                             // one tile per wave
-    if (spw == 16) RC_(launch_slices_k<1, NG, 8, 16, 16, 1>(sa, st));
-    else if (spw == 43) RC_(launch_slices_k<1, NG, 8, 43, 16, 1>(sa, st));
-    else RC_(launch_slices_k<1, NG, 8, 56, 16, 1>(sa, st));
+    if (spw == 16) RC_(launch_slices_k<1, NG, 8, 16, 16, 1>(sa, a.wf, st));
+    else if (spw == 43) RC_(launch_slices_k<1, NG, 8, 43, 16, 1>(sa, a.wf, st));
+    else RC_(launch_slices_k<1, NG, 8, 56, 16, 1>(sa, a.wf, st));
     launch_finish<EPI_RESID, 1, NG, 8>(a, nt, st);
   } else {  // EPI_SILU: slice pairs, one workgroup per CU
     if (spw != 16 || a.part_floats < need4) return SLICES_UNSUPPORTED;
     sa.n_groups = nt;
     sa.G = 64;
-    RC_(launch_slices_k<1, NG, 8, 16, 16, 2>(sa, st));
+    RC_(launch_slices_k<1, NG, 8, 16, 16, 2>(sa, a.wf, st));
     launch_finish<EPI_SILU, 2, NG, 4>(a, a.n_tiles, st);
   }
   return DD_OK;
@@ -1190,8 +1193,8 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
     for (int u = 0; u < 8; ++u) num += w_sh[sp + u] * o[u];
   }
   for (; sp < splits; ++sp) num += w_sh[sp] * po[(size_t)sp * o_stride];
-  if (NBT > 8) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5);
-  else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den);
+  if (NBT > 8) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5, a.wf);
+  else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den, a.wf);
 }
 
 // Key tiles the partial kernel is LAUNCHED with: the live count rounded up to a multiple of 4 (workgroups of tiles past
@@ -1325,7 +1328,7 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
 // y = w * (x * rsqrt(mean(x^2) + eps)) in HF's op order, written as hi/lo bf16 planes (and optionally fp32)
 __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__ x, int d, const float* __restrict__ w,
                                                        float eps, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
-                                                       const int32_t* __restrict__ row_index, float* normed) {
+                                                       const int32_t* __restrict__ row_index, float* normed, int wf) {
   __shared__ float sh[4];
   int row = blockIdx.x;
   const float* xr = x + (size_t)(row_index ? row_index[row] : row) * d;
@@ -1342,7 +1345,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float y = w[i8 + j] * (xr[i8 + j] * rstd);
-      dd_split_hl(y, hh[j], ll[j]);
+      dd_split(y, hh[j], ll[j], wf);
       if (normed) normed[(size_t)row * d + i8 + j] = y;
     }
     if (hi) {
@@ -1358,13 +1361,13 @@ __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__
   }
 }
 int ddk_rmsnorm_split(const float* x, int M, int d, const float* w, float eps, uint16_t* hi, uint16_t* lo,
-                      const int32_t* row_index, float* normed, hipStream_t st) {
-  k_rmsnorm_split<<<M, 256, 0, st>>>(x, d, w, eps, hi, lo, row_index, normed);
+                      const int32_t* row_index, float* normed, hipStream_t st, int wf) {
+  k_rmsnorm_split<<<M, 256, 0, st>>>(x, d, w, eps, hi, lo, row_index, normed, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float eps, float* out, hipStream_t st) {
-  return ddk_rmsnorm_split(x, rows, d, w, eps, nullptr, nullptr, nullptr, out, st);
+  return ddk_rmsnorm_split(x, rows, d, w, eps, nullptr, nullptr, nullptr, out, st, 0);
 }
 
 // C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64; both operands are pre-tiled so every
@@ -1373,7 +1376,7 @@ int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float e
 // MI x NJ = 16x16 MFMA tiles per wave (rows x cols); 4 waves as 2x2: block = (32*MI) rows x (32*NJ) cols.
 // 4x4 (128x128 block) for the LM prefill; 2x2 (64x64) when the grid would otherwise be too small to fill 256 CUs
 // (the ViT: M = 577, N = 1024).
-template <int EPI, int MI, int NJ>
+template <int EPI, int MI, int NJ, int WF = 0>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1418,10 +1421,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ahi[i]),
-                                                            __builtin_bit_cast(bf16x8_t, w[j]), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, alo[i]),
-                                                            __builtin_bit_cast(bf16x8_t, w[j]), acc[i][j], 0, 0, 0);
+        acc[i][j] = dd_mfma16<WF>(ahi[i], w[j], acc[i][j]);
+        acc[i][j] = dd_mfma16<WF>(alo[i], w[j], acc[i][j]);
       }
   };
   load(ahi0, alo0, w0, 0);
@@ -1457,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
             if (a.wscale) u *= a.wscale[(size_t)(nt + 1) * 16 + c];
             float act = y / (1.0f + expf(-y));
             uint32_t h, l;
-            dd_split_hl(act * u, h, l);
+            dd_split(act * u, h, l, WF);
             int col = (nt >> 1) * 16 + c;
             if (ok) {
               size_t o = apack_off(row, col, a.ld_planes >> 5);
@@ -1470,7 +1471,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
           if (a.act == 0) v = y / (1.0f + expf(-1.702f * y));                        // quick_gelu: x * sigmoid(1.702 x)
           else if (a.act == 1) v = 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));  // gelu (erf form)
           uint32_t h, l;
-          dd_split_hl(v, h, l);
+          dd_split(v, h, l, WF);
           if (ok) {
             size_t o = apack_off(row, nt * 16 + c, a.ld_planes >> 5);
             a.o_hi[o] = (uint16_t)h;
@@ -1519,10 +1520,14 @@ template <int MI, int NJ>
 static int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.n_tiles + 2 * NJ - 1) / (2 * NJ), (a.M + 32 * MI - 1) / (32 * MI));
   switch (epi) {
-    case EPI_STORE: k_gemm<EPI_STORE, MI, NJ><<<grid, 256, 0, st>>>(a); break;
-    case EPI_RESID: k_gemm<EPI_RESID, MI, NJ><<<grid, 256, 0, st>>>(a); break;
-    case EPI_SILU: k_gemm<EPI_SILU, MI, NJ><<<grid, 256, 0, st>>>(a); break;
-    case EPI_QKV: k_gemm<EPI_QKV, MI, NJ><<<grid, 256, 0, st>>>(a); break;
+#define GM(E_)                                                          \
+  if (a.wf) k_gemm<E_, MI, NJ, 1><<<grid, 256, 0, st>>>(a);             \
+  else k_gemm<E_, MI, NJ, 0><<<grid, 256, 0, st>>>(a)
+    case EPI_STORE: GM(EPI_STORE); break;
+    case EPI_RESID: GM(EPI_RESID); break;
+    case EPI_SILU: GM(EPI_SILU); break;
+    case EPI_QKV: GM(EPI_QKV); break;
+#undef GM
     case EPI_ACT: k_gemm<EPI_ACT, MI, NJ><<<grid, 256, 0, st>>>(a); break;
     case EPI_QKV_VIT: k_gemm<EPI_QKV_VIT, MI, NJ><<<grid, 256, 0, st>>>(a); break;
     default: DD_REQUIRE(false, "gemm: unknown epilogue %d", epi);
@@ -1676,7 +1681,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
                                                            const float* __restrict__ vc, int T, int T_cap, int n_heads,
                                                            uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
                                                            const uint8_t* __restrict__ drop_plane, int drop_bit,
-                                                           int span_start, int span_len, int q0, int causal, float scaling) {
+                                                           int span_start, int span_len, int q0, int causal, float scaling, int wf) {
   constexpr int LD = HD + 4;   // padded row pitch (floats) of the staged K / V tiles: keeps the V^T reads conflict-free
   constexpr int KS = HD / 32, DT = HD / 16, C4 = HD / 4;
   __shared__ __align__(16) float Ksh[FA_KEYS * LD];
@@ -1816,7 +1821,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
   for (int dt = 0; dt < DT; ++dt) {
     uint32_t hh[4], ll[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dd_split_hl(acc[dt][r] * inv, hh[r], ll[r]);
+    for (int r = 0; r < 4; ++r) dd_split(acc[dt][r] * inv, hh[r], ll[r], wf);
     size_t o = apack_off(t_q, head * HD + dt * 16 + g4 * 4, q_dim >> 5);   // 4 consecutive k: one 8-byte packed store
     *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
     *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
@@ -1827,7 +1832,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
 int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
                       hipStream_t st) {
   k_attn_prefill_mfma<1, 64><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0,
-                                                                          0, 1.0f);
+                                                                          0, 1.0f, 0);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -1838,8 +1843,9 @@ int ddk_prefill_mfma_enabled() { return g_prefill_mfma; }
 
 int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads, int n_kv,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
-                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out, int kv16) {
+                     int span_len, int q0, hipStream_t st, u32x4_t* xop_out, int kv16, int wf) {
   int G = n_heads / n_kv;
+  DD_REQUIRE(!wf || (g_prefill_mfma && !xop_out), "attn_prefill: fp16-weight engines use the matrix-core prefill attention only");
   DD_REQUIRE(!kv16 || (g_prefill_mfma && !xop_out), "attn_prefill: the fp16 KV cache is read by the matrix-core prefill attention only");
   dim3 grid(n_heads, (T + (q0 & (PF_QR - 1)) + 4 * PF_QR - 1) / (4 * PF_QR));
 #define PF_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, xop_out
@@ -1853,7 +1859,7 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
   }
   if (g_prefill_mfma) {
     dim3 g2(n_heads, (T + (q0 & 15) + 63) / 64);
-#define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f
+#define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f, wf
     if (kv16) {
       if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
       else if (G == 2) k_attn_prefill_mfma<2, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
@@ -1881,19 +1887,19 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
 __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict__ embed, int d, const DDState* state,
                                                      float* __restrict__ x, const float* __restrict__ normw,
                                                      u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld,
-                                                     const int32_t* __restrict__ skip_if) {
+                                                     const int32_t* __restrict__ skip_if, int wf) {
   __shared__ float sh[16];
   if (skip_if && *skip_if) return;
   int tok = state->cur_tok;
   float ss = 0.f;
   for (int i = threadIdx.x; i < d; i += 1024) {
-    float e = dd_bf16_to_f32(embed[(size_t)tok * d + i]);
+    float e = dd_w16_to_f32(embed[(size_t)tok * d + i], wf);
     ss += e * e;
     float z = normw[i] * e;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       x[(size_t)m * d + i] = e;
-      xop_store(xop, i, m, z);
+      xop_store(xop, i, m, z, wf);
     }
   }
   ss = dd_wave_sum(ss);
@@ -1906,8 +1912,8 @@ __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict_
   }
 }
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
-                   float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if) {
-  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld, skip_if);
+                   float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if, int wf) {
+  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld, skip_if, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -1916,7 +1922,7 @@ int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x,
 template <int ROWS>
 __global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __restrict__ embed, int d, EmbedLanes lanes,
                                                            float* __restrict__ x, const float* __restrict__ normw,
-                                                           u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld) {
+                                                           u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld, int wf) {
   __shared__ float sh[ROWS][16];
   int tok[ROWS];
 #pragma unroll
@@ -1928,11 +1934,11 @@ __global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __res
     float w = normw[i];
 #pragma unroll
     for (int m = 0; m < ROWS; ++m) {
-      float e = tok[m] >= 0 ? dd_bf16_to_f32(embed[(size_t)tok[m] * d + i]) : 0.f;
+      float e = tok[m] >= 0 ? dd_w16_to_f32(embed[(size_t)tok[m] * d + i], wf) : 0.f;
       ss[m] += e * e;
       x[(size_t)m * d + i] = e;
-      if (ROWS > 8) xop_store16(xop, i, m, w * e, d >> 5);
-      else xop_store(xop, i, m, w * e);
+      if (ROWS > 8) xop_store16(xop, i, m, w * e, d >> 5, wf);
+      else xop_store(xop, i, m, w * e, wf);
     }
   }
 #pragma unroll
@@ -1948,10 +1954,10 @@ __global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __res
   }
 }
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
-                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st) {
-  if (rows == 32) k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
-  else if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
-  else k_embed_rows_lanes<8><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld);
+                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf) {
+  if (rows == 32) k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
+  else if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
+  else k_embed_rows_lanes<8><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -1960,7 +1966,7 @@ int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, 
 template <int ROWS>
 __global__ __launch_bounds__(1024) void k_pack_embed_rows(const float* __restrict__ rows, int n, int d, float* __restrict__ x,
                                                           const float* __restrict__ normw, u32x4_t* __restrict__ xop,
-                                                          float* __restrict__ ssq, int ssq_ld) {
+                                                          float* __restrict__ ssq, int ssq_ld, int wf) {
   __shared__ float sh[ROWS][16];
   float ss[ROWS];
 #pragma unroll
@@ -1972,8 +1978,8 @@ __global__ __launch_bounds__(1024) void k_pack_embed_rows(const float* __restric
       float e = m < n ? rows[(size_t)m * d + i] : 0.f;
       ss[m] += e * e;
       x[(size_t)m * d + i] = e;
-      if (ROWS > 8) xop_store16(xop, i, m, w * e, d >> 5);
-      else xop_store(xop, i, m, w * e);
+      if (ROWS > 8) xop_store16(xop, i, m, w * e, d >> 5, wf);
+      else xop_store(xop, i, m, w * e, wf);
     }
   }
 #pragma unroll
@@ -1989,10 +1995,10 @@ __global__ __launch_bounds__(1024) void k_pack_embed_rows(const float* __restric
   }
 }
 int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x, const float* normw, u32x4_t* xop, float* ssq,
-                        int ssq_ld, hipStream_t st) {
-  if (rows_cap == 32) k_pack_embed_rows<32><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld);
-  else if (rows_cap == 16) k_pack_embed_rows<16><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld);
-  else k_pack_embed_rows<8><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld);
+                        int ssq_ld, hipStream_t st, int wf) {
+  if (rows_cap == 32) k_pack_embed_rows<32><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld, wf);
+  else if (rows_cap == 16) k_pack_embed_rows<16><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld, wf);
+  else k_pack_embed_rows<8><<<1, 1024, 0, st>>>(rows, n, d, x, normw, xop, ssq, ssq_ld, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -2027,13 +2033,13 @@ int ddk_scatter_kv_rows(const float* kr, const float* vr, int n, int kv_dim, flo
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-__global__ void k_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, float* x) {
+__global__ void k_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, float* x, int wf) {
   int row = blockIdx.x;
   int tok = tokens[row];
-  for (int i = threadIdx.x; i < d; i += 256) x[(size_t)row * d + i] = dd_bf16_to_f32(embed[(size_t)tok * d + i]);
+  for (int i = threadIdx.x; i < d; i += 256) x[(size_t)row * d + i] = dd_w16_to_f32(embed[(size_t)tok * d + i], wf);
 }
-int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st) {
-  k_embed_tokens<<<n, 256, 0, st>>>(embed, d, tokens, x);
+int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st, int wf) {
+  k_embed_tokens<<<n, 256, 0, st>>>(embed, d, tokens, x, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

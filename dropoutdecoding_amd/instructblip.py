@@ -70,7 +70,7 @@ class CustomInstructBlipForConditionalGeneration(DropoutVLM):
         cfg = hf.config
         sd = lm_state_dict_from_hf(hf)
         lm_cfg = LMConfig.from_hf(cfg.text_config)
-        eng = build_engine(lm_cfg, cls.family, max_visual=cfg.num_query_tokens, max_new_tokens=max_new_tokens,
+        eng = build_engine(lm_cfg, cls.family, checkpoint_dtype=sd["lm_head.weight"].dtype, max_visual=cfg.num_query_tokens, max_new_tokens=max_new_tokens,
                            seed=_config.effective_seed)
         eng.load_state_dict(sd)
         dev = eng.device

@@ -75,7 +75,7 @@ class CustomLlavaForConditionalGeneration(DropoutVLM):
         lm_cfg = LMConfig.from_hf(cfg.text_config)
         vc = cfg.vision_config
         L = (vc.image_size // vc.patch_size) ** 2 + (0 if cfg.vision_feature_select_strategy == "default" else 1)
-        eng = build_engine(lm_cfg, cls.family, max_visual=L, max_new_tokens=max_new_tokens, seed=_config.effective_seed)
+        eng = build_engine(lm_cfg, cls.family, checkpoint_dtype=sd["lm_head.weight"].dtype, max_visual=L, max_new_tokens=max_new_tokens, seed=_config.effective_seed)
         eng.load_state_dict(sd)
         dev = eng.device
         embed = sd["model.embed_tokens.weight"].to(dev, torch.bfloat16)

@@ -70,7 +70,7 @@ class CustomLlavaNextForConditionalGeneration(DropoutVLM):
         cfg = hf.config
         sd = lm_state_dict_from_hf(hf)
         lm_cfg = LMConfig.from_hf(cfg.text_config)
-        eng = build_engine(lm_cfg, cls.family, max_visual=max_visual, max_new_tokens=max_new_tokens,
+        eng = build_engine(lm_cfg, cls.family, checkpoint_dtype=sd["lm_head.weight"].dtype, max_visual=max_visual, max_new_tokens=max_new_tokens,
                            use_random=bool(settings["use_random"][0]), seed=_config.effective_seed)
         eng.load_state_dict(sd)
         dev = eng.device

@@ -130,7 +130,7 @@ class DropoutEngine:
         c = _lib.LMConfigC(cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads,
                            cfg.num_kv_heads, cfg.head_dim, cfg.rms_eps, cfg.rope_theta, max_seq, max_visual,
                            fam["k_top"], fam["mask_mode"], fam["vote_on"], fam["leak_mask"],
-                           {"bf16": 0, "fp8": 1}[weight_format], {"fp32": 0, "fp16": 1}[kv_format])
+                           {"bf16": 0, "fp8": 1, "fp16": 2}[weight_format], {"fp32": 0, "fp16": 1}[kv_format])
         self.weight_format = weight_format
         self._h = C.c_void_p()
         self.weight_owner = share_weights_with         # kept alive: a lane borrows the owner's weight memory
@@ -163,7 +163,7 @@ class DropoutEngine:
         t = t.detach()
         if t.dim() == 1:
             t = t[None]
-        t = t.to(torch.bfloat16).contiguous()
+        t = t.to(torch.float16 if self.weight_format == "fp16" else torch.bfloat16).contiguous()
         _lib.check(self.lib.dd_lm_load_tensor(self._h, tid, layer, t.view(torch.int16).data_ptr(), t.shape[0],
                                               t.shape[1], 1 if t.is_cuda else 0), f"dd_lm_load_tensor({tid},{layer})")
 
@@ -175,7 +175,8 @@ class DropoutEngine:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "") -> None:
         """HF LlamaForCausalLM / MistralForCausalLM parameter names (optionally under `prefix`).  An fp8 engine
-        quantises every matrix with `quantize_fp8` (per-row absmax / 448, OCP e4m3fn) on the way in."""
+        quantises every matrix with `quantize_fp8` (per-row absmax / 448, OCP e4m3fn) on the way in; a bf16 engine rounds to
+        bf16 (exact for bf16 checkpoints), an fp16 engine to fp16 (exact for the fp16 checkpoints the reference loads)."""
         g = lambda k: sd[prefix + k]
         mat = self._load_fp8 if self.weight_format == "fp8" else self._load
         self._load(T_EMBED, 0, g("model.embed_tokens.weight"))

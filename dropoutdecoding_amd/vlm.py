@@ -244,11 +244,14 @@ class DropoutVLM:
 
 
 def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens: int = 1024, prompt_tokens: int = 256,
-                 use_random: bool = False, seed: Optional[int] = None) -> DropoutEngine:
+                 use_random: bool = False, seed: Optional[int] = None, checkpoint_dtype=None) -> DropoutEngine:
     max_seq = max_visual + prompt_tokens + max_new_tokens + 8
+    wfmt = settings.get("weight_format", "auto")
+    if wfmt == "auto":            # keep the checkpoint's own 16-bit type: fp16 checkpoints (all the reference loads) stay exact
+        wfmt = "fp16" if checkpoint_dtype == torch.float16 else "bf16"
     return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random,
                          mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)),
-                         weight_format=settings.get("weight_format", "bf16"), kv_format=settings.get("kv_cache", "fp16"))
+                         weight_format=wfmt, kv_format=settings.get("kv_cache", "fp16"))
 
 
 @torch.no_grad()

@@ -155,7 +155,11 @@ typedef struct dd_lm_config {
   int32_t vote_on;           /* DD_VOTE_*                                   */
   int32_t leak_mask;         /* InstructBLIP Q2: 1 = the un-masked pass sees the last member's zeros (positions from the
                                 cache length, transformers 5.x); 2 = additionally position = T - #zeros (the 4.44 rule) */
-  int32_t weight_format;     /* 0 = bf16 matrices, 1 = OCP fp8 e4m3fn matrices + per-output-row fp32 scales (BASELINE config 5) */
+  int32_t weight_format;     /* 0 = bf16 matrices, 1 = OCP fp8 e4m3fn matrices + per-output-row fp32 scales (BASELINE config 5),
+                                2 = fp16 matrices / embeddings / norm vectors: fp16-native checkpoints (every model the reference
+                                loads: chair_test/chair_test.py:189-213, torch_dtype=float16) stay EXACT instead of losing three
+                                mantissa bits in a cast to bf16; activations are then split hi + lo in fp16 (~22 mantissa bits) and
+                                every weight product runs on v_mfma_f32_16x16x32_f16 */
   int32_t kv_format;         /* KV cache storage: 0 = fp32 (default), 1 = fp16 — the width the reference keeps its cache in
                                 (chair_test/chair_test.py:189-213: torch_dtype=float16): half the attention bytes; K/V are
                                 rounded to nearest-even when they enter the cache, attention arithmetic stays fp32 */
@@ -183,8 +187,9 @@ int dd_lm_destroy(dd_lm* h);
 /* bytes of device memory the handle holds (weights + KV + scratch) */
 size_t dd_lm_device_bytes(const dd_lm* h);
 
-/* Copy one HF-layout bf16 tensor (row-major, `rows` x `cols`) into the engine and re-tile it
- * for MFMA streaming. src may be a host or a device pointer (src_on_device).  Synchronous. */
+/* Copy one HF-layout 16-bit tensor (row-major, `rows` x `cols`) into the engine and re-tile it
+ * for MFMA streaming: bf16 bits for engines of weight_format 0 (and the embedding / norm vectors of fp8 engines), fp16 bits
+ * for weight_format 2.  src may be a host or a device pointer (src_on_device).  Synchronous. */
 int dd_lm_load_tensor(dd_lm* h, int tensor_id, int layer, const uint16_t* src_bf16, int rows, int cols,
                       int src_on_device);
 /* fp8 engines (weight_format 1): one matrix as OCP e4m3fn bytes [rows][cols] plus row_scale[rows]; W = scale * q.
