@@ -88,7 +88,6 @@ def cpu_baseline(K: int, budget_s: float = 20.0):
         host["malloc"] = "glibc defaults"
     torch.set_num_threads(max(1, int(host["physical_cores"])))
     torch.manual_seed(0)
-    cores = torch.get_num_threads()
     T, L, d, dff = 608, 576, 4096, 11008
     probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8][:K]
 
@@ -117,15 +116,23 @@ def cpu_baseline(K: int, budget_s: float = 20.0):
 
     t_all = time.perf_counter()
 
-    def probe(dt):
+    # the reference's CPU path runs in either dtype and torch's intra-op threading does not scale monotonically on big hosts
+    # (many small ops per layer): probe decode steps of a 2-layer slice over dtype x thread count, run the full model with the best
+    phys = max(1, int(host["physical_cores"]))
+    cand = sorted({t for t in (8, 16, 32, 64, phys) if t <= phys})
+    pr = {}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
         dec = make(2, dt)
-        dec.step(17)
-        t1 = time.perf_counter()
-        dec.step(17)
-        return time.perf_counter() - t1
-
-    pr = {"bf16": probe(torch.bfloat16), "fp32": probe(torch.float32)}
-    best = min(pr, key=pr.get)
+        for nt in cand:
+            torch.set_num_threads(nt)
+            dec.step(17)
+            t1 = time.perf_counter()
+            dec.step(17)
+            pr[(name, nt)] = time.perf_counter() - t1
+        del dec
+    best, cores = min(pr, key=pr.get)
+    torch.set_num_threads(cores)
+    probe_txt = ", ".join(f"{k[0]}/{k[1]}t {v:.2f}s" for k, v in sorted(pr.items()))
     need_gib = {"bf16": 13.3, "fp32": 26.5}[best] + 0.7 * (1 + K) * {"bf16": 0.5, "fp32": 1.0}[best] + 4
     layers = 32
     if host["mem_available_GiB"] and host["mem_available_GiB"] < need_gib:
@@ -149,8 +156,8 @@ def cpu_baseline(K: int, budget_s: float = 20.0):
             "weight_stream_GBs": round((1 + K) * wbytes / mean / 1e9, 1),
             "sample": f"oracle RefDecoder, reference-faithful decode steps ({1 + K} sequential batch-1 forwards, each on a copied KV cache) on the "
                       f"{'FULL 32-layer' if layers == 32 else str(layers) + '-layer slice (host memory too small for 32; scaled x32/' + str(layers) + ') of the'} "
-                      f"LLaVA-1.5-7B shapes at T=608, K={K}, torch-CPU {best} with {cores} threads (2-layer probe: bf16 {pr['bf16']:.2f} s, "
-                      f"fp32 {pr['fp32']:.2f} s per step); {len(steps)} timed steps after one warm-up: {[round(x, 2) for x in steps]} s "
+                      f"LLaVA-1.5-7B shapes at T=608, K={K}, torch-CPU {best} with {cores} of {phys} physical cores' worth of threads (the fastest of a "
+                      f"2-layer probe over dtype x threads, seconds per step: {probe_txt}); {len(steps)} timed steps after one warm-up: {[round(x, 2) for x in steps]} s "
                       f"(mean {sum(steps) / len(steps):.2f} s); decode only (prefill excluded); setup {t_setup:.0f} s + "
                       f"{time.perf_counter() - t_all - t_setup:.0f} s of timed CPU work"}
 
