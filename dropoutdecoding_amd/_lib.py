@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libdropdec.so")
 SYMBOLS = [
     "dd_version", "dd_last_error", "dd_arch",
     "dd_rng_create", "dd_rng_destroy", "dd_rng_seed", "dd_rng_uniform",
-    "dd_uncertainty_workspace_bytes", "dd_vision_uncertainty", "dd_overlap_keep", "dd_sample_masks", "dd_vote",
+    "dd_uncertainty_workspace_bytes", "dd_vision_uncertainty", "dd_overlap_keep", "dd_kl_keep", "dd_sample_masks", "dd_vote",
     "dd_argmax_rows",
     "dd_lm_create", "dd_lm_create_shared", "dd_lm_group_step", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_tensor_fp8", "dd_lm_load_synthetic",
     "dd_lm_prefill", "dd_lm_prefill_ensemble", "dd_lm_truncate", "dd_lm_prefill_extend", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     lib.dd_vision_uncertainty.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                           C.c_size_t, vp]
     lib.dd_overlap_keep.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.dd_kl_keep.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.dd_sample_masks.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,
                                     vp, vp]
     lib.dd_vote.argtypes = [vp, C.c_int, vp, vp]

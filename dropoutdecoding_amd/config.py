@@ -11,6 +11,7 @@ settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap
 # a harness that replaces this dict with the reference's three keys keeps working.
 #   settings['first_step_ensemble'] = True   -> the `# if True:` toggle at models/llava.py:336-337 (read per generate())
 #   settings['mask_method'] = 'epis_no_overlap' -> models/llava.py:663-683 / instructblip.py:486-505 (read at model build)
+#   settings['mask_method'] = 'epis_kl'      -> models/instructblip.py:464-485, 559-578 (InstructBLIP; read at model build)
 #   settings['use_avg'] = True               -> select_by_average, models/llava.py:37-52 (read at model build)
 # Not in the reference at all (its harness re-runs the whole prompt for every question):
 #   settings['reuse_image_prefix'] = True    -> consecutive prompts over the SAME image keep the image prefix's K/V,

@@ -405,6 +405,70 @@ int dd_overlap_keep_from_argmax(const int32_t* argmax_dev, const int32_t* topk_i
 }
 
 // ----------------------------------------------------------------------------------------------
+// "epis_kl" keep set (lowest_percent_kl_indices, reference models/instructblip.py:559-578; used at :483-485):
+//   kl[l] = sum_v p_step[v] * (log p_step[v] - log_softmax(image_logits[l])[v])      (F.kl_div(input = log-softmax of the
+//   token's prefill logits, target = softmax of the step's un-masked logits), summed over the vocabulary)
+//   keep = the int(0.1 * L) tokens with the smallest kl (value ascending, then index)
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_kl_rows(const float* __restrict__ step, const float* __restrict__ img, int V, int ld,
+                                                 float* __restrict__ kl_out, const int32_t* __restrict__ gate) {
+  __shared__ double sh_d[16];
+  __shared__ float sh_f[16];
+  if (gate && *gate) return;
+  const float* x = img + (size_t)blockIdx.x * ld;
+  float ms = -INFINITY, mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += 512) {
+    ms = fmaxf(ms, step[v]);
+    mx = fmaxf(mx, x[v]);
+  }
+  ms = block_max_f(ms, sh_f);
+  mx = block_max_f(mx, sh_f);
+  double ss = 0, sx = 0;
+  for (int v = threadIdx.x; v < V; v += 512) {
+    ss += (double)expf(step[v] - ms);
+    sx += (double)expf(x[v] - mx);
+  }
+  ss = block_sum_d(ss, sh_d);
+  sx = block_sum_d(sx, sh_d);
+  const float ls = ms + logf((float)ss), lx = mx + logf((float)sx);     // log-sum-exp of either row
+  double acc = 0;
+  for (int v = threadIdx.x; v < V; v += 512) {
+    float lp = step[v] - ls;                                            // log p_step
+    float p = expf(lp);
+    if (p > 0.f) acc += (double)(p * (lp - (x[v] - lx)));               // xlogy: a zero target contributes 0
+  }
+  acc = block_sum_d(acc, sh_d);
+  if (threadIdx.x == 0) kl_out[blockIdx.x] = (float)acc;
+}
+// one workgroup: keep[l] = 1 for the n_low smallest kl (rank by (value, index)); L <= 8192
+__global__ __launch_bounds__(1024) void k_kl_select(const float* __restrict__ kl, int L, int n_low, uint8_t* __restrict__ keep,
+                                                    const int32_t* __restrict__ gate) {
+  if (gate && *gate) return;
+  for (int l = threadIdx.x; l < L; l += 1024) {
+    const float v = kl[l];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) {
+      const float w = kl[j];
+      rank += (w < v || (w == v && j < l)) ? 1 : 0;
+    }
+    keep[l] = rank < n_low ? 1 : 0;
+  }
+}
+int dd_kl_keep_impl(const float* step_logits, const float* image_logits, int L, int V, int ld, float percent, uint8_t* keep,
+                    float* kl_ws, const int32_t* gate, hipStream_t st) {
+  DD_REQUIRE(step_logits && image_logits && keep && kl_ws && L >= 1 && L <= 8192 && V >= 2 && ld >= V, "dd_kl_keep: bad arguments");
+  k_kl_rows<<<L, 512, 0, st>>>(step_logits, image_logits, V, ld, kl_ws, gate);
+  DD_CHECK_LAUNCH();
+  k_kl_select<<<1, 1024, 0, st>>>(kl_ws, L, (int)(percent * (float)L), keep, gate);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+extern "C" int dd_kl_keep(const float* step_logits_dev, const float* image_logits_dev, int L, int V, int ld, uint8_t* keep_dev,
+                          float* kl_dev, void* stream) {
+  return dd_kl_keep_impl(step_logits_dev, image_logits_dev, L, V, ld, 0.1f, keep_dev, kl_dev, nullptr, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------------
 // mt19937 (torch CPU default generator) in device memory: 624 words + read index
 // ----------------------------------------------------------------------------------------------
 struct dd_rng {
@@ -621,7 +685,7 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
     }
   }
 
-  for (int k = 0; k < P.K; ++k) {
+  for (int k = 0; k < P.K; ++k) {   // DD_MASK_IBLIP_KL runs the NEXT_RESET rule: its keep flags come from dd_kl_keep instead of the overlap
     if (P.mode != DD_MASK_LLAVA_CUMULATIVE && P.mode != DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) {  // reset: llavanext.py:546, instructblip.py:121
       for (int l = tid; l < L; l += MASK_THREADS) running[l] = 0;
     }
@@ -773,7 +837,7 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
   DD_REQUIRE(epi && mprobs && drop && n_drop, "dd_sample_masks: null pointer");
   DD_REQUIRE(L >= 1 && L <= MASK_MAX_L, "dd_sample_masks: L=%d out of range (1..%d)", L, MASK_MAX_L);
   DD_REQUIRE(K >= 1 && K <= 64, "dd_sample_masks: K=%d out of range (1..64)", K);
-  DD_REQUIRE(mode >= 0 && mode <= 4, "dd_sample_masks: unknown mode %d", mode);
+  DD_REQUIRE(mode >= 0 && mode <= 5, "dd_sample_masks: unknown mode %d", mode);
   DD_REQUIRE(mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP || keep || empty_keep,
              "dd_sample_masks: keep flags required for mode %d", mode);
   if (mode != DD_MASK_IBLIP_QUANTILE) {

@@ -17,6 +17,8 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
                          int rng_mode, const float* uniforms, uint32_t* rng_state, uint8_t* drop, int32_t* n_drop,
                          int32_t* idx, uint8_t* drop_bits, const int32_t* gate, hipStream_t st, const uint32_t* rng_in = nullptr,
                          bool empty_keep = false);
+int dd_kl_keep_impl(const float* step_logits, const float* image_logits, int L, int V, int ld, float percent, uint8_t* keep,
+                    float* kl_ws, const int32_t* gate, hipStream_t st);
 int dd_spec_check(const uint8_t* keep, const uint8_t* drop_bits, int L, int K, const int32_t* done, int32_t* ok_out,
                   int keep_matters, hipStream_t st);
 int dd_copy_row_gated(const float* src, float* dst, int n, const int32_t* gate, hipStream_t st);
@@ -95,7 +97,7 @@ struct dd_lm {
   float *px, *pq, *image_logits;
   uint16_t *p1_hi, *p1_lo, *p2_hi, *p2_lo;
   int32_t* row_index;
-  float *epi, *alea, *var, *scalars, *topk_vals;
+  float *epi, *alea, *var, *scalars, *topk_vals, *kl_ws;
   int32_t* topk_ids;
   void* unc_ws;
   size_t unc_ws_bytes;
@@ -174,7 +176,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DD_REQUIRE(c->max_seq >= 2 && c->max_visual >= 1 && c->max_visual <= 8192, "dd_lm_create: bad max_seq/max_visual");
   DD_REQUIRE(c->max_seq <= 160 * 64, "dd_lm_create: max_seq %d exceeds the decode attention's %d key tiles of 64", c->max_seq, 160);
   DD_REQUIRE(c->k_top >= 1 && c->k_top <= DD_MAX_TOPK, "dd_lm_create: k_top out of range");
-  DD_REQUIRE(c->mask_mode >= 0 && c->mask_mode <= 4, "dd_lm_create: mask_mode");
+  DD_REQUIRE(c->mask_mode >= 0 && c->mask_mode <= 5, "dd_lm_create: mask_mode");
   DD_REQUIRE(c->vote_on >= 0 && c->vote_on <= 2, "dd_lm_create: vote_on");
   dd_lm* h = new dd_lm();
   h->serial = ++g_lm_serial;
@@ -293,6 +295,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->image_logits, (size_t)(h->Lmax + 1) * h->Vpad);
   DA(h->row_index, h->Lmax + 1);
   DA(h->epi, h->Lmax);
+  DA(h->kl_ws, h->Lmax);
   DA(h->alea, h->Lmax);
   DA(h->var, h->Lmax);
   DA(h->scalars, 4);
@@ -894,6 +897,14 @@ extern "C" int dd_lm_prefill_extend(dd_lm* h, const float* embeds, int n, void* 
   return DD_OK;
 }
 
+// the keep set of a step: overlap with the un-masked pass' argmax (models/llava.py:443-482) or, for "epis_kl", the tokens whose
+// prefill distribution is closest to the step's (instructblip.py:483-485)
+static int step_keep(dd_lm* h, const int32_t* gate, hipStream_t st) {
+  if (h->cfg.mask_mode == DD_MASK_IBLIP_KL)
+    return dd_kl_keep_impl(h->base_logits, h->image_logits, h->L, h->V, h->Vpad, 0.1f, h->keep, h->kl_ws, gate, st);
+  return dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, gate, st);
+}
+
 // the ensemble's vote (or mean) over the K member rows: sets state->winner / voted, member_tok[0] for the mean
 static int vote_members(dd_lm* h, int K, hipStream_t st) {
   if (h->cfg.vote_on == DD_VOTE_AVERAGE) {
@@ -1084,7 +1095,7 @@ extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rn
   RC(dd_argmax_rows_gated(h->base_logits, 1, h->V, h->Vpad, h->argmax_base, gate, st));
   h->last_K = K;
   if (K == 0) return DD_OK;
-  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, gate, st));
+  RC(step_keep(h, gate, st));
   int rng_mode = uniforms ? DD_RNG_INJECTED : DD_RNG_MT19937;
   DD_REQUIRE(h->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || uniforms || rng, "dd_lm_step: an rng or uniforms is required");
   RC(dd_sample_masks_impl(h->epi, h->L, mprobs, K, h->keep, h->cfg.mask_mode, rng_mode, uniforms,
@@ -1345,7 +1356,8 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   bool same_rule = true;
   for (int m = 0; m < n; ++m) {
     lanes[m]->last_K = K;
-    same_rule &= lanes[m]->cfg.mask_mode == h0->cfg.mask_mode && lanes[m]->cfg.k_top == h0->cfg.k_top;
+    same_rule &= lanes[m]->cfg.mask_mode == h0->cfg.mask_mode && lanes[m]->cfg.k_top == h0->cfg.k_top &&
+                 h0->cfg.mask_mode != DD_MASK_IBLIP_KL;        // the fused keep + mask launch computes the overlap keep set
   }
   if (K > 0 && same_rule) {          // keep sets + masks of all sequences: one launch, one workgroup per sequence
     MaskLaneArgs ml[32];
@@ -1358,7 +1370,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   } else if (K > 0) {
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
-      RC(dd_overlap_keep_from_argmax(q->argmax_base, q->topk_ids, q->L, q->cfg.k_top, q->keep, &q->state->done, st));
+      RC(step_keep(q, &q->state->done, st));
       RC(dd_sample_masks_impl(q->epi, q->L, mprobs, K, q->keep, q->cfg.mask_mode, DD_RNG_MT19937, nullptr,
                               dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop, nullptr, q->drop_bits,
                               &q->state->done, st));
@@ -1498,7 +1510,7 @@ static int decode_step_spec(dd_lm* h, const double* mprobs, int K, dd_rng* rng, 
   RC(dd_copy_row_gated(h->grp_logits, h->base_logits, h->Vpad, gate, st));
   RC(dd_argmax_rows_gated(h->base_logits, 1, h->V, h->Vpad, h->argmax_base, gate, st));
   // 3. the real keep set; did any member drop one of its tokens?
-  RC(dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, gate, st));
+  RC(step_keep(h, gate, st));
   const int keep_matters = (mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) ? 0 : 1;
   RC(dd_spec_check(h->keep, h->drop_bits, h->L, K, gate, h->spec_ok, keep_matters, st));
   // 4. fallback (returns at once when the speculation held): the reference's masks from the same draws, members re-run

@@ -16,6 +16,7 @@ from . import _lib
 
 MASK_LLAVA_CUMULATIVE, MASK_NEXT_RESET, MASK_NEXT_NO_OVERLAP, MASK_IBLIP_QUANTILE = 0, 1, 2, 3
 MASK_LLAVA_CUMULATIVE_NO_OVERLAP = 4      # models/llava.py:663-683 (dormant "epis_no_overlap"), cumulative call site
+MASK_IBLIP_KL = 5                         # models/instructblip.py:464-485 (dormant "epis_kl"): keep flags from lowest_percent_kl_indices
 RNG_INJECTED, RNG_MT19937 = 0, 1
 
 
@@ -147,3 +148,21 @@ def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.load().dd_argmax_rows(x2.data_ptr(), x2.shape[0], x2.shape[1], x2.stride(0), out.data_ptr(),
                                           _stream()), "dd_argmax_rows")
     return out
+
+
+def lowest_percent_kl_indices(image_logits: torch.Tensor, logits: torch.Tensor, percent: float = 0.1) -> torch.Tensor:
+    """models/instructblip.py:559-578 (same function at llava.py:758): indices of the int(percent * N) visual tokens whose
+    prefill distribution has the smallest KL from the step's distribution.  image_logits [1, N, V] (or [N, V]), logits [1, V]
+    (or [V]) fp32 on the GPU -> int64 indices, ascending KL."""
+    if percent != 0.1:
+        raise ValueError("the C-ABI entry point implements the reference's default percent = 0.1")
+    _need_cuda(image_logits, "image_logits")
+    img = image_logits.reshape(-1, image_logits.shape[-1]).float().contiguous()
+    st = logits.reshape(-1).float().contiguous()
+    L, V = img.shape
+    keep = torch.empty(L, dtype=torch.uint8, device=img.device)
+    kl = torch.empty(L, dtype=torch.float32, device=img.device)
+    _lib.check(_lib.load().dd_kl_keep(st.data_ptr(), img.data_ptr(), L, V, img.stride(0), keep.data_ptr(), kl.data_ptr(), _stream()),
+               "dd_kl_keep")
+    idx = torch.nonzero(keep).flatten()
+    return idx[torch.argsort(kl[idx], stable=True)]

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .config import settings
-from .dropout import (MASK_IBLIP_QUANTILE, MASK_LLAVA_CUMULATIVE, MASK_LLAVA_CUMULATIVE_NO_OVERLAP, MASK_NEXT_NO_OVERLAP,
+from .dropout import (MASK_IBLIP_KL, MASK_IBLIP_QUANTILE, MASK_LLAVA_CUMULATIVE, MASK_LLAVA_CUMULATIVE_NO_OVERLAP, MASK_NEXT_NO_OVERLAP,
                       MASK_NEXT_RESET,
                       TorchCpuCompatRNG)
 
@@ -117,8 +117,12 @@ class DropoutEngine:
             fam["mask_mode"] = MASK_NEXT_NO_OVERLAP           # settings['use_random'][0] (llavanext.py:547-550)
         if mask_method == "epis_no_overlap":                   # dormant variant (llava.py:663-683, instructblip.py:486-505)
             fam["mask_mode"] = MASK_LLAVA_CUMULATIVE_NO_OVERLAP if family == FAMILY_LLAVA else MASK_NEXT_NO_OVERLAP
+        elif mask_method == "epis_kl":                         # dormant variant, InstructBLIP only (instructblip.py:123, 464-485)
+            if family != FAMILY_IBLIP:
+                raise ValueError("mask_method 'epis_kl' exists for InstructBLIP only (models/instructblip.py:464-485)")
+            fam["mask_mode"] = MASK_IBLIP_KL
         elif mask_method != "epis":
-            raise ValueError(f"mask_method {mask_method!r}: only 'epis' (the shipped call sites) and 'epis_no_overlap'")
+            raise ValueError(f"mask_method {mask_method!r}: 'epis' (the shipped call sites), 'epis_no_overlap' or 'epis_kl'")
         if use_avg:
             fam["vote_on"] = VOTE_AVERAGE                       # select_by_average, llava.py:37-52 (settings['use_avg'])
         if family == FAMILY_IBLIP and iblip_positions == "mask":

@@ -48,6 +48,10 @@ extern "C" {
 #define DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP 4 /* models/llava.py:663-683 ("epis_no_overlap") at the :344 call site:
                                                * cumulative like mode 0, no keep-restore (dormant in the reference) */
 
+#define DD_MASK_IBLIP_KL 5          /* models/instructblip.py:464-485 ("epis_kl", the commented call at :123; dormant): stochastic rule
+                                     * and reset like mode 1, but the tokens restored are the 10 % with the lowest
+                                     * KL(step || token) — keep flags from dd_kl_keep — instead of the overlap keep set */
+
 /* where the dropout uniforms come from (models/llava.py:650 `torch.rand_like`) */
 #define DD_RNG_INJECTED 0           /* caller supplies uniforms[K][L] (parity tests)                     */
 #define DD_RNG_MT19937 1            /* torch-CPU-compatible mt19937 stream kept in device memory          */
@@ -101,6 +105,15 @@ int dd_overlap_keep(const float* step_logits_dev, int V, const int32_t* topk_ids
                     uint8_t* keep_dev, int32_t* argmax_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * "epis_kl" keep set. Replaces lowest_percent_kl_indices (models/instructblip.py:559-578; the same function at llava.py:758):
+ *   kl_dev[l] = sum_v softmax(step_logits)[v] * (log softmax(step_logits)[v] - log_softmax(image_logits[l])[v]),
+ *   keep_dev[l] = 1 for the int(0.1 * L) smallest (value, then index).  image_logits_dev [L][ld] fp32 (the prefill logits over
+ *   the visual span, models/llava.py:412-426), kl_dev [L] fp32 scratch / output.
+ * ------------------------------------------------------------------------------------------ */
+int dd_kl_keep(const float* step_logits_dev, const float* image_logits_dev, int L, int V, int ld, uint8_t* keep_dev,
+               float* kl_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Uncertainty-guided visual-token dropout masks for all K members of one step.
  * Replaces get_image_attention_mask(method="epis"/"epis_no_overlap") for the three families
  * (models/llava.py:589-683, llavanext.py:779-829, instructblip.py:447-460) including the
@@ -151,7 +164,7 @@ typedef struct dd_lm_config {
   int32_t max_seq;           /* KV capacity in tokens                       */
   int32_t max_visual;        /* max visual-span length L                    */
   int32_t k_top;             /* 5 (LLaVA-1.5) or 10 (NeXT, InstructBLIP)    */
-  int32_t mask_mode;         /* DD_MASK_*                                   */
+  int32_t mask_mode;         /* DD_MASK_* (0..5)                            */
   int32_t vote_on;           /* DD_VOTE_*                                   */
   int32_t leak_mask;         /* InstructBLIP Q2: 1 = the un-masked pass sees the last member's zeros (positions from the
                                 cache length, transformers 5.x); 2 = additionally position = T - #zeros (the 4.44 rule) */

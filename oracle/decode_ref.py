@@ -74,12 +74,15 @@ class RefDecoder:
         self.topk_vals, self.topk_ids = DR.topk_tokens(img, K_TOP[self.family])     # llava.py:310
         self.uncert = DR.vision_uncertainty(img[None])                  # llava.py:311-314
         self.epi = self.uncert["epis_uncert_per_token"][0]
+        self.image_logits = img
         self.prefill_logits = logits
         return int(torch.argmax(logits[-1]))                            # HF greedy on the prefill logits (Q9)
 
     def _mode(self) -> int:
         if self.family == FAMILY_LLAVA:
             return DR.MODE_LLAVA_CUMULATIVE_NO_OVERLAP if self.mask_method == "epis_no_overlap" else DR.MODE_LLAVA_CUMULATIVE
+        if self.mask_method == "epis_kl":
+            return DR.MODE_IBLIP_KL
         if self.mask_method == "epis_no_overlap":
             return DR.MODE_NEXT_NO_OVERLAP
         if self.family == FAMILY_NEXT:
@@ -162,9 +165,12 @@ class RefDecoder:
             return StepRecord(tok, np.zeros(self.L, bool), None, np.zeros((0, self.L), bool), [], [tok], 0, tok,
                               base_logits.numpy().copy(), base_logits.numpy().copy(), ph)
         t0 = time.perf_counter()
-        keep = DR.overlap_keep(base_logits, self.topk_ids)               # llava.py:603, 443-482
         K = len(self.mprobs)
         mode = self._mode()
+        if mode == DR.MODE_IBLIP_KL:
+            keep = DR.kl_keep(self.image_logits, base_logits)            # instructblip.py:483-485
+        else:
+            keep = DR.overlap_keep(base_logits, self.topk_ids)           # llava.py:603, 443-482
         uniforms = None
         if mode != DR.MODE_IBLIP_QUANTILE:
             # one rand_like(epi) per member, in list order (llava.py:650); contiguous stream

@@ -18,6 +18,9 @@ MODE_NEXT_RESET = 1         # models/llavanext.py:546-551 — reset before every
 MODE_NEXT_NO_OVERLAP = 2    # models/llavanext.py:809-829 — reset, no keep-restore ("epis_no_overlap")
 MODE_IBLIP_QUANTILE = 3     # models/instructblip.py:447-460 — deterministic top-quantile, reset, keep-restore
 MODE_LLAVA_CUMULATIVE_NO_OVERLAP = 4   # models/llava.py:663-683 at the :344 call site — cumulative, no keep-restore
+MODE_IBLIP_KL = 5           # models/instructblip.py:464-485 ("epis_kl", the commented call at :123) — reset, stochastic like
+                            # NeXT's rule, and the tokens restored are the 10 % with the LOWEST KL(step || token) instead of
+                            # the overlap keep set
 
 
 def vision_uncertainty(logits: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -71,6 +74,21 @@ def drop_probability(epi: torch.Tensor, mprob: float) -> torch.Tensor:
 def iblip_threshold(epi: torch.Tensor, mprob: float) -> torch.Tensor:
     """models/instructblip.py:450: `torch.quantile(epis_uncert, 1 - prob)` (linear interpolation)."""
     return torch.quantile(epi, 1 - mprob)
+
+
+def kl_keep(image_logits: torch.Tensor, step_logits: torch.Tensor, percent: float = 0.1) -> torch.Tensor:
+    """models/instructblip.py:559-578 (`lowest_percent_kl_indices`; same function at llava.py:758) as a bool[L] flag:
+    kl[l] = F.kl_div(log_softmax(image_logits[l]), softmax(step_logits), reduction='none').sum(-1) — i.e.
+    KL(step distribution || token l's distribution) — and the int(percent * L) smallest are restored (:483-485)."""
+    import torch.nn.functional as F
+    img = image_logits.reshape(-1, image_logits.shape[-1])
+    kl = F.kl_div(F.log_softmax(img, dim=-1), F.softmax(step_logits.reshape(1, -1), dim=-1).expand_as(img),
+                  reduction="none").sum(dim=-1)                          # :567-569
+    n = int(percent * kl.numel())                                       # :572
+    keep = torch.zeros(kl.numel(), dtype=torch.bool)
+    if n > 0:
+        keep[torch.topk(kl, n, largest=False).indices] = True           # :575
+    return keep
 
 
 def sample_masks(epi: torch.Tensor, mprobs: Sequence[float], keep: torch.Tensor, mode: int,

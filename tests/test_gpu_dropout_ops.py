@@ -193,3 +193,34 @@ def test_bad_arguments_raise(ops):
                          uniforms=torch.zeros(1, 9000).cuda())
     with pytest.raises(ValueError):
         ops.calculate_vision_uncertainty(torch.zeros(4, 8))          # CPU tensor: no CPU fallback
+
+
+@pytest.mark.parametrize("rng_mode", ["injected", "mt19937"])
+def test_epis_kl_keep_set_and_masks_golden(ops, golden_dir, rng_mode):
+    """dd_kl_keep (lowest_percent_kl_indices, instructblip.py:559-578) and the "epis_kl" masks (:464-485) against what the
+    reference's own functions produced; plus a 576 x 32064 case against the oracle."""
+    g, g7 = _load(golden_dir, "g3_masks.npz"), _load(golden_dir, "g7_variants.npz")
+    for c in range(int(g7["n_cases"])):
+        if f"c{c}_kl_lowest" not in g7.files:
+            continue
+        img = torch.from_numpy(g7[f"c{c}_kl_image_logits"]).cuda()
+        step = torch.from_numpy(g[f"c{c}_step_logits"]).cuda()
+        idx = ops.lowest_percent_kl_indices(img[None], step[None])
+        assert sorted(idx.cpu().tolist()) == sorted(g7[f"c{c}_kl_lowest"].tolist()), f"case {c}"
+        keep = torch.zeros(img.shape[0], dtype=torch.uint8, device="cuda")
+        keep[idx] = 1
+        epi = torch.from_numpy(g[f"c{c}_epi"]).cuda()
+        probs = [float(p) for p in g[f"c{c}_probs"]]
+        if rng_mode == "injected":
+            drop, nd = ops.sample_masks(epi, probs, keep, ops.MASK_IBLIP_KL, uniforms=torch.from_numpy(g[f"c{c}_uniforms"]).cuda())
+        else:
+            drop, nd = ops.sample_masks(epi, probs, keep, ops.MASK_IBLIP_KL, rng=ops.TorchCpuCompatRNG(int(g[f"c{c}_seed"])))
+        start, L = int(g[f"c{c}_start"]), epi.numel()
+        np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), g7[f"c{c}_iblip_kl_masks"][:, start:start + L] == 0,
+                                      err_msg=f"case {c} {rng_mode}")
+    gen = torch.Generator().manual_seed(4)
+    img = torch.randn(576, 32064, generator=gen) * 3.0
+    step = torch.randn(32064, generator=gen) * 3.0
+    want = torch.nonzero(DR.kl_keep(img, step)).flatten().tolist()
+    got = ops.lowest_percent_kl_indices(img.cuda(), step.cuda()).cpu().tolist()
+    assert sorted(got) == sorted(want) and len(got) == 57

@@ -77,3 +77,44 @@ def test_speculative_step_equals_two_sweep_step(E, family, K, use_random):
     want = RefDecoder(family, RC, w, probs, seed=7, use_random=use_random).generate(emb, s0, L, steps + 1)
     assert ref[1] == want
     eng.close()
+
+
+def test_epis_kl_mode_end_to_end_against_the_oracle(E):
+    """The dormant "epis_kl" method of InstructBLIP (models/instructblip.py:123, 464-485, 559-578): stochastic masks with the
+    reset, the 10 % of visual tokens whose prefill distribution is closest to the step's restored.  Engine (speculative and
+    two-sweep steps, and as a lane of a group) against the oracle restating the reference's functions."""
+    w = random_weights(RC, 31, 0.05)
+    cfg = E.LMConfig(RC.vocab_size, RC.hidden_size, RC.intermediate_size, RC.num_layers, RC.num_heads, RC.num_kv_heads,
+                     RC.head_dim, RC.rms_eps, RC.rope_theta)
+    L, s0, probs = 32, 0, [0.2, 0.4, 0.6, 0.8]
+    emb = torch.randn(L + 9, RC.hidden_size, generator=torch.Generator().manual_seed(78)) * 0.8
+    ref = RefDecoder(FAMILY_IBLIP, RC, w, probs, seed=7, mask_method="epis_kl")
+    want = ref.generate(emb, s0, L, 21)
+    eng = E.DropoutEngine(cfg, family=FAMILY_IBLIP, max_seq=192, max_visual=L, seed=7, mask_method="epis_kl")
+    eng.load_state_dict(w)
+    lib = eng.lib
+    for spec in (1, 0):
+        lib.dd_set_tuning(14, spec)
+        try:
+            eng.rng.manual_seed(7)
+            eng.prefill(emb.cuda(), s0, L)
+            for s in range(20):
+                eng.decode_step(probs)
+                st, r = eng.last_step(), ref.records[s]
+                np.testing.assert_array_equal(st["keep"], r.keep, err_msg=f"KL keep set, step {s} (spec={spec})")
+                np.testing.assert_array_equal(st["drop"], r.drop, err_msg=f"masks, step {s} (spec={spec})")
+                assert st["member_argmax"].tolist() == r.member_argmax and st["winner"] == r.winner
+            assert eng.tokens() == want
+        finally:
+            lib.dd_set_tuning(14, 1)
+    assert int(ref.records[0].keep.sum()) == 3                 # int(0.1 * 32)
+    lane = E.DropoutEngine(cfg, family=FAMILY_IBLIP, max_seq=192, max_visual=L, seed=9, mask_method="epis_kl", share_weights_with=eng)
+    emb2 = torch.randn(L + 5, RC.hidden_size, generator=torch.Generator().manual_seed(79)) * 0.8
+    eng.rng.manual_seed(7)
+    eng.prefill(emb.cuda(), s0, L)
+    lane.prefill(emb2.cuda(), s0, L)
+    got = E.EngineGroup([eng, lane]).generate(21, mprobs=probs)
+    assert got[0] == want
+    assert got[1] == RefDecoder(FAMILY_IBLIP, RC, w, probs, seed=9, mask_method="epis_kl").generate(emb2, s0, L, 21)
+    lane.close()
+    eng.close()

@@ -180,3 +180,23 @@ def test_g5_end_to_end_instructblip(golden_dir):
         np.testing.assert_array_equal(g["step_base_drop"][s].astype(bool), leaked)
     winners = [r.winner for r in dec.records]
     assert any(w != 0 for w in winners), "fixture should exercise a non-first winner"
+
+
+def test_g7_epis_kl_keep_set_and_masks(golden_dir):
+    """`epis_kl` (instructblip.py:464-485) and `lowest_percent_kl_indices` (:559-578): the reference's own outputs on the g3
+    inputs plus random image logits stored with the fixture."""
+    g, g7 = _load(golden_dir, "g3_masks.npz"), _load(golden_dir, "g7_variants.npz")
+    seen = 0
+    for c in range(int(g7["n_cases"])):
+        if f"c{c}_kl_lowest" not in g7.files:
+            continue
+        seen += 1
+        epi = torch.from_numpy(g[f"c{c}_epi"])
+        probs = [float(p) for p in g[f"c{c}_probs"]]
+        img = torch.from_numpy(g7[f"c{c}_kl_image_logits"])
+        keep = DR.kl_keep(img, torch.from_numpy(g[f"c{c}_step_logits"]))
+        assert sorted(torch.nonzero(keep).flatten().tolist()) == sorted(g7[f"c{c}_kl_lowest"].tolist()), f"case {c}"
+        drop = DR.sample_masks(epi, probs, keep, DR.MODE_IBLIP_KL, torch.from_numpy(g[f"c{c}_uniforms"]))
+        start, L = int(g[f"c{c}_start"]), epi.numel()
+        np.testing.assert_array_equal(drop.numpy(), g7[f"c{c}_iblip_kl_masks"][:, start:start + L] == 0, err_msg=f"case {c}")
+    assert seen >= 4
