@@ -78,3 +78,60 @@ class KShardDecoder:
                 self.decode_step(mprobs)
             toks = self.e.tokens()
         return toks[:n_new]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tensor-parallel decode: the only route to single-stream multi-GPU speed-up — K-sharding leaves
+# every rank streaming all weights twice per token.  What is here: the shard plan (which slice of which tensor a rank
+# holds, head-aligned), the collectives a sweep needs, and a torch reference of the sharded forward that runs under any
+# torch.distributed backend (the gloo tests check it against the unsharded forward).  The HIP engine does not take sharded
+# weights yet: its GEMV epilogues fuse residual + next-norm packing, which under TP have to run AFTER the all-reduce (see
+# DESIGN.md "Tensor-parallel decode": the row-parallel matrices end in the slice kernels' partial-sum form, the all-reduce
+# replaces the slice sum, and k_gemv_finish's epilogue runs unchanged on the reduced sums).
+# ---------------------------------------------------------------------------------------------------------------------
+class TensorParallelPlan:
+    """Megatron-style split of one decoder layer over `world` ranks:
+
+      q/k/v_proj   column-parallel, by kv head group (a rank owns kv heads [kv_lo, kv_hi) and their q heads): no comm
+      attention    local to the rank's heads (its slice of the KV cache: 1/world of the cache bytes)
+      o_proj       row-parallel over the rank's head columns -> partial [rows, d]  -> ALL-REDUCE (sum) #1
+      gate/up      column-parallel over d_ff / world                                 no comm
+      down_proj    row-parallel over the rank's d_ff slice -> partial [rows, d]     -> ALL-REDUCE (sum) #2
+      lm_head      column-parallel over the vocabulary; the argmax needs (value, index) pairs: one small all-gather per sweep
+
+    Per sweep: 2 * n_layers all-reduces of rows * d fp32 (LLaVA-1.5-7B, 9 rows: 147 KB each) — latency-bound on xGMI."""
+
+    def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, hidden: int, intermediate: int, world: int):
+        if num_kv_heads % world or intermediate % (world * 16):
+            raise ValueError(f"{num_kv_heads} kv heads / d_ff {intermediate} do not split over {world} ranks on head / tile boundaries")
+        self.world, self.H, self.Hkv, self.hd, self.d, self.dff = world, num_heads, num_kv_heads, head_dim, hidden, intermediate
+        self.G = num_heads // num_kv_heads
+
+    def kv_heads(self, rank: int) -> Tuple[int, int]:
+        per = self.Hkv // self.world
+        return rank * per, (rank + 1) * per
+
+    def ff_range(self, rank: int) -> Tuple[int, int]:
+        per = self.dff // self.world
+        return rank * per, (rank + 1) * per
+
+    def shard_layer(self, sd: dict, prefix: str, rank: int) -> dict:
+        """This rank's slices of one layer's HF tensors (norm vectors are replicated)."""
+        k0, k1 = self.kv_heads(rank)
+        q0, q1 = k0 * self.G * self.hd, k1 * self.G * self.hd
+        f0, f1 = self.ff_range(rank)
+        g = lambda n: sd[prefix + n]
+        return {
+            "input_layernorm.weight": g("input_layernorm.weight"), "post_attention_layernorm.weight": g("post_attention_layernorm.weight"),
+            "self_attn.q_proj.weight": g("self_attn.q_proj.weight")[q0:q1], "self_attn.k_proj.weight": g("self_attn.k_proj.weight")[k0 * self.hd:k1 * self.hd],
+            "self_attn.v_proj.weight": g("self_attn.v_proj.weight")[k0 * self.hd:k1 * self.hd], "self_attn.o_proj.weight": g("self_attn.o_proj.weight")[:, q0:q1],
+            "mlp.gate_proj.weight": g("mlp.gate_proj.weight")[f0:f1], "mlp.up_proj.weight": g("mlp.up_proj.weight")[f0:f1],
+            "mlp.down_proj.weight": g("mlp.down_proj.weight")[:, f0:f1],
+        }
+
+    def collectives_per_sweep(self, n_layers: int, rows: int) -> dict:
+        return {"all_reduce": 2 * n_layers, "bytes_each": rows * self.d * 4, "all_gather": 1, "all_gather_bytes": rows * 8 * self.world}
+
+    def weight_bytes_per_rank(self, n_layers: int, vocab: int, bytes_per_weight: int = 2) -> int:
+        per_layer = (self.H * self.hd * self.d * 2 + 2 * self.Hkv * self.hd * self.d + 3 * self.d * self.dff) // self.world
+        return (n_layers * per_layer + vocab * self.d // self.world) * bytes_per_weight

@@ -141,3 +141,83 @@ def test_kshard_protocol_matches_single_process(world):
     for rank, toks, ksum in out:
         assert toks == want, (rank, toks, want)
         assert abs(ksum - want_ksum) < 1e-6 * max(1.0, abs(want_ksum))      # caches identical on every rank
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+# ---- tensor-parallel plan: the sharded forward with two all-reduces per layer equals the unsharded one
+def _tp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dropoutdecoding_amd.dist import TensorParallelPlan
+        import torch.nn.functional as F
+        from oracle.lm_ref import _rotate_half, rms_norm, rope_cos_sin
+        cfg = LMConfig(128, 256, 512, 2, 4, 4, 64, 1e-5, 10000.0)      # 4 kv heads of 64: splits over 2 and 4 ranks
+        w = random_weights(cfg, 3, 0.05)
+        plan = TensorParallelPlan(cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size, world)
+        T = 12
+        x = torch.randn(T, cfg.hidden_size, generator=torch.Generator().manual_seed(5))
+        pos = torch.arange(T)
+        cos, sin = rope_cos_sin(cfg, pos, torch.float32)
+        k0, k1 = plan.kv_heads(rank)
+        nh = (k1 - k0) * plan.G
+        causal = torch.ones(T, T, dtype=torch.bool).tril()
+        h = x
+        for i in range(cfg.num_layers):
+            sh = plan.shard_layer(w, f"model.layers.{i}.", rank)
+            hn = rms_norm(h, sh["input_layernorm.weight"], cfg.rms_eps)
+            qh = F.linear(hn, sh["self_attn.q_proj.weight"]).view(T, nh, cfg.head_dim).transpose(0, 1)
+            kh = F.linear(hn, sh["self_attn.k_proj.weight"]).view(T, k1 - k0, cfg.head_dim).transpose(0, 1)
+            vh = F.linear(hn, sh["self_attn.v_proj.weight"]).view(T, k1 - k0, cfg.head_dim).transpose(0, 1)
+            qh = qh * cos[None] + _rotate_half(qh) * sin[None]
+            kh = kh * cos[None] + _rotate_half(kh) * sin[None]
+            att = (qh @ kh.repeat_interleave(plan.G, 0).transpose(1, 2)) * cfg.head_dim ** -0.5
+            att = torch.softmax(att.masked_fill(~causal, torch.finfo(torch.float32).min), -1)
+            o = (att @ vh.repeat_interleave(plan.G, 0)).transpose(0, 1).reshape(T, nh * cfg.head_dim)
+            part = F.linear(o, sh["self_attn.o_proj.weight"])                 # row-parallel: partial sums of [T, d]
+            dist.all_reduce(part)                                             # all-reduce #1
+            h = h + part
+            hn = rms_norm(h, sh["post_attention_layernorm.weight"], cfg.rms_eps)
+            part = F.linear(F.silu(F.linear(hn, sh["mlp.gate_proj.weight"])) * F.linear(hn, sh["mlp.up_proj.weight"]), sh["mlp.down_proj.weight"])
+            dist.all_reduce(part)                                             # all-reduce #2
+            h = h + part
+        hid = rms_norm(h, w["model.norm.weight"], cfg.rms_eps)
+        from oracle.lm_ref import KVCache
+        ref = lm_hidden(cfg, w, x, pos, KVCache())
+        err = float((hid - ref).abs().max() / ref.abs().max())
+        v0, v1 = rank * cfg.vocab_size // world, (rank + 1) * cfg.vocab_size // world
+        loc = F.linear(hid[-1:], w["lm_head.weight"][v0:v1])[0]               # column-parallel lm_head: local (value, index) best
+        best = torch.tensor([float(loc.max()), float(v0 + int(loc.argmax()))], dtype=torch.float64)
+        allb = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allb, best)
+        tok = int(max(allb, key=lambda t: (float(t[0]), -float(t[1])))[1])    # larger value first, then the lower index
+        want = int(torch.argmax(lm_logits(cfg, w, ref[-1:])[0]))
+        c = plan.collectives_per_sweep(cfg.num_layers, T)
+        q.put((rank, err, tok == want, c["all_reduce"], plan.weight_bytes_per_rank(cfg.num_layers, cfg.vocab_size)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tensor_parallel_plan_equals_the_unsharded_forward(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, err, tok_ok, n_ar, wbytes in res:
+        assert err < 1e-5 and tok_ok and n_ar == 4
+    assert len({r[4] for r in res}) == 1                      # every rank streams the same share of the weights
