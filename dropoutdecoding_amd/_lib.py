@@ -19,6 +19,7 @@ SYMBOLS = [
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_set_eos", "dd_lm_step_algorithmic_bytes",
     "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench",
     "dd_vit_create", "dd_vit_destroy", "dd_vit_load_tensor", "dd_vit_forward",
+    "dd_qformer_create", "dd_qformer_destroy", "dd_qformer_load_tensor", "dd_qformer_forward",
 ]
 
 
@@ -29,7 +30,14 @@ class DDError(RuntimeError):
 class VitConfigC(C.Structure):
     _fields_ = [("image_size", C.c_int32), ("patch_size", C.c_int32), ("hidden_size", C.c_int32),
                 ("intermediate_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
-                ("proj_dim", C.c_int32), ("act", C.c_int32), ("ln_eps", C.c_float), ("reserved", C.c_int32 * 7)]
+                ("proj_dim", C.c_int32), ("act", C.c_int32), ("ln_eps", C.c_float), ("flags", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+class QFormerConfigC(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("num_heads", C.c_int32), ("num_layers", C.c_int32), ("intermediate_size", C.c_int32),
+                ("encoder_hidden_size", C.c_int32), ("cross_attention_frequency", C.c_int32), ("num_query_tokens", C.c_int32),
+                ("vocab_size", C.c_int32), ("max_position_embeddings", C.c_int32), ("proj_dim", C.c_int32),
+                ("max_text_tokens", C.c_int32), ("max_encoder_tokens", C.c_int32), ("ln_eps", C.c_float)]
 
 
 class LMConfigC(C.Structure):
@@ -119,6 +127,10 @@ def load() -> C.CDLL:
     lib.dd_vit_destroy.argtypes = [vp]
     lib.dd_vit_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     lib.dd_vit_forward.argtypes = [vp, vp, C.c_int, vp, vp]
+    lib.dd_qformer_create.argtypes = [C.POINTER(QFormerConfigC), C.POINTER(vp)]
+    lib.dd_qformer_destroy.argtypes = [vp]
+    lib.dd_qformer_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    lib.dd_qformer_forward.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     if os.environ.get("DD_NO_GRAPH", "0") not in ("", "0"):
         lib.dd_set_tuning(8, 0)          # launch every decode step kernel by kernel instead of replaying hipGraphs

@@ -147,7 +147,9 @@ void ddk_set_attn_split(int v);
 void ddk_set_prefill_mfma(int on);
 int ddk_prefill_mfma_enabled();
 int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
-                      hipStream_t st);   // CLIP tower attention (head_dim 64, bidirectional) on the matrix cores
+                      hipStream_t st, int head_pitch = 64, int Tk = 0, float scaling = 1.0f);
+// bidirectional attention on the matrix cores: head pitch 64 or 96; Tk > 0: T queries against Tk keys (cross-attention);
+// scaling multiplies the scores (1 when q arrives pre-scaled)
 
 struct AttnDecodeArgs {
   const float* qbuf;     // [8][q_dim] roped
@@ -198,7 +200,9 @@ struct GemmArgs {
   const float* wscale;   // per-column (output row of W) scales in packed-row order, or nullptr
   const float* bias;     // per-column bias (natural order) added after the scale, or nullptr
   int act;               // EPI_ACT: 0 quick_gelu, 1 gelu(erf), 2 identity
-  int vit_hidden, vit_head_dim;   // EPI_QKV_VIT
+  int vit_hidden, vit_head_dim, vit_head_pad;   // EPI_QKV_VIT (head_pad: pitch of a head in q / K^T / V; 0 = head_dim)
+  int vit_col0;          // EPI_QKV_VIT: output column c of W counts as column c + vit_col0 of a fused [q | k | v] projection
+                         // (a [k | v] weight of a cross-attention runs with vit_col0 = hidden)
   float vit_qscale;
   int n_tiles;           // 16-col tiles (EPI_SILU: gate/up tiles interleaved, n_tiles = 2 * d_ff/16)
   float* out;            // EPI_STORE [M][ldo] / EPI_RESID x[M][ldo]

@@ -1479,15 +1479,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
           }
         } else if (EPI == EPI_QKV_VIT) {
           if (ok) {
-            int col = nt * 16 + c, hd = a.vit_head_dim;
+            // hp: head pitch of the q / K^T / V buffers (= hd, or hd padded to a multiple of 32 for the matrix-core attention:
+            // EVA ViT-g's 88 -> 96; the pad columns stay zero)
+            int col = nt * 16 + c + a.vit_col0, hd = a.vit_head_dim, hp = a.vit_head_pad ? a.vit_head_pad : hd;
             if (col < a.vit_hidden) {
-              a.qbuf[(size_t)row * a.vit_hidden + col] = y * a.vit_qscale;
+              a.qbuf[(size_t)row * (a.vit_hidden / hd * hp) + (col / hd) * hp + col % hd] = y * a.vit_qscale;
             } else if (col < 2 * a.vit_hidden) {
               int cc = col - a.vit_hidden, head = cc / hd, idx = cc % hd;
-              a.kc[(((size_t)head * (hd >> 2) + (idx >> 2)) * a.T_cap + row) * 4 + (idx & 3)] = y;
+              a.kc[(((size_t)head * (hp >> 2) + (idx >> 2)) * a.T_cap + row) * 4 + (idx & 3)] = y;
             } else {
               int cc = col - 2 * a.vit_hidden, head = cc / hd, idx = cc % hd;
-              a.vc[((size_t)head * a.T_cap + row) * hd + idx] = y;
+              a.vc[((size_t)head * a.T_cap + row) * hp + idx] = y;
             }
           }
         } else {  // EPI_QKV
@@ -1681,7 +1683,9 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
                                                            const float* __restrict__ vc, int T, int T_cap, int n_heads,
                                                            uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
                                                            const uint8_t* __restrict__ drop_plane, int drop_bit,
-                                                           int span_start, int span_len, int q0, int causal, float scaling, int wf) {
+                                                           int span_start, int span_len, int q0, int causal, float scaling, int wf,
+                                                           int Tk) {
+  // Tk: number of keys when not causal (cross-attention: T queries against Tk keys of another sequence; = T for self-attention)
   constexpr int LD = HD + 4;   // padded row pitch (floats) of the staged K / V tiles: keeps the V^T reads conflict-free
   constexpr int KS = HD / 32, DT = HD / 16, C4 = HD / 4;
   __shared__ __align__(16) float Ksh[FA_KEYS * LD];
@@ -1697,8 +1701,8 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
   const int pos_q = q0 + max(0, min(t_q, T - 1));             // its absolute position
   const int blk_last = min(blk_first + 63, T - 1);
   if (blk_last < 0) return;
-  const int p_max = causal ? q0 + blk_last : T - 1;           // last key any query of the workgroup attends to
-  const int wave_pmax = causal ? q0 + min(blk_first + wave * 16 + 15, T - 1) : T - 1;   // ... of this wave
+  const int p_max = causal ? q0 + blk_last : Tk - 1;          // last key any query of the workgroup attends to
+  const int wave_pmax = causal ? q0 + min(blk_first + wave * 16 + 15, T - 1) : Tk - 1;  // ... of this wave
   const bool wave_live = blk_first + wave * 16 < T && blk_first + wave * 16 + 15 >= 0;
 
   // Q^T operands of the lane: B[k = d 8 g4 .. +8][j = query c16], four 32-d steps, hi and lo
@@ -1771,7 +1775,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = t0 + kt * 16 + g4 * 4 + r;
-        bool ok = causal ? key <= pos_q : key < T;
+        bool ok = causal ? key <= pos_q : key < Tk;
         if (ok && drop_plane && key >= span_start && key < span_start + span_len) ok = !((drop_plane[key - span_start] >> drop_bit) & 1);
         sv[kt * 4 + r] = ok ? sacc[r] * scaling : -INFINITY;
       }
@@ -1830,9 +1834,15 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
 
 // bidirectional attention of the CLIP tower (head_dim 64, q pre-scaled by the QKV epilogue), same kernel
 int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
-                      hipStream_t st) {
-  k_attn_prefill_mfma<1, 64><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0,
-                                                                          0, 1.0f, 0);
+                      hipStream_t st, int head_pitch, int Tk, float scaling) {
+  DD_REQUIRE(head_pitch == 64 || head_pitch == 96, "attn_vit: head pitch %d (64, or 96 for 88-wide heads)", head_pitch);
+  if (Tk <= 0) Tk = T;
+  if (head_pitch == 96)
+    k_attn_prefill_mfma<1, 96><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0,
+                                                                            0, scaling, 0, Tk);
+  else
+    k_attn_prefill_mfma<1, 64><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0,
+                                                                          0, scaling, 0, Tk);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -1859,7 +1869,7 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
   }
   if (g_prefill_mfma) {
     dim3 g2(n_heads, (T + (q0 & 15) + 63) / 64);
-#define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f, wf
+#define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f, wf, T
     if (kv16) {
       if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
       else if (G == 2) k_attn_prefill_mfma<2, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);

@@ -1,4 +1,7 @@
-// CLIP-style vision tower + LLaVA projector on own kernels (the vision front-end).
+// ViT vision towers on own kernels (the vision front-end): CLIP ViT-L/14 + LLaVA projector, and
+// InstructBLIP's EVA ViT-g/14 (1408 wide, 16 heads of 88 — padded to a pitch of 96 for the matrix-core attention —, no
+// pre-LayerNorm, patch bias, post-LayerNorm over all 257 tokens: what models/instructblip.py:607-612 gets from
+// `self.vision_model(...)`).
 // Replaces, for LLaVA-1.5 / LLaVA-NeXT tiles, what the reference runs through third-party modules at
 // models/llava.py:233-246 (vision_tower(pixel_values, output_hidden_states=True).hidden_states[-2][:, 1:] ->
 // multi_modal_projector) and models/llavanext.py:409-417.
@@ -13,6 +16,8 @@
 // ---- tensor ids (HF CLIPVisionModel / LlavaMultiModalProjector parameter names) -----------------------------------
 // see include/dropdec.h
 
+__global__ void k_pad_head_cols(const uint16_t* __restrict__ src, int d, int hd, int hp, int H, uint16_t* __restrict__ dst);
+
 struct VitLayer {
   u32x4_t *wqkv, *wo, *wfc1, *wfc2;
   float *bqkv, *bo, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
@@ -20,12 +25,15 @@ struct VitLayer {
 
 struct dd_vit {
   dd_vit_config cfg;
-  int T, Tc, P, d, dff, H, hd, Kp, Sp, proj;   // tokens (patches+1), padded tokens, patches, hidden, mlp, heads, head dim, padded patch K
+  int T, Tc, P, d, dff, H, hd, hp, Kp, Sp, proj;   // tokens (patches+1), padded tokens, patches, hidden, mlp, heads, head dim, head pitch, padded patch K
+  int no_pre_ln = 0, post_ln = 0, keep_cls = 0;
   std::vector<void*> allocs;
   size_t bytes = 0;
   std::vector<VitLayer> lw;
   u32x4_t *wpatch = nullptr, *wp1 = nullptr, *wp2 = nullptr;
   float *cls = nullptr, *pos = nullptr, *prew = nullptr, *preb = nullptr, *bp1 = nullptr, *bp2 = nullptr;
+  float *bpatch = nullptr, *postw = nullptr, *postb = nullptr;
+  uint16_t* wo_pad = nullptr;   // staging for o_proj weights with head columns spread to the head pitch
   // scratch
   float *x = nullptr, *q = nullptr, *kt = nullptr, *v = nullptr;
   uint16_t *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
@@ -73,7 +81,7 @@ extern "C" int dd_vit_create(const dd_vit_config* c, dd_vit** out) {
   DD_REQUIRE(c->hidden_size % 64 == 0 && c->intermediate_size % 64 == 0, "dd_vit_create: hidden/intermediate must be multiples of 64");
   DD_REQUIRE(c->hidden_size % c->num_heads == 0, "dd_vit_create: heads");
   int hd = c->hidden_size / c->num_heads;
-  DD_REQUIRE(hd == 64, "dd_vit_create: head_dim must be 64 (CLIP ViT-L/14), got %d", hd);
+  DD_REQUIRE(hd == 64 || hd == 88, "dd_vit_create: head_dim must be 64 (CLIP ViT-L/14) or 88 (EVA ViT-g/14), got %d", hd);
   DD_REQUIRE(c->proj_dim == 0 || c->proj_dim % 64 == 0, "dd_vit_create: proj_dim must be a multiple of 64");
   DD_REQUIRE(c->num_layers >= 1, "dd_vit_create: num_layers");
   dd_vit* h = new dd_vit();
@@ -81,13 +89,16 @@ extern "C" int dd_vit_create(const dd_vit_config* c, dd_vit** out) {
   int g = c->image_size / c->patch_size;
   h->P = g * g, h->T = h->P + 1, h->Tc = (h->T + 63) / 64 * 64;
   h->d = c->hidden_size, h->dff = c->intermediate_size, h->H = c->num_heads, h->hd = hd, h->proj = c->proj_dim;
+  h->hp = (hd + 31) / 32 * 32;                      // 64 -> 64, 88 -> 96
+  h->no_pre_ln = c->flags & DD_VIT_NO_PRE_LN ? 1 : 0, h->post_ln = c->flags & DD_VIT_POST_LN ? 1 : 0, h->keep_cls = c->flags & DD_VIT_KEEP_CLASS ? 1 : 0;
+  DD_REQUIRE(!(h->proj && h->keep_cls), "dd_vit_create: the projector path drops the class token");
   int kp = 3 * c->patch_size * c->patch_size;
   h->Kp = (kp + 63) / 64 * 64, h->Sp = h->Kp / 32;
   const int d = h->d, dff = h->dff;
   h->lw.resize(c->num_layers);
   for (auto& w : h->lw) {
     VA(w.wqkv, (size_t)(3 * d / 16) * (d / 32) * 64);
-    VA(w.wo, (size_t)(d / 16) * (d / 32) * 64);
+    VA(w.wo, (size_t)(d / 16) * (h->H * h->hp / 32) * 64);
     VA(w.wfc1, (size_t)(dff / 16) * (d / 32) * 64);
     VA(w.wfc2, (size_t)(d / 16) * (dff / 32) * 64);
     VA(w.bqkv, 3 * d); VA(w.bo, d); VA(w.bfc1, dff); VA(w.bfc2, d);
@@ -95,6 +106,8 @@ extern "C" int dd_vit_create(const dd_vit_config* c, dd_vit** out) {
   }
   VA(h->wpatch, (size_t)(d / 16) * h->Sp * 64);
   VA(h->cls, d); VA(h->pos, (size_t)h->T * d); VA(h->prew, d); VA(h->preb, d);
+  VA(h->bpatch, d); VA(h->postw, d); VA(h->postb, d);
+  if (h->hp != hd) VA(h->wo_pad, (size_t)d * h->H * h->hp);
   if (h->proj) {
     VA(h->wp1, (size_t)(h->proj / 16) * (d / 32) * 64);
     VA(h->wp2, (size_t)(h->proj / 16) * (h->proj / 32) * 64);
@@ -102,12 +115,15 @@ extern "C" int dd_vit_create(const dd_vit_config* c, dd_vit** out) {
   }
   size_t wmax = (size_t)(dff > h->Kp ? dff : h->Kp);
   if ((size_t)h->proj > wmax) wmax = h->proj;
+  const size_t dq = (size_t)h->H * h->hp;           // width of q / K^T / V and of the attention output planes
+  size_t amax = d > h->Kp ? d : h->Kp;
+  if (dq > amax) amax = dq;
   VA(h->x, (size_t)h->Tc * d);
-  VA(h->q, (size_t)h->Tc * d);
-  VA(h->kt, (size_t)h->Tc * d);
-  VA(h->v, (size_t)h->Tc * d);
-  VA(h->a_hi, (size_t)h->Tc * (d > h->Kp ? d : h->Kp));
-  VA(h->a_lo, (size_t)h->Tc * (d > h->Kp ? d : h->Kp));
+  VA(h->q, (size_t)h->Tc * dq);
+  VA(h->kt, (size_t)h->Tc * dq);
+  VA(h->v, (size_t)h->Tc * dq);
+  VA(h->a_hi, (size_t)h->Tc * amax);
+  VA(h->a_lo, (size_t)h->Tc * amax);
   VA(h->b_hi, (size_t)h->Tc * wmax);
   VA(h->b_lo, (size_t)h->Tc * wmax);
   *out = h;
@@ -116,7 +132,7 @@ extern "C" int dd_vit_create(const dd_vit_config* c, dd_vit** out) {
 
 extern "C" int dd_vit_load_tensor(dd_vit* h, int id, int layer, const uint16_t* src, int rows, int cols, int on_device) {
   DD_REQUIRE(h && src, "dd_vit_load_tensor: null argument");
-  DD_REQUIRE(id >= DD_VT_PATCH && id <= DD_VT_PROJ2_B, "dd_vit_load_tensor: unknown tensor id %d", id);
+  DD_REQUIRE(id >= DD_VT_PATCH && id <= DD_VT_POST_LN_B, "dd_vit_load_tensor: unknown tensor id %d", id);
   bool per_layer = id >= DD_VT_LN1_W && id <= DD_VT_FC2_B;
   DD_REQUIRE(!per_layer || (layer >= 0 && layer < (int)h->lw.size()), "dd_vit_load_tensor: layer %d out of range", layer);
   const int d = h->d, dff = h->dff;
@@ -163,7 +179,15 @@ extern "C" int dd_vit_load_tensor(dd_vit* h, int id, int layer, const uint16_t* 
     case DD_VT_BQ: rc = vec(w->bqkv, d); break;
     case DD_VT_BK: rc = vec(w->bqkv + d, d); break;
     case DD_VT_BV: rc = vec(w->bqkv + 2 * d, d); break;
-    case DD_VT_WO: rc = mat(w->wo, d, d, 0, d / 16); break;
+    case DD_VT_WO:
+      if (h->hp == h->hd) {
+        rc = mat(w->wo, d, d, 0, d / 16);
+      } else {   // out_proj reads the attention output at the head pitch: its columns move to head * pitch + idx, pads are zero
+        DD_REQUIRE(rows == d && cols == d, "dd_vit_load_tensor: out_proj expects %d x %d", d, d);
+        k_pad_head_cols<<<d, 256>>>(dev, d, h->hd, h->hp, h->H, h->wo_pad);
+        rc = ddk_pack_weight(h->wo_pad, d, h->H * h->hp, w->wo, 0, 1, PACK_PLAIN, d / 16, nullptr);
+      }
+      break;
     case DD_VT_BO: rc = vec(w->bo, d); break;
     case DD_VT_LN2_W: rc = vec(w->ln2w, d); break;
     case DD_VT_LN2_B: rc = vec(w->ln2b, d); break;
@@ -175,6 +199,9 @@ extern "C" int dd_vit_load_tensor(dd_vit* h, int id, int layer, const uint16_t* 
     case DD_VT_PROJ1_B: DD_REQUIRE(h->proj, "no projector configured"); rc = vec(h->bp1, h->proj); break;
     case DD_VT_PROJ2_W: DD_REQUIRE(h->proj, "no projector configured"); rc = mat(h->wp2, h->proj, h->proj, 0, h->proj / 16); break;
     case DD_VT_PROJ2_B: DD_REQUIRE(h->proj, "no projector configured"); rc = vec(h->bp2, h->proj); break;
+    case DD_VT_PATCH_B: rc = vec(h->bpatch, d); break;
+    case DD_VT_POST_LN_W: rc = vec(h->postw, d); break;
+    case DD_VT_POST_LN_B: rc = vec(h->postb, d); break;
   }
   hipError_t e = hipDeviceSynchronize();
   if (staging) (void)hipFree(staging);
@@ -184,6 +211,14 @@ extern "C" int dd_vit_load_tensor(dd_vit* h, int id, int layer, const uint16_t* 
 }
 
 // ---- kernels --------------------------------------------------------------------------------------------------------
+// W_o [d][H * hd] -> [d][H * hp] (bf16 bits), head h's columns at h * hp, pad columns zero
+__global__ __launch_bounds__(256) void k_pad_head_cols(const uint16_t* __restrict__ src, int d, int hd, int hp, int H, uint16_t* __restrict__ dst) {
+  const int row = blockIdx.x;
+  for (int c = threadIdx.x; c < H * hp; c += 256) {
+    int head = c / hp, idx = c % hp;
+    dst[(size_t)row * H * hp + c] = idx < hd ? src[(size_t)row * d + head * hd + idx] : (uint16_t)0;
+  }
+}
 // pixels [3][H][W] fp32 -> im2col rows (one per patch, k = c*p*p + ky*p + kx, zero-padded to Kp) as packed hi/lo planes
 // with a row offset of 1 (row 0 is the class token, filled elsewhere)
 __global__ __launch_bounds__(256) void k_vit_patchify(const float* __restrict__ px, int img, int p, int Kp, uint16_t* hi,
@@ -320,29 +355,31 @@ extern "C" int dd_vit_forward(dd_vit* h, const float* pixels, int n_images, floa
     DD_CHECK_LAUNCH();
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = h->Sp, g.W = h->wpatch, g.n_tiles = d / 16;
+    g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = h->Sp, g.W = h->wpatch, g.n_tiles = d / 16, g.bias = h->bpatch;   // bias zero unless loaded
     g.out = h->x, g.ldo = d, g.n_valid = d;                      // row 0 (class token) is overwritten next
     RC(ddk_gemm(EPI_STORE, g, st));
     k_vit_embed<<<T, 256, 0, st>>>(h->x, h->cls, h->pos, d);
     DD_CHECK_LAUNCH();
-    k_layernorm<<<T, 256, 0, st>>>(h->x, d, h->prew, h->preb, h->cfg.ln_eps, h->x, nullptr, nullptr, 0);   // pre_layrnorm
-    DD_CHECK_LAUNCH();
+    if (!h->no_pre_ln) {
+      k_layernorm<<<T, 256, 0, st>>>(h->x, d, h->prew, h->preb, h->cfg.ln_eps, h->x, nullptr, nullptr, 0);   // pre_layrnorm (CLIP)
+      DD_CHECK_LAUNCH();
+    }
     for (auto& w : h->lw) {
       k_layernorm<<<T, 256, 0, st>>>(h->x, d, w.ln1w, w.ln1b, h->cfg.ln_eps, nullptr, h->a_hi, h->a_lo, 0);
       DD_CHECK_LAUNCH();
       memset(&g, 0, sizeof(g));
       g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = d / 32, g.W = w.wqkv, g.n_tiles = 3 * d / 16, g.bias = w.bqkv;
-      g.qbuf = h->q, g.kc = h->kt, g.vc = h->v, g.T_cap = h->Tc, g.vit_hidden = d, g.vit_head_dim = h->hd;
+      g.qbuf = h->q, g.kc = h->kt, g.vc = h->v, g.T_cap = h->Tc, g.vit_hidden = d, g.vit_head_dim = h->hd, g.vit_head_pad = h->hp;
       g.vit_qscale = 1.0f / sqrtf((float)h->hd);
       RC(ddk_gemm(EPI_QKV_VIT, g, st));
-      if (h->hd == 64 && ddk_prefill_mfma_enabled()) {
-        RC(ddk_attn_vit_mfma(h->q, h->kt, h->v, T, h->Tc, h->H, h->a_hi, h->a_lo, st));
+      if (h->hp != 64 || ddk_prefill_mfma_enabled()) {
+        RC(ddk_attn_vit_mfma(h->q, h->kt, h->v, T, h->Tc, h->H, h->a_hi, h->a_lo, st, h->hp));
       } else {
         k_attn_vit<<<dim3(h->H, (T + 3) / 4), 256, 0, st>>>(h->q, h->kt, h->v, T, h->Tc, d, h->a_hi, h->a_lo);
         DD_CHECK_LAUNCH();
       }
       memset(&g, 0, sizeof(g));
-      g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = d / 32, g.W = w.wo, g.n_tiles = d / 16, g.bias = w.bo;
+      g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = T, g.S = h->H * h->hp / 32, g.W = w.wo, g.n_tiles = d / 16, g.bias = w.bo;
       g.out = h->x, g.ldo = d;
       RC(ddk_gemm(EPI_RESID, g, st));
       k_layernorm<<<T, 256, 0, st>>>(h->x, d, w.ln2w, w.ln2b, h->cfg.ln_eps, nullptr, h->a_hi, h->a_lo, 0);
@@ -356,8 +393,15 @@ extern "C" int dd_vit_forward(dd_vit* h, const float* pixels, int n_images, floa
       g.out = h->x, g.ldo = d;
       RC(ddk_gemm(EPI_RESID, g, st));
     }
-    if (!h->proj) {   // raw features of the selected layer, class token dropped
-      DD_HIP(hipMemcpyAsync(o, h->x + d, (size_t)P * d * 4, hipMemcpyDeviceToDevice, st));
+    if (!h->proj) {   // raw features of the selected layer: class token dropped (CLIP feature layer) or kept, optionally post-normed
+      const int r0 = h->keep_cls ? 0 : 1, nr = h->keep_cls ? T : P;
+      float* oo = out + (size_t)im * nr * d;
+      if (h->post_ln) {
+        k_layernorm<<<nr, 256, 0, st>>>(h->x, d, h->postw, h->postb, h->cfg.ln_eps, oo, nullptr, nullptr, r0);
+        DD_CHECK_LAUNCH();
+      } else {
+        DD_HIP(hipMemcpyAsync(oo, h->x + (size_t)r0 * d, (size_t)nr * d * 4, hipMemcpyDeviceToDevice, st));
+      }
       continue;
     }
     // projector: linear_1 -> GELU(erf) -> linear_2 on rows 1..P  (LlavaMultiModalProjector)
@@ -372,5 +416,285 @@ extern "C" int dd_vit_forward(dd_vit* h, const float* pixels, int n_images, floa
     g.out = o, g.ldo = h->proj, g.n_valid = h->proj;
     RC(ddk_gemm(EPI_STORE, g, st));
   }
+  return DD_OK;
+}
+
+// =======================================================================================================================
+// InstructBLIP Q-Former + language projection (reference models/instructblip.py:613-633 calls HF's
+// InstructBlipQFormerModel and nn.Linear).  BERT-style post-LayerNorm encoder over S = Q + n rows (query tokens, then the
+// instruction tokens): self-attention over all rows; on layers l % freq == 0 the query rows cross-attend to the vision
+// tokens; the query rows and the instruction rows run separate GELU feed-forward blocks.  Every matrix product runs on
+// k_gemm (bf16 weights, fp32 activations as hi/lo planes), attention on the matrix-core kernel shared with the towers,
+// LayerNorm / residual stream in fp32.
+// =======================================================================================================================
+struct QfLayer {
+  u32x4_t *wqkv = nullptr, *wo = nullptr, *cwq = nullptr, *cwkv = nullptr, *cwo = nullptr, *wq1 = nullptr, *wq2 = nullptr, *wt1 = nullptr,
+          *wt2 = nullptr;
+  float *bqkv = nullptr, *bo = nullptr, *lnw = nullptr, *lnb = nullptr;
+  float *cbq = nullptr, *cbkv = nullptr, *cbo = nullptr, *clnw = nullptr, *clnb = nullptr;
+  float *bq1 = nullptr, *bq2 = nullptr, *qlnw = nullptr, *qlnb = nullptr, *bt1 = nullptr, *bt2 = nullptr, *tlnw = nullptr, *tlnb = nullptr;
+  bool cross = false;
+};
+
+struct dd_qformer {
+  dd_qformer_config cfg;
+  int d, H, dff, de, Q, Sc, Ec, proj;     // Sc / Ec: row capacities (multiples of 64) of the sequence and of the vision tokens
+  std::vector<void*> allocs;
+  std::vector<QfLayer> lw;
+  float *word = nullptr, *posemb = nullptr, *elnw = nullptr, *elnb = nullptr, *qtok = nullptr, *pb = nullptr;
+  u32x4_t* pw = nullptr;
+  // scratch
+  float *x = nullptr, *q = nullptr, *kt = nullptr, *v = nullptr, *ekt = nullptr, *ev = nullptr;
+  uint16_t *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr, *e_hi = nullptr, *e_lo = nullptr;
+};
+
+template <typename T>
+static int qalloc(dd_qformer* h, T** p, size_t n) {
+  void* q = nullptr;
+  size_t b = n * sizeof(T);
+  if (b == 0) b = 16;
+  if (hipMalloc(&q, b) != hipSuccess) {
+    dd_set_error("dd_qformer: hipMalloc(%zu) failed", b);
+    return DD_ENOMEM;
+  }
+  (void)hipMemset(q, 0, b);
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return DD_OK;
+}
+#define QA(ptr, n)                                   \
+  do {                                               \
+    int rc__ = qalloc(h, &(ptr), (size_t)(n));       \
+    if (rc__ != DD_OK) {                             \
+      dd_qformer_destroy(h);                         \
+      return rc__;                                   \
+    }                                                \
+  } while (0)
+
+extern "C" int dd_qformer_destroy(dd_qformer* h) {
+  if (!h) return DD_OK;
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return DD_OK;
+}
+
+extern "C" int dd_qformer_create(const dd_qformer_config* c, dd_qformer** out) {
+  DD_REQUIRE(c && out, "dd_qformer_create: null argument");
+  DD_REQUIRE(c->hidden_size % 64 == 0 && c->intermediate_size % 64 == 0 && c->encoder_hidden_size % 64 == 0 && c->proj_dim % 16 == 0,
+             "dd_qformer_create: hidden / intermediate / encoder widths must be multiples of 64 (projection: of 16)");
+  DD_REQUIRE(c->num_heads > 0 && c->hidden_size == c->num_heads * 64, "dd_qformer_create: head_dim must be 64, got %d / %d", c->hidden_size,
+             c->num_heads);
+  DD_REQUIRE(c->num_layers >= 1 && c->cross_attention_frequency >= 1 && c->num_query_tokens >= 1, "dd_qformer_create: layers / frequency / queries");
+  DD_REQUIRE(c->max_text_tokens >= 0 && c->max_text_tokens <= c->max_position_embeddings, "dd_qformer_create: max_text_tokens %d exceeds the position table (%d)",
+             c->max_text_tokens, c->max_position_embeddings);
+  DD_REQUIRE(c->max_encoder_tokens >= 1, "dd_qformer_create: max_encoder_tokens");
+  dd_qformer* h = new dd_qformer();
+  h->cfg = *c;
+  const int d = h->d = c->hidden_size, dff = h->dff = c->intermediate_size, de = h->de = c->encoder_hidden_size;
+  h->H = c->num_heads, h->Q = c->num_query_tokens, h->proj = c->proj_dim;
+  h->Sc = (c->num_query_tokens + c->max_text_tokens + 63) / 64 * 64;
+  h->Ec = (c->max_encoder_tokens + 63) / 64 * 64;
+  h->lw.resize(c->num_layers);
+  for (int l = 0; l < c->num_layers; ++l) {
+    QfLayer& w = h->lw[l];
+    w.cross = l % c->cross_attention_frequency == 0;
+    QA(w.wqkv, (size_t)(3 * d / 16) * (d / 32) * 64); QA(w.wo, (size_t)(d / 16) * (d / 32) * 64);
+    QA(w.bqkv, 3 * d); QA(w.bo, d); QA(w.lnw, d); QA(w.lnb, d);
+    if (w.cross) {
+      QA(w.cwq, (size_t)(d / 16) * (d / 32) * 64); QA(w.cwkv, (size_t)(2 * d / 16) * (de / 32) * 64); QA(w.cwo, (size_t)(d / 16) * (d / 32) * 64);
+      QA(w.cbq, d); QA(w.cbkv, 2 * d); QA(w.cbo, d); QA(w.clnw, d); QA(w.clnb, d);
+    }
+    QA(w.wq1, (size_t)(dff / 16) * (d / 32) * 64); QA(w.wq2, (size_t)(d / 16) * (dff / 32) * 64);
+    QA(w.wt1, (size_t)(dff / 16) * (d / 32) * 64); QA(w.wt2, (size_t)(d / 16) * (dff / 32) * 64);
+    QA(w.bq1, dff); QA(w.bq2, d); QA(w.qlnw, d); QA(w.qlnb, d); QA(w.bt1, dff); QA(w.bt2, d); QA(w.tlnw, d); QA(w.tlnb, d);
+  }
+  QA(h->word, (size_t)c->vocab_size * d); QA(h->posemb, (size_t)c->max_position_embeddings * d);
+  QA(h->elnw, d); QA(h->elnb, d); QA(h->qtok, (size_t)h->Q * d);
+  QA(h->pw, (size_t)(h->proj / 16) * (d / 32) * 64); QA(h->pb, h->proj);
+  QA(h->x, (size_t)h->Sc * d); QA(h->q, (size_t)h->Sc * d); QA(h->kt, (size_t)h->Sc * d); QA(h->v, (size_t)h->Sc * d);
+  QA(h->ekt, (size_t)h->Ec * d); QA(h->ev, (size_t)h->Ec * d);
+  QA(h->a_hi, (size_t)h->Sc * d); QA(h->a_lo, (size_t)h->Sc * d);
+  QA(h->b_hi, (size_t)h->Sc * dff); QA(h->b_lo, (size_t)h->Sc * dff);
+  QA(h->e_hi, (size_t)h->Ec * de); QA(h->e_lo, (size_t)h->Ec * de);
+  *out = h;
+  return DD_OK;
+}
+
+extern "C" int dd_qformer_load_tensor(dd_qformer* h, int id, int layer, const uint16_t* src, int rows, int cols, int on_device) {
+  DD_REQUIRE(h && src, "dd_qformer_load_tensor: null argument");
+  const bool per_layer = id >= DD_QF_SA_WQ;
+  DD_REQUIRE((id >= DD_QF_WORD_EMB && id <= DD_QF_PROJ_B) || (id >= DD_QF_SA_WQ && id <= DD_QF_FFT_LN_B), "dd_qformer_load_tensor: unknown tensor id %d", id);
+  DD_REQUIRE(!per_layer || (layer >= 0 && layer < (int)h->lw.size()), "dd_qformer_load_tensor: layer %d out of range", layer);
+  const int d = h->d, dff = h->dff, de = h->de;
+  QfLayer* w = per_layer ? &h->lw[layer] : nullptr;
+  DD_REQUIRE(!(per_layer && id >= DD_QF_CA_WQ && id <= DD_QF_CA_LN_B) || w->cross, "dd_qformer_load_tensor: layer %d has no cross-attention", layer);
+  size_t n = (size_t)rows * cols;
+  const uint16_t* dev = src;
+  uint16_t* staging = nullptr;
+  if (!on_device) {
+    DD_HIP(hipMalloc((void**)&staging, n * 2));
+    if (hipMemcpy(staging, src, n * 2, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(staging);
+      dd_set_error("dd_qformer_load_tensor: H2D copy failed");
+      return DD_EHIP;
+    }
+    dev = staging;
+  }
+  int rc = DD_OK;
+  auto vec = [&](float* dst, size_t len) -> int {
+    if (len != n) {
+      dd_set_error("dd_qformer_load_tensor: tensor %d expects %zu values, got %zu", id, len, n);
+      return DD_EINVAL;
+    }
+    return ddk_bf16_to_f32(dev, dst, (int)len, nullptr);
+  };
+  auto mat = [&](u32x4_t* dst, int er, int ec, int tile0) -> int {
+    if (rows != er || cols != ec) {
+      dd_set_error("dd_qformer_load_tensor: tensor %d expects %d x %d, got %d x %d", id, er, ec, rows, cols);
+      return DD_EINVAL;
+    }
+    return ddk_pack_weight(dev, rows, cols, dst, tile0, 1, PACK_PLAIN, er / 16, nullptr);
+  };
+  switch (id) {
+    case DD_QF_WORD_EMB: rc = vec(h->word, (size_t)h->cfg.vocab_size * d); break;
+    case DD_QF_POS_EMB: rc = vec(h->posemb, (size_t)h->cfg.max_position_embeddings * d); break;
+    case DD_QF_EMB_LN_W: rc = vec(h->elnw, d); break;
+    case DD_QF_EMB_LN_B: rc = vec(h->elnb, d); break;
+    case DD_QF_QUERY_TOKENS: rc = vec(h->qtok, (size_t)h->Q * d); break;
+    case DD_QF_PROJ_W: rc = mat(h->pw, h->proj, d, 0); break;
+    case DD_QF_PROJ_B: rc = vec(h->pb, h->proj); break;
+    case DD_QF_SA_WQ: rc = mat(w->wqkv, d, d, 0); break;
+    case DD_QF_SA_WK: rc = mat(w->wqkv, d, d, d / 16); break;
+    case DD_QF_SA_WV: rc = mat(w->wqkv, d, d, 2 * d / 16); break;
+    case DD_QF_SA_BQ: rc = vec(w->bqkv, d); break;
+    case DD_QF_SA_BK: rc = vec(w->bqkv + d, d); break;
+    case DD_QF_SA_BV: rc = vec(w->bqkv + 2 * d, d); break;
+    case DD_QF_SA_WO: rc = mat(w->wo, d, d, 0); break;
+    case DD_QF_SA_BO: rc = vec(w->bo, d); break;
+    case DD_QF_SA_LN_W: rc = vec(w->lnw, d); break;
+    case DD_QF_SA_LN_B: rc = vec(w->lnb, d); break;
+    case DD_QF_CA_WQ: rc = mat(w->cwq, d, d, 0); break;
+    case DD_QF_CA_BQ: rc = vec(w->cbq, d); break;
+    case DD_QF_CA_WK: rc = mat(w->cwkv, d, de, 0); break;
+    case DD_QF_CA_BK: rc = vec(w->cbkv, d); break;
+    case DD_QF_CA_WV: rc = mat(w->cwkv, d, de, d / 16); break;
+    case DD_QF_CA_BV: rc = vec(w->cbkv + d, d); break;
+    case DD_QF_CA_WO: rc = mat(w->cwo, d, d, 0); break;
+    case DD_QF_CA_BO: rc = vec(w->cbo, d); break;
+    case DD_QF_CA_LN_W: rc = vec(w->clnw, d); break;
+    case DD_QF_CA_LN_B: rc = vec(w->clnb, d); break;
+    case DD_QF_FFQ_W1: rc = mat(w->wq1, dff, d, 0); break;
+    case DD_QF_FFQ_B1: rc = vec(w->bq1, dff); break;
+    case DD_QF_FFQ_W2: rc = mat(w->wq2, d, dff, 0); break;
+    case DD_QF_FFQ_B2: rc = vec(w->bq2, d); break;
+    case DD_QF_FFQ_LN_W: rc = vec(w->qlnw, d); break;
+    case DD_QF_FFQ_LN_B: rc = vec(w->qlnb, d); break;
+    case DD_QF_FFT_W1: rc = mat(w->wt1, dff, d, 0); break;
+    case DD_QF_FFT_B1: rc = vec(w->bt1, dff); break;
+    case DD_QF_FFT_W2: rc = mat(w->wt2, d, dff, 0); break;
+    case DD_QF_FFT_B2: rc = vec(w->bt2, d); break;
+    case DD_QF_FFT_LN_W: rc = vec(w->tlnw, d); break;
+    case DD_QF_FFT_LN_B: rc = vec(w->tlnb, d); break;
+    default: rc = DD_EINVAL; dd_set_error("dd_qformer_load_tensor: unknown tensor id %d", id);
+  }
+  hipError_t e = hipDeviceSynchronize();
+  if (staging) (void)hipFree(staging);
+  if (rc != DD_OK) return rc;
+  DD_HIP(e);
+  return DD_OK;
+}
+
+// rows 0..Q-1 = query tokens; row Q + i = word_embeddings[ids[i]] + position_embeddings[i]   (InstructBlipQFormerEmbeddings,
+// before its LayerNorm).  An id outside the table raises the flag (checked by the caller through the returned rows: NaN).
+__global__ __launch_bounds__(256) void k_qf_embed(float* __restrict__ x, const float* __restrict__ qtok, const float* __restrict__ word,
+                                                  const float* __restrict__ pos, const int32_t* __restrict__ ids, int Q, int d, int vocab) {
+  const int row = blockIdx.x;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float v;
+    if (row < Q) {
+      v = qtok[(size_t)row * d + i];
+    } else {
+      int id = ids[row - Q];
+      v = (id >= 0 && id < vocab) ? word[(size_t)id * d + i] + pos[(size_t)(row - Q) * d + i] : __builtin_nanf("");
+    }
+    x[(size_t)row * d + i] = v;
+  }
+}
+
+extern "C" int dd_qformer_forward(dd_qformer* h, const int32_t* text_ids, int n_text, const float* enc, int n_enc, float* out,
+                                  float* hidden_out, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(h && enc && out, "dd_qformer_forward: null argument");
+  DD_REQUIRE(n_text >= 0 && n_text <= h->cfg.max_text_tokens, "dd_qformer_forward: %d instruction tokens, capacity %d", n_text, h->cfg.max_text_tokens);
+  DD_REQUIRE(n_text == 0 || text_ids, "dd_qformer_forward: text ids missing");
+  DD_REQUIRE(n_enc >= 1 && n_enc <= h->cfg.max_encoder_tokens, "dd_qformer_forward: %d vision tokens, capacity %d", n_enc, h->cfg.max_encoder_tokens);
+  const int d = h->d, dff = h->dff, de = h->de, Q = h->Q, S = Q + n_text;
+  const float eps = h->cfg.ln_eps;
+  GemmArgs g;
+  // embeddings + LayerNorm
+  k_qf_embed<<<S, 256, 0, st>>>(h->x, h->qtok, h->word, h->posemb, text_ids, Q, d, h->cfg.vocab_size);
+  DD_CHECK_LAUNCH();
+  k_layernorm<<<S, 256, 0, st>>>(h->x, d, h->elnw, h->elnb, eps, h->x, nullptr, nullptr, 0);
+  DD_CHECK_LAUNCH();
+  // vision tokens as operand planes, once for all cross-attention layers
+  k_layernorm<<<n_enc, 256, 0, st>>>(enc, de, nullptr, nullptr, 0.f, nullptr, h->e_hi, h->e_lo, 0);
+  DD_CHECK_LAUNCH();
+  // x[r0 .. r0+M) += planes(b) . W2^T + b2, then LayerNorm in place (BERT output block)
+  auto out_block = [&](uint16_t* p_hi, uint16_t* p_lo, int K, u32x4_t* W, float* bias, float* lnw, float* lnb, int r0, int M) -> int {
+    GemmArgs o;
+    memset(&o, 0, sizeof(o));
+    o.a_hi = p_hi, o.a_lo = p_lo, o.M = M, o.S = K / 32, o.W = W, o.n_tiles = d / 16, o.bias = bias;
+    o.out = h->x + (size_t)r0 * d, o.ldo = d;
+    RC(ddk_gemm(EPI_RESID, o, st));
+    k_layernorm<<<M, 256, 0, st>>>(h->x + (size_t)r0 * d, d, lnw, lnb, eps, h->x + (size_t)r0 * d, nullptr, nullptr, 0);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  };
+  auto ffn = [&](u32x4_t* W1, float* b1, u32x4_t* W2, float* b2, float* lnw, float* lnb, int r0, int M) -> int {
+    k_layernorm<<<M, 256, 0, st>>>(h->x, d, nullptr, nullptr, 0.f, nullptr, h->a_hi, h->a_lo, r0);   // plain split of rows r0..
+    DD_CHECK_LAUNCH();
+    GemmArgs f;
+    memset(&f, 0, sizeof(f));
+    f.a_hi = h->a_hi, f.a_lo = h->a_lo, f.M = M, f.S = d / 32, f.W = W1, f.n_tiles = dff / 16, f.bias = b1;
+    f.act = 1, f.o_hi = h->b_hi, f.o_lo = h->b_lo, f.ld_planes = dff;                                  // GELU (erf)
+    RC(ddk_gemm(EPI_ACT, f, st));
+    return out_block(h->b_hi, h->b_lo, dff, W2, b2, lnw, lnb, r0, M);
+  };
+  for (auto& w : h->lw) {
+    // self-attention over all S rows
+    k_layernorm<<<S, 256, 0, st>>>(h->x, d, nullptr, nullptr, 0.f, nullptr, h->a_hi, h->a_lo, 0);
+    DD_CHECK_LAUNCH();
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = S, g.S = d / 32, g.W = w.wqkv, g.n_tiles = 3 * d / 16, g.bias = w.bqkv;
+    g.qbuf = h->q, g.kc = h->kt, g.vc = h->v, g.T_cap = h->Sc, g.vit_hidden = d, g.vit_head_dim = 64, g.vit_qscale = 0.125f;
+    RC(ddk_gemm(EPI_QKV_VIT, g, st));
+    RC(ddk_attn_vit_mfma(h->q, h->kt, h->v, S, h->Sc, h->H, h->a_hi, h->a_lo, st, 64));
+    RC(out_block(h->a_hi, h->a_lo, d, w.wo, w.bo, w.lnw, w.lnb, 0, S));
+    if (w.cross) {   // query rows against the vision tokens
+      k_layernorm<<<Q, 256, 0, st>>>(h->x, d, nullptr, nullptr, 0.f, nullptr, h->a_hi, h->a_lo, 0);
+      DD_CHECK_LAUNCH();
+      memset(&g, 0, sizeof(g));
+      g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = Q, g.S = d / 32, g.W = w.cwq, g.n_tiles = d / 16, g.bias = w.cbq;
+      g.qbuf = h->q, g.kc = h->ekt, g.vc = h->ev, g.T_cap = h->Ec, g.vit_hidden = d, g.vit_head_dim = 64, g.vit_qscale = 0.125f;
+      RC(ddk_gemm(EPI_QKV_VIT, g, st));
+      memset(&g, 0, sizeof(g));
+      g.a_hi = h->e_hi, g.a_lo = h->e_lo, g.M = n_enc, g.S = de / 32, g.W = w.cwkv, g.n_tiles = 2 * d / 16, g.bias = w.cbkv;
+      g.qbuf = h->q, g.kc = h->ekt, g.vc = h->ev, g.T_cap = h->Ec, g.vit_hidden = d, g.vit_head_dim = 64, g.vit_qscale = 1.0f;
+      g.vit_col0 = d;                                                           // [k | v] columns of a fused [q | k | v]
+      RC(ddk_gemm(EPI_QKV_VIT, g, st));
+      RC(ddk_attn_vit_mfma(h->q, h->ekt, h->ev, Q, h->Ec, h->H, h->a_hi, h->a_lo, st, 64, n_enc));
+      RC(out_block(h->a_hi, h->a_lo, d, w.cwo, w.cbo, w.clnw, w.clnb, 0, Q));
+    }
+    RC(ffn(w.wq1, w.bq1, w.wq2, w.bq2, w.qlnw, w.qlnb, 0, Q));
+    if (n_text > 0) RC(ffn(w.wt1, w.bt1, w.wt2, w.bt2, w.tlnw, w.tlnb, Q, n_text));
+  }
+  if (hidden_out) DD_HIP(hipMemcpyAsync(hidden_out, h->x, (size_t)S * d * 4, hipMemcpyDeviceToDevice, st));
+  // language_projection on the query rows
+  k_layernorm<<<Q, 256, 0, st>>>(h->x, d, nullptr, nullptr, 0.f, nullptr, h->a_hi, h->a_lo, 0);
+  DD_CHECK_LAUNCH();
+  memset(&g, 0, sizeof(g));
+  g.a_hi = h->a_hi, g.a_lo = h->a_lo, g.M = Q, g.S = d / 32, g.W = h->pw, g.n_tiles = h->proj / 16, g.bias = h->pb;
+  g.out = out, g.ldo = h->proj, g.n_valid = h->proj;
+  RC(ddk_gemm(EPI_STORE, g, st));
   return DD_OK;
 }

@@ -26,6 +26,8 @@ class CustomInstructBlipForConditionalGeneration(DropoutVLM):
     def __init__(self, engine, embed_tokens, hf_front, eos_token_id=None, config=None):
         super().__init__(engine, embed_tokens, image_token_index=-1, eos_token_id=eos_token_id, config=config)
         self._hf = hf_front             # vision_model + qformer + language_projection (+ query_tokens)
+        self.tower_hip = None           # EVA ViT-g/14 on own kernels (vision.ClipTowerHIP.from_hf_instructblip)
+        self.qformer_hip = None         # Q-Former + language_projection on own kernels (vision.QFormerHIP.from_hf)
 
     # reference models/instructblip.py:607-633
     def _visual_embeds(self, pixel_values=None, qformer_input_ids=None, qformer_attention_mask=None,
@@ -33,9 +35,20 @@ class CustomInstructBlipForConditionalGeneration(DropoutVLM):
         if pixel_values is None:
             raise ValueError("pixel_values is required")
         hf, dev = self._hf, self.device
-        dt = next(hf.vision_model.parameters()).dtype
-        image_embeds = hf.vision_model(pixel_values.to(dev, dt), return_dict=True,
-                                       interpolate_pos_encoding=interpolate_pos_encoding).last_hidden_state
+        if self.tower_hip is not None and not interpolate_pos_encoding:
+            qdt = next(hf.qformer.parameters()).dtype
+            image_embeds = self.tower_hip(pixel_values.to(dev).float()).to(qdt)          # [1, 257, 1408]: fp32-grade, own kernels
+        else:
+            dt = next(hf.vision_model.parameters()).dtype
+            image_embeds = hf.vision_model(pixel_values.to(dev, dt), return_dict=True,
+                                           interpolate_pos_encoding=interpolate_pos_encoding).last_hidden_state
+        if (self.qformer_hip is not None and image_embeds.shape[0] == 1 and image_embeds.shape[1] <= self.qformer_hip.max_encoder_tokens
+                and qformer_input_ids.shape[0] == 1):
+            ids = qformer_input_ids[0].to(dev)
+            if qformer_attention_mask is not None:
+                ids = ids[qformer_attention_mask[0].to(dev).bool()]      # masked keys contribute nothing: drop the padding
+            if ids.numel() <= self.qformer_hip.max_text_tokens:
+                return self.qformer_hip(ids, image_embeds[0].float())    # [Q, d_lm] fp32
         image_attention_mask = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=dev)
         query_tokens = hf.query_tokens.expand(image_embeds.shape[0], -1, -1)
         query_attention_mask = torch.ones(query_tokens.size()[:-1], dtype=torch.long, device=dev)
@@ -74,7 +87,7 @@ class CustomInstructBlipForConditionalGeneration(DropoutVLM):
                            seed=_config.effective_seed)
         eng.load_state_dict(sd)
         dev = eng.device
-        embed = sd["model.embed_tokens.weight"].to(dev, torch.bfloat16)
+        embed = sd["model.embed_tokens.weight"].to(dev, torch.float16 if eng.weight_format == "fp16" else torch.bfloat16)   # the engine's 16-bit type
         inner = getattr(hf, "model", hf)
         if not hasattr(inner, "qformer"):
             inner = hf
@@ -86,6 +99,16 @@ class CustomInstructBlipForConditionalGeneration(DropoutVLM):
             eos = getattr(cfg.text_config, "eos_token_id", None)
         m = cls(eng, embed, inner, eos, cfg)
         m.original = original
+        vc = cfg.vision_config
+        if vc.hidden_size % 64 == 0 and vc.intermediate_size % 64 == 0 and vc.hidden_size // vc.num_attention_heads in (64, 88):
+            from .vision import ClipTowerHIP
+            m.tower_hip = ClipTowerHIP.from_hf_instructblip(inner.vision_model)
+        qc = cfg.qformer_config
+        if (qc.hidden_size == 64 * qc.num_attention_heads and qc.intermediate_size % 64 == 0 and qc.encoder_hidden_size % 64 == 0
+                and lm_cfg.hidden_size % 16 == 0 and getattr(qc, "hidden_act", "gelu") == "gelu"):
+            from .vision import QFormerHIP
+            n_enc = (vc.image_size // vc.patch_size) ** 2 + 1
+            m.qformer_hip = QFormerHIP.from_hf(inner.qformer, inner.query_tokens, inner.language_projection, max_encoder_tokens=n_enc)
         return m
 
     @classmethod

@@ -78,7 +78,7 @@ class CustomLlavaForConditionalGeneration(DropoutVLM):
         eng = build_engine(lm_cfg, cls.family, checkpoint_dtype=sd["lm_head.weight"].dtype, max_visual=L, max_new_tokens=max_new_tokens, seed=_config.effective_seed)
         eng.load_state_dict(sd)
         dev = eng.device
-        embed = sd["model.embed_tokens.weight"].to(dev, torch.bfloat16)
+        embed = sd["model.embed_tokens.weight"].to(dev, torch.float16 if eng.weight_format == "fp16" else torch.bfloat16)   # the engine's 16-bit type
         gen = getattr(hf, "generation_config", None)
         eos = getattr(gen, "eos_token_id", None) if gen is not None else None
         if eos is None:

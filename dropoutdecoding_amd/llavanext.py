@@ -74,7 +74,7 @@ class CustomLlavaNextForConditionalGeneration(DropoutVLM):
                            use_random=bool(settings["use_random"][0]), seed=_config.effective_seed)
         eng.load_state_dict(sd)
         dev = eng.device
-        embed = sd["model.embed_tokens.weight"].to(dev, torch.bfloat16)
+        embed = sd["model.embed_tokens.weight"].to(dev, torch.float16 if eng.weight_format == "fp16" else torch.bfloat16)   # the engine's 16-bit type
         inner = getattr(hf, "model", hf)
         inner.language_model = None                      # the LM now lives in the engine
         inner = inner.to(dev).eval()

@@ -340,15 +340,19 @@ int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, 
  * ------------------------------------------------------------------------------------------ */
 typedef struct dd_vit_config {
   int32_t image_size, patch_size;     /* 336, 14 */
-  int32_t hidden_size;                /* 1024 (multiple of 64; head_dim must be 64) */
+  int32_t hidden_size;                /* 1024 (CLIP ViT-L) or 1408 (EVA ViT-g): multiple of 64; head_dim 64 or 88 */
   int32_t intermediate_size;          /* 4096 */
   int32_t num_layers;                 /* encoder layers to run */
   int32_t num_heads;                  /* 16 */
   int32_t proj_dim;                   /* 0 = return raw features [P][hidden]; else LLaVA projector output width */
   int32_t act;                        /* MLP activation: 0 quick_gelu (CLIP), 1 gelu(erf) */
-  float ln_eps;                       /* 1e-5 */
-  int32_t reserved[7];
+  float ln_eps;                       /* 1e-5 (CLIP), 1e-6 (EVA) */
+  int32_t flags;                      /* DD_VIT_*: 0 = CLIP (pre-LayerNorm, class token dropped, no post-LayerNorm) */
+  int32_t reserved[6];
 } dd_vit_config;
+#define DD_VIT_NO_PRE_LN 1    /* the tower has no pre-LayerNorm (EVA ViT-g of InstructBLIP) */
+#define DD_VIT_POST_LN 2      /* apply post_layernorm to the returned tokens (InstructBlipVisionModel.last_hidden_state) */
+#define DD_VIT_KEEP_CLASS 4   /* return all P + 1 tokens, class token first (the Q-Former cross-attends to all 257) */
 typedef struct dd_vit dd_vit;
 
 /* tensor ids for dd_vit_load_tensor (HF CLIPVisionModel / LlavaMultiModalProjector names) */
@@ -377,12 +381,90 @@ typedef struct dd_vit dd_vit;
 #define DD_VT_PROJ1_B 22
 #define DD_VT_PROJ2_W 23   /* multi_modal_projector.linear_2.weight [proj][proj]   */
 #define DD_VT_PROJ2_B 24
+#define DD_VT_PATCH_B 25   /* embeddings.patch_embedding.bias [hidden] (EVA; CLIP's patch conv has none) */
+#define DD_VT_POST_LN_W 26 /* post_layernorm.weight */
+#define DD_VT_POST_LN_B 27
 
 int dd_vit_create(const dd_vit_config* cfg, dd_vit** out);
 int dd_vit_destroy(dd_vit* h);
 int dd_vit_load_tensor(dd_vit* h, int tensor_id, int layer, const uint16_t* src_bf16, int rows, int cols, int src_on_device);
-/* pixels_dev [n_images][3][H][W] fp32 (already normalised) -> out_dev [n_images][P][proj_dim or hidden] fp32 */
+/* pixels_dev [n_images][3][H][W] fp32 (already normalised) -> out_dev [n_images][P][proj_dim or hidden] fp32
+ * ([n_images][P + 1][hidden] with DD_VIT_KEEP_CLASS) */
 int dd_vit_forward(dd_vit* h, const float* pixels_dev, int n_images, float* out_dev, void* stream);
+
+/* ---- InstructBLIP Q-Former + language projection on own kernels ---------------------------------------------------------
+ * Replaces the third-party modules reference models/instructblip.py:613-633 calls (`self.qformer(input_ids=qformer_input_ids,
+ * attention_mask=..., query_embeds=query_tokens, encoder_hidden_states=image_embeds, ...)` then
+ * `self.language_projection(query_output[:, :Q])`): a BERT-style post-LayerNorm encoder over [query tokens ; instruction
+ * tokens] whose query rows cross-attend to the vision tower's output every `cross_attention_frequency` layers and whose
+ * query / instruction rows run separate feed-forward blocks.  One sequence per call (the reference's batch is 1); padded
+ * instruction tokens are dropped by the caller (masked keys contribute nothing, so the query rows are unchanged). */
+typedef struct dd_qformer_config {
+  int hidden_size;           /* 768 */
+  int num_heads;             /* 12 (head_dim must be 64) */
+  int num_layers;            /* 12 */
+  int intermediate_size;     /* 3072 */
+  int encoder_hidden_size;   /* 1408 (EVA ViT-g) */
+  int cross_attention_frequency; /* 2: layers 0, 2, 4, ... cross-attend */
+  int num_query_tokens;      /* 32 */
+  int vocab_size;            /* 30523 */
+  int max_position_embeddings; /* 512 */
+  int proj_dim;              /* language_projection width: 4096 */
+  int max_text_tokens;       /* capacity for instruction tokens per call */
+  int max_encoder_tokens;    /* capacity for vision tokens per call (257) */
+  float ln_eps;              /* 1e-12 */
+} dd_qformer_config;
+typedef struct dd_qformer dd_qformer;
+/* tensor ids for dd_qformer_load_tensor (HF InstructBlipQFormerModel parameter names) */
+#define DD_QF_WORD_EMB 0   /* embeddings.word_embeddings.weight [vocab][d] */
+#define DD_QF_POS_EMB 1    /* embeddings.position_embeddings.weight [max_pos][d] */
+#define DD_QF_EMB_LN_W 2   /* embeddings.layernorm */
+#define DD_QF_EMB_LN_B 3
+#define DD_QF_QUERY_TOKENS 4 /* query_tokens [Q][d] */
+#define DD_QF_PROJ_W 5     /* language_projection.weight [proj][d] */
+#define DD_QF_PROJ_B 6
+/* per layer (encoder.layer.N.) */
+#define DD_QF_SA_WQ 10     /* attention.attention.query / key / value */
+#define DD_QF_SA_WK 11
+#define DD_QF_SA_WV 12
+#define DD_QF_SA_BQ 13
+#define DD_QF_SA_BK 14
+#define DD_QF_SA_BV 15
+#define DD_QF_SA_WO 16     /* attention.output.dense */
+#define DD_QF_SA_BO 17
+#define DD_QF_SA_LN_W 18   /* attention.output.LayerNorm */
+#define DD_QF_SA_LN_B 19
+#define DD_QF_CA_WQ 20     /* crossattention.attention.query [d][d]; key / value [d][encoder_hidden] (cross layers only) */
+#define DD_QF_CA_BQ 21
+#define DD_QF_CA_WK 22
+#define DD_QF_CA_BK 23
+#define DD_QF_CA_WV 24
+#define DD_QF_CA_BV 25
+#define DD_QF_CA_WO 26     /* crossattention.output.dense */
+#define DD_QF_CA_BO 27
+#define DD_QF_CA_LN_W 28
+#define DD_QF_CA_LN_B 29
+#define DD_QF_FFQ_W1 30    /* intermediate_query.dense / output_query.dense + LayerNorm (query rows) */
+#define DD_QF_FFQ_B1 31
+#define DD_QF_FFQ_W2 32
+#define DD_QF_FFQ_B2 33
+#define DD_QF_FFQ_LN_W 34
+#define DD_QF_FFQ_LN_B 35
+#define DD_QF_FFT_W1 36    /* intermediate.dense / output.dense + LayerNorm (instruction rows) */
+#define DD_QF_FFT_B1 37
+#define DD_QF_FFT_W2 38
+#define DD_QF_FFT_B2 39
+#define DD_QF_FFT_LN_W 40
+#define DD_QF_FFT_LN_B 41
+
+int dd_qformer_create(const dd_qformer_config* cfg, dd_qformer** out);
+int dd_qformer_destroy(dd_qformer* h);
+int dd_qformer_load_tensor(dd_qformer* h, int tensor_id, int layer, const uint16_t* src_bf16, int rows, int cols, int src_on_device);
+/* text_ids_dev [n_text] int32 instruction token ids (n_text may be 0); enc_dev [n_enc][encoder_hidden] fp32 vision tokens ->
+ * out_dev [num_query_tokens][proj_dim] fp32: the Q visual embeddings the LM sees at positions 0..Q-1.
+ * hidden_out_dev (optional) receives the Q-Former's last hidden state rows [num_query_tokens + n_text][hidden]. */
+int dd_qformer_forward(dd_qformer* h, const int32_t* text_ids_dev, int n_text, const float* enc_dev, int n_enc, float* out_dev,
+                       float* hidden_out_dev, void* stream);
 
 /* Calibration for bench.py: streaming READ bandwidth (GB/s) this device delivers over buf_dev[bytes] (bytes >= 1 MiB;
  * use a buffer much larger than the 256 MiB Infinity Cache), HIP events on `stream`. */

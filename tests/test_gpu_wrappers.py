@@ -281,6 +281,51 @@ def test_instructblip_wrapper_with_hf_tiny_model(built):
     assert m.start_image_pos == [0] and m.end_image_pos == [31] and m.start_generation_pos == 38
 
 
+def test_instructblip_front_end_on_own_kernels(built):
+    """A vision config with heads of 88 (EVA ViT-g's shape) and a Q-Former with heads of 64: the wrapper must route the whole
+    visual front-end (tower -> Q-Former -> language_projection, reference models/instructblip.py:607-633) through the library's
+    kernels, and the result must match the HF modules it replaces."""
+    from transformers import (InstructBlipConfig, InstructBlipForConditionalGeneration, InstructBlipQFormerConfig,
+                              InstructBlipVisionConfig, LlamaConfig)
+    from dropoutdecoding_amd import config as ddc
+    from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration
+    torch.manual_seed(4)
+    vc = InstructBlipVisionConfig(hidden_size=704, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+                                  image_size=56, patch_size=14)
+    qc = InstructBlipQFormerConfig(vocab_size=100, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                   intermediate_size=256, encoder_hidden_size=704, cross_attention_frequency=2)
+    tc = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                     num_key_value_heads=2, head_dim=128, max_position_embeddings=512, tie_word_embeddings=False)
+    cfg = InstructBlipConfig(vision_config=vc.to_dict(), qformer_config=qc.to_dict(), text_config=tc.to_dict(),
+                             num_query_tokens=32)
+    hf = InstructBlipForConditionalGeneration(cfg).eval()
+    _in = getattr(hf, "model", hf)
+    (_in if hasattr(_in, "query_tokens") else hf).query_tokens.normal_(0, 1.0, generator=torch.Generator().manual_seed(9))
+    for n, p in hf.named_parameters():
+        if "language_model" not in n:
+            p.copy_((p * (2.0 if p.dim() > 1 else 1.0)).to(torch.bfloat16).float())       # bf16-valued on both sides
+    ddc.settings["voting_numbers"] = [0.3, 0.5, 0.7]
+    ddc._module_imported(5217)
+    m = CustomInstructBlipForConditionalGeneration.from_hf_model(hf, max_new_tokens=8)
+    assert m.tower_hip is not None and m.qformer_hip is not None
+    pv = torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(3))
+    qids = torch.tensor([[3, 9, 27, 4, 0, 0]])
+    qmask = torch.tensor([[1, 1, 1, 1, 0, 0]])
+    own = m._visual_embeds(pixel_values=pv, qformer_input_ids=qids, qformer_attention_mask=qmask).float()
+    tower, qf = m.tower_hip, m.qformer_hip
+    m.tower_hip = m.qformer_hip = None
+    want = m._visual_embeds(pixel_values=pv, qformer_input_ids=qids, qformer_attention_mask=qmask).float()
+    m.tower_hip, m.qformer_hip = tower, qf
+    assert own.shape == want.shape == (32, 256)
+    err = float((own - want).abs().max() / want.abs().max())
+    print(f"\n[InstructBLIP front-end] own kernels vs HF modules: {err:.2e}")
+    assert err < 2e-3
+    ids = torch.tensor([[1, 17, 45, 6, 7, 99]])
+    out = m.generate(pixel_values=pv, qformer_input_ids=qids, qformer_attention_mask=qmask, input_ids=ids,
+                     attention_mask=torch.ones_like(ids), max_new_tokens=5, eos_token_id=[])
+    assert out.shape == (1, 6) and int(out[0, 0]) == 2
+
+
 def test_generate_group_three_images_at_once(built):
     """spawn_lane() + generate_group(): three images decoded together over one set of weights; each equals its own solo
     generate() and the oracle started from a fresh rng stream (one reference process per lane)."""
