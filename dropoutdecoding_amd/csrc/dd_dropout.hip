@@ -316,9 +316,9 @@ __global__ __launch_bounds__(1024) void k_argmax_rows(const float* __restrict__ 
 
 // rows of up to 4 sequences (their K member logits) in one launch: grid (R, n)
 struct ArgmaxLanes {
-  const float* x[4];
-  int32_t* out[4];
-  const int32_t* gate[4];
+  const float* x[8];
+  int32_t* out[8];
+  const int32_t* gate[8];
 };
 __global__ __launch_bounds__(1024) void k_argmax_rows_lanes(ArgmaxLanes t, int V, int ld) {
   __shared__ ArgMax sh[16];
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(1024) void k_argmax_rows_lanes(ArgmaxLanes t, int V
 }
 int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, const int32_t* const* gates, int n, int R, int V, int ld,
                          hipStream_t st) {
-  DD_REQUIRE(x && out && n >= 1 && n <= 4 && R >= 1, "dd_argmax_rows_lanes: bad arguments");
+  DD_REQUIRE(x && out && n >= 1 && n <= 8 && R >= 1, "dd_argmax_rows_lanes: bad arguments");
   ArgmaxLanes t;
   memset(&t, 0, sizeof(t));
   for (int i = 0; i < n; ++i) t.x[i] = x[i], t.out[i] = out[i], t.gate[i] = gates ? gates[i] : nullptr;
@@ -936,9 +936,9 @@ __global__ void k_vote(const int32_t* __restrict__ ids, int K, int32_t* __restri
 
 // the votes of up to 4 sequences in one launch (block = sequence)
 struct VoteLanes {
-  const int32_t* ids[4];
-  int32_t* out2[4];
-  const int32_t* gate[4];
+  const int32_t* ids[8];
+  int32_t* out2[8];
+  const int32_t* gate[8];
 };
 __global__ void k_vote_lanes(VoteLanes t, int K) {
   if (threadIdx.x != 0) return;
@@ -960,7 +960,7 @@ __global__ void k_vote_lanes(VoteLanes t, int K) {
   t.out2[blockIdx.x][1] = ids[best_k];
 }
 int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, const int32_t* const* gates, int n, int K, hipStream_t st) {
-  DD_REQUIRE(ids && out2 && n >= 1 && n <= 4 && K >= 1 && K <= 4096, "dd_vote_lanes: bad arguments");
+  DD_REQUIRE(ids && out2 && n >= 1 && n <= 8 && K >= 1 && K <= 4096, "dd_vote_lanes: bad arguments");
   VoteLanes t;
   memset(&t, 0, sizeof(t));
   for (int i = 0; i < n; ++i) t.ids[i] = ids[i], t.out2[i] = out2[i], t.gate[i] = gates ? gates[i] : nullptr;

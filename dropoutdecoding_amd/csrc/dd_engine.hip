@@ -45,6 +45,7 @@ int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, const int32_t
 static unsigned long long g_lm_serial = 0;   // handles are identified in graph keys by a serial that is never reused
 
 #define MAX_MEMBERS DD_MAX_MEMBERS
+#define GROUP_ROWS 64     // rows of the widest decode pass: the members of eight sequences
 #define KV_ROWS 32        // new K/V rows kept per layer: 16 members, or the base rows of up to 32 lanes (group step)
 #define MAX_NEW_TOKENS 8192
 
@@ -243,12 +244,12 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->kc, h->lsk * h->Lyr);
   DA(h->vc, h->lsv * h->Lyr);
   // decode scratch
-  DA(h->xa, 32 * (size_t)d);                 // up to 32 rows: a member pass of four sequences (dd_lm_group_step)
-  DA(h->qbuf, 32 * (size_t)h->q_dim);
+  DA(h->xa, GROUP_ROWS * (size_t)d);         // up to 64 rows: a member pass of eight sequences (dd_lm_group_step)
+  DA(h->qbuf, GROUP_ROWS * (size_t)h->q_dim);
   DA(h->knew, (size_t)h->Lyr * KV_ROWS * h->kv_dim);
   DA(h->vnew, (size_t)h->Lyr * KV_ROWS * h->kv_dim);
-  DA(h->ssq_a, (size_t)(d / 16) * 32);
-  DA(h->ssq_b, (size_t)(d / 16) * 32);
+  DA(h->ssq_a, (size_t)(d / 16) * GROUP_ROWS);
+  DA(h->ssq_b, (size_t)(d / 16) * GROUP_ROWS);
   int max_splits = T / 64;
   DA(h->part_o, (size_t)h->Hkv * max_splits * 32 * G * 128);
   DA(h->part_ml, (size_t)h->Hkv * max_splits * 32 * G * 2);
@@ -258,13 +259,14 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   {
     // slice partials: 8 slices x tiles x 4 planes x 128 floats for qkv / o / down, 4 slice pairs for gate/up
     size_t t8 = (size_t)h->qkv_tiles > (size_t)d / 16 ? (size_t)h->qkv_tiles : (size_t)d / 16;
-    size_t nfl = 8 * t8 * 4 * 128, gu = (size_t)4 * (2 * dff / 16) * 4 * 128;
+    // (eight planes for a 64-row pass: single slices for every matrix)
+    size_t nfl = 8 * t8 * 8 * 128, gu = (size_t)8 * (2 * dff / 16) * 8 * 128;
     h->gemv_part_floats = h->fp8 ? 0 : (nfl > gu ? nfl : gu);
-    if (h->gemv_part_floats) DA(h->gemv_part, h->gemv_part_floats + 64);   // + rstd of the 32 operand rows
+    if (h->gemv_part_floats) DA(h->gemv_part, h->gemv_part_floats + 64);   // + rstd of the up to 64 operand rows
   }
-  DA(h->xop_d, (size_t)h->S_d * 64 * 4);     // four operand planes (8 rows each)
-  DA(h->xop_q, (size_t)h->S_q * 64 * 4);
-  DA(h->xop_ff, (size_t)h->S_ff * 64 * 4);
+  DA(h->xop_d, (size_t)h->S_d * 64 * 8);     // eight operand planes (8 rows each)
+  DA(h->xop_q, (size_t)h->S_q * 64 * 8);
+  DA(h->xop_ff, (size_t)h->S_ff * 64 * 8);
   DA(h->base_logits, h->Vpad);
   DA(h->grp_logits, (size_t)32 * h->Vpad);
   DA(h->grp_argmax, 32);
@@ -582,15 +584,15 @@ __global__ __launch_bounds__(256) void k_step_begin_lanes(StepBeginLanes t) {
   if (threadIdx.x == 0) t.st[q]->pos = t.st[q]->T - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
 }
 struct StepEndLanes {
-  DDState* st[4];
-  const int32_t* member_tok[4];
-  const float* member_logits[4];
-  float* last_logits[4];
-  int32_t* tokens[4];
-  const uint8_t* drop_bits[4];
-  uint8_t* leak_bits[4];
-  volatile int32_t* mirror[4];
-  int L[4], leak[4];
+  DDState* st[8];
+  const int32_t* member_tok[8];
+  const float* member_logits[8];
+  float* last_logits[8];
+  int32_t* tokens[8];
+  const uint8_t* drop_bits[8];
+  uint8_t* leak_bits[8];
+  volatile int32_t* mirror[8];
+  int L[8], leak[8];
 };
 __global__ __launch_bounds__(1024) void k_step_end_lanes(StepEndLanes t, int K, int Vpad) {
   const int q = blockIdx.x;
@@ -1149,7 +1151,7 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
 // buffers, so that vote and commit run per sequence exactly as after lm_sweep.
 // -----------------------------------------------------------------------------------------------
 static int g_use_graph = 1;    // dd_set_tuning key 8
-static int g_pair_sweeps = 4;  // dd_set_tuning key 9: sequences per member sweep in dd_lm_group_step (0/1: one, 2, 4)
+static int g_pair_sweeps = 8;  // dd_set_tuning key 9: sequences per member sweep in dd_lm_group_step (0/1: one, 2, 4, 8)
 void dd_engine_set_graph(int on) { g_use_graph = on; }
 void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
 
@@ -1236,9 +1238,9 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
 // the sweep with ONE launch per stage (dd_lm_step_commit's work, block = sequence)
 static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st) {
   const int d = h->d;
-  const float* lg[4];
-  int32_t* tk[4];
-  const int32_t* gates[4];
+  const float* lg[8];
+  int32_t* tk[8];
+  const int32_t* gates[8];
   for (int g = 0; g < ng; ++g) lg[g] = qs[g]->member_logits, tk[g] = qs[g]->member_tok, gates[g] = &qs[g]->state->done;
   RC(dd_argmax_rows_lanes(lg, tk, gates, ng, K, h->V, h->Vpad, st));
   bool plain_vote = true;
@@ -1257,8 +1259,8 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
     }
     return DD_OK;
   }
-  const int32_t* ids[4];
-  int32_t* out2[4];
+  const int32_t* ids[8];
+  int32_t* out2[8];
   CommitLanes cl;
   StepEndLanes el;
   memset(&cl, 0, sizeof(cl));
@@ -1381,7 +1383,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     dd_lm* q = lanes[m];
     if (K > 0) {
       const int left = n - m;
-      const int ng = !multi ? 1 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1));
+      const int ng = !multi ? 1 : (left >= 8 && g_pair_sweeps >= 8 && !h0->fp8 ? 8 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1)));
       if (ng > 1) {
         RC(lm_sweep_groups(h0, lanes + m, ng, K, st));
         RC(group_finish(h0, lanes + m, ng, K, st));
@@ -1941,7 +1943,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 4 && key != 3) || (key >= 8 && key <= 14), "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4 && key != 3) || (key >= 8 && key <= 16), "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 10) ddk_set_attn_split(value);
   else if (key == 11) dd_engine_set_extend_rows(value);
@@ -1949,6 +1951,8 @@ extern "C" int dd_set_tuning(int key, int value) {
   else if (key == 9) dd_engine_set_pairs(value);
   else if (key == 13) ddk_set_gemv_slices(value);
   else if (key == 14) dd_engine_set_speculate(value);
+  else if (key == 15) ddk_set_gemm_xcd_order(value);
+  else if (key == 16) ddk_set_gemm_big_rows(value);
   else ddk_set_tuning(key, value);
   return DD_OK;
 }

@@ -124,14 +124,14 @@ struct GemvArgs {
   const float* rope_cos; // [max_seq][64]
   const float* rope_sin;
   const DDState* state;
-  const DDState* state_rows[32];  // lanes: row m takes its position from state_rows[m] (null entries: `state`)
-  // multi-group passes (ddk_gemv_groups): rows 8g..8g+7 are group g (2 or 4 groups) — group g's operand plane is plane g
+  const DDState* state_rows[64];  // lanes: row m takes its position from state_rows[m] (null entries: `state`)
+  // multi-group passes (ddk_gemv_groups): rows 8g..8g+7 are group g (2, 4 or 8 groups) — group g's operand plane is plane g
   // of `xop` (and of xop_next: plane stride S_next * 64 u32x4); its logits / new K/V rows may live in another sequence's
   // buffers
   int n_groups;
-  float* out_g[4];      // EPI_STORE rows of group g (null: out + 8 g * ldo)
-  float* knew_g[4];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
-  float* vnew_g[4];
+  float* out_g[8];      // EPI_STORE rows of group g (null: out + 8 g * ldo)
+  float* knew_g[8];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
+  float* vnew_g[8];
   int S_next;           // K / 32 of the GEMV that consumes xop_next
   int wf;                   // 16-bit type of W and of the packed operands: 0 bf16, 1 fp16 (engines created with weight_format 2)
   const int32_t* skip_if;   // optional (k_gemv): *skip_if != 0 -> the launch returns at once (fallback sweep of a speculative step)
@@ -139,9 +139,11 @@ struct GemvArgs {
   size_t part_floats;   // capacity; 64 more floats behind it hold rstd of the operand rows
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
-int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2 or 4) groups of up to 8 rows (bf16 weights)
+int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2, 4 or 8) groups of up to 8 rows
 void ddk_set_tuning(int key, int value);
 void ddk_set_gemv_slices(int on);
+void ddk_set_gemm_big_rows(int rows);  // dd_set_tuning key 16: rows from which the prefill GEMM uses the 128 x 512 LDS-staged block (0: never; same bits)
+void ddk_set_gemm_xcd_order(int on);   // dd_set_tuning key 15: XCD-aware block order of the prefill GEMM (default on; same bits)
 void ddk_set_slices_only(int on);
 void ddk_set_attn_split(int v);
 void ddk_set_prefill_mfma(int on);
@@ -174,10 +176,10 @@ struct AttnDecodeArgs {
   // lanes (n_lanes > 0): row m of the pass belongs to sequence m — its own cache, length, span and (un-shifted) bits.
   // Used by the fused base pass of a group of sequences; kc/vc/state/drop_bits/span_* above are ignored then.
   int n_lanes;
-  int lane_groups;       // 0: lane m = row m (fused base pass of up to 16 sequences).  2 / 4: a 16- / 32-row pass of that many sequences — rows
+  int lane_groups;       // 0: lane m = row m (fused base pass of up to 16 sequences).  2 / 4 / 8: a 16- / 32- / 64-row pass of that many sequences — rows
                          // 8g..8g+7 are members of lane g (each group reads its own cache with its own drop bits, bit = row & 7)
-  const float* knew_g[4];  // lane_groups > 0: new K/V rows of group g
-  const float* vnew_g[4];
+  const float* knew_g[8];  // lane_groups > 0: new K/V rows of group g
+  const float* vnew_g[8];
   int max_T;             // host: largest prefix length among the lanes (grid sizing)
   const float* lane_kc[16];
   const float* lane_vc[16];
@@ -201,6 +203,7 @@ struct GemmArgs {
   const float* bias;     // per-column bias (natural order) added after the scale, or nullptr
   int act;               // EPI_ACT: 0 quick_gelu, 1 gelu(erf), 2 identity
   int vit_hidden, vit_head_dim, vit_head_pad;   // EPI_QKV_VIT (head_pad: pitch of a head in q / K^T / V; 0 = head_dim)
+  int grid_y, xcd_order; // set by the launcher: row blocks of the grid; XCD-aware block order on / off
   int vit_col0;          // EPI_QKV_VIT: output column c of W counts as column c + vit_col0 of a fused [q | k | v] projection
                          // (a [k | v] weight of a cross-attention runs with vit_col0 = hidden)
   float vit_qscale;
@@ -238,17 +241,17 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStr
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
                    float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if = nullptr, int wf = 0);
 struct EmbedLanes {
-  const DDState* state[32];   // row m embeds the current token of this sequence (null: row unused)
+  const DDState* state[64];   // row m embeds the current token of this sequence (null: row unused)
 };
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
-                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf = 0);   // rows = 8, 16 or 32
+                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf = 0);   // rows = 8, 16, 32 or 64
 int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st, int wf = 0);
-struct CommitLanes {       // winners of up to 4 sequences appended to their caches in one launch
-  const float* knew[4];
-  const float* vnew[4];
-  float* kc[4];
-  float* vc[4];
-  const DDState* state[4];
+struct CommitLanes {       // winners of up to 8 sequences appended to their caches in one launch
+  const float* knew[8];
+  const float* vnew[8];
+  float* kc[8];
+  float* vc[8];
+  const DDState* state[8];
   size_t lsk, lsv;
   int kv16;
 };

@@ -890,7 +890,31 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
   sa.rstd_out = a.part + a.part_floats;                              // 32 floats behind the partial sums
   const size_t need8 = (size_t)8 * nt * NG * 128, need4 = need8 / 2;
-  if (epi == EPI_QKV) {
+  if constexpr (NG == 8) {
+    // 64 rows: 8 operand planes fill the LDS with one slice (16 steps x 8 KiB = 128 KiB at K = 4096; long K in chunks of 8
+    // steps), one tile per wave group; tools/gemv_lab: qkv 28 us, o 10.7, gate/up 45, down 21 — 1.25 x the 32-row kernels for
+    // twice the rows
+    if (a.part_floats < need8) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    if (epi == EPI_QKV) {
+      if (spw != 16) return SLICES_UNSUPPORTED;
+      sa.G = (nt + 15) / 16;
+      RC_(launch_slices_k<1, 8, 8, 16, 16, 1>(sa, a.wf, st));
+      launch_finish<EPI_QKV, 1, 8, 8>(a, nt, st);
+    } else if (epi == EPI_RESID) {
+      sa.G = (nt + 7) / 8;
+      if (spw == 16) RC_(launch_slices_k<1, 8, 8, 16, 16, 1>(sa, a.wf, st));
+      else if (spw == 43) RC_(launch_slices_k<1, 8, 8, 43, 8, 1>(sa, a.wf, st));
+      else RC_(launch_slices_k<1, 8, 8, 56, 8, 1>(sa, a.wf, st));
+      launch_finish<EPI_RESID, 1, 8, 8>(a, nt, st);
+    } else {
+      if (spw != 16) return SLICES_UNSUPPORTED;
+      sa.G = (nt + 15) / 16;
+      RC_(launch_slices_k<1, 8, 8, 16, 16, 1>(sa, a.wf, st));
+      launch_finish<EPI_SILU, 2, 8, 8>(a, a.n_tiles, st);
+    }
+    return DD_OK;
+  } else if (epi == EPI_QKV) {
     if (spw != 16 || (nt & 1) || a.part_floats < need8) return SLICES_UNSUPPORTED;
     sa.n_groups = nt / 2;
     sa.G = sa.n_groups >= 256 ? (sa.n_groups + 15) / 16 : (sa.n_groups + 7) / 8;     // two tile pairs per wave when there are enough
@@ -920,14 +944,39 @@ int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv_groups: K=%d must be a multiple of 256", a.S * 32);
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv_groups: nb=%d rows per group", a.nb);
   DD_REQUIRE(!a.fp8 || a.wscale, "gemv_groups: fp8 weights need row scales");
-  DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4, "gemv_groups: %d groups (2 or 4)", a.n_groups);
+  DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4 || a.n_groups == 8, "gemv_groups: %d groups (2, 4 or 8)", a.n_groups);
   if (g_gemv_slices && !a.fp8 && a.part) {
-    int rs = a.n_groups == 2 ? try_slices<2>(epi, a, st) : try_slices<4>(epi, a, st);
+    int rs = a.n_groups == 2 ? try_slices<2>(epi, a, st) : (a.n_groups == 4 ? try_slices<4>(epi, a, st) : try_slices<8>(epi, a, st));
     if (rs != SLICES_UNSUPPORTED) {
       if (rs != DD_OK) return rs;
       DD_CHECK_LAUNCH();
       return DD_OK;
     }
+  }
+  if (a.n_groups == 8) {
+    // no 64-row kernel for this matrix (lm_head, fp8 weights, other shapes): two 32-row passes over rows 0..31 / 32..63 —
+    // the same bits, since a row's result does not depend on the kernel that computed it
+    for (int half = 0; half < 2; ++half) {
+      GemvArgs b = a;
+      b.n_groups = 4;
+      if (half) {
+        b.xop = a.xop + (size_t)4 * a.S * 64;
+        if (a.xop_next) b.xop_next = a.xop_next + (size_t)4 * a.S_next * 64;
+        if (a.out) b.out = a.out + (size_t)32 * a.ldo;
+        if (a.ssq_in) b.ssq_in = a.ssq_in + (size_t)32 * a.ssq_ld;
+        if (a.ssq_out) b.ssq_out = a.ssq_out + (size_t)32 * a.ssq_ld;
+        if (a.qbuf) b.qbuf = a.qbuf + (size_t)32 * a.q_dim;
+        if (a.knew) b.knew = a.knew + (size_t)32 * a.kv_dim;
+        if (a.vnew) b.vnew = a.vnew + (size_t)32 * a.kv_dim;
+        for (int i = 0; i < 32; ++i) b.state_rows[i] = a.state_rows[32 + i];
+        for (int i = 0; i < 4; ++i) b.out_g[i] = a.out_g[4 + i], b.knew_g[i] = a.knew_g[4 + i], b.vnew_g[i] = a.vnew_g[4 + i];
+      }
+      for (int i = 32; i < 64; ++i) b.state_rows[i] = nullptr;
+      for (int i = 4; i < 8; ++i) b.out_g[i] = b.knew_g[i] = b.vnew_g[i] = nullptr;
+      int rc2 = ddk_gemv_groups(epi, b, st);
+      if (rc2 != DD_OK) return rc2;
+    }
+    return DD_OK;
   }
   int rc = DD_OK;
   const bool two = a.n_groups == 2;
@@ -1289,8 +1338,30 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
   DD_REQUIRE(G == 1 || G == 2 || G == 4, "attn: GQA group %d unsupported (1, 2, 4)", G);
   int rc = DD_OK;                    // a launcher that refuses (too many key tiles, attribute failure) launches nothing
   if (a.n_lanes > 0 && a.lane_groups) {
+    if (a.lane_groups == 8 && a.n_lanes == 8) {   // 64 rows: two passes of four sequences (each sequence reads its own cache either way)
+      for (int half = 0; half < 2; ++half) {
+        AttnDecodeArgs b = a;
+        b.lane_groups = b.n_lanes = 4;
+        b.max_T = 0;
+        for (int i = 0; i < 4; ++i) {
+          const int s_ = 4 * half + i;
+          b.knew_g[i] = a.knew_g[s_], b.vnew_g[i] = a.vnew_g[s_];
+          b.lane_kc[i] = a.lane_kc[s_], b.lane_vc[i] = a.lane_vc[s_], b.lane_state[i] = a.lane_state[s_], b.lane_bits[i] = a.lane_bits[s_];
+          b.lane_span_start[i] = a.lane_span_start[s_], b.lane_span_len[i] = a.lane_span_len[s_];
+        }
+        b.max_T = a.max_T;
+        if (half) {
+          b.qbuf = a.qbuf + (size_t)32 * a.n_heads * HEAD_DIM;
+          b.xop_out = a.xop_out + (size_t)4 * (a.n_heads * HEAD_DIM / 32) * 64;
+        }
+        b.knew = b.knew_g[0], b.vnew = b.vnew_g[0];
+        int rc2 = ddk_attn_decode(b, st);
+        if (rc2 != DD_OK) return rc2;
+      }
+      return DD_OK;
+    }
     DD_REQUIRE((a.lane_groups == 2 || a.lane_groups == 4) && a.n_lanes == a.lane_groups && a.nb >= 1 && a.nb <= 8,
-               "attn: a multi-group pass takes 2 or 4 sequences of up to 8 members");
+               "attn: a multi-group pass takes 2, 4 or 8 sequences of up to 8 members");
     if (a.lane_groups == 2) {
       if (G == 1) rc = launch_attn_groups<1, 2>(a, st);
       else if (G == 2) rc = launch_attn_groups<2, 2>(a, st);
@@ -1370,69 +1441,11 @@ int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float e
   return ddk_rmsnorm_split(x, rows, d, w, eps, nullptr, nullptr, nullptr, out, st, 0);
 }
 
-// C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64; both operands are pre-tiled so every
-// fragment is a contiguous 1 KiB wave load straight to VGPRs (L2-resident A, streamed W)
-
-// MI x NJ = 16x16 MFMA tiles per wave (rows x cols); 4 waves as 2x2: block = (32*MI) rows x (32*NJ) cols.
-// 4x4 (128x128 block) for the LM prefill; 2x2 (64x64) when the grid would otherwise be too small to fill 256 CUs
-// (the ViT: M = 577, N = 1024).
-template <int EPI, int MI, int NJ, int WF = 0>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int m_base = blockIdx.y * (32 * MI) + wr * (16 * MI);
-  const int nt_base = blockIdx.x * (2 * NJ) + wc * NJ;
-  const int S = a.S;
-  f32x4_t acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const u32x4_t* pa_hi[MI];
-  const u32x4_t* pa_lo[MI];
-  const int m_tiles = (a.M + 15) >> 4;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    int mt = min((m_base >> 4) + i, m_tiles - 1);
-    pa_hi[i] = (const u32x4_t*)a.a_hi + (size_t)mt * S * 64 + lane;
-    pa_lo[i] = (const u32x4_t*)a.a_lo + (size_t)mt * S * 64 + lane;
-  }
-  const u32x4_t* pw[NJ];
-  bool wv[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    wv[j] = (nt_base + j) < a.n_tiles;
-    pw[j] = a.W + ((size_t)(wv[j] ? nt_base + j : 0) * S) * 64 + lane;
-  }
-  // explicit two-stage register pipeline: the fragments of k-step s+1 are requested before the 32 MFMAs of step s
-  // issue, so the L2 latency of one step hides behind the matrix work of the other (S is even: K multiple of 256)
-  u32x4_t ahi0[MI], alo0[MI], w0[NJ], ahi1[MI], alo1[MI], w1[NJ];
-  auto load = [&](u32x4_t* ahi, u32x4_t* alo, u32x4_t* w, int ks) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      ahi[i] = pa_hi[i][(size_t)ks * 64];
-      alo[i] = pa_lo[i][(size_t)ks * 64];
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) w[j] = pw[j][(size_t)ks * 64];
-  };
-  auto compute = [&](const u32x4_t* ahi, const u32x4_t* alo, const u32x4_t* w) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        acc[i][j] = dd_mfma16<WF>(ahi[i], w[j], acc[i][j]);
-        acc[i][j] = dd_mfma16<WF>(alo[i], w[j], acc[i][j]);
-      }
-  };
-  load(ahi0, alo0, w0, 0);
-  for (int ks = 0; ks < S; ks += 2) {
-    load(ahi1, alo1, w1, ks + 1);
-    compute(ahi0, alo0, w0);
-    if (ks + 2 < S) load(ahi0, alo0, w0, ks + 2);
-    compute(ahi1, alo1, w1);
-  }
-  // D[m][n]: m = 4*(lane>>4) + reg, n = lane & 15
+// Epilogue of the prefill GEMMs for a wave's MI x NJ accumulator tiles (rows m_base.., 16-column tiles nt_base..).
+// D[m][n]: m = 4*(lane>>4) + reg, n = lane & 15
+template <int EPI, int MI, int NJ, int WF>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[MI][NJ], const int m_base, const int nt_base,
+                                              const bool (&wv)[NJ], const int lane) {
   const int c = lane & 15;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -1518,9 +1531,196 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
   }
 }
 
+// C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64; both operands are pre-tiled so every
+// fragment is a contiguous 1 KiB wave load straight to VGPRs (L2-resident A, streamed W)
+
+// MI x NJ = 16x16 MFMA tiles per wave (rows x cols); 4 waves as 2x2: block = (32*MI) rows x (32*NJ) cols.
+// 4x4 (128x128 block) for the LM prefill; 2x2 (64x64) when the grid would otherwise be too small to fill 256 CUs
+// (the ViT: M = 577, N = 1024).
+template <int EPI, int MI, int NJ, int WF = 0>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // XCD-aware block order (1-D grid of gx * gy workgroups).  The dispatcher deals workgroup ids round-robin to the 8 XCDs,
+  // each with its own L2: id -> (XCD id & 7, slot id >> 3).  An XCD is given a contiguous run of the virtual order
+  // v = column block * gy + row block, so the gy row blocks that re-read one weight column block run back to back on ONE
+  // XCD (one fetch into one L2) and neighbouring column blocks share the activation rows in that L2.
+  int bx, by;
+  {
+    const int gy = a.grid_y, total = gridDim.x, per = total >> 3, id = blockIdx.x;
+    const int v = a.xcd_order && id < (per << 3) ? (id & 7) * per + (id >> 3) : id;
+    bx = v / gy, by = v - bx * gy;
+  }
+  const int m_base = by * (32 * MI) + wr * (16 * MI);
+  const int nt_base = bx * (2 * NJ) + wc * NJ;
+  const int S = a.S;
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const u32x4_t* pa_hi[MI];
+  const u32x4_t* pa_lo[MI];
+  const int m_tiles = (a.M + 15) >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int mt = min((m_base >> 4) + i, m_tiles - 1);
+    pa_hi[i] = (const u32x4_t*)a.a_hi + (size_t)mt * S * 64 + lane;
+    pa_lo[i] = (const u32x4_t*)a.a_lo + (size_t)mt * S * 64 + lane;
+  }
+  const u32x4_t* pw[NJ];
+  bool wv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    wv[j] = (nt_base + j) < a.n_tiles;
+    pw[j] = a.W + ((size_t)(wv[j] ? nt_base + j : 0) * S) * 64 + lane;
+  }
+  // explicit two-stage register pipeline: the fragments of k-step s+1 are requested before the 32 MFMAs of step s
+  // issue, so the L2 latency of one step hides behind the matrix work of the other (S is even: K multiple of 256)
+  u32x4_t ahi0[MI], alo0[MI], w0[NJ], ahi1[MI], alo1[MI], w1[NJ];
+  auto load = [&](u32x4_t* ahi, u32x4_t* alo, u32x4_t* w, int ks) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      ahi[i] = pa_hi[i][(size_t)ks * 64];
+      alo[i] = pa_lo[i][(size_t)ks * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) w[j] = pw[j][(size_t)ks * 64];
+  };
+  auto compute = [&](const u32x4_t* ahi, const u32x4_t* alo, const u32x4_t* w) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        acc[i][j] = dd_mfma16<WF>(ahi[i], w[j], acc[i][j]);
+        acc[i][j] = dd_mfma16<WF>(alo[i], w[j], acc[i][j]);
+      }
+  };
+  load(ahi0, alo0, w0, 0);
+  for (int ks = 0; ks < S; ks += 2) {
+    load(ahi1, alo1, w1, ks + 1);
+    compute(ahi0, alo0, w0);
+    if (ks + 2 < S) load(ahi0, alo0, w0, ks + 2);
+    compute(ahi1, alo1, w1);
+  }
+  gemm_epilogue<EPI, MI, NJ, WF>(a, acc, m_base, nt_base, wv, lane);
+}
+
+// The same product with a 128 x 512 block for many rows (a long prompt, or the prompts of several sequences back to back):
+// 8 waves as 2 x 4, each 64 rows x 128 columns (4 x 8 accumulator tiles).  The 128 x 128 kernel asks the L2 for
+// (128 x {hi, lo} + 128) x 64 B = 24 KiB per k-step of 32 and is bound by that (85 flop / B: DESIGN.md); this block asks for
+// (128 x 2 + 512) x 64 B = 48 KiB for four times the flops, staged once per workgroup in LDS (the pre-tiled fragments are
+// copied as they lie: a wave's fragment read is 64 consecutive 16-byte words, conflict-free) in a ring of three stages.
+// Per accumulator tile the MFMA sequence is the one k_gemm issues (k ascending; hi then lo), so the results are the same bits.
+#define GB_MT 8     // 16-row tiles of a block
+#define GB_NT 32    // 16-column tiles of a block
+#define GB_STAGE (GB_MT * 2 + GB_NT)   // 1 KiB fragments per k-step: A hi, A lo, W
+template <int EPI, int WF>
+__global__ __launch_bounds__(512) void k_gemm_big(GemmArgs a) {
+  extern __shared__ __align__(16) u32x4_t gb_sh[];          // [3 stages][GB_STAGE fragments][64]
+  constexpr int MI = 4, NJ = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  int bx, by;
+  {
+    const int gy = a.grid_y, total = gridDim.x, per = total >> 3, id = blockIdx.x;
+    const int v = a.xcd_order && id < (per << 3) ? (id & 7) * per + (id >> 3) : id;
+    bx = v / gy, by = v - bx * gy;
+  }
+  const int S = a.S;
+  const int m_tiles = (a.M + 15) >> 4;
+  // copy duty of this wave: fragment slots wave + 8 i, i < 6 -> A hi tile `wave`, A lo tile `wave`, W tiles wave + 8 (i - 2)
+  const u32x4_t* src[6];
+  {
+    const int mt = min(by * GB_MT + wave, m_tiles - 1);
+    src[0] = (const u32x4_t*)a.a_hi + (size_t)mt * S * 64 + lane;
+    src[1] = (const u32x4_t*)a.a_lo + (size_t)mt * S * 64 + lane;
+#pragma unroll
+    for (int i = 2; i < 6; ++i) {
+      const int nt = min(bx * GB_NT + wave + 8 * (i - 2), a.n_tiles - 1);
+      src[i] = a.W + (size_t)nt * S * 64 + lane;
+    }
+  }
+  u32x4_t* const my_dst = gb_sh + wave * 64 + lane;             // + stage * GB_STAGE * 64 + slot group i: A hi 0..7, A lo 8..15, W 16..47
+  const int m_base = by * (16 * GB_MT) + wr * (16 * MI);
+  const int nt_base = bx * GB_NT + wc * NJ;
+  bool wv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) wv[j] = (nt_base + j) < a.n_tiles;
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // three LDS stages: step ks multiplies from stage ks % 3 while the fragments of step ks + 2 travel global -> registers ->
+  // stage (ks + 2) % 3, and the wave's A fragments of step ks + 1 are read from stage (ks + 1) % 3 once the step's MFMAs are
+  // issued — so that after the barrier the next step starts multiplying at once instead of all 8 waves queueing on the LDS
+  // for their 9 KiB first (that start-up cost 40 % of a step with two stages).
+  u32x4_t pre[6];
+#pragma unroll
+  for (int s0 = 0; s0 < 2; ++s0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pre[i] = src[i][(size_t)s0 * 64];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) my_dst[s0 * (GB_STAGE * 64) + i * 8 * 64] = pre[i];
+  }
+  __syncthreads();
+  u32x4_t ahi[MI], alo[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    ahi[i] = gb_sh[(wr * MI + i) * 64 + lane];
+    alo[i] = gb_sh[(GB_MT + wr * MI + i) * 64 + lane];
+  }
+  int s_cur = 0;                                               // ks % 3
+  for (int ks = 0; ks < S; ++ks) {
+    const bool more2 = ks + 2 < S;
+    if (more2) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pre[i] = src[i][(size_t)(ks + 2) * 64];
+    }
+    const u32x4_t* st = gb_sh + s_cur * (GB_STAGE * 64);
+    const int s_next = s_cur == 2 ? 0 : s_cur + 1, s_next2 = s_next == 2 ? 0 : s_next + 1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const u32x4_t w = st[(2 * GB_MT + wc * NJ + j) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = dd_mfma16<WF>(ahi[i], w, acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = dd_mfma16<WF>(alo[i], w, acc[i][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < S) {
+      const u32x4_t* sn = gb_sh + s_next * (GB_STAGE * 64);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        ahi[i] = sn[(wr * MI + i) * 64 + lane];
+        alo[i] = sn[(GB_MT + wr * MI + i) * 64 + lane];
+      }
+    }
+    if (more2) {
+      u32x4_t* d = my_dst + s_next2 * (GB_STAGE * 64);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i * 8 * 64] = pre[i];
+    }
+    __syncthreads();
+    s_cur = s_next;
+  }
+  gemm_epilogue<EPI, MI, NJ, WF>(a, acc, m_base, nt_base, wv, lane);
+}
+
+static int g_gemm_big_rows = 1024;   // tuning key 16: rows from which ddk_gemm uses the 128 x 512 block (0: never)
+void ddk_set_gemm_big_rows(int v) { g_gemm_big_rows = v; }
+static int launch_gemm_big(int epi, const GemmArgs& a_, hipStream_t st);
+
+static int g_gemm_xcd_order = 1;   // tuning key 15
+void ddk_set_gemm_xcd_order(int v) { g_gemm_xcd_order = v ? 1 : 0; }
 template <int MI, int NJ>
-static int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
-  dim3 grid((a.n_tiles + 2 * NJ - 1) / (2 * NJ), (a.M + 32 * MI - 1) / (32 * MI));
+static int launch_gemm(int epi, const GemmArgs& a_, hipStream_t st) {
+  GemmArgs a = a_;
+  const int gx = (a.n_tiles + 2 * NJ - 1) / (2 * NJ);
+  a.grid_y = (a.M + 32 * MI - 1) / (32 * MI);
+  a.xcd_order = g_gemm_xcd_order;
+  dim3 grid(gx * a.grid_y);
   switch (epi) {
 #define GM(E_)                                                          \
   if (a.wf) k_gemm<E_, MI, NJ, 1><<<grid, 256, 0, st>>>(a);             \
@@ -1538,8 +1738,42 @@ static int launch_gemm(int epi, const GemmArgs& a, hipStream_t st) {
   return DD_OK;
 }
 
+static int launch_gemm_big(int epi, const GemmArgs& a_, hipStream_t st) {
+  GemmArgs a = a_;
+  const int gx = (a.n_tiles + GB_NT - 1) / GB_NT;
+  a.grid_y = (a.M + 16 * GB_MT - 1) / (16 * GB_MT);
+  a.xcd_order = g_gemm_xcd_order;
+  const size_t lds = (size_t)3 * GB_STAGE * 64 * sizeof(u32x4_t);   // 144 KiB
+  dim3 grid(gx * a.grid_y);
+#define GBK(E_, W_)                                                                                                          \
+  do {                                                                                                                       \
+    static bool attr = false;                                                                                                \
+    if (!attr) {                                                                                                             \
+      DD_HIP(hipFuncSetAttribute((const void*)k_gemm_big<E_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+      attr = true;                                                                                                           \
+    }                                                                                                                        \
+    k_gemm_big<E_, W_><<<grid, 512, lds, st>>>(a);                                                                           \
+  } while (0)
+#define GB(E_)                  \
+  if (a.wf) GBK(E_, 1);         \
+  else GBK(E_, 0)
+  switch (epi) {
+    case EPI_STORE: GB(EPI_STORE); break;
+    case EPI_RESID: GB(EPI_RESID); break;
+    case EPI_SILU: GB(EPI_SILU); break;
+    case EPI_QKV: GB(EPI_QKV); break;
+    default: DD_REQUIRE(false, "gemm (128 x 512 block): epilogue %d not built", epi);
+  }
+#undef GB
+#undef GBK
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S >= 2 && (a.S & 1) == 0, "gemm: K=%d must be a multiple of 64", a.S * 32);
+  if (g_gemm_big_rows > 0 && a.M >= g_gemm_big_rows && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_SILU || epi == EPI_QKV))
+    return launch_gemm_big(epi, a, st);
   long big = (long)((a.n_tiles + 7) / 8) * ((a.M + 127) / 128);      // workgroups of the 128x128 tiling
   if (big >= 150) return launch_gemm<4, 4>(epi, a, st);
   return launch_gemm<2, 2>(epi, a, st);                              // 64x64 blocks: 4x the workgroups
@@ -1965,7 +2199,16 @@ __global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __res
 }
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
                          u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf) {
-  if (rows == 32) k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
+  if (rows == 64) {   // rows 0..31 and 32..63: planes 0-3 / 4-7 of the operand
+    EmbedLanes l2;
+    memset(&l2, 0, sizeof(l2));
+    for (int m = 0; m < 32; ++m) l2.state[m] = lanes.state[32 + m];
+    EmbedLanes l1 = lanes;
+    for (int m = 32; m < 64; ++m) l1.state[m] = nullptr;
+    k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, l1, x, normw, xop, ssq, ssq_ld, wf);
+    k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, l2, x + (size_t)32 * d, normw, xop + (size_t)4 * (d >> 5) * 64, ssq + (size_t)32 * ssq_ld,
+                                                ssq_ld, wf);
+  } else if (rows == 32) k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
   else if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
   else k_embed_rows_lanes<8><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
   DD_CHECK_LAUNCH();

@@ -476,7 +476,9 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * 8 = replay decode steps from a hipGraph (default 1), 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4;
  * default 4), 10 = workgroups per group of 8 members in the grouped decode attention (1, 2, 4; default 1),
  * 13 = slice-resident 16 / 32-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits), 14 = speculative
- * single-sequence steps (default 1; 0: always two sweeps, same results).
+ * single-sequence steps (default 1; 0: always two sweeps, same results), 15 = XCD-aware block order of the prefill GEMM
+ * (default 1; 0: row-major block order, same bits), 16 = rows from which the prefill GEMM uses its 128 x 512 LDS-staged
+ * block (default 1024; 0: never; same bits).
  * Keys 1 and 2 are accepted and ignored (settled: non-temporal weight loads, interleaved k-steps). */
 int dd_set_tuning(int key, int value);
 

@@ -1,4 +1,4 @@
-"""The slice-resident 16 / 32-row decode GEMVs (csrc/dd_gemv_slices.h + k_gemv_finish) against the K-split-over-waves
+"""The slice-resident 16 / 32 / 64-row decode GEMVs (csrc/dd_gemv_slices.h + k_gemv_finish) against the K-split-over-waves
 kernels they replace on the lanes path: same k order, same MFMA chains, same reduction order, so every logit, token and
 KV row must be BIT-identical — and with it everything the solo 8-row kernel produces for the same sequence.
 Shapes are the 7B families' (K = 4096, 11008, 14336), two layers deep so the test stays small."""
@@ -51,6 +51,8 @@ def _run(E, engines, embs, spans, probs, steps, slices, graph):
     ("llama-7b-shapes, 2 lanes: 16 member rows", (4096, 11008, 32, 32), 2),
     ("llama-7b-shapes, 20 lanes: base rows in four planes", (4096, 11008, 32, 32), 20),
     ("mistral-7b-shapes (GQA 4, d_ff 14336), 5 lanes", (4096, 14336, 32, 8), 5),
+    ("llama-7b-shapes, 9 lanes: one 64-row member pass (eight operand planes) + one 8-row pass", (4096, 11008, 32, 32), 9),
+    ("mistral-7b-shapes, 8 lanes: 64 member rows, K = 14336 in chunks", (4096, 14336, 32, 8), 8),
 ])
 def test_slice_kernels_bit_identical_to_wave_split_kernels(E, name, dims, n_lanes):
     d, dff, H, Hkv = dims

@@ -290,8 +290,8 @@ int main(int argc, char** argv) {
     }
   }
   u32x4_t* X;
-  CK(hipMalloc((void**)&X, (size_t)344 * 64 * 16 * 4));
-  CK(hipMemcpy(X, W, (size_t)344 * 64 * 16 * 4, hipMemcpyDeviceToDevice));
+  CK(hipMalloc((void**)&X, (size_t)344 * 64 * 16 * 8));     // up to 8 operand planes (64 rows)
+  CK(hipMemcpy(X, W, (size_t)344 * 64 * 16 * 8, hipMemcpyDeviceToDevice));
   float* out;
   CK(hipMalloc((void**)&out, (size_t)64 << 20));
   for (const Shape& sh : shapes) {
@@ -311,6 +311,10 @@ int main(int argc, char** argv) {
       SL(2, 4, 8, 16, 16, 24);
       SL(2, 2, 8, 16, 16, 48);
       SL(2, 2, 16, 16, 16, 48);
+      SL(2, 8, 8, 16, 16, 48);   // 64 rows
+      SL(1, 8, 8, 16, 16, 48);
+      SL(1, 8, 16, 16, 16, 48);
+      SL(1, 8, 8, 16, 16, 96);
     } else if (!strcmp(sh.name, "o")) {
       A(1, 4, 8, 0);
       SL(1, 4, 8, 16, 16, 32);
@@ -318,6 +322,8 @@ int main(int argc, char** argv) {
       SL(2, 4, 8, 16, 16, 16);
       SL(2, 4, 16, 16, 16, 16);
       SL(1, 2, 16, 16, 16, 32);
+      SL(1, 8, 8, 16, 16, 32);
+      SL(1, 8, 16, 16, 16, 32);
     } else if (!strcmp(sh.name, "gateup")) {
       A(2, 4, 2, 0);
       SL(2, 4, 8, 16, 16, 43);
@@ -328,6 +334,11 @@ int main(int argc, char** argv) {
       SL(1, 4, 16, 16, 16, 43);
       SL(1, 4, 16, 16, 16, 86);
       SL(2, 2, 16, 16, 16, 43);
+      SL(1, 8, 8, 16, 16, 43);
+      SL(1, 8, 8, 16, 16, 86);
+      SL(1, 8, 16, 16, 16, 86);
+      SL(2, 8, 8, 16, 16, 43);
+      SL(1, 8, 8, 16, 8, 86);
     } else {
       A(1, 4, 8, 0);
       SL(1, 4, 8, 43, 16, 32);
@@ -336,6 +347,9 @@ int main(int argc, char** argv) {
       SL(1, 4, 16, 43, 32, 32);
       SL(1, 2, 16, 43, 32, 32);
       SL(2, 4, 8, 43, 32, 16);
+      SL(1, 8, 8, 43, 16, 32);
+      SL(1, 8, 16, 43, 16, 32);
+      SL(1, 8, 8, 43, 8, 32);
     }
   }
   return 0;

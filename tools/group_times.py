@@ -9,6 +9,8 @@ torch.cuda.set_device(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 KV = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 from dropoutdecoding_amd import _lib
+if len(sys.argv) > 3:
+    _lib.load().dd_set_tuning(9, int(sys.argv[3]))        # sequences per member sweep (1, 2, 4, 8)
 engs = []
 for i in range(B):
     engs.append(lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format=KV,
@@ -31,5 +33,5 @@ t1 = time.perf_counter()
 print("host ms per call:", per)
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"lanes {B} kv {KV}: host enqueue {(t1 - t0) / n * 1e3:.2f} ms/group-step, total {(t2 - t0) / n * 1e3:.2f} ms/group-step "
+print(f"lanes {B} kv {KV} seqs/sweep {sys.argv[3] if len(sys.argv) > 3 else 'default'}: host enqueue {(t1 - t0) / n * 1e3:.2f} ms/group-step, total {(t2 - t0) / n * 1e3:.2f} ms/group-step "
       f"= {(t2 - t0) / n / B * 1e3:.2f} ms per image-token")
