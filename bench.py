@@ -286,15 +286,17 @@ def main() -> int:
     value = tokens / dt
 
     # dominant kernel: the gate/up decode GEMV (44 % of the streamed bytes), HIP events on the launch stream, cycling over the
-    # 32 layers' weights.  With several images per GPU the member passes are 32-row passes (the members of four sequences):
-    # the slice-resident pair k_gemv_slices (streams the weights) + k_gemv_finish (adds the slices, epilogue).
+    # 32 layers' weights.  With several images per GPU the member passes are 64-row passes (the members of eight sequences; 32 /
+    # 16 rows with fewer images): the slice-resident pair k_gemv_slices (streams the weights) + k_gemv_finish (adds the slices,
+    # epilogue).  The trailing template argument of k_gemv_slices names the matrix (2 = gate/up + SiLU).
     K_eff = 0 if args.original else len(probs)
     rows8 = min(max(K_eff, 1), 8)
     wide = B > 1 and 1 <= K_eff <= 8
-    dom_rows = (32 if B >= 4 else 16) if wide else rows8
+    dom_rows = (64 if B >= 8 else (32 if B >= 4 else 16)) if wide else rows8
     ms_pair, by = eng.time_gemv(2, dom_rows, 96)                       # the whole GEMV (both kernels when wide)
     ms = eng.time_gemv(2 + 8, dom_rows, 96)[0] if wide else ms_pair    # the streaming kernel alone
-    dom_kernel = f"k_gemv_slices<1, {dom_rows // 8}, 8, 16, 16, 2>" if wide else "k_gemv<2, 2, 8, 1, 1, 0, 0>"
+    dom_kernel = (f"k_gemv_slices<1, {dom_rows // 8}, 8, 16, 16, {1 if dom_rows == 64 else 2}, 0, 2>" if wide
+                  else "k_gemv<2, 2, 8, 1, 1, 0, 0>")
     dom_name = (f"{dom_kernel} (gate/up decode GEMV of a {dom_rows}-row pass = the members of {dom_rows // 8} sequences: streams the 180 MB of "
                 "weights once; its finishing kernel k_gemv_finish adds the K slices and applies SiLU*up)") if wide \
         else f"{dom_kernel} (gate/up decode GEMV, 8 rows)"
@@ -350,8 +352,8 @@ def main() -> int:
                                    f"32-token prompt (prefill 608), {args.n_new} decoded tokens per image (EOS ignored), K={K_eff} voting_numbers={probs if K_eff else []}, "
                                    "random-init weights of the real shapes (bf16 weights, fp32 activations, fp16 KV cache = the reference's cache width)"
                                    + (f"; the {B} images are {B} independent sequences (own KV cache and rng stream, results identical to "
-                                      "decoding each alone) whose un-masked passes share one sweep over the weights and whose member passes run four sequences "
-                                      "per sweep; the next batch's CLIP + prefill overlap the current batch's decode on a second stream" if B > 1 else ""),
+                                      "decoding each alone) whose un-masked passes share one sweep over the weights and whose member passes run eight sequences "
+                                      "(64 rows) per sweep; the next batch's CLIP + prefill overlap the current batch's decode on a second stream" if B > 1 else ""),
                        "batch_note": (f"`value` is the aggregate over {B} independent images decoded concurrently per GPU (throughput mode, the "
                                       "reference's multi-process sharding on one GPU); the reference's own shape, one image at a time, is `single_stream`"
                                       if B > 1 else "one image at a time"),

@@ -251,8 +251,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->ssq_a, (size_t)(d / 16) * GROUP_ROWS);
   DA(h->ssq_b, (size_t)(d / 16) * GROUP_ROWS);
   int max_splits = T / 64;
-  DA(h->part_o, (size_t)h->Hkv * max_splits * 32 * G * 128);
-  DA(h->part_ml, (size_t)h->Hkv * max_splits * 32 * G * 2);
+  DA(h->part_o, (size_t)h->Hkv * max_splits * GROUP_ROWS * G * 128);
+  DA(h->part_ml, (size_t)h->Hkv * max_splits * GROUP_ROWS * G * 2);
   DA(h->hidden, (size_t)MAX_MEMBERS * d);
   DA(h->spec_ok, 4);
   DA(h->rng_backup, 640);
@@ -1885,8 +1885,8 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
   hipStream_t st = (hipStream_t)stream_;
   const bool stream_only = which >= 8;      // 8 + kind: the slice-resident path's streaming kernel alone (no finishing kernel)
   if (stream_only) which -= 8;
-  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16 || nb == 32) && iters >= 1,
-             "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 / 32 = the two- / four-group kernel)");
+  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16 || nb == 32 || nb == 64) && iters >= 1,
+             "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 / 32 / 64 = the two- / four- / eight-group kernel)");
   struct Restore {
     ~Restore() { ddk_set_slices_only(0); }
   } restore_;

@@ -68,7 +68,9 @@ __device__ __forceinline__ void dd_rows_rstd(const float* ssq_in, int ssq_n, int
 __device__ __forceinline__ int dd_part_index(int n, int m) { return (((n >> 2) * 8 + m) << 2) + (n & 3); }
 
 // grid = (8 / CH) * G workgroups of 512 threads; dynamic LDS = CH * min(SPW, CS) * NG KiB
-template <int TW, int NG, int U, int SPW, int CS, int CH = 1, int WF = 0>
+// EPI_TAG: the epilogue of the finishing kernel that follows (unused here: it only keeps the instantiations of the four
+// matrices apart, so that a kernel trace names each of them)
+template <int TW, int NG, int U, int SPW, int CS, int CH = 1, int WF = 0, int EPI_TAG = 0>
 __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
   constexpr int NCH = (SPW + CS - 1) / CS;             // LDS chunks per slice
   constexpr int PW = (CH * CS * NG + 7) / 8;           // operand pieces (1 KiB) per wave and chunk

@@ -862,17 +862,17 @@ void ddk_set_gemv_slices(int on) { g_gemv_slices = on; }
 void ddk_set_slices_only(int on) { g_slices_only = on; }
 #define SLICES_UNSUPPORTED 1
 
-template <int TW, int NG, int U, int SPW, int CS, int CH>
+template <int TW, int NG, int U, int SPW, int CS, int CH, int TAG>
 static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)CH * (SPW < CS ? SPW : CS) * NG * 1024;
   static bool attr = false;
   if (!attr) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
-  else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 template <int EPI, int TILES, int NG, int NP>
@@ -899,18 +899,18 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
     if (epi == EPI_QKV) {
       if (spw != 16) return SLICES_UNSUPPORTED;
       sa.G = (nt + 15) / 16;
-      RC_(launch_slices_k<1, 8, 8, 16, 16, 1>(sa, a.wf, st));
+      RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_QKV>(sa, a.wf, st));
       launch_finish<EPI_QKV, 1, 8, 8>(a, nt, st);
     } else if (epi == EPI_RESID) {
       sa.G = (nt + 7) / 8;
-      if (spw == 16) RC_(launch_slices_k<1, 8, 8, 16, 16, 1>(sa, a.wf, st));
-      else if (spw == 43) RC_(launch_slices_k<1, 8, 8, 43, 8, 1>(sa, a.wf, st));
-      else RC_(launch_slices_k<1, 8, 8, 56, 8, 1>(sa, a.wf, st));
+      if (spw == 16) RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+      else if (spw == 43) RC_(launch_slices_k<1, 8, 8, 43, 8, 1, EPI_RESID>(sa, a.wf, st));
+      else RC_(launch_slices_k<1, 8, 8, 56, 8, 1, EPI_RESID>(sa, a.wf, st));
       launch_finish<EPI_RESID, 1, 8, 8>(a, nt, st);
     } else {
       if (spw != 16) return SLICES_UNSUPPORTED;
       sa.G = (nt + 15) / 16;
-      RC_(launch_slices_k<1, 8, 8, 16, 16, 1>(sa, a.wf, st));
+      RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_SILU>(sa, a.wf, st));
       launch_finish<EPI_SILU, 2, 8, 8>(a, a.n_tiles, st);
     }
     return DD_OK;
@@ -918,7 +918,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
     if (spw != 16 || (nt & 1) || a.part_floats < need8) return SLICES_UNSUPPORTED;
     sa.n_groups = nt / 2;
     sa.G = sa.n_groups >= 256 ? (sa.n_groups + 15) / 16 : (sa.n_groups + 7) / 8;     // two tile pairs per wave when there are enough
-    RC_(launch_slices_k<2, NG, 8, 16, 16, 1>(sa, a.wf, st));
+    RC_(launch_slices_k<2, NG, 8, 16, 16, 1, EPI_QKV>(sa, a.wf, st));
     launch_finish<EPI_QKV, 1, NG, 8>(a, nt, st);
   } else if (epi == EPI_RESID) {
     // K = 4096 (o_proj): the wave-split kernel in one launch is as fast as slices + finish (13.5 vs 14.2 us at four planes,
@@ -926,15 +926,15 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
     if (a.part_floats < need8 || spw == 16) return SLICES_UNSUPPORTED;
     sa.n_groups = nt;
     sa.G = (nt + 7) / 8;                                             // one tile per wave
-    if (spw == 16) RC_(launch_slices_k<1, NG, 8, 16, 16, 1>(sa, a.wf, st));
-    else if (spw == 43) RC_(launch_slices_k<1, NG, 8, 43, 16, 1>(sa, a.wf, st));
-    else RC_(launch_slices_k<1, NG, 8, 56, 16, 1>(sa, a.wf, st));
+    if (spw == 16) RC_(launch_slices_k<1, NG, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+    else if (spw == 43) RC_(launch_slices_k<1, NG, 8, 43, 16, 1, EPI_RESID>(sa, a.wf, st));
+    else RC_(launch_slices_k<1, NG, 8, 56, 16, 1, EPI_RESID>(sa, a.wf, st));
     launch_finish<EPI_RESID, 1, NG, 8>(a, nt, st);
   } else {  // EPI_SILU: slice pairs, one workgroup per CU
     if (spw != 16 || a.part_floats < need4) return SLICES_UNSUPPORTED;
     sa.n_groups = nt;
     sa.G = 64;
-    RC_(launch_slices_k<1, NG, 8, 16, 16, 2>(sa, a.wf, st));
+    RC_(launch_slices_k<1, NG, 8, 16, 16, 2, EPI_SILU>(sa, a.wf, st));
     launch_finish<EPI_SILU, 2, NG, 4>(a, a.n_tiles, st);
   }
   return DD_OK;
@@ -1338,31 +1338,13 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
   DD_REQUIRE(G == 1 || G == 2 || G == 4, "attn: GQA group %d unsupported (1, 2, 4)", G);
   int rc = DD_OK;                    // a launcher that refuses (too many key tiles, attribute failure) launches nothing
   if (a.n_lanes > 0 && a.lane_groups) {
-    if (a.lane_groups == 8 && a.n_lanes == 8) {   // 64 rows: two passes of four sequences (each sequence reads its own cache either way)
-      for (int half = 0; half < 2; ++half) {
-        AttnDecodeArgs b = a;
-        b.lane_groups = b.n_lanes = 4;
-        b.max_T = 0;
-        for (int i = 0; i < 4; ++i) {
-          const int s_ = 4 * half + i;
-          b.knew_g[i] = a.knew_g[s_], b.vnew_g[i] = a.vnew_g[s_];
-          b.lane_kc[i] = a.lane_kc[s_], b.lane_vc[i] = a.lane_vc[s_], b.lane_state[i] = a.lane_state[s_], b.lane_bits[i] = a.lane_bits[s_];
-          b.lane_span_start[i] = a.lane_span_start[s_], b.lane_span_len[i] = a.lane_span_len[s_];
-        }
-        b.max_T = a.max_T;
-        if (half) {
-          b.qbuf = a.qbuf + (size_t)32 * a.n_heads * HEAD_DIM;
-          b.xop_out = a.xop_out + (size_t)4 * (a.n_heads * HEAD_DIM / 32) * 64;
-        }
-        b.knew = b.knew_g[0], b.vnew = b.vnew_g[0];
-        int rc2 = ddk_attn_decode(b, st);
-        if (rc2 != DD_OK) return rc2;
-      }
-      return DD_OK;
-    }
-    DD_REQUIRE((a.lane_groups == 2 || a.lane_groups == 4) && a.n_lanes == a.lane_groups && a.nb >= 1 && a.nb <= 8,
+    DD_REQUIRE((a.lane_groups == 2 || a.lane_groups == 4 || a.lane_groups == 8) && a.n_lanes == a.lane_groups && a.nb >= 1 && a.nb <= 8,
                "attn: a multi-group pass takes 2, 4 or 8 sequences of up to 8 members");
-    if (a.lane_groups == 2) {
+    if (a.lane_groups == 8) {
+      if (G == 1) rc = launch_attn_groups<1, 8>(a, st);
+      else if (G == 2) rc = launch_attn_groups<2, 8>(a, st);
+      else rc = launch_attn_groups<4, 8>(a, st);
+    } else if (a.lane_groups == 2) {
       if (G == 1) rc = launch_attn_groups<1, 2>(a, st);
       else if (G == 2) rc = launch_attn_groups<2, 2>(a, st);
       else rc = launch_attn_groups<4, 2>(a, st);
@@ -1719,7 +1701,7 @@ static int launch_gemm(int epi, const GemmArgs& a_, hipStream_t st) {
   GemmArgs a = a_;
   const int gx = (a.n_tiles + 2 * NJ - 1) / (2 * NJ);
   a.grid_y = (a.M + 32 * MI - 1) / (32 * MI);
-  a.xcd_order = g_gemm_xcd_order;
+  a.xcd_order = g_gemm_xcd_order && a.grid_y <= 8;   // many row blocks: the column-major runs thrash the L2 with activations (measured: 150 vs 125 ms at 2960 rows)
   dim3 grid(gx * a.grid_y);
   switch (epi) {
 #define GM(E_)                                                          \
@@ -1742,7 +1724,7 @@ static int launch_gemm_big(int epi, const GemmArgs& a_, hipStream_t st) {
   GemmArgs a = a_;
   const int gx = (a.n_tiles + GB_NT - 1) / GB_NT;
   a.grid_y = (a.M + 16 * GB_MT - 1) / (16 * GB_MT);
-  a.xcd_order = g_gemm_xcd_order;
+  a.xcd_order = g_gemm_xcd_order && a.grid_y <= 8;   // many row blocks: the column-major runs thrash the L2 with activations (measured: 150 vs 125 ms at 2960 rows)
   const size_t lds = (size_t)3 * GB_STAGE * 64 * sizeof(u32x4_t);   // 144 KiB
   dim3 grid(gx * a.grid_y);
 #define GBK(E_, W_)                                                                                                          \
