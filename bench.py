@@ -308,9 +308,16 @@ def main() -> int:
         m2, b2 = eng.time_gemv(which, dom_rows, 96)
         kinds[name] = round(b2 / (m2 * 1e-3) / 1e9, 1)
     kinds["gate_up_incl_finish"] = round(by / (ms_pair * 1e-3) / 1e9, 1)
+    rows_cmp = None
     if wide:
         m8, b8 = eng.time_gemv(2, rows8, 96)
         kinds["gate_up_8_rows"] = round(b8 / (m8 * 1e-3) / 1e9, 1)
+        # the same matrix at the other pass widths (streaming kernel alone): a wider pass streams the same weight bytes for more
+        # rows, so its algorithmic GB/s per launch is lower while the time per row falls
+        rows_cmp = {}
+        for r_ in (16, 32, 64):
+            mr = eng.time_gemv(2 + 8, r_, 96)[0]
+            rows_cmp[str(r_)] = {"us": round(mr * 1e3, 2), "frac": round(by / (mr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_8_rows": round(mr * 1e3 * 8 / r_, 2)}
 
     # HBM traffic / MFMA busy of the dominant kernel: NOT measured in this run (bench.py cannot collect PMCs) — read from the
     # committed profile of this round (separate rocprofv3 --pmc passes, FETCH_SIZE x2 for gfx950), matched by kernel name;
@@ -366,6 +373,11 @@ def main() -> int:
                          "traffic_source": {"source": "committed profile", "measured_in_this_run": False, "file": prof["pmc"],
                                             "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, FETCH_SIZE x2 (gfx950)"},
                          "mfma_util": mfma_util,     # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), same PMC summary
+                         "rows_per_launch": dom_rows,
+                         # frac counts the ALGORITHMIC bytes (the weights); the kernel also writes its K-slice partial sums (the
+                         # 8 slices x 64 rows x 22016 columns a finishing kernel adds up): HBM bytes actually moved / duration
+                         "traffic_frac": (round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                         "gate_up_streaming_kernel_by_rows": rows_cmp,
                          "bytes_per_launch": by, "ms_per_launch": round(ms, 5),
                          "kernel_stats_avg_us": stats_avg_us, "kernel_stats_file": prof["stats"],
                          "gemv_incl_finish": {"ms": round(ms_pair, 5), "GBs": round(by / (ms_pair * 1e-3) / 1e9, 1),

@@ -857,6 +857,7 @@ static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
 // families have (K = 4096: 16 k-steps per slice; K = 11008 / 14336: 43 / 56, staged in chunks of 16).  Anything else runs
 // through k_gemv_groups; both produce the same bits.
 static int g_gemv_slices = 1;     // dd_set_tuning key 13
+int g_exp_G[4] = {0, 0, 0, 0};   // dd_set_tuning keys 17..19: workgroups per slice of the 64-row kernels (qkv, o, gate/up); 0 = default
 static int g_slices_only = 0;     // dd_lm_time_gemv: launch the streaming kernel without its finishing kernel (timing only)
 void ddk_set_gemv_slices(int on) { g_gemv_slices = on; }
 void ddk_set_slices_only(int on) { g_slices_only = on; }
@@ -898,18 +899,21 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
     sa.n_groups = nt;
     if (epi == EPI_QKV) {
       if (spw != 16) return SLICES_UNSUPPORTED;
-      sa.G = (nt + 15) / 16;
+      // workgroups per slice: one round of 8 * G <= 256 workgroups (one per CU: 128 KiB of operands each) measured best inside
+      // the sweep (32 lanes: 32.6 -> 31.6 ms per group step for the three choices together)
+      sa.G = g_exp_G[0] ? g_exp_G[0] : (nt + 31) / 32;
       RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_QKV>(sa, a.wf, st));
       launch_finish<EPI_QKV, 1, 8, 8>(a, nt, st);
     } else if (epi == EPI_RESID) {
       sa.G = (nt + 7) / 8;
+      if (spw == 16) sa.G = g_exp_G[1] ? g_exp_G[1] : (nt + 15) / 16;
       if (spw == 16) RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
       else if (spw == 43) RC_(launch_slices_k<1, 8, 8, 43, 8, 1, EPI_RESID>(sa, a.wf, st));
       else RC_(launch_slices_k<1, 8, 8, 56, 8, 1, EPI_RESID>(sa, a.wf, st));
       launch_finish<EPI_RESID, 1, 8, 8>(a, nt, st);
     } else {
       if (spw != 16) return SLICES_UNSUPPORTED;
-      sa.G = (nt + 15) / 16;
+      sa.G = g_exp_G[2] ? g_exp_G[2] : (nt + 42) / 43;
       RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_SILU>(sa, a.wf, st));
       launch_finish<EPI_SILU, 2, 8, 8>(a, a.n_tiles, st);
     }

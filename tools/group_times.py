@@ -11,6 +11,9 @@ KV = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 from dropoutdecoding_amd import _lib
 if len(sys.argv) > 3:
     _lib.load().dd_set_tuning(9, int(sys.argv[3]))        # sequences per member sweep (1, 2, 4, 8)
+for kv in sys.argv[4:]:                                   # further tuning keys: key=value
+    k_, v_ = kv.split("=")
+    _lib.load().dd_set_tuning(int(k_), int(v_))
 engs = []
 for i in range(B):
     engs.append(lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format=KV,
