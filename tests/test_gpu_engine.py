@@ -832,3 +832,45 @@ def test_group_step_side_paths(E, kw, K):
         np.testing.assert_array_equal(e.logits(), finals[i])
     for e in reversed(engines):
         e.close()
+
+
+@pytest.mark.parametrize("dims,T0", [((512, 256, 512, 2, 2, 2), 1100),          # 16-tile matrices: part of one 32-tile column block
+                                     ((2048, 1024, 2816, 2, 8, 4), 1300)])      # several column blocks, K = 2816 (88 k-steps), GQA 2
+def test_prefill_gemm_block_shapes_and_orders_give_the_same_bits(E, dims, T0):
+    """The prefill GEMM has three forms — 128 x 128 blocks in row-major block order, the same in the XCD-aware order, and the
+    128 x 512 LDS-staged block used from 1024 rows on (k_gemm_big) — that issue the same MFMA sequence per accumulator tile:
+    image logits, last-row logits, the KV cache and the following ensemble steps must be bit-identical, and agree with the oracle."""
+    from dropoutdecoding_amd import _lib
+    lib = _lib.load()
+    V, d, dff, nl, H, Hkv = dims
+    rc = RefCfg(V, d, dff, nl, H, Hkv, 128, 1e-5, 10000.0)
+    w = random_weights(rc, 77, 0.05)
+    cfg = E.LMConfig(V, d, dff, nl, H, Hkv, 128, 1e-5, 10000.0)
+    L, s0 = 96, 3
+    probs = [0.3, 0.5, 0.7]
+    x = torch.randn(T0, d, generator=torch.Generator().manual_seed(5)) * 0.8
+    e = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=T0 + 64, max_visual=L, seed=3)
+    e.load_state_dict(w)
+    outs = []
+    try:
+        for order, big in ((0, 0), (1, 0), (0, 1024), (1, 1024), (1, 128)):
+            lib.dd_set_tuning(15, order)
+            lib.dd_set_tuning(16, big)
+            e.rng.manual_seed(3)
+            e.prefill(x.cuda(), s0, L)
+            rec = [e.image_logits().copy(), e.logits().copy(), e.kv_sums().copy()]
+            for _ in range(2):
+                e.decode_step(probs)
+                rec.append(e.logits().copy())
+            rec.append(np.asarray(e.tokens()))
+            outs.append(rec)
+    finally:
+        lib.dd_set_tuning(15, 1)
+        lib.dd_set_tuning(16, 1024)
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            np.testing.assert_array_equal(a, b)
+    ref = RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=3)
+    assert ref.generate(x, s0, L, 3) == outs[0][-1].tolist()
+    assert close(outs[0][-2], ref.records[-1].logits)
+    e.close()
