@@ -8,6 +8,7 @@ LlavaMultiModalProjector) into the library; `tower(pixel_values)` returns the pr
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -34,6 +35,7 @@ class ClipTowerHIP:
         c = _lib.VitConfigC(image_size, patch_size, hidden, intermediate, run_layers, heads, proj_dim,
                             {"quick_gelu": 0, "gelu": 1}[act], ln_eps, flags)
         self._h = C.c_void_p()
+        self._use_lock, self._last_use = threading.Lock(), None
         _lib.check(self.lib.dd_vit_create(C.byref(c), C.byref(self._h)), "dd_vit_create")
 
     def _load(self, tid: int, layer: int, t: torch.Tensor) -> None:
@@ -120,7 +122,13 @@ class ClipTowerHIP:
         if tuple(px.shape[1:]) != (3, self.image_size, self.image_size):
             raise ValueError(f"expected [n, 3, {self.image_size}, {self.image_size}], got {tuple(px.shape)}")
         out = torch.empty(n, self.n_out, self.proj_dim or self.hidden, dtype=torch.float32, device=px.device)
-        _lib.check(self.lib.dd_vit_forward(self._h, px.data_ptr(), n, out.data_ptr(), _stream()), "dd_vit_forward")
+        with self._use_lock:          # one scratch per tower: calls from several streams / host threads run one after the other
+            cur = torch.cuda.current_stream(px.device)
+            if self._last_use is not None:
+                cur.wait_event(self._last_use)
+            _lib.check(self.lib.dd_vit_forward(self._h, px.data_ptr(), n, out.data_ptr(), _stream()), "dd_vit_forward")
+            self._last_use = torch.cuda.Event()
+            self._last_use.record(cur)
         return out
 
     def close(self) -> None:
@@ -158,6 +166,7 @@ class QFormerHIP:
         c = _lib.QFormerConfigC(hidden, heads, layers, intermediate, encoder_hidden, cross_freq, n_query, vocab, max_pos, proj_dim,
                                 self.max_text_tokens, max_encoder_tokens, ln_eps)
         self._h = C.c_void_p()
+        self._use_lock, self._last_use = threading.Lock(), None
         _lib.check(self.lib.dd_qformer_create(C.byref(c), C.byref(self._h)), "dd_qformer_create")
 
     def _load(self, tid: int, layer: int, t: torch.Tensor) -> None:
@@ -218,8 +227,14 @@ class QFormerHIP:
         ids = None if n == 0 else text_ids.reshape(-1).to(enc.device, torch.int32).contiguous()
         out = torch.empty(self.n_query, self.proj_dim, dtype=torch.float32, device=enc.device)
         hid = torch.empty(self.n_query + n, self.hidden, dtype=torch.float32, device=enc.device) if return_hidden else None
-        _lib.check(self.lib.dd_qformer_forward(self._h, None if ids is None else ids.data_ptr(), n, enc.data_ptr(), enc.shape[0],
-                                               out.data_ptr(), None if hid is None else hid.data_ptr(), _stream()), "dd_qformer_forward")
+        with self._use_lock:          # one scratch per handle (see ClipTowerHIP.__call__)
+            cur = torch.cuda.current_stream(enc.device)
+            if self._last_use is not None:
+                cur.wait_event(self._last_use)
+            _lib.check(self.lib.dd_qformer_forward(self._h, None if ids is None else ids.data_ptr(), n, enc.data_ptr(), enc.shape[0],
+                                                   out.data_ptr(), None if hid is None else hid.data_ptr(), _stream()), "dd_qformer_forward")
+            self._last_use = torch.cuda.Event()
+            self._last_use.record(cur)
         return (out, hid) if return_hidden else out
 
     def close(self) -> None:
