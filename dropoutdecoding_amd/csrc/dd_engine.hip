@@ -97,6 +97,11 @@ struct dd_lm {
   // prefill scratch
   float *px, *pq, *image_logits;
   uint16_t *p1_hi, *p1_lo, *p2_hi, *p2_lo;
+  // scratch of dd_lm_prefill_group (weight owner only): n * seq_rows rows of residual, q, and the two operand plane pairs
+  SeqTab* seq_tab = nullptr;    // device table of a dd_lm_prefill_group call led by this handle
+  size_t pb_rows = 0;
+  float *pb_x = nullptr, *pb_q = nullptr;
+  uint16_t *pb1_hi = nullptr, *pb1_lo = nullptr, *pb2_hi = nullptr, *pb2_lo = nullptr;
   int32_t* row_index;
   float *epi, *alea, *var, *scalars, *topk_vals, *kl_ws;
   int32_t* topk_ids;
@@ -308,6 +313,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(ws, h->unc_ws_bytes);
   h->unc_ws = ws;
   DA(h->kv_sums, (size_t)h->Lyr * 2);
+  DA(h->seq_tab, 1);
   // RoPE table: inv_freq exactly as HF computes it (fp32 pow and reciprocal), cos/sin on the device
   std::vector<float> inv(64);
   for (int i = 0; i < 64; ++i) inv[i] = 1.0f / powf(c->rope_theta, (float)(2 * i) / 128.0f);
@@ -741,6 +747,7 @@ static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* l
   return ddk_gemm(EPI_STORE, g, st);
 }
 
+static int prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, int span_len, hipStream_t st);
 extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_start, int span_len, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && embeds, "dd_lm_prefill: null argument");
@@ -749,14 +756,21 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   DD_REQUIRE(span_len >= 1 && span_len <= h->Lmax && span_start >= 0 && span_start + span_len <= T0,
              "dd_lm_prefill: visual span [%d, %d) does not fit the %d input positions (max_visual %d)", span_start,
              span_start + span_len, T0, h->Lmax);
-  const int d = h->d, L = span_len;
+  const int d = h->d;
   DD_HIP(hipMemcpyAsync(h->px, embeds, (size_t)T0 * d * 4, hipMemcpyDeviceToDevice, st));
   RC(prefill_layers(h, T0, nullptr, 0, span_start, span_len, st));
+  return prefill_tail(h, h->px, T0, span_start, span_len, st);
+}
+
+// What follows the layers of a prefill: lm_head over the visual span + the last position, scorer, first token, state.
+// x_rows: the sequence's final residual rows [T0][d] (h->px, or its slice of a batch's rows).
+static int prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, int span_len, hipStream_t st) {
+  const int d = h->d, L = span_len;
   // lm_head over the visual span + the last position only (the reference projects all T0 positions,
   // llava.py:294-305, but consumes just these: llava.py:311-314 and HF's greedy argmax)
   k_prefill_rows<<<(L + 1 + 255) / 256, 256, 0, st>>>(h->row_index, span_start, L, T0);   // no host data: prefill stays asynchronous
   DD_CHECK_LAUNCH();
-  RC(prefill_head(h, h->row_index, L + 1, h->image_logits, st));
+  RC(prefill_head(h, h->row_index, L + 1, h->image_logits, st, x_rows));
   DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq + (size_t)L * d, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
   RC(dd_vision_uncertainty(h->image_logits, L, h->V, h->Vpad, h->var, h->epi, h->alea, h->scalars, h->cfg.k_top,
                            h->topk_vals, h->topk_ids, h->unc_ws, h->unc_ws_bytes, st));
@@ -770,6 +784,103 @@ extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_sta
   h->T_host = T0, h->span_start = span_start, h->L = L, h->n_tok_host = 1, h->prefilled = true, h->have_leak = false;
   h->last_K = 0;
   h->steps_since_prefill = 0;
+  return DD_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// Prefill of several sequences at once (lanes over one set of weights): their prompts are laid back to back — every
+// sequence padded to a whole number of 128-row blocks — and run through the layers as ONE matrix of n * seq_rows rows, so
+// the GEMMs stream each weight matrix once per batch instead of once per sequence and fill the chip with row blocks
+// (608 rows alone are five blocks: 0.81 PFLOP/s; thousands of rows: 1.05).  Rows are independent in every kernel of
+// the prefill except the attention, which runs per sequence as before; each accumulator tile sees the MFMA sequence of
+// the one-sequence prefill, so every sequence's logits, scores, first token and cache are bit-identical to
+// dd_lm_prefill on it alone.  fp8 weights, different cache capacities or a batch too small for the large blocks fall
+// back to one dd_lm_prefill per sequence.
+// -----------------------------------------------------------------------------------------------
+extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* const* embeds, const int32_t* T0s,
+                                   const int32_t* span_starts, const int32_t* span_lens, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(lanes && embeds && T0s && span_starts && span_lens && n >= 1 && n <= 32, "dd_lm_prefill_group: bad arguments (1..32 sequences)");
+  dd_lm* h0 = lanes[0];
+  DD_REQUIRE(h0, "dd_lm_prefill_group: null handle");
+  dd_lm* owner = h0->wsrc ? h0->wsrc : h0;
+  bool batched = !h0->fp8 && n > 1;
+  int maxT = 0;
+  for (int i = 0; i < n; ++i) {
+    dd_lm* q = lanes[i];
+    DD_REQUIRE(q && embeds[i], "dd_lm_prefill_group: null argument (sequence %d)", i);
+    DD_REQUIRE((q->wsrc ? q->wsrc : q) == owner, "dd_lm_prefill_group: sequence %d does not share the group's weights", i);
+    for (int j = 0; j < i; ++j) DD_REQUIRE(lanes[j] != q, "dd_lm_prefill_group: sequence listed twice");
+    DD_REQUIRE(T0s[i] >= 1 && T0s[i] < q->T_cap, "dd_lm_prefill_group: sequence %d: T0=%d out of range (KV capacity %d)", i, T0s[i], q->T_cap);
+    DD_REQUIRE(span_lens[i] >= 1 && span_lens[i] <= q->Lmax && span_starts[i] >= 0 && span_starts[i] + span_lens[i] <= T0s[i],
+               "dd_lm_prefill_group: sequence %d: visual span [%d, %d) does not fit the %d input positions (max_visual %d)", i,
+               span_starts[i], span_starts[i] + span_lens[i], T0s[i], q->Lmax);
+    batched = batched && q->T_cap == h0->T_cap && q->kv16 == h0->kv16 && q->lsk == h0->lsk && q->lsv == h0->lsv;
+    if (T0s[i] > maxT) maxT = T0s[i];
+  }
+  const int seq_rows = (maxT + 127) / 128 * 128;
+  const size_t M = (size_t)n * seq_rows;
+  if (!batched || M < 1024) {
+    for (int i = 0; i < n; ++i) RC(dd_lm_prefill(lanes[i], embeds[i], T0s[i], span_starts[i], span_lens[i], stream_));
+    return DD_OK;
+  }
+  // batch scratch, owned by the weight owner, grown on demand (the old blocks are released with the handle)
+  const int d = h0->d, dff = h0->dff;
+  if (owner->pb_rows < M) {
+    DD_HIP(hipDeviceSynchronize());                        // nobody may still be using the smaller scratch
+    const size_t w1 = (size_t)(d > h0->q_dim ? d : h0->q_dim);
+    if (dalloc(owner, &owner->pb_x, M * d) != DD_OK || dalloc(owner, &owner->pb_q, M * h0->q_dim) != DD_OK ||
+        dalloc(owner, &owner->pb1_hi, M * w1) != DD_OK || dalloc(owner, &owner->pb1_lo, M * w1) != DD_OK ||
+        dalloc(owner, &owner->pb2_hi, M * dff) != DD_OK || dalloc(owner, &owner->pb2_lo, M * dff) != DD_OK) {
+      owner->pb_rows = 0;
+      return DD_ENOMEM;
+    }
+    owner->pb_rows = M;
+  }
+  float *bx = owner->pb_x, *bq = owner->pb_q;
+  uint16_t *b1h = owner->pb1_hi, *b1l = owner->pb1_lo, *b2h = owner->pb2_hi, *b2l = owner->pb2_lo;
+  {
+    SeqTab tab;                                             // per-sequence lengths and cache bases, read by the QKV epilogue
+    memset(&tab, 0, sizeof(tab));
+    for (int i = 0; i < n; ++i) tab.T[i] = T0s[i], tab.kc[i] = lanes[i]->kc, tab.vc[i] = lanes[i]->vc;
+    DD_HIP(hipMemcpyAsync(h0->seq_tab, &tab, sizeof(tab), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
+  }
+  DD_HIP(hipMemsetAsync(bx, 0, M * d * 4, st));            // padding rows: zeros (finite everywhere downstream, never stored)
+  for (int i = 0; i < n; ++i)
+    DD_HIP(hipMemcpyAsync(bx + (size_t)i * seq_rows * d, embeds[i], (size_t)T0s[i] * d * 4, hipMemcpyDeviceToDevice, st));
+  for (int l = 0; l < h0->Lyr; ++l) {
+    LayerW& w = h0->lw[l];
+    RC(ddk_rmsnorm_split(bx, (int)M, d, w.norm1, h0->cfg.rms_eps, b1h, b1l, nullptr, nullptr, st, h0->wf));
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.wf = h0->wf;
+    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_d, g.n_tiles = h0->qkv_tiles, g.W = w.wqkv;
+    g.qbuf = bq, g.T_cap = h0->T_cap, g.q_tiles = h0->q_tiles, g.k_tiles = h0->k_tiles, g.q_dim = h0->q_dim, g.kv_dim = h0->kv_dim;
+    g.pos0 = 0, g.kv16 = h0->kv16, g.rope_cos = h0->rope_cos, g.rope_sin = h0->rope_sin;
+    g.seq_rows = seq_rows, g.seq_tab = h0->seq_tab, g.seq_off_k = (size_t)l * h0->lsk, g.seq_off_v = (size_t)l * h0->lsv;
+    g.kc = lanes[0]->kc + g.seq_off_k, g.vc = lanes[0]->vc + g.seq_off_v;
+    RC(ddk_gemm(EPI_QKV, g, st));
+    for (int i = 0; i < n; ++i) {                          // causal attention of each sequence over its own cache
+      const size_t r0 = (size_t)i * seq_rows;
+      RC(ddk_attn_prefill(bq + r0 * h0->q_dim, lanes[i]->kc + g.seq_off_k, lanes[i]->vc + g.seq_off_v, T0s[i], h0->T_cap, h0->H, h0->Hkv, b1h + r0 * h0->q_dim,
+                          b1l + r0 * h0->q_dim, nullptr, 0, span_starts[i], span_lens[i], 0, st, nullptr, h0->kv16, h0->wf));
+    }
+    memset(&g, 0, sizeof(g));
+    g.wf = h0->wf;
+    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_q, g.n_tiles = d / 16, g.out = bx, g.ldo = d, g.W = w.wo;
+    RC(ddk_gemm(EPI_RESID, g, st));
+    RC(ddk_rmsnorm_split(bx, (int)M, d, w.norm2, h0->cfg.rms_eps, b1h, b1l, nullptr, nullptr, st, h0->wf));
+    memset(&g, 0, sizeof(g));
+    g.wf = h0->wf;
+    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_d, g.n_tiles = 2 * dff / 16, g.W = w.wgu;
+    g.o_hi = b2h, g.o_lo = b2l, g.ld_planes = dff;
+    RC(ddk_gemm(EPI_SILU, g, st));
+    memset(&g, 0, sizeof(g));
+    g.wf = h0->wf;
+    g.a_hi = b2h, g.a_lo = b2l, g.M = (int)M, g.S = h0->S_ff, g.n_tiles = d / 16, g.out = bx, g.ldo = d, g.W = w.wdown;
+    RC(ddk_gemm(EPI_RESID, g, st));
+  }
+  for (int i = 0; i < n; ++i) RC(prefill_tail(lanes[i], bx + (size_t)i * seq_rows * d, T0s[i], span_starts[i], span_lens[i], st));
   return DD_OK;
 }
 

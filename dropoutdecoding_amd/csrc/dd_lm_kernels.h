@@ -222,6 +222,18 @@ struct GemmArgs {
   int wf;                // 16-bit type of W, the A planes and the planes written by the epilogue (0 bf16, 1 fp16)
   const float* rope_cos;
   const float* rope_sin;
+  // EPI_QKV over the prompts of several sequences laid back to back (dd_lm_prefill_group): seq_rows > 0 = rows per sequence
+  // (a multiple of 128: a row block never straddles two sequences); row r belongs to sequence r / seq_rows, is its position
+  // pos0 + r % seq_rows, is live below its sequence's length and writes that sequence's cache.  The per-sequence table lives in
+  // device memory (arrays inside this by-value struct would be indexed per lane and end up in scratch)
+  int seq_rows;
+  const struct SeqTab* seq_tab;
+  size_t seq_off_k, seq_off_v;   // this layer's offset into every sequence's K / V cache (floats of the storage)
+};
+struct SeqTab {
+  int32_t T[32];
+  float* kc[32];
+  float* vc[32];
 };
 int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st);
 

@@ -1433,14 +1433,25 @@ template <int EPI, int MI, int NJ, int WF>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[MI][NJ], const int m_base, const int nt_base,
                                               const bool (&wv)[NJ], const int lane) {
   const int c = lane & 15;
+  // loop order row (i, reg) outside, column tile inside: what depends on the row only (its sequence, position, cache) is
+  // computed 16 times per wave, not once per element — the unrolled body of the 4 x 8-tile kernel has to stay within the
+  // compiler's unroll budget, or the accumulators are indexed dynamically and the whole array moves to scratch
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int nt = nt_base + j;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = m_base + i * 16 + 4 * (lane >> 4) + reg;
+      int lrow = row, live_rows = a.M;
+      float *kc_r = a.kc, *vc_r = a.vc;
+      if (EPI == EPI_QKV && a.seq_rows) {     // several sequences back to back: the row's own sequence, position, liveness and cache
+        const int sq = min(row / a.seq_rows, 31);
+        lrow = row - sq * a.seq_rows, live_rows = a.seq_tab->T[sq];
+        kc_r = a.seq_tab->kc[sq] + a.seq_off_k, vc_r = a.seq_tab->vc[sq] + a.seq_off_v;
+      }
+      const int pos_c = a.pos0 + max(0, min(lrow, live_rows - 1));   // EPI_QKV: clamped position (rotary table row)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = m_base + i * 16 + 4 * (lane >> 4) + reg;
+      for (int j = 0; j < NJ; ++j) {
+        const int nt = nt_base + j;
         const bool ok = row < a.M && wv[j];
         float y = acc[i][j][reg];
         if (a.wscale) y *= a.wscale[(size_t)(wv[j] ? nt : 0) * 16 + c];
@@ -1493,23 +1504,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
           }
         } else {  // EPI_QKV
           float yp = __shfl_xor(y, 8);  // partner column c ^ 8 of the same row
+          const bool okr = ok && lrow < live_rows;
           if (nt < a.q_tiles + a.k_tiles) {
             bool is_q = nt < a.q_tiles;
             int ht = is_q ? nt : nt - a.q_tiles;
             int head = ht >> 3, f = (ht & 7) * 8 + (c & 7);
-            int pos = a.pos0 + min(row, a.M - 1);
+            const int pos = pos_c;
             float cs = a.rope_cos[(size_t)pos * ROPE_HALF + f], sn = a.rope_sin[(size_t)pos * ROPE_HALF + f];
             float o = (c < 8) ? __fadd_rn(__fmul_rn(y, cs), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, cs), __fmul_rn(yp, sn));
             int idx = (c < 8) ? f : ROPE_HALF + f;
-            if (ok) {
+            if (okr) {
               if (is_q) a.qbuf[(size_t)row * a.q_dim + head * HEAD_DIM + idx] = o;
-              else dd_kv_store(a.kc, a.vc, a.kv16, head, idx, pos, a.T_cap, true, o);
+              else dd_kv_store(kc_r, vc_r, a.kv16, head, idx, pos, a.T_cap, true, o);
             }
-          } else if (ok) {
+          } else if (okr) {
             int col = (nt - a.q_tiles - a.k_tiles) * 16 + c;
             int kvh = col / HEAD_DIM, idx = col % HEAD_DIM;
-            int pos = a.pos0 + row;
-            dd_kv_store(a.kc, a.vc, a.kv16, kvh, idx, pos, a.T_cap, false, y);
+            int pos = a.pos0 + lrow;
+            dd_kv_store(kc_r, vc_r, a.kv16, kvh, idx, pos, a.T_cap, false, y);
           }
         }
       }

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import time
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Tuple, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -442,6 +442,38 @@ class DropoutEngine:
             self.close()
         except Exception:
             pass
+
+
+def prefill_group(engines: Sequence["DropoutEngine"], embeds: Sequence[torch.Tensor], spans: Sequence[Tuple[int, int]],
+                  stream: Optional[torch.cuda.Stream] = None) -> None:
+    """DropoutEngine.prefill for several sequences over one set of weights in ONE pass over the weights
+    (dd_lm_prefill_group): engines[i] receives embeds[i] with the visual span spans[i] = (start, length).  Each engine ends up
+    bit for bit as its own prefill() would leave it."""
+    if not (len(engines) == len(embeds) == len(spans)) or not 1 <= len(engines) <= 32:
+        raise ValueError("prefill_group: one embeds tensor and one span per engine, 1..32 of them")
+    e0 = engines[0]
+    pstream = stream if stream is not None else e0.torch_stream
+    pstream.wait_stream(torch.cuda.current_stream(e0.device))
+    es = []
+    for eng, x in zip(engines, embeds):
+        if not x.is_cuda:
+            raise ValueError("embeds must be on the GPU")
+        x = x.reshape(-1, x.shape[-1]).float().contiguous()
+        if x.shape[1] != eng.cfg.hidden_size:
+            raise ValueError(f"embeds have width {x.shape[1]}, model hidden size is {eng.cfg.hidden_size}")
+        x.record_stream(pstream)
+        es.append(x)
+    n = len(engines)
+    hs = (C.c_void_p * n)(*[e._h for e in engines])
+    ps = (C.c_void_p * n)(*[x.data_ptr() for x in es])
+    t0 = (C.c_int32 * n)(*[x.shape[0] for x in es])
+    s0 = (C.c_int32 * n)(*[int(s[0]) for s in spans])
+    sl = (C.c_int32 * n)(*[int(s[1]) for s in spans])
+    _lib.check(e0.lib.dd_lm_prefill_group(hs, n, ps, t0, s0, sl, pstream.cuda_stream), "dd_lm_prefill_group")
+    for eng, x, sp in zip(engines, es, spans):
+        eng.L, eng.T0 = int(sp[1]), x.shape[0]
+        eng._last_K = 0
+        eng._n_enqueued = 1
 
 
 class EngineGroup:

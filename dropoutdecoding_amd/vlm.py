@@ -107,8 +107,12 @@ class DropoutVLM:
         return merged, start
 
     # ---- the boundary -------------------------------------------------------------------------
-    def _prepare(self, input_ids, max_new_tokens, max_length, num_beams, eos_token_id, do_sample, inputs, stream=None):
-        """Everything of generate() up to and including the prefill; -> (input_ids on device, n_new, eos ids)."""
+    def _prepare(self, input_ids, max_new_tokens, max_length, num_beams, eos_token_id, do_sample, inputs, stream=None,
+                 defer_prefill: bool = False):
+        """Everything of generate() up to and including the prefill; -> (input_ids on device, n_new, eos ids).
+        defer_prefill: leave the LM prefill to the caller, who runs it for several lanes at once (`prefill_lanes`); what it needs
+        is kept in self._deferred = (embeds, span start, span length), None when this call prefilled by itself."""
+        self._deferred = None
         if input_ids is None or input_ids.shape[0] != 1:
             raise ValueError("Dropout Decoding runs batch size 1 with exactly one image per prompt "
                              "(reference models/llava.py:75-76)")
@@ -133,7 +137,10 @@ class DropoutVLM:
         self.start_image_pos, self.end_image_pos = [start], [start + L - 1]
         self.start_generation_pos = embeds.shape[0]
         self.masked_numbers = []
-        self.engine.prefill(embeds, start, L, first_step_ensemble=first, stream=stream)
+        if defer_prefill and not first:
+            self._deferred = (embeds, start, L)
+        else:
+            self.engine.prefill(embeds, start, L, first_step_ensemble=first, stream=stream)
         self._prefix = None
         if self.supports_prefix_reuse and not first:
             ids = input_ids[0]
@@ -255,6 +262,20 @@ def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens:
 
 
 @torch.no_grad()
+def prefill_lanes(models: List["DropoutVLM"], stream=None, chunk: int = 16) -> None:
+    """The deferred LM prefills of `models` (see _prepare(defer_prefill=True)), `chunk` sequences per pass over the weights
+    (dd_lm_prefill_group: the prompts run through the layers as one matrix; every lane ends up bit for bit as its own prefill
+    would leave it; 21 instead of 28 ms per 608-position prompt at LLaVA-1.5-7B shapes)."""
+    from .lm import prefill_group
+    todo = [m for m in models if getattr(m, "_deferred", None) is not None]
+    for i in range(0, len(todo), chunk):
+        part = todo[i:i + chunk]
+        prefill_group([m.engine for m in part], [m._deferred[0] for m in part], [(m._deferred[1], m._deferred[2]) for m in part],
+                      stream=stream)
+        for m in part:
+            m._deferred = None
+
+
 def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens: Optional[int] = None, eos_token_id=None,
                    num_beams: int = 1, do_sample: bool = False, pad_token_id: Optional[int] = None) -> List[torch.LongTensor]:
     """`generate()` for up to 32 images at once: models[i] (a wrapper and its spawn_lane() copies) decodes inputs[i].
@@ -272,7 +293,8 @@ def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens:
         ids = kw.pop("input_ids", None)
         mnt = kw.pop("max_new_tokens", max_new_tokens)
         prepared.append(m._prepare(ids, mnt, kw.pop("max_length", None), num_beams, kw.pop("eos_token_id", eos_token_id),
-                                   do_sample, kw))
+                                   do_sample, kw, defer_prefill=True))
+    prefill_lanes(models)
     n_new = {p[1] for p in prepared}
     eos = prepared[0][2]
     if len(n_new) != 1 or any(p[2] != eos for p in prepared):
@@ -318,10 +340,11 @@ class GroupPipeline:
         self.sets = _sets if _sets is not None else [[model] + [model.spawn_lane() for _ in range(lanes - 1)],
                                                      [model.spawn_lane() for _ in range(lanes)]]
         self.pre_stream = torch.cuda.Stream(device=model.device)
+        self.prefill_chunk = 16          # sequences per LM prefill pass (dd_lm_prefill_group); 1: one prefill per image
 
     def _stage(self, lanes, batch, kw):
         """-> per-image closures that each enqueue one image's front-end + prefill on the second stream"""
-        state = {"prepared": [], "todo": list(zip(lanes, batch)), "event": None, "lanes": lanes[:len(batch)]}
+        state = {"prepared": [], "todo": list(zip(lanes, batch)), "event": None, "lanes": lanes[:len(batch)], "staged": []}
 
         def unit() -> bool:
             if not state["todo"]:
@@ -332,7 +355,11 @@ class GroupPipeline:
             with torch.cuda.stream(self.pre_stream):
                 state["prepared"].append(m._prepare(inp.pop("input_ids", None), inp.pop("max_new_tokens", kw["max_new_tokens"]),
                                                     inp.pop("max_length", None), 1, inp.pop("eos_token_id", kw["eos_token_id"]),
-                                                    False, inp, stream=self.pre_stream))
+                                                    False, inp, stream=self.pre_stream, defer_prefill=True))
+                state["staged"].append(m)
+                if not state["todo"] or len(state["staged"]) >= self.prefill_chunk:
+                    prefill_lanes(state["staged"], stream=self.pre_stream, chunk=self.prefill_chunk)   # one pass over the weights
+                    state["staged"].clear()
                 if not state["todo"]:
                     state["event"] = torch.cuda.Event()
                     state["event"].record(self.pre_stream)

@@ -221,6 +221,14 @@ int dd_lm_load_synthetic(dd_lm* h, uint32_t seed, float std);
  * Replaces the prefill branch of forward() (models/llava.py:285-314).  Resets the sequence. */
 int dd_lm_prefill(dd_lm* h, const float* embeds_dev, int T0, int span_start, int span_len, void* stream);
 
+/* dd_lm_prefill for n (<= 32) sequences that share one set of weights (dd_lm_create_shared), in one pass over the weights:
+ * the prompts run through the layers as one matrix (rows of sequence i: embeds_dev[i], [T0[i]][d] fp32 on the device).
+ * Every sequence ends up exactly as dd_lm_prefill would leave it (bit-identical logits, scores, first token, cache).
+ * The reference has no counterpart (it prefills one image per process: models/llava.py:285-314); this is the prefill side
+ * of the throughput mode (dd_lm_group_step). */
+int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* const* embeds_dev, const int32_t* T0, const int32_t* span_start,
+                        const int32_t* span_len, void* stream);
+
 /* Prefix reuse (several prompts over one image, e.g. the 6 POPE questions per image, pope_test/pope_test.py:215-241).
  * dd_lm_truncate cuts the sequence back to its first T_keep positions (>= end of the visual span; the image-derived
  * uncertainty / top-k stay valid: attention is causal); dd_lm_prefill_extend appends n more prompt positions (fp32

@@ -874,3 +874,47 @@ def test_prefill_gemm_block_shapes_and_orders_give_the_same_bits(E, dims, T0):
     assert ref.generate(x, s0, L, 3) == outs[0][-1].tolist()
     assert close(outs[0][-2], ref.records[-1].logits)
     e.close()
+
+
+@pytest.mark.parametrize("family", [FAMILY_LLAVA, FAMILY_IBLIP])
+def test_prefill_group_equals_one_prefill_per_sequence(E, family):
+    """dd_lm_prefill_group: the prompts of several lanes through the layers as ONE matrix (each sequence padded to whole 128-row
+    blocks, the QKV epilogue writing each row to its own sequence's cache).  Every lane must end up bit for bit as its own
+    prefill() leaves it — image logits, scores, top-k ids, first token, KV cache — and decode the same tokens afterwards;
+    ragged lengths, spans at different offsets, a batch small enough to fall back to single prefills."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    shapes = [(300, 3, 200), (257, 0, 32), (384, 9, 200), (129, 1, 100), (290, 5, 64)]       # 5 x 384 rows = 1920 >= 1024: batched
+    if family == FAMILY_IBLIP:
+        shapes = [(T0, 0, min(L, 32)) for T0, _, L in shapes]
+    probs = [0.3, 0.5, 0.7]
+    w, engines, embs = _lane_setup(E, family, rc, shapes, max_seq=448)
+    embs = [x.cuda() for x in embs]
+    solo = []
+    for e, x, (T0, s0, L) in zip(engines, embs, shapes):
+        e.rng.manual_seed(7)
+        e.prefill(x, s0, L)
+        rec = [e.image_logits().copy(), e.logits().copy(), e.kv_sums().copy(), e.vision_uncert_dict()["epis_uncert_per_token"].copy(),
+               np.asarray(e.topk()[1]).copy()]
+        for _ in range(3):
+            e.decode_step(probs)
+        rec += [e.logits().copy(), np.asarray(e.tokens())]
+        solo.append(rec)
+    for sub in (slice(0, 5), slice(1, 3)):                   # 5 sequences: one batch; 2 short ones: 2 x 384 < 1024 rows -> fallback
+        ee, xx, ss = engines[sub], embs[sub], shapes[sub]
+        for e in ee:
+            e.rng.manual_seed(7)
+        E.prefill_group(ee, xx, [(s0, L) for _, s0, L in ss])
+        for e, want in zip(ee, solo[sub]):
+            got = [e.image_logits().copy(), e.logits().copy(), e.kv_sums().copy(), e.vision_uncert_dict()["epis_uncert_per_token"].copy(),
+                   np.asarray(e.topk()[1]).copy()]
+            for _ in range(3):
+                e.decode_step(probs)
+            got += [e.logits().copy(), np.asarray(e.tokens())]
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a, b)
+    with pytest.raises(Exception):
+        E.prefill_group(engines[:2], embs[:2], [(0, 10), (250, 200)])         # span does not fit
+    with pytest.raises(ValueError):
+        E.prefill_group(engines[:2], embs[:1], [(0, 10)])
+    for e in reversed(engines):
+        e.close()

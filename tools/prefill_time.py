@@ -34,3 +34,28 @@ for order, big in VARIANTS:
         ref = sig
     same = all(a == b for a, b in zip(sig, ref))
     print(f"T0 {T0} xcd_order {order} big_rows {big}: prefill {ms:.2f} ms   same bits as the first variant: {same}", flush=True)
+
+# several sequences at once (dd_lm_prefill_group) against one prefill per sequence
+if T0 <= 1024:
+    lib.dd_set_tuning(15, 1)
+    lib.dd_set_tuning(16, 1024)
+    for n in (8, 16):
+        lanes = [e] + [lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=T0 + 192, max_visual=L, kv_format="fp16",
+                                        share_weights_with=e) for _ in range(n - 1)]
+        xs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(i)).cuda() for i in range(n)]
+        for mode in ("one by one", "group"):
+            def go():
+                if mode == "group":
+                    lm.prefill_group(lanes, xs, [(5, L)] * n)
+                else:
+                    for q, x_ in zip(lanes, xs):
+                        q.prefill(x_, 5, L)
+            go()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                go()
+            torch.cuda.synchronize()
+            print(f"{n} sequences of {T0} rows, {mode}: {(time.perf_counter() - t0) / 3 / n * 1e3:.2f} ms per sequence", flush=True)
+        for q in lanes[1:]:
+            q.close()
