@@ -2159,56 +2159,39 @@ int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x,
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-// row m embeds the current token of sequence lanes.state[m] (null: a zero row).  ROWS = 8: fused base pass of a group;
-// ROWS = 16: member pass of two sequences (rows 0-7 / 8-15), second operand plane for rows 8..15.
-template <int ROWS>
-__global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __restrict__ embed, int d, EmbedLanes lanes,
+// row m embeds the current token of sequence lanes.state[m] (null: a zero row): one workgroup per row (the rows are
+// independent; a row's sum of squares is reduced exactly as the one-workgroup kernel did it — thread t over columns t,
+// t + 1024, ..., wave sums, the 16 waves in order — so its bits do not depend on how many rows a pass has).
+// planes: rows 8g..8g+7 go to operand plane g (rows > 8), or all to the 8-row operand (rows == 8)
+__global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __restrict__ embed, int d, EmbedLanes lanes, int rows,
                                                            float* __restrict__ x, const float* __restrict__ normw,
                                                            u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld, int wf) {
-  __shared__ float sh[ROWS][16];
-  int tok[ROWS];
-#pragma unroll
-  for (int m = 0; m < ROWS; ++m) tok[m] = lanes.state[m] ? lanes.state[m]->cur_tok : -1;
-  float ss[ROWS];
-#pragma unroll
-  for (int m = 0; m < ROWS; ++m) ss[m] = 0.f;
+  __shared__ float sh[16];
+  const int m = blockIdx.x;
+  const DDState* sp = lanes.state[m];
+  const int tok = sp ? sp->cur_tok : -1;
+  float ss = 0.f;
   for (int i = threadIdx.x; i < d; i += 1024) {
     float w = normw[i];
-#pragma unroll
-    for (int m = 0; m < ROWS; ++m) {
-      float e = tok[m] >= 0 ? dd_w16_to_f32(embed[(size_t)tok[m] * d + i], wf) : 0.f;
-      ss[m] += e * e;
-      x[(size_t)m * d + i] = e;
-      if (ROWS > 8) xop_store16(xop, i, m, w * e, d >> 5, wf);
-      else xop_store(xop, i, m, w * e, wf);
-    }
+    float e = tok >= 0 ? dd_w16_to_f32(embed[(size_t)tok * d + i], wf) : 0.f;
+    ss += e * e;
+    x[(size_t)m * d + i] = e;
+    if (rows > 8) xop_store16(xop, i, m, w * e, d >> 5, wf);
+    else xop_store(xop, i, m, w * e, wf);
   }
-#pragma unroll
-  for (int m = 0; m < ROWS; ++m) {
-    float v = dd_wave_sum(ss[m]);
-    if ((threadIdx.x & 63) == 0) sh[m][threadIdx.x >> 6] = v;
-  }
+  float v = dd_wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x < ROWS) {
-    float v = 0.f;
-    for (int i = 0; i < 16; ++i) v += sh[threadIdx.x][i];
-    ssq[(size_t)threadIdx.x * ssq_ld] = v;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    ssq[(size_t)m * ssq_ld] = t;
   }
 }
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
                          u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf) {
-  if (rows == 64) {   // rows 0..31 and 32..63: planes 0-3 / 4-7 of the operand
-    EmbedLanes l2;
-    memset(&l2, 0, sizeof(l2));
-    for (int m = 0; m < 32; ++m) l2.state[m] = lanes.state[32 + m];
-    EmbedLanes l1 = lanes;
-    for (int m = 32; m < 64; ++m) l1.state[m] = nullptr;
-    k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, l1, x, normw, xop, ssq, ssq_ld, wf);
-    k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, l2, x + (size_t)32 * d, normw, xop + (size_t)4 * (d >> 5) * 64, ssq + (size_t)32 * ssq_ld,
-                                                ssq_ld, wf);
-  } else if (rows == 32) k_embed_rows_lanes<32><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
-  else if (rows == 16) k_embed_rows_lanes<16><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
-  else k_embed_rows_lanes<8><<<1, 1024, 0, st>>>(embed, d, lanes, x, normw, xop, ssq, ssq_ld, wf);
+  DD_REQUIRE(rows == 8 || rows == 16 || rows == 32 || rows == 64, "embed_rows_lanes: %d rows (8, 16, 32 or 64)", rows);
+  k_embed_rows_lanes<<<rows, 1024, 0, st>>>(embed, d, lanes, rows, x, normw, xop, ssq, ssq_ld, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
