@@ -36,6 +36,11 @@ struct SliceArgs {
   int ssq_n, ssq_ld;
   float inv_k, eps;
   float* rstd_out;      // [8 * NG]
+  // halves == 2: the launch covers 2 * NG planes as two half passes of NG planes each over the SAME weight tiles: workgroup
+  // ids b and b + 8 (same XCD under round-robin dispatch, scheduled back to back) run the two halves of one (slice, group), so
+  // the second reads the tiles from that XCD's L2 — HBM sees the weights once, each CU carries NG planes of MFMA / LDS work.
+  // Partial sums are laid out for 2 * NG planes (plane = half * NG + h).  grid = 2 * (8 / CH) * G, a multiple of 16.
+  int halves;
 };
 
 // rstd(row) = 1 / sqrt(mean(x^2) + eps) from per-workgroup partial sums of squares; wave w of the calling workgroup
@@ -79,11 +84,19 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
   extern __shared__ __align__(16) u32x4_t xs[];        // [CH][CS][NG][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NQ = 8 / CH;                           // slice sets
-  const int qs = blockIdx.x % NQ, j = blockIdx.x / NQ;
+  int bid = blockIdx.x, half = 0;
+  if (a.halves == 2) {
+    half = (bid >> 3) & 1;
+    bid = ((bid >> 4) << 3) | (bid & 7);
+  }
+  const int qs = bid % NQ, j = bid / NQ;
   const int q = qs * CH;                               // first slice of this workgroup
   const size_t xplane = (size_t)a.S * 64;
+  const u32x4_t* const xop = a.xop + (size_t)half * NG * xplane;
+  const int ng_all = a.halves == 2 ? 2 * NG : NG, plane0 = half * NG;
   const int n_tiles = a.n_groups * TW;
-  if (blockIdx.x == 0 && a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+  if (a.ssq_in && (blockIdx.x == 0 || (a.halves == 2 && blockIdx.x == 8)))   // the first workgroup of each half: its rows' rstd
+    dd_rows_rstd<NG>(a.ssq_in + (size_t)half * 8 * NG * a.ssq_ld, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out + half * 8 * NG);
 
   u32x4_t xv[PW];
   auto stage_issue = [&](int c0, int n) {              // chunk = slice steps c0 .. c0+n-1: piece p = (slice, step, plane)
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
       int p = wave + 8 * i;
       int pc = p < CH * n * NG ? p : 0;
       int ch = pc / (n * NG), r = pc % (n * NG);
-      xv[i] = a.xop[(size_t)(q + ch + 8 * (c0 + r / NG)) * 64 + (r % NG) * xplane + lane];
+      xv[i] = xop[(size_t)(q + ch + 8 * (c0 + r / NG)) * 64 + (r % NG) * xplane + lane];
     }
   };
   auto stage_commit = [&](int n) {
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
       for (int h = 0; h < NG; ++h)
         if ((lane & 8) == 0) {
           const int l32 = (lane >> 4) * 8 + (lane & 7);
-          *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + (size_t)g * TW + t) * NG + h) << 7) + l32 * 4] = sum[t][h];
+          *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + (size_t)g * TW + t) * ng_all + plane0 + h) << 7) + l32 * 4] = sum[t][h];
         }
   };
   auto mfma = [](u32x4_t w, u32x4_t b, f32x4_t c) -> f32x4_t { return dd_mfma16<WF>(w, b, c); };

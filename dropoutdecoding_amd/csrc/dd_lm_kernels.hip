@@ -872,8 +872,9 @@ static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
-  else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  const int grid = (sa.halves == 2 ? 2 : 1) * (8 / CH) * sa.G;
+  if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 template <int EPI, int TILES, int NG, int NP>
@@ -887,7 +888,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
   const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;      // 16-row weight tiles
   if (epi == EPI_STORE || !(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
   SliceArgs sa;
-  sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S;
+  sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
   sa.rstd_out = a.part + a.part_floats;                              // 32 floats behind the partial sums
   const size_t need8 = (size_t)8 * nt * NG * 128, need4 = need8 / 2;
@@ -906,8 +907,17 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
       launch_finish<EPI_QKV, 1, 8, 8>(a, nt, st);
     } else if (epi == EPI_RESID) {
       sa.G = (nt + 7) / 8;
-      if (spw == 16) sa.G = g_exp_G[1] ? g_exp_G[1] : (nt + 15) / 16;
-      if (spw == 16) RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+      if (spw == 16 && g_exp_G[1] < 0) {                       // tuning key 18 < 0: the eight-plane kernel (A/B)
+        sa.G = (nt + 15) / 16;
+        RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+      } else if (spw == 16) {
+        // o_proj (33 MB): two half passes of four planes over the same tiles, paired on one XCD so that the second reads the
+        // tiles from L2 (dd_gemv_slices.h `halves`): 10.4 vs 13.5 us for the eight-plane kernel (the wide matrices lose with it)
+        sa.G = g_exp_G[1] ? g_exp_G[1] : (nt + 15) / 16;
+        sa.halves = 2;
+        RC_(launch_slices_k<1, 4, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+        sa.halves = 1;
+      }
       else if (spw == 43) RC_(launch_slices_k<1, 8, 8, 43, 8, 1, EPI_RESID>(sa, a.wf, st));
       else RC_(launch_slices_k<1, 8, 8, 56, 8, 1, EPI_RESID>(sa, a.wf, st));
       launch_finish<EPI_RESID, 1, 8, 8>(a, nt, st);

@@ -254,21 +254,22 @@ static void run_e(const Shape& sh, int NSL, int G, const u32x4_t* W, size_t wstr
          WAVES, XSRC, NSL, G, NSL * G, smem >> 10, (double)n_groups / (G * WAVES), us, bytes / us * 1e-6);
 }
 
-template <int TW, int NG, int U, int SPW, int CS>
-static void run_s(const Shape& sh, int G, const u32x4_t* W, size_t wstride, int NL, const u32x4_t* X, float* out, hipStream_t st) {
-  size_t smem = (size_t)(CS < SPW ? CS : SPW) * NG * 1024;
-  CK(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+template <int TW, int NG, int U, int SPW, int CS, int CH = 1>
+static void run_s(const Shape& sh, int G, const u32x4_t* W, size_t wstride, int NL, const u32x4_t* X, float* out, hipStream_t st, int halves = 1) {
+  size_t smem = (size_t)CH * (CS < SPW ? CS : SPW) * NG * 1024;
+  CK(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   SliceArgs a;
   memset(&a, 0, sizeof(a));
-  a.xop = X, a.part = out, a.S = sh.S, a.n_groups = sh.n_tiles / TW, a.G = G;
+  a.xop = X, a.part = out, a.S = sh.S, a.n_groups = sh.n_tiles / TW, a.G = G, a.halves = halves;
+  const int grid = halves * (8 / CH) * G;
   float us = time_it(st, 64, [&](int i) {
     SliceArgs b = a;
     b.W = W + (size_t)(i % NL) * wstride;
-    k_gemv_slices<TW, NG, U, SPW, CS><<<8 * G, 512, smem, st>>>(b);
+    k_gemv_slices<TW, NG, U, SPW, CS, CH><<<grid, 512, smem, st>>>(b);
   });
   double bytes = (double)sh.n_tiles * sh.S * 1024;
-  printf("  S  %-8s TW=%d NG=%d U=%2d SPW=%d CS=%d G=%3d grid=%4d lds=%3zuK groups/wave=%.2f : %7.2f us  %5.2f TB/s\n", sh.name, TW, NG, U, SPW, CS,
-         G, 8 * G, smem >> 10, (double)a.n_groups / (G * 8), us, bytes / us * 1e-6);
+  printf("  S  %-8s TW=%d NG=%d U=%2d SPW=%d CS=%d CH=%d halves=%d G=%3d grid=%4d lds=%3zuK : %7.2f us  %5.2f TB/s (%d rows)\n", sh.name, TW, NG, U, SPW, CS,
+         CH, halves, G, grid, smem >> 10, us, bytes / us * 1e-6, 8 * NG * halves);
 }
 
 int main(int argc, char** argv) {
@@ -301,55 +302,31 @@ int main(int argc, char** argv) {
 #define A(T, NG, U, XM) run_a<T, NG, U, XM>(sh, W, wstride, NL, X, out, st)
 #define E(TW, NG, U, WV, XS, NSL, G) run_e<TW, NG, U, WV, XS>(sh, NSL, G, W, wstride, NL, X, out, st)
 #define SL(TW, NG, U, SPW, CS, G) run_s<TW, NG, U, SPW, CS>(sh, G, W, wstride, NL, X, out, st)
+#define SH(TW, NG, U, SPW, CS, CH, G, HV) run_s<TW, NG, U, SPW, CS, CH>(sh, G, W, wstride, NL, X, out, st, HV)
     if (!strcmp(sh.name, "qkv")) {
-      A(2, 4, 2, 0);
-      SL(1, 4, 8, 16, 16, 48);
-      SL(1, 4, 16, 16, 16, 48);
-      SL(1, 4, 16, 16, 16, 96);
-      SL(2, 4, 8, 16, 16, 48);
-      SL(2, 4, 16, 16, 16, 48);
-      SL(2, 4, 8, 16, 16, 24);
-      SL(2, 2, 8, 16, 16, 48);
-      SL(2, 2, 16, 16, 16, 48);
-      SL(2, 8, 8, 16, 16, 48);   // 64 rows
-      SL(1, 8, 8, 16, 16, 48);
-      SL(1, 8, 16, 16, 16, 48);
-      SL(1, 8, 8, 16, 16, 96);
+      SH(2, 4, 8, 16, 16, 1, 24, 1);
+      SH(1, 8, 8, 16, 16, 1, 24, 1);
+      SH(2, 4, 8, 16, 16, 1, 24, 2);
+      SH(2, 4, 8, 16, 16, 1, 16, 2);
+      SH(1, 4, 8, 16, 16, 2, 32, 2);
+      SH(1, 4, 8, 16, 16, 2, 64, 2);
     } else if (!strcmp(sh.name, "o")) {
-      A(1, 4, 8, 0);
-      SL(1, 4, 8, 16, 16, 32);
-      SL(1, 4, 16, 16, 16, 32);
-      SL(2, 4, 8, 16, 16, 16);
-      SL(2, 4, 16, 16, 16, 16);
-      SL(1, 2, 16, 16, 16, 32);
-      SL(1, 8, 8, 16, 16, 32);
-      SL(1, 8, 16, 16, 16, 32);
+      SH(1, 4, 8, 16, 16, 1, 32, 1);
+      SH(1, 8, 8, 16, 16, 1, 16, 1);
+      SH(1, 4, 8, 16, 16, 1, 16, 2);
+      SH(1, 4, 8, 16, 16, 1, 32, 2);
+      SH(1, 4, 8, 16, 16, 2, 32, 2);
     } else if (!strcmp(sh.name, "gateup")) {
-      A(2, 4, 2, 0);
-      SL(2, 4, 8, 16, 16, 43);
-      SL(2, 4, 16, 16, 16, 43);
-      SL(2, 4, 8, 16, 16, 86);
-      SL(2, 4, 16, 16, 16, 86);
-      SL(1, 4, 8, 16, 16, 43);
-      SL(1, 4, 16, 16, 16, 43);
-      SL(1, 4, 16, 16, 16, 86);
-      SL(2, 2, 16, 16, 16, 43);
-      SL(1, 8, 8, 16, 16, 43);
-      SL(1, 8, 8, 16, 16, 86);
-      SL(1, 8, 16, 16, 16, 86);
-      SL(2, 8, 8, 16, 16, 43);
-      SL(1, 8, 8, 16, 8, 86);
+      SH(1, 4, 8, 16, 16, 2, 64, 1);
+      SH(1, 8, 8, 16, 16, 1, 32, 1);
+      SH(1, 4, 8, 16, 16, 2, 64, 2);
+      SH(1, 4, 8, 16, 16, 2, 32, 2);
+      SH(1, 4, 8, 16, 16, 2, 128, 2);
+      SH(1, 4, 8, 16, 16, 1, 32, 2);
     } else {
-      A(1, 4, 8, 0);
-      SL(1, 4, 8, 43, 16, 32);
-      SL(1, 4, 16, 43, 16, 32);
-      SL(1, 4, 8, 43, 32, 32);
-      SL(1, 4, 16, 43, 32, 32);
-      SL(1, 2, 16, 43, 32, 32);
-      SL(2, 4, 8, 43, 32, 16);
-      SL(1, 8, 8, 43, 16, 32);
-      SL(1, 8, 16, 43, 16, 32);
-      SL(1, 8, 8, 43, 8, 32);
+      SH(1, 4, 8, 43, 16, 1, 32, 1);
+      SH(1, 8, 8, 43, 8, 1, 32, 1);
+      SH(1, 4, 8, 43, 16, 1, 32, 2);
     }
   }
   return 0;
