@@ -30,15 +30,15 @@ __host__ __device__ inline bool dd_is_eos(const DDState* st, int tok) {
 //                   V [kv_head][T_cap][128]
 // fp16 (kv16 = 1, the width the reference keeps its cache in — chair_test/chair_test.py:189-213 loads every model with
 //                   torch_dtype=float16):  K [kv_head][d/8][T_cap][8] halves (16 bytes per key and chunk),
-//                   V [kv_head][T_cap/2][32][2][4] halves: a 16-byte load = 4 consecutive d of keys 2p and 2p + 1, so the lane ->
-//                   (key, d) map of the P.V loop is the fp32 kernel's with two keys per load.
+//                   V [kv_head][T_cap/8][128][8] halves: a 16-byte load = 8 consecutive keys of one d — with K's chunks the two
+//                   A operands of v_mfma_f32_16x16x32_f16 as they lie (S^T = K . Q^T: 16 keys x 32 d; O^T = V^T . P^T: 16 d x 32 keys).
 // Pointers stay `float*` in the interfaces; layer strides are in floats of the actual storage (half the element count for
 // fp16).  Element offsets (in elements of the storage type) of key t, dimension d of kv head `kvh`:
 __host__ __device__ inline size_t dd_k32(int kvh, int d, int t, int Tc) { return (((size_t)kvh * 32 + (d >> 2)) * Tc + t) * 4 + (d & 3); }
 __host__ __device__ inline size_t dd_v32(int kvh, int d, int t, int Tc) { return ((size_t)kvh * Tc + t) * 128 + d; }
 __host__ __device__ inline size_t dd_k16(int kvh, int d, int t, int Tc) { return (((size_t)kvh * 16 + (d >> 3)) * Tc + t) * 8 + (d & 7); }
 __host__ __device__ inline size_t dd_v16(int kvh, int d, int t, int Tc) {
-  return (size_t)kvh * Tc * 128 + ((size_t)(t >> 1) * 32 + (d >> 2)) * 8 + (t & 1) * 4 + (d & 3);
+  return (((size_t)kvh * (Tc >> 3) + (t >> 3)) * 128 + d) * 8 + (t & 7);
 }
 typedef _Float16 dd_half;
 __device__ __forceinline__ void dd_kv_store(float* kc, float* vc, int kv16, int kvh, int d, int t, int Tc, bool is_k, float v) {
@@ -181,6 +181,7 @@ struct AttnDecodeArgs {
   const float* knew_g[8];  // lane_groups > 0: new K/V rows of group g
   const float* vnew_g[8];
   int max_T;             // host: largest prefix length among the lanes (grid sizing)
+  int splits_stride, tiles_per_wg;   // set by the launchers of k_attn_partial16: tile stride of the partial buffers, key tiles per workgroup
   const float* lane_kc[16];
   const float* lane_vc[16];
   const DDState* lane_state[16];

@@ -1034,7 +1034,8 @@ int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
 // ML == 2 (groups): NBT == 8; blockIdx.z = group * (G / GH) + GQA slice; group g's 8 rows (members of sequence g) read
 // that sequence's cache and drop bits; results go to an (8 * a.lane_groups)-rows-per-head layout (row = 8 * group + member).
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-template <int NBT, int G, int GH, int ML = 0, int KV16 = 0>
+// (fp32 cache; the fp16 cache goes through k_attn_partial16 below)
+template <int NBT, int G, int GH, int ML = 0>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
   const int lane_rows = a.n_lanes > 8 ? 16 : 8;   // ML == 1: rows per q head in the buffers (what the combine is built for)
@@ -1072,9 +1073,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 
   // 1. all K / V requests of this wave (addresses clamped to the last live key; dead keys get p = 0)
   const int kt = t0 + min(lane, nkeys - 1);
-  f32x4_t k4[KV16 ? 1 : 8], v4[KV16 ? 1 : 8];
-  u32x4_t k8[KV16 ? 4 : 1], v8[KV16 ? 4 : 1];
-  if constexpr (!KV16) {
+  f32x4_t k4[8], v4[8];
+  {
     const float* kbase = kc_l + (((size_t)kvh * 32 + wave * 8) * a.T_cap + kt) * 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) k4[i] = *(const f32x4_t*)(kbase + (size_t)i * a.T_cap * 4);
@@ -1083,19 +1083,6 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     for (int j = 0; j < 8; ++j) {
       int key = min(wave * 16 + 2 * j + half, nkeys - 1);
       v4[j] = *(const f32x4_t*)(vbase + (size_t)key * HEAD_DIM);
-    }
-  } else {
-    // fp16 cache: K [d/8][T_cap][8] — this wave's 32 d are 4 chunks of 16 bytes per key; V pair-interleaved — one 16-byte
-    // load = 4 d (dq) of keys 2p, 2p + 1; the wave's 16 keys are 8 pairs, two pairs (half 0 / 1) per instruction
-    const dd_half* kbase = (const dd_half*)kc_l + (((size_t)kvh * 16 + wave * 4) * a.T_cap + kt) * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) k8[i] = *(const u32x4_t*)(kbase + (size_t)i * a.T_cap * 8);
-    const dd_half* vbase = (const dd_half*)vc_l + (size_t)kvh * a.T_cap * HEAD_DIM + ((size_t)(t0 >> 1) * 32 + dq) * 8;
-    const int last_pair = (nkeys - 1) >> 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int pr = min(wave * 8 + 2 * j + half, last_pair);
-      v8[j] = *(const u32x4_t*)(vbase + (size_t)pr * 32 * 8);
     }
   }
   uint32_t bits = 0;
@@ -1115,21 +1102,10 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float sp = 0.f;
-    if constexpr (!KV16) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
-        sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f16x8_t kh = __builtin_bit_cast(f16x8_t, k8[i]);
-        f32x4_t qa = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 4 + i) * 8];
-        f32x4_t qb = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 4 + i) * 8 + 4];
-        sp += qa.x * (float)kh[0] + qa.y * (float)kh[1] + qa.z * (float)kh[2] + qa.w * (float)kh[3];
-        sp += qb.x * (float)kh[4] + qb.y * (float)kh[5] + qb.z * (float)kh[6] + qb.w * (float)kh[7];
-      }
+    for (int i = 0; i < 8; ++i) {
+      f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
+      sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
     }
     s_part[(wave * R + r) * ATT_SPLIT + lane] = sp;
   }
@@ -1157,26 +1133,12 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   f32x4_t acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  if constexpr (!KV16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int key = wave * 16 + 2 * j + half;
-      const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
+  for (int j = 0; j < 8; ++j) {
+    int key = wave * 16 + 2 * j + half;
+    const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int key0 = 2 * (wave * 8 + 2 * j + half);        // keys 2p, 2p + 1 of this lane's pair
-      const f16x8_t vh = __builtin_bit_cast(f16x8_t, v8[j]);
-      const f32x4_t va = {(float)vh[0], (float)vh[1], (float)vh[2], (float)vh[3]};
-      const f32x4_t vb = {(float)vh[4], (float)vh[5], (float)vh[6], (float)vh[7]};
-      const float* pa = &p_sh[key0 * R];
-      const float* pb = &p_sh[(key0 + 1) * R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] += pa[r] * va + pb[r] * vb;   // p = 0 for dead / dropped keys
-    }
+    for (int r = 0; r < R; ++r) acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1196,6 +1158,199 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * HEAD_DIM + dd] = o;
     } else {
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
+    }
+  }
+}
+
+// The same tile pass for the fp16 cache on the matrix cores.  The VALU form above costs ~1,100 vector instructions per wave and
+// tile at 8 rows — the grouped decode attention ran at 2.3 TB/s of K/V bytes, bound by them, not by HBM.  Here
+//   S^T = K . Q^T :  A = the 16-byte chunks of K as the cache stores them (16 keys x 32 d per fragment), B = the rows' q split
+//                    into fp16 hi + lo columns (8 rows x {hi, lo} = the 16 columns; 2^-22 relative), wave w takes keys 16w..16w+15;
+//   O^T = V^T . P^T: A = the cache's octets of V (16 d x 32 keys per fragment), B = the tile's probabilities as fp16 hi + lo,
+//                    wave w takes output dimensions 32w..32w+31, so no cross-wave reduction of the outputs is needed.
+// Tile softmax statistics, masks, buffers and row maps are those of k_attn_partial; all variants (rows alone, members of one
+// sequence, lanes, groups) go through this one body, so a row's bits do not depend on the pass it rides in.
+template <int NBT, int G, int GH, int ML>
+__global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
+  constexpr int R = NBT * GH, RB = (R + 7) / 8, RP = RB * 8;
+  const int lane_rows = a.n_lanes > 8 ? 16 : 8;
+  const int RT = ML == 1 ? lane_rows * G : (ML == 2 ? 8 * a.lane_groups * G : NBT * G);
+  constexpr int MSPLIT = ML == 2 ? 8 / NBT : 1;
+  const int zz = ML == 2 ? blockIdx.z % ((G / GH) * MSPLIT) : 0;
+  const int g0 = ML == 1 ? 0 : (ML == 2 ? (zz / MSPLIT) * GH : blockIdx.z * GH);
+  const int mo = ML == 2 ? (zz % MSPLIT) * NBT : 0;
+  const int lane_row = ML == 1 ? blockIdx.z : (ML == 2 ? blockIdx.z / ((G / GH) * MSPLIT) : 0);
+  auto buf_row = [&](int r) -> int {
+    if (ML == 1) return r * lane_rows + lane_row;
+    if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + mo + r % NBT;
+    return g0 * NBT + r;
+  };
+  __shared__ __align__(16) float q_sh[RP][HEAD_DIM + 4];
+  __shared__ __align__(16) float p_sh[RP][ATT_SPLIT + 4];
+  __shared__ float red_sh[2][4][RP];
+  if (a.skip_if && *a.skip_if) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, h4 = lane >> 4;
+  const int kvh = blockIdx.x;
+  const int T = ML ? a.lane_state[lane_row]->T : (a.state ? a.state->T : a.T);
+  // this workgroup's key tiles: tiles_per_wg consecutive ones (the launcher sizes the grid for ONE round of workgroups: with a
+  // tile per workgroup the 8-sequence pass had 1.25 rounds, a quarter-full second one)
+  const int tpw = a.tiles_per_wg > 0 ? a.tiles_per_wg : 1;
+  const int split0 = blockIdx.y * tpw, n_live = (T + ATT_SPLIT - 1) / ATT_SPLIT;
+  const int split1 = min(min(split0 + tpw, a.splits_stride), n_live);
+  if (split0 >= split1) return;   // shorter lane / stale graph: these tiles do not exist (the combine skips them as well)
+  const dd_half* kc_l = (const dd_half*)(ML ? a.lane_kc[lane_row] : a.kc);
+  const dd_half* vc_l = (const dd_half*)(ML ? a.lane_vc[lane_row] : a.vc);
+  const uint8_t* bits_l = ML ? a.lane_bits[lane_row] : a.drop_bits;
+  const int span0 = ML ? a.lane_span_start[lane_row] : a.span_start, spanL = ML ? a.lane_span_len[lane_row] : a.span_len;
+  const int q_dim = a.n_heads * HEAD_DIM;
+
+  // every K / V request of a tile at once (dead keys: the last live key's chunk / whatever the octet holds — cache memory is
+  // zero-initialised and only ever holds finite values; their probabilities are exactly 0)
+  auto load_tile = [&](int split, u32x4_t (&kf)[4], u32x4_t (&vf)[2][2], uint32_t (&kbits)[4]) {
+    const int t0 = split * ATT_SPLIT, nkeys = min(ATT_SPLIT, T - t0);
+    const int key = t0 + min(16 * wave + c, nkeys - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const u32x4_t*)(kc_l + (((size_t)kvh * 16 + 4 * ks + h4) * a.T_cap + key) * 8);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+        vf[dt][k2] = *(const u32x4_t*)(vc_l + (((size_t)kvh * (a.T_cap >> 3) + (t0 >> 3) + 4 * k2 + h4) * HEAD_DIM + 32 * wave + 16 * dt + c) * 8);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {              // drop bits of this lane's keys 16 w + 4 h4 + reg
+      const int kk = 16 * wave + 4 * h4 + reg, ka = t0 + kk;
+      kbits[reg] = (bits_l && kk < nkeys && ka >= span0 && ka < span0 + spanL) ? bits_l[ka - span0] : 0u;
+    }
+  };
+  u32x4_t kf[2][4], vf[2][2][2];
+  uint32_t kbits[2][4];
+  load_tile(split0, kf[0], vf[0], kbits[0]);
+  // q rows (r = g * NBT + m) into LDS, zero for rows past R or past the live members
+  for (int i = tid; i < RP * HEAD_DIM; i += 256) {
+    int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT;
+    int m = ML == 1 ? lane_row : mo + r % NBT;
+    int qrow = ML == 2 ? lane_row * 8 + m : m;
+    q_sh[r][d] = (r < R && m < a.nb) ? a.qbuf[(size_t)qrow * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
+  }
+  __syncthreads();
+  // fp32 x[8] -> this lane's B column: the fp16 hi part (columns 0-7) or the lo part (columns 8-15) of row c & 7
+  auto split_col = [&](const float* x) -> u32x4_t {
+    dd_f16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dd_half hi = (dd_half)x[j];
+      float rem = x[j] - (float)hi;
+      o[j] = c < 8 ? hi : (dd_half)rem;
+    }
+    return __builtin_bit_cast(u32x4_t, o);
+  };
+  // the rows' Q^T columns do not depend on the tile
+  u32x4_t qb[RB][4];
+#pragma unroll
+  for (int blk = 0; blk < RB; ++blk) {
+    const float* qr = &q_sh[8 * blk + (c & 7)][8 * h4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+      *(f32x4_t*)&x[0] = *(const f32x4_t*)(qr + 32 * ks);
+      *(f32x4_t*)&x[4] = *(const f32x4_t*)(qr + 32 * ks + 4);
+      qb[blk][ks] = split_col(x);
+    }
+  }
+  const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
+
+  auto tile = [&](int split, const u32x4_t (&kfr)[4], const u32x4_t (&vfr)[2][2], const uint32_t (&kb)[4]) {
+    const int t0 = split * ATT_SPLIT, nkeys = min(ATT_SPLIT, T - t0);
+    float pmax[RB], sv[RB][4];
+#pragma unroll
+    for (int blk = 0; blk < RB; ++blk) {
+      // S^T of this wave's 16 keys against block blk's 8 rows
+      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dd_f16x8_t, kfr[ks]), __builtin_bit_cast(dd_f16x8_t, qb[blk][ks]), sacc, 0, 0, 0);
+      // hi + lo columns; mask; the wave's maximum per row (lanes c < 8 carry row 8 blk + c, keys 16 w + 4 h4 + reg)
+      const int row = 8 * blk + (c & 7);
+      const int m = ML == 1 ? 0 : mo + row % NBT;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float s = (sacc[reg] + __shfl_down(sacc[reg], 8)) * scaling;
+        const int kk = 16 * wave + 4 * h4 + reg;
+        if (kk >= nkeys || ((kb[reg] >> (a.bit0 + m)) & 1u)) s = -INFINITY;   // zero in the 2-D mask: weight exactly 0
+        sv[blk][reg] = s;
+        mx = fmaxf(mx, s);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (h4 == 0 && c < 8) red_sh[0][wave][row] = mx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < RB; ++blk) {
+      const int row = 8 * blk + (c & 7);
+      const float M = fmaxf(fmaxf(red_sh[0][0][row], red_sh[0][1][row]), fmaxf(red_sh[0][2][row], red_sh[0][3][row]));
+      pmax[blk] = M;
+      float l = 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float p = (sv[blk][reg] == -INFINITY) ? 0.f : expf(sv[blk][reg] - M);
+        l += p;
+        if (c < 8) p_sh[row][16 * wave + 4 * h4 + reg] = p;
+      }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      if (h4 == 0 && c < 8) red_sh[1][wave][row] = l;
+    }
+    __syncthreads();
+    if (wave == 0 && h4 == 0 && c < 8) {
+#pragma unroll
+      for (int blk = 0; blk < RB; ++blk) {
+        const int row = 8 * blk + c;
+        if (row < R) {
+          float* ml = a.part_ml + (((size_t)kvh * a.splits_stride + split) * RT + buf_row(row)) * 2;
+          ml[0] = pmax[blk];
+          ml[1] = (red_sh[1][0][row] + red_sh[1][1][row]) + (red_sh[1][2][row] + red_sh[1][3][row]);
+        }
+      }
+    }
+    // O^T of this wave's 32 output dimensions: P^T columns from LDS (all 64 keys), V^T fragments from the registers
+#pragma unroll
+    for (int blk = 0; blk < RB; ++blk) {
+      u32x4_t pb[2];
+      const float* pr = &p_sh[8 * blk + (c & 7)][8 * h4];
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        float x[8];
+        *(f32x4_t*)&x[0] = *(const f32x4_t*)(pr + 32 * k2);
+        *(f32x4_t*)&x[4] = *(const f32x4_t*)(pr + 32 * k2 + 4);
+        pb[k2] = split_col(x);
+      }
+      const int row = 8 * blk + c;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f32x4_t oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+          oacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dd_f16x8_t, vfr[dt][k2]), __builtin_bit_cast(dd_f16x8_t, pb[k2]), oacc, 0, 0, 0);
+        f32x4_t o;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) o[reg] = oacc[reg] + __shfl_down(oacc[reg], 8);
+        if (c < 8 && row < R)
+          *(f32x4_t*)&a.part_o[(((size_t)kvh * a.splits_stride + split) * RT + buf_row(row)) * HEAD_DIM + 32 * wave + 16 * dt + 4 * h4] = o;
+      }
+    }
+  };
+  // tiles in pairs with the other register set prefetching: the next tile's loads are in flight while this one is computed
+  for (int sp = split0; sp < split1; sp += 2) {
+    if (sp + 1 < split1) load_tile(sp + 1, kf[1], vf[1], kbits[1]);
+    tile(sp, kf[0], vf[0], kbits[0]);
+    if (sp + 1 < split1) {
+      __syncthreads();                                  // p_sh / red_sh are reused
+      if (sp + 2 < split1) load_tile(sp + 2, kf[0], vf[0], kbits[0]);
+      tile(sp + 1, kf[1], vf[1], kbits[1]);
+      if (sp + 2 < split1) __syncthreads();
     }
   }
 }
@@ -1269,6 +1424,16 @@ int ddk_attn_grid_tiles(int T, int T_cap) {
   return up < cap ? up : (cap > tiles ? cap : tiles);
 }
 
+// k_attn_partial16: key tiles per workgroup (the next tile's loads travel while the current one is computed)
+int g_attn16_tpw = 0;   // dd_set_tuning key 21: key tiles per workgroup of the fp16-cache decode attention (0: sized for one round)
+static void attn16_grid(AttnDecodeArgs& b, int splits, int wg_per_tile) {
+  b.splits_stride = splits;
+  // up to 4 tiles per workgroup while at least ~1,000 workgroups remain (measured on the 32-lane step: 30.1 / 29.5 / 29.3 ms with
+  // 1 / 2 / 4 tiles; a single sequence's 384 tile-workgroups stay one tile each)
+  int tpw = (int)((long)wg_per_tile * splits / 1024);
+  tpw = tpw < 1 ? 1 : (tpw > 4 ? 4 : tpw);
+  b.tiles_per_wg = g_attn16_tpw > 0 ? g_attn16_tpw : tpw;
+}
 template <int NBT, int G>
 static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
   constexpr int GH = (NBT * G > 16) ? 2 : G;     // at most 16 rows per workgroup
@@ -1282,12 +1447,9 @@ static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
     attr = true;
   }
   if (a.kv16) {
-    static bool attr16 = false;
-    if (!attr16 && smem > 48 * 1024) {
-      DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      attr16 = true;
-    }
-    k_attn_partial<NBT, G, GH, 0, 1><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
+    AttnDecodeArgs b = a;
+    attn16_grid(b, splits, a.n_kv * (G / GH));
+    k_attn_partial16<NBT, G, GH, 0><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, G / GH), 256, 0, st>>>(b);
   } else {
     k_attn_partial<NBT, G, GH><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
   }
@@ -1302,8 +1464,13 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   int splits = ddk_attn_grid_tiles(a.max_T, a.T_cap);
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
-  if (a.kv16) k_attn_partial<1, G, G, 1, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
-  else k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
+  if (a.kv16) {
+    AttnDecodeArgs b = a;
+    attn16_grid(b, splits, a.n_kv * a.n_lanes);
+    k_attn_partial16<1, G, G, 1><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, a.n_lanes), 256, 0, st>>>(b);
+  } else {
+    k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
+  }
   if (a.n_lanes > 8) k_attn_combine<16, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   else k_attn_combine<8, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
   return DD_OK;
@@ -1326,12 +1493,9 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
     attr = true;
   }
   if (a.kv16) {
-    static bool attr16 = false;
-    if (!attr16 && smem > 48 * 1024) {
-      DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      attr16 = true;
-    }
-    k_attn_partial<NBT, G, GH, 2, 1><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
+    AttnDecodeArgs b = a;
+    attn16_grid(b, splits, a.n_kv * NG * (G / GH) * (8 / NBT));
+    k_attn_partial16<NBT, G, GH, 2><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, NG * (G / GH) * (8 / NBT)), 256, 0, st>>>(b);
   } else {
     k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
   }
@@ -1977,7 +2141,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
         *(f32x4_t*)&Vsh[k2 * LD + d4 * 4] = *(const f32x4_t*)(vc + ((size_t)kvh * T_cap + key2) * HD + d4 * 4);
       }
     } else {
-      // fp16 cache (dd_lm_kernels.h layouts): K chunks of 8 d, V pairs of keys x 4 d; expanded to fp32 in the staged tiles
+      // fp16 cache (dd_lm_kernels.h layouts): K chunks of 8 d, V octets of keys per d; expanded to fp32 in the staged tiles
       constexpr int C8 = HD / 8;
       for (int i = tid; i < FA_KEYS * C8; i += 256) {
         int kk = i & 31, c = i >> 5;
@@ -1986,12 +2150,12 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
         *(f32x4_t*)&Ksh[kk * LD + c * 8] = (f32x4_t){(float)kh[0], (float)kh[1], (float)kh[2], (float)kh[3]};
         *(f32x4_t*)&Ksh[kk * LD + c * 8 + 4] = (f32x4_t){(float)kh[4], (float)kh[5], (float)kh[6], (float)kh[7]};
       }
-      for (int i = tid; i < (FA_KEYS / 2) * C4; i += 256) {
-        int d4 = i % C4, pr = i / C4;                          // pair pr = keys t0 + 2 pr, t0 + 2 pr + 1 (t0 is even)
-        int pair = min((t0 >> 1) + pr, p_max >> 1);
-        const f16x8_t vh = *(const f16x8_t*)((const dd_half*)vc + (size_t)kvh * T_cap * HD + ((size_t)pair * C4 + d4) * 8);
-        *(f32x4_t*)&Vsh[(2 * pr) * LD + d4 * 4] = (f32x4_t){(float)vh[0], (float)vh[1], (float)vh[2], (float)vh[3]};
-        *(f32x4_t*)&Vsh[(2 * pr + 1) * LD + d4 * 4] = (f32x4_t){(float)vh[4], (float)vh[5], (float)vh[6], (float)vh[7]};
+      for (int i = tid; i < (FA_KEYS / 8) * HD; i += 256) {
+        int dd = i % HD, oc = i / HD;                          // octet oc = keys t0 + 8 oc .. + 7 (t0 is a multiple of 32) of dimension dd
+        int octet = min((t0 >> 3) + oc, p_max >> 3);           // keys past p_max inside the last octet carry weight 0
+        const f16x8_t vh = *(const f16x8_t*)((const dd_half*)vc + (((size_t)kvh * (T_cap >> 3) + octet) * HD + dd) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vsh[(8 * oc + j) * LD + dd] = (float)vh[j];
       }
     }
     __syncthreads();
