@@ -793,41 +793,38 @@ __global__ __launch_bounds__(128 * NG) void k_gemv_finish(GemvArgs a, const floa
                                                           int n_sets) {
   __shared__ float ssq_sh[16 * 8 * NG];
   __shared__ float rstd_sh[8 * NG];
+  __shared__ float y_sh[EPI == EPI_QKV ? TILES * 128 * NG : 1];   // rotary tiles: a thread needs its partner column's sum (n ^ 8)
   const int wg = blockIdx.x, tile0 = wg * TILES;
   const int et = threadIdx.x, eg = et >> 7, ml = et & 7, en = (et & 127) >> 3;
   const size_t ps = ((size_t)n_sets * TILES * NG) << 7;
-  // one batch of requests: the thread's partial sums (and, for rotary tiles, its partner column's: n ^ 8), rstd, the
-  // epilogue's operands — a single memory round trip before the arithmetic
-  constexpr int NV = EPI == EPI_QKV ? 2 : 1;
-  float v[TILES][NV][NP];
+  // one batch of requests: the thread's partial sums, rstd, the epilogue's operands — a single memory round trip before the
+  // arithmetic
+  float v[TILES][NP];
 #pragma unroll
-  for (int tt = 0; tt < TILES; ++tt)
+  for (int tt = 0; tt < TILES; ++tt) {
+    const float* p0 = part + (((size_t)(tile0 + tt) * NG + eg) << 7) + dd_part_index(en, ml);
 #pragma unroll
-    for (int x = 0; x < NV; ++x) {
-      const float* p0 = part + (((size_t)(tile0 + tt) * NG + eg) << 7) + dd_part_index(x ? en ^ 8 : en, ml);
-#pragma unroll
-      for (int q = 0; q < NP; ++q) v[tt][x][q] = p0[(size_t)q * ps];
-    }
+    for (int q = 0; q < NP; ++q) v[tt][q] = p0[(size_t)q * ps];
+  }
   if (a.ssq_in && et < 8 * NG) rstd_sh[et] = rstd_g[et];
   GroupsPre<TILES> pre;
   groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
-  float y_own[TILES][NV];
+  float y_own[TILES];
 #pragma unroll
-  for (int tt = 0; tt < TILES; ++tt)
+  for (int tt = 0; tt < TILES; ++tt) {
+    float y = 0.f;
+    if (NP == 8) {
 #pragma unroll
-    for (int x = 0; x < NV; ++x) {
-      float y = 0.f;
-      if (NP == 8) {
+      for (int q = 0; q < 8; q += 2) y += v[tt][q] + v[tt][q + 1];
+    } else {
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) y += v[tt][x][q] + v[tt][x][q + 1];
-      } else {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) y += v[tt][x][q];
-      }
-      y_own[tt][x] = y;
+      for (int q = 0; q < NP; ++q) y += v[tt][q];
     }
-  __syncthreads();                                   // rstd_sh
-  auto tile_sum = [&](int tt, int n) -> float { return (NV == 2 && n != en) ? y_own[tt][NV - 1] : y_own[tt][0]; };
+    y_own[tt] = y;
+    if (EPI == EPI_QKV) y_sh[tt * 128 * NG + et] = y;   // the partner (same group and row, column n ^ 8) is thread et ^ 64
+  }
+  __syncthreads();                                   // rstd_sh, y_sh
+  auto tile_sum = [&](int tt, int n) -> float { return (EPI == EPI_QKV && n != en) ? y_sh[tt * 128 * NG + (et ^ 64)] : y_own[tt]; };
   groups_epilogue<EPI, TILES, NG>(a, wg, pre, rstd_sh, ssq_sh, tile_sum);
 }
 
