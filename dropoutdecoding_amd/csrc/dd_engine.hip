@@ -860,10 +860,15 @@ extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* cons
     g.seq_rows = seq_rows, g.seq_tab = h0->seq_tab, g.seq_off_k = (size_t)l * h0->lsk, g.seq_off_v = (size_t)l * h0->lsv;
     g.kc = lanes[0]->kc + g.seq_off_k, g.vc = lanes[0]->vc + g.seq_off_v;
     RC(ddk_gemm(EPI_QKV, g, st));
-    for (int i = 0; i < n; ++i) {                          // causal attention of each sequence over its own cache
-      const size_t r0 = (size_t)i * seq_rows;
-      RC(ddk_attn_prefill(bq + r0 * h0->q_dim, lanes[i]->kc + g.seq_off_k, lanes[i]->vc + g.seq_off_v, T0s[i], h0->T_cap, h0->H, h0->Hkv, b1h + r0 * h0->q_dim,
-                          b1l + r0 * h0->q_dim, nullptr, 0, span_starts[i], span_lens[i], 0, st, nullptr, h0->kv16, h0->wf));
+    if (ddk_prefill_mfma_enabled()) {                      // causal attention of every sequence over its own cache, one launch
+      RC(ddk_attn_prefill_seqs(bq, h0->seq_tab, g.seq_off_k, g.seq_off_v, n, seq_rows, maxT, h0->T_cap, h0->H, h0->Hkv, b1h, b1l, st, h0->kv16,
+                               h0->wf));
+    } else {
+      for (int i = 0; i < n; ++i) {
+        const size_t r0 = (size_t)i * seq_rows;
+        RC(ddk_attn_prefill(bq + r0 * h0->q_dim, lanes[i]->kc + g.seq_off_k, lanes[i]->vc + g.seq_off_v, T0s[i], h0->T_cap, h0->H, h0->Hkv,
+                            b1h + r0 * h0->q_dim, b1l + r0 * h0->q_dim, nullptr, 0, span_starts[i], span_lens[i], 0, st, nullptr, h0->kv16, h0->wf));
+      }
     }
     memset(&g, 0, sizeof(g));
     g.wf = h0->wf;

@@ -242,6 +242,9 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
                      uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start,
                      int span_len, int q0, hipStream_t st, u32x4_t* xop_out = nullptr, int kv16 = 0, int wf = 0);   // q0 = position of query row 0
 // xop_out: write the rows as packed decode-GEMV operand planes (row-major [32 rows]) instead of the GEMM's A planes
+struct SeqTab;
+int ddk_attn_prefill_seqs(const float* qbuf, const SeqTab* tab, size_t off_k, size_t off_v, int n, int seq_rows, int max_T, int T_cap,
+                          int n_heads, int n_kv, uint16_t* o_hi, uint16_t* o_lo, hipStream_t st, int kv16, int wf);   // n sequences, one launch
 int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x, const float* normw, u32x4_t* xop, float* ssq,
                         int ssq_ld, hipStream_t st, int wf = 0);
 int ddk_chunk_positions(DDState* rows, const DDState* base, int n, hipStream_t st);

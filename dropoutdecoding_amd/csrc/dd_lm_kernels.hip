@@ -2082,13 +2082,25 @@ __device__ __forceinline__ void fa_split8(const float* v, u32x4_t& hi, u32x4_t& 
 
 // HD = head dimension (128: the LM; 64: the CLIP tower, bidirectional, q pre-scaled)
 template <int G, int HD = 128, int KV16 = 0>
-__global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restrict__ qbuf, const float* __restrict__ kc,
-                                                           const float* __restrict__ vc, int T, int T_cap, int n_heads,
-                                                           uint16_t* __restrict__ o_hi, uint16_t* __restrict__ o_lo,
+__global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* qbuf, const float* kc,
+                                                           const float* vc, int T, int T_cap, int n_heads,
+                                                           uint16_t* o_hi, uint16_t* o_lo,
                                                            const uint8_t* __restrict__ drop_plane, int drop_bit,
                                                            int span_start, int span_len, int q0, int causal, float scaling, int wf,
-                                                           int Tk) {
+                                                           int Tk, const SeqTab* tab = nullptr, int seq_rows = 0, size_t off_k = 0,
+                                                           size_t off_v = 0) {
   // Tk: number of keys when not causal (cross-attention: T queries against Tk keys of another sequence; = T for self-attention)
+  // tab: the prompts of several sequences in one launch (dd_lm_prefill_group): blockIdx.z = sequence; its length and cache
+  // bases come from the table, its q rows / output planes start at row blockIdx.z * seq_rows of the batch's buffers
+  if (tab) {
+    const int sq = blockIdx.z;
+    T = tab->T[sq];
+    if ((int)blockIdx.y * 64 >= T) return;
+    kc = tab->kc[sq] + off_k, vc = tab->vc[sq] + off_v;
+    const size_t r0 = (size_t)sq * seq_rows * (n_heads * HD);
+    qbuf += r0, o_hi += r0, o_lo += r0;
+    Tk = T;
+  }
   constexpr int LD = HD + 4;   // padded row pitch (floats) of the staged K / V tiles: keeps the V^T reads conflict-free
   constexpr int KS = HD / 32, DT = HD / 16, C4 = HD / 4;
   __shared__ __align__(16) float Ksh[FA_KEYS * LD];
@@ -2290,6 +2302,28 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
   else if (G == 2) k_attn_prefill<2><<<grid, 256, 0, st>>>(PF_ARGS);
   else if (G == 4) k_attn_prefill<4><<<grid, 256, 0, st>>>(PF_ARGS);
   else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// causal prefill attention of n sequences in ONE launch (the prompts of a batch: dd_lm_prefill_group): one sequence's
+// 608 rows are 320 workgroups — about one per CU — and n launches would run one after another
+int ddk_attn_prefill_seqs(const float* qbuf, const SeqTab* tab, size_t off_k, size_t off_v, int n, int seq_rows, int max_T, int T_cap,
+                          int n_heads, int n_kv, uint16_t* o_hi, uint16_t* o_lo, hipStream_t st, int kv16, int wf) {
+  const int G = n_heads / n_kv;
+  DD_REQUIRE(g_prefill_mfma, "attn_prefill_seqs: the matrix-core prefill attention is switched off");
+  dim3 g2(n_heads, (max_T + 63) / 64, n);
+#define FS_ARGS qbuf, nullptr, nullptr, max_T, T_cap, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 1, 0.08838834764831845f, wf, max_T, tab, seq_rows, off_k, off_v
+  if (kv16) {
+    if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FS_ARGS);
+    else if (G == 2) k_attn_prefill_mfma<2, 128, 1><<<g2, 256, 0, st>>>(FS_ARGS);
+    else if (G == 4) k_attn_prefill_mfma<4, 128, 1><<<g2, 256, 0, st>>>(FS_ARGS);
+    else DD_REQUIRE(false, "attn_prefill_seqs: GQA group %d unsupported", G);
+  } else if (G == 1) k_attn_prefill_mfma<1><<<g2, 256, 0, st>>>(FS_ARGS);
+  else if (G == 2) k_attn_prefill_mfma<2><<<g2, 256, 0, st>>>(FS_ARGS);
+  else if (G == 4) k_attn_prefill_mfma<4><<<g2, 256, 0, st>>>(FS_ARGS);
+  else DD_REQUIRE(false, "attn_prefill_seqs: GQA group %d unsupported", G);
+#undef FS_ARGS
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
