@@ -179,6 +179,8 @@ def main() -> int:
                     help="2 (with 16+ images per GPU): decode the lanes as two independent halves on two streams.  Decode alone gains "
                          "13 %% from it (28.2 vs 32.5 ms per 32-lane step), the whole pipeline loses 5 %% (792 vs 830 tok/s): the next "
                          "batch's prefill on its own stream already fills the gaps of the sweep")
+    ap.add_argument("--prefill-chunk", type=int, default=16, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (experiments)")
     ap.add_argument("--single-images", type=int, default=5, help="images of the one-image-at-a-time leg (after one warm-up image)")
     args = ap.parse_args()
 
@@ -202,6 +204,10 @@ def main() -> int:
     from dropoutdecoding_amd import config as ddcfg
     from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
 
+    for kv in args.tune:
+        from dropoutdecoding_amd import _lib as _ddlib
+        k_, v_ = kv.split("=")
+        _ddlib.check(_ddlib.load().dd_set_tuning(int(k_), int(v_)), "dd_set_tuning")
     probs = ddcfg.VOTING_NUMBERS_K8[:args.k] if args.k <= 8 else [0.1 + 0.05 * i for i in range(args.k)]
     ddcfg.settings["voting_numbers"] = probs
     model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
@@ -240,6 +246,8 @@ def main() -> int:
         # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
         from dropoutdecoding_amd.vlm import GroupPipeline
         pipe = GroupPipeline(model, lanes=B, decode_streams=args.decode_streams if B >= 16 else 1)
+        for p_ in (pipe.halves or [pipe]):
+            p_.prefill_chunk = max(1, args.prefill_chunk)
 
     def batch_inputs(i):
         out = []

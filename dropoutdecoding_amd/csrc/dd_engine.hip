@@ -265,7 +265,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
     // slice partials: 8 slices x tiles x 4 planes x 128 floats for qkv / o / down, 4 slice pairs for gate/up
     size_t t8 = (size_t)h->qkv_tiles > (size_t)d / 16 ? (size_t)h->qkv_tiles : (size_t)d / 16;
     // (eight planes for a 64-row pass: single slices for every matrix)
-    size_t nfl = 8 * t8 * 8 * 128, gu = (size_t)8 * (2 * dff / 16) * 8 * 128;
+    size_t nfl = 8 * t8 * 8 * 128, gu = (size_t)8 * (2 * dff / 16) * 8 * 128, lmh = (size_t)8 * (h->Vpad / 16) * 8 * 128;
+    if (lmh > gu) gu = lmh;                                   // lm_head: 66 MB at V = 32064
     h->gemv_part_floats = h->fp8 ? 0 : (nfl > gu ? nfl : gu);
     if (h->gemv_part_floats) DA(h->gemv_part, h->gemv_part_floats + 64);   // + rstd of the up to 64 operand rows
   }

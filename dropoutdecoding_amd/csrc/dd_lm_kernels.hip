@@ -883,12 +883,30 @@ template <int NG>
 static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
   const int spw = a.S / GEMV_WAVES;
   const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;      // 16-row weight tiles
-  if (epi == EPI_STORE || !(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
+  if (!(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
   sa.rstd_out = a.part + a.part_floats;                              // 32 floats behind the partial sums
   const size_t need8 = (size_t)8 * nt * NG * 128, need4 = need8 / 2;
+  if (epi == EPI_STORE) {
+    // lm_head (K = 4096): the wave-split kernel streams it at 2.8 TB/s with four planes (operand reads from L2); the slice kernels
+    // with the plain-store finish: 32 rows as slice pairs, 64 rows as single slices, 16 rows stay on the wave-split kernel
+    if (spw != 16 || NG < 4) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    if constexpr (NG == 8) {
+      if (a.part_floats < need8) return SLICES_UNSUPPORTED;
+      sa.G = (nt + 31) / 32;
+      RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_STORE>(sa, a.wf, st));
+      launch_finish<EPI_STORE, 1, 8, 8>(a, nt, st);
+    } else {
+      if (a.part_floats < need4) return SLICES_UNSUPPORTED;
+      sa.G = 64;
+      RC_(launch_slices_k<1, NG, 8, 16, 16, 2, EPI_STORE>(sa, a.wf, st));
+      launch_finish<EPI_STORE, 1, NG, 4>(a, nt, st);
+    }
+    return DD_OK;
+  }
   if constexpr (NG == 8) {
     // 64 rows: 8 operand planes fill the LDS with one slice (16 steps x 8 KiB = 128 KiB at K = 4096; long K in chunks of 8
     // steps), one tile per wave group; tools/gemv_lab: qkv 28 us, o 10.7, gate/up 45, down 21 — 1.25 x the 32-row kernels for
