@@ -175,3 +175,46 @@ def test_full_size_attention_time_fp16_vs_fp32_kv(E):
         eng.close()
     print(f"\n[fp16 KV] 2-layer 8-row sweep at T=672: fp32 cache {out['fp32'] * 1e3:.1f} us, fp16 cache {out['fp16'] * 1e3:.1f} us")
     assert out["fp16"] > 0 and out["fp32"] > 0
+
+
+@pytest.mark.parametrize("heads,kv_heads", [(4, 2), (8, 2), (4, 1)])
+def test_gqa_groups_through_the_matrix_core_decode_attention(E, heads, kv_heads):
+    """GQA 2 / 4 with the fp16 cache: k_attn_partial16 runs two blocks of 8 rows per workgroup (8 members x 2 query heads of a
+    kv head), the lanes form carries G rows, several key tiles per workgroup (contexts of 3-4 tiles).  Nine lanes — one 64-row
+    member pass + one 8-row pass — must equal their solo runs bit for bit and the fp32 oracle's tokens and masks."""
+    d = heads * 128
+    rc = RefCfg(512, d, 2 * d, 2, heads, kv_heads, 128, 1e-5, 10000.0)
+    w = random_weights(rc, 63, 0.04)
+    cfg = E.LMConfig(512, d, 2 * d, 2, heads, kv_heads, 128, 1e-5, 10000.0)
+    shapes = [(150 + 7 * i, 2 + i % 4, 120) for i in range(9)]
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    engines = []
+    for i in range(len(shapes)):
+        engines.append(E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=256, max_visual=120, seed=7, kv_format="fp16",
+                                       share_weights_with=engines[0] if engines else None))
+    engines[0].load_state_dict(w)
+    embs = [torch.randn(T0, d, generator=torch.Generator().manual_seed(300 + i)) * 0.8 for i, (T0, _, _) in enumerate(shapes)]
+    for e, emb, (T0, s0, L) in zip(engines, embs, shapes):
+        e.prefill(emb.cuda(), s0, L)
+    grp = E.EngineGroup(engines)
+    recs = []
+    for s in range(4):
+        grp.decode_step(probs)
+        recs.append([(e.logits().copy(), e.last_step()["drop"].copy()) for e in engines])
+    toks = [e.tokens() for e in engines]
+    for i in (0, 4, 8):                                      # lanes of the 64-row pass and the one of the 8-row pass, alone
+        e, emb, (T0, s0, L) = engines[i], embs[i], shapes[i]
+        e.rng.manual_seed(7)
+        e.prefill(emb.cuda(), s0, L)
+        for s in range(4):
+            e.decode_step(probs)
+            np.testing.assert_array_equal(e.logits(), recs[s][i][0])
+            np.testing.assert_array_equal(e.last_step()["drop"], recs[s][i][1])
+        assert e.tokens() == toks[i]
+        ref = RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=7)
+        assert ref.generate(embs[i], s0, L, 5) == toks[i]
+        for s, r in enumerate(ref.records):
+            np.testing.assert_array_equal(recs[s][i][1], r.drop)
+            assert rel(recs[s][i][0], r.logits) <= TOL
+    for e in reversed(engines):
+        e.close()
