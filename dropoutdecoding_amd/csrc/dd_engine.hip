@@ -1927,10 +1927,16 @@ extern "C" int dd_lm_get(dd_lm* h, int what, void* dst, size_t bytes, void* stre
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && dst, "dd_lm_get: null argument");
   DD_HIP(hipStreamSynchronize(st));
+  // copies go through `st`, not through the legacy stream: a synchronous hipMemcpy would order itself after every blocking stream
+  // of the process — including one another host thread is capturing a graph on (a second decode pipeline), which HIP refuses
+  auto d2h = [&](void* to, const void* from, size_t n) -> hipError_t {
+    hipError_t e = hipMemcpyAsync(to, from, n, hipMemcpyDeviceToHost, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  };
   if (h->prefilled) {
     // the host mirrors count ENQUEUED steps; steps enqueued beyond an EOS did not advance the sequence (DDState::done)
     DDState ds;
-    DD_HIP(hipMemcpy(&ds, h->state, sizeof(ds), hipMemcpyDeviceToHost));
+    DD_HIP(d2h(&ds, h->state, sizeof(ds)));
     h->T_host = ds.T, h->n_tok_host = ds.n_tok < MAX_NEW_TOKENS ? ds.n_tok : MAX_NEW_TOKENS;
   }
   const void* src = nullptr;
@@ -1957,8 +1963,9 @@ extern "C" int dd_lm_get(dd_lm* h, int what, void* dst, size_t bytes, void* stre
     case DD_GET_IMAGE_LOGITS: {
       DD_REQUIRE(bytes <= (size_t)L * h->V * 4, "dd_lm_get: image logits: at most %zu bytes", (size_t)L * h->V * 4);
       size_t rows = bytes / ((size_t)h->V * 4);
-      DD_HIP(hipMemcpy2D(dst, (size_t)h->V * 4, h->image_logits, (size_t)h->Vpad * 4, (size_t)h->V * 4, rows,
-                         hipMemcpyDeviceToHost));
+      DD_HIP(hipMemcpy2DAsync(dst, (size_t)h->V * 4, h->image_logits, (size_t)h->Vpad * 4, (size_t)h->V * 4, rows,
+                              hipMemcpyDeviceToHost, st));
+      DD_HIP(hipStreamSynchronize(st));
       return DD_OK;
     }
     case DD_GET_KV_SUMS:
@@ -1969,7 +1976,7 @@ extern "C" int dd_lm_get(dd_lm* h, int what, void* dst, size_t bytes, void* stre
     default: DD_REQUIRE(false, "dd_lm_get: unknown item %d", what);
   }
   DD_REQUIRE(bytes <= avail, "dd_lm_get(%d): asked for %zu bytes, only %zu available", what, bytes, avail);
-  DD_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  DD_HIP(d2h(dst, src, bytes));
   return DD_OK;
 }
 
