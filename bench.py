@@ -179,6 +179,7 @@ def main() -> int:
                     help="2 (with 16+ images per GPU): decode the lanes as two independent halves on two streams.  Decode alone gains "
                          "13 %% from it (28.2 vs 32.5 ms per 32-lane step), the whole pipeline loses 5 %% (792 vs 830 tok/s): the next "
                          "batch's prefill on its own stream already fills the gaps of the sweep")
+    ap.add_argument("--no-batch-tower", action="store_true", help="one vision-tower call per image instead of one per 16 images (A/B)")
     ap.add_argument("--prefill-chunk", type=int, default=16, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (experiments)")
     ap.add_argument("--single-images", type=int, default=5, help="images of the one-image-at-a-time leg (after one warm-up image)")
@@ -212,6 +213,9 @@ def main() -> int:
     ddcfg.settings["voting_numbers"] = probs
     model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
     model.original = args.original
+    if args.no_batch_tower:
+        from dropoutdecoding_amd.vlm import DropoutVLM
+        type(model)._visual_embeds_batch = DropoutVLM._visual_embeds_batch
     eng = model.engine
     if args.mode == "kshard" and use_dist:
         from dropoutdecoding_amd.dist import KShardDecoder

@@ -798,10 +798,6 @@ static int prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, i
 // dd_lm_prefill on it alone.  fp8 weights, different cache capacities or a batch too small for the large blocks fall
 // back to one dd_lm_prefill per sequence.
 // -----------------------------------------------------------------------------------------------
-__global__ void k_put_seq_tab(SeqTab tab, SeqTab* dst) {
-  const int i = threadIdx.x;
-  dst->T[i] = tab.T[i], dst->kc[i] = tab.kc[i], dst->vc[i] = tab.vc[i];
-}
 extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* const* embeds, const int32_t* T0s,
                                    const int32_t* span_starts, const int32_t* span_lens, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
@@ -848,8 +844,7 @@ extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* cons
     SeqTab tab;                                             // per-sequence lengths and cache bases, read by the QKV epilogue
     memset(&tab, 0, sizeof(tab));
     for (int i = 0; i < n; ++i) tab.T[i] = T0s[i], tab.kc[i] = lanes[i]->kc, tab.vc[i] = lanes[i]->vc;
-    k_put_seq_tab<<<1, 32, 0, st>>>(tab, h0->seq_tab);       // by value through the launch: no host buffer has to outlive the call
-    DD_CHECK_LAUNCH();
+    RC(ddk_put_seq_tab(tab, h0->seq_tab, st));
   }
   DD_HIP(hipMemsetAsync(bx, 0, M * d * 4, st));            // padding rows: zeros (finite everywhere downstream, never stored)
   for (int i = 0; i < n; ++i)

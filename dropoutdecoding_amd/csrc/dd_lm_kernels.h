@@ -205,6 +205,10 @@ struct GemmArgs {
   int act;               // EPI_ACT: 0 quick_gelu, 1 gelu(erf), 2 identity
   int vit_hidden, vit_head_dim, vit_head_pad;   // EPI_QKV_VIT (head_pad: pitch of a head in q / K^T / V; 0 = head_dim)
   int grid_y, xcd_order; // set by the launcher: row blocks of the grid; XCD-aware block order on / off
+  // EPI_QKV_VIT over the tokens of several images back to back (dd_vit_forward): vit_img_rows > 0 = rows per image (a multiple of
+  // 128); row r is token r % vit_img_rows of image r / vit_img_rows, live below vit_T, and writes that image's K^T / V block
+  int vit_img_rows, vit_T;
+  size_t vit_k_stride, vit_v_stride;   // floats between the K^T (V) blocks of consecutive images
   int vit_col0;          // EPI_QKV_VIT: output column c of W counts as column c + vit_col0 of a fused [q | k | v] projection
                          // (a [k | v] weight of a cross-attention runs with vit_col0 = hidden)
   float vit_qscale;
@@ -243,6 +247,9 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
                      int span_len, int q0, hipStream_t st, u32x4_t* xop_out = nullptr, int kv16 = 0, int wf = 0);   // q0 = position of query row 0
 // xop_out: write the rows as packed decode-GEMV operand planes (row-major [32 rows]) instead of the GEMM's A planes
 struct SeqTab;
+int ddk_put_seq_tab(const SeqTab& tab, SeqTab* dev, hipStream_t st);   // host table -> device, by value through a launch
+int ddk_attn_vit_mfma_batch(const float* q, const SeqTab* tab, int n, int img_rows, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
+                            hipStream_t st, int head_pitch);   // ddk_attn_vit_mfma for n images in one launch (q / planes: img_rows rows per image)
 int ddk_attn_prefill_seqs(const float* qbuf, const SeqTab* tab, size_t off_k, size_t off_v, int n, int seq_rows, int max_T, int T_cap,
                           int n_heads, int n_kv, uint16_t* o_hi, uint16_t* o_lo, hipStream_t st, int kv16, int wf);   // n sequences, one launch
 int ddk_pack_embed_rows(const float* rows, int n, int rows_cap, int d, float* x, const float* normw, u32x4_t* xop, float* ssq,

@@ -7,6 +7,8 @@
 //     all rows (ensemble members x GQA group) with their own drop bits; flash-decoding style combine.
 //   - prefill GEMM: the same packed weights as the MFMA B operand, activations as hi/lo bf16 planes.
 // Reference anchors: the third-party LM forward the reference calls at models/llava.py:294-303,350-359.
+#include <type_traits>
+
 #include "dd_lm_kernels.h"
 #include "dd_gemv_slices.h"
 
@@ -1616,6 +1618,14 @@ int ddk_final_norm_rows(const float* x, int rows, int d, const float* w, float e
   return ddk_rmsnorm_split(x, rows, d, w, eps, nullptr, nullptr, nullptr, out, st, 0);
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (indices stay constants whatever the body's size)
+template <int B, int E, typename F>
+__device__ __forceinline__ void dd_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    dd_static_for<B + 1, E>(f);
+  }
+}
 // Epilogue of the prefill GEMMs for a wave's MI x NJ accumulator tiles (rows m_base.., 16-column tiles nt_base..).
 // D[m][n]: m = 4*(lane>>4) + reg, n = lane & 15
 template <int EPI, int MI, int NJ, int WF>
@@ -1623,12 +1633,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
                                               const bool (&wv)[NJ], const int lane) {
   const int c = lane & 15;
   // loop order row (i, reg) outside, column tile inside: what depends on the row only (its sequence, position, cache) is
-  // computed 16 times per wave, not once per element — the unrolled body of the 4 x 8-tile kernel has to stay within the
-  // compiler's unroll budget, or the accumulators are indexed dynamically and the whole array moves to scratch
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
+  // computed 16 times per wave, not once per element.  The three loops are expanded at compile time (dd_static_for), not left to
+  // `#pragma unroll`: past the compiler's unroll budget (the 4 x 8-tile kernel with a large body: RoPE, erf, ViT scatter) a
+  // loop stays a loop, the accumulators are then indexed dynamically and the WHOLE array lives in scratch — in the main loop too
+  dd_static_for<0, MI>([&](auto ic_) {
+    constexpr int i = decltype(ic_)::value;
+    dd_static_for<0, 4>([&](auto rc_) {
+      constexpr int reg = decltype(rc_)::value;
       const int row = m_base + i * 16 + 4 * (lane >> 4) + reg;
       int lrow = row, live_rows = a.M;
       float *kc_r = a.kc, *vc_r = a.vc;
@@ -1638,8 +1649,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
         kc_r = a.seq_tab->kc[sq] + a.seq_off_k, vc_r = a.seq_tab->vc[sq] + a.seq_off_v;
       }
       const int pos_c = a.pos0 + max(0, min(lrow, live_rows - 1));   // EPI_QKV: clamped position (rotary table row)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      dd_static_for<0, NJ>([&](auto jc_) {
+        constexpr int j = decltype(jc_)::value;
         const int nt = nt_base + j;
         const bool ok = row < a.M && wv[j];
         float y = acc[i][j][reg];
@@ -1652,7 +1663,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
           int col = nt * 16 + c;
           if (ok) a.out[(size_t)row * a.ldo + col] += y;
         } else if (EPI == EPI_SILU) {
-          if ((j & 1) == 0) {
+          if constexpr ((j & 1) == 0 && j + 1 < NJ) {
             float u = acc[i][j + 1][reg];
             if (a.wscale) u *= a.wscale[(size_t)(nt + 1) * 16 + c];
             float act = y / (1.0f + expf(-y));
@@ -1681,14 +1692,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
             // hp: head pitch of the q / K^T / V buffers (= hd, or hd padded to a multiple of 32 for the matrix-core attention:
             // EVA ViT-g's 88 -> 96; the pad columns stay zero)
             int col = nt * 16 + c + a.vit_col0, hd = a.vit_head_dim, hp = a.vit_head_pad ? a.vit_head_pad : hd;
-            if (col < a.vit_hidden) {
+            int trow = row;                    // token within its image
+            float *kt_i = a.kc, *v_i = a.vc;
+            bool live = true;
+            if (a.vit_img_rows) {
+              const int im = row / a.vit_img_rows;
+              trow = row - im * a.vit_img_rows, live = trow < a.vit_T;
+              kt_i = a.kc + (size_t)im * a.vit_k_stride, v_i = a.vc + (size_t)im * a.vit_v_stride;
+            }
+            if (!live) {
+            } else if (col < a.vit_hidden) {
               a.qbuf[(size_t)row * (a.vit_hidden / hd * hp) + (col / hd) * hp + col % hd] = y * a.vit_qscale;
             } else if (col < 2 * a.vit_hidden) {
               int cc = col - a.vit_hidden, head = cc / hd, idx = cc % hd;
-              a.kc[(((size_t)head * (hp >> 2) + (idx >> 2)) * a.T_cap + row) * 4 + (idx & 3)] = y;
+              kt_i[(((size_t)head * (hp >> 2) + (idx >> 2)) * a.T_cap + trow) * 4 + (idx & 3)] = y;
             } else {
               int cc = col - 2 * a.vit_hidden, head = cc / hd, idx = cc % hd;
-              a.vc[((size_t)head * a.T_cap + row) * hp + idx] = y;
+              v_i[((size_t)head * a.T_cap + trow) * hp + idx] = y;
             }
           }
         } else {  // EPI_QKV
@@ -1713,9 +1733,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
             dd_kv_store(kc_r, vc_r, a.kv16, kvh, idx, pos, a.T_cap, false, y);
           }
         }
-      }
-    }
-  }
+      });
+    });
+  });
 }
 
 // C[M][N] = (A_hi + A_lo)[M][K] . W^T, block 128x128, 4 waves (2x2) of 64x64; both operands are pre-tiled so every
@@ -1949,6 +1969,8 @@ static int launch_gemm_big(int epi, const GemmArgs& a_, hipStream_t st) {
     case EPI_RESID: GB(EPI_RESID); break;
     case EPI_SILU: GB(EPI_SILU); break;
     case EPI_QKV: GB(EPI_QKV); break;
+    case EPI_ACT: GBK(EPI_ACT, 0); break;
+    case EPI_QKV_VIT: GBK(EPI_QKV_VIT, 0); break;
     default: DD_REQUIRE(false, "gemm (128 x 512 block): epilogue %d not built", epi);
   }
 #undef GB
@@ -1959,7 +1981,8 @@ static int launch_gemm_big(int epi, const GemmArgs& a_, hipStream_t st) {
 
 int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S >= 2 && (a.S & 1) == 0, "gemm: K=%d must be a multiple of 64", a.S * 32);
-  if (g_gemm_big_rows > 0 && a.M >= g_gemm_big_rows && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_SILU || epi == EPI_QKV))
+  if (g_gemm_big_rows > 0 && a.M >= g_gemm_big_rows &&
+      (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_SILU || epi == EPI_QKV || ((epi == EPI_ACT || epi == EPI_QKV_VIT) && !a.wf)))
     return launch_gemm_big(epi, a, st);
   long big = (long)((a.n_tiles + 7) / 8) * ((a.M + 127) / 128);      // workgroups of the 128x128 tiling
   if (big >= 150) return launch_gemm<4, 4>(epi, a, st);
@@ -2276,6 +2299,29 @@ int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, in
   else
     k_attn_prefill_mfma<1, 64><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0,
                                                                           0, scaling, 0, Tk);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+__global__ void k_put_seq_tab(SeqTab tab, SeqTab* dst) {
+  const int i = threadIdx.x;
+  dst->T[i] = tab.T[i], dst->kc[i] = tab.kc[i], dst->vc[i] = tab.vc[i];
+}
+int ddk_put_seq_tab(const SeqTab& tab, SeqTab* dev, hipStream_t st) {
+  k_put_seq_tab<<<1, 32, 0, st>>>(tab, dev);          // by value through the launch: no host buffer has to outlive the call
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+// bidirectional attention of n images in one launch (blockIdx.z = image): q rows / output planes of image i start at row
+// i * img_rows, its K^T / V blocks come from the table (SeqTab::kc / vc)
+int ddk_attn_vit_mfma_batch(const float* q, const SeqTab* tab, int n, int img_rows, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
+                            hipStream_t st, int head_pitch) {
+  DD_REQUIRE(head_pitch == 64 || head_pitch == 96, "attn_vit: head pitch %d (64, or 96 for 88-wide heads)", head_pitch);
+  dim3 grid(n_heads, (T + 63) / 64, n);
+  if (head_pitch == 96)
+    k_attn_prefill_mfma<1, 96><<<grid, 256, 0, st>>>(q, nullptr, nullptr, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 0, 1.0f, 0, T, tab, img_rows, 0, 0);
+  else
+    k_attn_prefill_mfma<1, 64><<<grid, 256, 0, st>>>(q, nullptr, nullptr, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 0, 1.0f, 0, T, tab, img_rows, 0, 0);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -37,6 +37,11 @@ struct dd_vit {
   // scratch
   float *x = nullptr, *q = nullptr, *kt = nullptr, *v = nullptr;
   uint16_t *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
+  // scratch of the batched forward (several images as one matrix), allocated on the first batch: bcap images of Tp rows
+  int bcap = 0, Tp = 0;
+  float *bx = nullptr, *bq = nullptr, *bkt = nullptr, *bv = nullptr;
+  uint16_t *ba_hi = nullptr, *ba_lo = nullptr, *bb_hi = nullptr, *bb_lo = nullptr;
+  SeqTab* btab = nullptr;
 };
 
 template <typename T>
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void k_pad_head_cols(const uint16_t* __restric
 // pixels [3][H][W] fp32 -> im2col rows (one per patch, k = c*p*p + ky*p + kx, zero-padded to Kp) as packed hi/lo planes
 // with a row offset of 1 (row 0 is the class token, filled elsewhere)
 __global__ __launch_bounds__(256) void k_vit_patchify(const float* __restrict__ px, int img, int p, int Kp, uint16_t* hi,
-                                                      uint16_t* lo) {
+                                                      uint16_t* lo, int row0 = 0) {
   int patch = blockIdx.x, g = img / p;
   int py = patch / g, pxx = patch % g;
   for (int k = threadIdx.x; k < Kp; k += 256) {
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void k_vit_patchify(const float* __restrict__ 
     }
     uint32_t h, l;
     dd_split_hl(v, h, l);
-    size_t o = apack_off(patch + 1, k, Kp >> 5);
+    size_t o = apack_off(row0 + patch + 1, k, Kp >> 5);
     hi[o] = (uint16_t)h;
     lo[o] = (uint16_t)l;
   }
@@ -246,13 +251,23 @@ __global__ __launch_bounds__(256) void k_vit_embed(float* x, const float* cls, c
     x[(size_t)row * d + i] = v + pos[(size_t)row * d + i];
   }
 }
+// the same for the tokens of several images back to back (Tp rows per image, T live ones)
+__global__ __launch_bounds__(256) void k_vit_embed_batch(float* x, const float* cls, const float* pos, int d, int T, int Tp) {
+  const int row = blockIdx.x, r = row % Tp;
+  if (r >= T) return;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float v = r == 0 ? cls[i] : x[(size_t)row * d + i];
+    x[(size_t)row * d + i] = v + pos[(size_t)r * d + i];
+  }
+}
 // LayerNorm (biased variance, fp32): out_f32 (optional, may alias x) and/or packed hi/lo planes at row (row + row_off)
+// img_out_rows > 0: a gather over images — output row j takes source row (j / img_out_rows) * img_src_rows + src_row0 + j % img_out_rows
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, int d, const float* __restrict__ w,
                                                    const float* __restrict__ b, float eps, float* out_f32, uint16_t* hi,
-                                                   uint16_t* lo, int src_row0) {
+                                                   uint16_t* lo, int src_row0, int img_out_rows = 0, int img_src_rows = 0) {
   __shared__ float sh[8];
   int row = blockIdx.x;
-  const float* xr = x + (size_t)(row + src_row0) * d;
+  const float* xr = x + (size_t)(img_out_rows ? (row / img_out_rows) * img_src_rows + src_row0 + row % img_out_rows : row + src_row0) * d;
   float s = 0.f;
   for (int i = threadIdx.x; i < d; i += 256) s += xr[i];
   s = dd_wave_sum(s);
@@ -343,11 +358,112 @@ __global__ __launch_bounds__(256) void k_attn_vit(const float* __restrict__ q, c
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------------
+// nb images at once: each image's T tokens padded to Tp (whole 128-row blocks) and all of them run through the layers as one
+// matrix (the GEMMs of one 577-token image are 5 row blocks: launch-bound at a seventh of the matrix-core rate), attention as
+// one launch over the images.  Rows are independent everywhere else, so the result equals nb single-image forwards bit for bit.
+static int vit_forward_batch(dd_vit* h, const float* pixels, int nb, float* out, hipStream_t st) {
+  const int d = h->d, dff = h->dff, T = h->T, P = h->P, img = h->cfg.image_size;
+  const size_t dq = (size_t)h->H * h->hp;
+  if (h->bcap < nb) {
+    DD_HIP(hipDeviceSynchronize());
+    const int cap = 16;
+    h->Tp = (T + 127) / 128 * 128;
+    const size_t M = (size_t)cap * h->Tp;
+    size_t wmax = (size_t)(dff > h->Kp ? dff : h->Kp);
+    if ((size_t)h->proj > wmax) wmax = h->proj;
+    size_t amax = d > h->Kp ? d : h->Kp;
+    if (dq > amax) amax = dq;
+    if (valloc(h, &h->bx, M * d) || valloc(h, &h->bq, M * dq) || valloc(h, &h->bkt, M * dq) || valloc(h, &h->bv, M * dq) ||
+        valloc(h, &h->ba_hi, M * amax) || valloc(h, &h->ba_lo, M * amax) || valloc(h, &h->bb_hi, M * wmax) || valloc(h, &h->bb_lo, M * wmax) ||
+        valloc(h, &h->btab, 1))
+      return DD_ENOMEM;
+    h->bcap = cap;
+  }
+  const int Tp = h->Tp, M = nb * Tp;
+  const size_t img_kv = (size_t)Tp * dq;                 // floats of one image's K^T (V) block
+  {
+    SeqTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int i = 0; i < nb; ++i) tab.T[i] = T, tab.kc[i] = h->bkt + (size_t)i * img_kv, tab.vc[i] = h->bv + (size_t)i * img_kv;
+    RC(ddk_put_seq_tab(tab, h->btab, st));
+  }
+  DD_HIP(hipMemsetAsync(h->ba_hi, 0, (size_t)M * h->Kp * 2, st));   // class-token and padding rows of the patch operand: zeros
+  DD_HIP(hipMemsetAsync(h->ba_lo, 0, (size_t)M * h->Kp * 2, st));
+  for (int i = 0; i < nb; ++i) {
+    k_vit_patchify<<<P, 256, 0, st>>>(pixels + (size_t)i * 3 * img * img, img, h->cfg.patch_size, h->Kp, h->ba_hi, h->ba_lo, i * Tp);
+    DD_CHECK_LAUNCH();
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = h->ba_hi, g.a_lo = h->ba_lo, g.M = M, g.S = h->Sp, g.W = h->wpatch, g.n_tiles = d / 16, g.bias = h->bpatch;
+  g.out = h->bx, g.ldo = d, g.n_valid = d;
+  RC(ddk_gemm(EPI_STORE, g, st));
+  k_vit_embed_batch<<<M, 256, 0, st>>>(h->bx, h->cls, h->pos, d, T, Tp);
+  DD_CHECK_LAUNCH();
+  if (!h->no_pre_ln) {
+    k_layernorm<<<M, 256, 0, st>>>(h->bx, d, h->prew, h->preb, h->cfg.ln_eps, h->bx, nullptr, nullptr, 0);
+    DD_CHECK_LAUNCH();
+  }
+  for (auto& w : h->lw) {
+    k_layernorm<<<M, 256, 0, st>>>(h->bx, d, w.ln1w, w.ln1b, h->cfg.ln_eps, nullptr, h->ba_hi, h->ba_lo, 0);
+    DD_CHECK_LAUNCH();
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->ba_hi, g.a_lo = h->ba_lo, g.M = M, g.S = d / 32, g.W = w.wqkv, g.n_tiles = 3 * d / 16, g.bias = w.bqkv;
+    g.qbuf = h->bq, g.kc = h->bkt, g.vc = h->bv, g.T_cap = Tp, g.vit_hidden = d, g.vit_head_dim = h->hd, g.vit_head_pad = h->hp;
+    g.vit_qscale = 1.0f / sqrtf((float)h->hd);
+    g.vit_img_rows = Tp, g.vit_T = T, g.vit_k_stride = img_kv, g.vit_v_stride = img_kv;
+    RC(ddk_gemm(EPI_QKV_VIT, g, st));
+    RC(ddk_attn_vit_mfma_batch(h->bq, h->btab, nb, Tp, T, Tp, h->H, h->ba_hi, h->ba_lo, st, h->hp));
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->ba_hi, g.a_lo = h->ba_lo, g.M = M, g.S = h->H * h->hp / 32, g.W = w.wo, g.n_tiles = d / 16, g.bias = w.bo;
+    g.out = h->bx, g.ldo = d;
+    RC(ddk_gemm(EPI_RESID, g, st));
+    k_layernorm<<<M, 256, 0, st>>>(h->bx, d, w.ln2w, w.ln2b, h->cfg.ln_eps, nullptr, h->ba_hi, h->ba_lo, 0);
+    DD_CHECK_LAUNCH();
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->ba_hi, g.a_lo = h->ba_lo, g.M = M, g.S = d / 32, g.W = w.wfc1, g.n_tiles = dff / 16, g.bias = w.bfc1;
+    g.act = h->cfg.act, g.o_hi = h->bb_hi, g.o_lo = h->bb_lo, g.ld_planes = dff;
+    RC(ddk_gemm(EPI_ACT, g, st));
+    memset(&g, 0, sizeof(g));
+    g.a_hi = h->bb_hi, g.a_lo = h->bb_lo, g.M = M, g.S = dff / 32, g.W = w.wfc2, g.n_tiles = d / 16, g.bias = w.bfc2;
+    g.out = h->bx, g.ldo = d;
+    RC(ddk_gemm(EPI_RESID, g, st));
+  }
+  if (!h->proj) {   // raw features of the selected layer, per image rows r0 .. r0 + nr - 1, optionally post-normed
+    const int r0 = h->keep_cls ? 0 : 1, nr = h->keep_cls ? T : P;
+    k_layernorm<<<nb * nr, 256, 0, st>>>(h->bx, d, h->post_ln ? h->postw : nullptr, h->post_ln ? h->postb : nullptr, h->cfg.ln_eps, out, nullptr,
+                                         nullptr, r0, nr, Tp);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
+  // projector on the P patch tokens of every image: gathered into nb * P contiguous rows = the layout of `out`
+  const int Mp = nb * P;
+  k_layernorm<<<Mp, 256, 0, st>>>(h->bx, d, nullptr, nullptr, 0.f, nullptr, h->ba_hi, h->ba_lo, 1, P, Tp);
+  DD_CHECK_LAUNCH();
+  memset(&g, 0, sizeof(g));
+  g.a_hi = h->ba_hi, g.a_lo = h->ba_lo, g.M = Mp, g.S = d / 32, g.W = h->wp1, g.n_tiles = h->proj / 16, g.bias = h->bp1;
+  g.act = 1, g.o_hi = h->bb_hi, g.o_lo = h->bb_lo, g.ld_planes = h->proj;
+  RC(ddk_gemm(EPI_ACT, g, st));
+  memset(&g, 0, sizeof(g));
+  g.a_hi = h->bb_hi, g.a_lo = h->bb_lo, g.M = Mp, g.S = h->proj / 32, g.W = h->wp2, g.n_tiles = h->proj / 16, g.bias = h->bp2;
+  g.out = out, g.ldo = h->proj, g.n_valid = h->proj;
+  RC(ddk_gemm(EPI_STORE, g, st));
+  return DD_OK;
+}
+
 extern "C" int dd_vit_forward(dd_vit* h, const float* pixels, int n_images, float* out, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && pixels && out && n_images >= 1, "dd_vit_forward: bad arguments");
   const int d = h->d, dff = h->dff, T = h->T, P = h->P, img = h->cfg.image_size;
   const int od = h->proj ? h->proj : d;
+  if (n_images > 1 && ddk_prefill_mfma_enabled()) {      // several images: their tokens as one matrix, up to 16 at a time
+    const int r_out = h->proj ? P : (h->keep_cls ? T : P);
+    for (int i0 = 0; i0 < n_images; i0 += 16) {
+      const int nb = n_images - i0 < 16 ? n_images - i0 : 16;
+      RC(vit_forward_batch(h, pixels + (size_t)i0 * 3 * img * img, nb, out + (size_t)i0 * r_out * od, st));
+    }
+    return DD_OK;
+  }
   for (int im = 0; im < n_images; ++im) {
     const float* px = pixels + (size_t)im * 3 * img * img;
     float* o = out + (size_t)im * P * od;

@@ -107,8 +107,12 @@ class DropoutVLM:
         return merged, start
 
     # ---- the boundary -------------------------------------------------------------------------
+    def _visual_embeds_batch(self, inputs_list: List[dict]) -> List[torch.Tensor]:
+        """_visual_embeds for several images; families whose tower takes a batch override this (one pass over the tower's weights)."""
+        return [self._visual_embeds(**inp) for inp in inputs_list]
+
     def _prepare(self, input_ids, max_new_tokens, max_length, num_beams, eos_token_id, do_sample, inputs, stream=None,
-                 defer_prefill: bool = False):
+                 defer_prefill: bool = False, visual: Optional[torch.Tensor] = None):
         """Everything of generate() up to and including the prefill; -> (input_ids on device, n_new, eos ids).
         defer_prefill: leave the LM prefill to the caller, who runs it for several lanes at once (`prefill_lanes`); what it needs
         is kept in self._deferred = (embeds, span start, span length), None when this call prefilled by itself."""
@@ -128,7 +132,8 @@ class DropoutVLM:
             eos = self.eos_token_ids if eos_token_id is None else (
                 list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
             return input_ids, max_new_tokens, eos
-        visual = self._visual_embeds(**inputs)
+        if visual is None:
+            visual = self._visual_embeds(**inputs)
         embeds, start = self._merge(input_ids, visual)
         L = visual.shape[0]
         # reference llava.py:218-226, 75-78, 285-286
@@ -261,6 +266,19 @@ def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens:
                          weight_format=wfmt, kv_format=settings.get("kv_cache", "fp16"))
 
 
+_NON_VISUAL_KEYS = ("input_ids", "attention_mask", "max_new_tokens", "max_length", "eos_token_id")
+
+
+@torch.no_grad()
+def _batched_visuals(model: "DropoutVLM", inputs: List[dict]) -> List[Optional[torch.Tensor]]:
+    """The visual tokens of several generate() inputs in one tower call where the family supports it (None entries: let
+    _prepare compute them — prefix reuse may make the tower unnecessary)."""
+    if not inputs or bool(settings.get("reuse_image_prefix", False)):
+        return [None] * len(inputs)
+    rest = [{k: v for k, v in kw.items() if k not in _NON_VISUAL_KEYS} for kw in inputs]
+    return list(model._visual_embeds_batch(rest))
+
+
 @torch.no_grad()
 def prefill_lanes(models: List["DropoutVLM"], stream=None, chunk: int = 16) -> None:
     """The deferred LM prefills of `models` (see _prepare(defer_prefill=True)), `chunk` sequences per pass over the weights
@@ -276,6 +294,7 @@ def prefill_lanes(models: List["DropoutVLM"], stream=None, chunk: int = 16) -> N
             m._deferred = None
 
 
+@torch.no_grad()
 def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens: Optional[int] = None, eos_token_id=None,
                    num_beams: int = 1, do_sample: bool = False, pad_token_id: Optional[int] = None) -> List[torch.LongTensor]:
     """`generate()` for up to 32 images at once: models[i] (a wrapper and its spawn_lane() copies) decodes inputs[i].
@@ -287,13 +306,14 @@ def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens:
     if len(models) != len(inputs) or not 1 <= len(models) <= 32:
         raise ValueError("generate_group: one model lane per input, 1..32 of them")
     prepared = []
-    for m, kw in zip(models, inputs):
+    visuals = _batched_visuals(models[0], inputs)
+    for m, kw, vis in zip(models, inputs, visuals):
         kw = dict(kw)
         kw.pop("attention_mask", None)
         ids = kw.pop("input_ids", None)
         mnt = kw.pop("max_new_tokens", max_new_tokens)
         prepared.append(m._prepare(ids, mnt, kw.pop("max_length", None), num_beams, kw.pop("eos_token_id", eos_token_id),
-                                   do_sample, kw, defer_prefill=True))
+                                   do_sample, kw, defer_prefill=True, visual=vis))
     prefill_lanes(models)
     n_new = {p[1] for p in prepared}
     eos = prepared[0][2]
@@ -344,18 +364,24 @@ class GroupPipeline:
 
     def _stage(self, lanes, batch, kw):
         """-> per-image closures that each enqueue one image's front-end + prefill on the second stream"""
-        state = {"prepared": [], "todo": list(zip(lanes, batch)), "event": None, "lanes": lanes[:len(batch)], "staged": []}
+        state = {"prepared": [], "todo": list(zip(lanes, batch)), "event": None, "lanes": lanes[:len(batch)], "staged": [], "vis": []}
 
         def unit() -> bool:
             if not state["todo"]:
                 return False
+            if not state["vis"]:                       # the vision tower for the next chunk of images, one call
+                with torch.cuda.stream(self.pre_stream):
+                    nxt = [inp for _, inp in state["todo"][:self.prefill_chunk]]
+                    state["vis"] = _batched_visuals(state["todo"][0][0], nxt)
+                return True
             m, inp = state["todo"].pop(0)
+            vis = state["vis"].pop(0)
             inp = dict(inp)
             inp.pop("attention_mask", None)
             with torch.cuda.stream(self.pre_stream):
                 state["prepared"].append(m._prepare(inp.pop("input_ids", None), inp.pop("max_new_tokens", kw["max_new_tokens"]),
                                                     inp.pop("max_length", None), 1, inp.pop("eos_token_id", kw["eos_token_id"]),
-                                                    False, inp, stream=self.pre_stream, defer_prefill=True))
+                                                    False, inp, stream=self.pre_stream, defer_prefill=True, visual=vis))
                 state["staged"].append(m)
                 if not state["todo"] or len(state["staged"]) >= self.prefill_chunk:
                     prefill_lanes(state["staged"], stream=self.pre_stream, chunk=self.prefill_chunk)   # one pass over the weights

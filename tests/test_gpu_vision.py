@@ -187,3 +187,40 @@ def test_qformer_and_language_projection_tiny_and_full_size(built):
         qf.close()
         del hf
         torch.cuda.empty_cache()
+
+
+def test_batched_tower_equals_single_image_calls_bitwise(built):
+    """Several images per call run through the tower as one matrix (each image padded to whole 128-row blocks, one attention
+    launch over the images): the result must be, bit for bit, what one call per image gives — CLIP tower + projector (LLaVA),
+    the raw-feature form, and the EVA form (class token kept, post-LayerNorm, heads of 88)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel, InstructBlipVisionConfig, InstructBlipVisionModel, LlavaConfig, LlamaConfig
+    from transformers.models.llava.modeling_llava import LlavaMultiModalProjector
+    from dropoutdecoding_amd.vision import ClipTowerHIP
+    torch.manual_seed(0)
+    vc = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4, image_size=112,
+                          patch_size=14, projection_dim=32)          # 65 tokens -> 128 rows per image
+    tc = LlamaConfig(vocab_size=64, hidden_size=256, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2)
+    cfg = LlavaConfig(vision_config=vc, text_config=tc, vision_feature_layer=-2, vision_feature_select_strategy="default")
+    vt = _bf16_(CLIPVisionModel(vc).eval())
+    proj = _bf16_(LlavaMultiModalProjector(cfg).eval())
+    px = torch.randn(19, 3, 112, 112, generator=torch.Generator().manual_seed(1)).cuda()    # 16 + 3: two chunks
+    for tower in (ClipTowerHIP.from_hf(vt, proj, feature_layer=-2), ClipTowerHIP.from_hf(vt, None, feature_layer=-2)):
+        one = torch.cat([tower(px[i:i + 1]) for i in range(px.shape[0])])
+        many = tower(px)
+        assert many.shape == one.shape
+        assert torch.equal(many, one)
+        tower.close()
+    assert close(many[:3].cpu().numpy(), _ref(vt, None, px[:3].cpu()).numpy())
+    ec = InstructBlipVisionConfig(hidden_size=704, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8, image_size=56,
+                                  patch_size=14)
+    ev = InstructBlipVisionModel(ec).eval().cuda()
+    for p in ev.parameters():
+        p.copy_(p.to(torch.bfloat16).float())
+    tower = ClipTowerHIP.from_hf_instructblip(ev)
+    px = torch.randn(4, 3, 56, 56, generator=torch.Generator().manual_seed(2)).cuda()
+    one = torch.cat([tower(px[i:i + 1]) for i in range(4)])
+    many = tower(px)
+    assert torch.equal(many, one)
+    want = ev(px).last_hidden_state.float()
+    assert float((many - want).abs().max() / want.abs().max()) < 1e-3
+    tower.close()
