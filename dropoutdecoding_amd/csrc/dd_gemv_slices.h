@@ -278,3 +278,119 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
     }
   }
 }
+
+// Slice PAIRS with one slice resident at a time (the eight-plane pass: a pair does not fit the LDS).  A workgroup owns the pair
+// (2 qs, 2 qs + 1) for its tile groups (one tile each, up to MAXG per wave): it takes slice 2 qs into LDS, streams that slice of
+// all its tiles keeping each tile's folded sum in registers, swaps slice 2 qs + 1 in, streams again, adds, and writes ONE
+// partial sum per pair — half the partial-sum traffic of single slices (gate/up at 64 rows: 22.5 instead of 45 MB written and
+// read back) for a second operand load per workgroup.  Same chains, same order: (hi+lo)(2p) + (hi+lo)(2p+1) as the pair kernels.
+// grid = 4 * G workgroups of 512 threads; dynamic LDS = SPW * NG KiB; a.part laid out for NP = 4.
+template <int NG, int U, int SPW, int MAXG, int WF = 0, int EPI_TAG = 0>
+__global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
+  static_assert(SPW % U == 0, "ring depth must divide the slice");
+  constexpr int PW = (SPW * NG + 7) / 8;               // operand pieces (1 KiB) per wave and slice
+  constexpr int NB = SPW / U;
+  extern __shared__ __align__(16) u32x4_t xs[];        // [SPW][NG][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qs = blockIdx.x & 3, j = blockIdx.x >> 2;
+  const size_t xplane = (size_t)a.S * 64;
+  const int n_tiles = a.n_groups;
+  if (blockIdx.x == 0 && a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+  const size_t wstep = 8 * 64;
+  int gidx[MAXG];
+  int ng = 0;
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    gidx[i] = j + a.G * (wave + 8 * i);
+    if (gidx[i] < n_tiles) ng = i + 1;
+  }
+  auto wptr = [&](int item) -> const u32x4_t* {        // item = slice half * MAXG + group slot (clamped to a live group)
+    const int half = item / MAXG, gi = item % MAXG;
+    const int g = gidx[gi < ng ? gi : 0] < n_tiles ? gidx[gi < ng ? gi : 0] : 0;
+    return a.W + ((size_t)g * a.S + 2 * qs + half) * 64 + lane;
+  };
+  auto stage = [&](int half) {                         // operand slice 2 qs + half -> LDS (all waves)
+    u32x4_t xv[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      int p = wave + 8 * i;
+      int pc = p < SPW * NG ? p : 0;
+      xv[i] = a.xop[(size_t)(2 * qs + half + 8 * (pc / NG)) * 64 + (pc % NG) * xplane + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      int p = wave + 8 * i;
+      if (p < SPW * NG) xs[(size_t)p * 64 + lane] = xv[i];
+    }
+  };
+  auto fold = [&](f32x4_t v) -> f32x4_t {
+    v.x += __shfl_down(v.x, 8);
+    v.y += __shfl_down(v.y, 8);
+    v.z += __shfl_down(v.z, 8);
+    v.w += __shfl_down(v.w, 8);
+    return v;
+  };
+  f32x4_t sum[MAXG][NG];
+  // the ring runs over the wave's items (slice half, group) in order; the next item's first U tiles are requested while the
+  // current item's last block is consumed — also across the operand swap
+  u32x4_t w[U];
+  {
+    const u32x4_t* p0 = wptr(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(p0 + (size_t)u * wstep);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  stage(0);
+  __syncthreads();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int gi = 0; gi < MAXG; ++gi) {
+      const int item = half * MAXG + gi;
+      const bool live = gi < ng;                       // wave-uniform
+      const bool last_item = item == 2 * MAXG - 1;
+      const u32x4_t* wp = wptr(item);
+      const u32x4_t* wn = wptr(last_item ? item : item + 1);
+      f32x4_t acc[NG];
+#pragma unroll
+      for (int h = 0; h < NG; ++h) acc[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (live) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int s = blk * U + u;
+            u32x4_t b[NG];
+#pragma unroll
+            for (int h = 0; h < NG; ++h) b[h] = xs[(size_t)(s * NG + h) * 64 + lane];
+#pragma unroll
+            for (int h = 0; h < NG; ++h) acc[h] = dd_mfma16<WF>(w[u], b[h], acc[h]);
+            if (blk + 1 < NB) w[u] = __builtin_nontemporal_load(wp + (size_t)(s + U) * wstep);
+            else if (!last_item) w[u] = __builtin_nontemporal_load(wn + (size_t)u * wstep);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < NG; ++h) {
+          f32x4_t f = fold(acc[h]);
+          if (half == 0) sum[gi][h] = f;
+          else sum[gi][h] = sum[gi][h] + f;            // (hi+lo)(2p) + (hi+lo)(2p+1)
+        }
+        if (half == 1 && (lane & 8) == 0) {
+          const int l32 = (lane >> 4) * 8 + (lane & 7);
+#pragma unroll
+          for (int h = 0; h < NG; ++h)
+            *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + gidx[gi]) * NG + h) << 7) + l32 * 4] = sum[gi][h];
+        }
+      } else if (!last_item) {                         // a slot this wave does not have: hand the ring to the next item
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wn + (size_t)u * wstep);
+      }
+    }
+    if (half == 0) {
+      __syncthreads();                                 // every wave has finished reading slice 2 qs
+      stage(1);
+      __syncthreads();
+    }
+  }
+}

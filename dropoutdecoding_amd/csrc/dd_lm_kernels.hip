@@ -940,9 +940,27 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
       launch_finish<EPI_RESID, 1, 8, 8>(a, nt, st);
     } else {
       if (spw != 16) return SLICES_UNSUPPORTED;
-      sa.G = g_exp_G[2] ? g_exp_G[2] : (nt + 42) / 43;
-      RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_SILU>(sa, a.wf, st));
-      launch_finish<EPI_SILU, 2, 8, 8>(a, a.n_tiles, st);
+      if (g_exp_G[2] >= 0 && 4 * ((nt + 23) / 24) <= 256) {
+        // slice pairs, one slice resident at a time: half the partial sums.  Three tiles per wave, as evenly as the tile count
+        // allows, in ONE round of workgroups (LLaVA-7B: 58 per pair = 232): 27.25 vs 27.75 ms per 32-lane step; 64 per pair
+        // (2.7 tiles per wave: uneven) 28.6, 86 (two tiles, 1.3 rounds) 29.1.  Tuning key 19 < 0: single slices (A/B)
+        sa.G = g_exp_G[2] ? g_exp_G[2] : (nt + 23) / 24;
+        constexpr size_t smem = (size_t)16 * 8 * 1024;
+        static bool attr = false;
+        if (!attr) {
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 3, 0, EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 3, 1, EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          attr = true;
+        }
+        DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
+        if (a.wf) k_gemv_slices_seq<8, 8, 16, 3, 1, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        else k_gemv_slices_seq<8, 8, 16, 3, 0, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        launch_finish<EPI_SILU, 2, 8, 4>(a, a.n_tiles, st);
+      } else {
+        sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 42) / 43;
+        RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_SILU>(sa, a.wf, st));
+        launch_finish<EPI_SILU, 2, 8, 8>(a, a.n_tiles, st);
+      }
     }
     return DD_OK;
   } else if (epi == EPI_QKV) {

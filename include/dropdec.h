@@ -487,7 +487,8 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * single-sequence steps (default 1; 0: always two sweeps, same results), 15 = XCD-aware block order of the prefill GEMM
  * (default 1; 0: row-major block order, same bits), 16 = rows from which the prefill GEMM uses its 128 x 512 LDS-staged
  * block (default 1024; 0: never; same bits), 17 / 18 / 19 = workgroups per K slice of the 64-row qkv / o_proj / gate-up GEMV
- * (0: default; same bits; 18 < 0: the eight-plane o_proj kernel instead of two four-plane half passes).  9 also takes 8 (default):
+ * (0: default; same bits; 18 < 0: the eight-plane o_proj kernel instead of two four-plane half passes; 19 < 0: single K slices
+ * for gate/up instead of slice pairs with one slice resident at a time).  9 also takes 8 (default):
  * the members of eight sequences per pass over the weights.  21 = key tiles per workgroup of the fp16-cache decode attention
  * (0, default: sized so that a launch is one round of workgroups; same bits).
  * Keys 1 and 2 are accepted and ignored (settled: non-temporal weight loads, interleaved k-steps). */
