@@ -311,10 +311,11 @@ def main() -> int:
     dom_rows = (64 if B >= 8 else (32 if B >= 4 else 16)) if wide else rows8
     ms_pair, by = eng.time_gemv(2, dom_rows, 96)                       # the whole GEMV (both kernels when wide)
     ms = eng.time_gemv(2 + 8, dom_rows, 96)[0] if wide else ms_pair    # the streaming kernel alone
-    dom_kernel = (f"k_gemv_slices<1, {dom_rows // 8}, 8, 16, 16, {1 if dom_rows == 64 else 2}, 0, 2>" if wide
-                  else "k_gemv<2, 2, 8, 1, 1, 0, 0>")
+    dom_kernel = ("k_gemv_slices_seq<8, 8, 16, 3, 0, 2>" if dom_rows == 64 else f"k_gemv_slices<1, {dom_rows // 8}, 8, 16, 16, 2, 0, 2>") if wide \
+        else "k_gemv<2, 2, 8, 1, 1, 0, 0>"
     dom_name = (f"{dom_kernel} (gate/up decode GEMV of a {dom_rows}-row pass = the members of {dom_rows // 8} sequences: streams the 180 MB of "
-                "weights once; its finishing kernel k_gemv_finish adds the K slices and applies SiLU*up)") if wide \
+                "weights once, K in 4 slice pairs (64 rows: one slice of a pair resident in LDS at a time); its finishing kernel k_gemv_finish adds the "
+                "pairs' partial sums and applies SiLU*up)") if wide \
         else f"{dom_kernel} (gate/up decode GEMV, 8 rows)"
     achieved = by / (ms * 1e-3) / 1e9
     sweep_ms = eng.time_sweep(rows8, 5)
@@ -393,7 +394,7 @@ def main() -> int:
                          "mfma_util": mfma_util,     # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), same PMC summary
                          "rows_per_launch": dom_rows,
                          # frac counts the ALGORITHMIC bytes (the weights); the kernel also writes its K-slice partial sums (the
-                         # 8 slices x 64 rows x 22016 columns a finishing kernel adds up): HBM bytes actually moved / duration
+                         # 4 slice pairs x 64 rows x 22016 columns a finishing kernel adds up): HBM bytes actually moved / duration
                          "traffic_frac": (round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                          "gate_up_streaming_kernel_by_rows": rows_cmp,
                          "bytes_per_launch": by, "ms_per_launch": round(ms, 5),

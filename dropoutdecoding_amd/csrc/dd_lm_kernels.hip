@@ -919,9 +919,25 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
       if (spw != 16) return SLICES_UNSUPPORTED;
       // workgroups per slice: one round of 8 * G <= 256 workgroups (one per CU: 128 KiB of operands each) measured best inside
       // the sweep (32 lanes: 32.6 -> 31.6 ms per group step for the three choices together)
-      sa.G = g_exp_G[0] ? g_exp_G[0] : (nt + 31) / 32;
-      RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_QKV>(sa, a.wf, st));
-      launch_finish<EPI_QKV, 1, 8, 8>(a, nt, st);
+      if (g_exp_G[0] >= 0 && (nt % 16) == 0 && nt / 16 * 4 <= 256) {
+        // slice pairs, one slice resident at a time (see gate/up below): two tiles per wave; tuning key 17 < 0: single slices (A/B)
+        sa.G = g_exp_G[0] ? g_exp_G[0] : nt / 16;
+        constexpr size_t smem = (size_t)16 * 8 * 1024;
+        static bool attr = false;
+        if (!attr) {
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 2, 0, EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 2, 1, EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          attr = true;
+        }
+        DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
+        if (a.wf) k_gemv_slices_seq<8, 8, 16, 2, 1, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        else k_gemv_slices_seq<8, 8, 16, 2, 0, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        launch_finish<EPI_QKV, 1, 8, 4>(a, nt, st);
+      } else {
+        sa.G = g_exp_G[0] > 0 ? g_exp_G[0] : (nt + 31) / 32;
+        RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_QKV>(sa, a.wf, st));
+        launch_finish<EPI_QKV, 1, 8, 8>(a, nt, st);
+      }
     } else if (epi == EPI_RESID) {
       sa.G = (nt + 7) / 8;
       if (spw == 16 && g_exp_G[1] < 0) {                       // tuning key 18 < 0: the eight-plane kernel (A/B)
