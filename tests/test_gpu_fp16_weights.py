@@ -85,17 +85,17 @@ def test_fp16_weights_exact_against_the_oracle(E, family, K):
 
 @pytest.mark.parametrize("wfmt,kvfmt", [("fp16", "fp16"), ("fp16", "fp32"), ("bf16", "fp16")])
 def test_fp16_weights_lanes_speculation_and_7b_shape_kernels(E, wfmt, kvfmt):
-    """Every kernel family with the f16 MFMA: lanes (slice-resident 32-row GEMVs at 7B shapes) bit-identical to solo runs,
-    speculative and two-sweep steps equal, the prefill GEMMs at M = 608."""
+    """Every kernel family with the f16 MFMA: nine lanes (one 64-row member pass through the eight-plane slice kernels at 7B
+    shapes + one 8-row pass; 32-row fused base pass) bit-identical to solo runs, speculative and two-sweep steps equal."""
     cfg = E.LMConfig(2048, 4096, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
     L = 24
     engines = []
-    for i in range(4):
+    for i in range(9):
         engines.append(E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=L + 96, max_visual=L, seed=50 + i, weight_format=wfmt,
                                        kv_format=kvfmt, share_weights_with=engines[0] if engines else None))
     engines[0].load_synthetic(3, 0.02)
     gen = torch.Generator().manual_seed(9)
-    embs = [(torch.randn(L + 6 + i, 4096, generator=gen) * 0.5).cuda() for i in range(4)]
+    embs = [(torch.randn(L + 6 + i, 4096, generator=gen) * 0.5).cuda() for i in range(9)]
     probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
     for e, x in zip(engines, embs):
         e.prefill(x, 2, L)
@@ -110,13 +110,14 @@ def test_fp16_weights_lanes_speculation_and_7b_shape_kernels(E, wfmt, kvfmt):
     for spec in (1, 0):
         lib.dd_set_tuning(14, spec)
         try:
-            e = engines[2]
-            e.rng.manual_seed(52)
-            e.prefill(embs[2], 2, L)
-            for s in range(4):
-                e.decode_step(probs)
-                np.testing.assert_array_equal(e.logits(), recs[s][2], err_msg=f"spec={spec} step {s}")
-            assert e.tokens() == toks[2]
+            for li in (2, 8):                                  # a lane of the 64-row pass, and the one of the 8-row pass
+                e = engines[li]
+                e.rng.manual_seed(50 + li)
+                e.prefill(embs[li], 2, L)
+                for s in range(4):
+                    e.decode_step(probs)
+                    np.testing.assert_array_equal(e.logits(), recs[s][li], err_msg=f"spec={spec} lane {li} step {s}")
+                assert e.tokens() == toks[li]
         finally:
             lib.dd_set_tuning(14, 1)
     for e in reversed(engines):
