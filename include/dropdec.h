@@ -397,7 +397,9 @@ int dd_vit_create(const dd_vit_config* cfg, dd_vit** out);
 int dd_vit_destroy(dd_vit* h);
 int dd_vit_load_tensor(dd_vit* h, int tensor_id, int layer, const uint16_t* src_bf16, int rows, int cols, int src_on_device);
 /* pixels_dev [n_images][3][H][W] fp32 (already normalised) -> out_dev [n_images][P][proj_dim or hidden] fp32
- * ([n_images][P + 1][hidden] with DD_VIT_KEEP_CLASS) */
+ * ([n_images][P + 1][hidden] with DD_VIT_KEEP_CLASS).  Several images per call run through the tower as one matrix, 16 at a
+ * time (each image's tokens padded to whole 128-row blocks, one attention launch over the images): the same values as one call
+ * per image, at 2.0 instead of 5.3 ms per image for CLIP-ViT-L/14-336 + projector. */
 int dd_vit_forward(dd_vit* h, const float* pixels_dev, int n_images, float* out_dev, void* stream);
 
 /* ---- InstructBLIP Q-Former + language projection on own kernels ---------------------------------------------------------
