@@ -614,11 +614,12 @@ def test_group_generate_with_uneven_stops_and_stock_greedy(E):
 
 
 def test_full_size_lanes_equal_solo_runs_bitwise(E):
-    """BASELINE size (LLaVA-1.5-7B shapes, K = 8): 6 lanes decoded as a group (fused base pass, one 4-sequence and one
-    2-sequence member sweep: the full-length k loops and the K = 11008 tail of k_gemv_groups) == each lane alone,
-    bit for bit — logits, masks, tokens, KV checksums."""
+    """BASELINE size (LLaVA-1.5-7B shapes, K = 8): 11 lanes decoded as a group (fused base pass in two operand planes, one
+    8-sequence = 64-row member sweep through the slice-pair kernels, one 2-sequence sweep and one single: every row width at
+    full depth) == each lane alone, bit for bit — logits, masks, tokens, KV checksums."""
     probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
-    shapes = [(608, 5, 576), (640, 9, 576), (600, 1, 576), (615, 20, 576), (609, 5, 576), (700, 60, 576)]   # tiles 10 / 11
+    shapes = [(608, 5, 576), (640, 9, 576), (600, 1, 576), (615, 20, 576), (609, 5, 576), (700, 60, 576),   # tiles 10 / 11
+              (610, 3, 576), (633, 7, 576), (655, 11, 576), (602, 2, 576), (690, 33, 576)]
     engs = []
     for i in range(len(shapes)):
         engs.append(E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=768, max_visual=576, seed=5217,
