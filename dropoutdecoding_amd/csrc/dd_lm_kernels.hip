@@ -1406,36 +1406,33 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
   }
 }
 
-// grid (n_heads, nb), block 128 (thread = d): merges the tiles of one (head, row), adds the row's own new key/value
-// (each ensemble member attends to the shared prefix + ITS OWN new token), packs hi/lo for o_proj.
-template <int NBT, int G>
-__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits_grid) {
-  constexpr int R = NBT * G;
-  __shared__ float red[2];
-  __shared__ float w_sh[ATT_MAX_SPLITS];
-  __shared__ float mx_sh[2], den_sh[2];
-  if (a.skip_if && *a.skip_if) return;
-  const int head = blockIdx.x, m = blockIdx.y, d = threadIdx.x, kvh = head / G, g = head % G;
+// Merge of the tiles of one (head, row) + the row's own new key / value (each ensemble member attends to the shared prefix + ITS
+// OWN new token) + hi/lo packing for o_proj: 128 threads (thread = output dimension d), shared by the stand-alone kernel
+// (tiles from the partial buffers in memory) and by the all-tiles form of k_attn_partial16 (tiles still in LDS) — ONE body, with
+// explicit fused multiply-adds, so that a row's bits do not depend on which of the two produced it.
+// ld_ml(tile) -> (max, sum) of the tile for this row; ld_o(tile) -> its un-normalised output at dimension d.
+// sh: 2 + ATT_MAX_SPLITS + 2 + 2 floats of shared memory for this group of 128 threads.
+#define ATT_COMB_SH (2 + ATT_MAX_SPLITS + 2 + 2)
+template <typename LD_ML, typename LD_O>
+__device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int head, int kvh, int m, bool wide, int d, int splits, float* sh,
+                                                  LD_ML ld_ml, LD_O ld_o) {
+  float* red = sh;
+  float* w_sh = sh + 2;
+  float* mx_sh = sh + 2 + ATT_MAX_SPLITS;
+  float* den_sh = mx_sh + 2;
   const int lane = d & 63, wv = d >> 6;
   const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
   const float scaling = 0.08838834764831845f;
-  const int r = g * NBT + m;
-  // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
-  // has the tiles of its own, possibly shorter, sequence
-  const int splits = a.n_lanes ? (a.lane_state[a.lane_groups ? m >> 3 : m]->T + ATT_SPLIT - 1) / ATT_SPLIT
-                               : (a.state ? (a.state->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid);
-  const int grp = NBT > 8 ? m >> 3 : 0;               // group of the row (multi-group passes)
-  const float* knew_r = (NBT > 8 && a.knew_g[grp]) ? a.knew_g[grp] + (size_t)(m & 7) * kv_dim : a.knew + (size_t)m * kv_dim;
-  const float* vnew_r = (NBT > 8 && a.vnew_g[grp]) ? a.vnew_g[grp] + (size_t)(m & 7) * kv_dim : a.vnew + (size_t)m * kv_dim;
+  const int grp = wide ? m >> 3 : 0;                  // group of the row (multi-group passes)
+  const float* knew_r = (wide && a.knew_g[grp]) ? a.knew_g[grp] + (size_t)(m & 7) * kv_dim : a.knew + (size_t)m * kv_dim;
+  const float* vnew_r = (wide && a.vnew_g[grp]) ? a.vnew_g[grp] + (size_t)(m & 7) * kv_dim : a.vnew + (size_t)m * kv_dim;
   // every load of this block is issued here, before the first dependent use
   float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
   float kd = knew_r[kvh * HEAD_DIM + d];
   float vd = vnew_r[kvh * HEAD_DIM + d];
-  const float* mlb = a.part_ml + ((size_t)kvh * splits_grid * R + r) * 2;
-  const size_t ml_stride = (size_t)R * 2;
   float ms0 = -INFINITY, ls0 = 0.f, ms1 = -INFINITY, ls1 = 0.f;   // two tiles per thread: up to 256 tiles
-  if (d < splits) { ms0 = mlb[d * ml_stride]; ls0 = mlb[d * ml_stride + 1]; }
-  if (d + 128 < splits) { ms1 = mlb[(d + 128) * ml_stride]; ls1 = mlb[(d + 128) * ml_stride + 1]; }
+  if (d < splits) ld_ml(d, ms0, ls0);
+  if (d + 128 < splits) ld_ml(d + 128, ms1, ls1);
   float part = dd_wave_sum(qd * kd);
   float mloc = dd_wave_max(fmaxf(ms0, ms1));
   if (lane == 0) { red[wv] = part; mx_sh[wv] = mloc; }
@@ -1445,25 +1442,36 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   float w0 = (ms0 == -INFINITY) ? 0.f : expf(ms0 - M), w1 = (ms1 == -INFINITY) ? 0.f : expf(ms1 - M);
   if (d < splits) w_sh[d] = w0;
   if (d + 128 < splits) w_sh[d + 128] = w1;
-  float dl = dd_wave_sum(w0 * ls0 + w1 * ls1);
+  float dl = dd_wave_sum(__builtin_fmaf(w1, ls1, w0 * ls0));
   if (lane == 0) den_sh[wv] = dl;
   __syncthreads();
   float w_self = expf(s_self - M);
   float den = w_self + (den_sh[0] + den_sh[1]);
   float num = w_self * vd;
+  for (int sp = 0; sp < splits; ++sp) num = __builtin_fmaf(w_sh[sp], ld_o(sp), num);
+  if (wide) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5, a.wf);
+  else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den, a.wf);
+}
+
+// grid (n_heads, nb), block 128 (thread = d): the merge above over the partial buffers in memory
+template <int NBT, int G>
+__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits_grid) {
+  constexpr int R = NBT * G;
+  __shared__ float sh[ATT_COMB_SH];
+  if (a.skip_if && *a.skip_if) return;
+  const int head = blockIdx.x, m = blockIdx.y, d = threadIdx.x, kvh = head / G, g = head % G;
+  const int r = g * NBT + m;
+  // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
+  // has the tiles of its own, possibly shorter, sequence
+  const int splits = a.n_lanes ? (a.lane_state[a.lane_groups ? m >> 3 : m]->T + ATT_SPLIT - 1) / ATT_SPLIT
+                               : (a.state ? (a.state->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid);
+  const float* mlb = a.part_ml + ((size_t)kvh * splits_grid * R + r) * 2;
+  const size_t ml_stride = (size_t)R * 2;
   const float* po = a.part_o + ((size_t)kvh * splits_grid * R + r) * HEAD_DIM + d;
   const size_t o_stride = (size_t)R * HEAD_DIM;
-  int sp = 0;
-  for (; sp + 8 <= splits; sp += 8) {
-    float o[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) o[u] = po[(size_t)(sp + u) * o_stride];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) num += w_sh[sp + u] * o[u];
-  }
-  for (; sp < splits; ++sp) num += w_sh[sp] * po[(size_t)sp * o_stride];
-  if (NBT > 8) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5, a.wf);
-  else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den, a.wf);
+  attn_combine_core(
+      a, head, kvh, m, NBT > 8, d, splits, sh, [&](int t, float& mx, float& l) { mx = mlb[t * ml_stride], l = mlb[t * ml_stride + 1]; },
+      [&](int t) -> float { return po[(size_t)t * o_stride]; });
 }
 
 // Key tiles the partial kernel is LAUNCHED with: the live count rounded up to a multiple of 4 (workgroups of tiles past
