@@ -2067,7 +2067,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // Tuning hook for the benchmark scripts (not part of the reference's surface): 0 = GEMV loads in flight per wave
 // (4/8/16), 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves (0/1).
 extern "C" int dd_set_tuning(int key, int value) {
-  DD_REQUIRE((key >= 0 && key <= 4 && key != 3) || (key >= 8 && key <= 21 && key != 20), "dd_set_tuning: unknown key %d", key);
+  DD_REQUIRE((key >= 0 && key <= 4 && key != 3) || (key >= 8 && key <= 22 && key != 20), "dd_set_tuning: unknown key %d", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 10) ddk_set_attn_split(value);
   else if (key == 11) dd_engine_set_extend_rows(value);
@@ -2079,6 +2079,7 @@ extern "C" int dd_set_tuning(int key, int value) {
   else if (key == 16) ddk_set_gemm_big_rows(value);
   else if (key >= 17 && key <= 19) { extern int g_exp_G[4]; g_exp_G[key - 17] = value; }
   else if (key == 21) { extern int g_attn16_tpw; g_attn16_tpw = value; }
+  else if (key == 22) { extern int g_attn16_full; g_attn16_full = value; }
   else ddk_set_tuning(key, value);
   return DD_OK;
 }

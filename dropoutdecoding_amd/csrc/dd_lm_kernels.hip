@@ -1213,6 +1213,54 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   }
 }
 
+// Merge of the tiles of one (head, row) + the row's own new key / value (each ensemble member attends to the shared prefix + ITS
+// OWN new token) + hi/lo packing for o_proj: 128 threads (thread = output dimension d), shared by the stand-alone kernel
+// (tiles from the partial buffers in memory) and by the all-tiles form of k_attn_partial16 (tiles still in LDS) — ONE body, with
+// explicit fused multiply-adds, so that a row's bits do not depend on which of the two produced it.
+// ld_ml(tile) -> (max, sum) of the tile for this row; ld_o(tile) -> its un-normalised output at dimension d.
+// sh: 2 + ATT_MAX_SPLITS + 2 + 2 floats of shared memory for this group of 128 threads.
+#define ATT_COMB_SH (2 + ATT_MAX_SPLITS + 2 + 2)
+template <typename LD_ML, typename LD_O>
+__device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int head, int kvh, int m, bool wide, int d, int splits, float* sh,
+                                                  LD_ML ld_ml, LD_O ld_o, bool store = true) {
+  float* red = sh;
+  float* w_sh = sh + 2;
+  float* mx_sh = sh + 2 + ATT_MAX_SPLITS;
+  float* den_sh = mx_sh + 2;
+  const int lane = d & 63, wv = d >> 6;
+  const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
+  const float scaling = 0.08838834764831845f;
+  const int grp = wide ? m >> 3 : 0;                  // group of the row (multi-group passes)
+  const float* knew_r = (wide && a.knew_g[grp]) ? a.knew_g[grp] + (size_t)(m & 7) * kv_dim : a.knew + (size_t)m * kv_dim;
+  const float* vnew_r = (wide && a.vnew_g[grp]) ? a.vnew_g[grp] + (size_t)(m & 7) * kv_dim : a.vnew + (size_t)m * kv_dim;
+  // every load of this block is issued here, before the first dependent use
+  float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
+  float kd = knew_r[kvh * HEAD_DIM + d];
+  float vd = vnew_r[kvh * HEAD_DIM + d];
+  float ms0 = -INFINITY, ls0 = 0.f, ms1 = -INFINITY, ls1 = 0.f;   // two tiles per thread: up to 256 tiles
+  if (d < splits) ld_ml(d, ms0, ls0);
+  if (d + 128 < splits) ld_ml(d + 128, ms1, ls1);
+  float part = dd_wave_sum(qd * kd);
+  float mloc = dd_wave_max(fmaxf(ms0, ms1));
+  if (lane == 0) { red[wv] = part; mx_sh[wv] = mloc; }
+  __syncthreads();
+  float s_self = (red[0] + red[1]) * scaling;
+  float M = fmaxf(s_self, fmaxf(mx_sh[0], mx_sh[1]));
+  float w0 = (ms0 == -INFINITY) ? 0.f : expf(ms0 - M), w1 = (ms1 == -INFINITY) ? 0.f : expf(ms1 - M);
+  if (d < splits) w_sh[d] = w0;
+  if (d + 128 < splits) w_sh[d + 128] = w1;
+  float dl = dd_wave_sum(__builtin_fmaf(w1, ls1, w0 * ls0));
+  if (lane == 0) den_sh[wv] = dl;
+  __syncthreads();
+  float w_self = expf(s_self - M);
+  float den = w_self + (den_sh[0] + den_sh[1]);
+  float num = w_self * vd;
+  for (int sp = 0; sp < splits; ++sp) num = __builtin_fmaf(w_sh[sp], ld_o(sp), num);
+  if (!store) return;
+  if (wide) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5, a.wf);
+  else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den, a.wf);
+}
+
 // The same tile pass for the fp16 cache on the matrix cores.  The VALU form above costs ~1,100 vector instructions per wave and
 // tile at 8 rows — the grouped decode attention ran at 2.3 TB/s of K/V bytes, bound by them, not by HBM.  Here
 //   S^T = K . Q^T :  A = the 16-byte chunks of K as the cache stores them (16 keys x 32 d per fragment), B = the rows' q split
@@ -1221,9 +1269,17 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 //                    wave w takes output dimensions 32w..32w+31, so no cross-wave reduction of the outputs is needed.
 // Tile softmax statistics, masks, buffers and row maps are those of k_attn_partial; all variants (rows alone, members of one
 // sequence, lanes, groups) go through this one body, so a row's bits do not depend on the pass it rides in.
-template <int NBT, int G, int GH, int ML>
+// FULL: the workgroup takes ALL tiles of its (kv head, sequence) — contexts of up to ATT_FULL_TILES tiles —, keeps the tiles'
+// statistics and outputs in LDS instead of the partial buffers and runs the merge itself (attn_combine_core, the body the
+// stand-alone k_attn_combine runs over the buffers): no partial-buffer round trip, no second launch, the same bits.
+#define ATT_FULL_TILES 12
+template <int NBT, int G, int GH, int ML, int FULL = 0>
 __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
   constexpr int R = NBT * GH, RB = (R + 7) / 8, RP = RB * 8;
+  extern __shared__ __align__(16) float full_sh[];        // FULL: [tiles][RP][HEAD_DIM] outputs, then [tiles][RP][2] statistics
+  float* const fo_sh = full_sh;
+  float* const fml_sh = full_sh + (size_t)ATT_FULL_TILES * RP * HEAD_DIM;
+  __shared__ float comb_sh[FULL ? 2 : 1][FULL ? ATT_COMB_SH : 1];
   const int lane_rows = a.n_lanes > 8 ? 16 : 8;
   const int RT = ML == 1 ? lane_rows * G : (ML == 2 ? 8 * a.lane_groups * G : NBT * G);
   constexpr int MSPLIT = ML == 2 ? 8 / NBT : 1;
@@ -1246,9 +1302,9 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
   const int T = ML ? a.lane_state[lane_row]->T : (a.state ? a.state->T : a.T);
   // this workgroup's key tiles: tiles_per_wg consecutive ones (the launcher sizes the grid for ONE round of workgroups: with a
   // tile per workgroup the 8-sequence pass had 1.25 rounds, a quarter-full second one)
-  const int tpw = a.tiles_per_wg > 0 ? a.tiles_per_wg : 1;
+  const int tpw = FULL ? ATT_FULL_TILES : (a.tiles_per_wg > 0 ? a.tiles_per_wg : 1);
   const int split0 = blockIdx.y * tpw, n_live = (T + ATT_SPLIT - 1) / ATT_SPLIT;
-  const int split1 = min(min(split0 + tpw, a.splits_stride), n_live);
+  const int split1 = min(min(split0 + tpw, FULL ? ATT_FULL_TILES : a.splits_stride), n_live);
   if (split0 >= split1) return;   // shorter lane / stale graph: these tiles do not exist (the combine skips them as well)
   const dd_half* kc_l = (const dd_half*)(ML ? a.lane_kc[lane_row] : a.kc);
   const dd_half* vc_l = (const dd_half*)(ML ? a.lane_vc[lane_row] : a.vc);
@@ -1360,7 +1416,8 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
       for (int blk = 0; blk < RB; ++blk) {
         const int row = 8 * blk + c;
         if (row < R) {
-          float* ml = a.part_ml + (((size_t)kvh * a.splits_stride + split) * RT + buf_row(row)) * 2;
+          float* ml = FULL ? fml_sh + ((size_t)split * RP + row) * 2
+                           : a.part_ml + (((size_t)kvh * a.splits_stride + split) * RT + buf_row(row)) * 2;
           ml[0] = pmax[blk];
           ml[1] = (red_sh[1][0][row] + red_sh[1][1][row]) + (red_sh[1][2][row] + red_sh[1][3][row]);
         }
@@ -1388,8 +1445,10 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
         f32x4_t o;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) o[reg] = oacc[reg] + __shfl_down(oacc[reg], 8);
-        if (c < 8 && row < R)
-          *(f32x4_t*)&a.part_o[(((size_t)kvh * a.splits_stride + split) * RT + buf_row(row)) * HEAD_DIM + 32 * wave + 16 * dt + 4 * h4] = o;
+        if (c < 8 && row < R) {
+          if constexpr (FULL) *(f32x4_t*)&fo_sh[((size_t)split * RP + row) * HEAD_DIM + 32 * wave + 16 * dt + 4 * h4] = o;
+          else *(f32x4_t*)&a.part_o[(((size_t)kvh * a.splits_stride + split) * RT + buf_row(row)) * HEAD_DIM + 32 * wave + 16 * dt + 4 * h4] = o;
+        }
       }
     }
   };
@@ -1404,53 +1463,24 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
       if (sp + 2 < split1) __syncthreads();
     }
   }
-}
-
-// Merge of the tiles of one (head, row) + the row's own new key / value (each ensemble member attends to the shared prefix + ITS
-// OWN new token) + hi/lo packing for o_proj: 128 threads (thread = output dimension d), shared by the stand-alone kernel
-// (tiles from the partial buffers in memory) and by the all-tiles form of k_attn_partial16 (tiles still in LDS) — ONE body, with
-// explicit fused multiply-adds, so that a row's bits do not depend on which of the two produced it.
-// ld_ml(tile) -> (max, sum) of the tile for this row; ld_o(tile) -> its un-normalised output at dimension d.
-// sh: 2 + ATT_MAX_SPLITS + 2 + 2 floats of shared memory for this group of 128 threads.
-#define ATT_COMB_SH (2 + ATT_MAX_SPLITS + 2 + 2)
-template <typename LD_ML, typename LD_O>
-__device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int head, int kvh, int m, bool wide, int d, int splits, float* sh,
-                                                  LD_ML ld_ml, LD_O ld_o) {
-  float* red = sh;
-  float* w_sh = sh + 2;
-  float* mx_sh = sh + 2 + ATT_MAX_SPLITS;
-  float* den_sh = mx_sh + 2;
-  const int lane = d & 63, wv = d >> 6;
-  const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
-  const float scaling = 0.08838834764831845f;
-  const int grp = wide ? m >> 3 : 0;                  // group of the row (multi-group passes)
-  const float* knew_r = (wide && a.knew_g[grp]) ? a.knew_g[grp] + (size_t)(m & 7) * kv_dim : a.knew + (size_t)m * kv_dim;
-  const float* vnew_r = (wide && a.vnew_g[grp]) ? a.vnew_g[grp] + (size_t)(m & 7) * kv_dim : a.vnew + (size_t)m * kv_dim;
-  // every load of this block is issued here, before the first dependent use
-  float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
-  float kd = knew_r[kvh * HEAD_DIM + d];
-  float vd = vnew_r[kvh * HEAD_DIM + d];
-  float ms0 = -INFINITY, ls0 = 0.f, ms1 = -INFINITY, ls1 = 0.f;   // two tiles per thread: up to 256 tiles
-  if (d < splits) ld_ml(d, ms0, ls0);
-  if (d + 128 < splits) ld_ml(d + 128, ms1, ls1);
-  float part = dd_wave_sum(qd * kd);
-  float mloc = dd_wave_max(fmaxf(ms0, ms1));
-  if (lane == 0) { red[wv] = part; mx_sh[wv] = mloc; }
-  __syncthreads();
-  float s_self = (red[0] + red[1]) * scaling;
-  float M = fmaxf(s_self, fmaxf(mx_sh[0], mx_sh[1]));
-  float w0 = (ms0 == -INFINITY) ? 0.f : expf(ms0 - M), w1 = (ms1 == -INFINITY) ? 0.f : expf(ms1 - M);
-  if (d < splits) w_sh[d] = w0;
-  if (d + 128 < splits) w_sh[d + 128] = w1;
-  float dl = dd_wave_sum(__builtin_fmaf(w1, ls1, w0 * ls0));
-  if (lane == 0) den_sh[wv] = dl;
-  __syncthreads();
-  float w_self = expf(s_self - M);
-  float den = w_self + (den_sh[0] + den_sh[1]);
-  float num = w_self * vd;
-  for (int sp = 0; sp < splits; ++sp) num = __builtin_fmaf(w_sh[sp], ld_o(sp), num);
-  if (wide) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5, a.wf);
-  else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den, a.wf);
+  if constexpr (FULL) {
+    // the merge, two rows at a time (threads 0-127 / 128-255 each run the 128-thread core on a row of their own)
+    __syncthreads();
+    const int half = tid >> 7, d = tid & 127;
+    const bool wide = ML == 2 || (ML == 1 && a.n_lanes > 8);
+#pragma unroll 1
+    for (int it = 0; 2 * it < R; ++it) {
+      const int rr = 2 * it + half, r = rr < R ? rr : R - 1;
+      const int g = g0 + r / NBT;
+      const int m = ML == 2 ? lane_row * 8 + mo + r % NBT : (ML == 1 ? lane_row : r % NBT);
+      const bool store = rr < R && (ML != 0 || m < a.nb);
+      attn_combine_core(
+          a, kvh * G + g, kvh, m, wide, d, n_live, comb_sh[half],
+          [&](int t, float& mx, float& l) { mx = fml_sh[((size_t)t * RP + r) * 2], l = fml_sh[((size_t)t * RP + r) * 2 + 1]; },
+          [&](int t) -> float { return fo_sh[((size_t)t * RP + r) * HEAD_DIM + d]; }, store);
+      __syncthreads();                                  // the core's scratch is reused by the next pair of rows
+    }
+  }
 }
 
 // grid (n_heads, nb), block 128 (thread = d): the merge above over the partial buffers in memory
@@ -1493,6 +1523,21 @@ static void attn16_grid(AttnDecodeArgs& b, int splits, int wg_per_tile) {
   tpw = tpw < 1 ? 1 : (tpw > 4 ? 4 : tpw);
   b.tiles_per_wg = g_attn16_tpw > 0 ? g_attn16_tpw : tpw;
 }
+// all-tiles form (FULL) of k_attn_partial16: contexts of up to ATT_FULL_TILES tiles and enough (kv head, sequence) workgroups
+int g_attn16_full = 1;   // dd_set_tuning key 22
+static bool attn16_full_ok(int splits, int wgs) { return g_attn16_full && splits <= ATT_FULL_TILES && wgs >= 128; }
+template <int NBT, int G, int GH, int ML>
+static int launch_attn16_full(const AttnDecodeArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int R = NBT * GH, RP = (R + 7) / 8 * 8;
+  constexpr size_t smem = (size_t)ATT_FULL_TILES * RP * (HEAD_DIM + 2) * sizeof(float);
+  static bool attr = false;
+  if (!attr && smem > 32 * 1024) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial16<NBT, G, GH, ML, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  k_attn_partial16<NBT, G, GH, ML, 1><<<grid, 256, smem, st>>>(a);
+  return DD_OK;
+}
 template <int NBT, int G>
 static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
   constexpr int GH = (NBT * G > 16) ? 2 : G;     // at most 16 rows per workgroup
@@ -1523,6 +1568,9 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   int splits = ddk_attn_grid_tiles(a.max_T, a.T_cap);
   DD_REQUIRE(splits >= 1 && splits <= ATT_MAX_SPLITS, "attn: %d key tiles unsupported (1..%d)", splits, ATT_MAX_SPLITS);
   size_t smem = (size_t)(R * HEAD_DIM + 4 * R * ATT_SPLIT + ATT_SPLIT * R + 4 * R * HEAD_DIM) * sizeof(float);
+  if (a.kv16 && attn16_full_ok(splits, a.n_kv * a.n_lanes)) {      // all tiles per workgroup, merge included: no combine launch
+    return launch_attn16_full<1, G, G, 1>(a, dim3(a.n_kv, 1, a.n_lanes), st);
+  }
   if (a.kv16) {
     AttnDecodeArgs b = a;
     attn16_grid(b, splits, a.n_kv * a.n_lanes);
@@ -1550,6 +1598,9 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
   if (!attr && smem > 48 * 1024) {
     DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
+  }
+  if (a.kv16 && NBT == 8 && g_attn16_full >= 2 && attn16_full_ok(splits, a.n_kv * NG * (G / GH))) {   // key 22 = 2: measured no faster (33 vs 26 + 6 us: one workgroup per CU walks ten tiles in a row)
+    return launch_attn16_full<NBT, G, GH, 2>(a, dim3(a.n_kv, 1, NG * (G / GH)), st);
   }
   if (a.kv16) {
     AttnDecodeArgs b = a;

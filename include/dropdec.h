@@ -492,7 +492,9 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * (0: default; same bits; 18 < 0: the eight-plane o_proj kernel instead of two four-plane half passes; 19 < 0: single K slices
  * for gate/up instead of slice pairs with one slice resident at a time).  9 also takes 8 (default):
  * the members of eight sequences per pass over the weights.  21 = key tiles per workgroup of the fp16-cache decode attention
- * (0, default: sized so that a launch is one round of workgroups; same bits).
+ * (0, default: up to 4 while about 1,000 workgroups remain; same bits).  22 = all-tiles form of that attention (a workgroup walks
+ * every key tile of its sequence and merges them itself: no partial buffers, no combine launch): 1 (default) for the one-row-per-
+ * sequence passes, 2 also for the grouped member passes, 0 never; same bits.
  * Keys 1 and 2 are accepted and ignored (settled: non-temporal weight loads, interleaved k-steps). */
 int dd_set_tuning(int key, int value);
 
