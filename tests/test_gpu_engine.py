@@ -877,8 +877,8 @@ def test_prefill_gemm_block_shapes_and_orders_give_the_same_bits(E, dims, T0):
     e.close()
 
 
-@pytest.mark.parametrize("family", [FAMILY_LLAVA, FAMILY_IBLIP])
-def test_prefill_group_equals_one_prefill_per_sequence(E, family):
+@pytest.mark.parametrize("family,wfmt", [(FAMILY_LLAVA, "bf16"), (FAMILY_IBLIP, "bf16"), (FAMILY_LLAVA, "fp16")])
+def test_prefill_group_equals_one_prefill_per_sequence(E, family, wfmt):
     """dd_lm_prefill_group: the prompts of several lanes through the layers as ONE matrix (each sequence padded to whole 128-row
     blocks, the QKV epilogue writing each row to its own sequence's cache).  Every lane must end up bit for bit as its own
     prefill() leaves it — image logits, scores, top-k ids, first token, KV cache — and decode the same tokens afterwards;
@@ -888,7 +888,7 @@ def test_prefill_group_equals_one_prefill_per_sequence(E, family):
     if family == FAMILY_IBLIP:
         shapes = [(T0, 0, min(L, 32)) for T0, _, L in shapes]
     probs = [0.3, 0.5, 0.7]
-    w, engines, embs = _lane_setup(E, family, rc, shapes, max_seq=448)
+    w, engines, embs = _lane_setup(E, family, rc, shapes, max_seq=448, weight_format=wfmt, kv_format="fp16" if wfmt == "fp16" else "fp32")
     embs = [x.cuda() for x in embs]
     solo = []
     for e, x, (T0, s0, L) in zip(engines, embs, shapes):
