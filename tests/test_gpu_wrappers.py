@@ -229,6 +229,16 @@ def test_llavanext_wrapper_with_hf_tiny_model(built):
     ref = RefDecoder(FAMILY_NEXT, rc, sd, [0.1, 0.3, 0.5, 0.7], seed=506)
     assert out[0, ids.shape[1]:].tolist() == ref.generate(emb.cpu(), start, L, 6)
     assert m.image_features[1].shape == (1, L, 10)                     # top-10 ids (llavanext.py:652)
+    # three NeXT images as lanes (the tower sees each image's five tiles as one batch; prompts prefilled per lane — 3 x 128 rows
+    # is under the batched prefill's threshold): each lane == its own generate()
+    from dropoutdecoding_amd.vlm import generate_group
+    lanes = [m.spawn_lane() for _ in range(3)]           # fresh lanes: each starts its rng stream like a fresh process, as `solo` below
+    pvs = [torch.randn(1, 5, 3, 56, 56, generator=torch.Generator().manual_seed(30 + i)) for i in range(3)]
+    ins = [dict(input_ids=ids, pixel_values=p_, image_sizes=sizes) for p_ in pvs]
+    outs = generate_group(lanes, ins, max_new_tokens=6, eos_token_id=[])
+    for i, (p_, o) in enumerate(zip(pvs, outs)):
+        solo = m.spawn_lane()
+        assert o.tolist() == solo.generate(input_ids=ids, pixel_values=p_, image_sizes=sizes, max_new_tokens=6, eos_token_id=[]).tolist(), f"lane {i}"
 
 
 def LMtheta(tc):
