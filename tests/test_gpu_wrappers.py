@@ -334,6 +334,14 @@ def test_instructblip_front_end_on_own_kernels(built):
     out = m.generate(pixel_values=pv, qformer_input_ids=qids, qformer_attention_mask=qmask, input_ids=ids,
                      attention_mask=torch.ones_like(ids), max_new_tokens=5, eos_token_id=[])
     assert out.shape == (1, 6) and int(out[0, 0]) == 2
+    # two InstructBLIP images as lanes (leaked mask bits, hidden-state vote per lane) == their own generate()
+    from dropoutdecoding_amd.vlm import generate_group
+    lanes = [m.spawn_lane() for _ in range(2)]
+    pvs = [torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(60 + i)) for i in range(2)]
+    ins = [dict(pixel_values=p_, qformer_input_ids=qids, qformer_attention_mask=qmask, input_ids=ids) for p_ in pvs]
+    outs = generate_group(lanes, ins, max_new_tokens=5, eos_token_id=[])
+    for i, (kw, o) in enumerate(zip(ins, outs)):
+        assert o.tolist() == m.spawn_lane().generate(**kw, max_new_tokens=5, eos_token_id=[]).tolist(), f"lane {i}"
 
 
 def test_generate_group_three_images_at_once(built):
