@@ -8,7 +8,8 @@ K = 8
 probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
 for name, cfg, fam, L, T0 in (("llava-next-mistral-7b", lm.MISTRAL_7B, lm.FAMILY_NEXT, 2928, 2960),
                              ("instructblip-vicuna-7b", lm.VICUNA_7B, lm.FAMILY_IBLIP, 32, 64)):
-    eng = lm.DropoutEngine(cfg, family=fam, max_seq=T0 + 140, max_visual=L)
+    KV = sys.argv[1] if len(sys.argv) > 1 else "fp16"
+    eng = lm.DropoutEngine(cfg, family=fam, max_seq=T0 + 140, max_visual=L, kv_format=KV)
     eng.load_synthetic(0, 0.02)
     emb = torch.randn(T0, 4096, device="cuda")
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -21,7 +22,7 @@ for name, cfg, fam, L, T0 in (("llava-next-mistral-7b", lm.MISTRAL_7B, lm.FAMILY
                       "sweep8_ms": round(eng.time_sweep(8, 3), 3), "device_GB": round(eng.device_bytes / 1e9, 2)}), flush=True)
     # the same shapes as 8 lanes over these weights (fused base pass + grouped member sweeps)
     B = 8
-    lanes = [eng] + [lm.DropoutEngine(cfg, family=fam, max_seq=T0 + 140, max_visual=L, share_weights_with=eng) for _ in range(B - 1)]
+    lanes = [eng] + [lm.DropoutEngine(cfg, family=fam, max_seq=T0 + 140, max_visual=L, share_weights_with=eng, kv_format=KV) for _ in range(B - 1)]
     for i, e in enumerate(lanes):
         e.prefill(torch.randn(T0, 4096, device="cuda"), 0 if fam == lm.FAMILY_IBLIP else 5, L)
     torch.cuda.synchronize(); t4 = time.perf_counter()
