@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libdropdec.so")
 # every symbol include/dropdec.h declares (tests/test_cabi.py checks the library exports all of them)
 SYMBOLS = [
     "dd_version", "dd_last_error", "dd_arch",
-    "dd_rng_create", "dd_rng_destroy", "dd_rng_seed", "dd_rng_uniform",
+    "dd_rng_create", "dd_rng_create_philox", "dd_rng_destroy", "dd_rng_seed", "dd_rng_uniform",
     "dd_uncertainty_workspace_bytes", "dd_vision_uncertainty", "dd_overlap_keep", "dd_kl_keep", "dd_sample_masks", "dd_vote",
     "dd_argmax_rows",
     "dd_lm_create", "dd_lm_create_shared", "dd_lm_group_step", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_tensor_fp8", "dd_lm_load_synthetic",
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     lib.dd_last_error.restype = C.c_char_p
     lib.dd_arch.restype = C.c_char_p
     lib.dd_rng_create.argtypes = [C.c_uint32, C.POINTER(vp)]
+    lib.dd_rng_create_philox.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(vp)]
     lib.dd_rng_destroy.argtypes = [vp]
     lib.dd_rng_seed.argtypes = [vp, C.c_uint32, vp]
     lib.dd_rng_uniform.argtypes = [vp, vp, C.c_int, vp]

@@ -17,6 +17,11 @@ settings['use_random'] = [False]     # LLaVA-NeXT: True selects "epis_no_overlap
 #   settings['reuse_image_prefix'] = True    -> consecutive prompts over the SAME image keep the image prefix's K/V,
 #                                               uncertainty and top-k ids and prefill only the new text (LLaVA families)
 
+# Which torch generator the dropout draws (models/llava.py:650 torch.rand_like) restate, read when a model is built:
+#   settings['rng_stream'] = 'cpu' (default) | 'gpu' -> 'cpu': mt19937, the reference run on CPU (what the golden fixtures hold);
+#                                               'gpu': Philox4x32-10 keyed by the module seed, bit-equal to torch.rand(...,
+#                                               device="cuda") on ROCm — the reference run on a GPU (tests/test_gpu_dropout_ops.py)
+
 # Storage formats, read when a model is built (from_pretrained / from_hf_model / from_synthetic):
 #   settings['kv_cache'] = 'fp16' (default) | 'fp32'  -> KV cache width.  fp16 is what the reference keeps (it loads every model
 #                                               with torch_dtype=float16, chair_test.py:189-213); K/V are rounded when they enter

@@ -469,11 +469,15 @@ extern "C" int dd_kl_keep(const float* step_logits_dev, const float* image_logit
 }
 
 // ----------------------------------------------------------------------------------------------
-// mt19937 (torch CPU default generator) in device memory: 624 words + read index
+// Device-resident generators. mt19937 (torch CPU default generator): 624 words + read index.
+// Philox4x32-10 (torch GPU default generator): the same 625-word block with word 624 = PHILOX_TAG and
+// words 0..3 = seed lo/hi, offset lo/hi — so every consumer (the mask sampler, the speculative step's
+// backup copy, the captured graphs) carries either kind through one pointer.
 // ----------------------------------------------------------------------------------------------
 struct dd_rng {
   uint32_t* state;  // device, 625 words
   unsigned long long serial;   // never reused: captured decode steps are keyed on it, not on the address
+  int kind;                    // 0 mt19937, 1 Philox
 };
 static unsigned long long g_rng_serial = 0;
 
@@ -521,8 +525,41 @@ __device__ __forceinline__ float mt_temper_uniform(uint32_t y) {
   return (float)(y & 0xFFFFFFu) * 5.9604644775390625e-08f;  // * 2^-24, exact
 }
 
-// Fill out[0..n) (LDS or global) with the next n uniforms; mt in LDS, *idx block-uniform.
+// Philox4x32-10 (Salmon et al., SC'11), first output word for counter (ctr, subseq) and key (k0, k1): the word ATen's
+// random kernel hands element `subseq` of a rand_like over <= 524288 elements (counter layout of cuRAND / rocRAND).
+#define PHILOX_TAG 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t philox_first(uint32_t k0, uint32_t k1, unsigned long long ctr, unsigned long long subseq) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)subseq, c3 = (uint32_t)(subseq >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1, c3 = (uint32_t)p0, c0 = n0, c2 = n2;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+// u32 -> (0,1] as rocRAND does it (one fused multiply-add), then ATen folds 1.0 back to 0.0
+__device__ __forceinline__ float philox_uniform(uint32_t x) {
+  float u = __builtin_fmaf((float)x, 2.3283064e-10f, 2.3283064e-10f);
+  return u == 1.0f ? 0.0f : u;
+}
+
+// Fill out[0..n) (LDS or global) with the next n uniforms; generator block in LDS, *idx block-uniform.
 __device__ void mt_fill_block(uint32_t* mt, int* idx_sh, float* out, int n) {
+  __syncthreads();
+  if ((uint32_t)*idx_sh == PHILOX_TAG) {   // one rand_like: element t = subsequence t at the current offset; offset += 4
+    const unsigned long long off = (unsigned long long)mt[2] | ((unsigned long long)mt[3] << 32);
+    const uint32_t k0 = mt[0], k1 = mt[1];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) out[t] = philox_uniform(philox_first(k0, k1, off >> 2, (unsigned long long)t));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long o2 = off + 4ull;
+      mt[2] = (uint32_t)o2, mt[3] = (uint32_t)(o2 >> 32);
+    }
+    __syncthreads();
+    return;
+  }
   int pos = 0;
   while (pos < n) {
     __syncthreads();
@@ -540,6 +577,15 @@ __device__ void mt_fill_block(uint32_t* mt, int* idx_sh, float* out, int n) {
   __syncthreads();
 }
 
+__global__ void k_philox_seed(uint32_t* st, unsigned long long seed, unsigned long long offset) {
+  for (int i = threadIdx.x; i < MT_N; i += blockDim.x) st[i] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st[0] = (uint32_t)seed, st[1] = (uint32_t)(seed >> 32), st[2] = (uint32_t)offset, st[3] = (uint32_t)(offset >> 32);
+    st[MT_N] = PHILOX_TAG;
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_mt_uniform(uint32_t* st, float* out, int n) {
   __shared__ uint32_t mt[MT_N];
   __shared__ int idx_sh;
@@ -555,6 +601,7 @@ extern "C" int dd_rng_create(uint32_t seed, dd_rng** out) {
   DD_REQUIRE(out, "dd_rng_create: null out");
   dd_rng* r = new dd_rng();
   r->serial = ++g_rng_serial;
+  r->kind = 0;
   hipError_t e = hipMalloc((void**)&r->state, (MT_N + 1) * sizeof(uint32_t));
   if (e != hipSuccess) {
     delete r;
@@ -562,6 +609,24 @@ extern "C" int dd_rng_create(uint32_t seed, dd_rng** out) {
     return DD_ENOMEM;
   }
   k_mt_seed<<<1, 64>>>(r->state, seed);
+  DD_CHECK_LAUNCH();
+  DD_HIP(hipDeviceSynchronize());
+  *out = r;
+  return DD_OK;
+}
+extern "C" int dd_rng_create_philox(unsigned long long seed, unsigned long long offset, dd_rng** out) {
+  DD_REQUIRE(out, "dd_rng_create_philox: null out");
+  DD_REQUIRE((offset & 3ull) == 0, "dd_rng_create_philox: offset %llu is not a multiple of 4 (torch advances it in fours)", offset);
+  dd_rng* r = new dd_rng();
+  r->serial = ++g_rng_serial;
+  r->kind = 1;
+  hipError_t e = hipMalloc((void**)&r->state, (MT_N + 1) * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    delete r;
+    dd_set_error("dd_rng_create_philox: hipMalloc -> %s", hipGetErrorString(e));
+    return DD_ENOMEM;
+  }
+  k_philox_seed<<<1, 64>>>(r->state, seed, offset);
   DD_CHECK_LAUNCH();
   DD_HIP(hipDeviceSynchronize());
   *out = r;
@@ -575,13 +640,17 @@ extern "C" int dd_rng_destroy(dd_rng* r) {
 }
 extern "C" int dd_rng_seed(dd_rng* r, uint32_t seed, void* stream_) {
   DD_REQUIRE(r, "dd_rng_seed: null rng");
-  k_mt_seed<<<1, 64, 0, (hipStream_t)stream_>>>(r->state, seed);
+  if (r->kind == 1)
+    k_philox_seed<<<1, 64, 0, (hipStream_t)stream_>>>(r->state, (unsigned long long)seed, 0ull);   // torch.manual_seed: offset back to 0
+  else
+    k_mt_seed<<<1, 64, 0, (hipStream_t)stream_>>>(r->state, seed);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 extern "C" int dd_rng_uniform(dd_rng* r, float* out, int n, void* stream_) {
   DD_REQUIRE(r && out && n >= 0, "dd_rng_uniform: bad arguments");
   if (n == 0) return DD_OK;
+  DD_REQUIRE(r->kind == 0 || n <= 524288, "dd_rng_uniform: a Philox draw covers at most 524288 elements per call (got %d)", n);
   k_mt_uniform<<<1, 1024, 0, (hipStream_t)stream_>>>(r->state, out, n);
   DD_CHECK_LAUNCH();
   return DD_OK;

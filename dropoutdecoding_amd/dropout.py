@@ -61,6 +61,21 @@ class TorchCpuCompatRNG:
             pass
 
 
+class TorchGpuCompatRNG(TorchCpuCompatRNG):
+    """Philox stream of torch's GPU default generator, kept on the device (dd_rng_create_philox).
+
+    `TorchGpuCompatRNG(seed).rand(n)` returns what `torch.manual_seed(seed); torch.rand(n, device="cuda")` returns
+    (n <= 524288), and successive calls continue the stream: the draws the reference makes at models/llava.py:650
+    when it runs on a GPU.  `offset` is the generator's philox offset to start from (a multiple of 4).
+    """
+
+    def __init__(self, seed: int, offset: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        _lib.check(self._lib.dd_rng_create_philox(C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(offset),
+                                                  C.byref(self._h)), "dd_rng_create_philox")
+
+
 def calculate_vision_uncertainty(logits: torch.Tensor, topk: int = 0):
     """logits [1, L, V] (or [L, V]) fp32 on GPU -> dict with the reference's six keys; with topk>0 also
     returns (values, ids) like get_topk_token_id."""

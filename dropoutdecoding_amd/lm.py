@@ -19,7 +19,7 @@ from . import _lib
 from .config import settings
 from .dropout import (MASK_IBLIP_KL, MASK_IBLIP_QUANTILE, MASK_LLAVA_CUMULATIVE, MASK_LLAVA_CUMULATIVE_NO_OVERLAP, MASK_NEXT_NO_OVERLAP,
                       MASK_NEXT_RESET,
-                      TorchCpuCompatRNG)
+                      TorchCpuCompatRNG, TorchGpuCompatRNG)
 
 FAMILY_LLAVA = "llava-1.5"
 FAMILY_NEXT = "llava-next"
@@ -99,7 +99,8 @@ class DropoutEngine:
     def __init__(self, cfg: LMConfig, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
                  seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
                  iblip_positions: str = "cache", weight_format: str = "bf16", mask_method: str = "epis",
-                 use_avg: bool = False, share_weights_with: Optional["DropoutEngine"] = None, kv_format: str = "fp32"):
+                 use_avg: bool = False, share_weights_with: Optional["DropoutEngine"] = None, kv_format: str = "fp32",
+                 rng_stream: str = "cpu"):
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
@@ -148,7 +149,12 @@ class DropoutEngine:
         # the reference seeds torch's global generator at import (llava.py:16-20); under chair_test all three
         # modules are imported so 5217 is in force. Default here: the family's own module seed.
         self.seed = fam["seed"] if seed is None else seed
-        self.rng = TorchCpuCompatRNG(self.seed)
+        # which torch generator the draws of llava.py:650 restate: "cpu" = mt19937 (the reference run on CPU, the golden
+        # fixtures), "gpu" = Philox4x32-10 (the reference run on a GPU; equals torch.rand(..., device="cuda") on ROCm)
+        if rng_stream not in ("cpu", "gpu"):
+            raise ValueError(f"rng_stream {rng_stream!r}: 'cpu' (mt19937) or 'gpu' (Philox)")
+        self.rng_stream = rng_stream
+        self.rng = TorchGpuCompatRNG(self.seed) if rng_stream == "gpu" else TorchCpuCompatRNG(self.seed)
         # the engine enqueues on its own (non-default) stream: decode steps can then be captured into hipGraphs, and
         # torch work of the caller (next image's preprocessing) does not interleave with the dependent chain
         self.torch_stream = (share_weights_with.torch_stream if share_weights_with is not None

@@ -211,7 +211,7 @@ class DropoutVLM:
         lane.engine = DropoutEngine(eng.cfg, family=eng.family, max_seq=eng.max_seq, max_visual=eng.max_visual,
                                     seed=eng.seed, use_random=eng.use_random, iblip_positions=eng.iblip_positions,
                                     weight_format=eng.weight_format, mask_method=eng.mask_method, use_avg=eng.use_avg,
-                                    share_weights_with=eng, kv_format=eng.kv_format)
+                                    share_weights_with=eng, kv_format=eng.kv_format, rng_stream=eng.rng_stream)
         lane.start_image_pos, lane.end_image_pos, lane.masked_numbers, lane.logits_mask_prob = [], [], [], []
         lane._prefix = None
         return lane
@@ -263,7 +263,8 @@ def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens:
         wfmt = "fp16" if checkpoint_dtype == torch.float16 else "bf16"
     return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random,
                          mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)),
-                         weight_format=wfmt, kv_format=settings.get("kv_cache", "fp16"))
+                         weight_format=wfmt, kv_format=settings.get("kv_cache", "fp16"),
+                         rng_stream=settings.get("rng_stream", "cpu"))
 
 
 _NON_VISUAL_KEYS = ("input_ids", "attention_mask", "max_new_tokens", "max_length", "eos_token_id")

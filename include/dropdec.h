@@ -54,7 +54,9 @@ extern "C" {
 
 /* where the dropout uniforms come from (models/llava.py:650 `torch.rand_like`) */
 #define DD_RNG_INJECTED 0           /* caller supplies uniforms[K][L] (parity tests)                     */
-#define DD_RNG_MT19937 1            /* torch-CPU-compatible mt19937 stream kept in device memory          */
+#define DD_RNG_MT19937 1            /* a dd_rng kept in device memory: the torch-CPU mt19937 stream (dd_rng_create) or
+                                     * the torch-GPU Philox stream (dd_rng_create_philox) — the handle knows which  */
+#define DD_RNG_DEVICE DD_RNG_MT19937
 
 /* what the ensemble votes on */
 #define DD_VOTE_LOGITS 0            /* models/llava.py:27, models/llavanext.py:31                         */
@@ -79,6 +81,16 @@ int dd_rng_destroy(dd_rng* r);
 int dd_rng_seed(dd_rng* r, uint32_t seed, void* stream);
 /* out_dev[n] = next n float32 uniforms of the stream, (x & 0xFFFFFF) * 2^-24 */
 int dd_rng_uniform(dd_rng* r, float* out_dev, int n, void* stream);
+/* torch's GPU default generator restated: what the reference draws when the model sits on a GPU
+ * (models/llava.py:650 with epis_uncert on the device; seed from models/llava.py:16-20).
+ * Philox4x32-10, key = seed, 64-bit offset advanced by 4 per rand_like; one rand_like over
+ * n <= 524288 float32 elements gives element i = first word of counter (offset/4, subsequence i)
+ * mapped by fma(x, 2^-32, 2^-32) with 1.0 folded to 0.0 (ATen's elementwise random kernel over
+ * rocRAND's uniform).  The state lives in the same 625-word device block (words 0..3, tag in
+ * word 624), so every entry point that takes a dd_rng accepts it and graph replays advance it on
+ * the device.  dd_rng_seed on such a handle = torch.manual_seed (offset back to 0);
+ * dd_rng_uniform = one torch.rand(n, device="cuda").  `offset` must be a multiple of 4. */
+int dd_rng_create_philox(unsigned long long seed, unsigned long long offset, dd_rng** out);
 
 /* ------------------------------------------------------------------------------------------
  * Per-visual-token uncertainty scorer.

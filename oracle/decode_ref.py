@@ -21,6 +21,7 @@ import torch
 from . import dropout_ref as DR
 from .lm_ref import KVCache, LMConfig, lm_hidden, lm_logits
 from .mt19937 import TorchCpuMT19937
+from .philox import TorchGpuPhilox
 
 FAMILY_LLAVA = "llava-1.5"
 FAMILY_NEXT = "llava-next"
@@ -48,10 +49,11 @@ class RefDecoder:
     def __init__(self, family: str, cfg: LMConfig, weights: Dict[str, torch.Tensor],
                  mprobs: Sequence[float], seed: int = 5217, use_random: bool = False,
                  dropout: bool = True, iblip_positions: str = "cache", mask_method: str = "epis",
-                 use_avg: bool = False, first_step_ensemble: bool = False):
+                 use_avg: bool = False, first_step_ensemble: bool = False, rng_stream: str = "cpu"):
         self.family, self.cfg, self.w = family, cfg, weights
         self.mprobs = list(mprobs)
-        self.rng = TorchCpuMT19937(seed)
+        # the generator torch.rand_like draws from (llava.py:650): mt19937 on CPU, Philox4x32-10 on a GPU
+        self.rng = TorchGpuPhilox(seed) if rng_stream == "gpu" else TorchCpuMT19937(seed)
         self.use_random = use_random            # settings['use_random'][0], llavanext.py:547
         self.dropout = dropout                  # False = the `--original` path (stock greedy)
         self.iblip_positions = iblip_positions  # "cache" (transformers 5.x) | "mask" (4.44 cumsum rule), SURVEY Q2

@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import dropout_ref as DR
 from oracle.mt19937 import TorchCpuMT19937
+from oracle.philox import TorchGpuPhilox
 
 
 def _load(golden_dir, name):
@@ -36,6 +37,60 @@ def test_rng_is_torch_cpu_stream(ops, golden_dir):
         np.testing.assert_array_equal(rng.rand(n).cpu().numpy(), ref.rand_f32(n))
     rng.manual_seed(5217)
     np.testing.assert_array_equal(rng.rand(700).cpu().numpy(), TorchCpuMT19937(5217).rand_f32(700))
+
+
+def test_philox_stream_is_torch_gpu_rand(ops, golden_dir):
+    """dd_rng_create_philox == torch.manual_seed(s); torch.rand(n, device="cuda") of THIS box's torch (the generator the
+    reference's rand_like at models/llava.py:650 draws from on a GPU), == oracle/philox.py, == the committed vectors."""
+    cpu_state, gpu_state = torch.get_rng_state(), torch.cuda.get_rng_state()
+    try:
+        for seed, sizes in ((0, [5, 576, 576]), (5217, [576, 2928, 8192, 1]), ((1 << 40) + 3, [1, 1023, 300000, 524288])):
+            torch.manual_seed(seed)
+            rng, ref = ops.TorchGpuCompatRNG(seed), TorchGpuPhilox(seed)
+            for n in sizes:
+                want = torch.rand(n, device="cuda")
+                mine = rng.rand(n)
+                assert torch.equal(mine, want), (seed, n)
+                np.testing.assert_array_equal(mine.cpu().numpy(), ref.rand_f32(n))
+        torch.manual_seed(77)
+        torch.rand(576, device="cuda")
+        torch.rand(576, device="cuda")                         # offset 8 from here
+        want = torch.rand(100, device="cuda")
+        assert torch.equal(ops.TorchGpuCompatRNG(77, offset=8).rand(100), want)
+        rng.manual_seed(9)                                      # torch.manual_seed on the same generator: offset back to 0
+        torch.manual_seed(9)
+        assert torch.equal(rng.rand(700), torch.rand(700, device="cuda"))
+    finally:
+        torch.set_rng_state(cpu_state)
+        torch.cuda.set_rng_state(gpu_state)
+    g = _load(golden_dir, "g8_philox.npz")
+    for c in range(int(g["n_cases"])):
+        rng = ops.TorchGpuCompatRNG(int(g[f"c{c}_seed"]))
+        got = []
+        for n in g[f"c{c}_sizes"]:
+            d = rng.rand(int(n)).cpu().numpy()
+            got.append(d if d.size <= 8192 else np.concatenate([d[:2048], d[-2048:]]))
+        np.testing.assert_array_equal(np.concatenate(got), g[f"c{c}_draws"])
+    with pytest.raises(Exception):
+        ops.TorchGpuCompatRNG(1, offset=6)
+    with pytest.raises(Exception):
+        ops.TorchGpuCompatRNG(1).rand(524289)
+
+
+@pytest.mark.parametrize("mode", [DR.MODE_LLAVA_CUMULATIVE, DR.MODE_NEXT_RESET])
+def test_masks_from_the_philox_stream(ops, mode):
+    """K members x several steps draw consecutive rand_like(epi) calls of the GPU generator, per member, like llava.py:650."""
+    rs = np.random.RandomState(3)
+    for L, probs in ((576, [0.3, 0.5, 0.7]), (2928, [0.5] * 5), (33, [0.1, 0.9]), (1500, [0.2, 0.4, 0.6, 0.8, 0.25, 0.33, 0.5, 0.7])):
+        epi = torch.from_numpy((rs.rand(L) * 2).astype(np.float32))
+        keep = torch.from_numpy(rs.rand(L) < 0.05)
+        rng, ref = ops.TorchGpuCompatRNG(5217), TorchGpuPhilox(5217)
+        for step in range(3):
+            uni = torch.from_numpy(np.stack([ref.rand_f32(L) for _ in probs]))
+            want = DR.sample_masks(epi, probs, keep, mode, uni)
+            drop, nd = ops.sample_masks(epi.cuda(), probs, keep.cuda(), mode, rng=rng)
+            np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), want.numpy(), err_msg=f"L={L} step={step}")
+        np.testing.assert_array_equal(rng.rand(64).cpu().numpy(), ref.rand_f32(64))      # both streams end at the same offset
 
 
 def test_uncertainty_golden(ops, golden_dir):

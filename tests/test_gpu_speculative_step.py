@@ -118,3 +118,44 @@ def test_epis_kl_mode_end_to_end_against_the_oracle(E):
     assert got[1] == RefDecoder(FAMILY_IBLIP, RC, w, probs, seed=9, mask_method="epis_kl").generate(emb2, s0, L, 21)
     lane.close()
     eng.close()
+
+
+@pytest.mark.parametrize("family,use_random", [(FAMILY_LLAVA, False), (FAMILY_NEXT, False), (FAMILY_NEXT, True)])
+def test_philox_stream_end_to_end(E, family, use_random):
+    """rng_stream="gpu": the draws of llava.py:650 come from the GPU generator's Philox stream (the reference run on a GPU).
+    Two-sweep step, speculative step (with its backup / re-run of the draws), graph replays and a 3-lane group all give the
+    oracle's tokens and leave the stream at the oracle's offset."""
+    w = random_weights(RC, 31, 0.05)
+    cfg = E.LMConfig(RC.vocab_size, RC.hidden_size, RC.intermediate_size, RC.num_layers, RC.num_heads, RC.num_kv_heads,
+                     RC.head_dim, RC.rms_eps, RC.rope_theta)
+    L, s0, probs, steps = 40, 3, [0.3, 0.5, 0.7, 0.9], 30
+    eng = E.DropoutEngine(cfg, family=family, max_seq=192, max_visual=L, seed=7, use_random=use_random, rng_stream="gpu")
+    eng.load_state_dict(w)
+    emb = torch.randn(L + 9, RC.hidden_size, generator=torch.Generator().manual_seed(77)) * 0.8
+    ref = RefDecoder(family, RC, w, probs, seed=7, use_random=use_random, rng_stream="gpu")
+    want = ref.generate(emb, s0, L, steps + 1)
+    tail = ref.rng.rand_f32(32)
+    cpu_tokens = RefDecoder(family, RC, w, probs, seed=7, use_random=use_random).generate(emb, s0, L, steps + 1)
+    assert want != cpu_tokens, "the two generators must lead to different sequences for the test to mean something"
+    oks_seen = []
+    for spec, graph in ((False, False), (True, False), (True, True)):
+        _, toks, _, after, oks = _run(E, eng, emb, s0, L, probs, steps, spec=spec, graph=graph, seed=7)
+        assert toks == want, (spec, graph)
+        np.testing.assert_array_equal(after, tail)
+        oks_seen += [o for o in oks if o >= 0]
+    if not use_random:
+        assert 0 < sum(oks_seen) < len(oks_seen), "both outcomes of the speculation must occur"
+    # lanes: each lane its own Philox stream (seeds differ), one group step for all
+    seeds = [7, 8, 9]
+    lanes = [eng] + [E.DropoutEngine(cfg, family=family, max_seq=192, max_visual=L, seed=s, use_random=use_random,
+                                     rng_stream="gpu", share_weights_with=eng) for s in seeds[1:]]
+    for e, s in zip(lanes, seeds):
+        e.rng.manual_seed(s)
+        e.prefill(emb.cuda(), s0, L)
+    got = E.EngineGroup(lanes).generate(steps + 1, mprobs=probs)
+    for i, s in enumerate(seeds):
+        r = RefDecoder(family, RC, w, probs, seed=s, use_random=use_random, rng_stream="gpu")
+        assert got[i] == r.generate(emb, s0, L, steps + 1), f"lane {i}"
+        np.testing.assert_array_equal(lanes[i].rng.rand(8).cpu().numpy(), r.rng.rand_f32(8))
+    for e in reversed(lanes):
+        e.close()

@@ -127,6 +127,28 @@ def test_g6_rng_stream(golden_dir):
         np.testing.assert_array_equal(mine, g[f"c{c}_draws"])
 
 
+def test_g8_philox_stream(golden_dir):
+    """oracle/philox.py against (a) the published Philox4x32-10 known answers (Random123 kat_vectors: zero, all-ones and the
+    pi-digits case) and (b) draws of torch's GPU generator recorded on the MI355X box (tools/gen_philox_golden.py)."""
+    from oracle.philox import TorchGpuPhilox, philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for ctr, key, want in kat:
+        assert tuple(int(v) for v in philox4x32_10(*ctr, *key)) == want
+    g = _load(golden_dir, "g8_philox.npz")
+    for c in range(int(g["n_cases"])):
+        rng = TorchGpuPhilox(int(g[f"c{c}_seed"]))
+        got = []
+        for n in g[f"c{c}_sizes"]:
+            d = rng.rand_f32(int(n))
+            got.append(d if d.size <= 8192 else np.concatenate([d[:2048], d[-2048:]]))
+        np.testing.assert_array_equal(np.concatenate(got), g[f"c{c}_draws"])
+        assert rng.offset == 4 * len(g[f"c{c}_sizes"])
+    with pytest.raises(ValueError):
+        TorchGpuPhilox(1, offset=2)
+
+
 def _decoder_from(g, family):
     v, d, f, nl, nh, nkv, hd = [int(x) for x in g["cfg"]]
     cfg = LMConfig(v, d, f, nl, nh, nkv, hd, float(g["rms_eps"]), float(g["rope_theta"]))
