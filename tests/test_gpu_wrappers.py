@@ -118,6 +118,16 @@ def test_llava_wrapper_generate_matches_oracle(built):
     ref4 = RefDecoder(FAMILY_LLAVA, rc, sd, [0.3, 0.5, 0.7], seed=9, first_step_ensemble=True)
     assert o4[0, 7:].tolist() == ref4.generate(emb.cpu(), start, 16, 3)
     assert m.engine.last_step()["winner"] == ref4.records[-1].winner
+    # settings['rng_stream'] = 'gpu': the same model drawing from torch's GPU generator (the reference run on a GPU), lanes too
+    ddc.settings["rng_stream"] = "gpu"
+    try:
+        mg = CustomLlavaForConditionalGeneration.from_hf_model(hf, max_new_tokens=16)
+    finally:
+        ddc.settings.pop("rng_stream")
+    assert mg.engine.rng_stream == "gpu" and mg.spawn_lane().engine.rng_stream == "gpu"
+    og = mg.generate(input_ids=ids1, pixel_values=pv, max_new_tokens=8, eos_token_id=[])
+    refg = RefDecoder(FAMILY_LLAVA, rc, sd, [0.3, 0.5, 0.7], seed=24, rng_stream="gpu")
+    assert og[0, 7:].tolist() == refg.generate(emb.cpu(), start, 16, 8) != want
 
 
 def test_instructblip_merge_and_output_format(built):
