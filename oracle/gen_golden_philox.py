@@ -1,6 +1,6 @@
 """Golden vectors for the Philox (torch GPU generator) stream: run ON THE GPU BOX.
 
-    python tools/gen_philox_golden.py            -> gpurun_out/g8_philox.npz  (copy to tests/golden/)
+    python oracle/gen_golden_philox.py            -> gpurun_out/g8_philox.npz  (copy to tests/golden/)
 
 Each case: torch.manual_seed(seed), then successive torch.rand(n, device="cuda") calls (what the reference's
 torch.rand_like draws at models/llava.py:650 when the model is on a GPU).  Also prints whether oracle/philox.py

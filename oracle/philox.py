@@ -16,7 +16,7 @@ SC'11; multipliers 0xD2511F53 / 0xCD9E8D57, Weyl constants 0x9E3779B9 / 0xBB67AE
 layout is the one cuRAND and rocRAND share (rocrand_philox4x32_10.h:199-233).  Pinned against
 `torch.manual_seed(s); torch.rand(n, device="cuda")` on the MI355X by
 tests/test_gpu_dropout_ops.py::test_philox_stream_is_torch_gpu_rand and by the vectors in
-tests/golden/g8_philox.npz (made there by tools/gen_philox_golden.py).
+tests/golden/g8_philox.npz (made there by oracle/gen_golden_philox.py).
 """
 from __future__ import annotations
 

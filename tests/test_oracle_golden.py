@@ -129,7 +129,7 @@ def test_g6_rng_stream(golden_dir):
 
 def test_g8_philox_stream(golden_dir):
     """oracle/philox.py against (a) the published Philox4x32-10 known answers (Random123 kat_vectors: zero, all-ones and the
-    pi-digits case) and (b) draws of torch's GPU generator recorded on the MI355X box (tools/gen_philox_golden.py)."""
+    pi-digits case) and (b) draws of torch's GPU generator recorded on the MI355X box (oracle/gen_golden_philox.py)."""
     from oracle.philox import TorchGpuPhilox, philox4x32_10
     kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
            ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
