@@ -173,7 +173,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
     ap.add_argument("--images-per-gpu", type=int, default=32,
-                    help="images decoded concurrently per GPU (lanes over one set of weights, 1..32); 1 = the reference's "
+                    help="images decoded concurrently per GPU (lanes over one set of weights, 1..64); 1 = the reference's "
                          "one-image-at-a-time loop")
     ap.add_argument("--decode-streams", type=int, default=1, choices=[1, 2],
                     help="2 (with 16+ images per GPU): decode the lanes as two independent halves on two streams.  Decode alone gains "
@@ -226,7 +226,7 @@ def main() -> int:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    B = 1 if args.mode == "kshard" else max(1, min(32, args.images_per_gpu))
+    B = 1 if args.mode == "kshard" else max(1, min(64, args.images_per_gpu))
     lanes = [model] + [model.spawn_lane() for _ in range(B - 1)]
     from dropoutdecoding_amd.vlm import generate_group
 

@@ -45,8 +45,9 @@ int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, const int32_t
 static unsigned long long g_lm_serial = 0;   // handles are identified in graph keys by a serial that is never reused
 
 #define MAX_MEMBERS DD_MAX_MEMBERS
-#define GROUP_ROWS 64     // rows of the widest decode pass: the members of eight sequences
-#define KV_ROWS 32        // new K/V rows kept per layer: 16 members, or the base rows of up to 32 lanes (group step)
+#define GROUP_ROWS 64     // rows of the widest decode pass: the members of eight sequences, or the un-masked rows of 64
+#define GROUP_MAX_LANES 64
+#define KV_ROWS 64        // new K/V rows kept per layer: 16 members, or the base rows of up to 64 lanes (group step)
 #define MAX_NEW_TOKENS 8192
 
 struct LayerW {
@@ -63,7 +64,7 @@ struct dd_lm {
   size_t bytes = 0;
   unsigned long long serial = 0;
   dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
-  float* grp_logits = nullptr; // [32][Vpad] base-pass logits of a group step (this handle is the group's first lane)
+  float* grp_logits = nullptr; // [GROUP_MAX_LANES][Vpad] base-pass logits of a group step (this handle is the group's first lane)
   int32_t* grp_argmax = nullptr;
   DDState* chunk_states = nullptr;   // [32] positions of the rows of a short prompt chunk (dd_lm_prefill_extend)
   float *chunk_k = nullptr, *chunk_v = nullptr;   // [32][kv_dim] roped K / V rows of the chunk, one layer at a time
@@ -274,8 +275,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->xop_q, (size_t)h->S_q * 64 * 8);
   DA(h->xop_ff, (size_t)h->S_ff * 64 * 8);
   DA(h->base_logits, h->Vpad);
-  DA(h->grp_logits, (size_t)32 * h->Vpad);
-  DA(h->grp_argmax, 32);
+  DA(h->grp_logits, (size_t)GROUP_MAX_LANES * h->Vpad);
+  DA(h->grp_argmax, GROUP_MAX_LANES);
   DA(h->chunk_states, 32);
   DA(h->chunk_k, (size_t)32 * h->kv_dim);
   DA(h->chunk_v, (size_t)32 * h->kv_dim);
@@ -575,9 +576,9 @@ __global__ void k_prefill_rows(int32_t* rows, int span_start, int L, int T0) {
 }
 // ---- the same two kernels for several sequences at once (group step): block = sequence
 struct StepBeginLanes {
-  DDState* st[32];
-  const uint8_t* leak_bits[32];
-  int L[32], mask_positions[32];
+  DDState* st[GROUP_MAX_LANES];
+  const uint8_t* leak_bits[GROUP_MAX_LANES];
+  int L[GROUP_MAX_LANES], mask_positions[GROUP_MAX_LANES];
 };
 __global__ __launch_bounds__(256) void k_step_begin_lanes(StepBeginLanes t) {
   __shared__ int cnt[4];
@@ -1091,9 +1092,10 @@ extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int
 static int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st,
                     dd_lm* const* lanes = nullptr, const int32_t* skip_if = nullptr) {
   const int d = h->d, dff = h->dff;
-  // more than 8 lanes: the base rows fill two (up to 16 lanes) or four operand planes and go through the grouped GEMV
+  // more than 8 lanes: the base rows fill two (up to 16 lanes), four (32) or eight (64) operand planes and go through the
+  // grouped GEMV
   const bool wide = lanes && nb > 8;
-  const int lane_groups = nb > 16 ? 4 : 2;
+  const int lane_groups = nb > 32 ? 8 : (nb > 16 ? 4 : 2);
   auto gemv = [&](int epi, GemvArgs& a) -> int {
     a.skip_if = skip_if;
     if (!wide) return ddk_gemv(epi, a, st);
@@ -1411,9 +1413,9 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
 // Per step and sequence the weights are read 1/n + 1 times instead of twice.
 // -----------------------------------------------------------------------------------------------
 struct ScatterTab {
-  float* logits[32];
-  int32_t* argmax[32];
-  const DDState* st[32];
+  float* logits[GROUP_MAX_LANES];
+  int32_t* argmax[GROUP_MAX_LANES];
+  const DDState* st[GROUP_MAX_LANES];
 };
 __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, ScatterTab tab) {
   int m = blockIdx.x;
@@ -1426,7 +1428,7 @@ __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argma
 
 static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  DD_REQUIRE(lanes && n >= 1 && n <= 32, "dd_lm_group_step: 1..32 sequences per group (got %d)", n);
+  DD_REQUIRE(lanes && n >= 1 && n <= GROUP_MAX_LANES, "dd_lm_group_step: 1..%d sequences per group (got %d)", GROUP_MAX_LANES, n);
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_group_step: bad K / mprobs");
   dd_lm* h0 = lanes[0];
   DD_REQUIRE(h0, "dd_lm_group_step: null handle");
@@ -1479,13 +1481,14 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
                  h0->cfg.mask_mode != DD_MASK_IBLIP_KL;        // the fused keep + mask launch computes the overlap keep set
   }
   if (K > 0 && same_rule) {          // keep sets + masks of all sequences: one launch, one workgroup per sequence
-    MaskLaneArgs ml[32];
+    MaskLaneArgs ml[GROUP_MAX_LANES];
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
       ml[m] = {q->epi, q->L, q->keep, q->argmax_base, q->topk_ids, dd_rng_state_ptr(rngs ? rngs[m] : nullptr), q->drop, q->n_drop,
                q->drop_bits, &q->state->done};
     }
-    RC(dd_sample_masks_lanes(ml, n, h0->cfg.k_top, mprobs, K, h0->cfg.mask_mode, st));
+    for (int m0 = 0; m0 < n; m0 += 32)       // the sampler's pointer table travels by value: 32 sequences per launch
+      RC(dd_sample_masks_lanes(ml + m0, n - m0 < 32 ? n - m0 : 32, h0->cfg.k_top, mprobs, K, h0->cfg.mask_mode, st));
   } else if (K > 0) {
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
@@ -1739,7 +1742,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
 // changed since it was captured; the cache lives in the first lane.
 extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= 32 && lanes[0] && (K == 0 || mprobs);
+  bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= GROUP_MAX_LANES && lanes[0] && (K == 0 || mprobs);
   for (int m = 0; graphable && m < n; ++m)
     graphable = lanes[m] && lanes[m]->prefilled && lanes[m]->steps_since_prefill >= 1 &&
                 lanes[m]->T_host + 1 < lanes[m]->T_cap && lanes[m]->n_tok_host < MAX_NEW_TOKENS;
@@ -1785,7 +1788,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   struct Saved {
     int T, N, K, S;
     bool leak;
-  } sv[32];
+  } sv[GROUP_MAX_LANES];
   for (int m = 0; m < n; ++m)
     sv[m] = {lanes[m]->T_host, lanes[m]->n_tok_host, lanes[m]->last_K, lanes[m]->steps_since_prefill, lanes[m]->have_leak};
   auto restore = [&]() {

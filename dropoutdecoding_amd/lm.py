@@ -483,7 +483,7 @@ def prefill_group(engines: Sequence["DropoutEngine"], embeds: Sequence[torch.Ten
 
 
 class EngineGroup:
-    """Up to 32 sequences ("lanes") decoded together over ONE set of weights (dd_lm_group_step).
+    """Up to 64 sequences ("lanes") decoded together over ONE set of weights (dd_lm_group_step).
 
     The reference decodes one image at a time and shards 500 images over processes, each with its own torch generator
     (chair_test.py:270-346).  A lane is such a process: its own KV cache, state and rng stream.  Every lane's
@@ -493,8 +493,8 @@ class EngineGroup:
 
     def __init__(self, engines: Sequence[DropoutEngine]):
         engines = list(engines)
-        if not 1 <= len(engines) <= 32:
-            raise ValueError("a group holds 1..32 sequences")
+        if not 1 <= len(engines) <= 64:
+            raise ValueError("a group holds 1..64 sequences")
         owner = engines[0].weight_owner or engines[0]
         for e in engines:
             if (e.weight_owner or e) is not owner:

@@ -298,14 +298,14 @@ def prefill_lanes(models: List["DropoutVLM"], stream=None, chunk: int = 16) -> N
 @torch.no_grad()
 def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens: Optional[int] = None, eos_token_id=None,
                    num_beams: int = 1, do_sample: bool = False, pad_token_id: Optional[int] = None) -> List[torch.LongTensor]:
-    """`generate()` for up to 32 images at once: models[i] (a wrapper and its spawn_lane() copies) decodes inputs[i].
+    """`generate()` for up to 64 images at once: models[i] (a wrapper and its spawn_lane() copies) decodes inputs[i].
 
     Each image is decoded exactly as `models[i].generate(**inputs[i])` would (same tokens, masks, logits; its own rng
     stream, like one process of the reference's sharded 500-image runs), but all sequences advance together and their
     un-masked passes share one sweep over the weights (EngineGroup) — the throughput mode for CHAIR-style jobs."""
     from .lm import EngineGroup
-    if len(models) != len(inputs) or not 1 <= len(models) <= 32:
-        raise ValueError("generate_group: one model lane per input, 1..32 of them")
+    if len(models) != len(inputs) or not 1 <= len(models) <= 64:
+        raise ValueError("generate_group: one model lane per input, 1..64 of them")
     prepared = []
     visuals = _batched_visuals(models[0], inputs)
     for m, kw, vis in zip(models, inputs, visuals):
@@ -342,8 +342,8 @@ class GroupPipeline:
     NOT pay: 792 vs 830 tok/s — the next batch's prefill, on its own stream, already fills those gaps — so 1 is the default."""
 
     def __init__(self, model: DropoutVLM, lanes: int = 8, decode_streams: int = 1, _sets=None):
-        if not 1 <= lanes <= 32:
-            raise ValueError("1..32 lanes per set")
+        if not 1 <= lanes <= 64:
+            raise ValueError("1..64 lanes per set")
         if decode_streams not in (1, 2):
             raise ValueError("decode_streams: 1 or 2")
         self.device = model.device
@@ -414,16 +414,31 @@ class GroupPipeline:
                 pass
             lanes, prepared = cur["lanes"], cur["prepared"]
             lanes[0].engine.torch_stream.wait_event(cur["event"])
-            nb = next(it, None)
-            while nb is not None and len(nb) == 0:
-                nb = next(it, None)
-            if nb is not None and len(nb) > len(self.sets[0]):
-                raise ValueError(f"a batch of {len(nb)} images for {len(self.sets[0])} lanes")
             k += 1
-            nxt = self._stage(self.sets[k % 2], nb, kw) if nb is not None else None
+            following = {"state": None, "asked": False}
+
+            def fetch(k=k, following=following):
+                # the next batch is pulled from the caller's iterator (image loading, preprocessing: host time) only once this
+                # batch's first decode steps are queued on the GPU, not between two batches with the GPU idle
+                following["asked"] = True
+                nb = next(it, None)
+                while nb is not None and len(nb) == 0:
+                    nb = next(it, None)
+                if nb is not None and len(nb) > len(self.sets[0]):
+                    raise ValueError(f"a batch of {len(nb)} images for {len(self.sets[0])} lanes")
+                following["state"] = self._stage(self.sets[k % 2], nb, kw) if nb is not None else None
+
+            def idle(following=following, fetch=fetch) -> bool:
+                if not following["asked"]:
+                    fetch()
+                    return True
+                return following["state"]["unit"]() if following["state"] is not None else False
+
             dropout = not lanes[0].original
-            toks = EngineGroup([m.engine for m in lanes]).generate(
-                prepared[0][1], eos=prepared[0][2], dropout=dropout, idle=(nxt["unit"] if nxt is not None else None))
+            toks = EngineGroup([m.engine for m in lanes]).generate(prepared[0][1], eos=prepared[0][2], dropout=dropout, idle=idle)
+            if not following["asked"]:
+                fetch()
+            nxt = following["state"]
             yield [m._finalize(p[0], t) for m, p, t in zip(lanes, prepared, toks)]
             cur = nxt
 

@@ -518,7 +518,7 @@ int dd_set_tuning(int key, int value);
  * un-masked base passes (models/llava.py:294-303 for each image) run as ONE sweep, so the weights are streamed
  * 1/n + ceil(K/8) times per sequence and token instead of 1 + ceil(K/8) times.
  *   dd_lm_create_shared: same cfg dimensions as the owner; max_seq must equal the owner's for lanes grouped together.
- *   dd_lm_group_step: lanes[0..n), n <= 32, all prefilled; rngs[m] is lane m's stream (may be NULL for InstructBLIP's
+ *   dd_lm_group_step: lanes[0..n), n <= 64, all prefilled; rngs[m] is lane m's stream (may be NULL for InstructBLIP's
  *   deterministic masks or K == 0).  The owner may itself be one of the lanes. */
 int dd_lm_create_shared(const dd_lm_config* cfg, dd_lm* weights_from, dd_lm** out);
 int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream);

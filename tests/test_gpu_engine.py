@@ -541,6 +541,7 @@ def _lane_setup(E, family, rc, shapes, seed=7, max_seq=160, **kw):
     (FAMILY_LLAVA, [(40, 3, 30), (70, 5, 50), (33, 1, 30), (66, 2, 60)]),       # lengths either side of a 64-key tile
     (FAMILY_LLAVA, [(34 + 3 * i, 1 + i % 3, 30) for i in range(11)]),           # > 8 lanes: base rows in two operand planes
     (FAMILY_LLAVA, [(34 + 2 * i, 1 + i % 3, 30) for i in range(21)]),           # > 16 lanes: four planes, two attention launches
+    (FAMILY_LLAVA, [(34 + (5 * i) % 37, 1 + i % 3, 30) for i in range(37)]),    # > 32 lanes: eight planes, two sampler launches
     (FAMILY_NEXT, [(90, 4, 80), (50, 4, 40)]),
     (FAMILY_IBLIP, [(40, 0, 32), (45, 0, 32), (38, 0, 32)]),                    # leaked mask bits per lane
 ])
@@ -650,6 +651,50 @@ def test_full_size_lanes_equal_solo_runs_bitwise(E):
             np.testing.assert_array_equal(e.base_logits(), rec[i][s][4], err_msg=f"lane {i} step {s}")
         assert e.tokens() == toks[i]
         np.testing.assert_array_equal(e.kv_sums(), sums[i])
+    for e in reversed(engs):
+        e.close()
+
+
+def test_full_size_forty_lanes_equal_solo_runs_bitwise(E):
+    """BASELINE size, 40 lanes in one group (the un-masked rows as ONE 64-row sweep: eight operand planes, three attention
+    launches, lm_head over 64 rows; five 64-row member sweeps; the mask sampler in two launches): lanes from every part of the
+    group == the same lane decoded alone, bit for bit."""
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    n = 40
+    shapes = [(600 + (7 * i) % 90, 1 + (3 * i) % 20, 576) for i in range(n)]
+    engs = []
+    for i in range(n):
+        engs.append(E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=704, max_visual=576, seed=5217,
+                                    share_weights_with=engs[0] if engs else None, kv_format="fp16"))
+    engs[0].load_synthetic(1, 0.02)
+    embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(50 + i)).cuda() for i, (T0, _, _) in enumerate(shapes)]
+    for e, x, (T0, s0, L) in zip(engs, embs, shapes):
+        e.prefill(x, s0, L)
+    grp = E.EngineGroup(engs)
+    n_steps, rec = 3, [[] for _ in engs]
+    for s in range(n_steps):
+        grp.decode_step(probs)
+        for i, e in enumerate(engs):
+            st = e.last_step()
+            rec[i].append((st["drop"].copy(), st["member_argmax"].tolist(), st["winner"], e.logits().copy(), e.base_logits().copy()))
+    toks = [e.tokens() for e in engs]
+    sums = [e.kv_sums().copy() for e in engs]
+    assert len({tuple(t) for t in toks}) > 1
+    for i in (0, 7, 8, 31, 32, 33, 39):
+        e, x, (T0, s0, L) = engs[i], embs[i], shapes[i]
+        e.rng.manual_seed(5217)
+        e.prefill(x, s0, L)
+        for s in range(n_steps):
+            e.decode_step(probs)
+            st = e.last_step()
+            np.testing.assert_array_equal(st["drop"], rec[i][s][0], err_msg=f"lane {i} step {s}")
+            assert st["member_argmax"].tolist() == rec[i][s][1] and st["winner"] == rec[i][s][2]
+            np.testing.assert_array_equal(e.logits(), rec[i][s][3], err_msg=f"lane {i} step {s}")
+            np.testing.assert_array_equal(e.base_logits(), rec[i][s][4], err_msg=f"lane {i} step {s}")
+        assert e.tokens() == toks[i]
+        np.testing.assert_array_equal(e.kv_sums(), sums[i])
+    with pytest.raises(ValueError):
+        E.EngineGroup(engs + [engs[0]] * 25)
     for e in reversed(engs):
         e.close()
 
