@@ -328,7 +328,7 @@ def generate_group(models: List[DropoutVLM], inputs: List[dict], max_new_tokens:
 
 
 class GroupPipeline:
-    """Caption a long list of images in batches of up to 32: while one set of lanes decodes, the vision tower and the
+    """Caption a long list of images in batches of up to 64: while one set of lanes decodes, the vision tower and the
     prefill of the NEXT batch are enqueued on a second stream (the decode step is HBM-bound, the prefill MFMA-bound, so
     they overlap) — the 500-image CHAIR job of the reference's SLURM launchers on one GPU.
 
