@@ -75,6 +75,11 @@ class TorchGpuCompatRNG(TorchCpuCompatRNG):
         _lib.check(self._lib.dd_rng_create_philox(C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(offset),
                                                   C.byref(self._h)), "dd_rng_create_philox")
 
+    def manual_seed(self, seed: int) -> None:
+        if not 0 <= seed < 1 << 32:          # dd_rng_seed carries 32 bits; wider seeds go through the constructor
+            raise ValueError("manual_seed on a Philox stream takes a 32-bit seed; build TorchGpuCompatRNG(seed) for wider ones")
+        super().manual_seed(seed)
+
 
 def calculate_vision_uncertainty(logits: torch.Tensor, topk: int = 0):
     """logits [1, L, V] (or [L, V]) fp32 on GPU -> dict with the reference's six keys; with topk>0 also
