@@ -290,7 +290,8 @@ def main() -> int:
         single = {"value": round(args.n_new / t1, 2), "unit": "tokens/s", "ms_per_image": round(t1 * 1e3, 1),
                   "images": args.single_images,
                   "note": "one image at a time: prefill + 128 ensemble steps; a step is ONE sweep over the weights when the masks sampled for "
-                          "an empty keep set stand (speculative step, exact), two otherwise"}
+                          "an empty keep set stand (speculative step, exact), two otherwise; the host reads the check's verdict and launches the re-run "
+                          "only when it is needed (dd_lm_decode_step_sync)"}
     if use_dist:
         torch.distributed.barrier()
     if use_dist:

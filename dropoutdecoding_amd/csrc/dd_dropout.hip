@@ -951,7 +951,7 @@ extern "C" int dd_sample_masks(const float* epi, int L, const double* mprobs, in
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_spec_check(const uint8_t* __restrict__ keep, const uint8_t* __restrict__ drop_bits, int L,
                                                      int K, const int32_t* __restrict__ done, int32_t* __restrict__ ok_out,
-                                                     int keep_matters) {
+                                                     int keep_matters, volatile int32_t* host_note) {
   __shared__ int hit;
   if (threadIdx.x == 0) hit = 0;
   __syncthreads();
@@ -962,11 +962,21 @@ __global__ __launch_bounds__(1024) void k_spec_check(const uint8_t* __restrict__
   }
   if (h) hit = 1;                       // benign race: every writer stores 1
   __syncthreads();
-  if (threadIdx.x == 0) ok_out[0] = hit ? 0 : 1;
+  if (threadIdx.x == 0) {
+    const int ok = hit ? 0 : 1;
+    ok_out[0] = ok;
+    if (host_note) {                    // host-decided fallback: tell the waiting host thread (pinned, device-mapped words)
+      const int seq = ok_out[2] + 1;    // checks announced so far (device copy of the counter)
+      ok_out[2] = seq;
+      host_note[1] = ok;
+      __threadfence_system();
+      host_note[0] = seq;
+    }
+  }
 }
 int dd_spec_check(const uint8_t* keep, const uint8_t* drop_bits, int L, int K, const int32_t* done, int32_t* ok_out,
-                  int keep_matters, hipStream_t st) {
-  k_spec_check<<<1, 1024, 0, st>>>(keep, drop_bits, L, K, done, ok_out, keep_matters);
+                  int keep_matters, hipStream_t st, int32_t* host_note) {
+  k_spec_check<<<1, 1024, 0, st>>>(keep, drop_bits, L, K, done, ok_out, keep_matters, host_note);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -20,7 +20,7 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
 int dd_kl_keep_impl(const float* step_logits, const float* image_logits, int L, int V, int ld, float percent, uint8_t* keep,
                     float* kl_ws, const int32_t* gate, hipStream_t st);
 int dd_spec_check(const uint8_t* keep, const uint8_t* drop_bits, int L, int K, const int32_t* done, int32_t* ok_out,
-                  int keep_matters, hipStream_t st);
+                  int keep_matters, hipStream_t st, int32_t* host_note = nullptr);
 int dd_copy_row_gated(const float* src, float* dst, int n, const int32_t* gate, hipStream_t st);
 int dd_argmax_rows_gated(const float* x, int R, int V, int ld, int32_t* out, const int32_t* gate, hipStream_t st);
 int dd_vote_gated(const int32_t* ids, int K, int32_t* out2, const int32_t* gate, hipStream_t st);
@@ -125,6 +125,7 @@ struct dd_lm {
   // host-visible token mirror (pinned, device-mapped): the decode loop can watch for EOS without synchronising
   int32_t* tok_host = nullptr;       // host pointer: [0] = count, [1..] = tokens
   int32_t* tok_host_dev = nullptr;   // the same memory as seen from the device
+  int spec_seq_host = 0;             // speculation checks announced to the host so far (dd_lm_decode_step_sync)
 };
 
 template <typename T>
@@ -329,13 +330,14 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   }
   (void)hipEventCreate(&h->ev0);
   (void)hipEventCreate(&h->ev1);
-  if (hipHostMalloc((void**)&h->tok_host, (MAX_NEW_TOKENS + 1) * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+  if (hipHostMalloc((void**)&h->tok_host, (MAX_NEW_TOKENS + 1 + 4) * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&h->tok_host_dev, h->tok_host, 0) != hipSuccess) {
     dd_set_error("dd_lm_create: pinned token mirror allocation failed");
     dd_lm_destroy(h);
     return DD_EHIP;
   }
   h->tok_host[0] = 0;
+  for (int i = 0; i < 4; ++i) h->tok_host[MAX_NEW_TOKENS + 1 + i] = 0;   // [seq, ok] of the host-decided speculative step
   *out = h;
   return DD_OK;
 }
@@ -1613,7 +1615,11 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
   return DD_OK;
 }
 
-static int decode_step_spec(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, hipStream_t st) {
+// The step in three phases.  A: masks for an empty keep set, the combined sweep, the real keep set and the check.  B: the
+// fallback (every kernel returns at once when the device flag says the speculation held).  C: member argmax, vote, commit.
+// dd_lm_decode_step enqueues A, B, C back to back (one graph: the host never waits, B's ~350 launches cost ≈0.7 ms even when
+// they have nothing to do); dd_lm_decode_step_sync enqueues A with a note to the host and B only when the note says so.
+static int spec_phase_a(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, hipStream_t st, bool note) {
   const int32_t* gate = &h->state->done;
   k_step_begin<<<1, 256, 0, st>>>(h->state, h->leak_bits, h->L, h->cfg.leak_mask == 2 ? 1 : 0);
   DD_CHECK_LAUNCH();
@@ -1634,13 +1640,25 @@ static int decode_step_spec(dd_lm* h, const double* mprobs, int K, dd_rng* rng, 
   // 3. the real keep set; did any member drop one of its tokens?
   RC(step_keep(h, gate, st));
   const int keep_matters = (mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) ? 0 : 1;
-  RC(dd_spec_check(h->keep, h->drop_bits, h->L, K, gate, h->spec_ok, keep_matters, st));
+  RC(dd_spec_check(h->keep, h->drop_bits, h->L, K, gate, h->spec_ok, keep_matters, st,
+                   note ? h->tok_host_dev + MAX_NEW_TOKENS + 1 : nullptr));
+  return DD_OK;
+}
+static int spec_phase_b(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, hipStream_t st) {
+  const int mode = h->cfg.mask_mode;
+  const int rng_mode = uniforms ? DD_RNG_INJECTED : DD_RNG_MT19937;
+  const bool draws = mode != DD_MASK_IBLIP_QUANTILE && !uniforms;
+  const int keep_matters = (mode == DD_MASK_NEXT_NO_OVERLAP || mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) ? 0 : 1;
   // 4. fallback (returns at once when the speculation held): the reference's masks from the same draws, members re-run
   if (keep_matters) {
-    RC(dd_sample_masks_impl(h->epi, h->L, mprobs, K, h->keep, mode, rng_mode, uniforms, rs, h->drop, h->n_drop, nullptr,
+    RC(dd_sample_masks_impl(h->epi, h->L, mprobs, K, h->keep, mode, rng_mode, uniforms, dd_rng_state_ptr(rng), h->drop, h->n_drop, nullptr,
                             h->drop_bits, h->spec_ok, st, draws ? h->rng_backup : nullptr, false));
     RC(lm_sweep(h, K, h->drop_bits, 0, h->member_logits, st, nullptr, h->spec_ok));
   }
+  return DD_OK;
+}
+static int spec_phase_c(dd_lm* h, int K, hipStream_t st) {
+  const int32_t* gate = &h->state->done;
   // 5. member argmax (+ InstructBLIP's hidden-state argmax), vote, commit — as after dd_lm_step_members
   RC(dd_argmax_rows_gated(h->member_logits, K, h->V, h->Vpad, h->member_tok, gate, st));
   if (h->cfg.vote_on == DD_VOTE_HIDDEN) {
@@ -1649,6 +1667,11 @@ static int decode_step_spec(dd_lm* h, const double* mprobs, int K, dd_rng* rng, 
   }
   h->last_K = K;
   return dd_lm_step_commit(h, K, st);
+}
+static int decode_step_spec(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, hipStream_t st) {
+  RC(spec_phase_a(h, mprobs, K, rng, uniforms, st, false));
+  RC(spec_phase_b(h, mprobs, K, rng, uniforms, st));
+  return spec_phase_c(h, K, st);
 }
 
 static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
@@ -1720,7 +1743,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   hipGraphExec_t exec = nullptr;
   if (rc == DD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
     (void)hipGraphDestroy(graph);
-    if (h->graphs.size() >= 6) {
+    if (h->graphs.size() >= 12) {
       (void)hipGraphExecDestroy(h->graphs.front().exec);
       h->graphs.erase(h->graphs.begin());
     }
@@ -1736,6 +1759,102 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
   if (rc == DD_OK) h->steps_since_prefill++;
   return rc;
+}
+
+// Launch `body`'s kernels on `st`: from the handle's graph cache when `key` is there, else captured now (and cached), else eagerly.
+template <typename F>
+static int replay_or_capture(dd_lm* h, unsigned long long key, hipStream_t st, bool use_graph, F&& body) {
+  if (!use_graph) return body();
+  for (auto& g : h->graphs)
+    if (g.key == key) {
+      DD_HIP(hipGraphLaunch(g.exec, st));
+      return DD_OK;
+    }
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return body();
+  }
+  int rc = body();
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  hipGraphExec_t exec = nullptr;
+  if (rc == DD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    if (h->graphs.size() >= 12) {
+      (void)hipGraphExecDestroy(h->graphs.front().exec);
+      h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back({key, exec});
+    DD_HIP(hipGraphLaunch(exec, st));
+    return DD_OK;
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  if (rc != DD_OK) return rc;
+  return body();             // nothing was executed by the failed capture
+}
+
+// One ensemble step of ONE sequence with the fallback decided by the host: phase A (the combined sweep and the check) is launched,
+// the host waits for the check's note in pinned memory (the only wait: a few microseconds after A's last kernel), and the members'
+// re-run is launched only when the speculation failed — instead of ~350 launches that find nothing to do (≈0.7 ms of a 4 ms step).
+// Results are those of dd_lm_decode_step in every case; *held (optional) reports what the check said.  Falls back to
+// dd_lm_decode_step where the speculative step does not apply (K = 0 or > 8, injected uniforms, speculation switched off).
+extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_rng* rng, void* stream, int* held) {
+  DD_REQUIRE(h, "dd_lm_decode_step_sync: null handle");
+  hipStream_t st = (hipStream_t)stream;
+  if (held) *held = -1;
+  if (!(g_speculate && K >= 1 && K <= 8 && mprobs && st != nullptr)) return dd_lm_decode_step(h, mprobs, K, rng, nullptr, stream);
+  if (!h->prefilled) {
+    dd_set_error("dd_lm_decode_step_sync: decode before prefill");
+    return DD_ESTATE;
+  }
+  if (h->T_host + 1 >= h->T_cap) {
+    dd_set_error("dd_lm_step: KV cache full (%d tokens)", h->T_cap);
+    return DD_ESTATE;
+  }
+  DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
+  DD_REQUIRE(h->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || rng, "dd_lm_step: an rng is required");
+  const bool use_graph = g_use_graph && h->steps_since_prefill >= 1;
+  unsigned long long key = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+  mix(0x73796e63ull);
+  mix((unsigned long long)K);
+  for (int k = 0; k < K; ++k) {
+    unsigned long long bits;
+    memcpy(&bits, &mprobs[k], 8);
+    mix(bits);
+  }
+  mix((unsigned long long)ddk_attn_grid_tiles(h->T_host, h->T_cap));
+  mix(((unsigned long long)h->L << 32) | (unsigned)h->span_start);
+  mix(dd_rng_serial(rng));
+  mix((unsigned long long)(uintptr_t)st);
+  const int sT = h->T_host, sN = h->n_tok_host;
+  volatile int32_t* note = h->tok_host + MAX_NEW_TOKENS + 1;
+  const int expect = ++h->spec_seq_host;
+  int rc = replay_or_capture(h, key ^ 0xA1ull, st, use_graph, [&]() { return spec_phase_a(h, mprobs, K, rng, nullptr, st, true); });
+  if (rc != DD_OK) {
+    h->spec_seq_host--;
+    return rc;
+  }
+  // the one wait of the step: the check's note (sequence number, then the verdict)
+  for (unsigned long long spins = 0; note[0] != expect; ++spins) {
+    if ((spins & 0xFFFFF) == 0xFFFFF && hipStreamQuery(st) == hipSuccess && note[0] != expect) {
+      dd_set_error("dd_lm_decode_step_sync: the stream drained without the speculation check reporting (expected note %d, saw %d)", expect, (int)note[0]);
+      return DD_EHIP;
+    }
+    __builtin_ia32_pause();
+  }
+  const int ok = note[1];
+  if (held) *held = ok;
+  if (!ok) RC(replay_or_capture(h, key ^ 0xB2ull, st, use_graph, [&]() { return spec_phase_b(h, mprobs, K, rng, nullptr, st); }));
+  h->last_K = K;
+  rc = replay_or_capture(h, key ^ 0xC3ull, st, use_graph, [&]() { return spec_phase_c(h, K, st); });
+  // host mirrors: exactly one step, whether the phases ran on the host now (eager / capture) or were replayed
+  h->T_host = sT, h->n_tok_host = sN, h->bit0 = 0;
+  if (rc != DD_OK) return rc;
+  h->last_K = K, h->T_host = sT + 1, h->n_tok_host = sN + 1, h->steps_since_prefill++;
+  if (h->cfg.leak_mask) h->have_leak = true;
+  return DD_OK;
 }
 
 // Replays the whole group step (n + 1 sweeps, ~1600 launches) from a hipGraph when nothing but device-side state has
@@ -1807,7 +1926,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   hipGraphExec_t exec = nullptr;
   if (rc == DD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
     (void)hipGraphDestroy(graph);
-    if (h0->graphs.size() >= 6) {
+    if (h0->graphs.size() >= 12) {
       (void)hipGraphExecDestroy(h0->graphs.front().exec);
       h0->graphs.erase(h0->graphs.begin());
     }

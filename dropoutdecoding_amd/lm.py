@@ -164,6 +164,7 @@ class DropoutEngine:
         self._peek_buf = np.zeros(8192, dtype=np.int32)
         self._n_enqueued = 0
         self._eos_dev: Optional[tuple] = None        # eos ids currently held in the sequence's device state
+        self.sync_steps = True                       # generate(): host-decided fallback of the speculative step
 
     def _s(self) -> int:
         return self.torch_stream.cuda_stream
@@ -281,6 +282,19 @@ class DropoutEngine:
         self._last_K = K
         self._n_enqueued += 1
 
+    def decode_step_sync(self, mprobs: Optional[Sequence[float]] = None, dropout: bool = True) -> int:
+        """One ensemble step with the speculative step's fallback decided by the host (dd_lm_decode_step_sync): the calling
+        thread waits for the check (microseconds after the sweep) and the members are re-run only when needed.  Same results
+        as decode_step().  Returns 1 (the speculative members stood), 0 (re-run) or -1 (went through decode_step's path)."""
+        probs, arr = self._probs(mprobs)
+        K = len(probs) if dropout else 0
+        held = C.c_int(-1)
+        _lib.check(self.lib.dd_lm_decode_step_sync(self._h, arr, K, self.rng.handle, self._s(), C.byref(held)),
+                   "dd_lm_decode_step_sync")
+        self._last_K = K
+        self._n_enqueued += 1
+        return held.value
+
     # phased form for K-sharding (see dist.py)
     def step_base(self, mprobs=None, uniforms=None) -> int:
         probs, arr = self._probs(mprobs)
@@ -350,6 +364,10 @@ class DropoutEngine:
         timing."""
         eos_set = set(_eos_ids(eos))
         self._sync_eos(eos_set)
+        if step_fn is None and dropout and self.sync_steps and 1 <= len(self._probs(mprobs)[0]) <= 8:
+            # one sequence on its own: the host decides the speculative step's fallback (no queue of steps ahead of the GPU;
+            # a step enqueued after the EOS step — the mirror lags by one — is a device-side no-op)
+            step_fn, lookahead = (lambda: self.decode_step_sync(mprobs)), 1 << 30
         step = step_fn or (lambda: self.decode_step(mprobs, dropout=dropout))
         enq = self._n_enqueued
         while enq < n_new:

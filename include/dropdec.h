@@ -271,6 +271,17 @@ int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds_dev, int T0, int span_s
 int dd_lm_decode_step(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, const float* uniforms_dev,
                       void* stream);
 
+/* dd_lm_decode_step for ONE sequence with the fallback of the speculative step decided by the host (the reference's
+ * loop, models/llava.py:326-359, one image at a time): the combined sweep (un-masked row + K members under masks drawn
+ * for an empty keep set) and the check are launched, the calling thread waits for the check's verdict in pinned memory
+ * (the only wait of the step, microseconds after the sweep's last kernel), and the members' re-run with the real keep
+ * set is launched only when the verdict asks for it — dd_lm_decode_step enqueues that re-run unconditionally (its ~350
+ * kernels return at once when not needed: about 0.7 ms of a 4 ms step).  Every result equals dd_lm_decode_step's.
+ * *held (may be NULL): 1 the speculative members stood, 0 they were re-run, -1 the call went through dd_lm_decode_step
+ * (K = 0 or > 8, speculation switched off).  The steps of one sequence must not be mixed between the two calls while
+ * earlier ones are still in flight on different streams. */
+int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, void* stream, int* held);
+
 /* The same step in phases, for sharding the K members over ranks (nothing in the reference to
  * mirror: its K members run sequentially in one process, models/llava.py:342-359):
  *   dd_lm_step_base     un-masked pass + keep set + masks for ALL K members (every rank, identical, no comm);

@@ -23,7 +23,7 @@ def E():
     return lm
 
 
-def _run(E, eng, emb, s0, L, probs, steps, spec, graph, seed):
+def _run(E, eng, emb, s0, L, probs, steps, spec, graph, seed, sync=False):
     lib = eng.lib
     lib.dd_set_tuning(14, 1 if spec else 0)
     lib.dd_set_tuning(8, 1 if graph else 0)
@@ -32,11 +32,14 @@ def _run(E, eng, emb, s0, L, probs, steps, spec, graph, seed):
         eng.prefill(emb.cuda(), s0, L)
         recs, oks = [], []
         for _ in range(steps):
-            eng.decode_step(probs)
+            held = eng.decode_step_sync(probs) if sync else None
+            if not sync:
+                eng.decode_step(probs)
             st = eng.last_step()
             recs.append((st["drop"].copy(), st["masked_numbers"].tolist(), st["member_argmax"].tolist(), st["winner"], st["keep"].copy(),
                          eng.logits().copy(), eng.base_logits().copy()))
             oks.append(eng.spec_ok() if spec else -1)
+            assert held is None or held == oks[-1]
         return recs, eng.tokens(), eng.kv_sums().copy(), eng.rng.rand(32).cpu().numpy(), oks
     finally:
         lib.dd_set_tuning(14, 1)
@@ -57,8 +60,8 @@ def test_speculative_step_equals_two_sweep_step(E, family, K, use_random):
     probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8][:K]
     steps = 40
     ref = _run(E, eng, emb, s0, L, probs, steps, spec=False, graph=False, seed=7)
-    for graph in (False, True):
-        got = _run(E, eng, emb, s0, L, probs, steps, spec=True, graph=graph, seed=7)
+    for graph, sync in ((False, False), (True, False), (False, True), (True, True)):   # sync: the host decides the fallback
+        got = _run(E, eng, emb, s0, L, probs, steps, spec=True, graph=graph, seed=7, sync=sync)
         assert got[1] == ref[1]
         for s, (a, b) in enumerate(zip(got[0], ref[0])):
             np.testing.assert_array_equal(a[0], b[0], err_msg=f"drop masks, step {s}")
@@ -138,9 +141,9 @@ def test_philox_stream_end_to_end(E, family, use_random):
     cpu_tokens = RefDecoder(family, RC, w, probs, seed=7, use_random=use_random).generate(emb, s0, L, steps + 1)
     assert want != cpu_tokens, "the two generators must lead to different sequences for the test to mean something"
     oks_seen = []
-    for spec, graph in ((False, False), (True, False), (True, True)):
-        _, toks, _, after, oks = _run(E, eng, emb, s0, L, probs, steps, spec=spec, graph=graph, seed=7)
-        assert toks == want, (spec, graph)
+    for spec, graph, sync in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+        _, toks, _, after, oks = _run(E, eng, emb, s0, L, probs, steps, spec=spec, graph=graph, seed=7, sync=sync)
+        assert toks == want, (spec, graph, sync)
         np.testing.assert_array_equal(after, tail)
         oks_seen += [o for o in oks if o >= 0]
     if not use_random:
@@ -159,3 +162,36 @@ def test_philox_stream_end_to_end(E, family, use_random):
         np.testing.assert_array_equal(lanes[i].rng.rand(8).cpu().numpy(), r.rng.rand_f32(8))
     for e in reversed(lanes):
         e.close()
+
+
+def test_generate_uses_the_host_decided_step_and_matches_the_queued_loop(E):
+    """DropoutEngine.generate(): the one-sequence loop goes through dd_lm_decode_step_sync; tokens, the rng stream afterwards
+    and the EOS stop equal the queued loop's (sync_steps = False) and the oracle's."""
+    w = random_weights(RC, 31, 0.05)
+    cfg = E.LMConfig(RC.vocab_size, RC.hidden_size, RC.intermediate_size, RC.num_layers, RC.num_heads, RC.num_kv_heads,
+                     RC.head_dim, RC.rms_eps, RC.rope_theta)
+    L, s0, probs = 40, 3, [0.2, 0.4, 0.6, 0.8]
+    eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=192, max_visual=L, seed=7)
+    eng.load_state_dict(w)
+    emb = torch.randn(L + 9, RC.hidden_size, generator=torch.Generator().manual_seed(77)) * 0.8
+    want = RefDecoder(FAMILY_LLAVA, RC, w, probs, seed=7).generate(emb, s0, L, 40)
+    eos = want[17]
+    cut = want[:want.index(eos) + 1]
+    outs = []
+    for sync in (True, False, True):
+        eng.sync_steps = sync
+        eng.rng.manual_seed(7)
+        eng.prefill(emb.cuda(), s0, L)
+        full = eng.generate(40, mprobs=probs)
+        eng.prefill(emb.cuda(), s0, L)                 # second image on the same stream, stopped by an EOS
+        short = eng.generate(40, eos=[eos], mprobs=probs)
+        outs.append((full, short, eng.rng.rand(16).cpu().numpy()))
+    assert outs[0][0] == want
+    ref2 = RefDecoder(FAMILY_LLAVA, RC, w, probs, seed=7)
+    ref2.generate(emb, s0, L, 40)
+    second = ref2.generate(emb, s0, L, 40)
+    assert outs[0][1] == second[:second.index(eos) + 1] if eos in second else second
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[1] == outs[0][1]
+        np.testing.assert_array_equal(o[2], outs[0][2])
+    eng.close()
