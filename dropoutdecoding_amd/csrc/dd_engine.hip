@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <chrono>
 #include <vector>
 
 #include "dd_lm_kernels.h"
@@ -1837,10 +1838,17 @@ extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_
     return rc;
   }
   // the one wait of the step: the check's note (sequence number, then the verdict)
+  const auto t_wait = std::chrono::steady_clock::now();
   for (unsigned long long spins = 0; note[0] != expect; ++spins) {
-    if ((spins & 0xFFFFF) == 0xFFFFF && hipStreamQuery(st) == hipSuccess && note[0] != expect) {
-      dd_set_error("dd_lm_decode_step_sync: the stream drained without the speculation check reporting (expected note %d, saw %d)", expect, (int)note[0]);
-      return DD_EHIP;
+    if ((spins & 0xFFFFF) == 0xFFFFF) {
+      if (hipStreamQuery(st) == hipSuccess && note[0] != expect) {
+        dd_set_error("dd_lm_decode_step_sync: the stream drained without the speculation check reporting (expected note %d, saw %d)", expect, (int)note[0]);
+        return DD_EHIP;
+      }
+      if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(300)) {
+        dd_set_error("dd_lm_decode_step_sync: no verdict from the speculation check after 300 s (note %d, expected %d)", (int)note[0], expect);
+        return DD_EHIP;
+      }
     }
     __builtin_ia32_pause();
   }
