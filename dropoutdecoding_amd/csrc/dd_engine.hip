@@ -1618,7 +1618,7 @@ static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
 
 // The step in three phases.  A: masks for an empty keep set, the combined sweep, the real keep set and the check.  B: the
 // fallback (every kernel returns at once when the device flag says the speculation held).  C: member argmax, vote, commit.
-// dd_lm_decode_step enqueues A, B, C back to back (one graph: the host never waits, B's ~350 launches cost ≈0.7 ms even when
+// dd_lm_decode_step enqueues A, B, C back to back (one graph: the host never waits, B's ~350 launches cost ≈0.3 ms even when
 // they have nothing to do); dd_lm_decode_step_sync enqueues A with a note to the host and B only when the note says so.
 static int spec_phase_a(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, hipStream_t st, bool note) {
   const int32_t* gate = &h->state->done;
@@ -1797,7 +1797,7 @@ static int replay_or_capture(dd_lm* h, unsigned long long key, hipStream_t st, b
 
 // One ensemble step of ONE sequence with the fallback decided by the host: phase A (the combined sweep and the check) is launched,
 // the host waits for the check's note in pinned memory (the only wait: a few microseconds after A's last kernel), and the members'
-// re-run is launched only when the speculation failed — instead of ~350 launches that find nothing to do (≈0.7 ms of a 4 ms step).
+// re-run is launched only when the speculation failed — instead of ~350 launches that find nothing to do (≈0.3 ms of a 4 ms step).
 // Results are those of dd_lm_decode_step in every case; *held (optional) reports what the check said.  Falls back to
 // dd_lm_decode_step where the speculative step does not apply (K = 0 or > 8, injected uniforms, speculation switched off).
 extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_rng* rng, void* stream, int* held) {

@@ -276,7 +276,7 @@ int dd_lm_decode_step(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, c
  * for an empty keep set) and the check are launched, the calling thread waits for the check's verdict in pinned memory
  * (the only wait of the step, microseconds after the sweep's last kernel), and the members' re-run with the real keep
  * set is launched only when the verdict asks for it — dd_lm_decode_step enqueues that re-run unconditionally (its ~350
- * kernels return at once when not needed: about 0.7 ms of a 4 ms step).  Every result equals dd_lm_decode_step's.
+ * kernels return at once when not needed: about 0.3 ms of a 4 ms step).  Every result equals dd_lm_decode_step's.
  * *held (may be NULL): 1 the speculative members stood, 0 they were re-run, -1 the call went through dd_lm_decode_step
  * (K = 0 or > 8, speculation switched off).  The steps of one sequence must not be mixed between the two calls while
  * earlier ones are still in flight on different streams. */
