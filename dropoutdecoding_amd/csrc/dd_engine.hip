@@ -1781,7 +1781,7 @@ static int replay_or_capture(dd_lm* h, unsigned long long key, hipStream_t st, b
   hipGraphExec_t exec = nullptr;
   if (rc == DD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
     (void)hipGraphDestroy(graph);
-    if (h->graphs.size() >= 12) {
+    if (h->graphs.size() >= 24) {
       (void)hipGraphExecDestroy(h->graphs.front().exec);
       h->graphs.erase(h->graphs.begin());
     }
