@@ -82,7 +82,7 @@ def cpu_baseline(K: int, budget_s: float = 20.0):
         import ctypes
         libc = ctypes.CDLL("libc.so.6")
         libc.mallopt(-3, 1 << 30)      # M_MMAP_THRESHOLD
-        libc.mallopt(-1, 1 << 31 - 1)  # M_TRIM_THRESHOLD
+        libc.mallopt(-1, (1 << 31) - 1)  # M_TRIM_THRESHOLD
         host["malloc"] = "glibc, M_MMAP_THRESHOLD=1GiB (large tensors reuse heap memory)"
     except Exception:
         host["malloc"] = "glibc defaults"
@@ -175,10 +175,6 @@ def main() -> int:
     ap.add_argument("--images-per-gpu", type=int, default=32,
                     help="images decoded concurrently per GPU (lanes over one set of weights, 1..64); 1 = the reference's "
                          "one-image-at-a-time loop")
-    ap.add_argument("--decode-streams", type=int, default=1, choices=[1, 2],
-                    help="2 (with 16+ images per GPU): decode the lanes as two independent halves on two streams.  Decode alone gains "
-                         "13 %% from it (28.2 vs 32.5 ms per 32-lane step), the whole pipeline loses 5 %% (792 vs 830 tok/s): the next "
-                         "batch's prefill on its own stream already fills the gaps of the sweep")
     ap.add_argument("--no-batch-tower", action="store_true", help="one vision-tower call per image instead of one per 16 images (A/B)")
     ap.add_argument("--prefill-chunk", type=int, default=16, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (experiments)")
@@ -249,9 +245,8 @@ def main() -> int:
     if B > 1:
         # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
         from dropoutdecoding_amd.vlm import GroupPipeline
-        pipe = GroupPipeline(model, lanes=B, decode_streams=args.decode_streams if B >= 16 else 1)
-        for p_ in (pipe.halves or [pipe]):
-            p_.prefill_chunk = max(1, args.prefill_chunk)
+        pipe = GroupPipeline(model, lanes=B)
+        pipe.prefill_chunk = max(1, args.prefill_chunk)
 
     def batch_inputs(i):
         out = []
@@ -379,7 +374,6 @@ def main() -> int:
                                    + (f"; the {B} images are {B} independent sequences (own KV cache and rng stream, results identical to "
                                       "decoding each alone) whose un-masked passes share one sweep over the weights and whose member passes run eight sequences "
                                       "(64 rows) per sweep; the next batch's CLIP + prefill overlap the current batch's decode on a second stream"
-                                      + (f"; the {B} sequences decode as two independent halves of {(B + 1) // 2} on two streams" if B >= 16 and args.decode_streams == 2 else "")
                                       if B > 1 else ""),
                        "batch_note": (f"`value` is the aggregate over {B} independent images decoded concurrently per GPU (throughput mode, the "
                                       "reference's multi-process sharding on one GPU); the reference's own shape, one image at a time, is `single_stream`"

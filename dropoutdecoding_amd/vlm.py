@@ -332,34 +332,14 @@ class GroupPipeline:
     prefill of the NEXT batch are enqueued on a second stream (the decode step is HBM-bound, the prefill MFMA-bound, so
     they overlap) — the 500-image CHAIR job of the reference's SLURM launchers on one GPU.
 
-    Each image is still decoded exactly as `generate()` would decode it on a lane of its own (see generate_group).
+    Each image is still decoded exactly as `generate()` would decode it on a lane of its own (see generate_group)."""
 
-    decode_streams = 2: the lanes are split into two halves, each a pipeline of its own (decode stream, prefill stream, host
-    thread).  A sweep over the weights leaves the memory system idle between its streaming kernels (finishing kernels,
-    attention, launch boundaries); a second, independent group of sequences fills those gaps: 32 lanes as 2 x 16 take 28.2 ms
-    per step against 32.5 ms as one group, although each half runs its own un-masked pass.  Lanes are independent sequences
-    (own KV cache, own rng stream), so the split changes no result.  Measured end to end (bench.py, 32 images per batch) it does
-    NOT pay: 792 vs 830 tok/s — the next batch's prefill, on its own stream, already fills those gaps — so 1 is the default."""
-
-    def __init__(self, model: DropoutVLM, lanes: int = 8, decode_streams: int = 1, _sets=None):
+    def __init__(self, model: DropoutVLM, lanes: int = 8):
         if not 1 <= lanes <= 64:
             raise ValueError("1..64 lanes per set")
-        if decode_streams not in (1, 2):
-            raise ValueError("decode_streams: 1 or 2")
         self.device = model.device
-        self.halves = None
-        if decode_streams == 2 and lanes >= 2:
-            na = (lanes + 1) // 2
-            second = [[model.spawn_lane() for _ in range(lanes - na)] for _ in range(2)]
-            st = torch.cuda.Stream(device=model.device)
-            for lane_set in second:
-                for m in lane_set:
-                    m.engine.torch_stream = st                    # this half decodes on a stream of its own
-            self.halves = [GroupPipeline(model, na), GroupPipeline(model, lanes - na, _sets=second)]
-            self.sets = [self.halves[0].sets[k] + self.halves[1].sets[k] for k in range(2)]
-            return
-        self.sets = _sets if _sets is not None else [[model] + [model.spawn_lane() for _ in range(lanes - 1)],
-                                                     [model.spawn_lane() for _ in range(lanes)]]
+        # one host thread, one decode stream: the library's graph capture is not safe against a second capturing thread
+        self.sets = [[model] + [model.spawn_lane() for _ in range(lanes - 1)], [model.spawn_lane() for _ in range(lanes)]]
         self.pre_stream = torch.cuda.Stream(device=model.device)
         self.prefill_chunk = 16          # sequences per LM prefill pass (dd_lm_prefill_group); 1: one prefill per image
 
@@ -399,14 +379,13 @@ class GroupPipeline:
         """batches: iterable of lists of generate() keyword dicts (up to `lanes` each); yields the list of output id tensors
         of each batch, in order."""
         from .lm import EngineGroup
-        if self.halves is not None:
-            yield from self._run_halves(batches, max_new_tokens, eos_token_id)
-            return
         kw = {"max_new_tokens": max_new_tokens, "eos_token_id": eos_token_id}
         it = iter(batches)
         first = next(it, None)
         while first is not None and len(first) == 0:           # empty batches (a trailing [] of a batching generator) are skipped
             first = next(it, None)
+        if first is not None and len(first) > len(self.sets[0]):
+            raise ValueError(f"a batch of {len(first)} images for {len(self.sets[0])} lanes")
         cur = self._stage(self.sets[0], first, kw) if first is not None else None
         k = 0
         while cur is not None:
@@ -441,64 +420,3 @@ class GroupPipeline:
             nxt = following["state"]
             yield [m._finalize(p[0], t) for m, p, t in zip(lanes, prepared, toks)]
             cur = nxt
-
-    def _run_halves(self, batches, max_new_tokens, eos_token_id):
-        """Two half pipelines on two host threads; a feeder cuts every batch in two; outputs come back in batch order."""
-        import queue
-        import threading
-        na = len(self.halves[0].sets[0])
-        q_in = [queue.Queue(maxsize=2), queue.Queue(maxsize=2)]
-        q_out = [queue.Queue(), queue.Queue()]
-        sizes = queue.Queue()
-        errors = []
-
-        def feeder():
-            try:
-                for b in batches:
-                    b = list(b)
-                    if not b:
-                        continue
-                    if len(b) > len(self.sets[0]):
-                        raise ValueError(f"a batch of {len(b)} images for {len(self.sets[0])} lanes")
-                    sizes.put((min(len(b), na), max(0, len(b) - na)))
-                    q_in[0].put(b[:na])
-                    q_in[1].put(b[na:])                       # may be empty: the half skips it
-            except BaseException as e:                        # surfaced by the consumer below
-                errors.append(e)
-            finally:
-                sizes.put(None)
-                q_in[0].put(None)
-                q_in[1].put(None)
-
-        def worker(k):
-            try:
-                torch.cuda.set_device(self.device)
-                for outs in self.halves[k].run(iter(q_in[k].get, None), max_new_tokens, eos_token_id):
-                    q_out[k].put(outs)
-            except BaseException as e:
-                errors.append(e)
-            finally:
-                q_out[k].put(None)
-
-        threads = [threading.Thread(target=feeder, daemon=True)] + [threading.Thread(target=worker, args=(k,), daemon=True) for k in (0, 1)]
-        for t in threads:
-            t.start()
-        while True:
-            sz = sizes.get()
-            if sz is None or errors:
-                break
-            outs = []
-            for k in (0, 1):
-                if sz[k]:
-                    got = q_out[k].get()
-                    if got is None:
-                        break
-                    outs += got
-            else:
-                yield outs
-                continue
-            break
-        for t in threads:
-            t.join(timeout=60)
-        if errors:
-            raise errors[0]
