@@ -14,7 +14,7 @@ SYMBOLS = [
     "dd_uncertainty_workspace_bytes", "dd_vision_uncertainty", "dd_overlap_keep", "dd_kl_keep", "dd_sample_masks", "dd_vote",
     "dd_argmax_rows",
     "dd_lm_create", "dd_lm_create_shared", "dd_lm_group_step", "dd_lm_destroy", "dd_lm_device_bytes", "dd_lm_load_tensor", "dd_lm_load_tensor_fp8", "dd_lm_load_synthetic",
-    "dd_lm_prefill", "dd_lm_prefill_group", "dd_lm_decode_step_sync", "dd_lm_prefill_ensemble", "dd_lm_truncate", "dd_lm_prefill_extend", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
+    "dd_lm_prefill", "dd_lm_prefill_group", "dd_lm_decode_step_sync", "dd_lm_set_speculation", "dd_lm_spec_stats", "dd_lm_prefill_ensemble", "dd_lm_truncate", "dd_lm_prefill_extend", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_set_eos", "dd_lm_step_algorithmic_bytes",
     "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench",
@@ -107,6 +107,8 @@ def load() -> C.CDLL:
     lib.dd_lm_prefill_ensemble.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, vp, vp, vp]
     lib.dd_lm_decode_step.argtypes = [vp, C.POINTER(C.c_double), C.c_int, vp, vp, vp]
     lib.dd_lm_decode_step_sync.argtypes = [vp, C.POINTER(C.c_double), C.c_int, vp, vp, C.POINTER(C.c_int)]
+    lib.dd_lm_set_speculation.argtypes = [vp, C.c_int]
+    lib.dd_lm_spec_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
     lib.dd_lm_step_base.argtypes = [vp, C.POINTER(C.c_double), C.c_int, vp, vp, vp]
     lib.dd_lm_step_members.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.dd_lm_step_commit.argtypes = [vp, C.c_int, vp]

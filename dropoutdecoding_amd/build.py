@@ -14,19 +14,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libdropdec.so")
-SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_engine.hip", "dd_vision.hip"]
-HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_gemv_slices.h", os.path.join(ROOT, "include", "dropdec.h")]
+SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_gemv.hip", "dd_attn_decode.hip", "dd_prefill.hip", "dd_engine.hip", "dd_vision.hip"]
+HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
+FLAGS = ["-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 
-def _src_hash() -> str:
+def _file_hash(paths) -> str:
     import hashlib
     h = hashlib.sha256()
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [x if os.path.isabs(x) else os.path.join(CSRC, x) for x in HEADERS]
-    for d in deps:
+    for d in paths:
         with open(d, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def _header_paths():
+    return [x if os.path.isabs(x) else os.path.join(CSRC, x) for x in HEADERS]
+
+
+def _src_hash() -> str:
+    return _file_hash([os.path.join(CSRC, s) for s in SOURCES] + _header_paths()) + "|" + " ".join(FLAGS)
 
 
 def _stale() -> bool:
@@ -38,19 +46,32 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the sources whose content (or a header's) changed — all of them in parallel — and link."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objs, jobs = [], []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
     for s in SOURCES:
-        o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-c",
-               os.path.join(CSRC, s), "-o", o]
+        o = os.path.join(bdir, s.replace(".hip", ".o"))
+        objs.append(o)
+        want = _file_hash([os.path.join(CSRC, s)] + _header_paths()) + "|" + " ".join(FLAGS)
+        stamp = o + ".srchash"
+        if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            continue
+        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(o)
+        jobs.append((subprocess.Popen(cmd), cmd, stamp, want))
+    for pr, cmd, stamp, want in jobs:
+        if pr.wait() != 0:
+            for other, *_ in jobs:
+                if other.poll() is None:
+                    other.kill()
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        with open(stamp, "w") as f:
+            f.write(want)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -127,6 +127,12 @@ struct dd_lm {
   int32_t* tok_host = nullptr;       // host pointer: [0] = count, [1..] = tokens
   int32_t* tok_host_dev = nullptr;   // the same memory as seen from the device
   int spec_seq_host = 0;             // speculation checks announced to the host so far (dd_lm_decode_step_sync)
+  // speculation policy of this sequence (dd_lm_set_speculation): -1 the process default, 0 never, 1 always, 2 adaptive —
+  // dd_lm_decode_step_sync learns every check's verdict and stops speculating while too few of them hold
+  int spec_mode = -1;
+  float spec_rate = 1.0f;            // running share of speculative steps that held (weight 1/8 per step)
+  int spec_cooldown = 0;             // adaptive: two-sweep steps left before speculation is tried again
+  long long spec_n[4] = {0, 0, 0, 0};   // speculative steps that held / were re-run, two-sweep steps, switches to two-sweep
 };
 
 template <typename T>
@@ -1537,8 +1543,16 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
 // and the members re-run (the classic second sweep) — its kernels are enqueued either way and return at once when the
 // device-side flag says the speculation held.  Results are those of the two-sweep step in every case.
 // -----------------------------------------------------------------------------------------------
-static int g_speculate = 1;   // dd_set_tuning key 14
-void dd_engine_set_speculate(int on) { g_speculate = on; }
+static int g_speculate = 2;   // dd_set_tuning key 14: process default of the policy — 0 never, 1 always, 2 adaptive
+void dd_engine_set_speculate(int mode) { g_speculate = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+static int spec_mode_of(const dd_lm* h) { return h->spec_mode >= 0 ? h->spec_mode : g_speculate; }
+// Break-even of the speculative step (LLaVA-1.5-7B shapes, K = 8): it costs one 16-row sweep when the masks stand and that
+// sweep plus the 8-row re-run when they do not, against a 1-row and an 8-row sweep for the plain step: 4.0 + (1 - h) * 3.1 ms
+// against 6.1 ms, equal at h = 0.33.  On a checkpoint whose keep sets (models/llava.py:443-482) are rarely empty the share
+// that holds falls below that and the plain step is the faster one.
+#define SPEC_BREAK_EVEN 0.35f
+#define SPEC_COOLDOWN_STEPS 32
+#define SPEC_PROBE_RATE 0.5f      // rate a probe phase starts from: three misses in a row end it
 
 static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
   const int d = h->d, dff = h->dff;
@@ -1675,8 +1689,8 @@ static int decode_step_spec(dd_lm* h, const double* mprobs, int K, dd_rng* rng, 
   return spec_phase_c(h, K, st);
 }
 
-static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
-  if (g_speculate && K >= 1 && K <= 8 && h && h->prefilled && mprobs && h->T_host + 1 < h->T_cap && h->n_tok_host < MAX_NEW_TOKENS)
+static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream, bool speculate) {
+  if (speculate && K >= 1 && K <= 8 && h && h->prefilled && mprobs && h->T_host + 1 < h->T_cap && h->n_tok_host < MAX_NEW_TOKENS)
     return decode_step_spec(h, mprobs, K, rng, uniforms, (hipStream_t)stream);
   RC(dd_lm_step_base(h, mprobs, K, rng, uniforms, stream));
   if (K > 0) RC(dd_lm_step_members(h, 0, K, stream));
@@ -1690,12 +1704,12 @@ static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng,
 // in device memory), except the number of 64-key attention tiles the launch is shaped for (rounded up to 4, so it changes
 // every 256 tokens), which is part of the cache key together with K, the
 // probabilities and the rng.  Host cost per step drops from ~3.4 ms of launches to one hipGraphLaunch.
-extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
+static int decode_step_queued(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream, bool speculate) {
   DD_REQUIRE(h, "dd_lm_decode_step: null handle");
   hipStream_t st = (hipStream_t)stream;
   const bool graphable = g_use_graph && !uniforms && h->prefilled && h->steps_since_prefill >= 1 && st != nullptr;
   if (!graphable) {
-    int rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
+    int rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream, speculate);
     if (rc == DD_OK) h->steps_since_prefill++;
     return rc;
   }
@@ -1721,7 +1735,7 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   mix(((unsigned long long)h->L << 32) | (unsigned)h->span_start);   // launch arguments fixed by the last prefill
   mix(dd_rng_serial(rng));
   mix((unsigned long long)(uintptr_t)st);
-  mix((unsigned long long)g_speculate);
+  mix(speculate ? 1ull : 0ull);
   for (auto& g : h->graphs)
     if (g.key == key) {
       DD_HIP(hipGraphLaunch(g.exec, st));
@@ -1734,11 +1748,11 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   const bool sL = h->have_leak;
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
-    int rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
+    int rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream, speculate);
     if (rc == DD_OK) h->steps_since_prefill++;
     return rc;
   }
-  int rc = decode_step_eager(h, mprobs, K, rng, nullptr, stream);
+  int rc = decode_step_eager(h, mprobs, K, rng, nullptr, stream, speculate);
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(st, &graph);
   hipGraphExec_t exec = nullptr;
@@ -1757,9 +1771,14 @@ extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* 
   if (graph) (void)hipGraphDestroy(graph);
   (void)hipGetLastError();
   h->T_host = sT, h->n_tok_host = sN, h->last_K = sK, h->bit0 = sB, h->have_leak = sL;
-  rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream);
+  rc = decode_step_eager(h, mprobs, K, rng, uniforms, stream, speculate);
   if (rc == DD_OK) h->steps_since_prefill++;
   return rc;
+}
+extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
+  DD_REQUIRE(h, "dd_lm_decode_step: null handle");
+  // queued steps never tell the host how their check went: "adaptive" speculates here like "always"
+  return decode_step_queued(h, mprobs, K, rng, uniforms, stream, spec_mode_of(h) != 0);
 }
 
 // Launch `body`'s kernels on `st`: from the handle's graph cache when `key` is there, else captured now (and cached), else eagerly.
@@ -1804,7 +1823,17 @@ extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_
   DD_REQUIRE(h, "dd_lm_decode_step_sync: null handle");
   hipStream_t st = (hipStream_t)stream;
   if (held) *held = -1;
-  if (!(g_speculate && K >= 1 && K <= 8 && mprobs && st != nullptr)) return dd_lm_decode_step(h, mprobs, K, rng, nullptr, stream);
+  const int mode = spec_mode_of(h);
+  if (!(mode && K >= 1 && K <= 8 && mprobs && st != nullptr)) return decode_step_queued(h, mprobs, K, rng, nullptr, stream, mode != 0);
+  if (mode == 2 && h->spec_cooldown > 0) {
+    // adaptive: too few of the recent speculative steps held — the plain two-sweep step (queued, no host wait) for a while
+    int rc = decode_step_queued(h, mprobs, K, rng, nullptr, stream, false);
+    if (rc == DD_OK) {
+      h->spec_cooldown--;
+      h->spec_n[2]++;
+    }
+    return rc;
+  }
   if (!h->prefilled) {
     dd_set_error("dd_lm_decode_step_sync: decode before prefill");
     return DD_ESTATE;
@@ -1854,6 +1883,12 @@ extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_
   }
   const int ok = note[1];
   if (held) *held = ok;
+  h->spec_n[ok ? 0 : 1]++;
+  h->spec_rate = 0.875f * h->spec_rate + (ok ? 0.125f : 0.0f);
+  if (mode == 2 && h->spec_rate < SPEC_BREAK_EVEN) {
+    h->spec_cooldown = SPEC_COOLDOWN_STEPS, h->spec_rate = SPEC_PROBE_RATE;
+    h->spec_n[3]++;
+  }
   if (!ok) RC(replay_or_capture(h, key ^ 0xB2ull, st, use_graph, [&]() { return spec_phase_b(h, mprobs, K, rng, nullptr, st); }));
   h->last_K = K;
   rc = replay_or_capture(h, key ^ 0xC3ull, st, use_graph, [&]() { return spec_phase_c(h, K, st); });
@@ -1947,6 +1982,20 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   (void)hipGetLastError();
   restore();               // nothing was executed
   return group_step_eager(lanes, n, mprobs, K, rngs, stream_);
+}
+
+extern "C" int dd_lm_set_speculation(dd_lm* h, int mode) {
+  DD_REQUIRE(h && mode >= -1 && mode <= 2, "dd_lm_set_speculation: mode %d (-1 process default, 0 never, 1 always, 2 adaptive)", mode);
+  h->spec_mode = mode;
+  h->spec_rate = 1.0f, h->spec_cooldown = 0;
+  return DD_OK;
+}
+extern "C" int dd_lm_spec_stats(dd_lm* h, int64_t* out4, int reset) {
+  DD_REQUIRE(h && out4, "dd_lm_spec_stats: null argument");
+  for (int i = 0; i < 4; ++i) out4[i] = h->spec_n[i];
+  if (reset)
+    for (int i = 0; i < 4; ++i) h->spec_n[i] = 0;
+  return DD_OK;
 }
 
 extern "C" size_t dd_lm_xchg_stride(const dd_lm* h) {

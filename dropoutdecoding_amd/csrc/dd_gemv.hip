@@ -1,0 +1,862 @@
+// Decode GEMVs of the K-way masked-context step (gfx950, wave64): v_mfma_f32_16x16x32 with the WEIGHT tile as the A operand
+// (16 output rows) and the packed activation hi/lo pairs of up to 8 ensemble rows as the 16 B-operand columns; weights are
+// streamed straight to VGPRs (1 KiB per wave instruction, non-temporal).  8 rows: K split over the 8 waves of a workgroup and
+// reduced through LDS in a fixed order; 16 / 32 / 64 rows: slice-resident kernels (dd_gemv_slices.h) + a finishing kernel.
+// Reference anchors: the third-party LM forward the reference calls at models/llava.py:294-303,350-359.
+#include <type_traits>
+
+#include "dd_lm_kernels.h"
+#include "dd_lm_device.h"
+#include "dd_gemv_slices.h"
+
+// ===============================================================================================
+// decode GEMV
+// ===============================================================================================
+#define GEMV_WAVES 8
+#define GEMV_THREADS (GEMV_WAVES * 64)
+// U   = weight tiles requested per wave before the first MFMA consumes one (loads in flight)
+// NT  = non-temporal weight loads (read-once stream, keeps L2/MALL for the x operand and the KV cache)
+// ILV = k-steps interleaved over the 8 waves (wave w takes steps w, w+8, ...: at any instant the workgroup reads
+//       8 consecutive KiB) instead of one contiguous chunk per wave
+template <int EPI, int TILES, int U, int NT, int ILV, int FP8 = 0, int PIPE = 0, int WF = 0>
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
+  __shared__ float red[TILES * GEMV_WAVES * 256];
+  __shared__ float rstd_sh[8];
+  __shared__ float ssq_sh[8 * 16];
+  if (a.skip_if && *a.skip_if) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S, spw = S / GEMV_WAVES;
+  const int s0 = ILV ? wave : wave * spw;
+  constexpr int SS = ILV ? GEMV_WAVES : 1;   // step stride of this wave
+  const int tile0 = blockIdx.x * TILES;
+
+  f32x4_t acc[TILES];
+  const u32x4_t* wp[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    wp[t] = a.W + ((size_t)(tile0 + t) * S + s0) * 64 + lane;
+  }
+  const u32x4_t* xp = a.xop + (size_t)s0 * 64 + lane;
+  auto ldw = [](const u32x4_t* p) -> u32x4_t { return NT ? __builtin_nontemporal_load(p) : *p; };
+
+  // Everything the epilogue needs from memory is requested BEFORE the weight stream so its latency hides behind it:
+  // the folded RMSNorm's rstd (wave w assembles row w's sum of squares from the producer's slots), the residual
+  // input + next norm weight (EPI_RESID) and the rotary cos/sin (EPI_QKV).  The sum-of-squares slots are only
+  // REQUESTED here; they are reduced after the first weight batch has been issued (loads return in order, so waiting
+  // on them does not wait on the weights behind them).
+  const bool has_ssq = a.ssq_in != nullptr;
+  f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
+  // row `wave`'s slots are contiguous: one 16-byte load per lane covers 256 slots (every workgroup of the launch reads
+  // these same few lines, so the request count matters: strided 4-byte reads here cost ~2 us per launch)
+  if (has_ssq && 4 * lane < a.ssq_n) sv = *(const f32x4_t*)(a.ssq_in + (size_t)wave * a.ssq_ld + 4 * lane);
+  float pre0 = 0.f, pre1 = 0.f;
+  {
+    const int em = threadIdx.x & 7, en = threadIdx.x >> 3;
+    if (threadIdx.x < 128 && em < a.nb) {
+      if (EPI == EPI_RESID) {
+        pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
+        pre1 = a.normw_next[tile0 * 16 + en];
+      } else if (EPI == EPI_QKV) {
+        if (tile0 < a.q_tiles + a.k_tiles) {
+          int ht = tile0 < a.q_tiles ? tile0 : tile0 - a.q_tiles;
+          int f = (ht & 7) * 8 + (en & 7);
+          const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+          int pos = sp->pos;
+          pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
+          pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+        }
+      } else if (EPI == EPI_STORE) {
+        // logits of a sequence that already emitted its EOS are not overwritten by look-ahead steps (DDState::done)
+        const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+        if (sp && sp->done) pre0 = 1.f;
+      }
+    }
+  }
+
+  if constexpr (FP8) {
+    // fp8 weights: one 1 KiB load = 64 k of a tile row = two MFMA k-steps; wave w takes 64-k steps w, w+8, ...
+    // (uneven tails allowed: K = 11008 has 172 such steps)
+    const int S2 = S >> 1;
+    const u32x4_t* wq[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) wq[t] = a.W + (size_t)(tile0 + t) * S2 * 64 + lane;
+    const u32x4_t* xq = a.xop + lane;
+    constexpr int UF = 4;   // fp8 loads in flight per tile = 8 bf16 k-steps
+    for (int s2 = wave; s2 < S2; s2 += GEMV_WAVES * UF) {
+      u32x4_t wf[TILES][UF], b0[UF], b1[UF];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) wf[t][u] = ldw(wq[t] + (size_t)ss * 64);
+          b0[u] = xq[(size_t)(2 * ss) * 64];
+          b1[u] = xq[(size_t)(2 * ss + 1) * 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            u32x4_t k0, k1;
+            fp8x16_to_bf16(wf[t][u], k0, k1);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0),
+                                                             __builtin_bit_cast(bf16x8_t, b0[u]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1),
+                                                             __builtin_bit_cast(bf16x8_t, b1[u]), acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  auto finish_rstd = [&]() {
+    if (has_ssq) {
+      const int i0 = 4 * lane;
+      float v = 0.f;
+      if (i0 < a.ssq_n) v += sv.x;
+      if (i0 + 1 < a.ssq_n) v += sv.y;
+      if (i0 + 2 < a.ssq_n) v += sv.z;
+      if (i0 + 3 < a.ssq_n) v += sv.w;
+      for (int i = lane + 256; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)wave * a.ssq_ld + i];
+      v = dd_wave_sum(v);
+      if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
+    }
+  };
+  finish_rstd();
+  if constexpr (!FP8 && PIPE == 0) {
+    // batches: U steps requested together, then consumed; the other resident waves cover the drain
+    int s = 0;
+    for (; s + U <= spw; s += U) {
+      u32x4_t b[U], w[TILES][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
+        b[u] = xp[(size_t)(s + u) * SS * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+          acc[t] = dd_mfma16<WF>(w[t][u], b[u], acc[t]);
+    }
+    if (s < spw) {  // tail: the remaining (< U) steps requested together as well (K = 11008: 43 steps per wave)
+      const int rem = spw - s;
+      u32x4_t b[U], w[TILES][U];
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        if (u < rem) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)(s + u) * SS * 64);
+          b[u] = xp[(size_t)(s + u) * SS * 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        if (u < rem) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t)
+            acc[t] = dd_mfma16<WF>(w[t][u], b[u], acc[t]);
+        }
+      }
+    }
+  }
+  if constexpr (!FP8 && PIPE == 1) {
+    // Ring of U requests per wave: slot u is consumed by its MFMA and immediately re-requested U steps ahead, so the
+    // wave always has ~U weight tiles in flight (no drain between batches).
+    const int n = spw;
+    u32x4_t b[U], w[TILES][U];
+    auto req = [&](int u, int step) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) w[t][u] = ldw(wp[t] + (size_t)step * SS * 64);
+      b[u] = xp[(size_t)step * SS * 64];
+    };
+    auto use = [&](int u) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+        acc[t] = dd_mfma16<WF>(w[t][u], b[u], acc[t]);
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < n) req(u, u);
+    int s = 0;
+    for (; s + 2 * U <= n; s += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        use(u);
+        req(u, s + U + u);
+        __builtin_amdgcn_sched_barrier(0);   // keep consume -> re-request order (otherwise the scheduler sinks all
+      }                                      // requests below the last MFMA, which is the batch order again)
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u < n) use(u);
+      if (s + U + u < n) req(u, s + U + u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s + U + u < n) use(u);
+  }
+
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
+  __syncthreads();
+
+  // D[n][c]: lane = (n>>2)*16 + c, reg = n&3.  y[m][n] = sum_w (D_w[n][m] + D_w[n][m+8])   (hi + lo columns)
+  const int t = threadIdx.x;
+  // fixed order: (hi + lo) per wave, waves added in pairs, pairs in sequence — the order the slice-resident kernels
+  // reproduce from partial sums (dd_gemv_slices.h): y = sum_p ((hi+lo)(2p) + (hi+lo)(2p+1))
+  auto tile_sum = [&](int tt, int n, int m) -> float {
+    float y = 0.f;
+    int o = ((n >> 2) * 16 + m) * 4 + (n & 3);
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; w += 2) {
+      const float* r = &red[(tt * GEMV_WAVES + w) * 256];
+      y += (r[o] + r[o + 32]) + (r[256 + o] + r[256 + o + 32]);
+    }
+    if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
+    return y;
+  };
+
+  if (EPI == EPI_STORE) {
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float y = tile_sum(0, n, m);
+        if (a.ssq_in) y *= rstd_sh[m];
+        int col = tile0 * 16 + n;
+        if (col < a.n_valid && pre0 == 0.f) a.out[(size_t)m * a.ldo + col] = y;
+      }
+    }
+  } else if (EPI == EPI_RESID) {
+    float sq = 0.f;
+    int m = t & 7, n = t >> 3;
+    if (t < 128 && m < a.nb) {
+      float y = tile_sum(0, n, m);
+      int col = tile0 * 16 + n;
+      float xn = pre0 + y;
+      a.out[(size_t)m * a.ldo + col] = xn;
+      xop_store(a.xop_next, col, m, pre1 * xn, WF);
+      sq = xn * xn;
+    }
+    if (t < 128) ssq_sh[n * 8 + m] = sq;
+    __syncthreads();
+    if (t < 8) {
+      float v = 0.f;
+      for (int i = 0; i < 16; ++i) v += ssq_sh[i * 8 + t];
+      a.ssq_out[(size_t)t * a.ssq_ld + blockIdx.x] = v;
+    }
+  } else if (EPI == EPI_SILU) {
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float g = tile_sum(0, n, m), u = tile_sum(TILES - 1, n, m);
+        if (a.ssq_in) {
+          g *= rstd_sh[m];
+          u *= rstd_sh[m];
+        }
+        float act = g / (1.0f + expf(-g));  // silu
+        xop_store(a.xop_next, blockIdx.x * 16 + n, m, act * u, WF);
+      }
+    }
+  } else {  // EPI_QKV
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float y = tile_sum(0, n, m);
+        if (a.ssq_in) y *= rstd_sh[m];
+        int nt = tile0;
+        if (nt < a.q_tiles + a.k_tiles) {
+          float yp = tile_sum(0, n ^ 8, m);
+          if (a.ssq_in) yp *= rstd_sh[m];
+          bool is_q = nt < a.q_tiles;
+          int ht = is_q ? nt : nt - a.q_tiles;
+          int head = ht >> 3, f = (ht & 7) * 8 + (n & 7);
+          float c = pre0, sn = pre1;
+          // q*cos + rotate_half(q)*sin, two rounded products then one add (HF apply_rotary_pos_emb)
+          float o = (n < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
+          int i = (n < 8) ? f : ROPE_HALF + f;
+          if (is_q) a.qbuf[(size_t)m * a.q_dim + head * HEAD_DIM + i] = o;
+          else a.knew[(size_t)m * a.kv_dim + head * HEAD_DIM + i] = o;
+        } else {
+          int col = (nt - a.q_tiles - a.k_tiles) * 16 + n;
+          a.vnew[(size_t)m * a.kv_dim + col] = y;
+        }
+      }
+    }
+  }
+}
+
+// tuning knobs (dd_set_tuning): 0 = U (4/8/16), 4 = ring (1) or batch (0) request order.
+// Keys 1 (non-temporal loads) and 2 (k-step interleave) are settled at 1 and kept only as accepted no-ops.
+static int g_gemv_u = 8, g_gemv_pipe = 0;
+void ddk_set_tuning(int key, int value) {
+  if (key == 0) g_gemv_u = value;
+  else if (key == 4) g_gemv_pipe = value;
+}
+
+template <int EPI, int TILES>
+static void launch_gemv(const GemvArgs& a_, hipStream_t st) {
+  const GemvArgs& a = a_;
+#define GV(U_, P_)                                                                             \
+  do {                                                                                         \
+    if (a.wf) k_gemv<EPI, TILES, U_, 1, 1, 0, P_, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a);   \
+    else k_gemv<EPI, TILES, U_, 1, 1, 0, P_, 0><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a);        \
+  } while (0)
+  if (a.fp8) { k_gemv<EPI, TILES, 8, 1, 1, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a); return; }
+  const int u = g_gemv_u;
+  if (g_gemv_pipe) { if (u == 4) GV(4, 1); else if (u == 16) GV(16, 1); else GV(8, 1); }
+  else { if (u == 4) GV(4, 0); else if (u == 16) GV(16, 0); else GV(8, 0); }
+#undef GV
+}
+
+int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
+  DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv: K=%d must be a multiple of 256", a.S * 32);
+  DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv: nb=%d", a.nb);
+  DD_REQUIRE(!a.fp8 || a.wscale, "gemv: fp8 weights need row scales");
+  DD_REQUIRE(!a.ssq_in || a.ssq_n >= 1, "gemv: ssq_n");
+  switch (epi) {
+    case EPI_STORE: launch_gemv<EPI_STORE, 1>(a, st); break;
+    case EPI_RESID: launch_gemv<EPI_RESID, 1>(a, st); break;
+    case EPI_SILU: launch_gemv<EPI_SILU, 2>(a, st); break;
+    case EPI_QKV: launch_gemv<EPI_QKV, 1>(a, st); break;
+    default: DD_REQUIRE(false, "gemv: unknown epilogue %d", epi);
+  }
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// ===============================================================================================
+// decode GEMV, NG groups of 8 rows (NG = 2 or 4; e.g. the members of NG sequences) against ONE pass over the weights.
+// Same tiles, same k order and the same fixed-order reduction per output as k_gemv, so a row's result does not depend
+// on which of the kernels computed it; group g's B operand is plane g of the packed operand and costs one more MFMA per
+// tile step (the kernel is HBM-bound; even 4 planes keep the MFMA pipe under half busy).
+// ===============================================================================================
+
+// What the epilogue needs from memory, requested before the weight stream (k_gemv_groups) or before the partial sums
+// (k_gemv_finish): residual + next norm weight (EPI_RESID), rotary cos/sin (EPI_QKV), the finished flag (EPI_STORE).
+// Epilogue thread t < 128 * NG: group t >> 7, row m = 8 * group + (t & 7), column n = (t & 127) >> 3.
+template <int TILES>
+struct GroupsPre {
+  float pre0, pre1;
+  float rope_c[TILES], rope_s[TILES];
+};
+template <int EPI, int TILES, int NG>
+__device__ __forceinline__ void groups_prefetch(const GemvArgs& a, int tile0, GroupsPre<TILES>& p) {
+  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
+  const bool erow = et < 128 * NG && ml < a.nb;
+  p.pre0 = p.pre1 = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < TILES; ++tt) p.rope_c[tt] = p.rope_s[tt] = 0.f;
+  if (erow) {
+    if (EPI == EPI_RESID) {
+      p.pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
+      p.pre1 = a.normw_next[tile0 * 16 + en];
+    } else if (EPI == EPI_QKV) {
+      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+      const int pos = sp->pos;
+#pragma unroll
+      for (int tt = 0; tt < TILES; ++tt) {     // one (cos, sin) pair per tile of the workgroup (q_tiles, k_tiles are even)
+        const int nt = tile0 + tt;
+        if (nt < a.q_tiles + a.k_tiles) {
+          int ht = nt < a.q_tiles ? nt : nt - a.q_tiles;
+          int f = (ht & 7) * 8 + (en & 7);
+          p.rope_c[tt] = a.rope_cos[(size_t)pos * ROPE_HALF + f];
+          p.rope_s[tt] = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+        }
+      }
+    } else if (EPI == EPI_STORE) {
+      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+      if (sp && sp->done) p.pre0 = 1.f;    // finished sequence: its logits stay as the EOS step left them
+    }
+  }
+}
+// folded RMSNorm: wave w assembles rstd of rows w, w + 8, ... from the producer's sum-of-squares slots
+template <int NG>
+__device__ __forceinline__ void groups_rstd(const GemvArgs& a, float* rstd_sh) {
+  if (a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, rstd_sh);
+}
+// everything after the reduction; tile_sum(tt, n) = this thread's (group, row) sum for output row n of tile tt.
+// wg = index of the workgroup's tile set (k_gemv_groups: blockIdx.x); rstd_sh must be visible (barrier before the call).
+template <int EPI, int TILES, int NG, typename TS>
+__device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const GroupsPre<TILES>& p, const float* rstd_sh,
+                                                float* ssq_sh, TS tile_sum) {
+  const int tile0 = wg * TILES;
+  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
+  const bool erow = et < 128 * NG && ml < a.nb;
+  if (EPI == EPI_STORE) {
+    if (erow) {
+      float y = tile_sum(0, en);
+      if (a.ssq_in) y *= rstd_sh[em];
+      int col = tile0 * 16 + en;
+      float* row = a.out_g[eg] ? a.out_g[eg] + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
+      if (col < a.n_valid && p.pre0 == 0.f) row[col] = y;
+    }
+  } else if (EPI == EPI_RESID) {
+    float sq = 0.f;
+    if (erow) {
+      float y = tile_sum(0, en);
+      int col = tile0 * 16 + en;
+      float xn = p.pre0 + y;
+      a.out[(size_t)em * a.ldo + col] = xn;
+      xop_store16(a.xop_next, col, em, p.pre1 * xn, a.S_next, a.wf);
+      sq = xn * xn;
+    }
+    if (et < 128 * NG) ssq_sh[en * (8 * NG) + em] = sq;
+    __syncthreads();
+    if (et < 8 * NG) {
+      float v = 0.f;
+      for (int i = 0; i < 16; ++i) v += ssq_sh[i * (8 * NG) + et];
+      a.ssq_out[(size_t)et * a.ssq_ld + wg] = v;
+    }
+  } else if (EPI == EPI_SILU) {
+    if (erow) {
+      float g = tile_sum(0, en), u = tile_sum(TILES - 1, en);
+      if (a.ssq_in) {
+        g *= rstd_sh[em];
+        u *= rstd_sh[em];
+      }
+      float act = g / (1.0f + expf(-g));  // silu
+      xop_store16(a.xop_next, wg * 16 + en, em, act * u, a.S_next, a.wf);
+    }
+  } else {  // EPI_QKV
+    if (erow) {
+      float* kn = a.knew_g[eg] ? a.knew_g[eg] + (size_t)ml * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
+      float* vn = a.vnew_g[eg] ? a.vnew_g[eg] + (size_t)ml * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+#pragma unroll
+      for (int tt = 0; tt < TILES; ++tt) {
+        float y = tile_sum(tt, en);
+        if (a.ssq_in) y *= rstd_sh[em];
+        const int nt = tile0 + tt;
+        if (nt < a.q_tiles + a.k_tiles) {
+          float yp = tile_sum(tt, en ^ 8);
+          if (a.ssq_in) yp *= rstd_sh[em];
+          bool is_q = nt < a.q_tiles;
+          int ht = is_q ? nt : nt - a.q_tiles;
+          int head = ht >> 3, f = (ht & 7) * 8 + (en & 7);
+          float c = p.rope_c[tt], sn = p.rope_s[tt];
+          float o = (en < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
+          int i = (en < 8) ? f : ROPE_HALF + f;
+          if (is_q) a.qbuf[(size_t)em * a.q_dim + head * HEAD_DIM + i] = o;
+          else kn[head * HEAD_DIM + i] = o;
+        } else {
+          int col = (nt - a.q_tiles - a.k_tiles) * 16 + en;
+          vn[col] = y;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int TILES, int NG, int U = 4, int FP8 = 0, int WF = 0>
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
+  extern __shared__ float gg_sh[];
+  float* red = gg_sh;                                   // [TILES * NG * 8 waves][256]
+  float* rstd_sh = red + TILES * NG * GEMV_WAVES * 256;  // [8 * NG]
+  float* ssq_sh = rstd_sh + 8 * NG;                     // [16][8 * NG]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S, spw = S / GEMV_WAVES;
+  const int tile0 = blockIdx.x * TILES;
+  f32x4_t acc[TILES][NG];
+  const u32x4_t* wp[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[t][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    wp[t] = a.W + ((size_t)(tile0 + t) * S + wave) * 64 + lane;
+  }
+  const u32x4_t* xp = a.xop + (size_t)wave * 64 + lane;      // plane g: + g * S * 64
+  const size_t xplane = (size_t)S * 64;
+  GroupsPre<TILES> pre;
+  groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
+  groups_rstd<NG>(a, rstd_sh);
+
+  if constexpr (FP8) {
+    // fp8 weights: one 1 KiB load = 64 k of a tile row = two MFMA k-steps, expanded exactly to bf16 in registers ONCE and
+    // used for all NG operand planes; wave w takes 64-k steps w, w+8, ... (same order as k_gemv's fp8 path)
+    const int S2 = S >> 1;
+    const u32x4_t* wq[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) wq[t] = a.W + (size_t)(tile0 + t) * S2 * 64 + lane;
+    const u32x4_t* xq = a.xop + lane;
+    constexpr int UF = 2;
+    for (int s2 = wave; s2 < S2; s2 += GEMV_WAVES * UF) {
+      u32x4_t wf[TILES][UF], b0[UF][NG], b1[UF][NG];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) wf[t][u] = __builtin_nontemporal_load(wq[t] + (size_t)ss * 64);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            b0[u][g] = xq[(size_t)(2 * ss) * 64 + g * xplane];
+            b1[u][g] = xq[(size_t)(2 * ss + 1) * 64 + g * xplane];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        int ss = s2 + u * GEMV_WAVES;
+        if (ss < S2) {
+#pragma unroll
+          for (int t = 0; t < TILES; ++t) {
+            u32x4_t k0, k1;
+            fp8x16_to_bf16(wf[t][u], k0, k1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0),
+                                                                  __builtin_bit_cast(bf16x8_t, b0[u][g]), acc[t][g], 0, 0, 0);
+              acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1),
+                                                                  __builtin_bit_cast(bf16x8_t, b1[u][g]), acc[t][g], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  int s = FP8 ? spw : 0;
+  for (; s + U <= spw; s += U) {
+    u32x4_t b[U][NG], w[TILES][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * GEMV_WAVES * 64);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) b[u][g] = xp[(size_t)(s + u) * GEMV_WAVES * 64 + g * xplane];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[t][g] = dd_mfma16<WF>(w[t][u], b[u][g], acc[t][g]);
+  }
+  if (s < spw) {
+    const int rem = spw - s;
+    u32x4_t b[U][NG], w[TILES][U];
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(s + u) * GEMV_WAVES * 64);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b[u][g] = xp[(size_t)(s + u) * GEMV_WAVES * 64 + g * xplane];
+      }
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[t][g] = dd_mfma16<WF>(w[t][u], b[u][g], acc[t][g]);
+      }
+  }
+
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) *(f32x4_t*)&red[((t * NG + g) * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t][g];
+  __syncthreads();
+
+  const int eg = threadIdx.x >> 7, ml = threadIdx.x & 7;
+  auto tile_sum = [&](int tt, int n) -> float {     // the order of k_gemv's tile_sum: (hi + lo) per wave, waves in pairs
+    float y = 0.f;
+    int o = ((n >> 2) * 16 + ml) * 4 + (n & 3);
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; w += 2) {
+      const float* r = &red[((tt * NG + eg) * GEMV_WAVES + w) * 256];
+      y += (r[o] + r[o + 32]) + (r[256 + o] + r[256 + o + 32]);
+    }
+    if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
+    return y;
+  };
+  groups_epilogue<EPI, TILES, NG>(a, blockIdx.x, pre, rstd_sh, ssq_sh, tile_sum);
+}
+
+// Second half of the slice-resident GEMV (dd_gemv_slices.h): adds the slices' partial sums in k_gemv's order and runs
+// k_gemv_groups' epilogue for ONE tile set per workgroup (128 * NG threads).  Everything it needs from memory — the
+// partial sums, rstd (assembled by the first kernel), residual / norm weight / rotary terms — is requested up front.
+// part: [NP][n_tiles_total][NG][128], NP = 8 (single slices) or 4 (slice pairs already added by the producer).
+template <int EPI, int TILES, int NG, int NP>
+__global__ __launch_bounds__(128 * NG) void k_gemv_finish(GemvArgs a, const float* __restrict__ part, const float* __restrict__ rstd_g,
+                                                          int n_sets) {
+  __shared__ float ssq_sh[16 * 8 * NG];
+  __shared__ float rstd_sh[8 * NG];
+  __shared__ float y_sh[EPI == EPI_QKV ? TILES * 128 * NG : 1];   // rotary tiles: a thread needs its partner column's sum (n ^ 8)
+  const int wg = blockIdx.x, tile0 = wg * TILES;
+  const int et = threadIdx.x, eg = et >> 7, ml = et & 7, en = (et & 127) >> 3;
+  const size_t ps = ((size_t)n_sets * TILES * NG) << 7;
+  // one batch of requests: the thread's partial sums, rstd, the epilogue's operands — a single memory round trip before the
+  // arithmetic
+  float v[TILES][NP];
+#pragma unroll
+  for (int tt = 0; tt < TILES; ++tt) {
+    const float* p0 = part + (((size_t)(tile0 + tt) * NG + eg) << 7) + dd_part_index(en, ml);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) v[tt][q] = p0[(size_t)q * ps];
+  }
+  if (a.ssq_in && et < 8 * NG) rstd_sh[et] = rstd_g[et];
+  GroupsPre<TILES> pre;
+  groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
+  float y_own[TILES];
+#pragma unroll
+  for (int tt = 0; tt < TILES; ++tt) {
+    float y = 0.f;
+    if (NP == 8) {
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) y += v[tt][q] + v[tt][q + 1];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) y += v[tt][q];
+    }
+    y_own[tt] = y;
+    if (EPI == EPI_QKV) y_sh[tt * 128 * NG + et] = y;   // the partner (same group and row, column n ^ 8) is thread et ^ 64
+  }
+  __syncthreads();                                   // rstd_sh, y_sh
+  auto tile_sum = [&](int tt, int n) -> float { return (EPI == EPI_QKV && n != en) ? y_sh[tt * 128 * NG + (et ^ 64)] : y_own[tt]; };
+  groups_epilogue<EPI, TILES, NG>(a, wg, pre, rstd_sh, ssq_sh, tile_sum);
+}
+
+template <int EPI, int TILES, int NG, int FP8>
+static int launch_gemv_groups_f(const GemvArgs& a, hipStream_t st) {
+  size_t smem = (size_t)(TILES * NG * GEMV_WAVES * 256 + 8 * NG + 16 * 8 * NG) * sizeof(float);
+  // weight tiles requested per wave before the first MFMA: 4; 2 for the two-tile kernels with four operand planes (keeps
+  // the register file at two workgroups per CU: gate/up 49 vs 53 us); 8 for o_proj / down (one workgroup per CU anyway:
+  // 32.0 vs 33.0 us)
+  constexpr int U = (TILES == 2 && NG == 4) ? 2 : (EPI == EPI_RESID ? 8 : 4);
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, FP8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (!FP8) DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  if (!FP8 && a.wf) k_gemv_groups<EPI, TILES, NG, U, 0, 1><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
+  else k_gemv_groups<EPI, TILES, NG, U, FP8, 0><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
+  return DD_OK;
+}
+template <int EPI, int TILES, int NG>
+static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
+  return a.fp8 ? launch_gemv_groups_f<EPI, TILES, NG, 1>(a, st) : launch_gemv_groups_f<EPI, TILES, NG, 0>(a, st);
+}
+
+// ---- slice-resident path (dd_gemv_slices.h + k_gemv_finish): bf16 weights, the per-layer matrices at the shapes the 7B
+// families have (K = 4096: 16 k-steps per slice; K = 11008 / 14336: 43 / 56, staged in chunks of 16).  Anything else runs
+// through k_gemv_groups; both produce the same bits.
+static int g_gemv_slices = 1;     // dd_set_tuning key 13
+int g_exp_G[4] = {0, 0, 0, 0};   // dd_set_tuning keys 17..19: workgroups per slice of the 64-row kernels (qkv, o, gate/up); 0 = default
+static int g_slices_only = 0;     // dd_lm_time_gemv: launch the streaming kernel without its finishing kernel (timing only)
+void ddk_set_gemv_slices(int on) { g_gemv_slices = on; }
+void ddk_set_slices_only(int on) { g_slices_only = on; }
+#define SLICES_UNSUPPORTED 1
+
+template <int TW, int NG, int U, int SPW, int CS, int CH, int TAG>
+static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
+  constexpr size_t smem = (size_t)CH * (SPW < CS ? SPW : CS) * NG * 1024;
+  static bool attr = false;
+  if (!attr) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  const int grid = (sa.halves == 2 ? 2 : 1) * (8 / CH) * sa.G;
+  if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
+  return DD_OK;
+}
+template <int EPI, int TILES, int NG, int NP>
+static void launch_finish(const GemvArgs& a, int n_sets, hipStream_t st) {
+  if (g_slices_only) return;
+  k_gemv_finish<EPI, TILES, NG, NP><<<n_sets, 128 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
+}
+template <int NG>
+static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
+  const int spw = a.S / GEMV_WAVES;
+  const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;      // 16-row weight tiles
+  if (!(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
+  SliceArgs sa;
+  sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
+  sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
+  sa.rstd_out = a.part + a.part_floats;                              // 32 floats behind the partial sums
+  const size_t need8 = (size_t)8 * nt * NG * 128, need4 = need8 / 2;
+  if (epi == EPI_STORE) {
+    // lm_head (K = 4096): the wave-split kernel streams it at 2.8 TB/s with four planes (operand reads from L2); the slice kernels
+    // with the plain-store finish: 32 rows as slice pairs, 64 rows as single slices, 16 rows stay on the wave-split kernel
+    if (spw != 16 || NG < 4) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    if constexpr (NG == 8) {
+      if (a.part_floats < need8) return SLICES_UNSUPPORTED;
+      sa.G = (nt + 31) / 32;
+      RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_STORE>(sa, a.wf, st));
+      launch_finish<EPI_STORE, 1, 8, 8>(a, nt, st);
+    } else {
+      if (a.part_floats < need4) return SLICES_UNSUPPORTED;
+      sa.G = 64;
+      RC_(launch_slices_k<1, NG, 8, 16, 16, 2, EPI_STORE>(sa, a.wf, st));
+      launch_finish<EPI_STORE, 1, NG, 4>(a, nt, st);
+    }
+    return DD_OK;
+  }
+  if constexpr (NG == 8) {
+    // 64 rows: 8 operand planes fill the LDS with one slice (16 steps x 8 KiB = 128 KiB at K = 4096; long K in chunks of 8
+    // steps), one tile per wave group; tools/gemv_lab: qkv 28 us, o 10.7, gate/up 45, down 21 — 1.25 x the 32-row kernels for
+    // twice the rows
+    if (a.part_floats < need8) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    if (epi == EPI_QKV) {
+      if (spw != 16) return SLICES_UNSUPPORTED;
+      // workgroups per slice: one round of 8 * G <= 256 workgroups (one per CU: 128 KiB of operands each) measured best inside
+      // the sweep (32 lanes: 32.6 -> 31.6 ms per group step for the three choices together)
+      if (g_exp_G[0] >= 0 && (nt % 16) == 0 && nt / 16 * 4 <= 256) {
+        // slice pairs, one slice resident at a time (see gate/up below): two tiles per wave; tuning key 17 < 0: single slices (A/B)
+        sa.G = g_exp_G[0] ? g_exp_G[0] : nt / 16;
+        constexpr size_t smem = (size_t)16 * 8 * 1024;
+        static bool attr = false;
+        if (!attr) {
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 2, 0, EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 2, 1, EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          attr = true;
+        }
+        DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
+        if (a.wf) k_gemv_slices_seq<8, 8, 16, 2, 1, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        else k_gemv_slices_seq<8, 8, 16, 2, 0, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        launch_finish<EPI_QKV, 1, 8, 4>(a, nt, st);
+      } else {
+        sa.G = g_exp_G[0] > 0 ? g_exp_G[0] : (nt + 31) / 32;
+        RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_QKV>(sa, a.wf, st));
+        launch_finish<EPI_QKV, 1, 8, 8>(a, nt, st);
+      }
+    } else if (epi == EPI_RESID) {
+      sa.G = (nt + 7) / 8;
+      if (spw == 16 && g_exp_G[1] < 0) {                       // tuning key 18 < 0: the eight-plane kernel (A/B)
+        sa.G = (nt + 15) / 16;
+        RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+      } else if (spw == 16) {
+        // o_proj (33 MB): two half passes of four planes over the same tiles, paired on one XCD so that the second reads the
+        // tiles from L2 (dd_gemv_slices.h `halves`): 10.4 vs 13.5 us for the eight-plane kernel (the wide matrices lose with it)
+        sa.G = g_exp_G[1] ? g_exp_G[1] : (nt + 15) / 16;
+        sa.halves = 2;
+        RC_(launch_slices_k<1, 4, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+        sa.halves = 1;
+      }
+      else if (spw == 43) RC_(launch_slices_k<1, 8, 8, 43, 8, 1, EPI_RESID>(sa, a.wf, st));
+      else RC_(launch_slices_k<1, 8, 8, 56, 8, 1, EPI_RESID>(sa, a.wf, st));
+      launch_finish<EPI_RESID, 1, 8, 8>(a, nt, st);
+    } else {
+      if (spw != 16) return SLICES_UNSUPPORTED;
+      if (g_exp_G[2] >= 0 && 4 * ((nt + 23) / 24) <= 256) {
+        // slice pairs, one slice resident at a time: half the partial sums.  Three tiles per wave, as evenly as the tile count
+        // allows, in ONE round of workgroups (LLaVA-7B: 58 per pair = 232): 27.25 vs 27.75 ms per 32-lane step; 64 per pair
+        // (2.7 tiles per wave: uneven) 28.6, 86 (two tiles, 1.3 rounds) 29.1.  Tuning key 19 < 0: single slices (A/B)
+        sa.G = g_exp_G[2] ? g_exp_G[2] : (nt + 23) / 24;
+        constexpr size_t smem = (size_t)16 * 8 * 1024;
+        static bool attr = false;
+        if (!attr) {
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 3, 0, EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 3, 1, EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+          attr = true;
+        }
+        DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
+        if (a.wf) k_gemv_slices_seq<8, 8, 16, 3, 1, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        else k_gemv_slices_seq<8, 8, 16, 3, 0, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        launch_finish<EPI_SILU, 2, 8, 4>(a, a.n_tiles, st);
+      } else {
+        sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 42) / 43;
+        RC_(launch_slices_k<1, 8, 8, 16, 16, 1, EPI_SILU>(sa, a.wf, st));
+        launch_finish<EPI_SILU, 2, 8, 8>(a, a.n_tiles, st);
+      }
+    }
+    return DD_OK;
+  } else if (epi == EPI_QKV) {
+    if (spw != 16 || (nt & 1) || a.part_floats < need8) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt / 2;
+    sa.G = sa.n_groups >= 256 ? (sa.n_groups + 15) / 16 : (sa.n_groups + 7) / 8;     // two tile pairs per wave when there are enough
+    RC_(launch_slices_k<2, NG, 8, 16, 16, 1, EPI_QKV>(sa, a.wf, st));
+    launch_finish<EPI_QKV, 1, NG, 8>(a, nt, st);
+  } else if (epi == EPI_RESID) {
+    // K = 4096 (o_proj): the wave-split kernel in one launch is as fast as slices + finish (13.5 vs 14.2 us at four planes,
+    // 10.3 vs 11.2 at two: 33 MB of weights do not amortise a second launch); the long-K matrix (down) gains 30 %
+    if (a.part_floats < need8 || spw == 16) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    sa.G = (nt + 7) / 8;                                             // one tile per wave
+    if (spw == 16) RC_(launch_slices_k<1, NG, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+    else if (spw == 43) RC_(launch_slices_k<1, NG, 8, 43, 16, 1, EPI_RESID>(sa, a.wf, st));
+    else RC_(launch_slices_k<1, NG, 8, 56, 16, 1, EPI_RESID>(sa, a.wf, st));
+    launch_finish<EPI_RESID, 1, NG, 8>(a, nt, st);
+  } else {  // EPI_SILU: slice pairs, one workgroup per CU
+    if (spw != 16 || a.part_floats < need4) return SLICES_UNSUPPORTED;
+    sa.n_groups = nt;
+    sa.G = 64;
+    RC_(launch_slices_k<1, NG, 8, 16, 16, 2, EPI_SILU>(sa, a.wf, st));
+    launch_finish<EPI_SILU, 2, NG, 4>(a, a.n_tiles, st);
+  }
+  return DD_OK;
+}
+
+int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
+  DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv_groups: K=%d must be a multiple of 256", a.S * 32);
+  DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv_groups: nb=%d rows per group", a.nb);
+  DD_REQUIRE(!a.fp8 || a.wscale, "gemv_groups: fp8 weights need row scales");
+  DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4 || a.n_groups == 8, "gemv_groups: %d groups (2, 4 or 8)", a.n_groups);
+  if (g_gemv_slices && !a.fp8 && a.part) {
+    int rs = a.n_groups == 2 ? try_slices<2>(epi, a, st) : (a.n_groups == 4 ? try_slices<4>(epi, a, st) : try_slices<8>(epi, a, st));
+    if (rs != SLICES_UNSUPPORTED) {
+      if (rs != DD_OK) return rs;
+      DD_CHECK_LAUNCH();
+      return DD_OK;
+    }
+  }
+  if (a.n_groups == 8) {
+    // no 64-row kernel for this matrix (lm_head, fp8 weights, other shapes): two 32-row passes over rows 0..31 / 32..63 —
+    // the same bits, since a row's result does not depend on the kernel that computed it
+    for (int half = 0; half < 2; ++half) {
+      GemvArgs b = a;
+      b.n_groups = 4;
+      if (half) {
+        b.xop = a.xop + (size_t)4 * a.S * 64;
+        if (a.xop_next) b.xop_next = a.xop_next + (size_t)4 * a.S_next * 64;
+        if (a.out) b.out = a.out + (size_t)32 * a.ldo;
+        if (a.ssq_in) b.ssq_in = a.ssq_in + (size_t)32 * a.ssq_ld;
+        if (a.ssq_out) b.ssq_out = a.ssq_out + (size_t)32 * a.ssq_ld;
+        if (a.qbuf) b.qbuf = a.qbuf + (size_t)32 * a.q_dim;
+        if (a.knew) b.knew = a.knew + (size_t)32 * a.kv_dim;
+        if (a.vnew) b.vnew = a.vnew + (size_t)32 * a.kv_dim;
+        for (int i = 0; i < 32; ++i) b.state_rows[i] = a.state_rows[32 + i];
+        for (int i = 0; i < 4; ++i) b.out_g[i] = a.out_g[4 + i], b.knew_g[i] = a.knew_g[4 + i], b.vnew_g[i] = a.vnew_g[4 + i];
+      }
+      for (int i = 32; i < 64; ++i) b.state_rows[i] = nullptr;
+      for (int i = 4; i < 8; ++i) b.out_g[i] = b.knew_g[i] = b.vnew_g[i] = nullptr;
+      int rc2 = ddk_gemv_groups(epi, b, st);
+      if (rc2 != DD_OK) return rc2;
+    }
+    return DD_OK;
+  }
+  int rc = DD_OK;
+  const bool two = a.n_groups == 2;
+  switch (epi) {
+    case EPI_STORE: rc = two ? launch_gemv_groups<EPI_STORE, 1, 2>(a, st) : launch_gemv_groups<EPI_STORE, 1, 4>(a, st); break;
+    case EPI_RESID: rc = two ? launch_gemv_groups<EPI_RESID, 1, 2>(a, st) : launch_gemv_groups<EPI_RESID, 1, 4>(a, st); break;
+    case EPI_SILU: rc = two ? launch_gemv_groups<EPI_SILU, 2, 2>(a, st) : launch_gemv_groups<EPI_SILU, 2, 4>(a, st); break;
+    case EPI_QKV:
+      // four planes: two tiles per workgroup share the operand reads (33.0 vs 37.8 us at LLaVA-7B shapes); with two
+      // planes one tile per workgroup is faster (24.6 vs 26.2 us: the extra workgroups matter more)
+      if (two || (a.q_tiles & 1) || (a.k_tiles & 1) || (a.n_tiles & 1)) {
+        rc = two ? launch_gemv_groups<EPI_QKV, 1, 2>(a, st) : launch_gemv_groups<EPI_QKV, 1, 4>(a, st);
+      } else {
+        GemvArgs b = a;
+        b.n_tiles = a.n_tiles / 2;
+        rc = launch_gemv_groups<EPI_QKV, 2, 4>(b, st);
+      }
+      break;
+    default: DD_REQUIRE(false, "gemv_groups: unknown epilogue %d", epi);
+  }
+  if (rc != DD_OK) return rc;
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+

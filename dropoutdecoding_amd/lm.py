@@ -295,6 +295,24 @@ class DropoutEngine:
         self._n_enqueued += 1
         return held.value
 
+    _SPEC_MODES = {"default": -1, "never": 0, "always": 1, "adaptive": 2}
+
+    def set_speculation(self, mode: str) -> None:
+        """When single-sequence steps take the speculative one-sweep form (dd_lm_set_speculation): 'never' (always the
+        un-masked sweep, then the members), 'always', 'adaptive' (speculate while enough of the recent checks held, the
+        library's default) or 'default' (the process-wide default).  Results never depend on it."""
+        _lib.check(self.lib.dd_lm_set_speculation(self._h, self._SPEC_MODES[mode]), "dd_lm_set_speculation")
+
+    def spec_stats(self, reset: bool = False) -> Dict[str, float]:
+        """Counts since creation / the last reset: speculative steps that held, that were re-run, plain two-sweep steps the
+        adaptive policy issued, times it switched speculation off; hit_rate = held / speculative steps."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self.lib.dd_lm_spec_stats(self._h, out, 1 if reset else 0), "dd_lm_spec_stats")
+        held, rerun, plain, off = (int(x) for x in out)
+        return {"held": held, "rerun": rerun, "plain": plain, "switched_off": off,
+                "hit_rate": (held / (held + rerun)) if held + rerun else None,
+                "sweeps_per_step": ((held + 2 * rerun + 2 * plain) / (held + rerun + plain)) if held + rerun + plain else None}
+
     # phased form for K-sharding (see dist.py)
     def step_base(self, mprobs=None, uniforms=None) -> int:
         probs, arr = self._probs(mprobs)
@@ -365,9 +383,11 @@ class DropoutEngine:
         eos_set = set(_eos_ids(eos))
         self._sync_eos(eos_set)
         if step_fn is None and dropout and self.sync_steps and 1 <= len(self._probs(mprobs)[0]) <= 8:
-            # one sequence on its own: the host decides the speculative step's fallback (no queue of steps ahead of the GPU;
-            # a step enqueued after the EOS step — the mirror lags by one — is a device-side no-op)
-            step_fn, lookahead = (lambda: self.decode_step_sync(mprobs)), 1 << 30
+            # one sequence on its own: the host decides the speculative step's fallback (it waits for the step's check, so no
+            # queue of steps builds up ahead of the GPU; a step enqueued after the EOS step — the mirror lags by one — is a
+            # device-side no-op).  While the adaptive policy issues plain two-sweep steps those are queued like decode_step's
+            # and the look-ahead limit applies.
+            step_fn = lambda: self.decode_step_sync(mprobs)
         step = step_fn or (lambda: self.decode_step(mprobs, dropout=dropout))
         enq = self._n_enqueued
         while enq < n_new:

@@ -257,7 +257,7 @@ int dd_lm_prefill_extend(dd_lm* h, const float* embeds_dev, int n, void* stream)
 int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds_dev, int T0, int span_start, int span_len, const double* mprobs,
                            int K, dd_rng* rng, const float* uniforms_dev, void* stream);
 
-/* Single-sequence steps with 1 <= K <= 8 run SPECULATIVELY (dd_set_tuning key 14, default on): the K members share ONE
+/* Single-sequence steps with 1 <= K <= 8 run SPECULATIVELY (policy: dd_lm_set_speculation): the K members share ONE
  * sweep over the weights with the un-masked pass, their masks sampled for an empty keep set from the same draws; when the
  * real keep set (models/llava.py:603, 660) would have restored a token some member dropped, the masks are re-sampled from
  * the saved rng state and the members re-run.  Every result (tokens, masks, logits, KV rows, rng stream) is that of the
@@ -281,6 +281,19 @@ int dd_lm_decode_step(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, c
  * (K = 0 or > 8, speculation switched off).  The steps of one sequence must not be mixed between the two calls while
  * earlier ones are still in flight on different streams. */
 int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs_host, int K, dd_rng* rng, void* stream, int* held);
+
+/* When to speculate (see above; results never depend on it).  mode: 0 never (always the un-masked sweep, then the member
+ * sweep — the reference's own order, models/llava.py:294-359), 1 always, 2 adaptive, -1 (default) the process default
+ * (dd_set_tuning key 14, itself 2 by default).  Adaptive: dd_lm_decode_step_sync sees every check's verdict; while the
+ * running share of speculative steps that held is below the break-even (about one in three: a failed speculation costs a
+ * 16-row sweep plus the 8-row re-run, more than the plain step's 1-row + 8-row sweeps) it issues plain two-sweep steps and
+ * re-probes every 32 steps.  The share depends on the checkpoint: the speculation holds when the step's keep set
+ * (models/llava.py:443-482) is empty or untouched by every member's drops.  dd_lm_decode_step (queued, the host never
+ * learns the verdicts) speculates under modes 1 and 2 alike.
+ * dd_lm_spec_stats: out4 = {speculative steps that held, that were re-run, plain two-sweep steps issued by the adaptive
+ * policy, times the policy switched speculation off} since creation or the last reset. */
+int dd_lm_set_speculation(dd_lm* h, int mode);
+int dd_lm_spec_stats(dd_lm* h, int64_t* out4, int reset);
 
 /* The same step in phases, for sharding the K members over ranks (nothing in the reference to
  * mirror: its K members run sequentially in one process, models/llava.py:342-359):
@@ -508,8 +521,8 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * 4 = ring (1) or batch (0, default) request order in the 8-row GEMV,
  * 8 = replay decode steps from a hipGraph (default 1), 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4;
  * default 4), 10 = workgroups per group of 8 members in the grouped decode attention (1, 2, 4; default 1),
- * 13 = slice-resident 16 / 32-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits), 14 = speculative
- * single-sequence steps (default 1; 0: always two sweeps, same results), 15 = XCD-aware block order of the prefill GEMM
+ * 13 = slice-resident 16 / 32-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits), 14 = process default of the
+ * speculation policy of single-sequence steps (dd_lm_set_speculation: 0 never, 1 always, 2 adaptive = default; same results), 15 = XCD-aware block order of the prefill GEMM
  * (default 1; 0: row-major block order, same bits), 16 = rows from which the prefill GEMM uses its 128 x 512 LDS-staged
  * block (default 1024; 0: never; same bits), 17 / 18 / 19 = workgroups per K slice of the 64-row qkv / o_proj / gate-up GEMV
  * (0: default; same bits; 18 < 0: the eight-plane o_proj kernel instead of two four-plane half passes; 19 < 0: single K slices

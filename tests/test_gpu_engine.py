@@ -115,12 +115,16 @@ def test_original_greedy_matches_oracle(E, golden_dir):
     eng.close()
 
 
-@pytest.mark.parametrize("family,K", [(FAMILY_LLAVA, 8), (FAMILY_NEXT, 3), (FAMILY_IBLIP, 4), (FAMILY_LLAVA, 1)])
+CHAIR_K4 = [0.1, 0.3, 0.5, 0.7]      # BASELINE config 2: the reference's shipped LLaVA-1.5 list (chair_test/chair_test.py:170)
+
+
+@pytest.mark.parametrize("family,K", [(FAMILY_LLAVA, 8), (FAMILY_NEXT, 3), (FAMILY_IBLIP, 4), (FAMILY_LLAVA, 1), (FAMILY_LLAVA, "chair4"),
+                                      (FAMILY_NEXT, "chair4")])
 def test_longer_decode_vs_oracle_first_divergence(E, golden_dir, family, K):
     """24 steps against the oracle on seeded inputs; reports the first divergence and the margin there."""
     gname = {FAMILY_LLAVA: "g5_llava_k3.npz", FAMILY_NEXT: "g5_next_k4.npz", FAMILY_IBLIP: "g5_iblip_k3.npz"}[family]
     g = _load(golden_dir, gname)
-    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8][:K] if K > 1 else [0.5]
+    probs = CHAIR_K4 if K == "chair4" else ([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8][:K] if K > 1 else [0.5])
     eng, rcfg, w = _engine(E, g, family, seed=77)
     ref = RefDecoder(family, rcfg, w, probs, seed=77)
     emb = torch.from_numpy(g["embeds"])
@@ -322,6 +326,24 @@ def test_full_size_llava15_7b_properties(E):
         eng.step_commit()
     assert eng.tokens() == ref_toks
     np.testing.assert_array_equal(eng.logits(), ref_logits)
+    # BASELINE config 2: K = 4 with the reference's shipped list [0.1, 0.3, 0.5, 0.7] (chair_test/chair_test.py:170) at this size:
+    # the same invariants, replay determinism, and speculative == two-sweep steps bit for bit
+    eng.rng.manual_seed(24)
+    eng.prefill(emb, 5, 576)
+    k4 = eng.generate(8, mprobs=CHAIR_K4)
+    st = eng.last_step()
+    nd = st["masked_numbers"]
+    assert st["drop"].shape == (4, 576) and not (st["drop"] & st["keep"][None]).any()
+    assert (np.diff(nd) >= -int(st["keep"].sum())).all() and 0.03 * 576 < nd[0] < 0.2 * 576 and nd[-1] > nd[0]
+    assert len(set(st["member_argmax"].tolist()) | {st["voted"]}) <= 4 and st["member_argmax"][st["winner"]] == st["voted"]
+    k4_logits, k4_sums = eng.logits(), eng.kv_sums().copy()
+    eng.set_speculation("never")
+    eng.rng.manual_seed(24)
+    eng.prefill(emb, 5, 576)
+    assert eng.generate(8, mprobs=CHAIR_K4) == k4
+    np.testing.assert_array_equal(eng.logits(), k4_logits)
+    np.testing.assert_array_equal(eng.kv_sums(), k4_sums)
+    eng.set_speculation("default")
     eng.close()
 
 

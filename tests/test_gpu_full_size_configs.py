@@ -220,3 +220,45 @@ def test_config5_weight_format_reaches_the_drop_in_class(E):
     finally:
         ddc.settings.clear()
         ddc.settings.update(old)
+
+
+def test_llava7b_speculation_policies_on_keep_sets_that_are_never_empty(E):
+    """LLaVA-1.5-7B shapes, K = 8, with 64 lm_head rows scaled up so that every step's keep set (models/llava.py:443-482)
+    holds tens of visual tokens — what a trained checkpoint does where the image shows what is being said, and what random
+    weights never do.  There the speculative step's check fails at (nearly) every step; the three policies must produce the
+    same tokens and cache, and the adaptive one must cost about what the plain two-sweep step costs (printed)."""
+    eng = E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format="fp16")
+    eng.load_synthetic(0, 0.02)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    W = torch.randn(32064, 4096, device="cuda", generator=g) * 0.02
+    W[1000:1064] *= 8.0
+    eng._load(E.T_LM_HEAD, 0, W)
+    del W
+    emb = (torch.randn(608, 4096, generator=torch.Generator().manual_seed(1)) * 0.5).cuda()
+    n_new, out = 97, {}
+    for mode in ("never", "always", "adaptive"):
+        eng.set_speculation(mode)
+        eng.rng.manual_seed(24)
+        eng.prefill(emb, 5, 576)
+        eng.generate(4, mprobs=PROBS8)                       # graphs captured, clocks up
+        eng.spec_stats(reset=True)
+        eng.torch_stream.synchronize()
+        t0 = time.perf_counter()
+        toks = eng.generate(n_new, mprobs=PROBS8)
+        eng.torch_stream.synchronize()
+        ms = (time.perf_counter() - t0) / (n_new - 4) * 1e3
+        st = eng.last_step()
+        out[mode] = (toks, eng.kv_sums().copy(), ms, eng.spec_stats(), int(st["keep"].sum()))
+    eng.set_speculation("default")
+    for mode in ("always", "adaptive"):
+        assert out[mode][0] == out["never"][0], mode
+        np.testing.assert_array_equal(out[mode][1], out["never"][1])
+    assert out["never"][4] >= 5                              # the last step kept several visual tokens
+    sa, sd = out["always"][3], out["adaptive"][3]
+    assert sa["hit_rate"] < 0.2 and sd["plain"] > 0.7 * (n_new - 4) and sd["switched_off"] >= 1
+    assert out["adaptive"][2] < out["always"][2]             # falling back pays on such a checkpoint
+    assert out["adaptive"][2] < 1.08 * out["never"][2]       # and costs at most the probes on top of the plain step
+    print(f"\n[keep sets never empty, LLaVA-1.5-7B shapes, K=8, fp16 KV, T~660] ms per ensemble step: plain two-sweep {out['never'][2]:.2f}, "
+          f"speculating always {out['always'][2]:.2f} (hit rate {sa['hit_rate']:.2f}), adaptive {out['adaptive'][2]:.2f} "
+          f"({sd['plain']} plain + {sd['held'] + sd['rerun']} probe steps, {sd['rerun']} re-runs)")
+    eng.close()

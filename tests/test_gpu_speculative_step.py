@@ -25,7 +25,7 @@ def E():
 
 def _run(E, eng, emb, s0, L, probs, steps, spec, graph, seed, sync=False):
     lib = eng.lib
-    lib.dd_set_tuning(14, 1 if spec else 0)
+    lib.dd_set_tuning(14, int(spec))            # 0 never, 1 always, 2 adaptive (the library's default policy)
     lib.dd_set_tuning(8, 1 if graph else 0)
     try:
         eng.rng.manual_seed(seed)
@@ -38,11 +38,11 @@ def _run(E, eng, emb, s0, L, probs, steps, spec, graph, seed, sync=False):
             st = eng.last_step()
             recs.append((st["drop"].copy(), st["masked_numbers"].tolist(), st["member_argmax"].tolist(), st["winner"], st["keep"].copy(),
                          eng.logits().copy(), eng.base_logits().copy()))
-            oks.append(eng.spec_ok() if spec else -1)
+            oks.append(held if int(spec) == 2 else (eng.spec_ok() if spec else -1))     # adaptive: -1 = a plain two-sweep step
             assert held is None or held == oks[-1]
         return recs, eng.tokens(), eng.kv_sums().copy(), eng.rng.rand(32).cpu().numpy(), oks
     finally:
-        lib.dd_set_tuning(14, 1)
+        lib.dd_set_tuning(14, 2)
         lib.dd_set_tuning(8, 1)
 
 
@@ -194,4 +194,50 @@ def test_generate_uses_the_host_decided_step_and_matches_the_queued_loop(E):
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[1] == outs[0][1]
         np.testing.assert_array_equal(o[2], outs[0][2])
+    eng.close()
+
+
+def test_adaptive_policy_on_a_keep_set_that_is_rarely_empty(E):
+    """On a real checkpoint the keep set (models/llava.py:443-482: visual tokens whose top-k ids contain the un-masked pass'
+    argmax) is routinely non-empty and some member has almost always dropped one of its tokens, so the speculation fails.
+    Built here by construction: 24 lm_head rows scaled up, so the un-masked argmax is always one of those ids and they fill
+    the top-k lists of the visual tokens — about 5 / 24 of the visual tokens are kept at every step.  The adaptive policy must then fall back to plain two-sweep steps (and re-probe), the
+    'always' policy must re-run nearly every step, and every result must equal the two-sweep step's and the oracle's."""
+    w = dict(random_weights(RC, 31, 0.05))
+    w["lm_head.weight"] = w["lm_head.weight"].clone()
+    w["lm_head.weight"][64:88] *= 4.0
+    cfg = E.LMConfig(RC.vocab_size, RC.hidden_size, RC.intermediate_size, RC.num_layers, RC.num_heads, RC.num_kv_heads,
+                     RC.head_dim, RC.rms_eps, RC.rope_theta)
+    L, s0, steps = 40, 3, 90
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=192, max_visual=L, seed=7)
+    eng.load_state_dict(w)
+    emb = torch.randn(L + 9, RC.hidden_size, generator=torch.Generator().manual_seed(77)) * 0.8
+    ref = _run(E, eng, emb, s0, L, probs, steps, spec=0, graph=False, seed=7)
+    kept = [int(r[4].sum()) for r in ref[0]]
+    assert sum(k > 0 for k in kept) > 0.6 * steps, kept              # the construction works: most steps have tokens to keep
+    for graph in (False, True):
+        eng.spec_stats(reset=True)
+        always = _run(E, eng, emb, s0, L, probs, steps, spec=1, graph=graph, seed=7, sync=True)
+        st_always = eng.spec_stats(reset=True)
+        adaptive = _run(E, eng, emb, s0, L, probs, steps, spec=2, graph=graph, seed=7, sync=True)
+        st_adapt = eng.spec_stats(reset=True)
+        for got in (always, adaptive):
+            assert got[1] == ref[1]
+            for s, (a, b) in enumerate(zip(got[0], ref[0])):
+                np.testing.assert_array_equal(a[0], b[0], err_msg=f"drop masks, step {s}")
+                assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], f"step {s}"
+                np.testing.assert_array_equal(a[4], b[4], err_msg=f"keep set, step {s}")
+                np.testing.assert_array_equal(a[5], b[5], err_msg=f"winner logits, step {s}")
+            np.testing.assert_array_equal(got[2], ref[2])
+            np.testing.assert_array_equal(got[3], ref[3])
+        assert st_always["held"] + st_always["rerun"] == steps and st_always["plain"] == 0
+        assert st_always["hit_rate"] < 0.35, st_always              # below the break-even: speculating always is the slow choice
+        assert all(ok == 1 for ok, k in zip(always[4], kept) if k == 0)     # an empty keep set can never fail the check
+        assert st_adapt["switched_off"] >= 1 and st_adapt["plain"] >= steps // 2, st_adapt
+        assert st_adapt["held"] + st_adapt["rerun"] + st_adapt["plain"] == steps
+        assert st_adapt["rerun"] < st_always["rerun"] // 2                  # the probes are the only re-runs left
+        assert adaptive[4].count(-1) == st_adapt["plain"]
+    want = RefDecoder(FAMILY_LLAVA, RC, w, probs, seed=7).generate(emb, s0, L, steps + 1)
+    assert ref[1] == want
     eng.close()
