@@ -2,8 +2,10 @@
 """bench.py — decoded tokens/s of the Dropout-Decoding hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...          # starts its own N ranks (torch.distributed.run, one per GPU) when not launched by one
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --config 4|5          # BASELINE configs 4 / 5 (InstructBLIP-Vicuna-7B, LLaVA-NeXT-Mistral-7B fp8) at engine level
 
 One "step" = one image through `CustomLlavaForConditionalGeneration.generate()`: CLIP-L/14-336 front-end +
 prefill of 608 positions (576 visual + 32 prompt tokens) + uncertainty scorer + `--n-new` (128) decoded tokens,
@@ -162,6 +164,128 @@ def cpu_baseline(K: int, budget_s: float = 20.0):
                       f"{time.perf_counter() - t_all - t_setup:.0f} s of timed CPU work"}
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes (one per GPU, RCCL rendezvous on
+    127.0.0.1) BEFORE this process makes any GPU call, relay their output (rank 0 prints the JSON line), exit with their status.
+    The reference's own multi-GPU shape is N independent jobs over image shards (scripts/run_main_experiments.py:81-86)."""
+    import socket
+    import subprocess
+    from dropoutdecoding_amd import build
+    build.build()                                  # hipcc only (no GPU call): the ranks find both libraries built
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _profile_files():
+    """The newest committed rocprofv3 summaries (profiles/rNN_*): PMC traffic / MFMA busy and kernel-trace durations."""
+    import glob
+    pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    st = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.csv")))
+    rel = lambda p_: os.path.relpath(p_, ROOT) if p_ else None
+    return rel(pm[-1] if pm else None), rel(st[-1] if st else None)
+
+
+def committed_profile(kernel: str):
+    """HBM traffic / MFMA busy / kernel-trace average of `kernel` from the committed profile of the newest round — NOT measured in
+    this run (bench.py cannot collect PMCs); the kernel is matched by the name the library reports for what it launched."""
+    pmc, stats = _profile_files()
+    traffic = mfma_util = stats_avg_us = None
+    try:
+        for name, v in json.load(open(os.path.join(ROOT, pmc)))["kernels"].items():
+            if name.startswith("void " + kernel):
+                traffic = v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0)
+                mfma_util = v.get("mfma_util")
+    except Exception:
+        pass
+    try:
+        import csv
+        for row in csv.DictReader(open(os.path.join(ROOT, stats))):
+            if row["Name"].startswith("void " + kernel):
+                stats_avg_us = round(float(row["AverageNs"]) / 1e3, 2)
+    except Exception:
+        pass
+    return {"traffic": traffic, "mfma_util": mfma_util, "stats_avg_us": stats_avg_us, "pmc_file": pmc, "stats_file": stats}
+
+
+def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows8, wide):
+    """The dominant kernel (gate/up decode GEMV of the member pass) timed alone with HIP events on its launch stream while cycling over
+    the layers' weights, on an engine of its own created through libdropdec_tools.so (the timing hooks are not in the product library)."""
+    from dropoutdecoding_amd import _lib, lm
+    tools = _lib.load_tools()
+    eng = lm.DropoutEngine(lm_cfg, family=family, max_seq=T0 + 80, max_visual=L, kv_format=kv_format, weight_format=weight_format, lib=tools)
+    eng.load_synthetic(0, 0.02)
+    eng.prefill(torch.randn(T0, lm_cfg.hidden_size, device="cuda") * 0.5, 0 if family == lm.FAMILY_IBLIP else 5, L)
+    ms_pair, by = eng.time_gemv(2, dom_rows, 96)                       # the whole GEMV (both kernels when wide)
+    ms = eng.time_gemv(2 + 8, dom_rows, 96)[0] if wide else ms_pair    # the streaming kernel alone
+    kernel = eng.last_gemv_kernel()
+    kinds = {}
+    for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down_proj")):
+        m2, b2 = eng.time_gemv(which, dom_rows, 96)
+        kinds[name] = round(b2 / (m2 * 1e-3) / 1e9, 1)
+    kinds["gate_up_incl_finish"] = round(by / (ms_pair * 1e-3) / 1e9, 1)
+    rows_cmp = None
+    if wide:
+        m8, b8 = eng.time_gemv(2, rows8, 96)
+        kinds["gate_up_8_rows"] = round(b8 / (m8 * 1e-3) / 1e9, 1)
+        rows_cmp = {}
+        for r_ in (16, 32, 64):        # the same matrix at the other pass widths (streaming kernel alone)
+            mr = eng.time_gemv(2 + 8, r_, 96)[0]
+            rows_cmp[str(r_)] = {"us": round(mr * 1e3, 2), "frac": round(by / (mr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_8_rows": round(mr * 1e3 * 8 / r_, 2)}
+    sweep_ms = eng.time_sweep(rows8, 5)
+    sweep_bytes = eng.algorithmic_bytes(0)
+    eng.close()
+    prof = committed_profile(kernel)
+    achieved = by / (ms * 1e-3) / 1e9
+    what = (f"{kernel} (gate/up decode GEMV of a {dom_rows}-row pass = the members of {dom_rows // 8} sequences: streams the matrix once, K in slices "
+            "resident in LDS; its finishing kernel k_gemv_finish adds the slices' partial sums and applies SiLU*up)") if wide \
+        else f"{kernel} (gate/up decode GEMV, {rows8} rows)"
+    return {"bound": "hbm", "kernel": what, "kernel_name": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof["traffic"],
+            "traffic_source": {"source": "committed profile", "measured_in_this_run": False, "file": prof["pmc_file"],
+                               "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, FETCH_SIZE x2 (gfx950); "
+                                      "matched by the kernel name the library reports (dd_tools_last_gemv_kernel)"},
+            "mfma_util": prof["mfma_util"], "rows_per_launch": dom_rows,
+            # frac counts the ALGORITHMIC bytes (the weights); the kernel also writes its K-slice partial sums: HBM bytes moved / duration
+            "traffic_frac": (round(prof["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if prof["traffic"] else None),
+            "gate_up_streaming_kernel_by_rows": rows_cmp, "bytes_per_launch": by, "ms_per_launch": round(ms, 5),
+            "kernel_stats_avg_us": prof["stats_avg_us"], "kernel_stats_file": prof["stats_file"],
+            "gemv_incl_finish": {"ms": round(ms_pair, 5), "GBs": round(by / (ms_pair * 1e-3) / 1e9, 1), "frac": round(by / (ms_pair * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "other_gemv_GBs": kinds,
+            "packed_sweep_8_rows": {"ms": round(sweep_ms, 4), "algorithmic_bytes": sweep_bytes, "GBs": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 1)}}
+
+
+def sweep_bytes(lm_cfg, T: float, weight_bytes: float, kv_bytes: float) -> float:
+    """HBM bytes of ONE sweep over the LM at context T: the matrices + the K/V cache (SURVEY.md 8d's per-token figure is two of these)."""
+    c = lm_cfg
+    q, kv = c.num_heads * c.head_dim, c.num_kv_heads * c.head_dim
+    params = c.num_layers * ((q + 2 * kv) * c.hidden_size + c.hidden_size * q + 3 * c.hidden_size * c.intermediate_size) + c.vocab_size * c.hidden_size
+    return params * weight_bytes + T * c.num_layers * 2 * kv * kv_bytes
+
+
+def end_to_end(single, lm_cfg, T_mean, weight_bytes, kv_bytes):
+    """One-image-at-a-time tokens/s against the HBM roofline, two ways: by SURVEY 8(d)'s algorithmic bytes per token (two sweeps — what
+    the reference's step streams) and by the bytes this build actually streamed (one sweep where the speculative step held)."""
+    if not single:
+        return None
+    one = sweep_bytes(lm_cfg, T_mean, weight_bytes, kv_bytes)
+    sw = single.get("sweeps_per_step") or 2.0
+    tps = single["value"]
+    return {"tokens_per_s": tps, "bytes_per_token_algorithmic": round(2 * one), "algorithmic_equivalent_GBs": round(2 * one * tps / 1e9, 1),
+            "frac_algorithmic": round(2 * one * tps / 1e9 / HBM_PEAK_GBS, 4),
+            "sweeps_per_token": round(sw, 3), "bytes_per_token_streamed": round(sw * one), "streamed_GBs": round(sw * one * tps / 1e9, 1),
+            "frac": round(sw * one * tps / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "frac = bytes actually streamed per token (sweeps_per_token x (W_lm + T x kv_tok) at the mean context; a failed speculation counts "
+                    "its 16-row sweep and its 8-row re-run) x tokens/s / 8 TB/s; frac_algorithmic credits SURVEY 8(d)'s 2 x (W_lm + T x kv_tok) per token "
+                    "whether or not both sweeps ran; one image at a time, prefill and vision front-end included in the time"}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,17 +293,29 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-new", type=int, default=128)
     ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json configs: 3 (default, the metric's: LLaVA-1.5-7B K=8), 2 (LLaVA-1.5-7B K=4 [0.1,0.3,0.5,0.7]), 1 (--original), "
+                         "4 (InstructBLIP-Vicuna-7B K=8, 32 visual tokens) and 5 (LLaVA-NeXT-Mistral-7B K=8, 2928 visual tokens, fp8 weights) at engine "
+                         "level: LM prefill from synthetic merged embeddings + ensemble decode, vision front-end not included")
     ap.add_argument("--mode", choices=["replicas", "kshard"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
-    ap.add_argument("--images-per-gpu", type=int, default=32,
+    ap.add_argument("--images-per-gpu", type=int, default=None,
                     help="images decoded concurrently per GPU (lanes over one set of weights, 1..64); 1 = the reference's "
-                         "one-image-at-a-time loop")
+                         "one-image-at-a-time loop; default 32 (config 5: 8)")
     ap.add_argument("--no-batch-tower", action="store_true", help="one vision-tower call per image instead of one per 16 images (A/B)")
-    ap.add_argument("--prefill-chunk", type=int, default=16, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
-    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (experiments)")
-    ap.add_argument("--single-images", type=int, default=5, help="images of the one-image-at-a-time leg (after one warm-up image)")
+    ap.add_argument("--prefill-chunk", type=int, default=None, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (product switches)")
+    ap.add_argument("--single-images", type=int, default=5, help="images of the one-image-at-a-time legs (after one warm-up image)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the isolated-kernel leg (libdropdec_tools.so)")
     args = ap.parse_args()
+    if args.config == 1:
+        args.original = True
+    if args.config == 2:
+        args.k = 4
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return spawn_ranks(args)                    # nothing in this process has touched the GPU yet
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -198,98 +334,157 @@ def main() -> int:
         build.build()                      # one builder per node; the others wait (no concurrent writes of the .so)
     if use_dist:
         torch.distributed.barrier()
+    from dropoutdecoding_amd import _lib as _ddlib
     from dropoutdecoding_amd import config as ddcfg
-    from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
+    from dropoutdecoding_amd import lm
 
     for kv in args.tune:
-        from dropoutdecoding_amd import _lib as _ddlib
         k_, v_ = kv.split("=")
         _ddlib.check(_ddlib.load().dd_set_tuning(int(k_), int(v_)), "dd_set_tuning")
-    probs = ddcfg.VOTING_NUMBERS_K8[:args.k] if args.k <= 8 else [0.1 + 0.05 * i for i in range(args.k)]
-    ddcfg.settings["voting_numbers"] = probs
-    model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
-    model.original = args.original
-    if args.no_batch_tower:
-        from dropoutdecoding_amd.vlm import DropoutVLM
-        type(model)._visual_embeds_batch = DropoutVLM._visual_embeds_batch
-    eng = model.engine
-    if args.mode == "kshard" and use_dist:
-        from dropoutdecoding_amd.dist import KShardDecoder
-        model.kshard = KShardDecoder(eng, rank, world)
+    probs = (ddcfg.VOTING_NUMBERS_K4 if args.k == 4 else ddcfg.VOTING_NUMBERS_K8[:args.k]) if args.k <= 8 else [0.1 + 0.05 * i for i in range(args.k)]
+    ddcfg.settings["voting_numbers"] = list(probs)
+    K_eff = 0 if args.original else len(probs)
+    engine_level = args.config in (4, 5)
+    if args.images_per_gpu is None:
+        args.images_per_gpu = 8 if args.config == 5 else 32
+    if args.prefill_chunk is None:
+        args.prefill_chunk = 2 if args.config == 5 else 16
+    B = 1 if args.mode == "kshard" else max(1, min(64, args.images_per_gpu))
 
     def barrier():
         if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    B = 1 if args.mode == "kshard" else max(1, min(64, args.images_per_gpu))
-    lanes = [model] + [model.spawn_lane() for _ in range(B - 1)]
-    from dropoutdecoding_amd.vlm import generate_group
+    # ------------------------------------------------------------------------------------------------------------------
+    # the workload: `run_steps(first, n)` = n batches of B images / sequences; `one_stream(i)` = one image / sequence alone
+    # ------------------------------------------------------------------------------------------------------------------
+    kshard = None
+    if not engine_level:
+        from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
+        from dropoutdecoding_amd.vlm import GroupPipeline
+        model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+        model.original = args.original
+        if args.no_batch_tower:
+            from dropoutdecoding_amd.vlm import DropoutVLM
+            type(model)._visual_embeds_batch = DropoutVLM._visual_embeds_batch
+        eng = model.engine
+        lm_cfg, family, T0, L, prompt_len = eng.cfg, lm.FAMILY_LLAVA, 608, 576, 32
+        wname, weight_bytes = "bf16", 2.0
+        if args.mode == "kshard" and use_dist:
+            from dropoutdecoding_amd.dist import KShardDecoder
+            kshard = model.kshard = KShardDecoder(eng, rank, world, time_exchange=True)
+        pipe = None
+        if B > 1:
+            # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
+            pipe = GroupPipeline(model, lanes=B)
+            pipe.prefill_chunk = max(1, args.prefill_chunk)
 
-    def one(i, n_lanes=B):
-        """one step = one batch of n_lanes images through generate(): CLIP + prefill each, then all decoded together"""
-        batch = []
-        for b in range(n_lanes):
-            ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
-            batch.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
-        if n_lanes == 1:
-            outs = [model.generate(**batch[0], max_new_tokens=args.n_new, eos_token_id=[])]
-        else:
-            outs = generate_group(lanes[:n_lanes], batch, max_new_tokens=args.n_new, eos_token_id=[])
-        for o, kw in zip(outs, batch):
+        def batch_inputs(i, n=B):
+            out = []
+            for b in range(n):
+                ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
+                out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
+            return out
+
+        def one_stream(i):
+            kw = batch_inputs(i, 1)[0]
+            o = model.generate(**kw, max_new_tokens=args.n_new, eos_token_id=[])
             assert o.shape[1] == kw["input_ids"].shape[1] + args.n_new
-        return outs
+
+        def run_steps(first, n):
+            if pipe is None:
+                for i in range(n):
+                    one_stream(first + i)
+                return
+            done = 0
+            for outs in pipe.run((batch_inputs(first + i) for i in range(n)), max_new_tokens=args.n_new, eos_token_id=[]):
+                assert len(outs) == B and all(o.shape[1] == prompt_len + args.n_new for o in outs)
+                done += 1
+            assert done == n
+        front = "CLIP-L/14-336 front-end + "
+        model_name = "LLaVA-1.5-7B"
+    else:
+        # BASELINE configs 4 / 5 at the engine: synthetic merged embeddings of the real shape -> LM prefill + scorer -> ensemble decode
+        if args.config == 4:
+            lm_cfg, family, L, prompt_len, wname, model_name = lm.VICUNA_7B, lm.FAMILY_IBLIP, 32, 32, "bf16", "InstructBLIP-Vicuna-7B"
+        else:
+            lm_cfg, family, L, prompt_len, wname, model_name = lm.MISTRAL_7B, lm.FAMILY_NEXT, 2928, 32, "fp8", "LLaVA-NeXT-Mistral-7B"
+        T0 = L + prompt_len
+        weight_bytes = 1.0 if wname == "fp8" else 2.0
+        s0 = 0 if family == lm.FAMILY_IBLIP else 5
+        mk = lambda owner: lm.DropoutEngine(lm_cfg, family=family, max_seq=T0 + args.n_new + 8, max_visual=L, kv_format="fp16",
+                                            weight_format=wname, share_weights_with=owner)
+        eng = mk(None)
+        eng.load_synthetic(0, 0.02)
+        sets = [[eng] + [mk(eng) for _ in range(B - 1)]]
+        gens = {}
+
+        def embeds(i):
+            g = gens.setdefault("g", torch.Generator(device="cuda"))
+            g.manual_seed(1000 + i)
+            return torch.randn(T0, lm_cfg.hidden_size, device="cuda", generator=g) * 0.5
+
+        def one_stream(i):
+            eng.prefill(embeds(i), s0, L)
+            toks = eng.generate(args.n_new, mprobs=probs, dropout=not args.original)
+            assert len(toks) == args.n_new
+
+        def run_steps(first, n):
+            lanes = sets[0]
+            for i in range(n):
+                if B == 1:
+                    one_stream(first + i)
+                    continue
+                for c0 in range(0, B, args.prefill_chunk):
+                    part = lanes[c0:c0 + args.prefill_chunk]
+                    lm.prefill_group(part, [embeds((first + i) * B + c0 + j) for j in range(len(part))], [(s0, L)] * len(part))
+                toks = lm.EngineGroup(lanes).generate(args.n_new, mprobs=probs, dropout=not args.original)
+                assert all(len(t) == args.n_new for t in toks)
+        front = ""
 
     img0 = rank * 10_000 if args.mode == "replicas" else 0
-    pipe = None
-    if B > 1:
-        # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
-        from dropoutdecoding_amd.vlm import GroupPipeline
-        pipe = GroupPipeline(model, lanes=B)
-        pipe.prefill_chunk = max(1, args.prefill_chunk)
-
-    def batch_inputs(i):
-        out = []
-        for b in range(B):
-            ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
-            out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
-        return out
-
-    def run_steps(first, n):
-        if pipe is None:
-            for i in range(n):
-                one(first + i)
-            return
-        done = 0
-        for outs in pipe.run((batch_inputs(first + i) for i in range(n)), max_new_tokens=args.n_new, eos_token_id=[]):
-            assert len(outs) == B and all(o.shape[1] == 32 + args.n_new for o in outs)
-            done += 1
-        assert done == n
-
     run_steps(img0, args.warmup)
+    if kshard is not None:
+        kshard.exchange_ms(reset=True)
     barrier()
     t0 = time.perf_counter()
     run_steps(img0 + args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    single = None
-    if B > 1 and rank == 0 and args.single_images > 0:
-        # the same path one image at a time (the reference's loop: chair_test.py:274-346), several images after a warm-up
-        one(img0 + 900, 1)
+    exchange = kshard.exchange_ms(reset=True) if kshard is not None else None
+
+    # ---- one image at a time (the reference's own loop: chair_test.py:274-346): adaptive speculation, always, never -------------
+    def single_leg(mode, first, images):
+        eng.set_speculation(mode)
+        one_stream(first)                           # warm-up image (graphs of this mode captured)
+        eng.spec_stats(reset=True)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(args.single_images):
-            one(img0 + 901 + i, 1)
+        for i in range(images):
+            one_stream(first + 1 + i)
         torch.cuda.synchronize()
-        t1 = (time.perf_counter() - t1) / args.single_images
-        single = {"value": round(args.n_new / t1, 2), "unit": "tokens/s", "ms_per_image": round(t1 * 1e3, 1),
-                  "images": args.single_images,
-                  "note": "one image at a time: prefill + 128 ensemble steps; a step is ONE sweep over the weights when the masks sampled for "
-                          "an empty keep set stand (speculative step, exact), two otherwise; the host reads the check's verdict and launches the re-run "
-                          "only when it is needed (dd_lm_decode_step_sync)"}
+        t1 = (time.perf_counter() - t1) / images
+        st = eng.spec_stats(reset=True)
+        eng.set_speculation("default")
+        return {"value": round(args.n_new / t1, 2), "unit": "tokens/s", "ms_per_image": round(t1 * 1e3, 1), "images": images,
+                "speculation": mode, "speculation_hit_rate": None if st["hit_rate"] is None else round(st["hit_rate"], 3),
+                "steps": {"held": st["held"], "rerun": st["rerun"], "plain_two_sweep": st["plain"], "policy_switched_off": st["switched_off"]},
+                "sweeps_per_step": None if st["sweeps_per_step"] is None else round(st["sweeps_per_step"], 3)}
+
+    single = single_two = single_keep = None
+    if B > 1 and rank == 0 and args.single_images > 0 and args.mode == "replicas":
+        single = single_leg("adaptive", img0 + 900, args.single_images)
+        single["note"] = ("one image at a time: " + front + "prefill + scorer + ensemble steps; a step is ONE sweep over the weights when the masks "
+                          "sampled for an empty keep set stand (speculative step, exact), two otherwise; the library's adaptive policy stops speculating "
+                          "while fewer than about one in three checks hold.  RANDOM weights almost never predict a token that is in a visual token's "
+                          "top-k list, so the keep set is nearly always empty and the hit rate here is far above a trained checkpoint's: see "
+                          "single_stream_two_sweep (what every step costs when the speculation never holds) and single_stream_nonempty_keep_sets")
+        if not args.original:
+            single_two = single_leg("never", img0 + 920, max(2, args.single_images // 2))
+            single_two["note"] = "the same with speculation off: un-masked sweep, then the packed member sweep, every step (the reference's order)"
     if use_dist:
         torch.distributed.barrier()
-    if use_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -297,111 +492,68 @@ def main() -> int:
     tokens = streams * args.steps * args.n_new * B
     value = tokens / dt
 
-    # dominant kernel: the gate/up decode GEMV (44 % of the streamed bytes), HIP events on the launch stream, cycling over the
-    # 32 layers' weights.  With several images per GPU the member passes are 64-row passes (the members of eight sequences; 32 /
-    # 16 rows with fewer images): the slice-resident pair k_gemv_slices (streams the weights) + k_gemv_finish (adds the slices,
-    # epilogue).  The trailing template argument of k_gemv_slices names the matrix (2 = gate/up + SiLU).
-    K_eff = 0 if args.original else len(probs)
     rows8 = min(max(K_eff, 1), 8)
     wide = B > 1 and 1 <= K_eff <= 8
-    dom_rows = (64 if B >= 8 else (32 if B >= 4 else 16)) if wide else rows8
-    ms_pair, by = eng.time_gemv(2, dom_rows, 96)                       # the whole GEMV (both kernels when wide)
-    ms = eng.time_gemv(2 + 8, dom_rows, 96)[0] if wide else ms_pair    # the streaming kernel alone
-    dom_kernel = ("k_gemv_slices_seq<8, 8, 16, 3, 0, 2>" if dom_rows == 64 else f"k_gemv_slices<1, {dom_rows // 8}, 8, 16, 16, 2, 0, 2>") if wide \
-        else "k_gemv<2, 2, 8, 1, 1, 0, 0>"
-    dom_name = (f"{dom_kernel} (gate/up decode GEMV of a {dom_rows}-row pass = the members of {dom_rows // 8} sequences: streams the 180 MB of "
-                "weights once, K in 4 slice pairs (64 rows: one slice of a pair resident in LDS at a time); its finishing kernel k_gemv_finish adds the "
-                "pairs' partial sums and applies SiLU*up)") if wide \
-        else f"{dom_kernel} (gate/up decode GEMV, 8 rows)"
-    achieved = by / (ms * 1e-3) / 1e9
-    sweep_ms = eng.time_sweep(rows8, 5)
-    sweep_bytes = eng.algorithmic_bytes(0)
-    kinds = {}
-    for which, name in ((0, "qkv"), (1, "o_proj"), (3, "down_proj")):
-        m2, b2 = eng.time_gemv(which, dom_rows, 96)
-        kinds[name] = round(b2 / (m2 * 1e-3) / 1e9, 1)
-    kinds["gate_up_incl_finish"] = round(by / (ms_pair * 1e-3) / 1e9, 1)
-    rows_cmp = None
-    if wide:
-        m8, b8 = eng.time_gemv(2, rows8, 96)
-        kinds["gate_up_8_rows"] = round(b8 / (m8 * 1e-3) / 1e9, 1)
-        # the same matrix at the other pass widths (streaming kernel alone): a wider pass streams the same weight bytes for more
-        # rows, so its algorithmic GB/s per launch is lower while the time per row falls
-        rows_cmp = {}
-        for r_ in (16, 32, 64):
-            mr = eng.time_gemv(2 + 8, r_, 96)[0]
-            rows_cmp[str(r_)] = {"us": round(mr * 1e3, 2), "frac": round(by / (mr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_8_rows": round(mr * 1e3 * 8 / r_, 2)}
-
-    # HBM traffic / MFMA busy of the dominant kernel: NOT measured in this run (bench.py cannot collect PMCs) — read from the
-    # committed profile of this round (separate rocprofv3 --pmc passes, FETCH_SIZE x2 for gfx950), matched by kernel name;
-    # the kernel-trace average duration of the same kernel from the committed stats sits beside the live HIP-event number.
-    traffic = mfma_util = stats_avg_us = None
-    prof = {"pmc": "profiles/r02_pmc_summary.json", "stats": "profiles/r02_kernel_stats.csv"}
-    try:
-        pm = json.load(open(os.path.join(ROOT, prof["pmc"])))
-        for name, v in pm["kernels"].items():
-            if name.startswith("void " + dom_kernel):
-                traffic = v["hbm_read_bytes_per_launch"] + v.get("hbm_write_bytes_per_launch", 0)
-                mfma_util = v.get("mfma_util")
-    except Exception:
-        pass
-    try:
-        import csv
-        for row in csv.DictReader(open(os.path.join(ROOT, prof["stats"]))):
-            if row["Name"].startswith("void " + dom_kernel):
-                stats_avg_us = round(float(row["AverageNs"]) / 1e3, 2)
-    except Exception:
-        pass
-    # end to end against SURVEY 8(d)'s per-token bytes (2 sweeps x (weights + KV at the mean context)): the one-image-at-a-time
-    # rate is the like-for-like figure (a batch amortises the weight read, so the aggregate is not comparable)
-    bytes_tok = 27.13e9
-    e2e = None
-    if single:
-        e2e = {"tokens_per_s": single["value"], "bytes_per_token": bytes_tok, "achieved_GBs": round(bytes_tok * single["value"] / 1e9, 1),
-               "frac": round(bytes_tok * single["value"] / 1e9 / HBM_PEAK_GBS, 4),
-               "note": "SURVEY 8(d): 2*W_lm + 2*T*kv_tok at T=672 (bf16 KV) per decoded token; one image at a time, prefill included"}
+    dom_rows = (64 if B >= 8 and wname != "fp8" else (32 if B >= 4 else 16)) if wide else rows8
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        try:
+            roof = roofline_leg(lm_cfg, family, wname, "fp16", T0, L, dom_rows, rows8, wide)
+        except Exception as e:                                         # the throughput number must still be reported
+            roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and single and not engine_level and not args.original:
+        # the keep sets a trained checkpoint has: 64 lm_head rows scaled up make the un-masked argmax one of those ids at every step and
+        # fill the visual tokens' top-k lists with them, so tens of visual tokens are kept per step and the check fails nearly always.
+        # (Changes the weights: last leg of the run.)
+        try:
+            g = torch.Generator(device="cuda").manual_seed(3)
+            W = torch.randn(lm_cfg.vocab_size, lm_cfg.hidden_size, device="cuda", generator=g) * 0.02
+            W[1000:1064] *= 8.0
+            eng._load(lm.T_LM_HEAD, 0, W)
+            del W
+            single_keep = single_leg("adaptive", img0 + 940, max(2, args.single_images // 2))
+            single_keep["note"] = ("lm_head with 64 rows scaled x8: every step keeps tens of visual tokens, the speculation's check fails, the adaptive "
+                                   "policy falls back to two-sweep steps and re-probes every 32 steps")
+        except Exception as e:
+            single_keep = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    if roof is not None and single:
+        roof["end_to_end"] = end_to_end(single, lm_cfg, T0 + args.n_new / 2, weight_bytes, 2.0)
+        if single_two:
+            roof["end_to_end_two_sweep"] = end_to_end(single_two, lm_cfg, T0 + args.n_new / 2, weight_bytes, 2.0)
 
     if rank == 0:
+        kv_note = "fp16 KV cache = the reference's cache width"
+        wl = (f"{model_name} Dropout Decoding, {B} synthetic " + ("336x336 image(s)" if not engine_level else "sequence(s)") + f" per step and GPU -> each {L} visual tokens + "
+              f"{prompt_len}-token prompt (prefill {T0}), {args.n_new} decoded tokens each (EOS ignored), K={K_eff} voting_numbers={list(probs) if K_eff else []}, "
+              f"random-init weights of the real shapes ({wname} weights, fp32 activations, {kv_note})"
+              + ("; engine level: the LM prefill starts from synthetic merged embeddings, the vision front-end is not part of the step" if engine_level else "")
+              + (f"; the {B} are independent sequences (own KV cache and rng stream, results identical to decoding each alone) whose un-masked passes "
+                 f"share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep"
+                 + ("; the next batch's CLIP + prefill overlap the current batch's decode on a second stream" if not engine_level else "") if B > 1 else ""))
+        metric = {1: f"decoded tokens/sec {model_name} --original", 2: f"decoded tokens/sec {model_name} K=4 ensemble", 3: f"decoded tokens/sec {model_name} K=8 ensemble",
+                  4: f"decoded tokens/sec {model_name} K=8 ensemble", 5: f"decoded tokens/sec {model_name} K=8 ensemble, fp8 weights"}[args.config]
+        if args.original:
+            metric = f"decoded tokens/sec {model_name} --original"
+        elif K_eff not in (4, 8) or (args.config == 3 and K_eff != 8):
+            metric = f"decoded tokens/sec {model_name} K={K_eff} ensemble"
         line = {
-            "metric": "decoded tokens/sec LLaVA-1.5-7B K=8 ensemble" if not args.original else "decoded tokens/sec LLaVA-1.5-7B --original",
-            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"LLaVA-1.5-7B Dropout Decoding, {B} synthetic 336x336 image(s) per step and GPU -> each 576 visual tokens + "
-                                   f"32-token prompt (prefill 608), {args.n_new} decoded tokens per image (EOS ignored), K={K_eff} voting_numbers={probs if K_eff else []}, "
-                                   "random-init weights of the real shapes (bf16 weights, fp32 activations, fp16 KV cache = the reference's cache width)"
-                                   + (f"; the {B} images are {B} independent sequences (own KV cache and rng stream, results identical to "
-                                      "decoding each alone) whose un-masked passes share one sweep over the weights and whose member passes run eight sequences "
-                                      "(64 rows) per sweep; the next batch's CLIP + prefill overlap the current batch's decode on a second stream"
-                                      if B > 1 else ""),
-                       "batch_note": (f"`value` is the aggregate over {B} independent images decoded concurrently per GPU (throughput mode, the "
+            "config": {"workload": wl, "baseline_config": args.config,
+                       "batch_note": (f"`value` is the aggregate over {B} independent sequences decoded concurrently per GPU (throughput mode, the "
                                       "reference's multi-process sharding on one GPU); the reference's own shape, one image at a time, is `single_stream`"
                                       if B > 1 else "one image at a time"),
                        "mode": args.mode, "images_per_step_per_gpu": B, "n_new": args.n_new, "K": K_eff,
-                       "one_image_at_a_time": single,
-                       "prefill_included": True, "device_bytes": eng.device_bytes},
-            "single_stream": single,
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": {"source": "committed profile", "measured_in_this_run": False, "file": prof["pmc"],
-                                            "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, FETCH_SIZE x2 (gfx950)"},
-                         "mfma_util": mfma_util,     # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), same PMC summary
-                         "rows_per_launch": dom_rows,
-                         # frac counts the ALGORITHMIC bytes (the weights); the kernel also writes its K-slice partial sums (the
-                         # 4 slice pairs x 64 rows x 22016 columns a finishing kernel adds up): HBM bytes actually moved / duration
-                         "traffic_frac": (round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
-                         "gate_up_streaming_kernel_by_rows": rows_cmp,
-                         "bytes_per_launch": by, "ms_per_launch": round(ms, 5),
-                         "kernel_stats_avg_us": stats_avg_us, "kernel_stats_file": prof["stats"],
-                         "gemv_incl_finish": {"ms": round(ms_pair, 5), "GBs": round(by / (ms_pair * 1e-3) / 1e9, 1),
-                                              "frac": round(by / (ms_pair * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                         "end_to_end": e2e,
-                         "other_gemv_GBs": kinds,
-                         "packed_sweep_8_rows": {"ms": round(sweep_ms, 4), "algorithmic_bytes": sweep_bytes,
-                                          "GBs": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 1)}},
+                       "prefill_included": True, "vision_front_end_included": not engine_level, "device_bytes": eng.device_bytes},
+            "single_stream": single, "single_stream_two_sweep": single_two, "single_stream_nonempty_keep_sets": single_keep,
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if exchange is not None:
+            line["kshard_exchange"] = exchange
+        if world == 1 and not args.no_cpu_baseline and not engine_level:   # the CPU leg restates config 3's shapes
             try:
                 line["cpu_baseline"] = cpu_baseline(max(K_eff, 1) if not args.original else 0)
             except Exception as e:                                     # the GPU number must still be reported

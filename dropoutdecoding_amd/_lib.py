@@ -17,10 +17,15 @@ SYMBOLS = [
     "dd_lm_prefill", "dd_lm_prefill_group", "dd_lm_decode_step_sync", "dd_lm_set_speculation", "dd_lm_spec_stats", "dd_lm_prefill_ensemble", "dd_lm_truncate", "dd_lm_prefill_extend", "dd_lm_decode_step", "dd_lm_step_base", "dd_lm_step_members", "dd_lm_step_commit",
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_set_eos", "dd_lm_step_algorithmic_bytes",
-    "dd_lm_time_sweep", "dd_lm_time_gemv", "dd_set_tuning", "dd_hbm_read_bench",
+    "dd_set_tuning",
     "dd_vit_create", "dd_vit_destroy", "dd_vit_load_tensor", "dd_vit_forward",
     "dd_qformer_create", "dd_qformer_destroy", "dd_qformer_load_tensor", "dd_qformer_forward",
 ]
+
+
+# include/dropdec_tools.h: libdropdec_tools.so only (bench.py's roofline leg, tools/)
+TOOLS_LIB_PATH = os.path.join(_HERE, "libdropdec_tools.so")
+TOOLS_SYMBOLS = ["dd_lm_time_sweep", "dd_lm_time_gemv", "dd_tools_last_gemv_kernel", "dd_hbm_read_bench", "dd_tools_set_tuning"]
 
 
 class DDError(RuntimeError):
@@ -50,6 +55,7 @@ class LMConfigC(C.Structure):
 
 
 _lib = None
+_tools = None
 
 
 def load() -> C.CDLL:
@@ -57,8 +63,32 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DDError(f"{LIB_PATH} is missing: build it with `python -m dropoutdecoding_amd.build` "
+    if os.environ.get("DD_USE_TOOLS_LIB", "0") not in ("", "0"):
+        _lib = load_tools()                # the scripts under tools/: one library for the whole process
+        return _lib
+    _lib = _open(LIB_PATH)
+    return _lib
+
+
+def load_tools() -> C.CDLL:
+    """libdropdec_tools.so: the product objects + the measurement hooks (include/dropdec_tools.h).  A second, independent
+    instance of the library: engines created through it must be driven through it (DropoutEngine(lib=...))."""
+    global _tools
+    if _tools is None:
+        _tools = _open(TOOLS_LIB_PATH)
+        lib = _tools
+        vp = C.c_void_p
+        lib.dd_lm_time_sweep.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
+        lib.dd_lm_time_gemv.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]
+        lib.dd_tools_last_gemv_kernel.restype = C.c_char_p
+        lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
+        lib.dd_tools_set_tuning.argtypes = [C.c_int, C.c_int]
+    return _tools
+
+
+def _open(path: str) -> C.CDLL:
+    if not os.path.exists(path):
+        raise DDError(f"{path} is missing: build it with `python -m dropoutdecoding_amd.build` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
     # torch must be imported BEFORE the dlopen: torch bundles its own libamdhip64.so.7 / libhsa-runtime64 and the
     # library's DT_NEEDED entries resolve to whichever copy is already in the process (same SONAME).  Loaded first,
@@ -71,7 +101,7 @@ def load() -> C.CDLL:
             torch.cuda.current_device()
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
     lib.dd_version.restype = C.c_int
     lib.dd_last_error.restype = C.c_char_p
@@ -125,8 +155,6 @@ def load() -> C.CDLL:
     lib.dd_lm_peek_tokens.restype = C.c_int
     lib.dd_lm_step_algorithmic_bytes.argtypes = [vp, C.c_int]
     lib.dd_lm_step_algorithmic_bytes.restype = C.c_double
-    lib.dd_lm_time_sweep.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
-    lib.dd_lm_time_gemv.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), vp]
     lib.dd_set_tuning.argtypes = [C.c_int, C.c_int]
     lib.dd_vit_create.argtypes = [C.POINTER(VitConfigC), C.POINTER(vp)]
     lib.dd_vit_destroy.argtypes = [vp]
@@ -136,16 +164,14 @@ def load() -> C.CDLL:
     lib.dd_qformer_destroy.argtypes = [vp]
     lib.dd_qformer_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     lib.dd_qformer_forward.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp]
-    lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     if os.environ.get("DD_NO_GRAPH", "0") not in ("", "0"):
         lib.dd_set_tuning(8, 0)          # launch every decode step kernel by kernel instead of replaying hipGraphs
-    _lib = lib
     return lib
 
 
-def check(rc: int, what: str = "") -> None:
+def check(rc: int, what: str = "", lib=None) -> None:
     if rc != 0:
-        msg = load().dd_last_error().decode("utf-8", "replace")
+        msg = (lib or load()).dd_last_error().decode("utf-8", "replace")
         if rc == -1:
             raise ValueError(f"{what}: {msg}")          # the reference raises ValueError on bad shapes (llava.py:134-138)
         raise DDError(f"{what}: rc={rc}: {msg}")

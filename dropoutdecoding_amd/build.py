@@ -1,4 +1,5 @@
-"""Build libdropdec.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+"""Build libdropdec.so (the C-ABI HIP library) and libdropdec_tools.so (the same objects + the measurement hooks of
+csrc/dd_tools.hip, for bench.py's roofline leg and tools/) in-tree with hipcc for gfx950.
 
     python -m dropoutdecoding_amd.build [--force]
 
@@ -14,8 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libdropdec.so")
+TOOLS_LIB = os.path.join(HERE, "libdropdec_tools.so")
+TOOLS_SOURCES = ["dd_tools.hip"]      # only in libdropdec_tools.so
 SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_gemv.hip", "dd_attn_decode.hip", "dd_prefill.hip", "dd_engine.hip", "dd_vision.hip"]
-HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", os.path.join(ROOT, "include", "dropdec.h")]
+HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", "dd_engine_internal.h",
+           os.path.join(ROOT, "include", "dropdec_tools.h"), os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
@@ -34,13 +38,13 @@ def _header_paths():
 
 
 def _src_hash() -> str:
-    return _file_hash([os.path.join(CSRC, s) for s in SOURCES] + _header_paths()) + "|" + " ".join(FLAGS)
+    return _file_hash([os.path.join(CSRC, s) for s in SOURCES + TOOLS_SOURCES] + _header_paths()) + "|" + " ".join(FLAGS)
 
 
 def _stale() -> bool:
     """Content hash, not mtimes: the gpurun snapshot does not preserve modification times."""
     stamp = LIB + ".srchash"
-    if not (os.path.exists(LIB) and os.path.exists(stamp)):
+    if not (os.path.exists(LIB) and os.path.exists(TOOLS_LIB) and os.path.exists(stamp)):
         return True
     return open(stamp).read().strip() != _src_hash()
 
@@ -53,9 +57,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs, jobs = [], []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
-    for s in SOURCES:
+    tools_objs = []
+    for s in SOURCES + TOOLS_SOURCES:
         o = os.path.join(bdir, s.replace(".hip", ".o"))
-        objs.append(o)
+        (tools_objs if s in TOOLS_SOURCES else objs).append(o)
         want = _file_hash([os.path.join(CSRC, s)] + _header_paths()) + "|" + " ".join(FLAGS)
         stamp = o + ".srchash"
         if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read().strip() == want:
@@ -72,13 +77,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
         with open(stamp, "w") as f:
             f.write(want)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd))
-    tmp = LIB + f".tmp{os.getpid()}"
-    cmd[cmd.index("-o") + 1] = tmp
-    subprocess.check_call(cmd)
-    os.replace(tmp, LIB)                       # atomic: concurrent ranks never see a half-written library
+    for lib, members in ((LIB, objs), (TOOLS_LIB, objs + tools_objs)):
+        tmp = lib + f".tmp{os.getpid()}"
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + members
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, lib)                   # atomic: concurrent ranks never see a half-written library
     with open(LIB + ".srchash", "w") as f:
         f.write(_src_hash())
     return LIB

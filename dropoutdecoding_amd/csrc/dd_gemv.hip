@@ -298,9 +298,16 @@ void ddk_set_tuning(int key, int value) {
   else if (key == 4) g_gemv_pipe = value;
 }
 
+// name (as a kernel trace prints it) of the streaming kernel the last ddk_gemv / ddk_gemv_groups call of this thread launched
+static thread_local char g_last_kernel[96] = "";
+const char* ddk_last_gemv_kernel() { return g_last_kernel; }
+#define NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
+
 template <int EPI, int TILES>
 static void launch_gemv(const GemvArgs& a_, hipStream_t st) {
   const GemvArgs& a = a_;
+  NOTE_KERNEL("k_gemv<%d, %d, %d, 1, 1, %d, %d, %d>", EPI, TILES, a.fp8 ? 8 : (g_gemv_u == 4 || g_gemv_u == 16 ? g_gemv_u : 8), a.fp8 ? 1 : 0,
+              a.fp8 ? 0 : (g_gemv_pipe ? 1 : 0), a.fp8 ? 0 : (a.wf ? 1 : 0));
 #define GV(U_, P_)                                                                             \
   do {                                                                                         \
     if (a.wf) k_gemv<EPI, TILES, U_, 1, 1, 0, P_, 1><<<a.n_tiles, GEMV_THREADS, 0, st>>>(a);   \
@@ -636,6 +643,7 @@ static int launch_gemv_groups_f(const GemvArgs& a, hipStream_t st) {
     if (!FP8) DD_HIP(hipFuncSetAttribute((const void*)k_gemv_groups<EPI, TILES, NG, U, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
+  NOTE_KERNEL("k_gemv_groups<%d, %d, %d, %d, %d, %d>", EPI, TILES, NG, U, FP8, (!FP8 && a.wf) ? 1 : 0);
   if (!FP8 && a.wf) k_gemv_groups<EPI, TILES, NG, U, 0, 1><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
   else k_gemv_groups<EPI, TILES, NG, U, FP8, 0><<<a.n_tiles, GEMV_THREADS, smem, st>>>(a);
   return DD_OK;
@@ -665,6 +673,7 @@ static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
     attr = true;
   }
   const int grid = (sa.halves == 2 ? 2 : 1) * (8 / CH) * sa.G;
+  NOTE_KERNEL("k_gemv_slices<%d, %d, %d, %d, %d, %d, %d, %d>", TW, NG, U, SPW, CS, CH, wf ? 1 : 0, TAG);
   if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
   else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
@@ -723,6 +732,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
           attr = true;
         }
         DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
+        NOTE_KERNEL("k_gemv_slices_seq<8, 8, 16, 2, %d, %d>", a.wf ? 1 : 0, EPI_QKV);
         if (a.wf) k_gemv_slices_seq<8, 8, 16, 2, 1, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
         else k_gemv_slices_seq<8, 8, 16, 2, 0, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
         launch_finish<EPI_QKV, 1, 8, 4>(a, nt, st);
@@ -762,6 +772,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
           attr = true;
         }
         DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
+        NOTE_KERNEL("k_gemv_slices_seq<8, 8, 16, 3, %d, %d>", a.wf ? 1 : 0, EPI_SILU);
         if (a.wf) k_gemv_slices_seq<8, 8, 16, 3, 1, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
         else k_gemv_slices_seq<8, 8, 16, 3, 0, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
         launch_finish<EPI_SILU, 2, 8, 4>(a, a.n_tiles, st);

@@ -37,9 +37,12 @@ class KShardDecoder:
     """Drives the phased engine API (step_base / step_members / export-import / step_commit) with two collectives per
     token.  `engine` is a DropoutEngine (GPU) or any object with the same phase methods (tests use a CPU stand-in)."""
 
-    def __init__(self, engine, rank: int, world: int, group=None):
+    def __init__(self, engine, rank: int, world: int, group=None, time_exchange: bool = False):
         self.e, self.rank, self.world, self.group = engine, rank, world, group
         self.ids, self.rec = engine.new_xchg_buffers()
+        # time_exchange: bracket every token's exchange (export ids -> all-reduce -> import -> export winner -> all-reduce ->
+        # import) with events on the engine's stream; exchange_ms() reports the mean (bench.py --mode kshard)
+        self._events = [] if time_exchange else None
 
     def decode_step(self, mprobs: Optional[Sequence[float]] = None, uniforms=None) -> None:
         st = getattr(self.e, "torch_stream", None)
@@ -63,13 +66,32 @@ class KShardDecoder:
             raise ValueError(f"K={K} members cannot be block-partitioned over {self.world} ranks inside groups of 8")
         if hi > lo:
             e.step_members(lo, hi)
+        ev = None
+        if self._events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         e.export_ids(lo, hi, self.ids)
         dist.all_reduce(self.ids, op=dist.ReduceOp.SUM, group=self.group)
         e.import_ids(self.ids)
         e.export_winner(lo, hi, self.rec)
         dist.all_reduce(self.rec, op=dist.ReduceOp.SUM, group=self.group)
         e.import_winner(self.rec)
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
         e.step_commit()
+
+    def exchange_ms(self, reset: bool = False):
+        """Mean milliseconds per token of the two collectives with their export / import kernels, and the bytes moved per rank."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._events]
+        out = {"ms_per_token": round(sum(ms) / len(ms), 4), "tokens": len(ms), "bytes_per_token": int(self.ids.numel() * 4 + self.rec.numel() * 4),
+               "collectives_per_token": 2, "backend": dist.get_backend(self.group), "world": self.world}
+        if reset:
+            self._events = []
+        return out
 
     def generate(self, n_new: int, mprobs=None) -> List[int]:
         toks = self.e.tokens()

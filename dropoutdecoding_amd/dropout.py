@@ -36,8 +36,8 @@ class TorchCpuCompatRNG:
     and successive calls continue the stream (reference models/llava.py:16-20, :650).
     """
 
-    def __init__(self, seed: int):
-        self._lib = _lib.load()
+    def __init__(self, seed: int, lib=None):
+        self._lib = lib if lib is not None else _lib.load()
         self._h = C.c_void_p()
         _lib.check(self._lib.dd_rng_create(C.c_uint32(seed & 0xFFFFFFFF), C.byref(self._h)), "dd_rng_create")
 
@@ -69,8 +69,8 @@ class TorchGpuCompatRNG(TorchCpuCompatRNG):
     when it runs on a GPU.  `offset` is the generator's philox offset to start from (a multiple of 4).
     """
 
-    def __init__(self, seed: int, offset: int = 0):
-        self._lib = _lib.load()
+    def __init__(self, seed: int, offset: int = 0, lib=None):
+        self._lib = lib if lib is not None else _lib.load()
         self._h = C.c_void_p()
         _lib.check(self._lib.dd_rng_create_philox(C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(offset),
                                                   C.byref(self._h)), "dd_rng_create_philox")

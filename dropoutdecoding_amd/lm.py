@@ -100,12 +100,13 @@ class DropoutEngine:
                  seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
                  iblip_positions: str = "cache", weight_format: str = "bf16", mask_method: str = "epis",
                  use_avg: bool = False, share_weights_with: Optional["DropoutEngine"] = None, kv_format: str = "fp32",
-                 rng_stream: str = "cpu"):
+                 rng_stream: str = "cpu", lib=None):
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
             raise _lib.DDError("DropoutEngine needs a GPU (MI355X); there is no CPU fallback for the product path")
-        self.lib = _lib.load()
+        # lib: another instance of the library than the process's (bench.py's roofline leg: _lib.load_tools())
+        self.lib = lib if lib is not None else (share_weights_with.lib if share_weights_with is not None else _lib.load())
         self.cfg, self.family = cfg, family
         # remembered so that a lane over these weights can be created with the same behaviour (DropoutVLM.spawn_lane)
         self.max_seq, self.max_visual, self.use_random, self.iblip_positions = max_seq, max_visual, use_random, iblip_positions
@@ -143,9 +144,9 @@ class DropoutEngine:
             # a lane: another sequence (own KV cache, state, rng stream) over the same weights — see EngineGroup
             if share_weights_with.weight_owner is not None:
                 share_weights_with = self.weight_owner = share_weights_with.weight_owner
-            _lib.check(self.lib.dd_lm_create_shared(C.byref(c), share_weights_with._h, C.byref(self._h)), "dd_lm_create_shared")
+            self._ck(self.lib.dd_lm_create_shared(C.byref(c), share_weights_with._h, C.byref(self._h)), "dd_lm_create_shared")
         else:
-            _lib.check(self.lib.dd_lm_create(C.byref(c), C.byref(self._h)), "dd_lm_create")
+            self._ck(self.lib.dd_lm_create(C.byref(c), C.byref(self._h)), "dd_lm_create")
         # the reference seeds torch's global generator at import (llava.py:16-20); under chair_test all three
         # modules are imported so 5217 is in force. Default here: the family's own module seed.
         self.seed = fam["seed"] if seed is None else seed
@@ -154,7 +155,7 @@ class DropoutEngine:
         if rng_stream not in ("cpu", "gpu"):
             raise ValueError(f"rng_stream {rng_stream!r}: 'cpu' (mt19937) or 'gpu' (Philox)")
         self.rng_stream = rng_stream
-        self.rng = TorchGpuCompatRNG(self.seed) if rng_stream == "gpu" else TorchCpuCompatRNG(self.seed)
+        self.rng = (TorchGpuCompatRNG if rng_stream == "gpu" else TorchCpuCompatRNG)(self.seed, lib=self.lib)
         # the engine enqueues on its own (non-default) stream: decode steps can then be captured into hipGraphs, and
         # torch work of the caller (next image's preprocessing) does not interleave with the dependent chain
         self.torch_stream = (share_weights_with.torch_stream if share_weights_with is not None
@@ -169,19 +170,22 @@ class DropoutEngine:
     def _s(self) -> int:
         return self.torch_stream.cuda_stream
 
+    def _ck(self, rc: int, what: str) -> None:
+        _lib.check(rc, what, self.lib)              # the error text of THIS engine's library instance
+
     # ---- weights ---------------------------------------------------------------------------
     def _load(self, tid: int, layer: int, t: torch.Tensor) -> None:
         t = t.detach()
         if t.dim() == 1:
             t = t[None]
         t = t.to(torch.float16 if self.weight_format == "fp16" else torch.bfloat16).contiguous()
-        _lib.check(self.lib.dd_lm_load_tensor(self._h, tid, layer, t.view(torch.int16).data_ptr(), t.shape[0],
+        self._ck(self.lib.dd_lm_load_tensor(self._h, tid, layer, t.view(torch.int16).data_ptr(), t.shape[0],
                                               t.shape[1], 1 if t.is_cuda else 0), f"dd_lm_load_tensor({tid},{layer})")
 
     def _load_fp8(self, tid: int, layer: int, t: torch.Tensor) -> None:
         q, s = quantize_fp8(t.detach())
         q, s = q.contiguous(), s.contiguous()
-        _lib.check(self.lib.dd_lm_load_tensor_fp8(self._h, tid, layer, q.data_ptr(), s.data_ptr(), q.shape[0], q.shape[1],
+        self._ck(self.lib.dd_lm_load_tensor_fp8(self._h, tid, layer, q.data_ptr(), s.data_ptr(), q.shape[0], q.shape[1],
                                                   1 if q.is_cuda else 0), f"dd_lm_load_tensor_fp8({tid},{layer})")
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "") -> None:
@@ -198,7 +202,7 @@ class DropoutEngine:
                 (self._load if tid in (T_ATTN_NORM, T_MLP_NORM) else mat)(tid, i, g(f"model.layers.{i}.{name}"))
 
     def load_synthetic(self, seed: int = 0, std: float = 0.02) -> None:
-        _lib.check(self.lib.dd_lm_load_synthetic(self._h, seed, std), "dd_lm_load_synthetic")
+        self._ck(self.lib.dd_lm_load_synthetic(self._h, seed, std), "dd_lm_load_synthetic")
 
     @property
     def device_bytes(self) -> int:
@@ -228,11 +232,11 @@ class DropoutEngine:
             if uniforms is not None:
                 un = uniforms.float().contiguous()
                 un.record_stream(pstream)
-            _lib.check(self.lib.dd_lm_prefill_ensemble(self._h, e.data_ptr(), e.shape[0], span_start, span_len, arr, K,
+            self._ck(self.lib.dd_lm_prefill_ensemble(self._h, e.data_ptr(), e.shape[0], span_start, span_len, arr, K,
                                                        self.rng.handle, un.data_ptr() if un is not None else None,
                                                        ps), "dd_lm_prefill_ensemble")
         else:
-            _lib.check(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, ps),
+            self._ck(self.lib.dd_lm_prefill(self._h, e.data_ptr(), e.shape[0], span_start, span_len, ps),
                        "dd_lm_prefill")
         self.L, self.T0 = span_len, e.shape[0]
         self._last_K = K
@@ -243,7 +247,7 @@ class DropoutEngine:
         pstream = stream if stream is not None else self.torch_stream
         if stream is not None:
             pstream.wait_stream(self.torch_stream)
-        _lib.check(self.lib.dd_lm_truncate(self._h, int(T_keep), pstream.cuda_stream), "dd_lm_truncate")
+        self._ck(self.lib.dd_lm_truncate(self._h, int(T_keep), pstream.cuda_stream), "dd_lm_truncate")
         self.T0 = int(T_keep)
         self._last_K = 0
         self._n_enqueued = 0
@@ -258,7 +262,7 @@ class DropoutEngine:
         pstream = stream if stream is not None else self.torch_stream
         pstream.wait_stream(torch.cuda.current_stream(self.device))
         e.record_stream(pstream)
-        _lib.check(self.lib.dd_lm_prefill_extend(self._h, e.data_ptr(), e.shape[0], pstream.cuda_stream), "dd_lm_prefill_extend")
+        self._ck(self.lib.dd_lm_prefill_extend(self._h, e.data_ptr(), e.shape[0], pstream.cuda_stream), "dd_lm_prefill_extend")
         self.T0 += e.shape[0]
         self._last_K = 0
         self._n_enqueued = 1
@@ -277,7 +281,7 @@ class DropoutEngine:
             un = uniforms.float().contiguous()
             self._keepalive = un
             self.torch_stream.wait_stream(torch.cuda.current_stream(self.device))
-        _lib.check(self.lib.dd_lm_decode_step(self._h, arr, K, self.rng.handle, un.data_ptr() if un is not None else None,
+        self._ck(self.lib.dd_lm_decode_step(self._h, arr, K, self.rng.handle, un.data_ptr() if un is not None else None,
                                               self._s()), "dd_lm_decode_step")
         self._last_K = K
         self._n_enqueued += 1
@@ -289,7 +293,7 @@ class DropoutEngine:
         probs, arr = self._probs(mprobs)
         K = len(probs) if dropout else 0
         held = C.c_int(-1)
-        _lib.check(self.lib.dd_lm_decode_step_sync(self._h, arr, K, self.rng.handle, self._s(), C.byref(held)),
+        self._ck(self.lib.dd_lm_decode_step_sync(self._h, arr, K, self.rng.handle, self._s(), C.byref(held)),
                    "dd_lm_decode_step_sync")
         self._last_K = K
         self._n_enqueued += 1
@@ -301,13 +305,13 @@ class DropoutEngine:
         """When single-sequence steps take the speculative one-sweep form (dd_lm_set_speculation): 'never' (always the
         un-masked sweep, then the members), 'always', 'adaptive' (speculate while enough of the recent checks held, the
         library's default) or 'default' (the process-wide default).  Results never depend on it."""
-        _lib.check(self.lib.dd_lm_set_speculation(self._h, self._SPEC_MODES[mode]), "dd_lm_set_speculation")
+        self._ck(self.lib.dd_lm_set_speculation(self._h, self._SPEC_MODES[mode]), "dd_lm_set_speculation")
 
     def spec_stats(self, reset: bool = False) -> Dict[str, float]:
         """Counts since creation / the last reset: speculative steps that held, that were re-run, plain two-sweep steps the
         adaptive policy issued, times it switched speculation off; hit_rate = held / speculative steps."""
         out = (C.c_int64 * 4)()
-        _lib.check(self.lib.dd_lm_spec_stats(self._h, out, 1 if reset else 0), "dd_lm_spec_stats")
+        self._ck(self.lib.dd_lm_spec_stats(self._h, out, 1 if reset else 0), "dd_lm_spec_stats")
         held, rerun, plain, off = (int(x) for x in out)
         return {"held": held, "rerun": rerun, "plain": plain, "switched_off": off,
                 "hit_rate": (held / (held + rerun)) if held + rerun else None,
@@ -320,16 +324,16 @@ class DropoutEngine:
         self._keepalive = un
         if un is not None:
             self.torch_stream.wait_stream(torch.cuda.current_stream(self.device))
-        _lib.check(self.lib.dd_lm_step_base(self._h, arr, len(probs), self.rng.handle,
+        self._ck(self.lib.dd_lm_step_base(self._h, arr, len(probs), self.rng.handle,
                                             un.data_ptr() if un is not None else None, self._s()), "dd_lm_step_base")
         self._last_K = len(probs)
         return len(probs)
 
     def step_members(self, m_lo: int, m_hi: int) -> None:
-        _lib.check(self.lib.dd_lm_step_members(self._h, m_lo, m_hi, self._s()), "dd_lm_step_members")
+        self._ck(self.lib.dd_lm_step_members(self._h, m_lo, m_hi, self._s()), "dd_lm_step_members")
 
     def step_commit(self) -> None:
-        _lib.check(self.lib.dd_lm_step_commit(self._h, self._last_K, self._s()), "dd_lm_step_commit")
+        self._ck(self.lib.dd_lm_step_commit(self._h, self._last_K, self._s()), "dd_lm_step_commit")
         self._n_enqueued += 1
 
     # exchange records for K-sharding (dist.py); tensors are torch CUDA tensors owned by the caller
@@ -337,16 +341,16 @@ class DropoutEngine:
         return int(self.lib.dd_lm_xchg_stride(self._h))
 
     def export_ids(self, m_lo: int, m_hi: int, ids: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_export_ids(self._h, m_lo, m_hi, ids.data_ptr(), self._s()), "dd_lm_xchg_export_ids")
+        self._ck(self.lib.dd_lm_xchg_export_ids(self._h, m_lo, m_hi, ids.data_ptr(), self._s()), "dd_lm_xchg_export_ids")
 
     def import_ids(self, ids: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_import_ids(self._h, ids.data_ptr(), self._s()), "dd_lm_xchg_import_ids")
+        self._ck(self.lib.dd_lm_xchg_import_ids(self._h, ids.data_ptr(), self._s()), "dd_lm_xchg_import_ids")
 
     def export_winner(self, m_lo: int, m_hi: int, rec: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_export_winner(self._h, m_lo, m_hi, rec.data_ptr(), self._s()), "dd_lm_xchg_export_winner")
+        self._ck(self.lib.dd_lm_xchg_export_winner(self._h, m_lo, m_hi, rec.data_ptr(), self._s()), "dd_lm_xchg_export_winner")
 
     def import_winner(self, rec: torch.Tensor) -> None:
-        _lib.check(self.lib.dd_lm_xchg_import_winner(self._h, rec.data_ptr(), self._s()), "dd_lm_xchg_import_winner")
+        self._ck(self.lib.dd_lm_xchg_import_winner(self._h, rec.data_ptr(), self._s()), "dd_lm_xchg_import_winner")
 
     def new_xchg_buffers(self):
         return (torch.zeros(32, dtype=torch.int32, device=self.device),
@@ -362,11 +366,11 @@ class DropoutEngine:
         if len(ids) > 8:
             raise ValueError("at most 8 eos ids")
         arr = (C.c_int32 * max(len(ids), 1))(*ids)
-        _lib.check(self.lib.dd_lm_set_eos(self._h, arr, len(ids), self._s()), "dd_lm_set_eos")
+        self._ck(self.lib.dd_lm_set_eos(self._h, arr, len(ids), self._s()), "dd_lm_set_eos")
         self._eos_dev = ids
 
     def set_next_token(self, token: int) -> None:
-        _lib.check(self.lib.dd_lm_set_next_token(self._h, int(token), self._s()), "dd_lm_set_next_token")
+        self._ck(self.lib.dd_lm_set_next_token(self._h, int(token), self._s()), "dd_lm_set_next_token")
 
     def peek_tokens(self) -> List[int]:
         """Tokens emitted so far WITHOUT synchronising (pinned host mirror written by the step kernels)."""
@@ -411,7 +415,7 @@ class DropoutEngine:
     # ---- read-backs (synchronise) -------------------------------------------------------------
     def _get(self, what: int, n: int, dtype) -> np.ndarray:
         out = np.empty(n, dtype=dtype)
-        _lib.check(self.lib.dd_lm_get(self._h, what, out.ctypes.data, out.nbytes, self._s()), f"dd_lm_get({what})")
+        self._ck(self.lib.dd_lm_get(self._h, what, out.ctypes.data, out.nbytes, self._s()), f"dd_lm_get({what})")
         return out
 
     def n_tokens(self) -> int:
@@ -465,16 +469,21 @@ class DropoutEngine:
     def algorithmic_bytes(self, K: int) -> float:
         return float(self.lib.dd_lm_step_algorithmic_bytes(self._h, K))
 
+    # measurement hooks: only on engines created through libdropdec_tools.so (lib=_lib.load_tools())
     def time_sweep(self, nb: int, iters: int) -> float:
         ms = C.c_float()
-        _lib.check(self.lib.dd_lm_time_sweep(self._h, nb, iters, C.byref(ms), self._s()), "dd_lm_time_sweep")
+        self._ck(self.lib.dd_lm_time_sweep(self._h, nb, iters, C.byref(ms), self._s()), "dd_lm_time_sweep")
         return float(ms.value)
 
     def time_gemv(self, which: int, nb: int, iters: int):
         """(mean ms per launch, algorithmic bytes per launch) of one decode GEMV kind; 0 qkv, 1 o, 2 gate/up, 3 down."""
         ms, by = C.c_float(), C.c_double()
-        _lib.check(self.lib.dd_lm_time_gemv(self._h, which, nb, iters, C.byref(ms), C.byref(by), self._s()), "dd_lm_time_gemv")
+        self._ck(self.lib.dd_lm_time_gemv(self._h, which, nb, iters, C.byref(ms), C.byref(by), self._s()), "dd_lm_time_gemv")
         return float(ms.value), float(by.value)
+
+    def last_gemv_kernel(self) -> str:
+        """Name (as rocprofv3's kernel trace prints it) of the streaming kernel the last time_gemv() launched."""
+        return self.lib.dd_tools_last_gemv_kernel().decode()
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -550,7 +559,7 @@ class EngineGroup:
         K = len(probs) if dropout else 0
         hs = (C.c_void_p * len(lanes))(*[e._h for e in lanes])
         rs = (C.c_void_p * len(lanes))(*[e.rng.handle for e in lanes])
-        _lib.check(self.lib.dd_lm_group_step(hs, len(lanes), arr, K, rs, lanes[0]._s()), "dd_lm_group_step")
+        self._ck(self.lib.dd_lm_group_step(hs, len(lanes), arr, K, rs, lanes[0]._s()), "dd_lm_group_step")
         for e in lanes:
             e._last_K = K
             e._n_enqueued += 1

@@ -362,19 +362,6 @@ int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream);
  * (2 * W_lm + 2 * T * kv_tok for dropout steps) */
 double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K);
 
-/* Time the packed member sweep alone with HIP events on `stream`: runs `iters` sweeps of
- * `nb` rows at the current length and returns the mean milliseconds (bench.py roofline leg). */
-int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stream);
-
-/* Time one decode GEMV kind in isolation (HIP events on `stream`), cycling over the layers' weights so every
- * launch streams bytes that are not cache-resident. which: 0 qkv, 1 o_proj, 2 gate/up, 3 down_proj; nb = rows (1..8, or
- * 16 / 32 = the two- / four-plane kernels of the lanes path: k_gemv_slices + k_gemv_finish, or k_gemv_groups).
- * which + 8: the slice-resident path's STREAMING kernel alone (k_gemv_slices without its finishing kernel) — the kernel
- * whose duration rocprofv3's kernel trace reports under that name.
- * bytes_per_launch_out = algorithmic (bf16 weight) bytes of one launch. */
-int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, double* bytes_per_launch_out,
-                    void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Vision front-end: CLIP-style ViT tower (+ optional LLaVA 2-layer projector) on own kernels.
  * Replaces what the reference runs through third-party modules at models/llava.py:233-246
@@ -512,26 +499,16 @@ int dd_qformer_load_tensor(dd_qformer* h, int tensor_id, int layer, const uint16
 int dd_qformer_forward(dd_qformer* h, const int32_t* text_ids_dev, int n_text, const float* enc_dev, int n_enc, float* out_dev,
                        float* hidden_out_dev, void* stream);
 
-/* Calibration for bench.py: streaming READ bandwidth (GB/s) this device delivers over buf_dev[bytes] (bytes >= 1 MiB;
- * use a buffer much larger than the 256 MiB Infinity Cache), HIP events on `stream`. */
-int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks, float* gbs_out, void* stream);
-
-/* Kernel tuning knobs for the benchmark scripts: key 0 = GEMV weight tiles in flight per wave (4/8/16),
- * 1 = non-temporal weight loads (0/1), 2 = interleave k-steps over the waves of a workgroup (0/1),
- * 4 = ring (1) or batch (0, default) request order in the 8-row GEMV,
- * 8 = replay decode steps from a hipGraph (default 1), 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4;
- * default 4), 10 = workgroups per group of 8 members in the grouped decode attention (1, 2, 4; default 1),
- * 13 = slice-resident 16 / 32-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits), 14 = process default of the
- * speculation policy of single-sequence steps (dd_lm_set_speculation: 0 never, 1 always, 2 adaptive = default; same results), 15 = XCD-aware block order of the prefill GEMM
- * (default 1; 0: row-major block order, same bits), 16 = rows from which the prefill GEMM uses its 128 x 512 LDS-staged
- * block (default 1024; 0: never; same bits), 17 / 18 / 19 = workgroups per K slice of the 64-row qkv / o_proj / gate-up GEMV
- * (0: default; same bits; 18 < 0: the eight-plane o_proj kernel instead of two four-plane half passes; 19 < 0: single K slices
- * for gate/up instead of slice pairs with one slice resident at a time).  9 also takes 8 (default):
- * the members of eight sequences per pass over the weights.  21 = key tiles per workgroup of the fp16-cache decode attention
- * (0, default: up to 4 while about 1,000 workgroups remain; same bits).  22 = all-tiles form of that attention (a workgroup walks
- * every key tile of its sequence and merges them itself: no partial buffers, no combine launch): 1 (default) for the one-row-per-
- * sequence passes, 2 also for the grouped member passes, 0 never; same bits.
- * Keys 1 and 2 are accepted and ignored (settled: non-temporal weight loads, interleaved k-steps). */
+/* Switches of the library (process-wide; every setting produces the same results):
+ *   8  replay decode steps from hipGraphs (default 1; 0: launch every kernel of a step),
+ *   11 short prompt chunks (dd_lm_prefill_extend, <= 32 rows) through the decode GEMVs (default 1; 0: the prefill GEMMs),
+ *   13 slice-resident 16 / 32 / 64-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits),
+ *   14 process default of the speculation policy of single-sequence steps (dd_lm_set_speculation: 0 never, 1 always,
+ *      2 adaptive = default),
+ *   15 XCD-aware block order of the prefill GEMM (default 1; same bits), 16 rows from which the prefill GEMM uses its
+ *      128 x 512 LDS-staged block (default 1024; 0: never; same bits).
+ * Kernel-variant experiment knobs and the timing hooks of bench.py / tools/ are not part of this library: they live in
+ * libdropdec_tools.so (include/dropdec_tools.h). */
 int dd_set_tuning(int key, int value);
 
 /* ---- several sequences over one set of weights -------------------------------------------------------------------------

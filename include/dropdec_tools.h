@@ -1,0 +1,45 @@
+/* Measurement hooks and experiment knobs of libdropdec_tools.so — NOT part of the drop-in boundary (include/dropdec.h).
+ *
+ * libdropdec_tools.so = the objects of libdropdec.so + csrc/dd_tools.hip.  bench.py's roofline leg and the scripts under
+ * tools/ load it instead of the product library; handles of one library must not be passed to the other (each has its own
+ * state).  Nothing here replaces a reference interface: the reference has no native code and no timing hooks. */
+#ifndef DROPDEC_TOOLS_H
+#define DROPDEC_TOOLS_H
+#include "dropdec.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Time the packed member sweep alone with HIP events on `stream`: runs `iters` sweeps of
+ * `nb` rows at the current length and returns the mean milliseconds (bench.py roofline leg). */
+int dd_lm_time_sweep(dd_lm* h, int nb, int iters, float* mean_ms_out, void* stream);
+
+/* Time one decode GEMV kind in isolation (HIP events on `stream`), cycling over the layers' weights so every
+ * launch streams bytes that are not cache-resident. which: 0 qkv, 1 o_proj, 2 gate/up, 3 down_proj; nb = rows (1..8, or
+ * 16 / 32 / 64 = the two- / four- / eight-plane kernels of the lanes path: k_gemv_slices + k_gemv_finish, or k_gemv_groups).
+ * which + 8: the slice-resident path's STREAMING kernel alone (without its finishing kernel) — the kernel
+ * whose duration rocprofv3's kernel trace reports under the name dd_tools_last_gemv_kernel() returns afterwards.
+ * bytes_per_launch_out = algorithmic (weight) bytes of one launch. */
+int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* mean_ms_out, double* bytes_per_launch_out,
+                    void* stream);
+
+/* Name, as a kernel trace prints it (template arguments included), of the decode-GEMV streaming kernel the calling
+ * thread's last GEMV launch used. */
+const char* dd_tools_last_gemv_kernel(void);
+
+/* Streaming READ bandwidth (GB/s) this device delivers over buf_dev[bytes] (bytes >= 1 MiB; use a buffer much larger than
+ * the 256 MiB Infinity Cache), HIP events on `stream`. */
+int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks, float* gbs_out, void* stream);
+
+/* A/B switches of kernel variants (every setting produces the same bits); keys as tools/ and DESIGN.md quote them:
+ * 0 GEMV weight tiles in flight per wave, 4 ring / batch request order of the 8-row GEMV, 9 sequences per member sweep of
+ * dd_lm_group_step (1, 2, 4, 8), 10 workgroups per group of 8 members in the grouped decode attention, 12 prefill attention
+ * on the matrix cores, 17 / 18 / 19 workgroups per K slice of the 64-row qkv / o_proj / gate-up GEMV, 21 key tiles per
+ * workgroup of the fp16-cache decode attention, 22 all-tiles form of that attention, 23 member sweeps of a group step that
+ * run concurrently (1 or 2).  Keys of dd_set_tuning are forwarded. */
+int dd_tools_set_tuning(int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DROPDEC_TOOLS_H */

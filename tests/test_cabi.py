@@ -15,8 +15,8 @@ def lib():
     return _lib.load()
 
 
-def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "dropdec.h")).read()
+def _header_symbols(name="dropdec.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", src)))
 
@@ -29,6 +29,19 @@ def test_header_and_binding_list_agree():
 def test_library_exports_every_declared_symbol(lib):
     for s in _header_symbols():
         assert hasattr(lib, s), f"libdropdec.so does not export {s}"
+
+
+def test_measurement_hooks_live_in_the_tools_library_only(lib):
+    """include/dropdec_tools.h (timing hooks, experiment knobs) = libdropdec_tools.so; the product library exports none of them."""
+    from dropoutdecoding_amd import _lib
+    assert _header_symbols("dropdec_tools.h") == sorted(_lib.TOOLS_SYMBOLS)
+    assert not set(_lib.TOOLS_SYMBOLS) & set(_lib.SYMBOLS)
+    import ctypes
+    tools = ctypes.CDLL(_lib.TOOLS_LIB_PATH)                 # plain dlopen: no compute calls without a GPU
+    for s in _lib.TOOLS_SYMBOLS + _lib.SYMBOLS:
+        assert hasattr(tools, s), f"libdropdec_tools.so does not export {s}"
+    for s in _lib.TOOLS_SYMBOLS:
+        assert not hasattr(lib, s), f"libdropdec.so exports the measurement hook {s}"
 
 
 def test_version_and_arch(lib):

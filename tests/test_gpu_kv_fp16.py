@@ -164,10 +164,11 @@ def test_truncate_extend_with_fp16_kv(E):
 def test_full_size_attention_time_fp16_vs_fp32_kv(E):
     """LLaVA-1.5-7B shapes, 2 layers: one 8-member sweep at T = 672 with either cache format (prints the times; the fp16
     numbers are printed, not asserted: the 8-row attention of one sequence is latency-bound, the bytes matter on the lanes path)."""
+    from dropoutdecoding_amd import _lib
     out = {}
     for fmt in ("fp32", "fp16"):
         cfg = E.LMConfig(2048, 4096, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
-        eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=784, max_visual=576, seed=1, kv_format=fmt)
+        eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=784, max_visual=576, seed=1, kv_format=fmt, lib=_lib.load_tools())
         eng.load_synthetic(1, 0.02)
         eng.prefill((torch.randn(672, 4096, generator=torch.Generator().manual_seed(2)) * 0.5).cuda(), 5, 576)
         eng.decode_step([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8])

@@ -1,5 +1,7 @@
 """Host-side logic of the drop-in wrappers on CPU (no GPU, no library calls): image-span bookkeeping for both
 processor layouts, error behaviour, return layouts, EOS handling, seed bookkeeping, fp8 quantiser round trip."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,3 +142,28 @@ def test_fp8_quantiser_round_trip():
     d = dequantize_fp8(q, s)
     assert float((d - w).abs().max()) <= float(w.abs().max()) / 16 + 1e-9          # e4m3: 3 mantissa bits
     assert float(d.abs().max(dim=1).values.sub(w.abs().max(dim=1).values).abs().max()) < 1e-6   # row maxima are exact
+
+
+def test_bench_gpus_n_starts_its_own_ranks_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher: N ranks through torch.distributed.run on 127.0.0.1, spawned as child processes
+    before the parent touches the GPU; inside a launcher (WORLD_SIZE set) nothing is spawned."""
+    import importlib
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched before the spawn")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    assert bench.main() == 7                                     # the children's status is the parent's
+    (cmd, env), = calls
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -1,5 +1,6 @@
 """fp8-weight engine timing (LLaVA-NeXT-Mistral-7B shapes = BASELINE config 5, and LLaVA-1.5-7B shapes)."""
 import json, os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import lm

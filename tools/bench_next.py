@@ -1,5 +1,6 @@
 """LLaVA-NeXT-Mistral-7B shapes (GQA 32/8, 5x576+48 = 2928 visual tokens), synthetic weights: engine-level timing."""
 import json, os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import lm

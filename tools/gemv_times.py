@@ -1,6 +1,7 @@
 """Decode GEMVs of the engine in isolation (dd_lm_time_gemv: HIP events, weights cycled over the 32 layers):
 per matrix and row count, the whole GEMV (streaming kernel + finishing kernel) and the streaming kernel alone."""
 import os, sys
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import lm

@@ -1,5 +1,6 @@
 """Host enqueue time vs GPU time of a group step (8 lanes, LLaVA-1.5-7B shapes, K=8)."""
 import os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import lm
@@ -10,10 +11,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 KV = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 from dropoutdecoding_amd import _lib
 if len(sys.argv) > 3:
-    _lib.load().dd_set_tuning(9, int(sys.argv[3]))        # sequences per member sweep (1, 2, 4, 8)
+    _lib.load().dd_tools_set_tuning(9, int(sys.argv[3]))        # sequences per member sweep (1, 2, 4, 8)
 for kv in sys.argv[4:]:                                   # further tuning keys: key=value
     k_, v_ = kv.split("=")
-    _lib.load().dd_set_tuning(int(k_), int(v_))
+    _lib.load().dd_tools_set_tuning(int(k_), int(v_))
 engs = []
 for i in range(B):
     engs.append(lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format=KV,

@@ -1,5 +1,6 @@
 """Streaming-read ceiling of this board as a function of kernel size (bytes per launch) and block count."""
 import ctypes as C, os, sys
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import _lib

@@ -1,5 +1,6 @@
 """Where does a reference-faithful CPU decode forward spend its time on the bench host? (one layer-forward, T=608)"""
 import sys, os, time, torch
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torch.profiler import profile, ProfilerActivity
 from oracle.lm_ref import LMConfig, KVCache, lm_hidden, lm_logits

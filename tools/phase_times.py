@@ -1,5 +1,6 @@
 """Wall-clock phases of one generate() on the GPU (vision front-end / merge / prefill / decode)."""
 import os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import synthetic_inputs

@@ -1,6 +1,7 @@
 """POPE-shaped load (one generated token per question, 6 questions per image), LLaVA-1.5-7B shapes, synthetic weights:
 questions per second with and without settings['reuse_image_prefix']."""
 import os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

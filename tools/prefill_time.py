@@ -2,6 +2,7 @@
 16 = rows from which the 128 x 512 LDS-staged block is used.  Also checks that every variant gives the same bits
 (image logits, prefill logits row, KV checksums).     python tools/prefill_time.py [T0] [order,big_rows]"""
 import os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -19,8 +20,8 @@ VARIANTS = ((0, 0), (1, 0), (1, 1024), (0, 1024), (1, 512), (1, 0))
 if len(sys.argv) > 2:                            # "order,big_rows": one variant only (for rocprofv3 --pmc passes)
     VARIANTS = (tuple(int(v) for v in sys.argv[2].split(",")),)
 for order, big in VARIANTS:
-    lib.dd_set_tuning(15, order)
-    lib.dd_set_tuning(16, big)
+    lib.dd_tools_set_tuning(15, order)
+    lib.dd_tools_set_tuning(16, big)
     for _ in range(2):
         e.prefill(x, 5, L)
     torch.cuda.synchronize()
@@ -37,8 +38,8 @@ for order, big in VARIANTS:
 
 # several sequences at once (dd_lm_prefill_group) against one prefill per sequence
 if T0 <= 1024:
-    lib.dd_set_tuning(15, 1)
-    lib.dd_set_tuning(16, 1024)
+    lib.dd_tools_set_tuning(15, 1)
+    lib.dd_tools_set_tuning(16, 1024)
     for n in (8, 16):
         lanes = [e] + [lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=T0 + 192, max_visual=L, kv_format="fp16",
                                         share_weights_with=e) for _ in range(n - 1)]

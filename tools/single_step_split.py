@@ -1,6 +1,7 @@
 """One sequence at LLaVA-1.5-7B shapes: ms per step with the speculative step on / off, how often the speculation holds, and
 the step's kernels by total time (from hipEvents around N steps; run under rocprofv3 --kernel-trace --stats for the split)."""
 import os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import lm, _lib
@@ -12,7 +13,7 @@ e = lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_vis
 e.load_synthetic(0, 0.02)
 x = torch.randn(608, 4096, generator=torch.Generator().manual_seed(1)).cuda()
 for spec in (1, 0):
-    _lib.load().dd_set_tuning(14, spec)
+    _lib.load().dd_tools_set_tuning(14, spec)
     e.rng.manual_seed(5217)
     e.prefill(x, 5, 576)
     for _ in range(4):

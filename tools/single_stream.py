@@ -1,6 +1,7 @@
 """One image at a time (the reference's loop): decoded tokens/s over several images, and how often the speculative
 single-sweep step held.  python tools/single_stream.py [n_images] [spec 0/1]"""
 import os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bench import synthetic_inputs
@@ -12,7 +13,7 @@ n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 spec = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ddcfg.settings["voting_numbers"] = ddcfg.VOTING_NUMBERS_K8
 model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=136)
-_lib.load().dd_set_tuning(14, spec)
+_lib.load().dd_tools_set_tuning(14, spec)
 eng = model.engine
 n_new = 128
 def one(i):

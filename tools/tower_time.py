@@ -1,5 +1,6 @@
 """CLIP-ViT-L/14-336 + LLaVA projector on own kernels: one image per call vs 16 images per call (ms per image)."""
 import os, sys, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 torch.set_grad_enabled(False)

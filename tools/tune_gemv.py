@@ -2,6 +2,7 @@
 kernels (k_gemv_groups) and with the slice-resident kernels (dd_gemv_slices.h + k_gemv_finish).  us per launch, TB/s of
 weight bytes."""
 import json, os, sys
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")      # timing hooks / experiment knobs: libdropdec_tools.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import _lib, lm
@@ -14,7 +15,7 @@ emb = torch.randn(672, 4096, device="cuda")
 eng.prefill(emb, 5, 576)
 L = _lib.load()
 for nb, slices in [(8, 0), (16, 0), (16, 1), (32, 0), (32, 1)]:
-    L.dd_set_tuning(13, slices)
+    L.dd_tools_set_tuning(13, slices)
     r = {"rows": nb, "slices": slices}
     tot = 0.0
     for which, name in ((0, "qkv"), (1, "o"), (2, "gateup"), (3, "down")):
@@ -27,4 +28,4 @@ for nb, slices in [(8, 0), (16, 0), (16, 1), (32, 0), (32, 1)]:
         tot += best * 1e3
     r["layer_us"] = round(tot, 1)
     print(json.dumps(r), flush=True)
-L.dd_set_tuning(13, 1)
+L.dd_tools_set_tuning(13, 1)
