@@ -82,6 +82,11 @@ extern "C" int dd_lm_destroy(dd_lm* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (int i = 0; i < 3; ++i) {
+    if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+  }
   if (h->tok_host) (void)hipHostFree(h->tok_host);
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   delete h;
@@ -1194,8 +1199,8 @@ static int g_use_graph = 1;    // dd_set_tuning key 8
 static int g_pair_sweeps = 8;  // dd_set_tuning key 9: sequences per member sweep in dd_lm_group_step (0/1: one, 2, 4, 8)
 void dd_engine_set_graph(int on) { g_use_graph = on; }
 void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
-static int g_branches = 1;     // dd_tools_set_tuning key 23: member sweeps of a group step that run concurrently (1 or 2)
-void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 2 ? 2 : n); }
+static int g_branches = 2;     // dd_tools_set_tuning key 23: member sweeps of a group step that run concurrently (1..4)
+void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }
 
 static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st) {
   const int d = h->d, dff = h->dff;
@@ -1422,14 +1427,34 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     }
   }
   const bool multi = g_pair_sweeps && K > 0 && K <= 8;
+  auto width = [&](int m) -> int {     // sequences of the member sweep that starts at lane m
+    const int left = n - m;
+    return !multi ? 1 : (left >= 8 && g_pair_sweeps >= 8 && !h0->fp8 ? 8 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1)));
+  };
+  // The member sweeps of a group step are independent of each other, and each is a chain of dependent launches in which every
+  // matrix ends in a finishing / combine kernel that streams nothing (a fifth of a 64-row sweep).  Dealt over two (up to four)
+  // streams — a side branch works on the scratch of ITS first lane, results unchanged — one sweep's small kernels and launch
+  // boundaries overlap another's weight streaming: 26.4 -> 22.5 ms per 32-lane step with two branches (tools/branch_ab.py).
+  int n_multi = 0;
+  for (int m = 0; m < n; m += width(m)) n_multi += width(m) > 1 ? 1 : 0;
+  const int nbr = g_branches < n_multi ? g_branches : n_multi;       // branches in use: the caller's stream + nbr - 1 side streams
+  const bool fork = nbr >= 2 && h0->side[nbr - 2] != nullptr;
+  if (fork) {
+    DD_HIP(hipEventRecord(h0->ev_fork, st));
+    for (int i = 0; i + 1 < nbr; ++i) DD_HIP(hipStreamWaitEvent(h0->side[i], h0->ev_fork, 0));
+  }
+  int i_multi = 0;
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
     if (K > 0) {
-      const int left = n - m;
-      const int ng = !multi ? 1 : (left >= 8 && g_pair_sweeps >= 8 && !h0->fp8 ? 8 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1)));
+      const int ng = width(m);
       if (ng > 1) {
-        RC(lm_sweep_groups(h0, lanes + m, ng, K, st));
-        RC(group_finish(h0, lanes + m, ng, K, st));
+        const int br = fork ? i_multi % nbr : 0;               // branch 0 = the caller's stream on the leader's scratch
+        dd_lm* scratch = br ? lanes[m] : h0;
+        hipStream_t bs = br ? h0->side[br - 1] : st;
+        RC(lm_sweep_groups(scratch, lanes + m, ng, K, bs));
+        RC(group_finish(scratch, lanes + m, ng, K, bs));
+        ++i_multi;
         m += ng - 1;
         continue;
       }
@@ -1443,6 +1468,11 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     RC(rc);
     q->steps_since_prefill++;
   }
+  if (fork)
+    for (int i = 0; i + 1 < nbr; ++i) {
+      DD_HIP(hipEventRecord(h0->ev_join[i], h0->side[i]));
+      DD_HIP(hipStreamWaitEvent(st, h0->ev_join[i], 0));
+    }
   return DD_OK;
 }
 
@@ -1814,6 +1844,18 @@ extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_
   return DD_OK;
 }
 
+// the second branch's stream and its fork / join events, created outside any capture
+static int group_side_stream(dd_lm* h0) {
+  if (g_branches < 2) return DD_OK;
+  if (!h0->ev_fork) DD_HIP(hipEventCreateWithFlags(&h0->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i + 1 < g_branches; ++i)
+    if (!h0->side[i]) {
+      DD_HIP(hipStreamCreateWithFlags(&h0->side[i], hipStreamNonBlocking));
+      DD_HIP(hipEventCreateWithFlags(&h0->ev_join[i], hipEventDisableTiming));
+    }
+  return DD_OK;
+}
+
 // Replays the whole group step (n + 1 sweeps, ~1600 launches) from a hipGraph when nothing but device-side state has
 // changed since it was captured; the cache lives in the first lane.
 extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
@@ -1824,12 +1866,14 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
                 lanes[m]->T_host + 1 < lanes[m]->T_cap && lanes[m]->n_tok_host < MAX_NEW_TOKENS;
   if (!graphable) {
     if (getenv("DD_DEBUG")) fprintf(stderr, "[dropdec] group step not graphable (eager)\n");
+    if (lanes && n >= 1 && lanes[0]) RC(group_side_stream(lanes[0]));
     return group_step_eager(lanes, n, mprobs, K, rngs, stream_);
   }
   dd_lm* h0 = lanes[0];
+  RC(group_side_stream(h0));
   unsigned long long key = 1469598103934665603ull;
   auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
-  mix(0x67726f7570ull + (unsigned long long)n);
+  mix(0x67726f7570ull + (unsigned long long)n + ((unsigned long long)g_branches << 40));
   mix((unsigned long long)K);
   for (int k = 0; k < K; ++k) {
     unsigned long long bits;

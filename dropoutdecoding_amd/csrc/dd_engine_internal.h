@@ -92,6 +92,10 @@ struct dd_lm {
   float spec_rate = 1.0f;            // running share of speculative steps that held (weight 1/8 per step)
   int spec_cooldown = 0;             // adaptive: two-sweep steps left before speculation is tried again
   long long spec_n[4] = {0, 0, 0, 0};   // speculative steps that held / were re-run, two-sweep steps, switches to two-sweep
+  // further branches of a group step (the group's first lane owns them): the member sweeps are dealt over the caller's stream
+  // and these, and run concurrently
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 
 // one packed sweep of nb rows through all layers + lm_head (dd_engine.hip)

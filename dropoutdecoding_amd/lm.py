@@ -548,6 +548,7 @@ class EngineGroup:
                 raise ValueError("all sequences of a group must share one set of weights (share_weights_with=...)")
         self.engines = engines
         self.lib = engines[0].lib
+        self._ck = engines[0]._ck
 
     def decode_step(self, mprobs: Optional[Sequence[float]] = None, dropout: bool = True,
                     active: Optional[Sequence[int]] = None) -> None:

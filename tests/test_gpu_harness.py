@@ -123,7 +123,8 @@ def test_caption_loop_and_pope_loop_over_the_hip_llava_wrapper(built, tmp_path):
         imgs = {path: _image(i) for i, (_, path) in enumerate(items)}
         log = H.CaptionLog(str(tmp_path / "captions" / "dd.json"))
         n = H.caption_images(m, proc, items, "llava-1.5", log, load_image=imgs.__getitem__, max_new_tokens=12)
-        assert n == 3 and proc.calls[0] == ((H.CHAIR_PROMPTS["llava-1.5"], items[0][1]), False)
+        # positional (prompt, image), as chair_test.py:294 calls the LLaVA processors
+        assert n == 3 and proc.calls[0][0][0] == H.CHAIR_PROMPTS["llava-1.5"] and proc.calls[0][0][1] is imgs[items[0][1]] and proc.calls[0][1] is False
         rows = H.read_caption_log(log.path)
         assert [r["image_id"] for r in rows] == [i for i, _ in items]
         # the oracle: one reference process captioning the three images back to back on one rng stream, stopping at EOS
@@ -211,7 +212,7 @@ def test_caption_loop_over_the_hip_instructblip_wrapper(built, tmp_path):
         items = [(100 + i, f"img{i}.jpg") for i in range(2)]
         log = H.CaptionLog(str(tmp_path / "iblip.json"))
         assert H.caption_images(m, proc, items, "instructblip", log, load_image=imgs.__getitem__, max_new_tokens=9) == 2
-        assert proc.calls[0] == ((), True)                       # keywords: processor(images=..., text=...) (chair_test.py:289-292)
+        assert proc.calls[0][0] == () and proc.calls[0][1] is True   # keywords: processor(images=..., text=...) (chair_test.py:289-292)
         rows = H.read_caption_log(log.path)
         ref = RefDecoder(FAMILY_IBLIP, rc, sd, [0.3, 0.5, 0.7])
         for (iid, path), row in zip(items, rows):
