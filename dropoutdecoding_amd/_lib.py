@@ -18,6 +18,7 @@ SYMBOLS = [
     "dd_lm_xchg_stride", "dd_lm_xchg_export_ids", "dd_lm_xchg_import_ids",
     "dd_lm_xchg_export_winner", "dd_lm_xchg_import_winner", "dd_lm_get", "dd_lm_peek_tokens", "dd_lm_set_next_token", "dd_lm_set_eos", "dd_lm_step_algorithmic_bytes",
     "dd_set_tuning",
+    "dd_lm_tp_link", "dd_lm_tp_set_exchange", "dd_lm_tp_prefill", "dd_lm_tp_decode_step",
     "dd_vit_create", "dd_vit_destroy", "dd_vit_load_tensor", "dd_vit_forward",
     "dd_qformer_create", "dd_qformer_destroy", "dd_qformer_load_tensor", "dd_qformer_forward",
 ]
@@ -26,6 +27,9 @@ SYMBOLS = [
 # include/dropdec_tools.h: libdropdec_tools.so only (bench.py's roofline leg, tools/)
 TOOLS_LIB_PATH = os.path.join(_HERE, "libdropdec_tools.so")
 TOOLS_SYMBOLS = ["dd_lm_time_sweep", "dd_lm_time_gemv", "dd_tools_last_gemv_kernel", "dd_hbm_read_bench", "dd_tools_set_tuning"]
+
+
+TP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)     # int exchange(void* ctx, int rows, void* stream)
 
 
 class DDError(RuntimeError):
@@ -156,6 +160,10 @@ def _open(path: str) -> C.CDLL:
     lib.dd_lm_step_algorithmic_bytes.argtypes = [vp, C.c_int]
     lib.dd_lm_step_algorithmic_bytes.restype = C.c_double
     lib.dd_set_tuning.argtypes = [C.c_int, C.c_int]
+    lib.dd_lm_tp_link.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    lib.dd_lm_tp_set_exchange.argtypes = [vp, vp, C.c_size_t, TP_EXCHANGE_FN, vp]
+    lib.dd_lm_tp_prefill.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.dd_lm_tp_decode_step.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(vp), vp]
     lib.dd_vit_create.argtypes = [C.POINTER(VitConfigC), C.POINTER(vp)]
     lib.dd_vit_destroy.argtypes = [vp]
     lib.dd_vit_load_tensor.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int]

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libdropdec.so")
 TOOLS_LIB = os.path.join(HERE, "libdropdec_tools.so")
 TOOLS_SOURCES = ["dd_tools.hip"]      # only in libdropdec_tools.so
-SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_gemv.hip", "dd_attn_decode.hip", "dd_prefill.hip", "dd_engine.hip", "dd_vision.hip"]
+SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_gemv.hip", "dd_attn_decode.hip", "dd_prefill.hip", "dd_engine.hip", "dd_tp.hip", "dd_vision.hip"]
 HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", "dd_engine_internal.h",
            os.path.join(ROOT, "include", "dropdec_tools.h"), os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"

@@ -119,6 +119,13 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   h->S_d = h->d / 32, h->S_q = h->q_dim / 32, h->S_ff = h->dff / 32;
   h->q_tiles = h->q_dim / 16, h->k_tiles = h->kv_dim / 16, h->qkv_tiles = (h->q_dim + 2 * h->kv_dim) / 16;
   const int d = h->d, dff = h->dff, T = h->T_cap;
+  h->tp_world = c->reserved[0] > 1 ? c->reserved[0] : 1;
+  h->tp_rank = h->tp_world > 1 ? c->reserved[1] : 0;
+  if (h->tp_world > 1 && (h->tp_rank < 0 || h->tp_rank >= h->tp_world || h->tp_world > 8 || c->weight_format == 1 || parent)) {
+    dd_set_error("dd_lm_create: tensor-parallel shard %d of %d (2..8 ranks, bf16 / fp16 weights, not a lane)", c->reserved[1], c->reserved[0]);
+    delete h;
+    return DD_EINVAL;
+  }
   h->fp8 = c->weight_format == 1 ? 1 : 0;
   h->wf = c->weight_format == 2 ? 1 : 0;
   h->kv16 = c->kv_format == 1 ? 1 : 0;
@@ -220,7 +227,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->state, 1);
   // prefill scratch
   DA(h->px, (size_t)T * d);
-  DA(h->pq, (size_t)T * h->q_dim);
+  DA(h->pq, (size_t)T * (h->q_dim > d ? h->q_dim : d));   // q rows of the prefill; also the final-normed rows [n][d] of prefill_head
   size_t p1 = (size_t)T * (d > h->q_dim ? d : h->q_dim);
   DA(h->p1_hi, p1);
   DA(h->p1_lo, p1);
@@ -676,9 +683,17 @@ static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* l
 }
 
 static int prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, int span_len, hipStream_t st);
+int dd_engine_prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* logits, hipStream_t st, const float* src) {
+  return prefill_head(h, row_index, n_rows, logits, st, src);
+}
+int dd_engine_prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, int span_len, hipStream_t st) {
+  return prefill_tail(h, x_rows, T0, span_start, span_len, st);
+}
+int dd_engine_tp_alloc(dd_lm* h, float** p, size_t floats) { return dalloc(h, p, floats); }
 extern "C" int dd_lm_prefill(dd_lm* h, const float* embeds, int T0, int span_start, int span_len, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && embeds, "dd_lm_prefill: null argument");
+  DD_REQUIRE(h->tp_world == 1, "this handle is a tensor-parallel shard: drive it through dd_lm_tp_* (include/dropdec.h)");
   DD_REQUIRE(T0 >= 1 && T0 < h->T_cap, "dd_lm_prefill: T0=%d out of range (KV capacity %d)", T0, h->T_cap);
   // reference llava.py:134-138 raises ValueError on an image-token / feature count mismatch; same contract here
   DD_REQUIRE(span_len >= 1 && span_len <= h->Lmax && span_start >= 0 && span_start + span_len <= T0,
@@ -737,6 +752,7 @@ extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* cons
   for (int i = 0; i < n; ++i) {
     dd_lm* q = lanes[i];
     DD_REQUIRE(q && embeds[i], "dd_lm_prefill_group: null argument (sequence %d)", i);
+    DD_REQUIRE(q->tp_world == 1, "dd_lm_prefill_group: sequence %d is a tensor-parallel shard", i);
     DD_REQUIRE((q->wsrc ? q->wsrc : q) == owner, "dd_lm_prefill_group: sequence %d does not share the group's weights", i);
     for (int j = 0; j < i; ++j) DD_REQUIRE(lanes[j] != q, "dd_lm_prefill_group: sequence listed twice");
     DD_REQUIRE(T0s[i] >= 1 && T0s[i] < q->T_cap, "dd_lm_prefill_group: sequence %d: T0=%d out of range (KV capacity %d)", i, T0s[i], q->T_cap);
@@ -752,11 +768,30 @@ extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* cons
     for (int i = 0; i < n; ++i) RC(dd_lm_prefill(lanes[i], embeds[i], T0s[i], span_starts[i], span_lens[i], stream_));
     return DD_OK;
   }
-  // batch scratch, owned by the weight owner, grown on demand (the old blocks are released with the handle)
+  // batch scratch, owned by the weight owner, grown on demand (a growth waits for the device and releases the smaller blocks:
+  // callers that batch the same number of prompts every time — GroupPipeline does — pay it once)
   const int d = h0->d, dff = h0->dff;
   if (owner->pb_rows < M) {
     DD_HIP(hipDeviceSynchronize());                        // nobody may still be using the smaller scratch
     const size_t w1 = (size_t)(d > h0->q_dim ? d : h0->q_dim);
+    {
+      const size_t old = owner->pb_rows;
+      void* olds[6] = {owner->pb_x, owner->pb_q, owner->pb1_hi, owner->pb1_lo, owner->pb2_hi, owner->pb2_lo};
+      const size_t old_bytes[6] = {old * d * 4, old * h0->q_dim * 4, old * w1 * 2, old * w1 * 2, old * dff * 2, old * dff * 2};
+      for (int i = 0; i < 6; ++i) {
+        if (!olds[i]) continue;
+        for (auto it = owner->allocs.begin(); it != owner->allocs.end(); ++it)
+          if (*it == olds[i]) {
+            owner->allocs.erase(it);
+            break;
+          }
+        (void)hipFree(olds[i]);
+        owner->bytes -= old_bytes[i] ? old_bytes[i] : 16;
+      }
+      owner->pb_x = owner->pb_q = nullptr;
+      owner->pb1_hi = owner->pb1_lo = owner->pb2_hi = owner->pb2_lo = nullptr;
+      owner->pb_rows = 0;
+    }
     if (dalloc(owner, &owner->pb_x, M * d) != DD_OK || dalloc(owner, &owner->pb_q, M * h0->q_dim) != DD_OK ||
         dalloc(owner, &owner->pb1_hi, M * w1) != DD_OK || dalloc(owner, &owner->pb1_lo, M * w1) != DD_OK ||
         dalloc(owner, &owner->pb2_hi, M * dff) != DD_OK || dalloc(owner, &owner->pb2_lo, M * dff) != DD_OK) {
@@ -921,6 +956,7 @@ static int prefill_extend_rows(dd_lm* h, const float* embeds, int n, hipStream_t
 extern "C" int dd_lm_prefill_extend(dd_lm* h, const float* embeds, int n, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && embeds && h->prefilled, "dd_lm_prefill_extend: null argument or no prefilled sequence");
+  DD_REQUIRE(h->tp_world == 1, "this handle is a tensor-parallel shard: drive it through dd_lm_tp_* (include/dropdec.h)");
   DD_REQUIRE(h->n_tok_host <= 1, "dd_lm_prefill_extend: the sequence has already generated tokens (dd_lm_truncate first)");
   DD_REQUIRE(n >= 1 && h->T_host + n < h->T_cap, "dd_lm_prefill_extend: %d more positions do not fit (length %d, capacity %d)",
              n, h->T_host, h->T_cap);
@@ -949,6 +985,13 @@ static int step_keep(dd_lm* h, const int32_t* gate, hipStream_t st) {
   if (h->cfg.mask_mode == DD_MASK_IBLIP_KL)
     return dd_kl_keep_impl(h->base_logits, h->image_logits, h->L, h->V, h->Vpad, 0.1f, h->keep, h->kl_ws, gate, st);
   return dd_overlap_keep_from_argmax(h->argmax_base, h->topk_ids, h->L, h->cfg.k_top, h->keep, gate, st);
+}
+
+int dd_engine_step_keep(dd_lm* h, const int32_t* gate, hipStream_t st) { return step_keep(h, gate, st); }
+int dd_engine_step_begin(dd_lm* h, hipStream_t st) {
+  k_step_begin<<<1, 256, 0, st>>>(h->state, h->leak_bits, h->L, h->cfg.leak_mask == 2 ? 1 : 0);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 
 // the ensemble's vote (or mean) over the K member rows: sets state->winner / voted, member_tok[0] for the mean
@@ -1120,6 +1163,7 @@ int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out,
 extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h, "dd_lm_step_base: null handle");
+  DD_REQUIRE(h->tp_world == 1, "this handle is a tensor-parallel shard: drive it through dd_lm_tp_* (include/dropdec.h)");
   if (!h->prefilled) {
     dd_set_error("dd_lm_step_base: decode before prefill");
     return DD_ESTATE;
@@ -1153,6 +1197,7 @@ extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rn
 extern "C" int dd_lm_step_members(dd_lm* h, int m_lo, int m_hi, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(h && h->prefilled, "dd_lm_step_members: bad state");
+  DD_REQUIRE(h->tp_world == 1, "this handle is a tensor-parallel shard: drive it through dd_lm_tp_* (include/dropdec.h)");
   DD_REQUIRE(m_lo >= 0 && m_lo <= m_hi && m_hi <= h->last_K, "dd_lm_step_members: range [%d,%d) outside K=%d", m_lo,
              m_hi, h->last_K);
   for (int g0 = m_lo; g0 < m_hi;) {
@@ -1364,6 +1409,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
     DD_REQUIRE(q, "dd_lm_group_step: null handle");
+    DD_REQUIRE(q->tp_world == 1, "dd_lm_group_step: sequence %d is a tensor-parallel shard", m);
     DD_REQUIRE((q->wsrc ? q->wsrc : q) == owner, "dd_lm_group_step: sequence %d does not share the group's weights", m);
     DD_REQUIRE(q->T_cap == h0->T_cap && q->Vpad == h0->Vpad && q->kv16 == h0->kv16,
                "dd_lm_group_step: sequence %d has a different KV capacity or cache format", m);
@@ -1650,6 +1696,7 @@ static int decode_step_eager(dd_lm* h, const double* mprobs, int K, dd_rng* rng,
 // probabilities and the rng.  Host cost per step drops from ~3.4 ms of launches to one hipGraphLaunch.
 static int decode_step_queued(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream, bool speculate) {
   DD_REQUIRE(h, "dd_lm_decode_step: null handle");
+  DD_REQUIRE(h->tp_world == 1, "this handle is a tensor-parallel shard: drive it through dd_lm_tp_* (include/dropdec.h)");
   hipStream_t st = (hipStream_t)stream;
   const bool graphable = g_use_graph && !uniforms && h->prefilled && h->steps_since_prefill >= 1 && st != nullptr;
   if (!graphable) {
@@ -1765,6 +1812,7 @@ static int replay_or_capture(dd_lm* h, unsigned long long key, hipStream_t st, b
 // dd_lm_decode_step where the speculative step does not apply (K = 0 or > 8, injected uniforms, speculation switched off).
 extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_rng* rng, void* stream, int* held) {
   DD_REQUIRE(h, "dd_lm_decode_step_sync: null handle");
+  DD_REQUIRE(h->tp_world == 1, "this handle is a tensor-parallel shard: drive it through dd_lm_tp_* (include/dropdec.h)");
   hipStream_t st = (hipStream_t)stream;
   if (held) *held = -1;
   const int mode = spec_mode_of(h);

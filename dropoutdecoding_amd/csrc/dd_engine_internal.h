@@ -96,8 +96,23 @@ struct dd_lm {
   // and these, and run concurrently
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  // tensor-parallel shard (dd_tp.hip): this handle holds the q/k/v/gate/up columns and the o/down rows of rank tp_rank of
+  // tp_world (its dims above are the LOCAL ones); the row-parallel matrices write partial sums into this rank's slot of the
+  // gather buffer [tp_world][rows][d] and every rank adds the slots in rank order
+  int tp_world = 1, tp_rank = 0;
+  float* tp_gather = nullptr;        // linked ranks of one process share rank 0's buffer; one rank per process: its own
+  size_t tp_gather_floats = 0;
+  int (*tp_exchange)(void* ctx, int rows, void* stream) = nullptr;   // one rank per process: all-gather of the slots (torch.distributed)
+  void* tp_ctx = nullptr;
 };
 
+#define KV_ROWS_PER_LAYER KV_ROWS
+// pieces of dd_engine.hip that the tensor-parallel driver (dd_tp.hip) reuses
+int dd_engine_prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* logits, hipStream_t st, const float* src);
+int dd_engine_prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, int span_len, hipStream_t st);
+int dd_engine_step_keep(dd_lm* h, const int32_t* gate, hipStream_t st);
+int dd_engine_step_begin(dd_lm* h, hipStream_t st);          // k_step_begin: the step's RoPE position
+int dd_engine_tp_alloc(dd_lm* h, float** p, size_t floats);  // device memory owned (and released) by the handle
 // one packed sweep of nb rows through all layers + lm_head (dd_engine.hip)
 int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st, dd_lm* const* lanes = nullptr,
              const int32_t* skip_if = nullptr);

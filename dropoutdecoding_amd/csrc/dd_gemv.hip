@@ -290,6 +290,41 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   }
 }
 
+// Tensor-parallel seam of a row-parallel matrix (o_proj, down_proj; dd_tp.hip): every rank's k_gemv wrote its partial product
+// y_r [rows][N] (EPI_STORE) into slot r of `gather` [W][rows][N]; this adds the slots in rank order and runs k_gemv's EPI_RESID
+// epilogue on the sum: x += y, the next matrix's packed operand z = normw * x, the sum-of-squares slots of the folded RMSNorm.
+// One workgroup per 16-column tile like k_gemv, so the slots land where the consuming k_gemv expects them.  W = 1 reproduces
+// k_gemv<EPI_RESID> bit for bit (0 + y = y).
+__global__ __launch_bounds__(128) void k_tp_finish(const float* __restrict__ gather, int W, size_t slot, int nb, float* x, int ldo,
+                                                   const float* __restrict__ normw, u32x4_t* xop_next, float* ssq_out, int ssq_ld,
+                                                   int wf) {
+  __shared__ float ssq_sh[8 * 16];
+  const int t = threadIdx.x, m = t & 7, n = t >> 3, col = blockIdx.x * 16 + n;
+  float sq = 0.f;
+  if (m < nb) {
+    float y = 0.f;
+    for (int r = 0; r < W; ++r) y += gather[(size_t)r * slot + (size_t)m * ldo + col];
+    const float xn = x[(size_t)m * ldo + col] + y;
+    x[(size_t)m * ldo + col] = xn;
+    xop_store(xop_next, col, m, normw[col] * xn, wf);
+    sq = xn * xn;
+  }
+  ssq_sh[n * 8 + m] = sq;
+  __syncthreads();
+  if (t < 8) {
+    float v = 0.f;
+    for (int i = 0; i < 16; ++i) v += ssq_sh[i * 8 + t];
+    ssq_out[(size_t)t * ssq_ld + blockIdx.x] = v;
+  }
+}
+int ddk_tp_finish(const float* gather, int W, size_t slot_floats, int nb, float* x, int N, const float* normw, u32x4_t* xop_next,
+                  float* ssq_out, int ssq_ld, int wf, hipStream_t st) {
+  DD_REQUIRE(gather && W >= 1 && nb >= 1 && nb <= 8 && N % 16 == 0, "tp_finish: bad arguments");
+  k_tp_finish<<<N / 16, 128, 0, st>>>(gather, W, slot_floats, nb, x, N, normw, xop_next, ssq_out, ssq_ld, wf);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 // tuning knobs (dd_set_tuning): 0 = U (4/8/16), 4 = ring (1) or batch (0) request order.
 // Keys 1 (non-temporal loads) and 2 (k-step interleave) are settled at 1 and kept only as accepted no-ops.
 static int g_gemv_u = 8, g_gemv_pipe = 0;
@@ -678,6 +713,22 @@ static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
+// (16 instead of 8 weight requests in flight per wave measured the same or slower: qkv 26.3 vs 25.4 us, gate/up 38.4 vs 38.0)
+template <int U, int MAXG, int TAG>
+static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
+  constexpr size_t smem = (size_t)16 * 8 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, U, 16, MAXG, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, U, 16, MAXG, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  NOTE_KERNEL("k_gemv_slices_seq<8, %d, 16, %d, %d, %d>", U, MAXG, wf ? 1 : 0, TAG);
+  if (wf) k_gemv_slices_seq<8, U, 16, MAXG, 1, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices_seq<8, U, 16, MAXG, 0, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  return DD_OK;
+}
+
 template <int EPI, int TILES, int NG, int NP>
 static void launch_finish(const GemvArgs& a, int n_sets, hipStream_t st) {
   if (g_slices_only) return;
@@ -724,17 +775,8 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
       if (g_exp_G[0] >= 0 && (nt % 16) == 0 && nt / 16 * 4 <= 256) {
         // slice pairs, one slice resident at a time (see gate/up below): two tiles per wave; tuning key 17 < 0: single slices (A/B)
         sa.G = g_exp_G[0] ? g_exp_G[0] : nt / 16;
-        constexpr size_t smem = (size_t)16 * 8 * 1024;
-        static bool attr = false;
-        if (!attr) {
-          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 2, 0, EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 2, 1, EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-          attr = true;
-        }
         DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
-        NOTE_KERNEL("k_gemv_slices_seq<8, 8, 16, 2, %d, %d>", a.wf ? 1 : 0, EPI_QKV);
-        if (a.wf) k_gemv_slices_seq<8, 8, 16, 2, 1, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-        else k_gemv_slices_seq<8, 8, 16, 2, 0, EPI_QKV><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        RC_(launch_slices_seq<8, 2, EPI_QKV>(sa, a.wf, st));
         launch_finish<EPI_QKV, 1, 8, 4>(a, nt, st);
       } else {
         sa.G = g_exp_G[0] > 0 ? g_exp_G[0] : (nt + 31) / 32;
@@ -764,17 +806,8 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
         // allows, in ONE round of workgroups (LLaVA-7B: 58 per pair = 232): 27.25 vs 27.75 ms per 32-lane step; 64 per pair
         // (2.7 tiles per wave: uneven) 28.6, 86 (two tiles, 1.3 rounds) 29.1.  Tuning key 19 < 0: single slices (A/B)
         sa.G = g_exp_G[2] ? g_exp_G[2] : (nt + 23) / 24;
-        constexpr size_t smem = (size_t)16 * 8 * 1024;
-        static bool attr = false;
-        if (!attr) {
-          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 3, 0, EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-          DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, 8, 16, 3, 1, EPI_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-          attr = true;
-        }
         DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
-        NOTE_KERNEL("k_gemv_slices_seq<8, 8, 16, 3, %d, %d>", a.wf ? 1 : 0, EPI_SILU);
-        if (a.wf) k_gemv_slices_seq<8, 8, 16, 3, 1, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-        else k_gemv_slices_seq<8, 8, 16, 3, 0, EPI_SILU><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+        RC_(launch_slices_seq<8, 3, EPI_SILU>(sa, a.wf, st));
         launch_finish<EPI_SILU, 2, 8, 4>(a, a.n_tiles, st);
       } else {
         sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 42) / 43;

@@ -140,6 +140,10 @@ struct GemvArgs {
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
 int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2, 4 or 8) groups of up to 8 rows
+// tensor-parallel seams (dd_tp.hip): slots of `gather` [W][...] added in rank order
+int ddk_tp_finish(const float* gather, int W, size_t slot_floats, int nb, float* x, int N, const float* normw, u32x4_t* xop_next,
+                  float* ssq_out, int ssq_ld, int wf, hipStream_t st);      // decode rows: + k_gemv's EPI_RESID epilogue
+int ddk_tp_add_rows(float* x, const float* gather, int W, size_t n, hipStream_t st);   // prefill rows: x += sum of the slots
 void ddk_set_tuning(int key, int value);
 void ddk_set_gemv_slices(int on);
 void ddk_set_gemm_big_rows(int rows);  // dd_set_tuning key 16: rows from which the prefill GEMM uses the 128 x 512 LDS-staged block (0: never; same bits)

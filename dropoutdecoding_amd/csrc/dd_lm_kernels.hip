@@ -420,3 +420,18 @@ int ddk_kv_sums(const float* kc, const float* vc, int n_layers, size_t lsk, size
   return DD_OK;
 }
 
+
+// Tensor-parallel seam of the prefill (dd_tp.hip): x[i] += sum over ranks (in rank order) of slot r of `gather` [W][n]
+__global__ __launch_bounds__(256) void k_tp_add_rows(float* __restrict__ x, const float* __restrict__ gather, int W, size_t n) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4_t y = {0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < W; ++r) y = y + *(const f32x4_t*)(gather + (size_t)r * n + i);
+  *(f32x4_t*)(x + i) = *(const f32x4_t*)(x + i) + y;
+}
+int ddk_tp_add_rows(float* x, const float* gather, int W, size_t n, hipStream_t st) {
+  DD_REQUIRE(x && gather && W >= 1 && n % 4 == 0, "tp_add_rows: bad arguments");
+  k_tp_add_rows<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(x, gather, W, n);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}

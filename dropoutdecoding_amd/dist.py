@@ -104,12 +104,88 @@ class KShardDecoder:
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Tensor-parallel decode: the only route to single-stream multi-GPU speed-up — K-sharding leaves
-# every rank streaming all weights twice per token.  What is here: the shard plan (which slice of which tensor a rank
-# holds, head-aligned), the collectives a sweep needs, and a torch reference of the sharded forward that runs under any
-# torch.distributed backend (the gloo tests check it against the unsharded forward).  The HIP engine does not take sharded
-# weights yet: its GEMV epilogues fuse residual + next-norm packing, which under TP have to run AFTER the all-reduce (see
-# DESIGN.md "Tensor-parallel decode": the row-parallel matrices end in the slice kernels' partial-sum form, the all-reduce
-# replaces the slice sum, and k_gemv_finish's epilogue runs unchanged on the reduced sums).
+# every rank streaming all weights twice per token.  The shard plan (which slice of which tensor a rank holds, head-aligned)
+# and the collectives a sweep needs are below; the engine side is csrc/dd_tp.hip (dd_lm_tp_*): a rank's row-parallel
+# matrices stop at their partial product, the partials are all-gathered at the two seams of a layer and every rank adds
+# them in rank order before the fused epilogue.  `TensorParallelRank` is the one-process-per-GPU driver: it registers the
+# all-gather (torch.distributed: "nccl" = RCCL over xGMI; "gloo" stages through the host for the tests) as the engine's
+# exchange.  lm.TensorParallelGroup is the single-process form (all ranks on one device).
+# ---------------------------------------------------------------------------------------------------------------------
+class TensorParallelRank:
+    """One rank of a sharded model in its own process.  `cfg` is the FULL model's LMConfig; the rank's engine holds its slices."""
+
+    def __init__(self, cfg, rank: int, world: int, group=None, family: str = "llava-1.5", max_seq: int = 1280, max_visual: int = 576,
+                 seed: Optional[int] = None, **engine_kw):
+        import ctypes as C
+        from . import _lib, lm
+        self.cfg, self.rank, self.world, self.group = cfg, rank, world, group
+        self.engine = lm.DropoutEngine(lm.tp_local_config(cfg, world), family=family, max_seq=max_seq, max_visual=max_visual, seed=seed,
+                                       tp=(rank, world), **engine_kw)
+        e = self.engine
+        self.rows_cap = max_seq + 64
+        self.gather = torch.zeros(world * self.rows_cap * cfg.hidden_size, dtype=torch.float32, device=e.device)
+        self.exchanges = 0
+        self.error = None
+        d = cfg.hidden_size
+
+        def exchange(ctx, rows, stream):
+            try:
+                n = rows * d
+                out = self.gather[: world * n]
+                mine = out[rank * n:(rank + 1) * n]
+                with torch.cuda.stream(e.torch_stream):         # the engine enqueues on this stream (== `stream`)
+                    if dist.get_backend(self.group) == "nccl":
+                        dist.all_gather_into_tensor(out, mine, group=self.group)        # in place: RCCL over xGMI
+                    else:                                       # gloo (tests): through the host
+                        e.torch_stream.synchronize()
+                        parts = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
+                        dist.all_gather(parts, mine.cpu(), group=self.group)
+                        out.copy_(torch.cat(parts).to(out.device))
+                self.exchanges += 1
+                return 0
+            except Exception as ex:                             # an exception must not unwind through the C frames
+                self.error = ex
+                return 1
+        self._cb = _lib.TP_EXCHANGE_FN(exchange)                # kept alive with the object
+        self._hs = (C.c_void_p * 1)(e._h)
+        e._ck(e.lib.dd_lm_tp_set_exchange(e._h, self.gather.data_ptr(), self.gather.numel(), self._cb, None), "dd_lm_tp_set_exchange")
+
+    def load_state_dict(self, sd, prefix: str = "") -> None:
+        from . import lm
+        self.engine.load_state_dict(lm.tp_shard_state_dict(sd, self.cfg, self.rank, self.world, prefix))
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0 and self.error is not None:
+            err, self.error = self.error, None
+            raise err
+        self.engine._ck(rc, what)
+
+    def prefill(self, embeds: torch.Tensor, span_start: int, span_len: int) -> None:
+        e = self.engine
+        x = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
+        e.torch_stream.wait_stream(torch.cuda.current_stream(e.device))
+        x.record_stream(e.torch_stream)
+        self._check(e.lib.dd_lm_tp_prefill(self._hs, 1, x.data_ptr(), x.shape[0], span_start, span_len, e._s()), "dd_lm_tp_prefill")
+        e.L, e.T0, e._last_K, e._n_enqueued = span_len, x.shape[0], 0, 1
+
+    def decode_step(self, mprobs: Optional[Sequence[float]] = None, dropout: bool = True) -> None:
+        import ctypes as C
+        e = self.engine
+        probs, arr = e._probs(mprobs)
+        K = len(probs) if dropout else 0
+        rs = (C.c_void_p * 1)(e.rng.handle)
+        self._check(e.lib.dd_lm_tp_decode_step(self._hs, 1, arr, K, rs, e._s()), "dd_lm_tp_decode_step")
+        e._last_K = K
+        e._n_enqueued += 1
+
+    def generate(self, n_new: int, mprobs=None) -> List[int]:
+        toks = self.engine.tokens()
+        while len(toks) < n_new:                                # every rank decodes the same tokens: the loops stay in step
+            self.decode_step(mprobs)
+            toks = self.engine.tokens()
+        return toks[:n_new]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 class TensorParallelPlan:
     """Megatron-style split of one decoder layer over `world` ranks:

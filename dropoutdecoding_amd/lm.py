@@ -100,7 +100,9 @@ class DropoutEngine:
                  seed: Optional[int] = None, use_random: bool = False, device: Optional[torch.device] = None,
                  iblip_positions: str = "cache", weight_format: str = "bf16", mask_method: str = "epis",
                  use_avg: bool = False, share_weights_with: Optional["DropoutEngine"] = None, kv_format: str = "fp32",
-                 rng_stream: str = "cpu", lib=None):
+                 rng_stream: str = "cpu", lib=None, tp: Optional[Tuple[int, int]] = None):
+        """tp = (rank, world): this engine is one tensor-parallel shard — `cfg` then carries the rank's LOCAL head counts and
+        intermediate size (tp_local_config) and the engine is driven through TensorParallelGroup / dist.TensorParallelRank."""
         if family not in _FAMILY:
             raise ValueError(f"unknown family {family!r}")
         if not torch.cuda.is_available():
@@ -137,6 +139,9 @@ class DropoutEngine:
                            cfg.num_kv_heads, cfg.head_dim, cfg.rms_eps, cfg.rope_theta, max_seq, max_visual,
                            fam["k_top"], fam["mask_mode"], fam["vote_on"], fam["leak_mask"],
                            {"bf16": 0, "fp8": 1, "fp16": 2}[weight_format], {"fp32": 0, "fp16": 1}[kv_format])
+        self.tp = tp
+        if tp is not None:
+            c.reserved[0], c.reserved[1] = int(tp[1]), int(tp[0])
         self.weight_format = weight_format
         self._h = C.c_void_p()
         self.weight_owner = share_weights_with         # kept alive: a lane borrows the owner's weight memory
@@ -495,6 +500,109 @@ class DropoutEngine:
             self.close()
         except Exception:
             pass
+
+
+# ---- tensor-parallel decode (include/dropdec.h dd_lm_tp_*) ---------------------------------------------
+def tp_local_config(cfg: LMConfig, world: int) -> LMConfig:
+    """A rank's LOCAL dimensions: heads and kv heads / world, d_ff / world padded up to a multiple of 256 (the padding rows of
+    gate / up and columns of down are zeros: silu(0) * 0 = 0 contributes nothing)."""
+    if cfg.num_kv_heads % world or cfg.num_heads % world or (cfg.num_heads // world) % 2 or cfg.intermediate_size % (16 * world):
+        raise ValueError(f"{cfg.num_heads} heads / {cfg.num_kv_heads} kv heads / d_ff {cfg.intermediate_size} do not split over {world} ranks "
+                         "(whole kv-head groups, an even number of q heads and whole 16-row tiles per rank)")
+    ff = cfg.intermediate_size // world
+    return LMConfig(cfg.vocab_size, cfg.hidden_size, (ff + 255) // 256 * 256, cfg.num_layers, cfg.num_heads // world,
+                    cfg.num_kv_heads // world, cfg.head_dim, cfg.rms_eps, cfg.rope_theta)
+
+
+def tp_shard_state_dict(sd: Dict[str, torch.Tensor], cfg: LMConfig, rank: int, world: int, prefix: str = "") -> Dict[str, torch.Tensor]:
+    """This rank's slices of a LlamaForCausalLM state dict (dist.TensorParallelPlan.shard_layer per layer, d_ff padded);
+    embeddings, norm vectors and lm_head are replicated."""
+    from .dist import TensorParallelPlan
+    plan = TensorParallelPlan(cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size, world)
+    ff_pad = tp_local_config(cfg, world).intermediate_size
+    out = {k: sd[prefix + k] for k in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")}
+    for i in range(cfg.num_layers):
+        lp = f"model.layers.{i}."
+        for name, t in plan.shard_layer(sd, prefix + lp, rank).items():
+            pad = ff_pad - cfg.intermediate_size // world
+            if pad and name in ("mlp.gate_proj.weight", "mlp.up_proj.weight"):
+                t = torch.cat([t, t.new_zeros(pad, t.shape[1])], dim=0)
+            elif pad and name == "mlp.down_proj.weight":
+                t = torch.cat([t, t.new_zeros(t.shape[0], pad)], dim=1)
+            out[lp + name] = t
+    return out
+
+
+class TensorParallelGroup:
+    """All `world` ranks of a sharded model in ONE process on one device ("linked": dd_lm_tp_link) — the form a single GPU can
+    run and test: every rank's kernels are issued in lock step on one stream and the seams read the shared gather buffer.
+    Same surface as DropoutEngine where it matters (prefill / decode_step / generate / tokens / logits / last_step)."""
+
+    def __init__(self, cfg: LMConfig, world: int, family: str = FAMILY_LLAVA, max_seq: int = 1280, max_visual: int = 576,
+                 seed: Optional[int] = None, **kw):
+        self.cfg, self.world = cfg, world
+        local = tp_local_config(cfg, world)
+        self.ranks = [DropoutEngine(local, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, tp=(r, world), **kw)
+                      for r in range(world)]
+        e0 = self.ranks[0]
+        for e in self.ranks[1:]:
+            e.torch_stream = e0.torch_stream                     # one stream: the ranks' phases are issued in lock step
+        self.lib = e0.lib
+        self._hs = (C.c_void_p * world)(*[e._h for e in self.ranks])
+        e0._ck(self.lib.dd_lm_tp_link(self._hs, world, max_seq), "dd_lm_tp_link")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "") -> None:
+        for r, e in enumerate(self.ranks):
+            e.load_state_dict(tp_shard_state_dict(sd, self.cfg, r, self.world, prefix))
+
+    def manual_seed(self, seed: int) -> None:
+        for e in self.ranks:
+            e.rng.manual_seed(seed)
+
+    def prefill(self, embeds: torch.Tensor, span_start: int, span_len: int) -> None:
+        e0 = self.ranks[0]
+        x = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
+        if not x.is_cuda or x.shape[1] != self.cfg.hidden_size:
+            raise ValueError("embeds must be [T0, hidden] on the GPU")
+        e0.torch_stream.wait_stream(torch.cuda.current_stream(e0.device))
+        x.record_stream(e0.torch_stream)
+        e0._ck(self.lib.dd_lm_tp_prefill(self._hs, self.world, x.data_ptr(), x.shape[0], span_start, span_len, e0._s()), "dd_lm_tp_prefill")
+        for e in self.ranks:
+            e.L, e.T0, e._last_K, e._n_enqueued = span_len, x.shape[0], 0, 1
+
+    def decode_step(self, mprobs: Optional[Sequence[float]] = None, dropout: bool = True) -> None:
+        e0 = self.ranks[0]
+        probs, arr = e0._probs(mprobs)
+        K = len(probs) if dropout else 0
+        rs = (C.c_void_p * self.world)(*[e.rng.handle for e in self.ranks])
+        e0._ck(self.lib.dd_lm_tp_decode_step(self._hs, self.world, arr, K, rs, e0._s()), "dd_lm_tp_decode_step")
+        for e in self.ranks:
+            e._last_K = K
+            e._n_enqueued += 1
+
+    def generate(self, n_new: int, mprobs=None, eos=None, dropout: bool = True) -> List[int]:
+        eos_set = set(_eos_ids(eos))
+        for e in self.ranks:
+            e.set_eos(sorted(eos_set))
+        toks = self.ranks[0].tokens()
+        while len(toks) < n_new and not (eos_set and toks[-1] in eos_set):
+            self.decode_step(mprobs, dropout=dropout)
+            toks = self.ranks[0].tokens()
+        return toks[:n_new]
+
+    # every rank holds the same tokens, logits, masks: read rank 0's (tests compare the others)
+    def tokens(self) -> List[int]:
+        return self.ranks[0].tokens()
+
+    def logits(self) -> np.ndarray:
+        return self.ranks[0].logits()
+
+    def last_step(self):
+        return self.ranks[0].last_step()
+
+    def close(self) -> None:
+        for e in reversed(self.ranks):
+            e.close()
 
 
 def prefill_group(engines: Sequence["DropoutEngine"], embeds: Sequence[torch.Tensor], spans: Sequence[Tuple[int, int]],

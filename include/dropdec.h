@@ -188,7 +188,8 @@ typedef struct dd_lm_config {
   int32_t kv_format;         /* KV cache storage: 0 = fp32 (default), 1 = fp16 — the width the reference keeps its cache in
                                 (chair_test/chair_test.py:189-213: torch_dtype=float16): half the attention bytes; K/V are
                                 rounded to nearest-even when they enter the cache, attention arithmetic stays fp32 */
-  int32_t reserved[3];
+  int32_t reserved[3];       /* [0], [1]: tensor-parallel shard — world (2..8; 0 or 1: not sharded) and rank (dd_lm_tp_*): the head
+                                counts and intermediate_size above are then the rank's LOCAL ones; [2]: 0 */
 } dd_lm_config;
 
 typedef struct dd_lm dd_lm;
@@ -523,6 +524,32 @@ int dd_set_tuning(int key, int value);
  *   deterministic masks or K == 0).  The owner may itself be one of the lanes. */
 int dd_lm_create_shared(const dd_lm_config* cfg, dd_lm* weights_from, dd_lm** out);
 int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream);
+
+/* ---- tensor-parallel decode: ONE sequence over several GPUs ------------------------------------------------------------
+ * Nothing in the reference to mirror (it runs the K members sequentially in one process, models/llava.py:342-359; its
+ * multi-GPU shape is independent jobs, scripts/run_main_experiments.py:81-86).  Sharding the K members leaves every rank
+ * streaming all of W_lm twice per token (dd_lm_step_* / dist.KShardDecoder); sharding the WEIGHTS divides the bytes: q/k/v
+ * and gate/up column-parallel (by kv-head group / d_ff slice), o_proj and down_proj row-parallel with one exchange each
+ * per layer, everything else replicated.  A rank is a dd_lm created with its LOCAL num_heads / num_kv_heads /
+ * intermediate_size (padded with zero rows / columns to a multiple of 256) and cfg.reserved = {world, rank}, loaded with
+ * its slices through dd_lm_load_tensor; it only accepts the calls below (+ dd_lm_get, dd_lm_set_eos, dd_lm_peek_tokens, ...).
+ *   dd_lm_tp_link          all `world` ranks live in ONE process on one device (tests; what one GPU can show): they share a
+ *                          gather buffer [world][rows][d] and the calls below take all of them, in rank order;
+ *   dd_lm_tp_set_exchange  one rank per process (one per GPU): gather_dev [world][rows_cap][d] fp32 belongs to the caller;
+ *                          at each of the 2 seams per layer the engine writes this rank's slot (slot stride rows * d floats)
+ *                          and calls exchange(ctx, rows, stream), which all-gathers the slots in place, ordered on `stream`
+ *                          (torch.distributed over RCCL / xGMI: dropoutdecoding_amd/dist.py TensorParallelRank); the calls
+ *                          below then take that one handle (n = 1).
+ *   dd_lm_tp_prefill       = dd_lm_prefill; dd_lm_tp_decode_step = dd_lm_decode_step (two-sweep form, 0 <= K <= 8; rngs[i]:
+ *                          the i-th passed rank's copy of the stream — every rank draws the same masks, no exchange).
+ * The slots are added in rank order: results are deterministic for a given world size, and linked and distributed runs of
+ * the same world size agree bit for bit; against the un-sharded engine they differ by fp32 reassociation (logits ~1e-6
+ * relative), world = 1 not at all. */
+int dd_lm_tp_link(dd_lm* const* ranks, int world, int rows_cap);
+int dd_lm_tp_set_exchange(dd_lm* h, float* gather_dev, size_t gather_floats, int (*exchange)(void* ctx, int rows, void* stream),
+                          void* ctx);
+int dd_lm_tp_prefill(dd_lm* const* ranks, int n, const float* embeds_dev, int T0, int span_start, int span_len, void* stream);
+int dd_lm_tp_decode_step(dd_lm* const* ranks, int n, const double* mprobs_host, int K, dd_rng* const* rngs, void* stream);
 
 #ifdef __cplusplus
 }

@@ -167,3 +167,35 @@ def test_bench_gpus_n_starts_its_own_ranks_before_any_gpu_call(monkeypatch):
     i = cmd.index(os.path.join(root, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_tensor_parallel_shards_reassemble_the_layer():
+    """lm.tp_local_config / tp_shard_state_dict: head-aligned slices, d_ff padded to a multiple of 256 with zero rows / columns —
+    the ranks' partial MLP and attention-output products add up to the un-sharded layer's."""
+    import torch.nn.functional as F
+    from dropoutdecoding_amd import lm
+    cfg = lm.LMConfig(64, 512, 1280, 1, 4, 2, 128, 1e-5, 10000.0)
+    g = torch.Generator().manual_seed(0)
+    sd = {"model.embed_tokens.weight": torch.randn(64, 512, generator=g), "model.norm.weight": torch.ones(512), "lm_head.weight": torch.randn(64, 512, generator=g)}
+    p = "model.layers.0."
+    sd[p + "input_layernorm.weight"] = sd[p + "post_attention_layernorm.weight"] = torch.ones(512)
+    sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.o_proj.weight"] = torch.randn(512, 512, generator=g), torch.randn(512, 512, generator=g)
+    sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = torch.randn(256, 512, generator=g), torch.randn(256, 512, generator=g)
+    sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = torch.randn(1280, 512, generator=g), torch.randn(1280, 512, generator=g)
+    sd[p + "mlp.down_proj.weight"] = torch.randn(512, 1280, generator=g)
+    local = lm.tp_local_config(cfg, 2)
+    assert (local.num_heads, local.num_kv_heads, local.intermediate_size) == (2, 1, 768)      # 640 columns padded to 768
+    x = torch.randn(5, 512, generator=g)
+    full = F.linear(F.silu(F.linear(x, sd[p + "mlp.gate_proj.weight"])) * F.linear(x, sd[p + "mlp.up_proj.weight"]), sd[p + "mlp.down_proj.weight"])
+    o_full = F.linear(x, sd[p + "self_attn.o_proj.weight"])
+    part, o_part = 0, 0
+    for r in range(2):
+        sh = lm.tp_shard_state_dict(sd, cfg, r, 2)
+        assert sh[p + "mlp.gate_proj.weight"].shape == (768, 512) and sh[p + "mlp.down_proj.weight"].shape == (512, 768)
+        assert sh[p + "self_attn.q_proj.weight"].shape == (256, 512) and sh[p + "self_attn.k_proj.weight"].shape == (128, 512)
+        assert sh["lm_head.weight"] is sd["lm_head.weight"]
+        part = part + F.linear(F.silu(F.linear(x, sh[p + "mlp.gate_proj.weight"])) * F.linear(x, sh[p + "mlp.up_proj.weight"]), sh[p + "mlp.down_proj.weight"])
+        o_part = o_part + F.linear(x[:, 256 * r:256 * (r + 1)], sh[p + "self_attn.o_proj.weight"])
+    assert torch.allclose(part, full, rtol=1e-4, atol=1e-3) and torch.allclose(o_part, o_full, rtol=1e-4, atol=1e-3)
+    with pytest.raises(ValueError):
+        lm.tp_local_config(cfg, 4)                        # 2 kv heads do not split over 4 ranks

@@ -7,11 +7,19 @@ import torch
 from dropoutdecoding_amd import lm
 
 torch.cuda.set_device(0)
+from dropoutdecoding_amd import _lib
+row_sets = (8, 16, 32, 64)
+for kv in sys.argv[1:]:                      # key=value: dd_tools_set_tuning; rows=64: only that pass width
+    k_, v_ = kv.split("=")
+    if k_ == "rows":
+        row_sets = (int(v_),)
+    else:
+        _lib.load().dd_tools_set_tuning(int(k_), int(v_))
 e = lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format="fp16")
 e.load_synthetic(0, 0.02)
 e.prefill(torch.randn(608, 4096, generator=torch.Generator().manual_seed(0)).cuda(), 5, 576)
 names = {0: "qkv", 1: "o_proj", 2: "gate/up", 3: "down"}
-for rows in (8, 16, 32, 64):
+for rows in row_sets:
     out = []
     for which in range(4):
         ms, by = e.time_gemv(which, rows, 96)
