@@ -1484,7 +1484,9 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   int n_multi = 0;
   for (int m = 0; m < n; m += width(m)) n_multi += width(m) > 1 ? 1 : 0;
   const int nbr = g_branches < n_multi ? g_branches : n_multi;       // branches in use: the caller's stream + nbr - 1 side streams
-  const bool fork = nbr >= 2 && h0->side[nbr - 2] != nullptr;
+  // (fp16-cache engines only: with the fp32 cache's VALU attention kernels running beside another sweep, lanes did not always
+  // reproduce their solo runs bit for bit — cause not found; tools/lanes_mixed_ab.py shows it — so those keep one branch)
+  const bool fork = nbr >= 2 && h0->kv16 && h0->side[nbr - 2] != nullptr;
   if (fork) {
     DD_HIP(hipEventRecord(h0->ev_fork, st));
     for (int i = 0; i + 1 < nbr; ++i) DD_HIP(hipStreamWaitEvent(h0->side[i], h0->ev_fork, 0));

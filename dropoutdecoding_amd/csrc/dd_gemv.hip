@@ -276,8 +276,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
           int ht = is_q ? nt : nt - a.q_tiles;
           int head = ht >> 3, f = (ht & 7) * 8 + (n & 7);
           float c = pre0, sn = pre1;
-          // q*cos + rotate_half(q)*sin, two rounded products then one add (HF apply_rotary_pos_emb)
-          float o = (n < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
+          float o = dd_rope_mix(y, yp, c, sn, n < 8);     // q*cos + rotate_half(q)*sin (HF apply_rotary_pos_emb)
           int i = (n < 8) ? f : ROPE_HALF + f;
           if (is_q) a.qbuf[(size_t)m * a.q_dim + head * HEAD_DIM + i] = o;
           else a.knew[(size_t)m * a.kv_dim + head * HEAD_DIM + i] = o;
@@ -480,7 +479,7 @@ __device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const
           int ht = is_q ? nt : nt - a.q_tiles;
           int head = ht >> 3, f = (ht & 7) * 8 + (en & 7);
           float c = p.rope_c[tt], sn = p.rope_s[tt];
-          float o = (en < 8) ? __fadd_rn(__fmul_rn(y, c), __fmul_rn(-yp, sn)) : __fadd_rn(__fmul_rn(y, c), __fmul_rn(yp, sn));
+          float o = dd_rope_mix(y, yp, c, sn, en < 8);
           int i = (en < 8) ? f : ROPE_HALF + f;
           if (is_q) a.qbuf[(size_t)em * a.q_dim + head * HEAD_DIM + i] = o;
           else kn[head * HEAD_DIM + i] = o;
@@ -665,6 +664,170 @@ __global__ __launch_bounds__(128 * NG) void k_gemv_finish(GemvArgs a, const floa
   groups_epilogue<EPI, TILES, NG>(a, wg, pre, rstd_sh, ssq_sh, tile_sum);
 }
 
+// The same finishing step with FOUR output columns per thread: one 16-byte load per partial-sum slab instead of four 4-byte
+// ones (the slabs' element order — dd_part_index — keeps columns n & 3 adjacent), 16-byte residual / logits accesses, 8-byte
+// operand stores, the rotary partner column (n ^ 8) by one wave shuffle.  32 * NG threads per tile set: thread = (plane eg,
+// column quad c4 = columns 4 c4 .. 4 c4 + 3, row ml).  Every output is computed by the same operations in the same order as in
+// k_gemv_finish (and so as in k_gemv / k_gemv_groups): the bits do not change.
+__device__ __forceinline__ void xop_store16x4(u32x4_t* xop, int k0, int m, const float (&y)[4], int S, int wf) {
+  uint32_t hi[4], lo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dd_split(y[i], hi[i], lo[i], wf);
+  uint16_t* p = (uint16_t*)(xop + (size_t)(m >> 3) * S * 64);
+  const int ks = k0 >> 5, h = (k0 >> 3) & 3, j = k0 & 7, ml = m & 7;      // k0 is a multiple of 4: the four k share (ks, h)
+  const size_t base = ((size_t)ks * 64 + h * 16) * 8 + j;
+  *(u32x2_t*)&p[base + (size_t)ml * 8] = (u32x2_t){hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
+  *(u32x2_t*)&p[base + (size_t)(ml + 8) * 8] = (u32x2_t){lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16)};
+}
+
+template <int EPI, int TILES, int NG, int NP>
+__global__ __launch_bounds__(32 * NG) void k_gemv_finish4(GemvArgs a, const float* __restrict__ part, const float* __restrict__ rstd_g,
+                                                          int n_sets) {
+  __shared__ float ssq_sh[EPI == EPI_RESID ? 16 * 8 * NG : 1];
+  __shared__ f32x4_t yq_sh[EPI == EPI_QKV ? TILES * 32 * NG : 1];   // rotary tiles: a thread needs its partner quad's sums (columns n ^ 8)
+  const int wg = blockIdx.x, tile0 = wg * TILES;
+  const int t = threadIdx.x, eg = t >> 5, c4 = (t & 31) >> 3, ml = t & 7, em = (eg << 3) + ml, n0 = c4 * 4;
+  const bool erow = ml < a.nb;
+  const size_t ps = ((size_t)n_sets * TILES * NG) << 7;
+  // one batch of requests: the thread's partial sums, rstd, the epilogue's operands
+  f32x4_t v[TILES][NP];
+#pragma unroll
+  for (int tt = 0; tt < TILES; ++tt) {
+    const float* p0 = part + (((size_t)(tile0 + tt) * NG + eg) << 7) + ((c4 * 8 + ml) << 2);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) v[tt][q] = *(const f32x4_t*)(p0 + (size_t)q * ps);
+  }
+  const float rstd = a.ssq_in ? rstd_g[em] : 1.0f;
+  f32x4_t pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, rc[TILES], rs[TILES];
+  bool done = false;
+  if (erow) {
+    if (EPI == EPI_RESID) {
+      pre0 = *(const f32x4_t*)&a.out[(size_t)em * a.ldo + tile0 * 16 + n0];
+      pre1 = *(const f32x4_t*)&a.normw_next[tile0 * 16 + n0];
+    } else if (EPI == EPI_QKV) {
+      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+      const int pos = sp->pos;
+#pragma unroll
+      for (int tt = 0; tt < TILES; ++tt) {
+        const int nt = tile0 + tt;
+        rc[tt] = rs[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (nt < a.q_tiles + a.k_tiles) {
+          const int ht = nt < a.q_tiles ? nt : nt - a.q_tiles;
+          const int f = (ht & 7) * 8 + (n0 & 7);
+          rc[tt] = *(const f32x4_t*)&a.rope_cos[(size_t)pos * ROPE_HALF + f];
+          rs[tt] = *(const f32x4_t*)&a.rope_sin[(size_t)pos * ROPE_HALF + f];
+        }
+      }
+    } else if (EPI == EPI_STORE) {
+      const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
+      done = sp && sp->done;               // finished sequence: its logits stay as the EOS step left them
+    }
+  }
+  float y[TILES][4];
+#pragma unroll
+  for (int tt = 0; tt < TILES; ++tt) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (NP == 8) {
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) acc = acc + (v[tt][q] + v[tt][q + 1]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) acc = acc + v[tt][q];
+    }
+    y[tt][0] = acc.x, y[tt][1] = acc.y, y[tt][2] = acc.z, y[tt][3] = acc.w;
+  }
+  if (EPI == EPI_STORE) {
+    if (erow && !done) {
+      float* row = a.out_g[eg] ? a.out_g[eg] + (size_t)ml * a.ldo : a.out + (size_t)em * a.ldo;
+      const int col = tile0 * 16 + n0;
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = a.ssq_in ? y[0][i] * rstd : y[0][i];
+      if (col + 3 < a.n_valid && (a.ldo & 3) == 0) *(f32x4_t*)&row[col] = (f32x4_t){o[0], o[1], o[2], o[3]};
+      else
+        for (int i = 0; i < 4; ++i)
+          if (col + i < a.n_valid) row[col + i] = o[i];
+    }
+  } else if (EPI == EPI_RESID) {
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (erow) {
+      const int col = tile0 * 16 + n0;
+      float xn[4], z[4];
+      const float p0[4] = {pre0.x, pre0.y, pre0.z, pre0.w}, p1[4] = {pre1.x, pre1.y, pre1.z, pre1.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xn[i] = p0[i] + y[0][i];
+        z[i] = p1[i] * xn[i];
+        sq[i] = xn[i] * xn[i];
+      }
+      *(f32x4_t*)&a.out[(size_t)em * a.ldo + col] = (f32x4_t){xn[0], xn[1], xn[2], xn[3]};
+      xop_store16x4(a.xop_next, col, em, z, a.S_next, a.wf);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ssq_sh[(n0 + i) * (8 * NG) + em] = sq[i];
+    __syncthreads();
+    if (t < 8 * NG) {
+      float s = 0.f;
+      for (int i = 0; i < 16; ++i) s += ssq_sh[i * (8 * NG) + t];
+      a.ssq_out[(size_t)t * a.ssq_ld + wg] = s;
+    }
+  } else if (EPI == EPI_SILU) {
+    if (erow) {
+      float z[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float g = y[0][i], u = y[TILES - 1][i];
+        if (a.ssq_in) {
+          g *= rstd;
+          u *= rstd;
+        }
+        const float act = g / (1.0f + expf(-g));  // silu
+        z[i] = act * u;
+      }
+      xop_store16x4(a.xop_next, wg * 16 + n0, em, z, a.S_next, a.wf);
+    }
+  } else {  // EPI_QKV
+    float* kn = a.knew_g[eg] ? a.knew_g[eg] + (size_t)ml * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
+    float* vn = a.vnew_g[eg] ? a.vnew_g[eg] + (size_t)ml * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) yq_sh[tt * 32 * NG + t] = (f32x4_t){y[tt][0], y[tt][1], y[tt][2], y[tt][3]};
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) {
+      const int nt = tile0 + tt;
+      float yy[4], yp[4];
+      const f32x4_t pq = yq_sh[tt * 32 * NG + (t ^ 16)];   // columns n ^ 8 of the same (plane, row): the thread whose quad is c4 ^ 2
+      const float pr[4] = {pq.x, pq.y, pq.z, pq.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        yy[i] = y[tt][i];
+        yp[i] = pr[i];
+        if (a.ssq_in) {
+          yy[i] *= rstd;
+          yp[i] *= rstd;
+        }
+      }
+      if (!erow) continue;
+      if (nt < a.q_tiles + a.k_tiles) {
+        const bool is_q = nt < a.q_tiles;
+        const int ht = is_q ? nt : nt - a.q_tiles;
+        const int head = ht >> 3, f = (ht & 7) * 8 + (n0 & 7);
+        const float c[4] = {rc[tt].x, rc[tt].y, rc[tt].z, rc[tt].w}, sn[4] = {rs[tt].x, rs[tt].y, rs[tt].z, rs[tt].w};
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          o[i] = dd_rope_mix(yy[i], yp[i], c[i], sn[i], n0 < 8);
+        const int i0 = (n0 < 8) ? f : ROPE_HALF + f;
+        float* dst = is_q ? a.qbuf + (size_t)em * a.q_dim + head * HEAD_DIM + i0 : kn + head * HEAD_DIM + i0;
+        *(f32x4_t*)dst = (f32x4_t){o[0], o[1], o[2], o[3]};
+      } else {
+        const int col = (nt - a.q_tiles - a.k_tiles) * 16 + n0;
+        *(f32x4_t*)&vn[col] = (f32x4_t){yy[0], yy[1], yy[2], yy[3]};
+      }
+    }
+  }
+}
+
 template <int EPI, int TILES, int NG, int FP8>
 static int launch_gemv_groups_f(const GemvArgs& a, hipStream_t st) {
   size_t smem = (size_t)(TILES * NG * GEMV_WAVES * 256 + 8 * NG + 16 * 8 * NG) * sizeof(float);
@@ -729,10 +892,12 @@ static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
   return DD_OK;
 }
 
+int g_finish4 = 15;   // dd_tools_set_tuning key 24: the four-columns-per-thread finishing kernel per epilogue (bit = EPI_*; 0: k_gemv_finish, same bits)
 template <int EPI, int TILES, int NG, int NP>
 static void launch_finish(const GemvArgs& a, int n_sets, hipStream_t st) {
   if (g_slices_only) return;
-  k_gemv_finish<EPI, TILES, NG, NP><<<n_sets, 128 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
+  if (g_finish4 & (1 << EPI)) k_gemv_finish4<EPI, TILES, NG, NP><<<n_sets, 32 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
+  else k_gemv_finish<EPI, TILES, NG, NP><<<n_sets, 128 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
 }
 template <int NG>
 static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {

@@ -42,3 +42,14 @@ __device__ __forceinline__ void xop_store(u32x4_t* xop, int k, int m, float y, i
 __device__ __forceinline__ void xop_store16(u32x4_t* xop, int k, int m, float y, int S, int wf = 0) {
   xop_store(xop + (size_t)(m >> 3) * S * 64, k, m & 7, y, wf);   // plane = group of the row
 }
+
+// Rotary mix of one element: q * cos -/+ q_partner * sin (HF apply_rotary_pos_emb with rotate_half: the first half of a head
+// takes -partner, the second +partner), in ONE fixed form for every kernel that applies it: the partner product rounded on its
+// own, then a fused multiply-add — fma(y, c, -/+ round(yp * sn)).  hipcc's default -ffp-contract=fast would otherwise pick a
+// contraction per call site (it did: a four-wide epilogue got a different one for its fourth element), and a row's bits must
+// not depend on which kernel roped it.
+__device__ __forceinline__ float dd_rope_mix(float y, float yp, float c, float sn, bool first_half) {
+  float p = yp * sn;
+  asm volatile("" : "+v"(p));
+  return __builtin_fmaf(y, c, first_half ? -p : p);
+}

@@ -91,15 +91,15 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // GEMV, 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4, 8), 10 = workgroups per group of 8 members in the grouped
 // decode attention, 12 = prefill attention on the matrix cores, 17 / 18 / 19 = workgroups per K slice of the 64-row qkv / o_proj /
 // gate-up GEMV (18 < 0: eight-plane o_proj kernel; 19 < 0: single K slices for gate/up), 21 = key tiles per workgroup of the
-// fp16-cache decode attention, 22 = all-tiles form of that attention, 23 = concurrent member sweeps of a group step; the product
+// fp16-cache decode attention, 22 = all-tiles form of that attention, 23 = concurrent member sweeps of a group step, 24 = four-columns-per-thread finishing kernel of the slice GEMVs; the product
 // switches (8, 11, 13-16) are forwarded to dd_set_tuning.
 extern int g_exp_G[4];
-extern int g_attn16_tpw, g_attn16_full;
+extern int g_attn16_tpw, g_attn16_full, g_finish4;
 void dd_engine_set_pairs(int on);
 void dd_engine_set_branches(int n);
 extern "C" int dd_tools_set_tuning(int key, int value) {
   if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 23),
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24),
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -108,6 +108,7 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 21) g_attn16_tpw = value;
   else if (key == 22) g_attn16_full = value;
   else if (key == 23) dd_engine_set_branches(value);
+  else if (key == 24) g_finish4 = value;
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }

@@ -636,16 +636,18 @@ def test_group_generate_with_uneven_stops_and_stock_greedy(E):
         e.close()
 
 
-def test_full_size_lanes_equal_solo_runs_bitwise(E):
+@pytest.mark.parametrize("kv_format", ["fp32", "fp16"])
+def test_full_size_lanes_equal_solo_runs_bitwise(E, kv_format):
     """BASELINE size (LLaVA-1.5-7B shapes, K = 8): 11 lanes decoded as a group (fused base pass in two operand planes, one
     8-sequence = 64-row member sweep through the slice-pair kernels, one 2-sequence sweep and one single: every row width at
-    full depth) == each lane alone, bit for bit — logits, masks, tokens, KV checksums."""
+    full depth) == each lane alone, bit for bit — logits, masks, tokens, KV checksums.  With the fp16 cache the 64-row and the
+    16-row sweep run concurrently on two streams (dd_engine.hip group_step_eager), with the fp32 cache one after the other."""
     probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
     shapes = [(608, 5, 576), (640, 9, 576), (600, 1, 576), (615, 20, 576), (609, 5, 576), (700, 60, 576),   # tiles 10 / 11
               (610, 3, 576), (633, 7, 576), (655, 11, 576), (602, 2, 576), (690, 33, 576)]
     engs = []
     for i in range(len(shapes)):
-        engs.append(E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=768, max_visual=576, seed=5217,
+        engs.append(E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=768, max_visual=576, seed=5217, kv_format=kv_format,
                                     share_weights_with=engs[0] if engs else None))
     engs[0].load_synthetic(1, 0.02)
     embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(50 + i)).cuda() for i, (T0, _, _) in enumerate(shapes)]
