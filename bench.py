@@ -494,7 +494,7 @@ def main() -> int:
 
     rows8 = min(max(K_eff, 1), 8)
     wide = B > 1 and 1 <= K_eff <= 8
-    dom_rows = (64 if B >= 8 and wname != "fp8" else (32 if B >= 4 else 16)) if wide else rows8
+    dom_rows = (64 if B >= 8 else (32 if B >= 4 else 16)) if wide else rows8
     roof = None
     if rank == 0 and not args.no_roofline:
         try:

@@ -200,7 +200,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
     // (eight planes for a 64-row pass: single slices for every matrix)
     size_t nfl = 8 * t8 * 8 * 128, gu = (size_t)8 * (2 * dff / 16) * 8 * 128, lmh = (size_t)8 * (h->Vpad / 16) * 8 * 128;
     if (lmh > gu) gu = lmh;                                   // lm_head: 66 MB at V = 32064
-    h->gemv_part_floats = h->fp8 ? 0 : (nfl > gu ? nfl : gu);
+    h->gemv_part_floats = nfl > gu ? nfl : gu;
     if (h->gemv_part_floats) DA(h->gemv_part, h->gemv_part_floats + 64);   // + rstd of the up to 64 operand rows
   }
   DA(h->xop_d, (size_t)h->S_d * 64 * 8);     // eight operand planes (8 rows each)
@@ -1475,7 +1475,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   const bool multi = g_pair_sweeps && K > 0 && K <= 8;
   auto width = [&](int m) -> int {     // sequences of the member sweep that starts at lane m
     const int left = n - m;
-    return !multi ? 1 : (left >= 8 && g_pair_sweeps >= 8 && !h0->fp8 ? 8 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1)));
+    return !multi ? 1 : (left >= 8 && g_pair_sweeps >= 8 ? 8 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1)));
   };
   // The member sweeps of a group step are independent of each other, and each is a chain of dependent launches in which every
   // matrix ends in a finishing / combine kernel that streams nothing (a fifth of a 64-row sweep).  Dealt over two (up to four)

@@ -735,6 +735,10 @@ __global__ __launch_bounds__(32 * NG) void k_gemv_finish4(GemvArgs a, const floa
       for (int q = 0; q < NP; ++q) acc = acc + v[tt][q];
     }
     y[tt][0] = acc.x, y[tt][1] = acc.y, y[tt][2] = acc.z, y[tt][3] = acc.w;
+    if (a.fp8 && EPI != EPI_RESID) {         // fp8 tiles: the output rows' scales, after the sum as in k_gemv
+      const f32x4_t sc = *(const f32x4_t*)&a.wscale[(size_t)(tile0 + tt) * 16 + n0];
+      y[tt][0] *= sc.x, y[tt][1] *= sc.y, y[tt][2] *= sc.z, y[tt][3] *= sc.w;
+    }
   }
   if (EPI == EPI_STORE) {
     if (erow && !done) {
@@ -754,9 +758,14 @@ __global__ __launch_bounds__(32 * NG) void k_gemv_finish4(GemvArgs a, const floa
       const int col = tile0 * 16 + n0;
       float xn[4], z[4];
       const float p0[4] = {pre0.x, pre0.y, pre0.z, pre0.w}, p1[4] = {pre1.x, pre1.y, pre1.z, pre1.w};
+      // fp8 tiles: x + scale * sum as ONE fused multiply-add — the form the 8-row kernel's epilogue compiles to (its scale multiply
+      // and residual add contract), which the rows of every pass width must reproduce
+      f32x4_t sc4 = {1.f, 1.f, 1.f, 1.f};
+      if (a.fp8) sc4 = *(const f32x4_t*)&a.wscale[(size_t)tile0 * 16 + n0];
+      const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xn[i] = p0[i] + y[0][i];
+        xn[i] = a.fp8 ? __builtin_fmaf(y[0][i], sc[i], p0[i]) : p0[i] + y[0][i];
         z[i] = p1[i] * xn[i];
         sq[i] = xn[i] * xn[i];
       }
@@ -896,11 +905,60 @@ int g_finish4 = 15;   // dd_tools_set_tuning key 24: the four-columns-per-thread
 template <int EPI, int TILES, int NG, int NP>
 static void launch_finish(const GemvArgs& a, int n_sets, hipStream_t st) {
   if (g_slices_only) return;
-  if (g_finish4 & (1 << EPI)) k_gemv_finish4<EPI, TILES, NG, NP><<<n_sets, 32 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
+  if ((g_finish4 & (1 << EPI)) || a.fp8) k_gemv_finish4<EPI, TILES, NG, NP><<<n_sets, 32 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
   else k_gemv_finish<EPI, TILES, NG, NP><<<n_sets, 128 * NG, 0, st>>>(a, a.part, a.part + a.part_floats, n_sets);
 }
+template <int NG, int SPW2, int CH, int UW>
+static int launch_slices_fp8(const SliceArgs& sa, hipStream_t st) {
+  constexpr size_t smem = (size_t)CH * 2 * SPW2 * NG * 1024;
+  static bool attr = false;
+  if (!attr) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_fp8<NG, SPW2, CH, UW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  NOTE_KERNEL("k_gemv_slices_fp8<%d, %d, %d, %d, 0>", NG, SPW2, CH, UW);
+  k_gemv_slices_fp8<NG, SPW2, CH, UW><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  return DD_OK;
+}
+template <int EPI, int TILES, int NG>
+static void finish_fp8(const GemvArgs& a, int n_sets, int ch, hipStream_t st) {
+  if (ch == 2) launch_finish<EPI, TILES, NG, 4>(a, n_sets, st);
+  else launch_finish<EPI, TILES, NG, 8>(a, n_sets, st);
+}
+// fp8 tiles (weight_format 1): K = 4096 (8 steps of 64 k per slice: slice pairs up to four planes, single slices at eight) and,
+// for two planes, K = 14336 (28 steps); other shapes stay on the wave-split kernels — the same bits either way
+template <int NG>
+static int try_slices_fp8(int epi, const GemvArgs& a, hipStream_t st) {
+  const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;
+  const int spw2 = a.S / 16;
+  if (a.S % 16 || nt < 64 || !(spw2 == 8 || (spw2 == 28 && NG == 2))) return SLICES_UNSUPPORTED;
+  const int ch = (spw2 == 8 && NG <= 4) ? 2 : 1;
+  if (a.part_floats < (size_t)(8 / ch) * nt * NG * 128) return SLICES_UNSUPPORTED;
+  SliceArgs sa;
+  sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1, sa.n_groups = nt;
+  sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
+  sa.rstd_out = a.part + a.part_floats;
+  const int per_set = 256 / (8 / ch);                  // one round of workgroups (one per CU at 64-128 KiB of operands)
+  sa.G = (nt + 7) / 8 < per_set ? (nt + 7) / 8 : per_set;
+  if (spw2 == 28) {
+    if constexpr (NG == 2) RC_(launch_slices_fp8<2, 28, 1, 7>(sa, st));
+  } else if constexpr (NG <= 4) {
+    RC_(launch_slices_fp8<NG, 8, 2, 8>(sa, st));
+  } else {
+    RC_(launch_slices_fp8<NG, 8, 1, 8>(sa, st));
+  }
+  switch (epi) {
+    case EPI_STORE: finish_fp8<EPI_STORE, 1, NG>(a, nt, ch, st); break;
+    case EPI_RESID: finish_fp8<EPI_RESID, 1, NG>(a, nt, ch, st); break;
+    case EPI_SILU: finish_fp8<EPI_SILU, 2, NG>(a, a.n_tiles, ch, st); break;
+    default: finish_fp8<EPI_QKV, 1, NG>(a, nt, ch, st); break;
+  }
+  return DD_OK;
+}
+
 template <int NG>
 static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
+  if (a.fp8) return try_slices_fp8<NG>(epi, a, st);
   const int spw = a.S / GEMV_WAVES;
   const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;      // 16-row weight tiles
   if (!(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
@@ -1012,7 +1070,7 @@ int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv_groups: nb=%d rows per group", a.nb);
   DD_REQUIRE(!a.fp8 || a.wscale, "gemv_groups: fp8 weights need row scales");
   DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4 || a.n_groups == 8, "gemv_groups: %d groups (2, 4 or 8)", a.n_groups);
-  if (g_gemv_slices && !a.fp8 && a.part) {
+  if (g_gemv_slices && a.part) {
     int rs = a.n_groups == 2 ? try_slices<2>(epi, a, st) : (a.n_groups == 4 ? try_slices<4>(epi, a, st) : try_slices<8>(epi, a, st));
     if (rs != SLICES_UNSUPPORTED) {
       if (rs != DD_OK) return rs;

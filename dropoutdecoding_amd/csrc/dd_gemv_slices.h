@@ -22,6 +22,7 @@
 // tile group (its accumulators live across the chunks).
 #pragma once
 #include "dd_common.h"
+#include "dd_lm_device.h"
 
 struct SliceArgs {
   const u32x4_t* W;     // packed weight tiles [n_tiles][S][64]
@@ -392,5 +393,114 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
       stage(1);
       __syncthreads();
     }
+  }
+}
+
+// The slice-resident GEMV for FP8 weight tiles (weight_format 1: OCP e4m3fn + per-row scales, BASELINE config 5).  One 1 KiB
+// weight load = 16 rows x 64 k = TWO bf16 k-steps after an exact in-register expansion (fp8x16_to_bf16), which is done once per
+// load and feeds all NG operand planes — the conversion VALU that bounds the 8-row fp8 kernel is amortised over the planes.
+// K is cut as the 8-row fp8 kernel cuts it: slice q = 64-k steps q, q + 8, ... (its wave q), each step = bf16 k-steps 2 s and
+// 2 s + 1 in that order, so every accumulator chain — and with the pairwise slice order the final sum — is the 8-row kernel's,
+// bit for bit; the row scale is applied by the finishing kernel after the sum, as there.
+// SPW2 = 64-k steps per slice (K / 512); CH = slices per workgroup (2: the pair is added here, half the partial sums);
+// UW = weight loads in flight per wave (a divisor of SPW2).  A wave owns whole tiles g = j + G (wave + 8 i) over its slice(s).
+// grid = (8 / CH) * G workgroups of 512 threads; dynamic LDS = CH * 2 * SPW2 * NG KiB.
+template <int NG, int SPW2, int CH, int UW, int EPI_TAG = 0>
+__global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
+  static_assert(SPW2 % UW == 0, "loads in flight must divide the slice");
+  constexpr int NB = SPW2 / UW;                        // weight blocks per (tile, slice)
+  constexpr int PIECES = CH * 2 * SPW2 * NG;           // operand pieces (1 KiB) of the workgroup
+  constexpr int PW = (PIECES + 7) / 8;
+  extern __shared__ __align__(16) u32x4_t xs[];        // [CH][2 * SPW2][NG][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NQ = 8 / CH;
+  const int qs = blockIdx.x % NQ, j = blockIdx.x / NQ, q = qs * CH;
+  const int S2 = a.S >> 1;
+  const size_t xplane = (size_t)a.S * 64;
+  const int n_tiles = a.n_groups;
+  if (a.ssq_in && blockIdx.x == 0) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+  int g = j + a.G * wave;
+  const bool any = g < n_tiles;
+  // block b (0 .. CH * NB - 1) of tile g: slice q + b / NB, 64-k steps (b % NB) * UW ...; consecutive steps of a slice are 8 apart
+  auto wptr = [&](int tile, int b) -> const u32x4_t* {
+    return a.W + ((size_t)tile * S2 + q + b / NB + (size_t)8 * (b % NB) * UW) * 64 + lane;
+  };
+  u32x4_t wc[UW], wn[UW];
+  if (any) {
+    const u32x4_t* p = wptr(g, 0);
+#pragma unroll
+    for (int u = 0; u < UW; ++u) wc[u] = __builtin_nontemporal_load(p + (size_t)u * 8 * 64);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    u32x4_t xv[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int p = wave + 8 * i, pc = p < PIECES ? p : 0;
+      const int ch = pc / (2 * SPW2 * NG), r = pc % (2 * SPW2 * NG), t = r / NG, h = r % NG;
+      xv[i] = a.xop[(size_t)(2 * (q + ch + 8 * (t >> 1)) + (t & 1)) * 64 + h * xplane + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int p = wave + 8 * i;
+      if (p < PIECES) xs[(size_t)p * 64 + lane] = xv[i];
+    }
+  }
+  __syncthreads();
+  if (!any) return;
+  auto fold = [&](f32x4_t v) -> f32x4_t {              // hi + lo column of a row (lanes c < 8 of 16)
+    v.x += __shfl_down(v.x, 8);
+    v.y += __shfl_down(v.y, 8);
+    v.z += __shfl_down(v.z, 8);
+    v.w += __shfl_down(v.w, 8);
+    return v;
+  };
+  while (true) {
+    const int gn = g + a.G * 8;
+    const bool has_next = gn < n_tiles;
+    f32x4_t acc[NG], sum[NG];
+#pragma unroll
+    for (int b = 0; b < CH * NB; ++b) {
+      // request the next block (of this tile, or the first of the wave's next tile) before consuming this one
+      if (b + 1 < CH * NB || has_next) {
+        const u32x4_t* p = b + 1 < CH * NB ? wptr(g, b + 1) : wptr(gn, 0);
+#pragma unroll
+        for (int u = 0; u < UW; ++u) wn[u] = __builtin_nontemporal_load(p + (size_t)u * 8 * 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (b % NB == 0) {
+#pragma unroll
+        for (int h = 0; h < NG; ++h) acc[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+      const int ch = b / NB, s0 = (b % NB) * UW;
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        u32x4_t k0, k1;
+        fp8x16_to_bf16(wc[u], k0, k1);
+        const u32x4_t* x0 = xs + ((size_t)(ch * 2 * SPW2 + 2 * (s0 + u)) * NG) * 64 + lane;
+#pragma unroll
+        for (int h = 0; h < NG; ++h) {
+          acc[h] = dd_mfma16<0>(k0, x0[(size_t)h * 64], acc[h]);
+          acc[h] = dd_mfma16<0>(k1, x0[(size_t)(NG + h) * 64], acc[h]);
+        }
+      }
+      if (b % NB == NB - 1) {                          // the slice's chain is complete
+#pragma unroll
+        for (int h = 0; h < NG; ++h) {
+          f32x4_t f = fold(acc[h]);
+          if (ch == 0) sum[h] = f;
+          else sum[h] = sum[h] + f;                    // (hi+lo)(2p) + (hi+lo)(2p+1)
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UW; ++u) wc[u] = wn[u];
+    }
+    if ((lane & 8) == 0) {
+      const int l32 = (lane >> 4) * 8 + (lane & 7);
+#pragma unroll
+      for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + g) * NG + h) << 7) + l32 * 4] = sum[h];
+    }
+    if (!has_next) break;
+    g = gn;
   }
 }

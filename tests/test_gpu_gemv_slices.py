@@ -17,11 +17,11 @@ def E():
     return lm
 
 
-def _group(E, cfg, n, family, L, seed=3):
+def _group(E, cfg, n, family, L, seed=3, **kw):
     engines = []
     for i in range(n):
         e = E.DropoutEngine(cfg, family=family, max_seq=L + 96, max_visual=L, seed=50 + i,
-                            share_weights_with=engines[0] if engines else None)
+                            share_weights_with=engines[0] if engines else None, **kw)
         engines.append(e)
     engines[0].load_synthetic(seed=seed, std=0.02)
     return engines
@@ -82,5 +82,44 @@ def test_slice_kernels_bit_identical_to_wave_split_kernels(E, name, dims, n_lane
         e.decode_step(probs)
         np.testing.assert_array_equal(e.logits(), ref[s][1][0])
     assert e.tokens() == rtoks[1]
+    for e in reversed(engines):
+        e.close()
+
+
+@pytest.mark.parametrize("name,dff,n_lanes", [("fp8, mistral-7b shapes, 2 lanes: 16 rows, K = 14336 through the slice kernel too", 14336, 2),
+                                              ("fp8, mistral-7b shapes, 4 lanes: 32 rows", 14336, 4),
+                                              ("fp8, mistral-7b shapes, 9 lanes: one 64-row pass + one 8-row pass", 14336, 9),
+                                              ("fp8, llama-7b shapes, 4 lanes (K = 11008 stays on the wave-split kernel)", 11008, 4)])
+def test_fp8_slice_kernels_bit_identical_to_wave_split_kernels(E, name, dff, n_lanes):
+    """BASELINE config 5's weight format on the slice-resident kernels (k_gemv_slices_fp8: the fp8 -> bf16 expansion done once per
+    weight load for all operand planes; row scales in the finishing kernel): every logit and KV row as the wave-split fp8 kernels
+    and the 8-row fp8 kernel produce them."""
+    cfg = E.LMConfig(2048, 4096, dff, 2, 32, 8 if dff == 14336 else 32, 128, 1e-5, 10000.0)
+    L = 24
+    engines = _group(E, cfg, n_lanes, "llava-next", L, weight_format="fp8", kv_format="fp16")
+    gen = torch.Generator().manual_seed(9)
+    T0s = [L + 6 + (i % 5) for i in range(n_lanes)]
+    embs = [(torch.randn(T0, 4096, generator=gen) * 0.5).cuda() for T0 in T0s]
+    spans = [(2 + (i % 3), L) for i in range(n_lanes)]
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    ref, rtoks, rsums = _run(E, engines, embs, spans, probs, 3, slices=False, graph=False)
+    got, gtoks, gsums = _run(E, engines, embs, spans, probs, 3, slices=True, graph=True)
+    assert gtoks == rtoks, name
+    for s in range(3):
+        for i in range(n_lanes):
+            np.testing.assert_array_equal(got[s][i][0], ref[s][i][0], err_msg=f"{name}: member logits, step {s} lane {i}")
+            np.testing.assert_array_equal(got[s][i][1], ref[s][i][1], err_msg=f"{name}: base logits, step {s} lane {i}")
+    for a, b in zip(gsums, rsums):
+        np.testing.assert_array_equal(a, b)
+    e = engines[1]                                         # alone: two-sweep 8-row kernels, then the speculative 16-row step
+    for mode in ("never", "always"):
+        e.set_speculation(mode)
+        e.rng.manual_seed(51)
+        e.prefill(embs[1], *spans[1])
+        for s in range(3):
+            e.decode_step(probs)
+            np.testing.assert_array_equal(e.logits(), ref[s][1][0], err_msg=f"{name}: solo ({mode}), step {s}")
+        assert e.tokens() == rtoks[1]
+    e.set_speculation("default")
     for e in reversed(engines):
         e.close()
