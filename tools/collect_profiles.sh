@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round profiles (run through gpurun from the repo root):  bash tools/collect_profiles.sh r02 [stats|pmc]
+# Round profiles (run through gpurun from the repo root):  bash tools/collect_profiles.sh r03 [stats|pmc]
+# (--no-roofline: the isolated-kernel timing leg would mix its back-to-back launches into the in-sweep averages)
 # stats: rocprofv3 kernel trace + stats of a SHORT bench run (32 lanes, 32 new tokens per image: the per-kernel durations
 #        do not depend on the number of tokens; the full default run produces millions of trace records);
 # pmc:   three separate --pmc passes (one counter each, never combined with other trace domains) over 4 tokens.
@@ -10,17 +11,17 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 if [ "$WHAT" = stats ]; then
   rm -rf /tmp/${R}_stats
-  timeout 1000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_stats -- python3 bench.py --steps 1 --warmup 0 --n-new 32 --no-cpu-baseline --single-images 1 > $OUT/${R}_bench_under_rocprof.log 2>&1
+  timeout 1000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_stats -- python3 bench.py --steps 1 --warmup 0 --n-new 32 --no-cpu-baseline --no-roofline --single-images 1 > $OUT/${R}_bench_under_rocprof.log 2>&1
   echo "rocprof rc=$?"
   f=$(find /tmp/${R}_stats -name "*kernel_stats.csv" | head -1)
-  head -50 "$f" > $OUT/${R}_kernel_stats.csv
+  head -70 "$f" > $OUT/${R}_kernel_stats.csv
   rm -rf /tmp/${R}_stats
   tail -1 $OUT/${R}_bench_under_rocprof.log | cut -c1-200
   head -32 $OUT/${R}_kernel_stats.csv | cut -c1-160
 else
   for c in FETCH_SIZE:fetch WRITE_SIZE:write SQ_VALU_MFMA_BUSY_CYCLES:mfma; do
     rm -rf /tmp/${R}_pmc_${c##*:}
-    timeout 500 rocprofv3 --pmc ${c%%:*} --kernel-trace --output-format csv -d /tmp/${R}_pmc_${c##*:} -- python3 bench.py --steps 1 --warmup 0 --n-new 3 --images-per-gpu 8 --no-cpu-baseline --single-images 0 > $OUT/${R}_pmc_${c##*:}.log 2>&1
+    timeout 500 rocprofv3 --pmc ${c%%:*} --kernel-trace --output-format csv -d /tmp/${R}_pmc_${c##*:} -- python3 bench.py --steps 1 --warmup 0 --n-new 3 --images-per-gpu 8 --no-cpu-baseline --no-roofline --single-images 0 > $OUT/${R}_pmc_${c##*:}.log 2>&1
     echo "pmc ${c%%:*} rc=$?"
   done
   python3 tools/pmc_summary.py /tmp/${R}_pmc_fetch /tmp/${R}_pmc_write /tmp/${R}_pmc_mfma > $OUT/${R}_pmc_summary.json
