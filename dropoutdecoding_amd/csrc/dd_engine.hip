@@ -1243,6 +1243,7 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
 static int g_use_graph = 1;    // dd_set_tuning key 8
 static int g_pair_sweeps = 8;  // dd_set_tuning key 9: sequences per member sweep in dd_lm_group_step (0/1: one, 2, 4, 8)
 void dd_engine_set_graph(int on) { g_use_graph = on; }
+int dd_engine_use_graph() { return g_use_graph; }
 void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
 static int g_branches = 2;     // dd_tools_set_tuning key 23: member sweeps of a group step that run concurrently (1..4)
 void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }

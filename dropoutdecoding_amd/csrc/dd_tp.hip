@@ -240,10 +240,8 @@ static int tp_sweep(dd_lm* const* R, int n, int nb, const uint8_t* const* bits, 
 
 // dd_lm_decode_step for a sharded model (1 <= K <= 8, or K = 0: stock greedy): un-masked sweep, keep set, masks, packed member
 // sweep, vote, commit — the two-sweep form, every small kernel replicated per rank.  rngs[r]: rank r's copy of the stream.
-extern "C" int dd_lm_tp_decode_step(dd_lm* const* ranks, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
+static int tp_step_body(dd_lm* const* ranks, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  RC(tp_check(ranks, n, "dd_lm_tp_decode_step"));
-  DD_REQUIRE(K >= 0 && K <= 8 && (K == 0 || mprobs), "dd_lm_tp_decode_step: K=%d (0..8)", K);
   const uint8_t* bits[8];
   float* logits[8];
   for (int r = 0; r < n; ++r) {
@@ -290,4 +288,80 @@ extern "C" int dd_lm_tp_decode_step(dd_lm* const* ranks, int n, const double* mp
     ranks[r]->steps_since_prefill++;
   }
   return DD_OK;
+}
+
+// Linked ranks issue no host callback, so their whole step (2 sweeps x world ranks: ~3,000 launches at 8 ranks and 32 layers)
+// replays from a hipGraph like dd_lm_decode_step's; a distributed rank's exchange is a host call at every seam and stays eager.
+int dd_engine_use_graph();
+unsigned long long dd_rng_serial(dd_rng* r);
+extern "C" int dd_lm_tp_decode_step(dd_lm* const* ranks, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  RC(tp_check(ranks, n, "dd_lm_tp_decode_step"));
+  DD_REQUIRE(K >= 0 && K <= 8 && (K == 0 || mprobs), "dd_lm_tp_decode_step: K=%d (0..8)", K);
+  dd_lm* h0 = ranks[0];
+  bool graphable = dd_engine_use_graph() && st != nullptr && n == h0->tp_world;
+  for (int r = 0; graphable && r < n; ++r)
+    graphable = ranks[r]->prefilled && ranks[r]->steps_since_prefill >= 1 && ranks[r]->T_host + 1 < ranks[r]->T_cap &&
+                ranks[r]->n_tok_host < MAX_NEW_TOKENS;
+  if (!graphable) return tp_step_body(ranks, n, mprobs, K, rngs, stream_);
+  unsigned long long key = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
+  mix(0x7470ull + (unsigned long long)n);
+  mix((unsigned long long)K);
+  for (int k = 0; k < K; ++k) {
+    unsigned long long b;
+    memcpy(&b, &mprobs[k], 8);
+    mix(b);
+  }
+  for (int r = 0; r < n; ++r) {
+    mix(ranks[r]->serial);
+    mix(dd_rng_serial(rngs ? rngs[r] : nullptr));
+  }
+  mix((unsigned long long)ddk_attn_grid_tiles(h0->T_host, h0->T_cap));
+  mix(((unsigned long long)h0->L << 32) | (unsigned)h0->span_start);
+  mix((unsigned long long)(uintptr_t)st);
+  auto advance = [&]() {
+    for (int r = 0; r < n; ++r) {
+      dd_lm* q = ranks[r];
+      q->last_K = K, q->T_host += 1, q->n_tok_host += 1, q->steps_since_prefill++;
+      if (q->cfg.leak_mask && K > 0) q->have_leak = true;
+    }
+  };
+  for (auto& g : h0->graphs)
+    if (g.key == key) {
+      DD_HIP(hipGraphLaunch(g.exec, st));
+      advance();
+      return DD_OK;
+    }
+  struct Saved {
+    int T, N, K, S;
+    bool leak;
+  } sv[8];
+  for (int r = 0; r < n; ++r) sv[r] = {ranks[r]->T_host, ranks[r]->n_tok_host, ranks[r]->last_K, ranks[r]->steps_since_prefill, ranks[r]->have_leak};
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return tp_step_body(ranks, n, mprobs, K, rngs, stream_);
+  }
+  int rc = tp_step_body(ranks, n, mprobs, K, rngs, stream_);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  hipGraphExec_t exec = nullptr;
+  if (rc == DD_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    if (h0->graphs.size() >= 12) {
+      (void)hipGraphExecDestroy(h0->graphs.front().exec);
+      h0->graphs.erase(h0->graphs.begin());
+    }
+    h0->graphs.push_back({key, exec});
+    DD_HIP(hipGraphLaunch(exec, st));
+    return DD_OK;          // the captured call advanced the host mirrors
+  }
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  for (int r = 0; r < n; ++r) {      // nothing was executed
+    dd_lm* q = ranks[r];
+    q->T_host = sv[r].T, q->n_tok_host = sv[r].N, q->last_K = sv[r].K, q->steps_since_prefill = sv[r].S, q->have_leak = sv[r].leak;
+  }
+  if (rc != DD_OK) return rc;
+  return tp_step_body(ranks, n, mprobs, K, rngs, stream_);
 }

@@ -233,5 +233,5 @@ def test_llava7b_matrices_over_8_linked_ranks(E):
     tp.ranks[0].torch_stream.synchronize()
     ms_tp = (time.perf_counter() - t0) / 10 * 1e3
     print(f"\n[tensor-parallel, LLaVA-1.5-7B matrices x 8 layers, K=8, T~620] un-sharded two-sweep step {ms_full:.2f} ms; 8 linked ranks run back to back "
-          f"on one GPU {ms_tp:.2f} ms = {ms_tp / 8:.2f} ms per rank (eager launches, no exchange cost); logits vs un-sharded {worst:.1e}")
+          f"on one GPU {ms_tp:.2f} ms = {ms_tp / 8:.2f} ms per rank (one hipGraph per step, no exchange cost); logits vs un-sharded {worst:.1e}")
     tp.close()
