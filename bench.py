@@ -256,6 +256,9 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
             "traffic_frac": (round(prof["traffic"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if prof["traffic"] else None),
             "gate_up_streaming_kernel_by_rows": rows_cmp, "bytes_per_launch": by, "ms_per_launch": round(ms, 5),
             "kernel_stats_avg_us": prof["stats_avg_us"], "kernel_stats_file": prof["stats_file"],
+            # the same kernel inside the running step (committed kernel trace): there it shares the chip with the other branch's kernels of
+            # the two-branch group step, so its duration is above the solo launch timed here — the fraction by that duration:
+            "frac_in_step": (round(by / (prof["stats_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if prof["stats_avg_us"] else None),
             "gemv_incl_finish": {"ms": round(ms_pair, 5), "GBs": round(by / (ms_pair * 1e-3) / 1e9, 1), "frac": round(by / (ms_pair * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "other_gemv_GBs": kinds,
             "packed_sweep_8_rows": {"ms": round(sweep_ms, 4), "algorithmic_bytes": sweep_bytes, "GBs": round(sweep_bytes / (sweep_ms * 1e-3) / 1e9, 1)}}

@@ -1539,13 +1539,16 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
 static int g_speculate = 2;   // dd_set_tuning key 14: process default of the policy — 0 never, 1 always, 2 adaptive
 void dd_engine_set_speculate(int mode) { g_speculate = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 static int spec_mode_of(const dd_lm* h) { return h->spec_mode >= 0 ? h->spec_mode : g_speculate; }
-// Break-even of the speculative step (LLaVA-1.5-7B shapes, K = 8): it costs one 16-row sweep when the masks stand and that
-// sweep plus the 8-row re-run when they do not, against a 1-row and an 8-row sweep for the plain step: 4.0 + (1 - h) * 3.1 ms
-// against 6.1 ms, equal at h = 0.33.  On a checkpoint whose keep sets (models/llava.py:443-482) are rarely empty the share
-// that holds falls below that and the plain step is the faster one.
-#define SPEC_BREAK_EVEN 0.35f
+// Break-even of the speculative step (LLaVA-1.5-7B shapes, K = 8, measured: tests/test_gpu_full_size_configs.py): it costs one
+// 16-row sweep when the masks stand (4.0 ms) and that sweep plus the 8-row re-run when they do not (6.85 ms), against a 1-row and
+// an 8-row sweep for the plain step (6.12 ms): 4.0 + (1 - h) * 2.85 = 6.12 at h = 0.25.  On a checkpoint whose keep sets
+// (models/llava.py:443-482) are rarely empty the share that holds falls below that and the plain step is the faster one.  The
+// running share moves by 1/16 per step: misses come in runs (they depend on the token being said), and a policy that backs off
+// after five of them costs a workload with a 2/3 hit rate 7 % (measured with 1/8 and a threshold of 0.35).
+#define SPEC_BREAK_EVEN 0.25f
+#define SPEC_RATE_WEIGHT 0.0625f
 #define SPEC_COOLDOWN_STEPS 32
-#define SPEC_PROBE_RATE 0.5f      // rate a probe phase starts from: three misses in a row end it
+#define SPEC_PROBE_RATE 0.33f     // rate a probe phase starts from: five misses in a row end it
 
 static int lm_sweep_spec(dd_lm* h, int K, hipStream_t st) {
   const int d = h->d, dff = h->dff;
@@ -1879,7 +1882,7 @@ extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_
   const int ok = note[1];
   if (held) *held = ok;
   h->spec_n[ok ? 0 : 1]++;
-  h->spec_rate = 0.875f * h->spec_rate + (ok ? 0.125f : 0.0f);
+  h->spec_rate = (1.0f - SPEC_RATE_WEIGHT) * h->spec_rate + (ok ? SPEC_RATE_WEIGHT : 0.0f);
   if (mode == 2 && h->spec_rate < SPEC_BREAK_EVEN) {
     h->spec_cooldown = SPEC_COOLDOWN_STEPS, h->spec_rate = SPEC_PROBE_RATE;
     h->spec_n[3]++;

@@ -286,7 +286,7 @@ int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs_host, int K, dd_rng* r
 /* When to speculate (see above; results never depend on it).  mode: 0 never (always the un-masked sweep, then the member
  * sweep — the reference's own order, models/llava.py:294-359), 1 always, 2 adaptive, -1 (default) the process default
  * (dd_set_tuning key 14, itself 2 by default).  Adaptive: dd_lm_decode_step_sync sees every check's verdict; while the
- * running share of speculative steps that held is below the break-even (about one in three: a failed speculation costs a
+ * running share of speculative steps that held is below the break-even (about one in four: a failed speculation costs a
  * 16-row sweep plus the 8-row re-run, more than the plain step's 1-row + 8-row sweeps) it issues plain two-sweep steps and
  * re-probes every 32 steps.  The share depends on the checkpoint: the speculation holds when the step's keep set
  * (models/llava.py:443-482) is empty or untouched by every member's drops.  dd_lm_decode_step (queued, the host never

@@ -208,9 +208,9 @@ def test_adaptive_policy_on_a_keep_set_that_is_rarely_empty(E):
     w["lm_head.weight"][64:88] *= 4.0
     cfg = E.LMConfig(RC.vocab_size, RC.hidden_size, RC.intermediate_size, RC.num_layers, RC.num_heads, RC.num_kv_heads,
                      RC.head_dim, RC.rms_eps, RC.rope_theta)
-    L, s0, steps = 40, 3, 90
+    L, s0, steps = 40, 3, 150
     probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
-    eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=192, max_visual=L, seed=7)
+    eng = E.DropoutEngine(cfg, family=FAMILY_LLAVA, max_seq=256, max_visual=L, seed=7)
     eng.load_state_dict(w)
     emb = torch.randn(L + 9, RC.hidden_size, generator=torch.Generator().manual_seed(77)) * 0.8
     ref = _run(E, eng, emb, s0, L, probs, steps, spec=0, graph=False, seed=7)
@@ -232,9 +232,9 @@ def test_adaptive_policy_on_a_keep_set_that_is_rarely_empty(E):
             np.testing.assert_array_equal(got[2], ref[2])
             np.testing.assert_array_equal(got[3], ref[3])
         assert st_always["held"] + st_always["rerun"] == steps and st_always["plain"] == 0
-        assert st_always["hit_rate"] < 0.35, st_always              # below the break-even: speculating always is the slow choice
+        assert st_always["hit_rate"] < 0.25, st_always              # below the break-even: speculating always is the slow choice
         assert all(ok == 1 for ok, k in zip(always[4], kept) if k == 0)     # an empty keep set can never fail the check
-        assert st_adapt["switched_off"] >= 1 and st_adapt["plain"] >= steps // 2, st_adapt
+        assert st_adapt["switched_off"] >= 1 and st_adapt["plain"] >= steps // 3, st_adapt
         assert st_adapt["held"] + st_adapt["rerun"] + st_adapt["plain"] == steps
         assert st_adapt["rerun"] < st_always["rerun"] // 2                  # the probes are the only re-runs left
         assert adaptive[4].count(-1) == st_adapt["plain"]
