@@ -55,8 +55,8 @@ static int tp_check(dd_lm* const* R, int n, const char* who) {
 // slots are written: linked ranks wrote them in place; a lone rank of several asks the host to all-gather them
 static int tp_seam(dd_lm* const* R, int n, int rows, hipStream_t st) {
   dd_lm* h = R[0];
-  if (n == h->tp_world) return DD_OK;
-  int rc = h->tp_exchange(h->tp_ctx, rows, (void*)st);
+  if (n == h->tp_world && !(n == 1 && h->tp_exchange)) return DD_OK;     // (a lone rank of ONE with an exchange registered calls it too:
+  int rc = h->tp_exchange(h->tp_ctx, rows, (void*)st);                    //  the world-1 run of the distributed driver exercises the collective)
   if (rc != 0) {
     dd_set_error("tensor-parallel exchange callback failed (rc=%d)", rc);
     return DD_EHIP;
@@ -299,7 +299,7 @@ extern "C" int dd_lm_tp_decode_step(dd_lm* const* ranks, int n, const double* mp
   RC(tp_check(ranks, n, "dd_lm_tp_decode_step"));
   DD_REQUIRE(K >= 0 && K <= 8 && (K == 0 || mprobs), "dd_lm_tp_decode_step: K=%d (0..8)", K);
   dd_lm* h0 = ranks[0];
-  bool graphable = dd_engine_use_graph() && st != nullptr && n == h0->tp_world;
+  bool graphable = dd_engine_use_graph() && st != nullptr && n == h0->tp_world && !h0->tp_exchange;   // a host exchange cannot be replayed
   for (int r = 0; graphable && r < n; ++r)
     graphable = ranks[r]->prefilled && ranks[r]->steps_since_prefill >= 1 && ranks[r]->T_host + 1 < ranks[r]->T_cap &&
                 ranks[r]->n_tok_host < MAX_NEW_TOKENS;

@@ -67,3 +67,54 @@ def test_kshard_decoder_over_rccl_world_1():
     assert x["backend"] == "nccl" and x["world"] == 1 and x["tokens"] >= 8 and x["ms_per_token"] > 0
     print(f"\n[K-shard over RCCL, world 1] {x['ms_per_token']:.3f} ms per token for the two all-reduces + export / import kernels "
           f"({x['bytes_per_token']} bytes per token)")
+
+
+TP_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["DD_ROOT"])
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from dropoutdecoding_amd import lm
+from dropoutdecoding_amd.dist import TensorParallelRank
+from oracle.decode_ref import FAMILY_LLAVA, RefDecoder
+from oracle.lm_ref import LMConfig as RefCfg, random_weights
+rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+w = random_weights(rc, 1234, 0.05)
+probs = [0.1, 0.3, 0.5, 0.7]
+emb = torch.randn(30, 256, generator=torch.Generator().manual_seed(5))
+want = RefDecoder(FAMILY_LLAVA, rc, w, probs, seed=5217).generate(emb, 2, 20, 9)
+tp = TensorParallelRank(lm.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0), dist.get_rank(), dist.get_world_size(), family=lm.FAMILY_LLAVA,
+                        max_seq=128, max_visual=32, seed=5217)
+tp.load_state_dict(w)
+tp.prefill(emb.cuda(), 2, 20)
+got = tp.generate(9, probs)
+logits = tp.engine.logits()
+eng = lm.DropoutEngine(lm.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0), family=lm.FAMILY_LLAVA, max_seq=128, max_visual=32, seed=5217)
+eng.load_state_dict(w)
+eng.set_speculation("never")
+eng.prefill(emb.cuda(), 2, 20)
+solo = eng.generate(9, mprobs=probs)
+same = bool((eng.logits() == logits).all())
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"want": want, "got": got, "solo": solo, "same_logits": same, "exchanges": tp.exchanges}))
+'''
+
+
+def test_tensor_parallel_rank_exchange_over_rccl_world_1():
+    """The distributed tensor-parallel driver with its RCCL exchange (in-place all_gather_into_tensor on the engine's stream, called
+    by the engine at every seam) at world 1 — the world the box offers: 2 layers x 2 seams for the prefill and for each of the two
+    sweeps of 8 steps; a world of one adds one slot, so the result is the un-sharded engine's bit for bit."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", DD_ROOT=ROOT,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", TP_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["got"] == res["want"] == res["solo"] and res["same_logits"]
+    assert res["exchanges"] == 4 * (1 + 2 * 8)
