@@ -91,7 +91,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // GEMV, 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4, 8), 10 = workgroups per group of 8 members in the grouped
 // decode attention, 12 = prefill attention on the matrix cores, 17 / 18 / 19 = workgroups per K slice of the 64-row qkv / o_proj /
 // gate-up GEMV (18 < 0: eight-plane o_proj kernel; 19 < 0: single K slices for gate/up), 21 = key tiles per workgroup of the
-// fp16-cache decode attention, 22 = all-tiles form of that attention, 23 = concurrent member sweeps of a group step, 24 = four-columns-per-thread finishing kernel of the slice GEMVs; the product
+// fp16-cache decode attention, 22 = all-tiles form of that attention, 23 = concurrent member sweeps of a group step, 24 = four-columns-per-thread finishing kernel of the slice GEMVs (bit mask over the epilogues); the product
 // switches (8, 11, 13-16) are forwarded to dd_set_tuning.
 extern int g_exp_G[4];
 extern int g_attn16_tpw, g_attn16_full, g_finish4;

@@ -36,7 +36,8 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * dd_lm_group_step (1, 2, 4, 8), 10 workgroups per group of 8 members in the grouped decode attention, 12 prefill attention
  * on the matrix cores, 17 / 18 / 19 workgroups per K slice of the 64-row qkv / o_proj / gate-up GEMV, 21 key tiles per
  * workgroup of the fp16-cache decode attention, 22 all-tiles form of that attention, 23 member sweeps of a group step that
- * run concurrently (1..4), 24 four-columns-per-thread finishing kernel of the slice GEMVs (default 1).  Keys of dd_set_tuning are forwarded. */
+ * run concurrently (1..4), 24 four-columns-per-thread finishing kernel of the slice GEMVs (bit mask over the epilogues
+ * EPI_STORE / RESID / SILU / QKV, default 15; 0: the one-column kernel it replaced).  Keys of dd_set_tuning are forwarded. */
 int dd_tools_set_tuning(int key, int value);
 
 #ifdef __cplusplus
