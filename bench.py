@@ -298,8 +298,8 @@ def main() -> int:
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help="BASELINE.json configs: 3 (default, the metric's: LLaVA-1.5-7B K=8), 2 (LLaVA-1.5-7B K=4 [0.1,0.3,0.5,0.7]), 1 (--original), "
-                         "4 (InstructBLIP-Vicuna-7B K=8, 32 visual tokens) and 5 (LLaVA-NeXT-Mistral-7B K=8, 2928 visual tokens, fp8 weights) at engine "
-                         "level: LM prefill from synthetic merged embeddings + ensemble decode, vision front-end not included")
+                         "4 (InstructBLIP-Vicuna-7B K=8: EVA ViT-g + Q-Former front-end, 32 visual tokens), 5 (LLaVA-NeXT-Mistral-7B K=8, 2928 visual "
+                         "tokens, fp8 weights) at engine level: LM prefill from synthetic merged embeddings + ensemble decode, vision front-end not included")
     ap.add_argument("--mode", choices=["replicas", "kshard"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
@@ -347,7 +347,7 @@ def main() -> int:
     probs = (ddcfg.VOTING_NUMBERS_K4 if args.k == 4 else ddcfg.VOTING_NUMBERS_K8[:args.k]) if args.k <= 8 else [0.1 + 0.05 * i for i in range(args.k)]
     ddcfg.settings["voting_numbers"] = list(probs)
     K_eff = 0 if args.original else len(probs)
-    engine_level = args.config in (4, 5)
+    engine_level = args.config == 5          # config 4 runs through its drop-in class with the vision front-end, like config 3
     if args.images_per_gpu is None:
         args.images_per_gpu = 8 if args.config == 5 else 32
     if args.prefill_chunk is None:
@@ -364,15 +364,22 @@ def main() -> int:
     # ------------------------------------------------------------------------------------------------------------------
     kshard = None
     if not engine_level:
-        from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
         from dropoutdecoding_amd.vlm import GroupPipeline
-        model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+        if args.config == 4:
+            from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration
+            model = CustomInstructBlipForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+            family, L, model_name, front = lm.FAMILY_IBLIP, 32, "InstructBLIP-Vicuna-7B", "EVA ViT-g/14 + Q-Former front-end + "
+        else:
+            from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
+            model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+            family, L, model_name, front = lm.FAMILY_LLAVA, 576, "LLaVA-1.5-7B", "CLIP-L/14-336 front-end + "
         model.original = args.original
         if args.no_batch_tower:
             from dropoutdecoding_amd.vlm import DropoutVLM
             type(model)._visual_embeds_batch = DropoutVLM._visual_embeds_batch
         eng = model.engine
-        lm_cfg, family, T0, L, prompt_len = eng.cfg, lm.FAMILY_LLAVA, 608, 576, 32
+        lm_cfg, prompt_len = eng.cfg, 32
+        T0 = L + prompt_len
         wname, weight_bytes = "bf16", 2.0
         if args.mode == "kshard" and use_dist:
             from dropoutdecoding_amd.dist import KShardDecoder
@@ -386,6 +393,13 @@ def main() -> int:
         def batch_inputs(i, n=B):
             out = []
             for b in range(n):
+                if args.config == 4:        # InstructBLIP: 224 x 224 image, instruction ids for the Q-Former, prompt ids for the LM (no placeholder)
+                    rng = np.random.default_rng(i * B + b)
+                    px = torch.from_numpy(rng.standard_normal((1, 3, 224, 224), dtype=np.float32))
+                    ids = torch.from_numpy(rng.integers(3, 31999, size=prompt_len).astype(np.int64))[None]
+                    qids = torch.from_numpy(rng.integers(1000, 30000, size=12).astype(np.int64))[None]
+                    out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda(), qformer_input_ids=qids.cuda(), qformer_attention_mask=torch.ones_like(qids).cuda()))
+                    continue
                 ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
                 out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
             return out
@@ -393,7 +407,7 @@ def main() -> int:
         def one_stream(i):
             kw = batch_inputs(i, 1)[0]
             o = model.generate(**kw, max_new_tokens=args.n_new, eos_token_id=[])
-            assert o.shape[1] == kw["input_ids"].shape[1] + args.n_new
+            assert o.shape[1] == (1 if args.config == 4 else kw["input_ids"].shape[1]) + args.n_new      # InstructBLIP returns BOS + new ids
 
         def run_steps(first, n):
             if pipe is None:
@@ -402,17 +416,12 @@ def main() -> int:
                 return
             done = 0
             for outs in pipe.run((batch_inputs(first + i) for i in range(n)), max_new_tokens=args.n_new, eos_token_id=[]):
-                assert len(outs) == B and all(o.shape[1] == prompt_len + args.n_new for o in outs)
+                assert len(outs) == B and all(o.shape[1] == (1 if args.config == 4 else prompt_len) + args.n_new for o in outs)
                 done += 1
             assert done == n
-        front = "CLIP-L/14-336 front-end + "
-        model_name = "LLaVA-1.5-7B"
     else:
-        # BASELINE configs 4 / 5 at the engine: synthetic merged embeddings of the real shape -> LM prefill + scorer -> ensemble decode
-        if args.config == 4:
-            lm_cfg, family, L, prompt_len, wname, model_name = lm.VICUNA_7B, lm.FAMILY_IBLIP, 32, 32, "bf16", "InstructBLIP-Vicuna-7B"
-        else:
-            lm_cfg, family, L, prompt_len, wname, model_name = lm.MISTRAL_7B, lm.FAMILY_NEXT, 2928, 32, "fp8", "LLaVA-NeXT-Mistral-7B"
+        # BASELINE config 5 at the engine: synthetic merged embeddings of the real shape -> LM prefill + scorer -> ensemble decode
+        lm_cfg, family, L, prompt_len, wname, model_name = lm.MISTRAL_7B, lm.FAMILY_NEXT, 2928, 32, "fp8", "LLaVA-NeXT-Mistral-7B"
         T0 = L + prompt_len
         weight_bytes = 1.0 if wname == "fp8" else 2.0
         s0 = 0 if family == lm.FAMILY_IBLIP else 5
@@ -505,7 +514,7 @@ def main() -> int:
         except Exception as e:                                         # the throughput number must still be reported
             roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                     "error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and single and not engine_level and not args.original:
+    if rank == 0 and single and args.config in (1, 2, 3) and not args.original:
         # the keep sets a trained checkpoint has: 64 lm_head rows scaled up make the un-masked argmax one of those ids at every step and
         # fill the visual tokens' top-k lists with them, so tens of visual tokens are kept per step and the check fails nearly always.
         # (Changes the weights: last leg of the run.)
@@ -527,13 +536,13 @@ def main() -> int:
 
     if rank == 0:
         kv_note = "fp16 KV cache = the reference's cache width"
-        wl = (f"{model_name} Dropout Decoding, {B} synthetic " + ("336x336 image(s)" if not engine_level else "sequence(s)") + f" per step and GPU -> each {L} visual tokens + "
+        wl = (f"{model_name} Dropout Decoding, {B} synthetic " + (("224x224" if args.config == 4 else "336x336") + " image(s)" if not engine_level else "sequence(s)") + f" per step and GPU -> each {L} visual tokens + "
               f"{prompt_len}-token prompt (prefill {T0}), {args.n_new} decoded tokens each (EOS ignored), K={K_eff} voting_numbers={list(probs) if K_eff else []}, "
               f"random-init weights of the real shapes ({wname} weights, fp32 activations, {kv_note})"
               + ("; engine level: the LM prefill starts from synthetic merged embeddings, the vision front-end is not part of the step" if engine_level else "")
               + (f"; the {B} are independent sequences (own KV cache and rng stream, results identical to decoding each alone) whose un-masked passes "
                  f"share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep"
-                 + ("; the next batch's CLIP + prefill overlap the current batch's decode on a second stream" if not engine_level else "") if B > 1 else ""))
+                 + ("; the next batch's vision front-end + prefill overlap the current batch's decode on a second stream" if not engine_level else "") if B > 1 else ""))
         metric = {1: f"decoded tokens/sec {model_name} --original", 2: f"decoded tokens/sec {model_name} K=4 ensemble", 3: f"decoded tokens/sec {model_name} K=8 ensemble",
                   4: f"decoded tokens/sec {model_name} K=8 ensemble", 5: f"decoded tokens/sec {model_name} K=8 ensemble, fp8 weights"}[args.config]
         if args.original:
@@ -556,7 +565,7 @@ def main() -> int:
         }
         if exchange is not None:
             line["kshard_exchange"] = exchange
-        if world == 1 and not args.no_cpu_baseline and not engine_level:   # the CPU leg restates config 3's shapes
+        if world == 1 and not args.no_cpu_baseline and args.config in (1, 2, 3):   # the CPU leg restates config 3's shapes
             try:
                 line["cpu_baseline"] = cpu_baseline(max(K_eff, 1) if not args.original else 0)
             except Exception as e:                                     # the GPU number must still be reported

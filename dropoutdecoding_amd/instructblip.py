@@ -61,6 +61,31 @@ class CustomInstructBlipForConditionalGeneration(DropoutVLM):
         query_output = q.last_hidden_state[:, : query_tokens.size(1), :]
         return hf.language_projection(query_output)[0]
 
+    def _visual_embeds_batch(self, inputs_list):
+        """One EVA tower call for several images (dd_vit_forward runs them as one matrix: the same bits as one call per image),
+        then the Q-Former per image (its instruction tokens differ per image)."""
+        pvs = [inp.get("pixel_values") for inp in inputs_list]
+        ok = (self.tower_hip is not None and self.qformer_hip is not None and len(inputs_list) > 1
+              and all(p is not None and p.dim() == 4 and p.shape[0] == 1 for p in pvs) and len({tuple(p.shape) for p in pvs}) == 1
+              and all(inp.get("qformer_input_ids") is not None and inp["qformer_input_ids"].shape[0] == 1
+                      and not inp.get("interpolate_pos_encoding", False) for inp in inputs_list))
+        if not ok:
+            return [self._visual_embeds(**inp) for inp in inputs_list]
+        dev = self.device
+        qdt = next(self._hf.qformer.parameters()).dtype
+        embeds = self.tower_hip(torch.cat([p.to(dev).float() for p in pvs], dim=0)).to(qdt)       # [n, 257, 1408]
+        out = []
+        for inp, e in zip(inputs_list, embeds):
+            ids = inp["qformer_input_ids"][0].to(dev)
+            m = inp.get("qformer_attention_mask")
+            if m is not None:
+                ids = ids[m[0].to(dev).bool()]
+            if ids.numel() > self.qformer_hip.max_text_tokens or e.shape[0] > self.qformer_hip.max_encoder_tokens:
+                out.append(self._visual_embeds(**inp))
+            else:
+                out.append(self.qformer_hip(ids, e.float()))
+        return out
+
     # reference models/instructblip.py:661-664: [query embeds ; prompt embeds], span = positions 0..Q-1
     def _merge(self, input_ids, visual):
         ids = input_ids[0]
@@ -109,6 +134,34 @@ class CustomInstructBlipForConditionalGeneration(DropoutVLM):
             from .vision import QFormerHIP
             n_enc = (vc.image_size // vc.patch_size) ** 2 + 1
             m.qformer_hip = QFormerHIP.from_hf(inner.qformer, inner.query_tokens, inner.language_projection, max_encoder_tokens=n_enc)
+        return m
+
+    @classmethod
+    def from_synthetic(cls, lm_cfg: Optional[LMConfig] = None, seed: int = 0, max_new_tokens: int = 256):
+        """Random-init weights of the real InstructBLIP-Vicuna-7B shapes (bench.py --config 4: no network, no checkpoints): EVA
+        ViT-g/14-224 tower (1408 wide, 39 layers, 16 heads of 88), Q-Former (768 wide, 12 layers, cross-attention every second layer,
+        32 queries), language projection 768 -> 4096, Vicuna-7B language model — the front-end on the dd_vit_* / dd_qformer_* kernels."""
+        import types
+        from transformers import InstructBlipQFormerConfig, InstructBlipVisionConfig
+        from transformers.models.instructblip.modeling_instructblip import InstructBlipQFormerModel, InstructBlipVisionModel
+        from .lm import VICUNA_7B
+        from .vision import ClipTowerHIP, QFormerHIP
+        lm_cfg = lm_cfg or VICUNA_7B
+        vc, qc = InstructBlipVisionConfig(), InstructBlipQFormerConfig()
+        eng = build_engine(lm_cfg, cls.family, max_visual=32, max_new_tokens=max_new_tokens, prompt_tokens=64, seed=_config.effective_seed)
+        eng.load_synthetic(seed, 0.02)
+        dev = eng.device
+        torch.manual_seed(seed)
+        with torch.device(dev):
+            front = types.SimpleNamespace(vision_model=InstructBlipVisionModel(vc).eval(), qformer=InstructBlipQFormerModel(qc).eval(),
+                                          language_projection=torch.nn.Linear(qc.hidden_size, lm_cfg.hidden_size),
+                                          query_tokens=torch.nn.Parameter(torch.randn(1, 32, qc.hidden_size)))
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        embed = (torch.randn(lm_cfg.vocab_size, 64, generator=g).repeat(1, lm_cfg.hidden_size // 64)).to(dev, torch.bfloat16)
+        m = cls(eng, embed, front, None, None)
+        m.tower_hip = ClipTowerHIP.from_hf_instructblip(front.vision_model)
+        m.qformer_hip = QFormerHIP.from_hf(front.qformer, front.query_tokens, front.language_projection,
+                                           max_encoder_tokens=(vc.image_size // vc.patch_size) ** 2 + 1)
         return m
 
     @classmethod
