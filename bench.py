@@ -298,8 +298,8 @@ def main() -> int:
     ap.add_argument("--k", type=int, default=8)
     ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help="BASELINE.json configs: 3 (default, the metric's: LLaVA-1.5-7B K=8), 2 (LLaVA-1.5-7B K=4 [0.1,0.3,0.5,0.7]), 1 (--original), "
-                         "4 (InstructBLIP-Vicuna-7B K=8: EVA ViT-g + Q-Former front-end, 32 visual tokens), 5 (LLaVA-NeXT-Mistral-7B K=8, 2928 visual "
-                         "tokens, fp8 weights) at engine level: LM prefill from synthetic merged embeddings + ensemble decode, vision front-end not included")
+                         "4 (InstructBLIP-Vicuna-7B K=8: EVA ViT-g + Q-Former front-end, 32 visual tokens), 5 (LLaVA-NeXT-Mistral-7B K=8: CLIP over 5 anyres "
+                         "tiles, 2928 visual tokens, fp8 weights); each through its drop-in class")
     ap.add_argument("--mode", choices=["replicas", "kshard"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
@@ -347,7 +347,8 @@ def main() -> int:
     probs = (ddcfg.VOTING_NUMBERS_K4 if args.k == 4 else ddcfg.VOTING_NUMBERS_K8[:args.k]) if args.k <= 8 else [0.1 + 0.05 * i for i in range(args.k)]
     ddcfg.settings["voting_numbers"] = list(probs)
     K_eff = 0 if args.original else len(probs)
-    engine_level = args.config == 5          # config 4 runs through its drop-in class with the vision front-end, like config 3
+    engine_level = False                     # every config runs through its drop-in class with the vision front-end (the engine-level
+    #                                          step — synthetic merged embeddings -> prefill + decode — remains below for experiments)
     if args.images_per_gpu is None:
         args.images_per_gpu = 8 if args.config == 5 else 32
     if args.prefill_chunk is None:
@@ -365,10 +366,16 @@ def main() -> int:
     kshard = None
     if not engine_level:
         from dropoutdecoding_amd.vlm import GroupPipeline
+        wname, weight_bytes = "bf16", 2.0
         if args.config == 4:
             from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration
             model = CustomInstructBlipForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
             family, L, model_name, front = lm.FAMILY_IBLIP, 32, "InstructBLIP-Vicuna-7B", "EVA ViT-g/14 + Q-Former front-end + "
+        elif args.config == 5:
+            from dropoutdecoding_amd.llavanext import CustomLlavaNextForConditionalGeneration
+            model = CustomLlavaNextForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+            family, L, model_name, front = lm.FAMILY_NEXT, 2928, "LLaVA-NeXT-Mistral-7B", "CLIP-L/14-336 over 5 anyres tiles + "
+            wname, weight_bytes = "fp8", 1.0
         else:
             from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
             model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
@@ -379,8 +386,7 @@ def main() -> int:
             type(model)._visual_embeds_batch = DropoutVLM._visual_embeds_batch
         eng = model.engine
         lm_cfg, prompt_len = eng.cfg, 32
-        T0 = L + prompt_len
-        wname, weight_bytes = "bf16", 2.0
+        T0 = L + prompt_len - (0 if args.config == 4 else 1)       # LLaVA families: the <image> placeholder is replaced by the L tokens
         if args.mode == "kshard" and use_dist:
             from dropoutdecoding_amd.dist import KShardDecoder
             kshard = model.kshard = KShardDecoder(eng, rank, world, time_exchange=True)
@@ -401,6 +407,11 @@ def main() -> int:
                     out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda(), qformer_input_ids=qids.cuda(), qformer_attention_mask=torch.ones_like(qids).cuda()))
                     continue
                 ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
+                if args.config == 5:        # LLaVA-NeXT anyres: a 672 x 672 image = the base view + 2 x 2 tiles of 336 x 336
+                    rng = np.random.default_rng(7_000_000 + i * B + b)
+                    px = torch.from_numpy(rng.standard_normal((1, 5, 3, 336, 336), dtype=np.float32))
+                    out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda(), image_sizes=torch.tensor([[672, 672]])))
+                    continue
                 out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
             return out
 
@@ -536,7 +547,7 @@ def main() -> int:
 
     if rank == 0:
         kv_note = "fp16 KV cache = the reference's cache width"
-        wl = (f"{model_name} Dropout Decoding, {B} synthetic " + (("224x224" if args.config == 4 else "336x336") + " image(s)" if not engine_level else "sequence(s)") + f" per step and GPU -> each {L} visual tokens + "
+        wl = (f"{model_name} Dropout Decoding, {B} synthetic " + ({4: "224x224", 5: "672x672 (anyres: 5 tiles of 336x336)"}.get(args.config, "336x336") + " image(s)" if not engine_level else "sequence(s)") + f" per step and GPU -> each {L} visual tokens + "
               f"{prompt_len}-token prompt (prefill {T0}), {args.n_new} decoded tokens each (EOS ignored), K={K_eff} voting_numbers={list(probs) if K_eff else []}, "
               f"random-init weights of the real shapes ({wname} weights, fp32 activations, {kv_note})"
               + ("; engine level: the LM prefill starts from synthetic merged embeddings, the vision front-end is not part of the step" if engine_level else "")

@@ -87,6 +87,43 @@ class CustomLlavaNextForConditionalGeneration(DropoutVLM):
         return m
 
     @classmethod
+    def from_synthetic(cls, lm_cfg: Optional[LMConfig] = None, seed: int = 0, max_new_tokens: int = 256, weight_format: str = "fp8"):
+        """Random-init weights of the real LLaVA-NeXT-Mistral-7B shapes (bench.py --config 5: no network, no checkpoints): CLIP-L/14-336
+        tower + projector over the anyres tiles (a 672 x 672 image: base + 2 x 2 tiles -> 576 + 48 x 48 + 48 newline = 2928 visual
+        tokens), Mistral-7B language model (GQA 4) with fp8 matrices by default (BASELINE config 5).  HF's LlavaNextModel supplies the
+        unpad / image_newline packing (index arithmetic); its language model is a one-layer stand-in that is dropped."""
+        from transformers import CLIPVisionConfig, LlavaNextConfig, MistralConfig
+        from transformers.models.llava_next.modeling_llava_next import LlavaNextModel
+        from .lm import MISTRAL_7B
+        lm_cfg = lm_cfg or MISTRAL_7B
+        vc = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336,
+                              patch_size=14, projection_dim=768)
+        tc = MistralConfig(vocab_size=64, hidden_size=lm_cfg.hidden_size, intermediate_size=256, num_hidden_layers=1, num_attention_heads=32,
+                           num_key_value_heads=8, head_dim=128)
+        cfg = LlavaNextConfig(vision_config=vc, text_config=tc, image_token_index=32000, vision_feature_layer=-2,
+                              vision_feature_select_strategy="default",
+                              image_grid_pinpoints=[[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]])
+        saved = settings.get("weight_format", None)
+        settings["weight_format"] = weight_format
+        try:
+            eng = build_engine(lm_cfg, cls.family, max_visual=2944, max_new_tokens=max_new_tokens, prompt_tokens=64,
+                               use_random=bool(settings["use_random"][0]), seed=_config.effective_seed)
+        finally:
+            if saved is None:
+                settings.pop("weight_format", None)
+            else:
+                settings["weight_format"] = saved
+        eng.load_synthetic(seed, 0.02)
+        dev = eng.device
+        torch.manual_seed(seed)
+        with torch.device(dev):
+            inner = LlavaNextModel(cfg).to(torch.bfloat16).eval()
+        inner.language_model = None
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        embed = (torch.randn(lm_cfg.vocab_size, 64, generator=g).repeat(1, lm_cfg.hidden_size // 64)).to(dev, torch.bfloat16)
+        return cls(eng, embed, inner, 32000, None, cfg)
+
+    @classmethod
     def from_pretrained(cls, model_path, torch_dtype=torch.float16, device_map="auto", max_new_tokens: int = 1024, **kw):
         from transformers import LlavaNextForConditionalGeneration
         hf = LlavaNextForConditionalGeneration.from_pretrained(model_path, torch_dtype=torch_dtype, low_cpu_mem_usage=True)

@@ -262,3 +262,43 @@ def test_llava7b_speculation_policies_on_keep_sets_that_are_never_empty(E):
           f"speculating always {out['always'][2]:.2f} (hit rate {sa['hit_rate']:.2f}), adaptive {out['adaptive'][2]:.2f} "
           f"({sd['plain']} plain + {sd['held'] + sd['rerun']} probe steps, {sd['rerun']} re-runs)")
     eng.close()
+
+
+def test_configs_4_and_5_through_their_drop_in_classes_at_full_size():
+    """`from_synthetic` of the InstructBLIP and LLaVA-NeXT wrappers (what `bench.py --config 4 / 5` runs): the real front-end shapes on
+    own kernels — EVA ViT-g/14 + Q-Former -> 32 visual tokens; CLIP-L/14-336 over the 5 anyres tiles of a 672 x 672 image -> 2928 visual
+    tokens — feeding the drop-in `generate()`; return layouts, span bookkeeping, and a lane decoding the same inputs to the same ids."""
+    from dropoutdecoding_amd import build, config as ddc
+    build.build()
+    from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration
+    from dropoutdecoding_amd.llavanext import CustomLlavaNextForConditionalGeneration
+    from dropoutdecoding_amd.vlm import generate_group
+    saved = dict(ddc.settings)
+    try:
+        ddc.settings["voting_numbers"] = PROBS8
+        g = torch.Generator().manual_seed(0)
+        m = CustomInstructBlipForConditionalGeneration.from_synthetic(max_new_tokens=16)
+        assert m.tower_hip is not None and m.qformer_hip is not None
+        kw = dict(input_ids=torch.randint(3, 31000, (1, 12), generator=g), pixel_values=torch.randn(1, 3, 224, 224, generator=g),
+                  qformer_input_ids=torch.randint(1000, 30000, (1, 9), generator=g), qformer_attention_mask=torch.ones(1, 9, dtype=torch.long))
+        out = m.generate(**kw, max_new_tokens=5, eos_token_id=[])
+        assert out.shape == (1, 6) and int(out[0, 0]) == 2 and m.start_image_pos == [0] and m.end_image_pos == [31] and m.start_generation_pos == 44
+        lanes = [m.spawn_lane(), m.spawn_lane()]
+        kw2 = dict(kw, pixel_values=torch.randn(1, 3, 224, 224, generator=g))
+        outs = generate_group(lanes, [kw, kw2], max_new_tokens=5, eos_token_id=[])          # the tower batched over the two images
+        assert outs[0].tolist() == out.tolist()
+        assert outs[1].tolist() == m.spawn_lane().generate(**kw2, max_new_tokens=5, eos_token_id=[]).tolist()
+        del m, lanes
+        torch.cuda.empty_cache()
+        n = CustomLlavaNextForConditionalGeneration.from_synthetic(max_new_tokens=16)
+        assert n.tower_hip is not None and n.engine.weight_format == "fp8"
+        ids = torch.randint(3, 31000, (1, 20), generator=g)
+        ids[0, 4] = 32000
+        out = n.generate(input_ids=ids, pixel_values=torch.randn(1, 5, 3, 336, 336, generator=g), image_sizes=torch.tensor([[672, 672]]),
+                         max_new_tokens=4, eos_token_id=[])
+        assert out.shape == (1, 24) and out[0, :20].tolist() == ids[0].tolist()
+        assert n.start_image_pos == [4] and n.end_image_pos == [4 + 2928 - 1] and n.start_generation_pos == 19 + 2928
+        assert n.image_features[1].shape == (1, 2928, 10)
+    finally:
+        ddc.settings.clear()
+        ddc.settings.update(saved)
