@@ -7,12 +7,12 @@
         bench.py --gpus N --steps K --warmup W
     python bench.py --config 4|5          # BASELINE configs 4 / 5 (InstructBLIP-Vicuna-7B, LLaVA-NeXT-Mistral-7B fp8) at engine level
 
-One "step" = one image through `CustomLlavaForConditionalGeneration.generate()`: CLIP-L/14-336 front-end +
-prefill of 608 positions (576 visual + 32 prompt tokens) + uncertainty scorer + `--n-new` (128) decoded tokens,
-each by the K=8 ensemble step (un-masked pass, masks, 8 masked members in one packed sweep, vote).  Weights are
-random-init tensors of the real LLaVA-1.5-7B shapes (no network / checkpoints), data is synthetic; EOS is ignored
-so every run decodes the same number of tokens.  N > 1: every rank decodes its own images (the path shards over
-independent images with no data-path collective) -> "scaling": "weak"; `--mode kshard` instead shards the K
+One "step" = one batch of images (default 32 per GPU, lanes over one set of weights) through the drop-in class's `generate()` path: vision
+front-end (CLIP-L/14-336; config 4: EVA ViT-g + Q-Former; config 5: CLIP over 5 anyres tiles) + LM prefill (576 visual + 32 prompt
+positions for LLaVA-1.5) + uncertainty scorer + `--n-new` (128) decoded tokens per image, each by the K=8 ensemble step (un-masked
+pass, masks, 8 masked members in one packed sweep, vote).  Weights are random-init tensors of the real shapes (no network /
+checkpoints), data is synthetic; EOS is ignored so every run decodes the same number of tokens.  N > 1: every rank decodes its own images
+(the path shards over independent images with no data-path collective) -> "scaling": "weak"; `--mode kshard` instead shards the K
 members of ONE stream over the ranks with the RCCL exchange of dropoutdecoding_amd/dist.py.
 Rank 0 prints ONE JSON line.
 """
@@ -347,8 +347,6 @@ def main() -> int:
     probs = (ddcfg.VOTING_NUMBERS_K4 if args.k == 4 else ddcfg.VOTING_NUMBERS_K8[:args.k]) if args.k <= 8 else [0.1 + 0.05 * i for i in range(args.k)]
     ddcfg.settings["voting_numbers"] = list(probs)
     K_eff = 0 if args.original else len(probs)
-    engine_level = False                     # every config runs through its drop-in class with the vision front-end (the engine-level
-    #                                          step — synthetic merged embeddings -> prefill + decode — remains below for experiments)
     if args.images_per_gpu is None:
         args.images_per_gpu = 8 if args.config == 5 else 32
     if args.prefill_chunk is None:
@@ -364,107 +362,71 @@ def main() -> int:
     # the workload: `run_steps(first, n)` = n batches of B images / sequences; `one_stream(i)` = one image / sequence alone
     # ------------------------------------------------------------------------------------------------------------------
     kshard = None
-    if not engine_level:
-        from dropoutdecoding_amd.vlm import GroupPipeline
-        wname, weight_bytes = "bf16", 2.0
-        if args.config == 4:
-            from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration
-            model = CustomInstructBlipForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
-            family, L, model_name, front = lm.FAMILY_IBLIP, 32, "InstructBLIP-Vicuna-7B", "EVA ViT-g/14 + Q-Former front-end + "
-        elif args.config == 5:
-            from dropoutdecoding_amd.llavanext import CustomLlavaNextForConditionalGeneration
-            model = CustomLlavaNextForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
-            family, L, model_name, front = lm.FAMILY_NEXT, 2928, "LLaVA-NeXT-Mistral-7B", "CLIP-L/14-336 over 5 anyres tiles + "
-            wname, weight_bytes = "fp8", 1.0
-        else:
-            from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
-            model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
-            family, L, model_name, front = lm.FAMILY_LLAVA, 576, "LLaVA-1.5-7B", "CLIP-L/14-336 front-end + "
-        model.original = args.original
-        if args.no_batch_tower:
-            from dropoutdecoding_amd.vlm import DropoutVLM
-            type(model)._visual_embeds_batch = DropoutVLM._visual_embeds_batch
-        eng = model.engine
-        lm_cfg, prompt_len = eng.cfg, 32
-        T0 = L + prompt_len - (0 if args.config == 4 else 1)       # LLaVA families: the <image> placeholder is replaced by the L tokens
-        if args.mode == "kshard" and use_dist:
-            from dropoutdecoding_amd.dist import KShardDecoder
-            kshard = model.kshard = KShardDecoder(eng, rank, world, time_exchange=True)
-        pipe = None
-        if B > 1:
-            # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
-            pipe = GroupPipeline(model, lanes=B)
-            pipe.prefill_chunk = max(1, args.prefill_chunk)
-
-        def batch_inputs(i, n=B):
-            out = []
-            for b in range(n):
-                if args.config == 4:        # InstructBLIP: 224 x 224 image, instruction ids for the Q-Former, prompt ids for the LM (no placeholder)
-                    rng = np.random.default_rng(i * B + b)
-                    px = torch.from_numpy(rng.standard_normal((1, 3, 224, 224), dtype=np.float32))
-                    ids = torch.from_numpy(rng.integers(3, 31999, size=prompt_len).astype(np.int64))[None]
-                    qids = torch.from_numpy(rng.integers(1000, 30000, size=12).astype(np.int64))[None]
-                    out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda(), qformer_input_ids=qids.cuda(), qformer_attention_mask=torch.ones_like(qids).cuda()))
-                    continue
-                ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
-                if args.config == 5:        # LLaVA-NeXT anyres: a 672 x 672 image = the base view + 2 x 2 tiles of 336 x 336
-                    rng = np.random.default_rng(7_000_000 + i * B + b)
-                    px = torch.from_numpy(rng.standard_normal((1, 5, 3, 336, 336), dtype=np.float32))
-                    out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda(), image_sizes=torch.tensor([[672, 672]])))
-                    continue
-                out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
-            return out
-
-        def one_stream(i):
-            kw = batch_inputs(i, 1)[0]
-            o = model.generate(**kw, max_new_tokens=args.n_new, eos_token_id=[])
-            assert o.shape[1] == (1 if args.config == 4 else kw["input_ids"].shape[1]) + args.n_new      # InstructBLIP returns BOS + new ids
-
-        def run_steps(first, n):
-            if pipe is None:
-                for i in range(n):
-                    one_stream(first + i)
-                return
-            done = 0
-            for outs in pipe.run((batch_inputs(first + i) for i in range(n)), max_new_tokens=args.n_new, eos_token_id=[]):
-                assert len(outs) == B and all(o.shape[1] == (1 if args.config == 4 else prompt_len) + args.n_new for o in outs)
-                done += 1
-            assert done == n
+    from dropoutdecoding_amd.vlm import GroupPipeline
+    wname, weight_bytes = "bf16", 2.0
+    if args.config == 4:
+        from dropoutdecoding_amd.instructblip import CustomInstructBlipForConditionalGeneration
+        model = CustomInstructBlipForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+        family, L, model_name, front = lm.FAMILY_IBLIP, 32, "InstructBLIP-Vicuna-7B", "EVA ViT-g/14 + Q-Former front-end + "
+    elif args.config == 5:
+        from dropoutdecoding_amd.llavanext import CustomLlavaNextForConditionalGeneration
+        model = CustomLlavaNextForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+        family, L, model_name, front = lm.FAMILY_NEXT, 2928, "LLaVA-NeXT-Mistral-7B", "CLIP-L/14-336 over 5 anyres tiles + "
+        wname, weight_bytes = "fp8", 1.0
     else:
-        # BASELINE config 5 at the engine: synthetic merged embeddings of the real shape -> LM prefill + scorer -> ensemble decode
-        lm_cfg, family, L, prompt_len, wname, model_name = lm.MISTRAL_7B, lm.FAMILY_NEXT, 2928, 32, "fp8", "LLaVA-NeXT-Mistral-7B"
-        T0 = L + prompt_len
-        weight_bytes = 1.0 if wname == "fp8" else 2.0
-        s0 = 0 if family == lm.FAMILY_IBLIP else 5
-        mk = lambda owner: lm.DropoutEngine(lm_cfg, family=family, max_seq=T0 + args.n_new + 8, max_visual=L, kv_format="fp16",
-                                            weight_format=wname, share_weights_with=owner)
-        eng = mk(None)
-        eng.load_synthetic(0, 0.02)
-        sets = [[eng] + [mk(eng) for _ in range(B - 1)]]
-        gens = {}
+        from dropoutdecoding_amd.llava import CustomLlavaForConditionalGeneration
+        model = CustomLlavaForConditionalGeneration.from_synthetic(max_new_tokens=args.n_new + 8)
+        family, L, model_name, front = lm.FAMILY_LLAVA, 576, "LLaVA-1.5-7B", "CLIP-L/14-336 front-end + "
+    model.original = args.original
+    if args.no_batch_tower:
+        from dropoutdecoding_amd.vlm import DropoutVLM
+        type(model)._visual_embeds_batch = DropoutVLM._visual_embeds_batch
+    eng = model.engine
+    lm_cfg, prompt_len = eng.cfg, 32
+    T0 = L + prompt_len - (0 if args.config == 4 else 1)       # LLaVA families: the <image> placeholder is replaced by the L tokens
+    if args.mode == "kshard" and use_dist:
+        from dropoutdecoding_amd.dist import KShardDecoder
+        kshard = model.kshard = KShardDecoder(eng, rank, world, time_exchange=True)
+    pipe = None
+    if B > 1:
+        # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
+        pipe = GroupPipeline(model, lanes=B)
+        pipe.prefill_chunk = max(1, args.prefill_chunk)
 
-        def embeds(i):
-            g = gens.setdefault("g", torch.Generator(device="cuda"))
-            g.manual_seed(1000 + i)
-            return torch.randn(T0, lm_cfg.hidden_size, device="cuda", generator=g) * 0.5
+    def batch_inputs(i, n=B):
+        out = []
+        for b in range(n):
+            if args.config == 4:        # InstructBLIP: 224 x 224 image, instruction ids for the Q-Former, prompt ids for the LM (no placeholder)
+                rng = np.random.default_rng(i * B + b)
+                px = torch.from_numpy(rng.standard_normal((1, 3, 224, 224), dtype=np.float32))
+                ids = torch.from_numpy(rng.integers(3, 31999, size=prompt_len).astype(np.int64))[None]
+                qids = torch.from_numpy(rng.integers(1000, 30000, size=12).astype(np.int64))[None]
+                out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda(), qformer_input_ids=qids.cuda(), qformer_attention_mask=torch.ones_like(qids).cuda()))
+                continue
+            ids, px = synthetic_inputs(i * B + b, eng.cfg.vocab_size, model.image_token_index)
+            if args.config == 5:        # LLaVA-NeXT anyres: a 672 x 672 image = the base view + 2 x 2 tiles of 336 x 336
+                rng = np.random.default_rng(7_000_000 + i * B + b)
+                px = torch.from_numpy(rng.standard_normal((1, 5, 3, 336, 336), dtype=np.float32))
+                out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda(), image_sizes=torch.tensor([[672, 672]])))
+                continue
+            out.append(dict(input_ids=ids.cuda(), pixel_values=px.cuda()))
+        return out
 
-        def one_stream(i):
-            eng.prefill(embeds(i), s0, L)
-            toks = eng.generate(args.n_new, mprobs=probs, dropout=not args.original)
-            assert len(toks) == args.n_new
+    def one_stream(i):
+        kw = batch_inputs(i, 1)[0]
+        o = model.generate(**kw, max_new_tokens=args.n_new, eos_token_id=[])
+        assert o.shape[1] == (1 if args.config == 4 else kw["input_ids"].shape[1]) + args.n_new      # InstructBLIP returns BOS + new ids
 
-        def run_steps(first, n):
-            lanes = sets[0]
+    def run_steps(first, n):
+        if pipe is None:
             for i in range(n):
-                if B == 1:
-                    one_stream(first + i)
-                    continue
-                for c0 in range(0, B, args.prefill_chunk):
-                    part = lanes[c0:c0 + args.prefill_chunk]
-                    lm.prefill_group(part, [embeds((first + i) * B + c0 + j) for j in range(len(part))], [(s0, L)] * len(part))
-                toks = lm.EngineGroup(lanes).generate(args.n_new, mprobs=probs, dropout=not args.original)
-                assert all(len(t) == args.n_new for t in toks)
-        front = ""
+                one_stream(first + i)
+            return
+        done = 0
+        for outs in pipe.run((batch_inputs(first + i) for i in range(n)), max_new_tokens=args.n_new, eos_token_id=[]):
+            assert len(outs) == B and all(o.shape[1] == (1 if args.config == 4 else prompt_len) + args.n_new for o in outs)
+            done += 1
+        assert done == n
 
     img0 = rank * 10_000 if args.mode == "replicas" else 0
     run_steps(img0, args.warmup)
@@ -547,13 +509,12 @@ def main() -> int:
 
     if rank == 0:
         kv_note = "fp16 KV cache = the reference's cache width"
-        wl = (f"{model_name} Dropout Decoding, {B} synthetic " + ({4: "224x224", 5: "672x672 (anyres: 5 tiles of 336x336)"}.get(args.config, "336x336") + " image(s)" if not engine_level else "sequence(s)") + f" per step and GPU -> each {L} visual tokens + "
+        wl = (f"{model_name} Dropout Decoding, {B} synthetic " + ({4: "224x224", 5: "672x672 (anyres: 5 tiles of 336x336)"}.get(args.config, "336x336") + " image(s)") + f" per step and GPU -> each {L} visual tokens + "
               f"{prompt_len}-token prompt (prefill {T0}), {args.n_new} decoded tokens each (EOS ignored), K={K_eff} voting_numbers={list(probs) if K_eff else []}, "
               f"random-init weights of the real shapes ({wname} weights, fp32 activations, {kv_note})"
-              + ("; engine level: the LM prefill starts from synthetic merged embeddings, the vision front-end is not part of the step" if engine_level else "")
               + (f"; the {B} are independent sequences (own KV cache and rng stream, results identical to decoding each alone) whose un-masked passes "
                  f"share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep"
-                 + ("; the next batch's vision front-end + prefill overlap the current batch's decode on a second stream" if not engine_level else "") if B > 1 else ""))
+                 + "; the next batch's vision front-end + prefill overlap the current batch's decode on a second stream" if B > 1 else ""))
         metric = {1: f"decoded tokens/sec {model_name} --original", 2: f"decoded tokens/sec {model_name} K=4 ensemble", 3: f"decoded tokens/sec {model_name} K=8 ensemble",
                   4: f"decoded tokens/sec {model_name} K=8 ensemble", 5: f"decoded tokens/sec {model_name} K=8 ensemble, fp8 weights"}[args.config]
         if args.original:
@@ -570,7 +531,7 @@ def main() -> int:
                                       "reference's multi-process sharding on one GPU); the reference's own shape, one image at a time, is `single_stream`"
                                       if B > 1 else "one image at a time"),
                        "mode": args.mode, "images_per_step_per_gpu": B, "n_new": args.n_new, "K": K_eff,
-                       "prefill_included": True, "vision_front_end_included": not engine_level, "device_bytes": eng.device_bytes},
+                       "prefill_included": True, "vision_front_end_included": True, "device_bytes": eng.device_bytes},
             "single_stream": single, "single_stream_two_sweep": single_two, "single_stream_nonempty_keep_sets": single_keep,
             "roofline": roof,
         }
