@@ -244,7 +244,7 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
     prof = committed_profile(kernel)
     achieved = by / (ms * 1e-3) / 1e9
     what = (f"{kernel} (gate/up decode GEMV of a {dom_rows}-row pass = the members of {dom_rows // 8} sequences: streams the matrix once, K in slices "
-            "resident in LDS; its finishing kernel k_gemv_finish adds the slices' partial sums and applies SiLU*up)") if wide \
+            "resident in LDS; its finishing kernel k_gemv_finish4 adds the slices' partial sums and applies SiLU*up)") if wide \
         else f"{kernel} (gate/up decode GEMV, {rows8} rows)"
     return {"bound": "hbm", "kernel": what, "kernel_name": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": prof["traffic"],
