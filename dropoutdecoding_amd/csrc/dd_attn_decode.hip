@@ -213,7 +213,7 @@ __device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int h
 // stand-alone k_attn_combine runs over the buffers): no partial-buffer round trip, no second launch, the same bits.
 #define ATT_FULL_TILES 12
 template <int NBT, int G, int GH, int ML, int FULL = 0>
-__global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
+__device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, const int bx, const int by, const int bz) {
   constexpr int R = NBT * GH, RB = (R + 7) / 8, RP = RB * 8;
   extern __shared__ __align__(16) float full_sh[];        // FULL: [tiles][RP][HEAD_DIM] outputs, then [tiles][RP][2] statistics
   float* const fo_sh = full_sh;
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
   const int lane_rows = a.n_lanes > 8 ? 16 : 8;
   const int RT = ML == 1 ? lane_rows * G : (ML == 2 ? 8 * a.lane_groups * G : NBT * G);
   constexpr int MSPLIT = ML == 2 ? 8 / NBT : 1;
-  const int zz = ML == 2 ? blockIdx.z % ((G / GH) * MSPLIT) : 0;
-  const int g0 = ML == 1 ? 0 : (ML == 2 ? (zz / MSPLIT) * GH : blockIdx.z * GH);
+  const int zz = ML == 2 ? bz % ((G / GH) * MSPLIT) : 0;
+  const int g0 = ML == 1 ? 0 : (ML == 2 ? (zz / MSPLIT) * GH : bz * GH);
   const int mo = ML == 2 ? (zz % MSPLIT) * NBT : 0;
-  const int lane_row = ML == 1 ? blockIdx.z : (ML == 2 ? blockIdx.z / ((G / GH) * MSPLIT) : 0);
+  const int lane_row = ML == 1 ? bz : (ML == 2 ? bz / ((G / GH) * MSPLIT) : 0);
   auto buf_row = [&](int r) -> int {
     if (ML == 1) return r * lane_rows + lane_row;
     if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + mo + r % NBT;
@@ -237,12 +237,12 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
   if (a.skip_if && *a.skip_if) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, h4 = lane >> 4;
-  const int kvh = blockIdx.x;
+  const int kvh = bx;
   const int T = ML ? a.lane_state[lane_row]->T : (a.state ? a.state->T : a.T);
   // this workgroup's key tiles: tiles_per_wg consecutive ones (the launcher sizes the grid for ONE round of workgroups: with a
   // tile per workgroup the 8-sequence pass had 1.25 rounds, a quarter-full second one)
   const int tpw = FULL ? ATT_FULL_TILES : (a.tiles_per_wg > 0 ? a.tiles_per_wg : 1);
-  const int split0 = blockIdx.y * tpw, n_live = (T + ATT_SPLIT - 1) / ATT_SPLIT;
+  const int split0 = by * tpw, n_live = (T + ATT_SPLIT - 1) / ATT_SPLIT;
   const int split1 = min(min(split0 + tpw, FULL ? ATT_FULL_TILES : a.splits_stride), n_live);
   if (split0 >= split1) return;   // shorter lane / stale graph: these tiles do not exist (the combine skips them as well)
   const dd_half* kc_l = (const dd_half*)(ML ? a.lane_kc[lane_row] : a.kc);
@@ -422,13 +422,26 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
   }
 }
 
+template <int NBT, int G, int GH, int ML, int FULL = 0>
+__global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
+  attn_partial16_body<NBT, G, GH, ML, FULL>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// Rider sweeps (dd_engine.hip group_step_rider): the members of eight sequences (a: the groups form, workgroups z < za) AND the
+// riding un-masked rows of up to eight other sequences (u: the lanes form, one row per sequence) in ONE launch — the two are
+// independent and each alone leaves the chip half idle; the bodies are the ones above, so every row keeps its bits.
+template <int G, int GH>
+__global__ __launch_bounds__(256) void k_attn_partial16_ride(AttnDecodeArgs a, AttnDecodeArgs u, int za) {
+  if ((int)blockIdx.z < za) attn_partial16_body<8, G, GH, 2, 0>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+  else attn_partial16_body<1, G, G, 1, 0>(u, blockIdx.x, blockIdx.y, blockIdx.z - za);
+}
+
 // grid (n_heads, nb), block 128 (thread = d): the merge above over the partial buffers in memory
 template <int NBT, int G>
-__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits_grid) {
+__device__ __forceinline__ void attn_combine_body(const AttnDecodeArgs& a, int splits_grid, const int bx, const int by) {
   constexpr int R = NBT * G;
   __shared__ float sh[ATT_COMB_SH];
   if (a.skip_if && *a.skip_if) return;
-  const int head = blockIdx.x, m = blockIdx.y, d = threadIdx.x, kvh = head / G, g = head % G;
+  const int head = bx, m = by, d = threadIdx.x, kvh = head / G, g = head % G;
   const int r = g * NBT + m;
   // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
   // has the tiles of its own, possibly shorter, sequence
@@ -441,6 +454,16 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   attn_combine_core(
       a, head, kvh, m, NBT > 8, d, splits, sh, [&](int t, float& mx, float& l) { mx = mlb[t * ml_stride], l = mlb[t * ml_stride + 1]; },
       [&](int t) -> float { return po[(size_t)t * o_stride]; });
+}
+template <int NBT, int G>
+__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits_grid) {
+  attn_combine_body<NBT, G>(a, splits_grid, blockIdx.x, blockIdx.y);
+}
+// the merges of a rider sweep in one launch: rows 0..63 the members' (a), rows 64.. the riding rows' (u)
+template <int G>
+__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine_ride(AttnDecodeArgs a, AttnDecodeArgs u, int splits_a, int splits_u) {
+  if (blockIdx.y < 64) attn_combine_body<64, G>(a, splits_a, blockIdx.x, blockIdx.y);
+  else attn_combine_body<8, G>(u, splits_u, blockIdx.x, blockIdx.y - 64);
 }
 
 // Key tiles the partial kernel is LAUNCHED with: the live count rounded up to a multiple of 4 (workgroups of tiles past
@@ -557,6 +580,35 @@ static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
   if (g_attn_msplit == 4) return launch_attn_groups_n<G, NG, 2>(a, st);
   if (g_attn_msplit == 2) return launch_attn_groups_n<G, NG, 4>(a, st);
   return launch_attn_groups_n<G, NG, 8>(a, st);
+}
+
+template <int G>
+static int launch_attn_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, hipStream_t st) {
+  constexpr int GH = (8 * G > 16) ? 2 : G;
+  const int splits_a = ddk_attn_grid_tiles(a.max_T, a.T_cap), splits_u = ddk_attn_grid_tiles(u.max_T, u.T_cap);
+  DD_REQUIRE(splits_a >= 1 && splits_a <= ATT_MAX_SPLITS && splits_u >= 1 && splits_u <= ATT_MAX_SPLITS,
+             "attn: %d / %d key tiles unsupported (1..%d)", splits_a, splits_u, ATT_MAX_SPLITS);
+  AttnDecodeArgs b = a, v = u;
+  attn16_grid(b, splits_a, a.n_kv * 8 * (G / GH));
+  attn16_grid(v, splits_u, u.n_kv * u.n_lanes);
+  const int ya = (splits_a + b.tiles_per_wg - 1) / b.tiles_per_wg, yu = (splits_u + v.tiles_per_wg - 1) / v.tiles_per_wg;
+  const int za = 8 * (G / GH);
+  k_attn_partial16_ride<G, GH><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
+  k_attn_combine_ride<G><<<dim3(a.n_heads, 64 + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u);
+  return DD_OK;
+}
+// a: the member pass of eight sequences (lane_groups == 8), u: un-masked rows of up to eight sequences (lanes form, own partial
+// buffers), both over fp16 caches: the two attentions of a rider sweep in one partial + one combine launch
+int ddk_attn_decode_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, hipStream_t st) {
+  DD_REQUIRE(a.kv16 && u.kv16 && a.lane_groups == 8 && a.n_lanes == 8 && a.nb >= 1 && a.nb <= 8 && u.n_lanes >= 1 && u.n_lanes <= 8 &&
+                 u.nb == u.n_lanes && !u.lane_groups && a.n_heads == u.n_heads && a.n_kv == u.n_kv && a.part_o != u.part_o && a.part_ml != u.part_ml,
+             "attn_ride: a member pass of eight sequences + up to eight riding rows, fp16 caches, separate partial buffers");
+  const int G = a.n_heads / a.n_kv;
+  DD_REQUIRE(a.n_heads % a.n_kv == 0 && (G == 1 || G == 2 || G == 4), "attn_ride: GQA group %d unsupported (1, 2, 4)", G);
+  int rc = G == 1 ? launch_attn_ride<1>(a, u, st) : (G == 2 ? launch_attn_ride<2>(a, u, st) : launch_attn_ride<4>(a, u, st));
+  if (rc != DD_OK) return rc;
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {

@@ -191,6 +191,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   int max_splits = T / 64;
   DA(h->part_o, (size_t)h->Hkv * max_splits * GROUP_ROWS * G * 128);
   DA(h->part_ml, (size_t)h->Hkv * max_splits * GROUP_ROWS * G * 2);
+  DA(h->part_o_ride, (size_t)h->Hkv * max_splits * 8 * G * 128);
+  DA(h->part_ml_ride, (size_t)h->Hkv * max_splits * 8 * G * 2);
   DA(h->hidden, (size_t)MAX_MEMBERS * d);
   DA(h->spec_ok, 4);
   DA(h->rng_backup, 640);
@@ -198,17 +200,19 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
     // slice partials: 8 slices x tiles x 4 planes x 128 floats for qkv / o / down, 4 slice pairs for gate/up
     size_t t8 = (size_t)h->qkv_tiles > (size_t)d / 16 ? (size_t)h->qkv_tiles : (size_t)d / 16;
     // (eight planes for a 64-row pass: single slices for every matrix)
-    size_t nfl = 8 * t8 * 8 * 128, gu = (size_t)8 * (2 * dff / 16) * 8 * 128, lmh = (size_t)8 * (h->Vpad / 16) * 8 * 128;
+    size_t nfl = 8 * t8 * GROUP_PLANES * 128, gu = (size_t)8 * (2 * dff / 16) * GROUP_PLANES * 128, lmh = (size_t)8 * (h->Vpad / 16) * GROUP_PLANES * 128;
     if (lmh > gu) gu = lmh;                                   // lm_head: 66 MB at V = 32064
     h->gemv_part_floats = nfl > gu ? nfl : gu;
-    if (h->gemv_part_floats) DA(h->gemv_part, h->gemv_part_floats + 64);   // + rstd of the up to 64 operand rows
+    if (h->gemv_part_floats) DA(h->gemv_part, h->gemv_part_floats + GROUP_ROWS + 8);   // + rstd of the operand rows
   }
-  DA(h->xop_d, (size_t)h->S_d * 64 * 8);     // eight operand planes (8 rows each)
-  DA(h->xop_q, (size_t)h->S_q * 64 * 8);
-  DA(h->xop_ff, (size_t)h->S_ff * 64 * 8);
+  DA(h->xop_d, (size_t)h->S_d * 64 * GROUP_PLANES);     // operand planes (8 rows each)
+  DA(h->xop_q, (size_t)h->S_q * 64 * GROUP_PLANES);
+  DA(h->xop_ff, (size_t)h->S_ff * 64 * GROUP_PLANES);
   DA(h->base_logits, h->Vpad);
   DA(h->grp_logits, (size_t)GROUP_MAX_LANES * h->Vpad);
   DA(h->grp_argmax, GROUP_MAX_LANES);
+  DA(h->base_next, h->Vpad);
+  DA(h->argmax_next, 4);
   DA(h->chunk_states, 32);
   DA(h->chunk_k, (size_t)32 * h->kv_dim);
   DA(h->chunk_v, (size_t)32 * h->kv_dim);
@@ -726,7 +730,7 @@ static int prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, i
   DD_HIP(hipMemsetAsync(h->leak_bits, 0, h->Lmax, st));
   h->T_host = T0, h->span_start = span_start, h->L = L, h->n_tok_host = 1, h->prefilled = true, h->have_leak = false;
   h->last_K = 0;
-  h->steps_since_prefill = 0;
+  h->steps_since_prefill = 0, h->pend_valid = false;
   return DD_OK;
 }
 
@@ -867,7 +871,7 @@ extern "C" int dd_lm_truncate(dd_lm* h, int T_keep, void* stream_) {
   DD_CHECK_LAUNCH();
   DD_HIP(hipMemsetAsync(h->leak_bits, 0, h->Lmax, st));
   h->tok_host[0] = 0;
-  h->T_host = T_keep, h->n_tok_host = 0, h->have_leak = false, h->last_K = 0, h->steps_since_prefill = 0;
+  h->T_host = T_keep, h->n_tok_host = 0, h->have_leak = false, h->last_K = 0, h->steps_since_prefill = 0, h->pend_valid = false;
   return DD_OK;
 }
 
@@ -975,7 +979,7 @@ extern "C" int dd_lm_prefill_extend(dd_lm* h, const float* embeds, int n, void* 
   h->tok_host[0] = 0;
   k_state_after_prefill<<<1, 64, 0, st>>>(h->state, pos0 + n, h->argmax_base, h->tokens, h->tok_host_dev);
   DD_CHECK_LAUNCH();
-  h->T_host = pos0 + n, h->n_tok_host = 1, h->have_leak = false, h->last_K = 0, h->steps_since_prefill = 0;
+  h->T_host = pos0 + n, h->n_tok_host = 1, h->have_leak = false, h->last_K = 0, h->steps_since_prefill = 0, h->pend_valid = false;
   return DD_OK;
 }
 
@@ -1241,27 +1245,38 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
 // buffers, so that vote and commit run per sequence exactly as after lm_sweep.
 // -----------------------------------------------------------------------------------------------
 static int g_use_graph = 1;    // dd_set_tuning key 8
+// bumped by every tuning call and mixed into every graph key: a step captured under other settings is never replayed
+static unsigned long long g_tune_epoch = 0;
+void dd_engine_bump_epoch() { ++g_tune_epoch; }
+unsigned long long dd_engine_epoch() { return g_tune_epoch; }
 static int g_pair_sweeps = 8;  // dd_set_tuning key 9: sequences per member sweep in dd_lm_group_step (0/1: one, 2, 4, 8)
 void dd_engine_set_graph(int on) { g_use_graph = on; }
 int dd_engine_use_graph() { return g_use_graph; }
 void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
 static int g_branches = 2;     // dd_tools_set_tuning key 23: member sweeps of a group step that run concurrently (1..4)
 void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }
+static int g_ride_beside = 1;    // dd_tools_set_tuning key 27: the riding rows' attention in the members' launches (0: launches of its own)
+void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 
-static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st) {
+#define RIDER_KV_ROW0 16   // rows of the sweeping handle's new-K/V scratch that hold the riding un-masked rows (0..15: members)
+// rider / n_rider (ng == 8 only): up to 8 sequences whose UN-MASKED rows ride in a ninth operand plane of the sweep (row 64 + m =
+// sequence rider[m]); their logits go to rows 0.. of h->grp_logits.  See group_step_rider.
+static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st, dd_lm* const* rider = nullptr, int n_rider = 0) {
   const int d = h->d, dff = h->dff;
+  const int planes = n_rider > 0 ? 9 : ng;
   EmbedLanes el;
   memset(&el, 0, sizeof(el));
   for (int g = 0; g < ng; ++g)
     for (int m = 0; m < K; ++m) el.state[8 * g + m] = qs[g]->state;
-  RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * ng, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
+  for (int m = 0; m < n_rider; ++m) el.state[64 + m] = rider[m]->state;
+  RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * planes, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
     GemvArgs a;
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider;
     a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
@@ -1284,18 +1299,47 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     }
     a.knew = a.knew_g[0], a.vnew = a.vnew_g[0], t.knew = t.knew_g[0], t.vnew = t.vnew_g[0];
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
+    float* rk = h->knew + ((size_t)l * KV_ROWS + RIDER_KV_ROW0) * h->kv_dim;
+    float* rv = h->vnew + ((size_t)l * KV_ROWS + RIDER_KV_ROW0) * h->kv_dim;
+    if (n_rider) {
+      a.knew_g[8] = rk, a.vnew_g[8] = rv;
+      for (int m = 0; m < n_rider; ++m) a.state_rows[64 + m] = rider[m]->state;
+    }
     RC(ddk_gemv_groups(EPI_QKV, a, st));
-    RC(ddk_attn_decode(t, st));
+    if (n_rider) {
+      // the riding rows: one single-query attention per sequence over its own cache (the fused base pass's form), into plane 8
+      AttnDecodeArgs u;
+      memset(&u, 0, sizeof(u));
+      u.wf = h->wf, u.T_cap = h->T_cap, u.kv16 = h->kv16, u.n_heads = h->H, u.n_kv = h->Hkv;
+      u.part_o = h->part_o_ride, u.part_ml = h->part_ml_ride;
+      u.qbuf = h->qbuf + (size_t)64 * h->q_dim, u.nb = n_rider, u.n_lanes = n_rider;
+      u.knew = rk, u.vnew = rv, u.xop_out = h->xop_q + (size_t)8 * h->S_q * 64;
+      for (int m = 0; m < n_rider; ++m) {
+        dd_lm* q = rider[m];
+        u.lane_kc[m] = q->kc + (size_t)l * q->lsk, u.lane_vc[m] = q->vc + (size_t)l * q->lsv, u.lane_state[m] = q->state;
+        u.lane_bits[m] = q->cfg.leak_mask ? q->leak_bits : nullptr;
+        u.lane_span_start[m] = q->span_start, u.lane_span_len[m] = q->L;
+        if (q->T_host > u.max_T) u.max_T = q->T_host;
+      }
+      if (g_ride_beside) {           // beside the members' attention: one partial + one combine launch for both
+        RC(ddk_attn_decode_ride(t, u, st));
+      } else {
+        RC(ddk_attn_decode(t, st));
+        RC(ddk_attn_decode(u, st));
+      }
+    } else {
+      RC(ddk_attn_decode(t, st));
+    }
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = ng;
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = planes, a.nb_rider = n_rider;
     a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
@@ -1303,7 +1347,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = ng;
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = planes, a.nb_rider = n_rider;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
@@ -1314,7 +1358,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   GemvArgs a;
   memset(&a, 0, sizeof(a));
   a.wf = h->wf;
-  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = ng;
+  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider;
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   for (int g = 0; g < ng; ++g) {
@@ -1323,7 +1367,11 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   }
   a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
   a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
-    RC(ddk_gemv_groups(EPI_STORE, a, st));
+  if (n_rider) {
+    a.out_g[8] = h->grp_logits;
+    for (int m = 0; m < n_rider; ++m) a.state_rows[64 + m] = rider[m]->state;
+  }
+  RC(ddk_gemv_groups(EPI_STORE, a, st));
   return DD_OK;
 }
 
@@ -1400,6 +1448,150 @@ __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argma
   if (threadIdx.x == 0) tab.argmax[m][0] = grp_argmax[m];
 }
 
+// -----------------------------------------------------------------------------------------------
+// Rider form of the group step (16, 24, ... 64 sequences in groups of eight, K <= 8, fp16 cache, 16-bit weights of the 7B shapes).
+// The un-masked rows of a group step do not need a sweep of their own: a 64-row member sweep streams every weight anyway, and
+// eight more rows are a ninth operand plane of the same kernels (dd_gemv.hip try_slices9).  The groups of a branch form a ring
+// c0, c1, ... : the sweep of c_j carries the members of c_j AND the un-masked rows of c_(j+1) — whose previous token was voted a
+// step ago (or, for the last sweep of the ring, the rows of c0's NEXT step: c0's token of this step was voted in the ring's first
+// sweep).  c_(j+1)'s masks are sampled when that sweep ends, its members run next.  c0's rows for the next step are parked in
+// base_next / argmax_next and promoted when that step starts; a ring whose c0 has nothing parked (first step after a prefill,
+// a changed line-up) starts with the classic fused pass over those sequences.  Every row goes through the kernels of the other
+// pass widths (rows bit-identical across widths), every sequence draws its masks from its own stream in the same order: the
+// tokens, masks, logits and caches are those of the classic group step and of every sequence decoded alone.
+// Per step and sequence the weights are read 1/8 times ... the sweep count of a 32-sequence step drops from five to four.
+// -----------------------------------------------------------------------------------------------
+static int g_rider = 1;          // dd_tools_set_tuning key 26
+void dd_engine_set_rider(int on) { g_rider = on; }
+// branches of the rider form for this call, 0: not applicable
+static int rider_branches(dd_lm* const* lanes, int n, int K) {
+  if (!g_rider || K < 1 || K > 8 || g_pair_sweeps < 8 || n < 16 || (n % 8) != 0 || n > GROUP_MAX_LANES) return 0;
+  dd_lm* h0 = lanes[0];
+  if (!h0->kv16 || h0->fp8 || !h0->gemv_part) return 0;
+  // shapes with nine-plane kernels (dd_gemv.hip try_slices9)
+  const int qt = h0->qkv_tiles, gt = 2 * h0->dff / 16;
+  if (h0->S_d != 128 || h0->S_q != 128 || !(h0->S_ff == 8 * 43 || h0->S_ff == 8 * 56) || (qt % 16) != 0 || qt / 16 * 4 > 256 ||
+      4 * ((gt + 23) / 24) > 256 || h0->d / 16 < 64 || h0->Vpad / 16 < 64)
+    return 0;
+  for (int m = 0; m < n; ++m) {
+    const dd_lm* q = lanes[m];
+    if (q->cfg.mask_mode != h0->cfg.mask_mode || q->cfg.k_top != h0->cfg.k_top || q->cfg.mask_mode == DD_MASK_IBLIP_KL ||
+        q->cfg.vote_on == DD_VOTE_AVERAGE)
+      return 0;
+  }
+  const int groups = n / 8;
+  int nbr = (g_branches >= 2 && h0->side[0]) ? (g_branches < groups / 2 ? g_branches : groups / 2) : 1;
+  while (nbr > 1 && !h0->side[nbr - 2]) --nbr;
+  return nbr < 1 ? 1 : nbr;
+}
+static bool rider_parked(const dd_lm* q) { return q->pend_valid && q->pend_step == q->steps_since_prefill; }
+
+struct PromoteTab {
+  const float* src[GROUP_MAX_LANES];
+  float* dst[GROUP_MAX_LANES];
+  const int32_t* asrc[GROUP_MAX_LANES];
+  int32_t* adst[GROUP_MAX_LANES];
+  const DDState* st[GROUP_MAX_LANES];
+};
+__global__ void k_promote_base(PromoteTab tab, int Vpad) {
+  const int m = blockIdx.x;
+  if (tab.st[m]->done) return;
+  const float* src = tab.src[m];
+  float* dst = tab.dst[m];
+  for (int i = threadIdx.x; i < Vpad; i += 256) dst[i] = src[i];
+  if (threadIdx.x == 0) tab.adst[m][0] = tab.asrc[m][0];
+}
+
+static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, int nbr, hipStream_t st) {
+  dd_lm* h0 = lanes[0];
+  const int groups = n / 8, n_early = 8 * nbr;
+  auto begin_lanes = [&](dd_lm* const* qs, int cnt, hipStream_t s) -> int {
+    StepBeginLanes t;
+    memset(&t, 0, sizeof(t));
+    for (int m = 0; m < cnt; ++m) {
+      dd_lm* q = qs[m];
+      t.st[m] = q->state, t.leak_bits[m] = q->leak_bits, t.L[m] = q->L, t.mask_positions[m] = q->cfg.leak_mask == 2 ? 1 : 0;
+    }
+    k_step_begin_lanes<<<cnt, 256, 0, s>>>(t);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  };
+  auto masks = [&](int m0, int cnt, hipStream_t s) -> int {           // keep sets + masks of lanes m0 .. m0 + cnt - 1 (cnt <= 32)
+    MaskLaneArgs ml[32];
+    for (int i = 0; i < cnt; ++i) {
+      dd_lm* q = lanes[m0 + i];
+      ml[i] = {q->epi, q->L, q->keep, q->argmax_base, q->topk_ids, dd_rng_state_ptr(rngs ? rngs[m0 + i] : nullptr), q->drop, q->n_drop,
+               q->drop_bits, &q->state->done};
+    }
+    return dd_sample_masks_lanes(ml, cnt, h0->cfg.k_top, mprobs, K, h0->cfg.mask_mode, s);
+  };
+  RC(begin_lanes(lanes, n, st));
+  h0->bit0 = 0;
+  for (int m = 0; m < n; ++m) lanes[m]->last_K = K;
+  // the ring leaders' un-masked rows: parked by the previous step, or the classic fused pass over them
+  bool parked = true;
+  for (int m = 0; m < n_early; ++m) parked &= rider_parked(lanes[m]);
+  if (parked) {
+    PromoteTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int m = 0; m < n_early; ++m) {
+      dd_lm* q = lanes[m];
+      tab.src[m] = q->base_next, tab.dst[m] = q->base_logits, tab.asrc[m] = q->argmax_next, tab.adst[m] = q->argmax_base, tab.st[m] = q->state;
+    }
+    k_promote_base<<<n_early, 256, 0, st>>>(tab, h0->Vpad);
+    DD_CHECK_LAUNCH();
+  } else {
+    RC(lm_sweep(h0, n_early, nullptr, 0, h0->grp_logits, st, lanes));
+    RC(dd_argmax_rows(h0->grp_logits, n_early, h0->V, h0->Vpad, h0->grp_argmax, st));
+    ScatterTab tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int m = 0; m < n_early; ++m) tab.logits[m] = lanes[m]->base_logits, tab.argmax[m] = lanes[m]->argmax_base, tab.st[m] = lanes[m]->state;
+    k_scatter_base<<<n_early, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
+    DD_CHECK_LAUNCH();
+  }
+  RC(masks(0, n_early, st));
+  const bool fork = nbr >= 2;
+  if (fork) {
+    DD_HIP(hipEventRecord(h0->ev_fork, st));
+    for (int i = 0; i + 1 < nbr; ++i) DD_HIP(hipStreamWaitEvent(h0->side[i], h0->ev_fork, 0));
+  }
+  for (int br = 0; br < nbr; ++br) {
+    hipStream_t bs = br ? h0->side[br - 1] : st;
+    int ring[8], k = 0;
+    for (int g = br; g < groups; g += nbr) ring[k++] = g;
+    for (int j = 0; j < k; ++j) {
+      dd_lm* const* qs = lanes + 8 * ring[j];
+      const int pg = ring[(j + 1) % k];                    // the group whose un-masked rows ride
+      dd_lm* const* rd = lanes + 8 * pg;
+      const bool ahead = j == k - 1;                       // the ring leader's rows of the NEXT step
+      dd_lm* scratch = br ? qs[0] : h0;
+      if (ahead) RC(begin_lanes(rd, 8, bs));               // positions of the step ahead (the leader's token was voted in sweep 0)
+      RC(lm_sweep_groups(scratch, qs, 8, K, bs, rd, 8));
+      RC(group_finish(scratch, qs, 8, K, bs));
+      RC(dd_argmax_rows(scratch->grp_logits, 8, h0->V, h0->Vpad, scratch->grp_argmax, bs));
+      ScatterTab tab;
+      memset(&tab, 0, sizeof(tab));
+      for (int m = 0; m < 8; ++m) {
+        dd_lm* q = rd[m];
+        tab.logits[m] = ahead ? q->base_next : q->base_logits, tab.argmax[m] = ahead ? q->argmax_next : q->argmax_base, tab.st[m] = q->state;
+      }
+      k_scatter_base<<<8, 256, 0, bs>>>(scratch->grp_logits, scratch->grp_argmax, h0->Vpad, tab);
+      DD_CHECK_LAUNCH();
+      if (!ahead) RC(masks(8 * pg, 8, bs));
+    }
+  }
+  if (fork)
+    for (int i = 0; i + 1 < nbr; ++i) {
+      DD_HIP(hipEventRecord(h0->ev_join[i], h0->side[i]));
+      DD_HIP(hipStreamWaitEvent(st, h0->ev_join[i], 0));
+    }
+  for (int m = 0; m < n; ++m) {
+    dd_lm* q = lanes[m];
+    q->pend_valid = m < n_early, q->pend_step = q->steps_since_prefill;
+  }
+  return DD_OK;
+}
+
 static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(lanes && n >= 1 && n <= GROUP_MAX_LANES, "dd_lm_group_step: 1..%d sequences per group (got %d)", GROUP_MAX_LANES, n);
@@ -1426,6 +1618,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     DD_REQUIRE(q->n_tok_host < MAX_NEW_TOKENS, "dd_lm_group_step: token buffer full");
     DD_REQUIRE(K == 0 || q->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || (rngs && rngs[m]), "dd_lm_group_step: sequence %d needs an rng", m);
   }
+  if (const int nbr = rider_branches(lanes, n, K)) return group_step_rider(lanes, n, mprobs, K, rngs, nbr, st);
   {
     StepBeginLanes t;
     memset(&t, 0, sizeof(t));
@@ -1720,7 +1913,7 @@ static int decode_step_queued(dd_lm* h, const double* mprobs, int K, dd_rng* rng
     return DD_ESTATE;
   }
   DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
-  unsigned long long key = 1469598103934665603ull;
+  unsigned long long key = 1469598103934665603ull ^ (g_tune_epoch * 0x9e3779b97f4a7c15ull);
   auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
   mix((unsigned long long)K);
   for (int k = 0; k < K; ++k) {
@@ -1843,7 +2036,7 @@ extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_
   DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
   DD_REQUIRE(h->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || rng, "dd_lm_step: an rng is required");
   const bool use_graph = g_use_graph && h->steps_since_prefill >= 1;
-  unsigned long long key = 1469598103934665603ull;
+  unsigned long long key = 1469598103934665603ull ^ (g_tune_epoch * 0x9e3779b97f4a7c15ull);
   auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
   mix(0x73796e63ull);
   mix((unsigned long long)K);
@@ -1925,7 +2118,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   }
   dd_lm* h0 = lanes[0];
   RC(group_side_stream(h0));
-  unsigned long long key = 1469598103934665603ull;
+  unsigned long long key = 1469598103934665603ull ^ (g_tune_epoch * 0x9e3779b97f4a7c15ull);
   auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
   mix(0x67726f7570ull + (unsigned long long)n + ((unsigned long long)g_branches << 40));
   mix((unsigned long long)K);
@@ -1945,11 +2138,19 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   }
   mix((unsigned long long)ddk_attn_grid_tiles(max_T, h0->T_cap));
   mix((unsigned long long)(uintptr_t)st);
+  // rider form: which ring leaders have their un-masked rows parked, and the grids of the rows computed a step ahead
+  const int rider_nbr = rider_branches(lanes, n, K);
+  mix(0x7269646572ull + (unsigned long long)rider_nbr);
+  for (int m = 0; m < 8 * rider_nbr; ++m) {
+    mix(rider_parked(lanes[m]) ? 1ull : 2ull);
+    mix((unsigned long long)ddk_attn_grid_tiles(lanes[m]->T_host + 1, lanes[m]->T_cap));
+  }
   auto advance = [&]() {
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
       q->last_K = K, q->T_host += 1, q->n_tok_host += 1, q->steps_since_prefill++;
       if (q->cfg.leak_mask && K > 0) q->have_leak = true;
+      q->pend_valid = m < 8 * rider_nbr, q->pend_step = q->steps_since_prefill;
     }
   };
   for (auto& g : h0->graphs)
@@ -2103,6 +2304,7 @@ extern "C" int dd_lm_set_next_token(dd_lm* h, int32_t token, void* stream_) {
   DD_REQUIRE(h && token >= 0 && token < h->V, "dd_lm_set_next_token: bad token %d", token);
   k_set_token<<<1, 64, 0, (hipStream_t)stream_>>>(h->state, token);
   DD_CHECK_LAUNCH();
+  h->pend_valid = false;
   return DD_OK;
 }
 
@@ -2183,6 +2385,7 @@ extern "C" double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K) {
 // 13 = slice-resident 16 / 32 / 64-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits), 14 = process default of the
 // speculation policy (dd_lm_set_speculation), 15 / 16 = block order / big-block threshold of the prefill GEMM (same bits).
 extern "C" int dd_set_tuning(int key, int value) {
+  dd_engine_bump_epoch();
   DD_REQUIRE(key == 8 || key == 11 || (key >= 13 && key <= 16), "dd_set_tuning: unknown key %d (8, 11, 13, 14, 15, 16)", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 11) dd_engine_set_extend_rows(value);

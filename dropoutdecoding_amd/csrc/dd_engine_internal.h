@@ -5,7 +5,8 @@
 #include "dd_lm_kernels.h"
 
 #define MAX_MEMBERS DD_MAX_MEMBERS
-#define GROUP_ROWS 64     // rows of the widest decode pass: the members of eight sequences, or the un-masked rows of 64
+#define GROUP_ROWS 72     // rows of the widest decode pass: the members of eight sequences + eight un-masked rows riding along (nine operand planes)
+#define GROUP_PLANES (GROUP_ROWS / 8)
 #define GROUP_MAX_LANES 64
 #define KV_ROWS 64        // new K/V rows kept per layer: 16 members, or the base rows of up to 64 lanes (group step)
 #define MAX_NEW_TOKENS 8192
@@ -26,6 +27,12 @@ struct dd_lm {
   dd_lm* wsrc = nullptr;       // lane created by dd_lm_create_shared: weights (and rope tables) belong to this handle
   float* grp_logits = nullptr; // [GROUP_MAX_LANES][Vpad] base-pass logits of a group step (this handle is the group's first lane)
   int32_t* grp_argmax = nullptr;
+  // rider (group_step_rider): the un-masked row of this sequence's NEXT step, computed ahead while it rode in another group's member
+  // sweep — logits / argmax parked here until the step they belong to starts; valid while pend_step == steps_since_prefill
+  float* base_next = nullptr;
+  int32_t* argmax_next = nullptr;
+  bool pend_valid = false;
+  int pend_step = -1;
   DDState* chunk_states = nullptr;   // [32] positions of the rows of a short prompt chunk (dd_lm_prefill_extend)
   float *chunk_k = nullptr, *chunk_v = nullptr;   // [32][kv_dim] roped K / V rows of the chunk, one layer at a time
   const float *commit_k = nullptr, *commit_v = nullptr;   // K == 0 group step: this lane's base row in the leader's scratch
@@ -96,6 +103,7 @@ struct dd_lm {
   // and these, and run concurrently
   hipStream_t side[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  float *part_o_ride = nullptr, *part_ml_ride = nullptr;   // flash-decoding partials of the riding rows (their attention shares a launch with the members')
   // tensor-parallel shard (dd_tp.hip): this handle holds the q/k/v/gate/up columns and the o/down rows of rank tp_rank of
   // tp_world (its dims above are the LOCAL ones); the row-parallel matrices write partial sums into this rank's slot of the
   // gather buffer [tp_world][rows][d] and every rank adds the slots in rank order
@@ -112,6 +120,8 @@ int dd_engine_prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float
 int dd_engine_prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, int span_len, hipStream_t st);
 int dd_engine_step_keep(dd_lm* h, const int32_t* gate, hipStream_t st);
 int dd_engine_step_begin(dd_lm* h, hipStream_t st);          // k_step_begin: the step's RoPE position
+void dd_engine_bump_epoch();                 // every tuning call: graph keys carry the epoch, a step captured under other settings is not replayed
+unsigned long long dd_engine_epoch();
 int dd_engine_tp_alloc(dd_lm* h, float** p, size_t floats);  // device memory owned (and released) by the handle
 // one packed sweep of nb rows through all layers + lm_head (dd_engine.hip)
 int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st, dd_lm* const* lanes = nullptr,

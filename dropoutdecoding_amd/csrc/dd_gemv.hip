@@ -388,7 +388,7 @@ struct GroupsPre {
 template <int EPI, int TILES, int NG>
 __device__ __forceinline__ void groups_prefetch(const GemvArgs& a, int tile0, GroupsPre<TILES>& p) {
   const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
-  const bool erow = et < 128 * NG && ml < a.nb;
+  const bool erow = et < 128 * NG && ml < a.rows_live(eg);
   p.pre0 = p.pre1 = 0.f;
 #pragma unroll
   for (int tt = 0; tt < TILES; ++tt) p.rope_c[tt] = p.rope_s[tt] = 0.f;
@@ -427,7 +427,7 @@ __device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const
                                                 float* ssq_sh, TS tile_sum) {
   const int tile0 = wg * TILES;
   const int et = threadIdx.x, eg = et >> 7, ml = et & 7, em = (eg << 3) + ml, en = (et & 127) >> 3;
-  const bool erow = et < 128 * NG && ml < a.nb;
+  const bool erow = et < 128 * NG && ml < a.rows_live(eg);
   if (EPI == EPI_STORE) {
     if (erow) {
       float y = tile_sum(0, en);
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(32 * NG) void k_gemv_finish4(GemvArgs a, const floa
   __shared__ f32x4_t yq_sh[EPI == EPI_QKV ? TILES * 32 * NG : 1];   // rotary tiles: a thread needs its partner quad's sums (columns n ^ 8)
   const int wg = blockIdx.x, tile0 = wg * TILES;
   const int t = threadIdx.x, eg = t >> 5, c4 = (t & 31) >> 3, ml = t & 7, em = (eg << 3) + ml, n0 = c4 * 4;
-  const bool erow = ml < a.nb;
+  const bool erow = ml < a.rows_live(eg);
   const size_t ps = ((size_t)n_sets * TILES * NG) << 7;
   // one batch of requests: the thread's partial sums, rstd, the epilogue's operands
   f32x4_t v[TILES][NP];
@@ -886,18 +886,18 @@ static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   return DD_OK;
 }
 // (16 instead of 8 weight requests in flight per wave measured the same or slower: qkv 26.3 vs 25.4 us, gate/up 38.4 vs 38.0)
-template <int U, int MAXG, int TAG>
+template <int NG, int U, int MAXG, int TAG>
 static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
-  constexpr size_t smem = (size_t)16 * 8 * 1024;
+  constexpr size_t smem = (size_t)16 * NG * 1024;
   static bool attr = false;
   if (!attr) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, U, 16, MAXG, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<8, U, 16, MAXG, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  NOTE_KERNEL("k_gemv_slices_seq<8, %d, 16, %d, %d, %d>", U, MAXG, wf ? 1 : 0, TAG);
-  if (wf) k_gemv_slices_seq<8, U, 16, MAXG, 1, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-  else k_gemv_slices_seq<8, U, 16, MAXG, 0, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG);
+  if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 
@@ -999,7 +999,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
         // slice pairs, one slice resident at a time (see gate/up below): two tiles per wave; tuning key 17 < 0: single slices (A/B)
         sa.G = g_exp_G[0] ? g_exp_G[0] : nt / 16;
         DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
-        RC_(launch_slices_seq<8, 2, EPI_QKV>(sa, a.wf, st));
+        RC_(launch_slices_seq<8, 8, 2, EPI_QKV>(sa, a.wf, st));
         launch_finish<EPI_QKV, 1, 8, 4>(a, nt, st);
       } else {
         sa.G = g_exp_G[0] > 0 ? g_exp_G[0] : (nt + 31) / 32;
@@ -1030,7 +1030,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
         // (2.7 tiles per wave: uneven) 28.6, 86 (two tiles, 1.3 rounds) 29.1.  Tuning key 19 < 0: single slices (A/B)
         sa.G = g_exp_G[2] ? g_exp_G[2] : (nt + 23) / 24;
         DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
-        RC_(launch_slices_seq<8, 3, EPI_SILU>(sa, a.wf, st));
+        RC_(launch_slices_seq<8, 8, 3, EPI_SILU>(sa, a.wf, st));
         launch_finish<EPI_SILU, 2, 8, 4>(a, a.n_tiles, st);
       } else {
         sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 42) / 43;
@@ -1065,11 +1065,63 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
   return DD_OK;
 }
 
+// Nine operand planes (72 rows): the members of eight sequences + ONE plane of un-masked rows that ride along (dd_engine.hip,
+// "rider": the base rows of the partner group's next pass, so that a group step needs no sweep of its own for them).  The 64-row
+// kernels with one more plane: a slice of K = 4096 is 144 KiB of LDS, one workgroup per CU as there; bf16 / fp16 tiles only, the
+// 7B families' shapes only (the engine does not plan riders otherwise).
+static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
+  if (a.fp8) return SLICES_UNSUPPORTED;
+  const int spw = a.S / GEMV_WAVES;
+  const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;
+  if (!(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
+  SliceArgs sa;
+  sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
+  sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
+  sa.rstd_out = a.part + a.part_floats;
+  const size_t need8 = (size_t)8 * nt * 9 * 128;
+  if (a.part_floats < need8) return SLICES_UNSUPPORTED;
+  sa.n_groups = nt;
+  if (epi == EPI_STORE) {
+    if (spw != 16) return SLICES_UNSUPPORTED;
+    sa.G = (nt + 31) / 32;
+    RC_(launch_slices_k<1, 9, 8, 16, 16, 1, EPI_STORE>(sa, a.wf, st));
+    launch_finish<EPI_STORE, 1, 9, 8>(a, nt, st);
+  } else if (epi == EPI_QKV) {
+    if (spw != 16 || (nt % 16) != 0 || nt / 16 * 4 > 256) return SLICES_UNSUPPORTED;
+    sa.G = nt / 16;
+    RC_(launch_slices_seq<9, 8, 2, EPI_QKV>(sa, a.wf, st));
+    launch_finish<EPI_QKV, 1, 9, 4>(a, nt, st);
+  } else if (epi == EPI_RESID) {
+    if (spw == 16) {
+      sa.G = (nt + 15) / 16;
+      RC_(launch_slices_k<1, 9, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
+    } else {
+      sa.G = (nt + 7) / 8;
+      if (spw == 43) RC_(launch_slices_k<1, 9, 8, 43, 8, 1, EPI_RESID>(sa, a.wf, st));
+      else RC_(launch_slices_k<1, 9, 8, 56, 8, 1, EPI_RESID>(sa, a.wf, st));
+    }
+    launch_finish<EPI_RESID, 1, 9, 8>(a, nt, st);
+  } else {
+    if (spw != 16 || 4 * ((nt + 23) / 24) > 256) return SLICES_UNSUPPORTED;
+    sa.G = (nt + 23) / 24;
+    RC_(launch_slices_seq<9, 8, 3, EPI_SILU>(sa, a.wf, st));
+    launch_finish<EPI_SILU, 2, 9, 4>(a, a.n_tiles, st);
+  }
+  return DD_OK;
+}
+
 int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv_groups: K=%d must be a multiple of 256", a.S * 32);
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv_groups: nb=%d rows per group", a.nb);
   DD_REQUIRE(!a.fp8 || a.wscale, "gemv_groups: fp8 weights need row scales");
-  DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4 || a.n_groups == 8, "gemv_groups: %d groups (2, 4 or 8)", a.n_groups);
+  DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4 || a.n_groups == 8 || a.n_groups == 9, "gemv_groups: %d groups (2, 4, 8 or 9)", a.n_groups);
+  if (a.n_groups == 9) {
+    int rs = a.part ? try_slices9(epi, a, st) : SLICES_UNSUPPORTED;
+    DD_REQUIRE(rs != SLICES_UNSUPPORTED, "gemv_groups: no nine-plane kernel for this matrix (K = %d, %d tiles, fp8 %d)", a.S * 32, a.n_tiles, a.fp8);
+    if (rs != DD_OK) return rs;
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   if (g_gemv_slices && a.part) {
     int rs = a.n_groups == 2 ? try_slices<2>(epi, a, st) : (a.n_groups == 4 ? try_slices<4>(epi, a, st) : try_slices<8>(epi, a, st));
     if (rs != SLICES_UNSUPPORTED) {

@@ -124,22 +124,24 @@ struct GemvArgs {
   const float* rope_cos; // [max_seq][64]
   const float* rope_sin;
   const DDState* state;
-  const DDState* state_rows[64];  // lanes: row m takes its position from state_rows[m] (null entries: `state`)
-  // multi-group passes (ddk_gemv_groups): rows 8g..8g+7 are group g (2, 4 or 8 groups) — group g's operand plane is plane g
+  const DDState* state_rows[72];  // lanes: row m takes its position from state_rows[m] (null entries: `state`)
+  // multi-group passes (ddk_gemv_groups): rows 8g..8g+7 are group g (2, 4, 8 or 9 groups) — group g's operand plane is plane g
   // of `xop` (and of xop_next: plane stride S_next * 64 u32x4); its logits / new K/V rows may live in another sequence's
   // buffers
   int n_groups;
-  float* out_g[8];      // EPI_STORE rows of group g (null: out + 8 g * ldo)
-  float* knew_g[8];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
-  float* vnew_g[8];
+  int nb_rider;         // n_groups == 9: live rows of plane 8 (the riding un-masked rows: one per sequence, not one per member); 0: nb
+  __host__ __device__ int rows_live(int plane) const { return (plane == 8 && nb_rider) ? nb_rider : nb; }
+  float* out_g[9];      // EPI_STORE rows of group g (null: out + 8 g * ldo)
+  float* knew_g[9];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
+  float* vnew_g[9];
   int S_next;           // K / 32 of the GEMV that consumes xop_next
   int wf;                   // 16-bit type of W and of the packed operands: 0 bf16, 1 fp16 (engines created with weight_format 2)
   const int32_t* skip_if;   // optional (k_gemv): *skip_if != 0 -> the launch returns at once (fallback sweep of a speculative step)
   float* part;          // scratch for the slice-resident path (dd_gemv_slices.h): partial sums, or nullptr (then k_gemv_groups runs)
-  size_t part_floats;   // capacity; 64 more floats behind it hold rstd of the operand rows
+  size_t part_floats;   // capacity; 72 more floats behind it hold rstd of the operand rows
 };
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st);
-int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2, 4 or 8) groups of up to 8 rows
+int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st);   // the same for a.n_groups (2, 4, 8 or 9) groups of up to 8 rows
 // tensor-parallel seams (dd_tp.hip): slots of `gather` [W][...] added in rank order
 int ddk_tp_finish(const float* gather, int W, size_t slot_floats, int nb, float* x, int N, const float* normw, u32x4_t* xop_next,
                   float* ssq_out, int ssq_ld, int wf, hipStream_t st);      // decode rows: + k_gemv's EPI_RESID epilogue
@@ -193,6 +195,7 @@ struct AttnDecodeArgs {
   int lane_span_start[16], lane_span_len[16];
 };
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+int ddk_attn_decode_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, hipStream_t st);   // member pass of 8 sequences + riding rows, one launch
 int ddk_attn_grid_tiles(int T, int T_cap);   // tiles the decode attention is launched with for a prefix of T keys
 
 // ---- prefill (M rows) -------------------------------------------------------------------------
@@ -268,10 +271,10 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStr
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
                    float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if = nullptr, int wf = 0);
 struct EmbedLanes {
-  const DDState* state[64];   // row m embeds the current token of this sequence (null: row unused)
+  const DDState* state[72];   // row m embeds the current token of this sequence (null: row unused)
 };
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
-                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf = 0);   // rows = 8, 16, 32 or 64
+                         u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf = 0);   // rows = 8, 16, 32, 64 or 72
 int ddk_embed_tokens(const uint16_t* embed, int d, const int32_t* tokens, int n, float* x, hipStream_t st, int wf = 0);
 struct CommitLanes {       // winners of up to 8 sequences appended to their caches in one launch
   const float* knew[8];

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1024) void k_embed_rows_lanes(const uint16_t* __res
 }
 int ddk_embed_rows_lanes(const uint16_t* embed, int d, const EmbedLanes& lanes, int rows, float* x, const float* normw,
                          u32x4_t* xop, float* ssq, int ssq_ld, hipStream_t st, int wf) {
-  DD_REQUIRE(rows == 8 || rows == 16 || rows == 32 || rows == 64, "embed_rows_lanes: %d rows (8, 16, 32 or 64)", rows);
+  DD_REQUIRE(rows == 8 || rows == 16 || rows == 32 || rows == 64 || rows == 72, "embed_rows_lanes: %d rows (8, 16, 32, 64 or 72)", rows);
   k_embed_rows_lanes<<<rows, 1024, 0, st>>>(embed, d, lanes, rows, x, normw, xop, ssq, ssq_ld, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;

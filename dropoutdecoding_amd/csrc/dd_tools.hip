@@ -31,8 +31,8 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
   hipStream_t st = (hipStream_t)stream_;
   const bool stream_only = which >= 8;      // 8 + kind: the slice-resident path's streaming kernel alone (no finishing kernel)
   if (stream_only) which -= 8;
-  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16 || nb == 32 || nb == 64) && iters >= 1,
-             "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 / 32 / 64 = the two- / four- / eight-group kernel)");
+  DD_REQUIRE(h && mean_ms && bytes_per_launch && which >= 0 && which <= 3 && ((nb >= 1 && nb <= 8) || nb == 16 || nb == 32 || nb == 64 || nb == 72) && iters >= 1,
+             "dd_lm_time_gemv: bad arguments (nb 1..8, or 16 / 32 / 64 / 72 = the two- / four- / eight- / nine-group kernel)");
   struct Restore {
     ~Restore() { ddk_set_slices_only(0); }
   } restore_;
@@ -97,9 +97,12 @@ extern int g_exp_G[4];
 extern int g_attn16_tpw, g_attn16_full, g_finish4;
 void dd_engine_set_pairs(int on);
 void dd_engine_set_branches(int n);
+void dd_engine_set_rider(int on);
+void dd_engine_set_ride_beside(int on);
 extern "C" int dd_tools_set_tuning(int key, int value) {
+  dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24),
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || key == 26 || key == 27,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -109,6 +112,8 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 22) g_attn16_full = value;
   else if (key == 23) dd_engine_set_branches(value);
   else if (key == 24) g_finish4 = value;
+  else if (key == 26) dd_engine_set_rider(value);
+  else if (key == 27) dd_engine_set_ride_beside(value);
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }

@@ -304,7 +304,7 @@ extern "C" int dd_lm_tp_decode_step(dd_lm* const* ranks, int n, const double* mp
     graphable = ranks[r]->prefilled && ranks[r]->steps_since_prefill >= 1 && ranks[r]->T_host + 1 < ranks[r]->T_cap &&
                 ranks[r]->n_tok_host < MAX_NEW_TOKENS;
   if (!graphable) return tp_step_body(ranks, n, mprobs, K, rngs, stream_);
-  unsigned long long key = 1469598103934665603ull;
+  unsigned long long key = 1469598103934665603ull ^ (dd_engine_epoch() * 0x9e3779b97f4a7c15ull);
   auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
   mix(0x7470ull + (unsigned long long)n);
   mix((unsigned long long)K);

@@ -8,7 +8,7 @@ from dropoutdecoding_amd import lm
 
 torch.cuda.set_device(0)
 from dropoutdecoding_amd import _lib
-row_sets = (8, 16, 32, 64)
+row_sets = (8, 16, 32, 64, 72)
 for kv in sys.argv[1:]:                      # key=value: dd_tools_set_tuning; rows=64: only that pass width
     k_, v_ = kv.split("=")
     if k_ == "rows":
