@@ -1088,12 +1088,15 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
     launch_finish<EPI_STORE, 1, 9, 8>(a, nt, st);
   } else if (epi == EPI_QKV) {
     if (spw != 16 || (nt % 16) != 0 || nt / 16 * 4 > 256) return SLICES_UNSUPPORTED;
-    sa.G = nt / 16;
+    sa.G = g_exp_G[0] > 0 ? g_exp_G[0] : nt / 16;
+    DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
     RC_(launch_slices_seq<9, 8, 2, EPI_QKV>(sa, a.wf, st));
     launch_finish<EPI_QKV, 1, 9, 4>(a, nt, st);
   } else if (epi == EPI_RESID) {
     if (spw == 16) {
-      sa.G = (nt + 15) / 16;
+      // two tiles per wave on 8 * 16 = 128 workgroups at N = 4096: alone 14.7 us against 11.2 with one tile per wave on 256, but inside
+      // the step, beside the other branch's kernels, the half-chip grid wins (20.9 vs 21.4 ms per 32-lane step; tuning key 18)
+      sa.G = g_exp_G[1] > 0 ? g_exp_G[1] : (nt + 15) / 16;
       RC_(launch_slices_k<1, 9, 8, 16, 16, 1, EPI_RESID>(sa, a.wf, st));
     } else {
       sa.G = (nt + 7) / 8;
@@ -1103,7 +1106,8 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
     launch_finish<EPI_RESID, 1, 9, 8>(a, nt, st);
   } else {
     if (spw != 16 || 4 * ((nt + 23) / 24) > 256) return SLICES_UNSUPPORTED;
-    sa.G = (nt + 23) / 24;
+    sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 23) / 24;
+    DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
     RC_(launch_slices_seq<9, 8, 3, EPI_SILU>(sa, a.wf, st));
     launch_finish<EPI_SILU, 2, 9, 4>(a, a.n_tiles, st);
   }
