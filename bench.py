@@ -7,7 +7,7 @@
         bench.py --gpus N --steps K --warmup W
     python bench.py --config 4|5          # BASELINE configs 4 / 5 (InstructBLIP-Vicuna-7B, LLaVA-NeXT-Mistral-7B fp8) at engine level
 
-One "step" = one batch of images (default 32 per GPU, lanes over one set of weights) through the drop-in class's `generate()` path: vision
+One "step" = one batch of images (default 64 per GPU, lanes over one set of weights) through the drop-in class's `generate()` path: vision
 front-end (CLIP-L/14-336; config 4: EVA ViT-g + Q-Former; config 5: CLIP over 5 anyres tiles) + LM prefill (576 visual + 32 prompt
 positions for LLaVA-1.5) + uncertainty scorer + `--n-new` (128) decoded tokens per image, each by the K=8 ensemble step (un-masked
 pass, masks, 8 masked members in one packed sweep, vote).  Weights are random-init tensors of the real shapes (no network /
@@ -235,7 +235,7 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
         m8, b8 = eng.time_gemv(2, rows8, 96)
         kinds["gate_up_8_rows"] = round(b8 / (m8 * 1e-3) / 1e9, 1)
         rows_cmp = {}
-        for r_ in (16, 32, 64):        # the same matrix at the other pass widths (streaming kernel alone)
+        for r_ in (16, 32, 64) + ((72,) if dom_rows == 72 else ()):        # the same matrix at the other pass widths (streaming kernel alone)
             mr = eng.time_gemv(2 + 8, r_, 96)[0]
             rows_cmp[str(r_)] = {"us": round(mr * 1e3, 2), "frac": round(by / (mr * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "us_per_8_rows": round(mr * 1e3 * 8 / r_, 2)}
     sweep_ms = eng.time_sweep(rows8, 5)
@@ -243,7 +243,9 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
     eng.close()
     prof = committed_profile(kernel)
     achieved = by / (ms * 1e-3) / 1e9
-    what = (f"{kernel} (gate/up decode GEMV of a {dom_rows}-row pass = the members of {dom_rows // 8} sequences: streams the matrix once, K in slices "
+    rows_what = ("the members of 8 sequences + the un-masked rows of 8 more riding in a ninth operand plane" if dom_rows == 72
+                 else f"the members of {dom_rows // 8} sequences")
+    what = (f"{kernel} (gate/up decode GEMV of a {dom_rows}-row pass = {rows_what}: streams the matrix once, K in slices "
             "resident in LDS; its finishing kernel k_gemv_finish4 adds the slices' partial sums and applies SiLU*up)") if wide \
         else f"{kernel} (gate/up decode GEMV, {rows8} rows)"
     return {"bound": "hbm", "kernel": what, "kernel_name": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -305,7 +307,7 @@ def main() -> int:
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
     ap.add_argument("--images-per-gpu", type=int, default=None,
                     help="images decoded concurrently per GPU (lanes over one set of weights, 1..64); 1 = the reference's "
-                         "one-image-at-a-time loop; default 32 (config 5: 8)")
+                         "one-image-at-a-time loop; default 64 (config 5: 8)")
     ap.add_argument("--no-batch-tower", action="store_true", help="one vision-tower call per image instead of one per 16 images (A/B)")
     ap.add_argument("--prefill-chunk", type=int, default=None, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (product switches)")
@@ -348,7 +350,7 @@ def main() -> int:
     ddcfg.settings["voting_numbers"] = list(probs)
     K_eff = 0 if args.original else len(probs)
     if args.images_per_gpu is None:
-        args.images_per_gpu = 8 if args.config == 5 else 32
+        args.images_per_gpu = 8 if args.config == 5 else 64
     if args.prefill_chunk is None:
         args.prefill_chunk = 2 if args.config == 5 else 16
     B = 1 if args.mode == "kshard" else max(1, min(64, args.images_per_gpu))
@@ -480,6 +482,11 @@ def main() -> int:
     rows8 = min(max(K_eff, 1), 8)
     wide = B > 1 and 1 <= K_eff <= 8
     dom_rows = (64 if B >= 8 else (32 if B >= 4 else 16)) if wide else rows8
+    # rider form of the group step (csrc/dd_engine.hip): from 16 sequences on (whole groups of eight, 16-bit weights) the un-masked rows ride in
+    # a ninth operand plane of the member sweeps
+    rider = wide and B >= 16 and B % 8 == 0 and wname != "fp8"
+    if rider:
+        dom_rows = 72
     roof = None
     if rank == 0 and not args.no_roofline:
         try:
@@ -512,8 +519,10 @@ def main() -> int:
         wl = (f"{model_name} Dropout Decoding, {B} synthetic " + ({4: "224x224", 5: "672x672 (anyres: 5 tiles of 336x336)"}.get(args.config, "336x336") + " image(s)") + f" per step and GPU -> each {L} visual tokens + "
               f"{prompt_len}-token prompt (prefill {T0}), {args.n_new} decoded tokens each (EOS ignored), K={K_eff} voting_numbers={list(probs) if K_eff else []}, "
               f"random-init weights of the real shapes ({wname} weights, fp32 activations, {kv_note})"
-              + (f"; the {B} are independent sequences (own KV cache and rng stream, results identical to decoding each alone) whose un-masked passes "
-                 f"share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep"
+              + (f"; the {B} are independent sequences (own KV cache and rng stream, results identical to decoding each alone) whose "
+                 + ("member passes run 8 sequences (64 rows) per sweep over the weights, each sweep carrying the un-masked rows of 8 other sequences "
+                    f"in a ninth operand plane (72 rows; no sweep of their own: {B // 8} sweeps per step)" if rider else
+                    f"un-masked passes share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep")
                  + "; the next batch's vision front-end + prefill overlap the current batch's decode on a second stream" if B > 1 else ""))
         metric = {1: f"decoded tokens/sec {model_name} --original", 2: f"decoded tokens/sec {model_name} K=4 ensemble", 3: f"decoded tokens/sec {model_name} K=8 ensemble",
                   4: f"decoded tokens/sec {model_name} K=8 ensemble", 5: f"decoded tokens/sec {model_name} K=8 ensemble, fp8 weights"}[args.config]

@@ -1255,6 +1255,10 @@ int dd_engine_use_graph() { return g_use_graph; }
 void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
 static int g_branches = 2;     // dd_tools_set_tuning key 23: member sweeps of a group step that run concurrently (1..4)
 void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }
+// the same for the rider form (rings of at least two groups each): 64 lanes 42.5 / 38.2 / 36.9 ms per step with 2 / 3 / 4 branches
+// (tools/rider_ab.py), where the classic form gained nothing beyond two; dd_tools_set_tuning key 28
+static int g_rider_branches = 4;
+void dd_engine_set_rider_branches(int n) { g_rider_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }
 static int g_ride_beside = 1;    // dd_tools_set_tuning key 27: the riding rows' attention in the members' launches (0: launches of its own)
 void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 
@@ -1480,7 +1484,7 @@ static int rider_branches(dd_lm* const* lanes, int n, int K) {
       return 0;
   }
   const int groups = n / 8;
-  int nbr = (g_branches >= 2 && h0->side[0]) ? (g_branches < groups / 2 ? g_branches : groups / 2) : 1;
+  int nbr = (g_rider_branches >= 2 && h0->side[0]) ? (g_rider_branches < groups / 2 ? g_rider_branches : groups / 2) : 1;
   while (nbr > 1 && !h0->side[nbr - 2]) --nbr;
   return nbr < 1 ? 1 : nbr;
 }
@@ -2093,9 +2097,10 @@ extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_
 
 // the second branch's stream and its fork / join events, created outside any capture
 static int group_side_stream(dd_lm* h0) {
-  if (g_branches < 2) return DD_OK;
+  const int want = g_branches > g_rider_branches ? g_branches : g_rider_branches;
+  if (want < 2) return DD_OK;
   if (!h0->ev_fork) DD_HIP(hipEventCreateWithFlags(&h0->ev_fork, hipEventDisableTiming));
-  for (int i = 0; i + 1 < g_branches; ++i)
+  for (int i = 0; i + 1 < want; ++i)
     if (!h0->side[i]) {
       DD_HIP(hipStreamCreateWithFlags(&h0->side[i], hipStreamNonBlocking));
       DD_HIP(hipEventCreateWithFlags(&h0->ev_join[i], hipEventDisableTiming));
@@ -2120,7 +2125,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   RC(group_side_stream(h0));
   unsigned long long key = 1469598103934665603ull ^ (g_tune_epoch * 0x9e3779b97f4a7c15ull);
   auto mix = [&](unsigned long long v) { key = (key ^ v) * 1099511628211ull; };
-  mix(0x67726f7570ull + (unsigned long long)n + ((unsigned long long)g_branches << 40));
+  mix(0x67726f7570ull + (unsigned long long)n + ((unsigned long long)g_branches << 40) + ((unsigned long long)g_rider_branches << 44));
   mix((unsigned long long)K);
   for (int k = 0; k < K; ++k) {
     unsigned long long bits;

@@ -693,6 +693,14 @@ class EngineGroup:
                 if idle is None or not idle():
                     time.sleep(0.0002)                  # far enough ahead of the GPU
                 continue
+            # whole groups of eight keep the rider form of the step (csrc/dd_engine.hip group_step_rider): sequences that ended at an EOS
+            # stay in the line-up while they fill the last group — their steps are no-ops on the device (DDState::done: nothing is
+            # written, nothing drawn from their rng streams)
+            if eos_set and len(active) >= 16 and len(active) % 8:
+                ended = [i for i in range(len(E)) if i not in active and any(t in eos_set for t in seen[i])]
+                need = -len(active) % 8
+                if len(ended) >= need:
+                    active = sorted(active + ended[:need])
             self.decode_step(mprobs, dropout=dropout, active=active)
         out = []
         for e in E:

@@ -165,3 +165,43 @@ def test_rider_step_with_sequences_that_end_and_line_ups_that_change(E, T):
         np.testing.assert_array_equal(x, y)
     for e in reversed(engines):
         e.close()
+
+
+def test_generate_keeps_whole_groups_while_sequences_end(E, T):
+    """EngineGroup.generate with EOS ids: sequences that ended stay in the line-up as long as they fill the last group of eight (their steps
+    are no-ops on the device), so the step keeps its rider form; every sequence's tokens and rng stream are those of the classic form and
+    of the sequence generated alone."""
+    d = 4096
+    cfg = E.LMConfig(2048, d, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
+    L, n, n_new = 24, 24, 9
+    engines = _group(E, T, cfg, n, "llava-1.5", L)
+    gen = torch.Generator().manual_seed(13)
+    embs = [(torch.randn(L + 6 + (i % 5), d, generator=gen) * 0.5).cuda() for i in range(n)]
+    spans = [(2 + (i % 3), L) for i in range(n)]
+
+    def run(rider, eos):
+        T.dd_tools_set_tuning(26, 1 if rider else 0)
+        for i, e in enumerate(engines):
+            e.rng.manual_seed(50 + i)
+            e.prefill(embs[i], *spans[i])
+        toks = E.EngineGroup(engines).generate(n_new, eos=eos, mprobs=K8, lookahead=3)
+        tails = [e.rng.rand(8).cpu().numpy().copy() for e in engines]
+        T.dd_tools_set_tuning(26, 1)
+        return toks, tails
+
+    free, _ = run(False, None)
+    eos = sorted({free[2][2], free[13][4], free[20][6]})          # ends lanes 2, 13, 20 (and whoever else emits one of them) at different steps
+    want, wtails = run(False, eos)
+    lens = sorted(len(t) for t in want)
+    assert lens[0] < n_new and lens[-1] == n_new, lens
+    got, gtails = run(True, eos)
+    assert got == want
+    for a, b in zip(gtails, wtails):
+        np.testing.assert_array_equal(a, b)
+    for li in (2, 13, 23):
+        e = engines[li]
+        e.rng.manual_seed(50 + li)
+        e.prefill(embs[li], *spans[li])
+        assert e.generate(n_new, eos=eos, mprobs=K8) == want[li], f"lane {li} alone"
+    for e in reversed(engines):
+        e.close()

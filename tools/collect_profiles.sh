@@ -3,7 +3,7 @@
 # (--no-roofline: the isolated-kernel timing leg would mix its back-to-back launches into the in-sweep averages)
 # stats: rocprofv3 kernel trace + stats of a SHORT bench run (32 lanes, 32 new tokens per image: the per-kernel durations
 #        do not depend on the number of tokens; the full default run produces millions of trace records);
-# pmc:   three separate --pmc passes (one counter each, never combined with other trace domains) over 4 tokens.
+# pmc:   three separate --pmc passes (one counter each, never combined with other trace domains) over 3 tokens of 16 lanes (one rider ring).
 # Raw output is deleted after the summaries are extracted (gpurun_out/ is capped at 64 MiB).
 R=${1:-r02}
 WHAT=${2:-stats}
@@ -21,7 +21,7 @@ if [ "$WHAT" = stats ]; then
 else
   for c in FETCH_SIZE:fetch WRITE_SIZE:write SQ_VALU_MFMA_BUSY_CYCLES:mfma; do
     rm -rf /tmp/${R}_pmc_${c##*:}
-    timeout 500 rocprofv3 --pmc ${c%%:*} --kernel-trace --output-format csv -d /tmp/${R}_pmc_${c##*:} -- python3 bench.py --steps 1 --warmup 0 --n-new 3 --images-per-gpu 8 --no-cpu-baseline --no-roofline --single-images 0 > $OUT/${R}_pmc_${c##*:}.log 2>&1
+    timeout 500 rocprofv3 --pmc ${c%%:*} --kernel-trace --output-format csv -d /tmp/${R}_pmc_${c##*:} -- python3 bench.py --steps 1 --warmup 0 --n-new 3 --images-per-gpu 16 --no-cpu-baseline --no-roofline --single-images 0 > $OUT/${R}_pmc_${c##*:}.log 2>&1
     echo "pmc ${c%%:*} rc=$?"
   done
   python3 tools/pmc_summary.py /tmp/${R}_pmc_fetch /tmp/${R}_pmc_write /tmp/${R}_pmc_mfma > $OUT/${R}_pmc_summary.json

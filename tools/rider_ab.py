@@ -41,4 +41,4 @@ for rep in range(2):
             first = toks
         print(f"{stg}: {ms:.2f} ms per group step of {B} lanes; tokens {'same' if toks == first else 'DIFFER'}", flush=True)
         for k, v in kv:          # back to the defaults
-            L.dd_tools_set_tuning(k, {26: 1, 27: 1, 22: 1, 23: 2, 21: 0}.get(k, 0))
+            L.dd_tools_set_tuning(k, {26: 1, 27: 1, 28: 4, 29: 4, 22: 1, 23: 2, 21: 0}.get(k, 0))
