@@ -509,6 +509,23 @@ def main() -> int:
                                    "policy falls back to two-sweep steps and re-probes every 32 steps")
         except Exception as e:
             single_keep = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    if roof is not None and roof.get("achieved") and wide:
+        # what a group step of B sequences streams: rider form = B / 8 sweeps over the matrices (classic: one fused un-masked sweep + the member
+        # sweeps); every sequence's cache is read twice (un-masked row, members).  `value` includes the vision front-end and the prefill, so
+        # the rate below is a lower bound on what the decode steps sustain.
+        T_mean = T0 + args.n_new / 2
+        w_only = sweep_bytes(lm_cfg, 0, weight_bytes, 2.0)
+        kv_seq = sweep_bytes(lm_cfg, T_mean, weight_bytes, 2.0) - w_only
+        sweeps = B // 8 if rider else 1 + -(-B // (dom_rows // 8))
+        per_tok = (sweeps * w_only + 2 * B * kv_seq) / B
+        per_gpu = value / max(1, streams)
+        roof["group_step"] = {"sequences": B, "form": "rider" if rider else "classic", "sweeps_per_step": sweeps, "rows_per_sweep": dom_rows,
+                              "bytes_per_token_streamed": round(per_tok), "bytes_per_token_algorithmic": round(2 * (w_only + kv_seq)),
+                              "streamed_GBs_at_value": round(per_tok * per_gpu / 1e9, 1), "frac_at_value": round(per_tok * per_gpu / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "roofline.frac is per LAUNCH of the dominant kernel by its weight bytes: a 72-row launch (rider form) carries 9/8 of a "
+                                      "64-row launch's rows and takes ~1.13x its time (gate_up_streaming_kernel_by_rows.us_per_8_rows), but a step needs one "
+                                      "sweep fewer; frac_at_value = bytes the steps stream per token x tokens/s per GPU / 8 TB/s, with the vision front-end "
+                                      "and the prefill inside the time"}
     if roof is not None and single:
         roof["end_to_end"] = end_to_end(single, lm_cfg, T0 + args.n_new / 2, weight_bytes, 2.0)
         if single_two:

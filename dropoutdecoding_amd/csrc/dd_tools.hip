@@ -91,8 +91,11 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // GEMV, 9 = sequences per member sweep in dd_lm_group_step (1, 2, 4, 8), 10 = workgroups per group of 8 members in the grouped
 // decode attention, 12 = prefill attention on the matrix cores, 17 / 18 / 19 = workgroups per K slice of the 64-row qkv / o_proj /
 // gate-up GEMV (18 < 0: eight-plane o_proj kernel; 19 < 0: single K slices for gate/up), 21 = key tiles per workgroup of the
-// fp16-cache decode attention, 22 = all-tiles form of that attention, 23 = concurrent member sweeps of a group step, 24 = four-columns-per-thread finishing kernel of the slice GEMVs (bit mask over the epilogues); the product
-// switches (8, 11, 13-16) are forwarded to dd_set_tuning.
+// fp16-cache decode attention, 22 = all-tiles form of that attention, 23 = concurrent member sweeps of a
+// classic group step, 24 = four-columns-per-thread finishing kernel of the slice GEMVs (bit mask over the epilogues), 26 = rider form of the
+// group step (0: the classic form always), 27 = the riding rows' attention inside the members' launches, 28 = branches of the rider
+// form (1..4), 29 = weight requests in flight per wave of the nine-plane qkv / gate-up kernels (4 or 8); the product switches
+// (8, 11, 13-16) are forwarded to dd_set_tuning.  Every call bumps the graph-key epoch: steps captured under other settings are not replayed.
 extern int g_exp_G[4];
 extern int g_attn16_tpw, g_attn16_full, g_finish4;
 void dd_engine_set_pairs(int on);

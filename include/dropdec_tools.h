@@ -37,7 +37,11 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * on the matrix cores, 17 / 18 / 19 workgroups per K slice of the 64-row qkv / o_proj / gate-up GEMV, 21 key tiles per
  * workgroup of the fp16-cache decode attention, 22 all-tiles form of that attention, 23 member sweeps of a group step that
  * run concurrently (1..4), 24 four-columns-per-thread finishing kernel of the slice GEMVs (bit mask over the epilogues
- * EPI_STORE / RESID / SILU / QKV, default 15; 0: the one-column kernel it replaced).  Keys of dd_set_tuning are forwarded. */
+ * EPI_STORE / RESID / SILU / QKV, default 15; 0: the one-column kernel it replaced), 26 rider form of the group step (default 1;
+ * 0: always the classic form: one fused un-masked sweep + the member sweeps), 27 the riding rows' attention inside the members'
+ * launches (default 1), 28 branches of the rider form (1..4, default 4), 29 weight requests in flight per wave of the nine-plane
+ * qkv / gate-up kernels (4 or 8, default 4).  Keys of dd_set_tuning are forwarded.  Every call starts a new epoch of the step-graph
+ * keys: a step captured under other settings is never replayed. */
 int dd_tools_set_tuning(int key, int value);
 
 #ifdef __cplusplus
