@@ -205,3 +205,37 @@ def test_generate_keeps_whole_groups_while_sequences_end(E, T):
         assert e.generate(n_new, eos=eos, mprobs=K8) == want[li], f"lane {li} alone"
     for e in reversed(engines):
         e.close()
+
+
+@pytest.mark.parametrize("name,family,dims,kw", [
+    ("InstructBLIP rule (quantile masks, vote on the hidden state, the last member's zeros leak into the next un-masked row)", "instructblip",
+     (4096, 11008, 32, 32), {}),
+    ("InstructBLIP with masked positions (the riding row's RoPE position depends on the leaked zeros)", "instructblip", (4096, 11008, 32, 32),
+     {"iblip_positions": "mask"}),
+    ("LLaVA-NeXT rule (masks reset every step), GQA", "llava-next", (4096, 14336, 32, 8), {}),
+    ("LLaVA-1.5 rule, draws from the Philox stream", "llava-1.5", (4096, 11008, 32, 32), {"rng_stream": "gpu"}),
+])
+def test_rider_step_other_families(E, T, name, family, dims, kw):
+    d, dff, H, Hkv = dims
+    cfg = E.LMConfig(2048, d, dff, 2, H, Hkv, 128, 1e-5, 10000.0)
+    L, n, steps = 24, 16, 5
+    engines = _group(E, T, cfg, n, family, L, **kw)
+    gen = torch.Generator().manual_seed(17)
+    embs = [(torch.randn(L + 6 + (i % 5), d, generator=gen) * 0.5).cuda() for i in range(n)]
+    spans = [((0 if family == "instructblip" else 2 + (i % 3)), L) for i in range(n)]
+    ref = _run(E, T, engines, embs, spans, K8, steps, rider=False, graph=False)
+    for graph in (False, True):
+        got = _run(E, T, engines, embs, spans, K8, steps, rider=True, graph=graph)
+        _same(got, ref, f"{name} (graph {graph})")
+    for li in (3, 12):
+        e = engines[li]
+        e.set_speculation("never")
+        e.rng.manual_seed(50 + li)
+        e.prefill(embs[li], *spans[li])
+        for s in range(steps):
+            e.decode_step(K8)
+            np.testing.assert_array_equal(e.logits(), ref[0][s][li][0], err_msg=f"{name}: solo lane {li} step {s}")
+        assert e.tokens() == ref[1][li]
+        e.set_speculation("default")
+    for e in reversed(engines):
+        e.close()
