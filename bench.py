@@ -484,7 +484,10 @@ def main() -> int:
     dom_rows = (64 if B >= 8 else (32 if B >= 4 else 16)) if wide else rows8
     # rider form of the group step (csrc/dd_engine.hip): from 16 sequences on (whole groups of eight, 16-bit weights) the un-masked rows ride in
     # a ninth operand plane of the member sweeps
-    rider = wide and B >= 16 and B % 8 == 0 and wname != "fp8"
+    # K <= 4 (BASELINE config 2, the reference's own settings): the members of a sequence fill half an operand plane, a 64-row member sweep
+    # carries sixteen sequences (classic form: one fused un-masked sweep + B / 16 member sweeps)
+    half_planes = wide and B >= 16 and K_eff <= 4 and wname != "fp8"
+    rider = wide and B >= 16 and B % 8 == 0 and wname != "fp8" and not half_planes
     if rider:
         dom_rows = 72
     roof = None
@@ -516,10 +519,10 @@ def main() -> int:
         T_mean = T0 + args.n_new / 2
         w_only = sweep_bytes(lm_cfg, 0, weight_bytes, 2.0)
         kv_seq = sweep_bytes(lm_cfg, T_mean, weight_bytes, 2.0) - w_only
-        sweeps = B // 8 if rider else 1 + -(-B // (dom_rows // 8))
+        sweeps = B // 8 if rider else 1 + -(-B // (16 if half_planes else dom_rows // 8))
         per_tok = (sweeps * w_only + 2 * B * kv_seq) / B
         per_gpu = value / max(1, streams)
-        roof["group_step"] = {"sequences": B, "form": "rider" if rider else "classic", "sweeps_per_step": sweeps, "rows_per_sweep": dom_rows,
+        roof["group_step"] = {"sequences": B, "form": "rider" if rider else ("classic, half planes" if half_planes else "classic"), "sweeps_per_step": sweeps, "rows_per_sweep": dom_rows,
                               "bytes_per_token_streamed": round(per_tok), "bytes_per_token_algorithmic": round(2 * (w_only + kv_seq)),
                               "streamed_GBs_at_value": round(per_tok * per_gpu / 1e9, 1), "frac_at_value": round(per_tok * per_gpu / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "roofline.frac is per LAUNCH of the dominant kernel by its weight bytes: a 72-row launch (rider form) carries 9/8 of a "
@@ -539,7 +542,9 @@ def main() -> int:
               + (f"; the {B} are independent sequences (own KV cache and rng stream, results identical to decoding each alone) whose "
                  + ("member passes run 8 sequences (64 rows) per sweep over the weights, each sweep carrying the un-masked rows of 8 other sequences "
                     f"in a ninth operand plane (72 rows; no sweep of their own: {B // 8} sweeps per step)" if rider else
-                    f"un-masked passes share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep")
+                    (f"un-masked passes share one sweep over the weights and whose member passes run 16 sequences (64 rows: K <= 4 members fill "
+                     f"half an operand plane, two sequences share one) per sweep: 1 + {-(-B // 16)} sweeps per step" if half_planes else
+                     f"un-masked passes share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep"))
                  + "; the next batch's vision front-end + prefill overlap the current batch's decode on a second stream" if B > 1 else ""))
         metric = {1: f"decoded tokens/sec {model_name} --original", 2: f"decoded tokens/sec {model_name} K=4 ensemble", 3: f"decoded tokens/sec {model_name} K=8 ensemble",
                   4: f"decoded tokens/sec {model_name} K=8 ensemble", 5: f"decoded tokens/sec {model_name} K=8 ensemble, fp8 weights"}[args.config]

@@ -169,9 +169,10 @@ __device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int h
   const int lane = d & 63, wv = d >> 6;
   const int q_dim = a.n_heads * HEAD_DIM, kv_dim = a.n_kv * HEAD_DIM;
   const float scaling = 0.08838834764831845f;
-  const int grp = wide ? m >> 3 : 0;                  // group of the row (multi-group passes)
-  const float* knew_r = (wide && a.knew_g[grp]) ? a.knew_g[grp] + (size_t)(m & 7) * kv_dim : a.knew + (size_t)m * kv_dim;
-  const float* vnew_r = (wide && a.vnew_g[grp]) ? a.vnew_g[grp] + (size_t)(m & 7) * kv_dim : a.vnew + (size_t)m * kv_dim;
+  const int grp = wide ? (a.half_planes ? m >> 2 : m >> 3) : 0;                  // group (half planes: sequence) of the row
+  const int mrow = a.half_planes ? (m & 3) : (m & 7);
+  const float* knew_r = (wide && a.knew_g[grp]) ? a.knew_g[grp] + (size_t)mrow * kv_dim : a.knew + (size_t)m * kv_dim;
+  const float* vnew_r = (wide && a.vnew_g[grp]) ? a.vnew_g[grp] + (size_t)mrow * kv_dim : a.vnew + (size_t)m * kv_dim;
   // every load of this block is issued here, before the first dependent use
   float qd = a.qbuf[(size_t)m * q_dim + head * HEAD_DIM + d];
   float kd = knew_r[kvh * HEAD_DIM + d];
@@ -226,6 +227,9 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
   const int g0 = ML == 1 ? 0 : (ML == 2 ? (zz / MSPLIT) * GH : bz * GH);
   const int mo = ML == 2 ? (zz % MSPLIT) * NBT : 0;
   const int lane_row = ML == 1 ? bz : (ML == 2 ? bz / ((G / GH) * MSPLIT) : 0);
+  // half planes (ML == 2, NBT == 4): the workgroup's four rows are the members of sequence 2 * plane + (mo >> 2)
+  const int seq_row = (ML == 2 && a.half_planes) ? 2 * lane_row + (mo >> 2) : lane_row;
+  const int mo_bit = (ML == 2 && a.half_planes) ? 0 : mo;      // member index of row 0 (drop bit, liveness)
   auto buf_row = [&](int r) -> int {
     if (ML == 1) return r * lane_rows + lane_row;
     if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + mo + r % NBT;
@@ -238,17 +242,17 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, h4 = lane >> 4;
   const int kvh = bx;
-  const int T = ML ? a.lane_state[lane_row]->T : (a.state ? a.state->T : a.T);
+  const int T = ML ? a.lane_state[seq_row]->T : (a.state ? a.state->T : a.T);
   // this workgroup's key tiles: tiles_per_wg consecutive ones (the launcher sizes the grid for ONE round of workgroups: with a
   // tile per workgroup the 8-sequence pass had 1.25 rounds, a quarter-full second one)
   const int tpw = FULL ? ATT_FULL_TILES : (a.tiles_per_wg > 0 ? a.tiles_per_wg : 1);
   const int split0 = by * tpw, n_live = (T + ATT_SPLIT - 1) / ATT_SPLIT;
   const int split1 = min(min(split0 + tpw, FULL ? ATT_FULL_TILES : a.splits_stride), n_live);
   if (split0 >= split1) return;   // shorter lane / stale graph: these tiles do not exist (the combine skips them as well)
-  const dd_half* kc_l = (const dd_half*)(ML ? a.lane_kc[lane_row] : a.kc);
-  const dd_half* vc_l = (const dd_half*)(ML ? a.lane_vc[lane_row] : a.vc);
-  const uint8_t* bits_l = ML ? a.lane_bits[lane_row] : a.drop_bits;
-  const int span0 = ML ? a.lane_span_start[lane_row] : a.span_start, spanL = ML ? a.lane_span_len[lane_row] : a.span_len;
+  const dd_half* kc_l = (const dd_half*)(ML ? a.lane_kc[seq_row] : a.kc);
+  const dd_half* vc_l = (const dd_half*)(ML ? a.lane_vc[seq_row] : a.vc);
+  const uint8_t* bits_l = ML ? a.lane_bits[seq_row] : a.drop_bits;
+  const int span0 = ML ? a.lane_span_start[seq_row] : a.span_start, spanL = ML ? a.lane_span_len[seq_row] : a.span_len;
   const int q_dim = a.n_heads * HEAD_DIM;
 
   // every K / V request of a tile at once (dead keys: the last live key's chunk / whatever the octet holds — cache memory is
@@ -277,7 +281,8 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
     int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT;
     int m = ML == 1 ? lane_row : mo + r % NBT;
     int qrow = ML == 2 ? lane_row * 8 + m : m;
-    q_sh[r][d] = (r < R && m < a.nb) ? a.qbuf[(size_t)qrow * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
+    const int mlive = ML == 2 ? mo_bit + r % NBT : m;      // member index within its sequence
+    q_sh[r][d] = (r < R && mlive < a.nb) ? a.qbuf[(size_t)qrow * q_dim + (kvh * G + g) * HEAD_DIM + d] : 0.f;
   }
   __syncthreads();
   // fp32 x[8] -> this lane's B column: the fp16 hi part (columns 0-7) or the lo part (columns 8-15) of row c & 7
@@ -318,7 +323,7 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
         sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dd_f16x8_t, kfr[ks]), __builtin_bit_cast(dd_f16x8_t, qb[blk][ks]), sacc, 0, 0, 0);
       // hi + lo columns; mask; the wave's maximum per row (lanes c < 8 carry row 8 blk + c, keys 16 w + 4 h4 + reg)
       const int row = 8 * blk + (c & 7);
-      const int m = ML == 1 ? 0 : mo + row % NBT;
+      const int m = ML == 1 ? 0 : mo_bit + row % NBT;
       float mx = -INFINITY;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
@@ -445,7 +450,7 @@ __device__ __forceinline__ void attn_combine_body(const AttnDecodeArgs& a, int s
   const int r = g * NBT + m;
   // `splits_grid` is the stride of the partial buffers (tiles the partial kernel was launched with); a lane's row only
   // has the tiles of its own, possibly shorter, sequence
-  const int splits = a.n_lanes ? (a.lane_state[a.lane_groups ? m >> 3 : m]->T + ATT_SPLIT - 1) / ATT_SPLIT
+  const int splits = a.n_lanes ? (a.lane_state[a.lane_groups ? (a.half_planes ? m >> 2 : m >> 3) : m]->T + ATT_SPLIT - 1) / ATT_SPLIT
                                : (a.state ? (a.state->T + ATT_SPLIT - 1) / ATT_SPLIT : splits_grid);
   const float* mlb = a.part_ml + ((size_t)kvh * splits_grid * R + r) * 2;
   const size_t ml_stride = (size_t)R * 2;
@@ -577,6 +582,7 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
 // multi-group pass: members of NG sequences (8 rows each), every group over its own cache
 template <int G, int NG>
 static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
+  if (a.half_planes) return launch_attn_groups_n<G, NG, 4>(a, st);      // two workgroups per plane, one per sequence of the pair
   if (g_attn_msplit == 4) return launch_attn_groups_n<G, NG, 2>(a, st);
   if (g_attn_msplit == 2) return launch_attn_groups_n<G, NG, 4>(a, st);
   return launch_attn_groups_n<G, NG, 8>(a, st);
@@ -619,6 +625,7 @@ int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
   if (a.n_lanes > 0 && a.lane_groups) {
     DD_REQUIRE((a.lane_groups == 2 || a.lane_groups == 4 || a.lane_groups == 8) && a.n_lanes == a.lane_groups && a.nb >= 1 && a.nb <= 8,
                "attn: a multi-group pass takes 2, 4 or 8 sequences of up to 8 members");
+    DD_REQUIRE(!a.half_planes || (a.kv16 && a.lane_groups == 8 && a.nb <= 4), "attn: half planes take eight planes over fp16 caches, K <= 4");
     if (a.lane_groups == 8) {
       if (G == 1) rc = launch_attn_groups<1, 8>(a, st);
       else if (G == 2) rc = launch_attn_groups<2, 8>(a, st);

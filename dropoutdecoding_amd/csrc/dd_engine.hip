@@ -1265,13 +1265,19 @@ void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 #define RIDER_KV_ROW0 16   // rows of the sweeping handle's new-K/V scratch that hold the riding un-masked rows (0..15: members)
 // rider / n_rider (ng == 8 only): up to 8 sequences whose UN-MASKED rows ride in a ninth operand plane of the sweep (row 64 + m =
 // sequence rider[m]); their logits go to rows 0.. of h->grp_logits.  See group_step_rider.
-static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st, dd_lm* const* rider = nullptr, int n_rider = 0) {
+// packed (K <= 4, ng == 16): half planes — plane p carries the members of sequences 2 p (rows 0..3) and 2 p + 1 (rows 4..7), so a 64-row
+// sweep serves sixteen sequences; per-sequence buffers and attention arguments are indexed by sequence (GemvArgs / AttnDecodeArgs
+// half_planes), every row goes through the kernels of the plain pass.
+static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st, dd_lm* const* rider = nullptr, int n_rider = 0,
+                           bool packed = false) {
   const int d = h->d, dff = h->dff;
-  const int planes = n_rider > 0 ? 9 : ng;
+  const int planes = packed ? 8 : (n_rider > 0 ? 9 : ng);
+  const int rows_g = packed ? 4 : 8;                                  // rows a sequence owns
+  auto row0 = [&](int g) -> int { return packed ? 8 * (g >> 1) + 4 * (g & 1) : 8 * g; };
   EmbedLanes el;
   memset(&el, 0, sizeof(el));
   for (int g = 0; g < ng; ++g)
-    for (int m = 0; m < K; ++m) el.state[8 * g + m] = qs[g]->state;
+    for (int m = 0; m < K; ++m) el.state[row0(g) + m] = qs[g]->state;
   for (int m = 0; m < n_rider; ++m) el.state[64 + m] = rider[m]->state;
   RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * planes, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
   int ssq_n = 1;
@@ -1280,7 +1286,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     GemvArgs a;
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider;
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
     a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
@@ -1290,13 +1296,13 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     t.wf = h->wf;
     t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0, t.kv16 = h->kv16;
     t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
-    t.n_lanes = ng, t.lane_groups = ng;
+    t.n_lanes = packed ? 8 : ng, t.lane_groups = packed ? 8 : ng, t.half_planes = packed ? 1 : 0;
     for (int g = 0; g < ng; ++g) {
       dd_lm* q = qs[g];
       float* kn = q->knew + (size_t)l * KV_ROWS * q->kv_dim;
       float* vn = q->vnew + (size_t)l * KV_ROWS * q->kv_dim;
       a.knew_g[g] = kn, a.vnew_g[g] = vn, t.knew_g[g] = kn, t.vnew_g[g] = vn;
-      for (int m = 0; m < 8; ++m) a.state_rows[8 * g + m] = q->state;
+      for (int m = 0; m < rows_g; ++m) a.state_rows[row0(g) + m] = q->state;
       t.lane_kc[g] = q->kc + (size_t)l * q->lsk, t.lane_vc[g] = q->vc + (size_t)l * q->lsv, t.lane_state[g] = q->state;
       t.lane_bits[g] = q->drop_bits, t.lane_span_start[g] = q->span_start, t.lane_span_len[g] = q->L;
       if (q->T_host > t.max_T) t.max_T = q->T_host;
@@ -1336,14 +1342,14 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     }
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = planes, a.nb_rider = n_rider;
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
     a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider;
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
@@ -1351,7 +1357,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = planes, a.nb_rider = n_rider;
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
@@ -1362,12 +1368,12 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   GemvArgs a;
   memset(&a, 0, sizeof(a));
   a.wf = h->wf;
-  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider;
+  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   for (int g = 0; g < ng; ++g) {
     a.out_g[g] = qs[g]->member_logits;
-    for (int m = 0; m < 8; ++m) a.state_rows[8 * g + m] = qs[g]->state;
+    for (int m = 0; m < rows_g; ++m) a.state_rows[row0(g) + m] = qs[g]->state;
   }
   a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
   a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
@@ -1381,7 +1387,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
 
 // what follows a multi-group sweep: member argmax, vote, winner's K/V appended, token emitted — for the ng sequences of
 // the sweep with ONE launch per stage (dd_lm_step_commit's work, block = sequence)
-static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st) {
+// (packed_base >= 0: the sequences are numbers packed_base.. of a half-plane sweep — their rows in h->xa start at 8 (s >> 1) + 4 (s & 1))
+static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st, int packed_base = -1) {
   const int d = h->d;
   const float* lg[8];
   int32_t* tk[8];
@@ -1392,7 +1399,8 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
   for (int g = 0; g < ng; ++g) {
     dd_lm* q = qs[g];
     if (q->cfg.vote_on == DD_VOTE_HIDDEN) {    // InstructBLIP: argmax over the final-normed hidden state (instructblip.py:125-137)
-      RC(ddk_final_norm_rows(h->xa + (size_t)g * 8 * d, K, d, h->final_norm, h->cfg.rms_eps, q->hidden, st));
+      const int sq = packed_base + g, xrow = packed_base >= 0 ? 8 * (sq >> 1) + 4 * (sq & 1) : 8 * g;
+      RC(ddk_final_norm_rows(h->xa + (size_t)xrow * d, K, d, h->final_norm, h->cfg.rms_eps, q->hidden, st));
       RC(dd_argmax_rows_gated(q->hidden, K, d, d, q->member_vote, &q->state->done, st));
     }
     plain_vote &= q->cfg.vote_on != DD_VOTE_AVERAGE;
@@ -1465,11 +1473,28 @@ __global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argma
 // tokens, masks, logits and caches are those of the classic group step and of every sequence decoded alone.
 // Per step and sequence the weights are read 1/8 times ... the sweep count of a 32-sequence step drops from five to four.
 // -----------------------------------------------------------------------------------------------
+static int g_half_planes_first = 1;   // dd_tools_set_tuning key 31: where both apply, half planes (classic form) before the rider form
+void dd_engine_set_half_planes_first(int on) { g_half_planes_first = on; }
+static int g_half_planes = 1;    // dd_tools_set_tuning key 30: K <= 4 packs two sequences per operand plane (0: one, rows 4..7 empty)
+void dd_engine_set_half_planes(int on) { g_half_planes = on; }
+// sixteen sequences per 64-row member sweep: K <= 4, fp16 caches, 16-bit weights of the shapes with eight-plane slice kernels for every matrix
+static bool half_planes_ok(dd_lm* const* lanes, int n, int K) {
+  if (!g_half_planes || K < 1 || K > 4 || g_pair_sweeps < 8 || n < 16) return false;
+  dd_lm* h0 = lanes[0];
+  if (!h0->kv16 || h0->fp8 || !h0->gemv_part) return false;
+  const int qt = h0->qkv_tiles, gt = 2 * h0->dff / 16;
+  if (h0->S_d != 128 || h0->S_q != 128 || !(h0->S_ff == 8 * 43 || h0->S_ff == 8 * 56) || qt < 64 || gt < 64 || h0->d / 16 < 64 || h0->Vpad / 16 < 64)
+    return false;
+  for (int m = 0; m < n; ++m)
+    if (lanes[m]->cfg.vote_on == DD_VOTE_AVERAGE) return false;
+  return true;
+}
 static int g_rider = 1;          // dd_tools_set_tuning key 26
 void dd_engine_set_rider(int on) { g_rider = on; }
 // branches of the rider form for this call, 0: not applicable
 static int rider_branches(dd_lm* const* lanes, int n, int K) {
   if (!g_rider || K < 1 || K > 8 || g_pair_sweeps < 8 || n < 16 || (n % 8) != 0 || n > GROUP_MAX_LANES) return 0;
+  if (g_half_planes_first && half_planes_ok(lanes, n, K)) return 0;          // K <= 4: the classic form with half planes (sixteen sequences per sweep)
   dd_lm* h0 = lanes[0];
   if (!h0->kv16 || h0->fp8 || !h0->gemv_part) return 0;
   // shapes with nine-plane kernels (dd_gemv.hip try_slices9)
@@ -1671,8 +1696,10 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     }
   }
   const bool multi = g_pair_sweeps && K > 0 && K <= 8;
+  const bool pack16 = multi && half_planes_ok(lanes, n, K);      // K <= 4: sixteen sequences per 64-row sweep (two per operand plane)
   auto width = [&](int m) -> int {     // sequences of the member sweep that starts at lane m
     const int left = n - m;
+    if (pack16 && left >= 16) return 16;
     return !multi ? 1 : (left >= 8 && g_pair_sweeps >= 8 ? 8 : (left >= 4 && g_pair_sweeps >= 4 ? 4 : (left >= 2 ? 2 : 1)));
   };
   // The member sweeps of a group step are independent of each other, and each is a chain of dependent launches in which every
@@ -1698,8 +1725,14 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
         const int br = fork ? i_multi % nbr : 0;               // branch 0 = the caller's stream on the leader's scratch
         dd_lm* scratch = br ? lanes[m] : h0;
         hipStream_t bs = br ? h0->side[br - 1] : st;
-        RC(lm_sweep_groups(scratch, lanes + m, ng, K, bs));
-        RC(group_finish(scratch, lanes + m, ng, K, bs));
+        if (ng == 16) {
+          RC(lm_sweep_groups(scratch, lanes + m, 16, K, bs, nullptr, 0, true));
+          RC(group_finish(scratch, lanes + m, 8, K, bs, 0));
+          RC(group_finish(scratch, lanes + m + 8, 8, K, bs, 8));
+        } else {
+          RC(lm_sweep_groups(scratch, lanes + m, ng, K, bs));
+          RC(group_finish(scratch, lanes + m, ng, K, bs));
+        }
         ++i_multi;
         m += ng - 1;
         continue;

@@ -130,10 +130,18 @@ struct GemvArgs {
   // buffers
   int n_groups;
   int nb_rider;         // n_groups == 9: live rows of plane 8 (the riding un-masked rows: one per sequence, not one per member); 0: nb
-  __host__ __device__ int rows_live(int plane) const { return (plane == 8 && nb_rider) ? nb_rider : nb; }
-  float* out_g[9];      // EPI_STORE rows of group g (null: out + 8 g * ldo)
-  float* knew_g[9];     // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
-  float* vnew_g[9];
+  // half_planes (K <= 4): a plane carries the members of TWO sequences — rows 0..3 sequence 2 g, rows 4..7 sequence 2 g + 1, nb (<= 4)
+  // live rows each — and out_g / knew_g / vnew_g are indexed by SEQUENCE (16 of them in a 64-row pass), rows by member
+  int half_planes;
+  __host__ __device__ bool row_live(int plane, int ml) const {
+    if (half_planes) return (ml & 3) < nb;
+    return ml < ((plane == 8 && nb_rider) ? nb_rider : nb);
+  }
+  __host__ __device__ int slot(int plane, int ml) const { return half_planes ? 2 * plane + (ml >> 2) : plane; }   // index into out_g / knew_g / vnew_g
+  __host__ __device__ int slot_row(int ml) const { return half_planes ? (ml & 3) : ml; }                          // row within that buffer
+  float* out_g[16];     // EPI_STORE rows of group g (null: out + 8 g * ldo)
+  float* knew_g[16];    // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
+  float* vnew_g[16];
   int S_next;           // K / 32 of the GEMV that consumes xop_next
   int wf;                   // 16-bit type of W and of the packed operands: 0 bf16, 1 fp16 (engines created with weight_format 2)
   const int32_t* skip_if;   // optional (k_gemv): *skip_if != 0 -> the launch returns at once (fallback sweep of a speculative step)
@@ -184,8 +192,10 @@ struct AttnDecodeArgs {
   int n_lanes;
   int lane_groups;       // 0: lane m = row m (fused base pass of up to 16 sequences).  2 / 4 / 8: a 16- / 32- / 64-row pass of that many sequences — rows
                          // 8g..8g+7 are members of lane g (each group reads its own cache with its own drop bits, bit = row & 7)
-  const float* knew_g[8];  // lane_groups > 0: new K/V rows of group g
-  const float* vnew_g[8];
+  const float* knew_g[16];  // lane_groups > 0: new K/V rows of group g (half_planes: of sequence s, rows = members)
+  const float* vnew_g[16];
+  int half_planes;          // lane_groups == 8, K <= 4: plane g carries sequences 2 g (rows 0..3) and 2 g + 1 (rows 4..7); the lane_* arrays, knew_g
+                            // and vnew_g are indexed by sequence (16), a member's drop bit is its index within its sequence
   int max_T;             // host: largest prefix length among the lanes (grid sizing)
   int splits_stride, tiles_per_wg;   // set by the launchers of k_attn_partial16: tile stride of the partial buffers, key tiles per workgroup
   const float* lane_kc[16];

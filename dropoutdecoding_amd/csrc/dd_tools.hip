@@ -103,11 +103,13 @@ void dd_engine_set_branches(int n);
 void dd_engine_set_rider(int on);
 void dd_engine_set_ride_beside(int on);
 void dd_engine_set_rider_branches(int n);
+void dd_engine_set_half_planes(int on);
+void dd_engine_set_half_planes_first(int on);
 extern int g_exp_U9;
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 29),
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31),
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -121,6 +123,8 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 27) dd_engine_set_ride_beside(value);
   else if (key == 28) dd_engine_set_rider_branches(value);
   else if (key == 29) g_exp_U9 = value;
+  else if (key == 30) dd_engine_set_half_planes(value);
+  else if (key == 31) dd_engine_set_half_planes_first(value);
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }

@@ -39,6 +39,7 @@ def _group(E, T, cfg, n, family, L, **kw):
 
 def _run(E, T, engines, embs, spans, probs, steps, rider, graph, eos=None, read_every_step=True):
     T.dd_tools_set_tuning(26, 1 if rider else 0)
+    T.dd_tools_set_tuning(30, 0)                # (K <= 4 would otherwise take the half-plane form: tests/test_gpu_half_planes.py)
     T.dd_tools_set_tuning(8, 1 if graph else 0)
     for i, (e, emb, (s0, L)) in enumerate(zip(engines, embs, spans)):
         e.rng.manual_seed(50 + i)
@@ -58,6 +59,7 @@ def _run(E, T, engines, embs, spans, probs, steps, rider, graph, eos=None, read_
     sums = [e.kv_sums().copy() for e in engines]
     tails = [e.rng.rand(8).cpu().numpy().copy() for e in engines]
     T.dd_tools_set_tuning(26, 1)
+    T.dd_tools_set_tuning(30, 1)
     T.dd_tools_set_tuning(8, 1)
     return out, toks, sums, tails
 

@@ -1,4 +1,4 @@
-"""A/B of the rider group step: ms per 32-lane step for tuning settings given as key=value lists separated by '/'.
+"""A/B of the group step forms: ms per step for tuning settings given as key=value lists (26 rider form, 30 half planes for K <= 4, ...).
    python tools/rider_ab.py 32 "26=0" "26=1" "26=1,22=0" """
 import os, sys, time
 os.environ.setdefault("DD_USE_TOOLS_LIB", "1")
@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dropoutdecoding_amd import _lib, lm
 from dropoutdecoding_amd.config import VOTING_NUMBERS_K8
+
+PROBS = {8: VOTING_NUMBERS_K8, 4: [0.1, 0.3, 0.5, 0.7], 3: [0.3, 0.5, 0.7]}[int(os.environ.get("DD_AB_K", "8"))]   # DD_AB_K=4: the reference's K = 4
 
 torch.cuda.set_device(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -29,11 +31,11 @@ for rep in range(2):
             e.prefill(x, 5, 576)
         g = lm.EngineGroup(engs)
         for _ in range(4):
-            g.decode_step(VOTING_NUMBERS_K8)
+            g.decode_step(PROBS)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            g.decode_step(VOTING_NUMBERS_K8)
+            g.decode_step(PROBS)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         toks = [e.tokens() for e in engs]
@@ -41,4 +43,4 @@ for rep in range(2):
             first = toks
         print(f"{stg}: {ms:.2f} ms per group step of {B} lanes; tokens {'same' if toks == first else 'DIFFER'}", flush=True)
         for k, v in kv:          # back to the defaults
-            L.dd_tools_set_tuning(k, {26: 1, 27: 1, 28: 4, 29: 4, 22: 1, 23: 2, 21: 0}.get(k, 0))
+            L.dd_tools_set_tuning(k, {26: 1, 27: 1, 28: 4, 29: 4, 30: 1, 31: 1, 22: 1, 23: 2, 21: 0}.get(k, 0))
