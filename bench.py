@@ -243,7 +243,7 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
     eng.close()
     prof = committed_profile(kernel)
     achieved = by / (ms * 1e-3) / 1e9
-    rows_what = ("the members of 8 sequences + the un-masked rows of 8 more riding in a ninth operand plane" if dom_rows == 72
+    rows_what = ("the members of a group of sequences + the un-masked rows of another group riding in further operand planes" if dom_rows == 72
                  else f"the members of {dom_rows // 8} sequences")
     what = (f"{kernel} (gate/up decode GEMV of a {dom_rows}-row pass = {rows_what}: streams the matrix once, K in slices "
             "resident in LDS; its finishing kernel k_gemv_finish4 adds the slices' partial sums and applies SiLU*up)") if wide \
@@ -350,7 +350,7 @@ def main() -> int:
     ddcfg.settings["voting_numbers"] = list(probs)
     K_eff = 0 if args.original else len(probs)
     if args.images_per_gpu is None:
-        args.images_per_gpu = 8 if args.config == 5 else 64
+        args.images_per_gpu = 8 if args.config == 5 else (56 if args.config == 2 else 64)      # K = 4: whole groups of fourteen
     if args.prefill_chunk is None:
         args.prefill_chunk = 2 if args.config == 5 else 16
     B = 1 if args.mode == "kshard" else max(1, min(64, args.images_per_gpu))
@@ -487,8 +487,9 @@ def main() -> int:
     # K <= 4 (BASELINE config 2, the reference's own settings): the members of a sequence fill half an operand plane, a 64-row member sweep
     # carries sixteen sequences (classic form: one fused un-masked sweep + B / 16 member sweeps)
     half_planes = wide and B >= 16 and K_eff <= 4 and wname != "fp8"
+    rider_hp = half_planes and B >= 28 and B % 14 == 0        # whole groups of fourteen: seven half planes + two riding planes per sweep
     rider = wide and B >= 16 and B % 8 == 0 and wname != "fp8" and not half_planes
-    if rider:
+    if rider or rider_hp:
         dom_rows = 72
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -519,10 +520,10 @@ def main() -> int:
         T_mean = T0 + args.n_new / 2
         w_only = sweep_bytes(lm_cfg, 0, weight_bytes, 2.0)
         kv_seq = sweep_bytes(lm_cfg, T_mean, weight_bytes, 2.0) - w_only
-        sweeps = B // 8 if rider else 1 + -(-B // (16 if half_planes else dom_rows // 8))
+        sweeps = B // 8 if rider else (B // 14 if rider_hp else 1 + -(-B // (16 if half_planes else dom_rows // 8)))
         per_tok = (sweeps * w_only + 2 * B * kv_seq) / B
         per_gpu = value / max(1, streams)
-        roof["group_step"] = {"sequences": B, "form": "rider" if rider else ("classic, half planes" if half_planes else "classic"), "sweeps_per_step": sweeps, "rows_per_sweep": dom_rows,
+        roof["group_step"] = {"sequences": B, "form": "rider" if rider else ("rider, half planes" if rider_hp else ("classic, half planes" if half_planes else "classic")), "sweeps_per_step": sweeps, "rows_per_sweep": dom_rows,
                               "bytes_per_token_streamed": round(per_tok), "bytes_per_token_algorithmic": round(2 * (w_only + kv_seq)),
                               "streamed_GBs_at_value": round(per_tok * per_gpu / 1e9, 1), "frac_at_value": round(per_tok * per_gpu / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "roofline.frac is per LAUNCH of the dominant kernel by its weight bytes: a 72-row launch (rider form) carries 9/8 of a "
@@ -542,6 +543,9 @@ def main() -> int:
               + (f"; the {B} are independent sequences (own KV cache and rng stream, results identical to decoding each alone) whose "
                  + ("member passes run 8 sequences (64 rows) per sweep over the weights, each sweep carrying the un-masked rows of 8 other sequences "
                     f"in a ninth operand plane (72 rows; no sweep of their own: {B // 8} sweeps per step)" if rider else
+                    (f"member passes run 14 sequences per sweep over the weights (K <= 4 members fill half an operand plane: seven planes of two "
+                     f"sequences), each sweep carrying the un-masked rows of 14 other sequences in two more planes (72 rows; {B // 14} sweeps per step)"
+                     if rider_hp else None) or
                     (f"un-masked passes share one sweep over the weights and whose member passes run 16 sequences (64 rows: K <= 4 members fill "
                      f"half an operand plane, two sequences share one) per sweep: 1 + {-(-B // 16)} sweeps per step" if half_planes else
                      f"un-masked passes share one sweep over the weights and whose member passes run {dom_rows // 8} sequences ({dom_rows} rows) per sweep"))

@@ -434,9 +434,9 @@ __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
 // Rider sweeps (dd_engine.hip group_step_rider): the members of eight sequences (a: the groups form, workgroups z < za) AND the
 // riding un-masked rows of up to eight other sequences (u: the lanes form, one row per sequence) in ONE launch — the two are
 // independent and each alone leaves the chip half idle; the bodies are the ones above, so every row keeps its bits.
-template <int G, int GH>
+template <int G, int GH, int NBT>
 __global__ __launch_bounds__(256) void k_attn_partial16_ride(AttnDecodeArgs a, AttnDecodeArgs u, int za) {
-  if ((int)blockIdx.z < za) attn_partial16_body<8, G, GH, 2, 0>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+  if ((int)blockIdx.z < za) attn_partial16_body<NBT, G, GH, 2, 0>(a, blockIdx.x, blockIdx.y, blockIdx.z);
   else attn_partial16_body<1, G, G, 1, 0>(u, blockIdx.x, blockIdx.y, blockIdx.z - za);
 }
 
@@ -465,10 +465,11 @@ __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int
   attn_combine_body<NBT, G>(a, splits_grid, blockIdx.x, blockIdx.y);
 }
 // the merges of a rider sweep in one launch: rows 0..63 the members' (a), rows 64.. the riding rows' (u)
-template <int G>
-__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine_ride(AttnDecodeArgs a, AttnDecodeArgs u, int splits_a, int splits_u) {
-  if (blockIdx.y < 64) attn_combine_body<64, G>(a, splits_a, blockIdx.x, blockIdx.y);
-  else attn_combine_body<8, G>(u, splits_u, blockIdx.x, blockIdx.y - 64);
+// (rows_a = 8 x the member planes; RU = rows per head of the riding rows' partial buffers: 8, or 16 with more than eight of them)
+template <int G, int RU>
+__global__ __launch_bounds__(HEAD_DIM) void k_attn_combine_ride(AttnDecodeArgs a, AttnDecodeArgs u, int splits_a, int splits_u, int rows_a) {
+  if ((int)blockIdx.y < rows_a) attn_combine_body<64, G>(a, splits_a, blockIdx.x, blockIdx.y);
+  else attn_combine_body<RU, G>(u, splits_u, blockIdx.x, blockIdx.y - rows_a);
 }
 
 // Key tiles the partial kernel is LAUNCHED with: the live count rounded up to a multiple of 4 (workgroups of tiles past
@@ -588,30 +589,35 @@ static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
   return launch_attn_groups_n<G, NG, 8>(a, st);
 }
 
-template <int G>
-static int launch_attn_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, hipStream_t st) {
-  constexpr int GH = (8 * G > 16) ? 2 : G;
+template <int G, int NBT>
+static int launch_attn_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, int planes_m, hipStream_t st) {
+  constexpr int GH = (NBT * G > 16) ? 2 : G;
   const int splits_a = ddk_attn_grid_tiles(a.max_T, a.T_cap), splits_u = ddk_attn_grid_tiles(u.max_T, u.T_cap);
   DD_REQUIRE(splits_a >= 1 && splits_a <= ATT_MAX_SPLITS && splits_u >= 1 && splits_u <= ATT_MAX_SPLITS,
              "attn: %d / %d key tiles unsupported (1..%d)", splits_a, splits_u, ATT_MAX_SPLITS);
   AttnDecodeArgs b = a, v = u;
-  attn16_grid(b, splits_a, a.n_kv * 8 * (G / GH));
+  attn16_grid(b, splits_a, a.n_kv * planes_m * (G / GH) * (8 / NBT));
   attn16_grid(v, splits_u, u.n_kv * u.n_lanes);
   const int ya = (splits_a + b.tiles_per_wg - 1) / b.tiles_per_wg, yu = (splits_u + v.tiles_per_wg - 1) / v.tiles_per_wg;
-  const int za = 8 * (G / GH);
-  k_attn_partial16_ride<G, GH><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
-  k_attn_combine_ride<G><<<dim3(a.n_heads, 64 + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u);
+  const int za = planes_m * (G / GH) * (8 / NBT);
+  k_attn_partial16_ride<G, GH, NBT><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
+  if (u.n_lanes > 8) k_attn_combine_ride<G, 16><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
+  else k_attn_combine_ride<G, 8><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
   return DD_OK;
 }
-// a: the member pass of eight sequences (lane_groups == 8), u: un-masked rows of up to eight sequences (lanes form, own partial
-// buffers), both over fp16 caches: the two attentions of a rider sweep in one partial + one combine launch
-int ddk_attn_decode_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, hipStream_t st) {
-  DD_REQUIRE(a.kv16 && u.kv16 && a.lane_groups == 8 && a.n_lanes == 8 && a.nb >= 1 && a.nb <= 8 && u.n_lanes >= 1 && u.n_lanes <= 8 &&
-                 u.nb == u.n_lanes && !u.lane_groups && a.n_heads == u.n_heads && a.n_kv == u.n_kv && a.part_o != u.part_o && a.part_ml != u.part_ml,
-             "attn_ride: a member pass of eight sequences + up to eight riding rows, fp16 caches, separate partial buffers");
+// a: the member pass of a rider sweep (lane_groups == 8: eight sequences, one per plane — or, with half planes, fourteen in planes_m = 7
+// planes), u: un-masked rows of up to sixteen sequences (lanes form, own partial buffers), both over fp16 caches: the two attentions of
+// the sweep in one partial + one combine launch
+int ddk_attn_decode_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, int planes_m, hipStream_t st) {
+  DD_REQUIRE(a.kv16 && u.kv16 && a.lane_groups == 8 && a.n_lanes == 8 && a.nb >= 1 && a.nb <= 8 && u.n_lanes >= 1 && u.n_lanes <= 16 &&
+                 u.nb == u.n_lanes && !u.lane_groups && a.n_heads == u.n_heads && a.n_kv == u.n_kv && a.part_o != u.part_o && a.part_ml != u.part_ml &&
+                 (a.half_planes ? (planes_m == 7 && a.nb <= 4) : planes_m == 8),
+             "attn_ride: a member pass of eight sequences (or fourteen in seven half planes) + up to sixteen riding rows, fp16 caches, separate partial buffers");
   const int G = a.n_heads / a.n_kv;
   DD_REQUIRE(a.n_heads % a.n_kv == 0 && (G == 1 || G == 2 || G == 4), "attn_ride: GQA group %d unsupported (1, 2, 4)", G);
-  int rc = G == 1 ? launch_attn_ride<1>(a, u, st) : (G == 2 ? launch_attn_ride<2>(a, u, st) : launch_attn_ride<4>(a, u, st));
+  int rc;
+  if (a.half_planes) rc = G == 1 ? launch_attn_ride<1, 4>(a, u, planes_m, st) : (G == 2 ? launch_attn_ride<2, 4>(a, u, planes_m, st) : launch_attn_ride<4, 4>(a, u, planes_m, st));
+  else rc = G == 1 ? launch_attn_ride<1, 8>(a, u, planes_m, st) : (G == 2 ? launch_attn_ride<2, 8>(a, u, planes_m, st) : launch_attn_ride<4, 8>(a, u, planes_m, st));
   if (rc != DD_OK) return rc;
   DD_CHECK_LAUNCH();
   return DD_OK;

@@ -191,8 +191,8 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   int max_splits = T / 64;
   DA(h->part_o, (size_t)h->Hkv * max_splits * GROUP_ROWS * G * 128);
   DA(h->part_ml, (size_t)h->Hkv * max_splits * GROUP_ROWS * G * 2);
-  DA(h->part_o_ride, (size_t)h->Hkv * max_splits * 8 * G * 128);
-  DA(h->part_ml_ride, (size_t)h->Hkv * max_splits * 8 * G * 2);
+  DA(h->part_o_ride, (size_t)h->Hkv * max_splits * 16 * G * 128);
+  DA(h->part_ml_ride, (size_t)h->Hkv * max_splits * 16 * G * 2);
   DA(h->hidden, (size_t)MAX_MEMBERS * d);
   DA(h->spec_ok, 4);
   DA(h->rng_backup, 640);
@@ -1271,14 +1271,16 @@ void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st, dd_lm* const* rider = nullptr, int n_rider = 0,
                            bool packed = false) {
   const int d = h->d, dff = h->dff;
-  const int planes = packed ? 8 : (n_rider > 0 ? 9 : ng);
+  const int planes = n_rider > 0 ? 9 : (packed ? 8 : ng);
+  const int hp = packed ? (n_rider > 0 ? 7 : 8) : 0;                  // half planes (with riders: seven of them + two riding planes)
+  const int ride_plane0 = packed ? 7 : 8, ride_row0 = 8 * ride_plane0, ride_slot0 = 2 * hp + (ride_plane0 - hp);
   const int rows_g = packed ? 4 : 8;                                  // rows a sequence owns
   auto row0 = [&](int g) -> int { return packed ? 8 * (g >> 1) + 4 * (g & 1) : 8 * g; };
   EmbedLanes el;
   memset(&el, 0, sizeof(el));
   for (int g = 0; g < ng; ++g)
     for (int m = 0; m < K; ++m) el.state[row0(g) + m] = qs[g]->state;
-  for (int m = 0; m < n_rider; ++m) el.state[64 + m] = rider[m]->state;
+  for (int m = 0; m < n_rider; ++m) el.state[ride_row0 + m] = rider[m]->state;
   RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * planes, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
@@ -1286,7 +1288,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     GemvArgs a;
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
+    a.W = w.wqkv, a.S = h->S_d, a.n_tiles = h->qkv_tiles, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
     a.fp8 = h->fp8, a.wscale = w.s_qkv;
     a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.qbuf = h->qbuf, a.q_tiles = h->q_tiles, a.k_tiles = h->k_tiles;
@@ -1312,8 +1314,9 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     float* rk = h->knew + ((size_t)l * KV_ROWS + RIDER_KV_ROW0) * h->kv_dim;
     float* rv = h->vnew + ((size_t)l * KV_ROWS + RIDER_KV_ROW0) * h->kv_dim;
     if (n_rider) {
-      a.knew_g[8] = rk, a.vnew_g[8] = rv;
-      for (int m = 0; m < n_rider; ++m) a.state_rows[64 + m] = rider[m]->state;
+      a.knew_g[ride_slot0] = rk, a.vnew_g[ride_slot0] = rv;
+      if (n_rider > 8) a.knew_g[ride_slot0 + 1] = rk + (size_t)8 * h->kv_dim, a.vnew_g[ride_slot0 + 1] = rv + (size_t)8 * h->kv_dim;
+      for (int m = 0; m < n_rider; ++m) a.state_rows[ride_row0 + m] = rider[m]->state;
     }
     RC(ddk_gemv_groups(EPI_QKV, a, st));
     if (n_rider) {
@@ -1322,8 +1325,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
       memset(&u, 0, sizeof(u));
       u.wf = h->wf, u.T_cap = h->T_cap, u.kv16 = h->kv16, u.n_heads = h->H, u.n_kv = h->Hkv;
       u.part_o = h->part_o_ride, u.part_ml = h->part_ml_ride;
-      u.qbuf = h->qbuf + (size_t)64 * h->q_dim, u.nb = n_rider, u.n_lanes = n_rider;
-      u.knew = rk, u.vnew = rv, u.xop_out = h->xop_q + (size_t)8 * h->S_q * 64;
+      u.qbuf = h->qbuf + (size_t)ride_row0 * h->q_dim, u.nb = n_rider, u.n_lanes = n_rider;
+      u.knew = rk, u.vnew = rv, u.xop_out = h->xop_q + (size_t)ride_plane0 * h->S_q * 64;
       for (int m = 0; m < n_rider; ++m) {
         dd_lm* q = rider[m];
         u.lane_kc[m] = q->kc + (size_t)l * q->lsk, u.lane_vc[m] = q->vc + (size_t)l * q->lsv, u.lane_state[m] = q->state;
@@ -1331,8 +1334,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
         u.lane_span_start[m] = q->span_start, u.lane_span_len[m] = q->L;
         if (q->T_host > u.max_T) u.max_T = q->T_host;
       }
-      if (g_ride_beside) {           // beside the members' attention: one partial + one combine launch for both
-        RC(ddk_attn_decode_ride(t, u, st));
+      if (g_ride_beside || packed) { // beside the members' attention: one partial + one combine launch for both
+        RC(ddk_attn_decode_ride(t, u, packed ? 7 : 8, st));
       } else {
         RC(ddk_attn_decode(t, st));
         RC(ddk_attn_decode(u, st));
@@ -1342,14 +1345,14 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     }
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
+    a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
     a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
+    a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
     a.fp8 = h->fp8, a.wscale = w.s_gu;
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
@@ -1357,7 +1360,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     RC(ddk_gemv_groups(EPI_SILU, a, st));
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
-    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
+    a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
     a.fp8 = h->fp8, a.wscale = w.s_down;
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
@@ -1368,7 +1371,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   GemvArgs a;
   memset(&a, 0, sizeof(a));
   a.wf = h->wf;
-  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = packed ? 1 : 0;
+  a.W = h->lm_head, a.S = h->S_d, a.n_tiles = h->Vpad / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
   a.fp8 = h->fp8, a.wscale = h->s_lm;
   a.ssq_in = h->ssq_a, a.ssq_n = ssq_n, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
   for (int g = 0; g < ng; ++g) {
@@ -1378,8 +1381,9 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   a.out = qs[0]->member_logits, a.ldo = h->Vpad, a.n_valid = h->V;
   a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
   if (n_rider) {
-    a.out_g[8] = h->grp_logits;
-    for (int m = 0; m < n_rider; ++m) a.state_rows[64 + m] = rider[m]->state;
+    a.out_g[ride_slot0] = h->grp_logits;
+    if (n_rider > 8) a.out_g[ride_slot0 + 1] = h->grp_logits + (size_t)8 * h->Vpad;
+    for (int m = 0; m < n_rider; ++m) a.state_rows[ride_row0 + m] = rider[m]->state;
   }
   RC(ddk_gemv_groups(EPI_STORE, a, st));
   return DD_OK;
@@ -1492,9 +1496,15 @@ static bool half_planes_ok(dd_lm* const* lanes, int n, int K) {
 static int g_rider = 1;          // dd_tools_set_tuning key 26
 void dd_engine_set_rider(int on) { g_rider = on; }
 // branches of the rider form for this call, 0: not applicable
-static int rider_branches(dd_lm* const* lanes, int n, int K) {
-  if (!g_rider || K < 1 || K > 8 || g_pair_sweeps < 8 || n < 16 || (n % 8) != 0 || n > GROUP_MAX_LANES) return 0;
-  if (g_half_planes_first && half_planes_ok(lanes, n, K)) return 0;          // K <= 4: the classic form with half planes (sixteen sequences per sweep)
+// (*gs: sequences per group — 8, or 14 with half planes (K <= 4): seven planes of two sequences + two riding planes)
+static int rider_branches(dd_lm* const* lanes, int n, int K, int* gs_out = nullptr) {
+  if (gs_out) *gs_out = 8;
+  if (!g_rider || K < 1 || K > 8 || g_pair_sweeps < 8 || n < 16 || n > GROUP_MAX_LANES) return 0;
+  const bool hp = half_planes_ok(lanes, n, K);
+  const int gs = (hp && n >= 28 && n % 14 == 0) ? 14 : 8;
+  if (hp && gs == 8 && g_half_planes_first) return 0;            // K <= 4, not whole groups of fourteen: the classic form with half planes
+  if (n % gs) return 0;
+  if (gs_out) *gs_out = gs;
   dd_lm* h0 = lanes[0];
   if (!h0->kv16 || h0->fp8 || !h0->gemv_part) return 0;
   // shapes with nine-plane kernels (dd_gemv.hip try_slices9)
@@ -1508,7 +1518,7 @@ static int rider_branches(dd_lm* const* lanes, int n, int K) {
         q->cfg.vote_on == DD_VOTE_AVERAGE)
       return 0;
   }
-  const int groups = n / 8;
+  const int groups = n / gs;
   int nbr = (g_rider_branches >= 2 && h0->side[0]) ? (g_rider_branches < groups / 2 ? g_rider_branches : groups / 2) : 1;
   while (nbr > 1 && !h0->side[nbr - 2]) --nbr;
   return nbr < 1 ? 1 : nbr;
@@ -1531,9 +1541,12 @@ __global__ void k_promote_base(PromoteTab tab, int Vpad) {
   if (threadIdx.x == 0) tab.adst[m][0] = tab.asrc[m][0];
 }
 
-static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, int nbr, hipStream_t st) {
+// gs = 8: one sequence per member plane; gs = 14 (K <= 4): half planes — fourteen sequences in seven planes, their partners' un-masked
+// rows in planes 7 and 8
+static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, int nbr, int gs, hipStream_t st) {
   dd_lm* h0 = lanes[0];
-  const int groups = n / 8, n_early = 8 * nbr;
+  const int groups = n / gs, n_early = gs * nbr;
+  const bool packed = gs == 14;
   auto begin_lanes = [&](dd_lm* const* qs, int cnt, hipStream_t s) -> int {
     StepBeginLanes t;
     memset(&t, 0, sizeof(t));
@@ -1589,24 +1602,29 @@ static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, in
     int ring[8], k = 0;
     for (int g = br; g < groups; g += nbr) ring[k++] = g;
     for (int j = 0; j < k; ++j) {
-      dd_lm* const* qs = lanes + 8 * ring[j];
+      dd_lm* const* qs = lanes + gs * ring[j];
       const int pg = ring[(j + 1) % k];                    // the group whose un-masked rows ride
-      dd_lm* const* rd = lanes + 8 * pg;
+      dd_lm* const* rd = lanes + gs * pg;
       const bool ahead = j == k - 1;                       // the ring leader's rows of the NEXT step
       dd_lm* scratch = br ? qs[0] : h0;
-      if (ahead) RC(begin_lanes(rd, 8, bs));               // positions of the step ahead (the leader's token was voted in sweep 0)
-      RC(lm_sweep_groups(scratch, qs, 8, K, bs, rd, 8));
-      RC(group_finish(scratch, qs, 8, K, bs));
-      RC(dd_argmax_rows(scratch->grp_logits, 8, h0->V, h0->Vpad, scratch->grp_argmax, bs));
+      if (ahead) RC(begin_lanes(rd, gs, bs));              // positions of the step ahead (the leader's token was voted in sweep 0)
+      RC(lm_sweep_groups(scratch, qs, gs, K, bs, rd, gs, packed));
+      if (packed) {
+        RC(group_finish(scratch, qs, 8, K, bs, 0));
+        RC(group_finish(scratch, qs + 8, gs - 8, K, bs, 8));
+      } else {
+        RC(group_finish(scratch, qs, 8, K, bs));
+      }
+      RC(dd_argmax_rows(scratch->grp_logits, gs, h0->V, h0->Vpad, scratch->grp_argmax, bs));
       ScatterTab tab;
       memset(&tab, 0, sizeof(tab));
-      for (int m = 0; m < 8; ++m) {
+      for (int m = 0; m < gs; ++m) {
         dd_lm* q = rd[m];
         tab.logits[m] = ahead ? q->base_next : q->base_logits, tab.argmax[m] = ahead ? q->argmax_next : q->argmax_base, tab.st[m] = q->state;
       }
-      k_scatter_base<<<8, 256, 0, bs>>>(scratch->grp_logits, scratch->grp_argmax, h0->Vpad, tab);
+      k_scatter_base<<<gs, 256, 0, bs>>>(scratch->grp_logits, scratch->grp_argmax, h0->Vpad, tab);
       DD_CHECK_LAUNCH();
-      if (!ahead) RC(masks(8 * pg, 8, bs));
+      if (!ahead) RC(masks(gs * pg, gs, bs));
     }
   }
   if (fork)
@@ -1647,7 +1665,8 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     DD_REQUIRE(q->n_tok_host < MAX_NEW_TOKENS, "dd_lm_group_step: token buffer full");
     DD_REQUIRE(K == 0 || q->cfg.mask_mode == DD_MASK_IBLIP_QUANTILE || (rngs && rngs[m]), "dd_lm_group_step: sequence %d needs an rng", m);
   }
-  if (const int nbr = rider_branches(lanes, n, K)) return group_step_rider(lanes, n, mprobs, K, rngs, nbr, st);
+  int rider_gs = 8;
+  if (const int nbr = rider_branches(lanes, n, K, &rider_gs)) return group_step_rider(lanes, n, mprobs, K, rngs, nbr, rider_gs, st);
   {
     StepBeginLanes t;
     memset(&t, 0, sizeof(t));
@@ -2177,9 +2196,10 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
   mix((unsigned long long)ddk_attn_grid_tiles(max_T, h0->T_cap));
   mix((unsigned long long)(uintptr_t)st);
   // rider form: which ring leaders have their un-masked rows parked, and the grids of the rows computed a step ahead
-  const int rider_nbr = rider_branches(lanes, n, K);
-  mix(0x7269646572ull + (unsigned long long)rider_nbr);
-  for (int m = 0; m < 8 * rider_nbr; ++m) {
+  int rider_gs = 8;
+  const int rider_nbr = rider_branches(lanes, n, K, &rider_gs);
+  mix(0x7269646572ull + (unsigned long long)rider_nbr + ((unsigned long long)rider_gs << 8));
+  for (int m = 0; m < rider_gs * rider_nbr; ++m) {
     mix(rider_parked(lanes[m]) ? 1ull : 2ull);
     mix((unsigned long long)ddk_attn_grid_tiles(lanes[m]->T_host + 1, lanes[m]->T_cap));
   }
@@ -2188,7 +2208,7 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
       dd_lm* q = lanes[m];
       q->last_K = K, q->T_host += 1, q->n_tok_host += 1, q->steps_since_prefill++;
       if (q->cfg.leak_mask && K > 0) q->have_leak = true;
-      q->pend_valid = m < 8 * rider_nbr, q->pend_step = q->steps_since_prefill;
+      q->pend_valid = m < rider_gs * rider_nbr, q->pend_step = q->steps_since_prefill;
     }
   };
   for (auto& g : h0->graphs)

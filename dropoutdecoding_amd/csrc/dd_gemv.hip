@@ -433,7 +433,7 @@ __device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const
       float y = tile_sum(0, en);
       if (a.ssq_in) y *= rstd_sh[em];
       int col = tile0 * 16 + en;
-      float* row = a.out_g[a.slot(eg, ml)] ? a.out_g[a.slot(eg, ml)] + (size_t)a.slot_row(ml) * a.ldo : a.out + (size_t)em * a.ldo;
+      float* row = a.out_g[a.slot(eg, ml)] ? a.out_g[a.slot(eg, ml)] + (size_t)a.slot_row(eg, ml) * a.ldo : a.out + (size_t)em * a.ldo;
       if (col < a.n_valid && p.pre0 == 0.f) row[col] = y;
     }
   } else if (EPI == EPI_RESID) {
@@ -465,8 +465,8 @@ __device__ __forceinline__ void groups_epilogue(const GemvArgs& a, int wg, const
     }
   } else {  // EPI_QKV
     if (erow) {
-      float* kn = a.knew_g[a.slot(eg, ml)] ? a.knew_g[a.slot(eg, ml)] + (size_t)a.slot_row(ml) * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
-      float* vn = a.vnew_g[a.slot(eg, ml)] ? a.vnew_g[a.slot(eg, ml)] + (size_t)a.slot_row(ml) * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+      float* kn = a.knew_g[a.slot(eg, ml)] ? a.knew_g[a.slot(eg, ml)] + (size_t)a.slot_row(eg, ml) * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
+      float* vn = a.vnew_g[a.slot(eg, ml)] ? a.vnew_g[a.slot(eg, ml)] + (size_t)a.slot_row(eg, ml) * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
 #pragma unroll
       for (int tt = 0; tt < TILES; ++tt) {
         float y = tile_sum(tt, en);
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(32 * NG) void k_gemv_finish4(GemvArgs a, const floa
   }
   if (EPI == EPI_STORE) {
     if (erow && !done) {
-      float* row = a.out_g[a.slot(eg, ml)] ? a.out_g[a.slot(eg, ml)] + (size_t)a.slot_row(ml) * a.ldo : a.out + (size_t)em * a.ldo;
+      float* row = a.out_g[a.slot(eg, ml)] ? a.out_g[a.slot(eg, ml)] + (size_t)a.slot_row(eg, ml) * a.ldo : a.out + (size_t)em * a.ldo;
       const int col = tile0 * 16 + n0;
       float o[4];
 #pragma unroll
@@ -796,8 +796,8 @@ __global__ __launch_bounds__(32 * NG) void k_gemv_finish4(GemvArgs a, const floa
       xop_store16x4(a.xop_next, wg * 16 + n0, em, z, a.S_next, a.wf);
     }
   } else {  // EPI_QKV
-    float* kn = a.knew_g[a.slot(eg, ml)] ? a.knew_g[a.slot(eg, ml)] + (size_t)a.slot_row(ml) * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
-    float* vn = a.vnew_g[a.slot(eg, ml)] ? a.vnew_g[a.slot(eg, ml)] + (size_t)a.slot_row(ml) * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
+    float* kn = a.knew_g[a.slot(eg, ml)] ? a.knew_g[a.slot(eg, ml)] + (size_t)a.slot_row(eg, ml) * a.kv_dim : a.knew + (size_t)em * a.kv_dim;
+    float* vn = a.vnew_g[a.slot(eg, ml)] ? a.vnew_g[a.slot(eg, ml)] + (size_t)a.slot_row(eg, ml) * a.kv_dim : a.vnew + (size_t)em * a.kv_dim;
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) yq_sh[tt * 32 * NG + t] = (f32x4_t){y[tt][0], y[tt][1], y[tt][2], y[tt][3]};
     __syncthreads();
@@ -1122,7 +1122,8 @@ int ddk_gemv_groups(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv_groups: nb=%d rows per group", a.nb);
   DD_REQUIRE(!a.fp8 || a.wscale, "gemv_groups: fp8 weights need row scales");
   DD_REQUIRE(a.n_groups == 2 || a.n_groups == 4 || a.n_groups == 8 || a.n_groups == 9, "gemv_groups: %d groups (2, 4, 8 or 9)", a.n_groups);
-  DD_REQUIRE(!a.half_planes || (a.n_groups == 8 && a.nb <= 4 && !a.fp8 && a.part && g_gemv_slices), "gemv_groups: half planes take an eight-plane pass of 16-bit weights, K <= 4");
+  DD_REQUIRE(!a.half_planes || (((a.n_groups == 8 && a.half_planes == 8) || (a.n_groups == 9 && a.half_planes == 7)) && a.nb <= 4 && !a.fp8 && a.part && g_gemv_slices),
+             "gemv_groups: half planes take an eight- or nine-plane pass of 16-bit weights, K <= 4");
   if (a.n_groups == 9) {
     int rs = a.part ? try_slices9(epi, a, st) : SLICES_UNSUPPORTED;
     DD_REQUIRE(rs != SLICES_UNSUPPORTED, "gemv_groups: no nine-plane kernel for this matrix (K = %d, %d tiles, fp8 %d)", a.S * 32, a.n_tiles, a.fp8);

@@ -130,15 +130,19 @@ struct GemvArgs {
   // buffers
   int n_groups;
   int nb_rider;         // n_groups == 9: live rows of plane 8 (the riding un-masked rows: one per sequence, not one per member); 0: nb
-  // half_planes (K <= 4): a plane carries the members of TWO sequences — rows 0..3 sequence 2 g, rows 4..7 sequence 2 g + 1, nb (<= 4)
-  // live rows each — and out_g / knew_g / vnew_g are indexed by SEQUENCE (16 of them in a 64-row pass), rows by member
+  // half_planes = H > 0 (K <= 4): the first H planes carry the members of TWO sequences each — rows 0..3 sequence 2 g, rows 4..7 sequence
+  // 2 g + 1, nb (<= 4) live rows each; H = 8: all planes of a 64-row pass (sixteen sequences), H = 7 with n_groups == 9: fourteen
+  // sequences + TWO riding planes (7 and 8: nb_rider un-masked rows, one per sequence).  out_g / knew_g / vnew_g are indexed by slot:
+  // sequence s for the half planes, 2 H + (plane - H) for the others; rows by member (riding planes: by row)
   int half_planes;
   __host__ __device__ bool row_live(int plane, int ml) const {
-    if (half_planes) return (ml & 3) < nb;
-    return ml < ((plane == 8 && nb_rider) ? nb_rider : nb);
+    if (plane < half_planes) return (ml & 3) < nb;
+    const int ride0 = half_planes ? half_planes : 8;                  // first riding plane
+    if (nb_rider && plane >= ride0) return ml < nb_rider - 8 * (plane - ride0);
+    return ml < nb;
   }
-  __host__ __device__ int slot(int plane, int ml) const { return half_planes ? 2 * plane + (ml >> 2) : plane; }   // index into out_g / knew_g / vnew_g
-  __host__ __device__ int slot_row(int ml) const { return half_planes ? (ml & 3) : ml; }                          // row within that buffer
+  __host__ __device__ int slot(int plane, int ml) const { return plane < half_planes ? 2 * plane + (ml >> 2) : 2 * half_planes + (plane - half_planes); }
+  __host__ __device__ int slot_row(int plane, int ml) const { return plane < half_planes ? (ml & 3) : ml; }
   float* out_g[16];     // EPI_STORE rows of group g (null: out + 8 g * ldo)
   float* knew_g[16];    // EPI_QKV rows of group g (null: knew + 8 g * kv_dim)
   float* vnew_g[16];
@@ -205,7 +209,7 @@ struct AttnDecodeArgs {
   int lane_span_start[16], lane_span_len[16];
 };
 int ddk_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
-int ddk_attn_decode_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, hipStream_t st);   // member pass of 8 sequences + riding rows, one launch
+int ddk_attn_decode_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, int planes_m, hipStream_t st);   // member pass (planes_m planes) + riding rows, one launch
 int ddk_attn_grid_tiles(int T, int T_cap);   // tiles the decode attention is launched with for a prefix of T keys
 
 // ---- prefill (M rows) -------------------------------------------------------------------------

@@ -1,7 +1,9 @@
 """K <= 4 (the reference's own settings: voting_numbers [0.1, 0.3, 0.5, 0.7], [0.3, 0.5, 0.7], ... — chair_test/chair_test.py:165-170,
 models/config.py:2): the members of a sequence fill half an operand plane, so a 64-row member sweep carries SIXTEEN sequences, two per
 plane (csrc/dd_engine.hip lm_sweep_groups `packed`, GemvArgs / AttnDecodeArgs `half_planes`).  Tokens, logits, masks, KV checksums and
-rng streams must be bit-identical to the one-sequence-per-plane sweeps and to every sequence decoded alone.  7B-family shapes, two layers."""
+rng streams must be bit-identical to the one-sequence-per-plane sweeps and to every sequence decoded alone.  Whole groups of fourteen (28,
+42, 56 lanes) take the rider form on top: seven half planes + TWO riding planes with their partners' un-masked rows.  7B-family shapes,
+two layers."""
 import numpy as np
 import pytest
 import torch
@@ -30,7 +32,8 @@ def T():
 
 def _run(E, T, engines, embs, spans, probs, steps, half, graph, eos=None):
     T.dd_tools_set_tuning(30, 1 if half else 0)
-    T.dd_tools_set_tuning(26, 0)                # reference run: the classic form, one sequence per plane
+    T.dd_tools_set_tuning(26, 1 if half else 0)  # reference run: the classic form, one sequence per plane; half planes: whole groups of
+                                                 # fourteen take the rider form (seven half planes + two riding planes), other line-ups the classic one
     T.dd_tools_set_tuning(8, 1 if graph else 0)
     for i, (e, emb, (s0, L)) in enumerate(zip(engines, embs, spans)):
         e.rng.manual_seed(50 + i)
@@ -61,6 +64,10 @@ def _run(E, T, engines, embs, spans, probs, steps, half, graph, eos=None):
     ("mistral-7b shapes (GQA 4), 16 lanes, K = 4, LLaVA-NeXT rule", "llava-next", (4096, 14336, 32, 8), 16, K4, {}),
     ("InstructBLIP rule (vote on the hidden rows of a half plane, leaked zeros), 16 lanes, K = 4", "instructblip", (4096, 11008, 32, 32), 16, K4, {}),
     ("llama-7b shapes, 16 lanes, K = 2, Philox stream", "llava-1.5", (4096, 11008, 32, 32), 16, [0.5, 0.3], {"rng_stream": "gpu"}),
+    ("rider form, 28 lanes, K = 4: one ring of two groups of fourteen", "llava-1.5", (4096, 11008, 32, 32), 28, K4, {}),
+    ("rider form, 56 lanes, K = 3: two branches, rings of two", "llava-1.5", (4096, 11008, 32, 32), 56, K3, {}),
+    ("rider form, 42 lanes, K = 4: one ring of three, GQA, LLaVA-NeXT rule", "llava-next", (4096, 14336, 32, 8), 42, K4, {}),
+    ("rider form, 28 lanes, K = 4, InstructBLIP rule with masked positions", "instructblip", (4096, 11008, 32, 32), 28, K4, {"iblip_positions": "mask"}),
 ])
 def test_half_plane_sweeps_equal_plain_sweeps_and_solo_runs(E, T, name, family, dims, n_lanes, probs, kw):
     d, dff, H, Hkv = dims
@@ -74,7 +81,7 @@ def test_half_plane_sweeps_equal_plain_sweeps_and_solo_runs(E, T, name, family, 
     for graph in (False, True):
         got = _run(E, T, engines, embs, spans, probs, steps, half=True, graph=graph)
         _same(got, ref, f"{name} (graph {graph})")
-    for li in (1, 8, n_lanes - 1):          # second sequence of a plane, first of another, the last lane
+    for li in (1, 8, 15, n_lanes - 1):      # second sequence of a plane, first of another, a rider of the second riding plane, the last lane
         e = engines[li]
         e.set_speculation("never")
         e.rng.manual_seed(50 + li)
