@@ -94,7 +94,8 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // fp16-cache decode attention, 22 = all-tiles form of that attention, 23 = concurrent member sweeps of a
 // classic group step, 24 = four-columns-per-thread finishing kernel of the slice GEMVs (bit mask over the epilogues), 26 = rider form of the
 // group step (0: the classic form always), 27 = the riding rows' attention inside the members' launches, 28 = branches of the rider
-// form (1..4), 29 = weight requests in flight per wave of the nine-plane qkv / gate-up kernels (4 or 8); the product switches
+// form (1..4), 29 = weight requests in flight per wave of the nine-plane qkv / gate-up kernels (4 or 8), 30 = half planes for K <= 4, 31 = half
+// planes (classic form) before the rider form for line-ups that are not whole groups of fourteen; the product switches
 // (8, 11, 13-16) are forwarded to dd_set_tuning.  Every call bumps the graph-key epoch: steps captured under other settings are not replayed.
 extern int g_exp_G[4];
 extern int g_attn16_tpw, g_attn16_full, g_finish4;
