@@ -696,9 +696,11 @@ class EngineGroup:
             # whole groups of eight keep the rider form of the step (csrc/dd_engine.hip group_step_rider): sequences that ended at an EOS
             # stay in the line-up while they fill the last group — their steps are no-ops on the device (DDState::done: nothing is
             # written, nothing drawn from their rng streams)
-            if eos_set and len(active) >= 16 and len(active) % 8:
+            # (K <= 4: groups of fourteen — two sequences per operand plane, seven planes + two riding planes)
+            group = 14 if (dropout and len(E[0]._probs(mprobs)[0]) <= 4 and len(E) % 14 == 0 and len(active) >= 28) else 8
+            if eos_set and len(active) >= 16 and len(active) % group:
                 ended = [i for i in range(len(E)) if i not in active and any(t in eos_set for t in seen[i])]
-                need = -len(active) % 8
+                need = -len(active) % group
                 if len(ended) >= need:
                     active = sorted(active + ended[:need])
             self.decode_step(mprobs, dropout=dropout, active=active)

@@ -112,3 +112,44 @@ def test_half_plane_sweeps_with_sequences_that_end(E, T):
         _same(got, ref, f"EOS run (graph {graph})")
     for e in reversed(engines):
         e.close()
+
+
+def test_generate_keeps_groups_of_fourteen_while_sequences_end(E, T):
+    """EngineGroup.generate at K = 4 with EOS ids and 28 lanes: ended sequences stay in the line-up while they fill the last group of
+    fourteen; tokens and rng streams as with one sequence per plane in the classic form, and as each sequence alone."""
+    d = 4096
+    cfg = E.LMConfig(2048, d, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
+    L, n, n_new = 24, 28, 9
+    engines = _group(E, T, cfg, n, "llava-1.5", L)
+    gen = torch.Generator().manual_seed(29)
+    embs = [(torch.randn(L + 6 + (i % 5), d, generator=gen) * 0.5).cuda() for i in range(n)]
+    spans = [(2 + (i % 3), L) for i in range(n)]
+
+    def run(half, eos):
+        T.dd_tools_set_tuning(30, 1 if half else 0)
+        T.dd_tools_set_tuning(26, 1 if half else 0)
+        for i, e in enumerate(engines):
+            e.rng.manual_seed(50 + i)
+            e.prefill(embs[i], *spans[i])
+        toks = E.EngineGroup(engines).generate(n_new, eos=eos, mprobs=K4, lookahead=3)
+        tails = [e.rng.rand(8).cpu().numpy().copy() for e in engines]
+        T.dd_tools_set_tuning(30, 1)
+        T.dd_tools_set_tuning(26, 1)
+        return toks, tails
+
+    free, _ = run(False, None)
+    eos = sorted({free[2][2], free[15][4], free[20][6]})
+    want, wtails = run(False, eos)
+    lens = sorted(len(t) for t in want)
+    assert lens[0] < n_new and lens[-1] == n_new, lens
+    got, gtails = run(True, eos)
+    assert got == want
+    for a, b in zip(gtails, wtails):
+        np.testing.assert_array_equal(a, b)
+    for li in (2, 15, 27):
+        e = engines[li]
+        e.rng.manual_seed(50 + li)
+        e.prefill(embs[li], *spans[li])
+        assert e.generate(n_new, eos=eos, mprobs=K4) == want[li], f"lane {li} alone"
+    for e in reversed(engines):
+        e.close()
