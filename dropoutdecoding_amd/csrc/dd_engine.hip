@@ -1494,6 +1494,8 @@ static bool half_planes_ok(dd_lm* const* lanes, int n, int K) {
   return true;
 }
 static int g_rider = 1;          // dd_tools_set_tuning key 26
+static int g_rider_staged = 1;   // dd_tools_set_tuning key 33: the rings' sweeps in stages, late groups' masks sampled between the stages on the caller's stream
+void dd_engine_set_rider_staged(int on) { g_rider_staged = on; }
 void dd_engine_set_rider(int on) { g_rider = on; }
 // branches of the rider form for this call, 0: not applicable
 // (*gs: sequences per group — 8, or 14 with half planes (K <= 4): seven planes of two sequences + two riding planes)
@@ -1597,13 +1599,40 @@ static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, in
     DD_HIP(hipEventRecord(h0->ev_fork, st));
     for (int i = 0; i + 1 < nbr; ++i) DD_HIP(hipStreamWaitEvent(h0->side[i], h0->ev_fork, 0));
   }
+  // Stages: stage j runs the j-th sweep of every ring, one ring per branch; the branches meet after each stage, and the masks of the
+  // groups whose un-masked rows just rode are sampled in ONE launch on the caller's stream with nothing beside it — as the masks of the
+  // ring leaders (above) and of the classic step are.  (Sampled on the branches, beside the other rings' sweeps, a sequence's tokens
+  // differed between two identical runs about once in 2,000 64-lane steps — always a sequence whose masks had been sampled that way;
+  // tools/stress_lanes.py.  dd_tools_set_tuning key 33 = 0 restores that form for the comparison.)
+  int ring[4][8], klen[4], kmax = 0;
   for (int br = 0; br < nbr; ++br) {
-    hipStream_t bs = br ? h0->side[br - 1] : st;
-    int ring[8], k = 0;
-    for (int g = br; g < groups; g += nbr) ring[k++] = g;
-    for (int j = 0; j < k; ++j) {
-      dd_lm* const* qs = lanes + gs * ring[j];
-      const int pg = ring[(j + 1) % k];                    // the group whose un-masked rows ride
+    klen[br] = 0;
+    for (int g = br; g < groups; g += nbr) ring[br][klen[br]++] = g;
+    if (klen[br] > kmax) kmax = klen[br];
+  }
+  auto fork_all = [&]() -> int {
+    if (!fork) return DD_OK;
+    DD_HIP(hipEventRecord(h0->ev_fork, st));
+    for (int i = 0; i + 1 < nbr; ++i) DD_HIP(hipStreamWaitEvent(h0->side[i], h0->ev_fork, 0));
+    return DD_OK;
+  };
+  auto join_all = [&]() -> int {
+    if (!fork) return DD_OK;
+    for (int i = 0; i + 1 < nbr; ++i) {
+      DD_HIP(hipEventRecord(h0->ev_join[i], h0->side[i]));
+      DD_HIP(hipStreamWaitEvent(st, h0->ev_join[i], 0));
+    }
+    return DD_OK;
+  };
+  for (int j = 0; j < kmax; ++j) {
+    if (j > 0 && g_rider_staged) RC(fork_all());
+    int late[4], n_late = 0;                               // groups whose masks follow this stage
+    for (int br = 0; br < nbr; ++br) {
+      if (j >= klen[br]) continue;
+      const int k = klen[br];
+      hipStream_t bs = br ? h0->side[br - 1] : st;
+      dd_lm* const* qs = lanes + gs * ring[br][j];
+      const int pg = ring[br][(j + 1) % k];                // the group whose un-masked rows ride
       dd_lm* const* rd = lanes + gs * pg;
       const bool ahead = j == k - 1;                       // the ring leader's rows of the NEXT step
       dd_lm* scratch = br ? qs[0] : h0;
@@ -1624,14 +1653,28 @@ static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, in
       }
       k_scatter_base<<<gs, 256, 0, bs>>>(scratch->grp_logits, scratch->grp_argmax, h0->Vpad, tab);
       DD_CHECK_LAUNCH();
-      if (!ahead) RC(masks(gs * pg, gs, bs));
+      if (!ahead) {
+        if (g_rider_staged) late[n_late++] = pg;
+        else RC(masks(gs * pg, gs, bs));
+      }
+    }
+    if (g_rider_staged || j == kmax - 1) RC(join_all());
+    if (n_late) {                                          // one launch for all of them (at most 32 sequences per launch)
+      MaskLaneArgs ml[32];
+      int cnt = 0;
+      for (int i = 0; i < n_late; ++i)
+        for (int m = 0; m < gs; ++m) {
+          const int li = gs * late[i] + m;
+          dd_lm* q = lanes[li];
+          ml[cnt++] = {q->epi, q->L, q->keep, q->argmax_base, q->topk_ids, dd_rng_state_ptr(rngs ? rngs[li] : nullptr), q->drop, q->n_drop,
+                       q->drop_bits, &q->state->done};
+          if (cnt == 32 || (i == n_late - 1 && m == gs - 1)) {
+            RC(dd_sample_masks_lanes(ml, cnt, h0->cfg.k_top, mprobs, K, h0->cfg.mask_mode, st));
+            cnt = 0;
+          }
+        }
     }
   }
-  if (fork)
-    for (int i = 0; i + 1 < nbr; ++i) {
-      DD_HIP(hipEventRecord(h0->ev_join[i], h0->side[i]));
-      DD_HIP(hipStreamWaitEvent(st, h0->ev_join[i], 0));
-    }
   for (int m = 0; m < n; ++m) {
     dd_lm* q = lanes[m];
     q->pend_valid = m < n_early, q->pend_step = q->steps_since_prefill;

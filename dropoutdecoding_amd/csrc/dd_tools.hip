@@ -95,7 +95,8 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // classic group step, 24 = four-columns-per-thread finishing kernel of the slice GEMVs (bit mask over the epilogues), 26 = rider form of the
 // group step (0: the classic form always), 27 = the riding rows' attention inside the members' launches, 28 = branches of the rider
 // form (1..4), 29 = weight requests in flight per wave of the nine-plane qkv / gate-up kernels (4 or 8), 30 = half planes for K <= 4, 31 = half
-// planes (classic form) before the rider form for line-ups that are not whole groups of fourteen; the product switches
+// planes (classic form) before the rider form for line-ups that are not whole groups of fourteen, 33 = rider rings in stages (masks
+// between the stages on the caller's stream); the product switches
 // (8, 11, 13-16) are forwarded to dd_set_tuning.  Every call bumps the graph-key epoch: steps captured under other settings are not replayed.
 extern int g_exp_G[4];
 extern int g_attn16_tpw, g_attn16_full, g_finish4;
@@ -106,11 +107,12 @@ void dd_engine_set_ride_beside(int on);
 void dd_engine_set_rider_branches(int n);
 void dd_engine_set_half_planes(int on);
 void dd_engine_set_half_planes_first(int on);
+void dd_engine_set_rider_staged(int on);
 extern int g_exp_U9;
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31),
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -126,6 +128,7 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 29) g_exp_U9 = value;
   else if (key == 30) dd_engine_set_half_planes(value);
   else if (key == 31) dd_engine_set_half_planes_first(value);
+  else if (key == 33) dd_engine_set_rider_staged(value);
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }

@@ -41,7 +41,9 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * 0: always the classic form: one fused un-masked sweep + the member sweeps), 27 the riding rows' attention inside the members'
  * launches (default 1), 28 branches of the rider form (1..4, default 4), 29 weight requests in flight per wave of the nine-plane
  * qkv / gate-up kernels (4 or 8, default 4), 30 half planes for K <= 4 (two sequences per operand plane, default 1), 31 half planes
- * before the rider form where both apply and the line-up is not whole groups of fourteen (default 1).  Keys of dd_set_tuning are forwarded.  Every call starts a new epoch of the step-graph
+ * before the rider form where both apply and the line-up is not whole groups of fourteen (default 1), 33 the rider form's rings in stages with
+ * the masks of the groups whose rows rode sampled between the stages on the caller's stream (default 1; 0: on the branches).  Keys of
+ * dd_set_tuning are forwarded.  Every call starts a new epoch of the step-graph
  * keys: a step captured under other settings is never replayed. */
 int dd_tools_set_tuning(int key, int value);
 

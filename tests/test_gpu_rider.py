@@ -241,3 +241,36 @@ def test_rider_step_other_families(E, T, name, family, dims, kw):
         e.set_speculation("default")
     for e in reversed(engines):
         e.close()
+
+
+def test_full_size_64_lanes_repeat_bitwise(E):
+    """LLaVA-1.5-7B shapes, all 32 layers, 64 lanes (the bench's line-up: four rings on four branches, stages): three repetitions of
+    (prefill, 40 steps) from the same seeds give the same tokens and the same KV checksums — the check tools/stress_lanes.py runs for
+    thousands of steps (branch-local mask sampling failed it about once in 2,000 steps)."""
+    n, steps = 64, 40
+    engines = []
+    for i in range(n):
+        engines.append(E.DropoutEngine(E.LLAVA15_7B, family=E.FAMILY_LLAVA, max_seq=704, max_visual=576, kv_format="fp16",
+                                       share_weights_with=engines[0] if engines else None))
+    engines[0].load_synthetic(0, 0.02)
+    embs = [torch.randn(608, 4096, generator=torch.Generator().manual_seed(i)).cuda() for i in range(n)]
+    first = None
+    for rep in range(3):
+        torch.cuda.synchronize()
+        for e in engines:
+            e.rng.manual_seed(24)
+        torch.cuda.synchronize()
+        for e, x in zip(engines, embs):
+            e.prefill(x, 5, 576)
+        grp = E.EngineGroup(engines)
+        for _ in range(steps):
+            grp.decode_step(K8)
+        got = ([e.tokens() for e in engines], [e.kv_sums().copy() for e in engines])
+        if first is None:
+            first = got
+            continue
+        assert got[0] == first[0], f"repetition {rep}: tokens"
+        for i, (a, b) in enumerate(zip(got[1], first[1])):
+            np.testing.assert_array_equal(a, b, err_msg=f"repetition {rep}: KV checksums, lane {i}")
+    for e in reversed(engines):
+        e.close()
