@@ -26,7 +26,8 @@ SYMBOLS = [
 
 # include/dropdec_tools.h: libdropdec_tools.so only (bench.py's roofline leg, tools/)
 TOOLS_LIB_PATH = os.path.join(_HERE, "libdropdec_tools.so")
-TOOLS_SYMBOLS = ["dd_lm_time_sweep", "dd_lm_time_gemv", "dd_tools_last_gemv_kernel", "dd_hbm_read_bench", "dd_tools_set_tuning"]
+TOOLS_SYMBOLS = ["dd_lm_time_sweep", "dd_lm_time_gemv", "dd_tools_last_gemv_kernel", "dd_hbm_read_bench", "dd_tools_set_tuning",
+                 "dd_tools_trace_attach", "dd_tools_lds_poison", "dd_tools_scratch_probe", "dd_tools_sample_masks_lanes"]
 
 
 TP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)     # int exchange(void* ctx, int rows, void* stream)
@@ -87,6 +88,10 @@ def load_tools() -> C.CDLL:
         lib.dd_tools_last_gemv_kernel.restype = C.c_char_p
         lib.dd_hbm_read_bench.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
         lib.dd_tools_set_tuning.argtypes = [C.c_int, C.c_int]
+        lib.dd_tools_trace_attach.argtypes = [vp, vp, C.c_int, vp]
+        lib.dd_tools_lds_poison.argtypes = [C.c_int, C.c_int, C.c_int, vp]
+        lib.dd_tools_scratch_probe.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
+        lib.dd_tools_sample_masks_lanes.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
     return _tools
 
 

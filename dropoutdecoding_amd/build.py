@@ -4,10 +4,17 @@ csrc/dd_tools.hip, for bench.py's roofline leg and tools/) in-tree with hipcc fo
     python -m dropoutdecoding_amd.build [--force]
 
 The built .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+
+Gate: every object is compiled with -Rpass-analysis=kernel-resource-usage and the build FAILS when a kernel of the product
+library reports private scratch (ScratchSize > 0).  Round 3's one run-to-run token difference sat in the one kernel of 381
+that had any (DESIGN.md "Determinism"); a by-value struct indexed at run time or an unroll budget that is exceeded puts
+arrays into scratch silently, and scratch is both slow and allocated per queue by the runtime at dispatch time.
 """
 from __future__ import annotations
 
+import fcntl
 import os
+import re
 import subprocess
 import sys
 
@@ -18,10 +25,14 @@ LIB = os.path.join(HERE, "libdropdec.so")
 TOOLS_LIB = os.path.join(HERE, "libdropdec_tools.so")
 TOOLS_SOURCES = ["dd_tools.hip"]      # only in libdropdec_tools.so
 SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_gemv.hip", "dd_attn_decode.hip", "dd_prefill.hip", "dd_engine.hip", "dd_tp.hip", "dd_vision.hip"]
+# sources that libdropdec_tools.so takes in a second compilation with extra macros (A/B variants that must not be in the product)
+TOOLS_VARIANTS = {"dd_dropout.hip": ["-DDD_KEEP_SCRATCH_SAMPLER"]}
 HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", "dd_engine_internal.h",
            os.path.join(ROOT, "include", "dropdec_tools.h"), os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+FLAGS = ["-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
+# kernels allowed to use scratch in the PRODUCT library: none
+SCRATCH_ALLOWED: tuple = ()
 
 
 def _file_hash(paths) -> str:
@@ -38,7 +49,7 @@ def _header_paths():
 
 
 def _src_hash() -> str:
-    return _file_hash([os.path.join(CSRC, s) for s in SOURCES + TOOLS_SOURCES] + _header_paths()) + "|" + " ".join(FLAGS)
+    return _file_hash([os.path.join(CSRC, s) for s in SOURCES + TOOLS_SOURCES] + _header_paths() + [__file__]) + "|" + " ".join(FLAGS)
 
 
 def _stale() -> bool:
@@ -49,35 +60,142 @@ def _stale() -> bool:
     return open(stamp).read().strip() != _src_hash()
 
 
+_REMARK = re.compile(r"remark: (?:\s*)(Function Name|ScratchSize \[bytes/lane\]|VGPRs|AGPRs|LDS Size \[bytes/block\]|Occupancy \[waves/SIMD\]): (\S+)")
+
+
+def parse_resource_remarks(text: str):
+    """[{name, scratch, vgprs, agprs, lds, occupancy}] from hipcc's -Rpass-analysis=kernel-resource-usage output."""
+    out, cur = [], None
+    for line in text.splitlines():
+        m = _REMARK.search(line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k == "Function Name":
+            cur = {"name": v, "scratch": 0, "vgprs": 0, "agprs": 0, "lds": 0, "occupancy": 0}
+            out.append(cur)
+        elif cur is not None:
+            key = {"ScratchSize [bytes/lane]": "scratch", "VGPRs": "vgprs", "AGPRs": "agprs", "LDS Size [bytes/block]": "lds",
+                   "Occupancy [waves/SIMD]": "occupancy"}[k]
+            cur[key] = int(v)
+    return out
+
+
+def _demangle(name: str) -> str:
+    try:
+        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+    except Exception:
+        return name
+
+
+def kernel_resources():
+    """Resource usage of every kernel of the last build: {object file name: [records]} (from build/<obj>.remarks)."""
+    bdir = os.path.join(HERE, "build")
+    res = {}
+    for f in sorted(os.listdir(bdir)) if os.path.isdir(bdir) else []:
+        if f.endswith(".remarks"):
+            res[f[:-len(".remarks")]] = parse_resource_remarks(open(os.path.join(bdir, f)).read())
+    return res
+
+
+def _check_scratch(objs) -> None:
+    bad = []
+    for o in objs:
+        rp = o + ".remarks"
+        if not os.path.exists(rp):
+            continue
+        for k in parse_resource_remarks(open(rp).read()):
+            if k["scratch"] > 0 and not any(a in k["name"] for a in SCRATCH_ALLOWED):
+                bad.append((os.path.basename(o), _demangle(k["name"]), k["scratch"]))
+    if bad:
+        msg = "\n".join(f"  {o}: {n}: ScratchSize {s} bytes/lane" for o, n, s in bad)
+        raise RuntimeError("kernels of the product library use private scratch (see dropoutdecoding_amd/build.py):\n" + msg)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the sources whose content (or a header's) changed — all of them in parallel — and link."""
+    """Compile the sources whose content (or a header's) changed and link.  One builder at a time (file lock), a bounded number of
+    hipcc jobs, objects and stamps written to temporaries and renamed."""
     if not force and not _stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs, jobs = [], []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
-    tools_objs = []
-    for s in SOURCES + TOOLS_SOURCES:
-        o = os.path.join(bdir, s.replace(".hip", ".o"))
-        (tools_objs if s in TOOLS_SOURCES else objs).append(o)
-        want = _file_hash([os.path.join(CSRC, s)] + _header_paths()) + "|" + " ".join(FLAGS)
+    with open(os.path.join(bdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)             # spawned ranks / test workers after a source change: the second one waits
+        if not force and not _stale():
+            return LIB
+        return _build_locked(force, verbose, bdir)
+
+
+def _build_locked(force: bool, verbose: bool, bdir: str) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs, tools_objs, todo = [], [], []
+    units = [(s, [], s.replace(".hip", ".o")) for s in SOURCES + TOOLS_SOURCES]
+    units += [(s, extra, s.replace(".hip", "_tools.o")) for s, extra in TOOLS_VARIANTS.items()]
+    for s, extra, oname in units:
+        o = os.path.join(bdir, oname)
+        if extra:
+            pass                                          # variant objects: picked per library below
+        elif s in TOOLS_SOURCES:
+            tools_objs.append(o)
+        else:
+            objs.append(o)
+        want = _file_hash([os.path.join(CSRC, s)] + _header_paths()) + "|" + " ".join(FLAGS + extra)
         stamp = o + ".srchash"
-        if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        if not force and os.path.exists(o) and os.path.exists(stamp) and os.path.exists(o + ".remarks") and open(stamp).read().strip() == want:
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        todo.append((s, extra, o, stamp, want))
+    max_jobs = max(1, min(len(todo), int(os.environ.get("DD_BUILD_JOBS", "0")) or max(1, (os.cpu_count() or 2) // 2)))
+    running, failed = [], None
+
+    def reap(block: bool):
+        nonlocal failed
+        for item in list(running):
+            pr, cmd, o, stamp, want, tmp_o, err_path, err_f = item
+            rc = pr.wait() if block else pr.poll()
+            if rc is None:
+                continue
+            running.remove(item)
+            err_f.close()
+            text = open(err_path, errors="replace").read()
+            lines = text.splitlines()
+            other = []                                # warnings / errors with the lines that follow them; the resource remarks stay in the file
+            for i, ln in enumerate(lines):
+                if re.search(r"(warning|error|fatal error): ", ln) and "[-Rpass-analysis" not in ln:
+                    other.extend(lines[i:i + 4])
+            if rc != 0:
+                failed = failed or subprocess.CalledProcessError(rc, cmd, stderr="\n".join(other[-40:]))
+                sys.stderr.write("\n".join(other[-40:]) + "\n")
+                continue
+            if other and verbose:
+                sys.stderr.write("\n".join(other) + "\n")
+            os.replace(tmp_o, o)
+            os.replace(err_path, o + ".remarks")
+            with open(stamp + f".tmp{os.getpid()}", "w") as f:
+                f.write(want)
+            os.replace(stamp + f".tmp{os.getpid()}", stamp)
+
+    for s, extra, o, stamp, want in todo:
+        while len(running) >= max_jobs and failed is None:
+            reap(block=False)
+            if len(running) >= max_jobs:
+                running[0][0].wait()
+        if failed is not None:
+            break
+        tmp_o = o + f".tmp{os.getpid()}"
+        err_path = o + f".err{os.getpid()}"
+        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *extra, "-c", os.path.join(CSRC, s), "-o", tmp_o]
         if verbose:
             print(" ".join(cmd))
-        jobs.append((subprocess.Popen(cmd), cmd, stamp, want))
-    for pr, cmd, stamp, want in jobs:
-        if pr.wait() != 0:
-            for other, *_ in jobs:
-                if other.poll() is None:
-                    other.kill()
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-        with open(stamp, "w") as f:
-            f.write(want)
-    for lib, members in ((LIB, objs), (TOOLS_LIB, objs + tools_objs)):
+        err_f = open(err_path, "w")
+        running.append((subprocess.Popen(cmd, stderr=err_f), cmd, o, stamp, want, tmp_o, err_path, err_f))
+    while running:
+        reap(block=True)
+    if failed is not None:
+        raise failed
+    _check_scratch(objs)
+    variant_of = {os.path.join(bdir, s.replace(".hip", ".o")): os.path.join(bdir, s.replace(".hip", "_tools.o")) for s in TOOLS_VARIANTS}
+    tools_members = [variant_of.get(o, o) for o in objs] + tools_objs
+    for lib, members in ((LIB, objs), (TOOLS_LIB, tools_members)):
         tmp = lib + f".tmp{os.getpid()}"
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + members
         if verbose:
@@ -91,3 +209,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--resources" in sys.argv:
+        for obj, ks in kernel_resources().items():
+            for k in ks:
+                if k["scratch"]:
+                    print(f"{obj}: {_demangle(k['name'])}: scratch {k['scratch']} B/lane")

@@ -37,6 +37,21 @@ void dd_set_error(const char* fmt, ...);
     }                                                                                           \
   } while (0)
 
+// One sequence of a dd_sample_masks_lanes launch (dd_dropout.hip; called by the group step in dd_engine.hip and by dd_tools.hip)
+struct MaskLaneArgs {
+  const float* epi;
+  int L;
+  uint8_t* keep;
+  const int32_t* argmax;
+  const int32_t* topk;
+  uint32_t* rng_state;
+  uint8_t* drop;
+  int32_t* n_drop;
+  uint8_t* drop_bits;
+  const int32_t* gate;
+};
+int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st);
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 dd_f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;

@@ -678,8 +678,9 @@ struct MaskParams {
   const uint32_t* rng_in; // optional: read the mt19937 state from here instead of rng_state and do NOT write it back (a re-run
                           // of the draws a speculative launch already made: the stream has advanced by exactly these draws)
   float scale[64];        // f32(mprob - 0.1)   (reference llava.py:646: python double, rounded when it meets fp32)
-  float q[64];            // f32(1 - mprob)     (reference instructblip.py:450)
+  float q[64];            // f32(1 - mprob)     (reference instructblip.py:450); directly behind scale[]: the kernels stage both as one table
 };
+static_assert(offsetof(MaskParams, q) == offsetof(MaskParams, scale) + 64 * sizeof(float), "scale[] and q[] must be adjacent");
 
 __device__ float block_min_max(const float* e, int L, bool want_max, float* sh) {
   float v = want_max ? -INFINITY : INFINITY;
@@ -706,7 +707,28 @@ __device__ int block_exclusive_scan_flag(bool flag, int* sh /*>=17*/, int* total
   return off + within;
 }
 
-__device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned char* smem) {
+// The per-sequence operands of one workgroup's sampling, in registers.
+struct MaskSeq {
+  const float* epi;
+  int L;
+  const uint8_t* keep;
+  const float* uniforms;
+  uint32_t* rng_state;
+  uint8_t* drop;
+  int32_t* n_drop;
+  int32_t* idx;
+  uint8_t* drop_bits;
+  const uint32_t* rng_in;
+};
+// C: the launch-wide constants; the per-member tables scale[] / q[] are staged in LDS by the kernel (mask_const_stage).  (A by-value
+// MaskParams copy indexed by the member loop lives in private scratch — 616 bytes per lane, the only kernel of the library that had
+// any; see DESIGN.md "determinism" and tests/test_gpu_sampler_repro.py.)
+struct MaskConst {
+  int K, mode, rng_mode;
+  const float* scale;   // [K] f32(mprob - 0.1), in LDS
+  const float* q;       // [K] f32(1 - mprob), in LDS
+};
+__device__ __forceinline__ void sample_masks_body(const MaskConst C, const MaskSeq P, unsigned char* smem) {
   float* e = (float*)smem;                       // [Lp]
   float* u = e + MASK_MAX_L;                     // [Lp] uniforms of the current member, or sort buffer
   uint8_t* running = (uint8_t*)(u + MASK_MAX_L);  // [L]
@@ -720,14 +742,14 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
     e[l] = P.epi[l];
     running[l] = 0;
   }
-  if (P.rng_mode == DD_RNG_MT19937) {
+  if (C.rng_mode == DD_RNG_MT19937) {
     const uint32_t* src = P.rng_in ? P.rng_in : P.rng_state;
     for (int i = tid; i < MT_N; i += MASK_THREADS) mt[i] = src[i];
     if (tid == 0) idx_sh = (int)src[MT_N];
   }
   __syncthreads();
   float lo = 0.f, hi = 0.f;
-  if (P.mode != DD_MASK_IBLIP_QUANTILE) {
+  if (C.mode != DD_MASK_IBLIP_QUANTILE) {
     lo = block_min_max(e, L, false, sh_f);  // torch.quantile(e, 0) == min   (llava.py:641)
     hi = block_min_max(e, L, true, sh_f);   // torch.quantile(e, 1) == max   (llava.py:642)
   } else {
@@ -754,37 +776,37 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
     }
   }
 
-  for (int k = 0; k < P.K; ++k) {   // DD_MASK_IBLIP_KL runs the NEXT_RESET rule: its keep flags come from dd_kl_keep instead of the overlap
-    if (P.mode != DD_MASK_LLAVA_CUMULATIVE && P.mode != DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) {  // reset: llavanext.py:546, instructblip.py:121
+  for (int k = 0; k < C.K; ++k) {   // DD_MASK_IBLIP_KL runs the NEXT_RESET rule: its keep flags come from dd_kl_keep instead of the overlap
+    if (C.mode != DD_MASK_LLAVA_CUMULATIVE && C.mode != DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) {  // reset: llavanext.py:546, instructblip.py:121
       for (int l = tid; l < L; l += MASK_THREADS) running[l] = 0;
     }
     float thr = 0.f;
-    if (P.mode == DD_MASK_IBLIP_QUANTILE) {
+    if (C.mode == DD_MASK_IBLIP_QUANTILE) {
       // torch.quantile(e, q) with linear interpolation, fp32: rank = q*(n-1); lerp(sorted[floor], sorted[ceil], frac)
       // ATen's lerp: weight < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w), contracted to one fma on the CPU build.
-      float rank = P.q[k] * (float)(L - 1);
+      float rank = C.q[k] * (float)(L - 1);
       float fl = floorf(rank);
       int i0 = (int)fl, i1 = (int)ceilf(rank);
       float w = rank - fl;
       float a = u[i0], b = u[i1], diff = b - a;
       thr = (w < 0.5f) ? fmaf(w, diff, a) : fmaf(-diff, 1.0f - w, b);
-    } else if (P.rng_mode == DD_RNG_MT19937) {
+    } else if (C.rng_mode == DD_RNG_MT19937) {
       mt_fill_block(mt, &idx_sh, u, L);  // one rand_like(e) per member (llava.py:650)
     }
     __syncthreads();
-    const float scale = P.scale[k];
+    const float scale = C.scale[k];
     const float range = __fsub_rn(hi, lo);
-    const bool no_overlap = P.mode == DD_MASK_NEXT_NO_OVERLAP || P.mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP;
+    const bool no_overlap = C.mode == DD_MASK_NEXT_NO_OVERLAP || C.mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP;
     int total = 0, cnt = 0;
     for (int base = 0; base < L; base += MASK_THREADS) {
       int l = base + tid;
       bool dropped = false;
       if (l < L) {
         bool d;
-        if (P.mode == DD_MASK_IBLIP_QUANTILE) {
+        if (C.mode == DD_MASK_IBLIP_QUANTILE) {
           d = e[l] >= thr;  // instructblip.py:453
         } else {
-          float r = (P.rng_mode == DD_RNG_MT19937) ? u[l] : P.uniforms[(size_t)k * L + l];
+          float r = (C.rng_mode == DD_RNG_MT19937) ? u[l] : P.uniforms[(size_t)k * L + l];
           // p = 0.1 + (mprob-0.1)*(clamp(e,lo,hi)-lo)/(hi-lo), every step rounded to fp32 (llava.py:646-647)
           float c = fminf(fmaxf(e[l], lo), hi);
           float p = __fadd_rn(0.1f, __fdiv_rn(__fmul_rn(scale, __fsub_rn(c, lo)), range));
@@ -813,7 +835,7 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
     }
     __syncthreads();
   }
-  if (P.rng_mode == DD_RNG_MT19937 && !P.rng_in) {
+  if (C.rng_mode == DD_RNG_MT19937 && !P.rng_in) {
     for (int i = tid; i < MT_N; i += MASK_THREADS) P.rng_state[i] = mt[i];
     if (tid == 0) P.rng_state[MT_N] = (uint32_t)idx_sh;
   }
@@ -822,7 +844,16 @@ __device__ __forceinline__ void sample_masks_body(const MaskParams& P, unsigned 
 __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (P.gate && *P.gate) return;          // sequence finished (EOS): draw nothing, write nothing
-  sample_masks_body(P, smem);
+  __shared__ float sh_tab[128];
+  {
+    const float __attribute__((address_space(4)))* tab = (const float __attribute__((address_space(4)))*)(
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MaskParams, scale));
+    if (threadIdx.x < 128) sh_tab[threadIdx.x] = tab[threadIdx.x];
+  }
+  __syncthreads();
+  const MaskSeq S = {P.epi, P.L, P.keep, P.uniforms, P.rng_state, P.drop, P.n_drop, P.idx, P.drop_bits, P.rng_in};
+  const MaskConst C = {P.K, P.mode, P.rng_mode, sh_tab, sh_tab + 64};
+  sample_masks_body(C, S, smem);
 }
 
 // Group step: the keep set (models/llava.py:443-482 from the base argmax already on the device) and the K masks of up to
@@ -852,25 +883,46 @@ __global__ __launch_bounds__(MASK_THREADS) void k_sample_masks_lanes(MaskLanes M
     for (int j = 0; j < k; ++j) hit |= (M.topk[m][(size_t)l * k + j] == tok);
     M.keep[m][l] = hit ? 1 : 0;
   }
+  __shared__ float sh_tab[128];
+  {  // scale[] and q[] are adjacent in the kernel arguments: 128 floats read straight from the kernarg segment
+    const float __attribute__((address_space(4)))* tab = (const float __attribute__((address_space(4)))*)(
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MaskLanes, common.scale));
+    if (threadIdx.x < 128) sh_tab[threadIdx.x] = tab[threadIdx.x];
+  }
   __syncthreads();                   // keep[] is read back by this same workgroup
-  MaskParams P = M.common;
-  P.epi = M.epi[m], P.L = L, P.keep = M.keep[m], P.uniforms = nullptr, P.rng_state = M.rng_state[m];
-  P.drop = M.drop[m], P.n_drop = M.n_drop[m], P.idx = nullptr, P.drop_bits = M.drop_bits[m];
-  sample_masks_body(P, smem);
+  // (uniforms / idx / rng_in are null for lanes — taken from the zeroed common block, not written as literal nullptr: with the
+  // constants folded into the inlined body hipcc 7.2's instcombine dies on the dead injected-uniforms load)
+  const MaskSeq S = {M.epi[m], L, M.keep[m], M.common.uniforms, M.rng_state[m], M.drop[m], M.n_drop[m], M.common.idx, M.drop_bits[m], M.common.rng_in};
+  const MaskConst C = {M.common.K, M.common.mode, M.common.rng_mode, sh_tab, sh_tab + 64};
+  sample_masks_body(C, S, smem);
 }
+#ifdef DD_KEEP_SCRATCH_SAMPLER
+// The form this kernel had until round 4, kept in libdropdec_tools.so ONLY (build.py compiles this file a second time with the macro)
+// for the A/B of tools/stress_lanes.py and the unit reproducer: the by-value copy below is indexed by the member loop, so the compiler
+// keeps it in private scratch (616 bytes per lane).
+__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks_lanes_scratch(MaskLanes M) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int m = blockIdx.x;
+  if (M.gate[m] && *M.gate[m]) return;
+  const int L = M.L[m], k = M.k_top;
+  const int tok = M.argmax[m][0];
+  for (int l = threadIdx.x; l < L; l += MASK_THREADS) {
+    bool hit = false;
+    for (int j = 0; j < k; ++j) hit |= (M.topk[m][(size_t)l * k + j] == tok);
+    M.keep[m][l] = hit ? 1 : 0;
+  }
+  __syncthreads();
+  MaskParams P = M.common;           // (uniforms, idx, rng_in: null in the common block)
+  P.epi = M.epi[m], P.L = L, P.keep = M.keep[m], P.rng_state = M.rng_state[m];
+  P.drop = M.drop[m], P.n_drop = M.n_drop[m], P.drop_bits = M.drop_bits[m];
+  const MaskSeq S = {P.epi, P.L, P.keep, P.uniforms, P.rng_state, P.drop, P.n_drop, P.idx, P.drop_bits, P.rng_in};
+  const MaskConst C = {P.K, P.mode, P.rng_mode, P.scale, P.q};     // tables in the private copy
+  sample_masks_body(C, S, smem);
+}
+static int g_lanes_sampler_scratch = 0;
+void dd_dropout_set_lanes_sampler_scratch(int on) { g_lanes_sampler_scratch = on; }
+#endif
 
-struct MaskLaneArgs {                // host-side description of one sequence for dd_sample_masks_lanes
-  const float* epi;
-  int L;
-  uint8_t* keep;
-  const int32_t* argmax;
-  const int32_t* topk;
-  uint32_t* rng_state;
-  uint8_t* drop;
-  int32_t* n_drop;
-  uint8_t* drop_bits;
-  const int32_t* gate;
-};
 int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st) {
   DD_REQUIRE(lanes && n >= 1 && n <= 32 && K >= 1 && K <= 64 && mode >= 0 && mode <= 4, "dd_sample_masks_lanes: bad arguments");
   MaskLanes M;
@@ -894,6 +946,18 @@ int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const dou
     DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
+#ifdef DD_KEEP_SCRATCH_SAMPLER
+  if (g_lanes_sampler_scratch) {
+    static bool attr2 = false;
+    if (!attr2) {
+      DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes_scratch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      attr2 = true;
+    }
+    k_sample_masks_lanes_scratch<<<n, MASK_THREADS, smem, st>>>(M);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
+#endif
   k_sample_masks_lanes<<<n, MASK_THREADS, smem, st>>>(M);
   DD_CHECK_LAUNCH();
   return DD_OK;

@@ -27,19 +27,6 @@ int dd_argmax_rows_gated(const float* x, int R, int V, int ld, int32_t* out, con
 int dd_vote_gated(const int32_t* ids, int K, int32_t* out2, const int32_t* gate, hipStream_t st);
 uint32_t* dd_rng_state_ptr(dd_rng* r);
 unsigned long long dd_rng_serial(dd_rng* r);
-struct MaskLaneArgs {
-  const float* epi;
-  int L;
-  uint8_t* keep;
-  const int32_t* argmax;
-  const int32_t* topk;
-  uint32_t* rng_state;
-  uint8_t* drop;
-  int32_t* n_drop;
-  uint8_t* drop_bits;
-  const int32_t* gate;
-};
-int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st);
 int dd_argmax_rows_lanes(const float* const* x, int32_t* const* out, const int32_t* const* gates, int n, int R, int V, int ld,
                          hipStream_t st);
 int dd_vote_lanes(const int32_t* const* ids, int32_t* const* out2, const int32_t* const* gates, int n, int K, hipStream_t st);
@@ -1181,6 +1168,7 @@ extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rn
   DD_REQUIRE(h->n_tok_host < MAX_NEW_TOKENS, "dd_lm_step: token buffer full");
   // leak_bits are all zero until the first dropout step, so passing them unconditionally is equivalent and keeps the
   // launch arguments identical from step to step (graph replay)
+  h->pend_valid = false;       // a row parked by a rider group step is void once the sequence is stepped any other way
   k_step_begin<<<1, 256, 0, st>>>(h->state, h->leak_bits, h->L, h->cfg.leak_mask == 2 ? 1 : 0);
   DD_CHECK_LAUNCH();
   const uint8_t* base_bits = h->cfg.leak_mask ? h->leak_bits : nullptr;
@@ -1235,6 +1223,7 @@ extern "C" int dd_lm_step_commit(dd_lm* h, int K, void* stream_) {
   DD_CHECK_LAUNCH();
   h->T_host += 1;
   h->n_tok_host += 1;
+  h->pend_valid = false;       // (the rider step re-parks its ring leaders after its sweeps; every other caller leaves nothing parked)
   if (h->cfg.leak_mask && K > 0) h->have_leak = true;
   return DD_OK;
 }
@@ -1392,6 +1381,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
 // what follows a multi-group sweep: member argmax, vote, winner's K/V appended, token emitted — for the ng sequences of
 // the sweep with ONE launch per stage (dd_lm_step_commit's work, block = sequence)
 // (packed_base >= 0: the sequences are numbers packed_base.. of a half-plane sweep — their rows in h->xa start at 8 (s >> 1) + 4 (s & 1))
+int (*dd_engine_group_finish_hook)(dd_lm* const* qs, int ng, int K, hipStream_t st) = nullptr;
 static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t st, int packed_base = -1) {
   const int d = h->d;
   const float* lg[8];
@@ -1441,6 +1431,7 @@ static int group_finish(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_t s
     q->T_host += 1, q->n_tok_host += 1, q->steps_since_prefill++;
     if (q->cfg.leak_mask) q->have_leak = true;
   }
+  if (dd_engine_group_finish_hook) RC(dd_engine_group_finish_hook(qs, ng, K, st));   // libdropdec_tools.so: per-step trace records
   return DD_OK;
 }
 
@@ -2262,15 +2253,17 @@ extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs
     }
   if (getenv("DD_DEBUG")) fprintf(stderr, "[dropdec] group step graph miss: capturing (cache holds %zu)\n", h0->graphs.size());
   struct Saved {
-    int T, N, K, S;
-    bool leak;
+    int T, N, K, S, pend_step;
+    bool leak, pend_valid;
   } sv[GROUP_MAX_LANES];
   for (int m = 0; m < n; ++m)
-    sv[m] = {lanes[m]->T_host, lanes[m]->n_tok_host, lanes[m]->last_K, lanes[m]->steps_since_prefill, lanes[m]->have_leak};
+    sv[m] = {lanes[m]->T_host, lanes[m]->n_tok_host, lanes[m]->last_K, lanes[m]->steps_since_prefill, lanes[m]->pend_step,
+             lanes[m]->have_leak, lanes[m]->pend_valid};
   auto restore = [&]() {
     for (int m = 0; m < n; ++m) {
       dd_lm* q = lanes[m];
       q->T_host = sv[m].T, q->n_tok_host = sv[m].N, q->last_K = sv[m].K, q->steps_since_prefill = sv[m].S, q->have_leak = sv[m].leak;
+      q->pend_valid = sv[m].pend_valid, q->pend_step = sv[m].pend_step;
     }
   };
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {

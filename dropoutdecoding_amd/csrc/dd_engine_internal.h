@@ -123,6 +123,8 @@ int dd_engine_step_begin(dd_lm* h, hipStream_t st);          // k_step_begin: th
 void dd_engine_bump_epoch();                 // every tuning call: graph keys carry the epoch, a step captured under other settings is not replayed
 unsigned long long dd_engine_epoch();
 int dd_engine_tp_alloc(dd_lm* h, float** p, size_t floats);  // device memory owned (and released) by the handle
+// set by libdropdec_tools.so (dd_tools_trace_*): called at the end of every group_finish, on the stream of that sweep
+extern int (*dd_engine_group_finish_hook)(dd_lm* const* qs, int ng, int K, hipStream_t st);
 // one packed sweep of nb rows through all layers + lm_head (dd_engine.hip)
 int lm_sweep(dd_lm* h, int nb, const uint8_t* bits, int row0, float* logits_out, hipStream_t st, dd_lm* const* lanes = nullptr,
              const int32_t* skip_if = nullptr);

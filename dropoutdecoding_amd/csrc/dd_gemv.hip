@@ -864,7 +864,7 @@ static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
 // families have (K = 4096: 16 k-steps per slice; K = 11008 / 14336: 43 / 56, staged in chunks of 16).  Anything else runs
 // through k_gemv_groups; both produce the same bits.
 static int g_gemv_slices = 1;     // dd_set_tuning key 13
-int g_exp_U9 = 4;                // dd_tools_set_tuning key 29: weight requests in flight per wave of the nine-plane qkv / gate-up kernels (4 or 8)
+int g_exp_U9 = 4;                // dd_tools_set_tuning key 29: weight requests in flight per wave of the nine-plane qkv kernel (4 or 8; gate/up: always 4)
 int g_exp_G[4] = {0, 0, 0, 0};   // dd_set_tuning keys 17..19: workgroups per slice of the 64-row kernels (qkv, o, gate/up); 0 = default
 static int g_slices_only = 0;     // dd_lm_time_gemv: launch the streaming kernel without its finishing kernel (timing only)
 void ddk_set_gemv_slices(int on) { g_gemv_slices = on; }
@@ -1110,8 +1110,9 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
     if (spw != 16 || 4 * ((nt + 23) / 24) > 256) return SLICES_UNSUPPORTED;
     sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 23) / 24;
     DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
-    if (g_exp_U9 == 8) RC_(launch_slices_seq<9, 8, 3, EPI_SILU>(sa, a.wf, st));
-    else RC_(launch_slices_seq<9, 4, 3, EPI_SILU>(sa, a.wf, st));
+    // (four weight requests in flight per wave: with eight, three tiles per wave and nine planes the kernel needs 257 registers and
+    // spills 28 bytes per lane to private scratch — that instantiation is gone, build.py refuses kernels with scratch)
+    RC_(launch_slices_seq<9, 4, 3, EPI_SILU>(sa, a.wf, st));
     launch_finish<EPI_SILU, 2, 9, 4>(a, a.n_tiles, st);
   }
   return DD_OK;

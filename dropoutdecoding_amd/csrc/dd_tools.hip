@@ -96,7 +96,8 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // group step (0: the classic form always), 27 = the riding rows' attention inside the members' launches, 28 = branches of the rider
 // form (1..4), 29 = weight requests in flight per wave of the nine-plane qkv / gate-up kernels (4 or 8), 30 = half planes for K <= 4, 31 = half
 // planes (classic form) before the rider form for line-ups that are not whole groups of fourteen, 33 = rider rings in stages (masks
-// between the stages on the caller's stream); the product switches
+// between the stages on the caller's stream), 34 = the lanes mask sampler in its round-3 form with a private-scratch copy of its parameters
+// (616 bytes per lane; this library only); the product switches
 // (8, 11, 13-16) are forwarded to dd_set_tuning.  Every call bumps the graph-key epoch: steps captured under other settings are not replayed.
 extern int g_exp_G[4];
 extern int g_attn16_tpw, g_attn16_full, g_finish4;
@@ -109,10 +110,11 @@ void dd_engine_set_half_planes(int on);
 void dd_engine_set_half_planes_first(int on);
 void dd_engine_set_rider_staged(int on);
 extern int g_exp_U9;
+void dd_dropout_set_lanes_sampler_scratch(int on);   // dd_dropout.hip compiled with -DDD_KEEP_SCRATCH_SAMPLER (this library only)
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33,
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -129,6 +131,7 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 30) dd_engine_set_half_planes(value);
   else if (key == 31) dd_engine_set_half_planes_first(value);
   else if (key == 33) dd_engine_set_rider_staged(value);
+  else if (key == 34) dd_dropout_set_lanes_sampler_scratch(value);
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }
@@ -178,3 +181,159 @@ extern "C" int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, i
   return DD_OK;
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------------------
+// Determinism diagnostics (DESIGN.md "Determinism"; tools/stress_lanes.py, tests/test_gpu_sampler_repro.py)
+// -------------------------------------------------------------------------------------------------------------------------------
+// Per-step trace: after every group_finish one 32-int record per sequence, so that two runs can be compared quantity by quantity and
+// the FIRST one that differs named: [0] tokens emitted so far, [1] argmax of the un-masked row, [2] size of the keep set, [3] hash of the
+// drop bit planes, [4..11] n_drop of members 0..7, [12..19] the members' argmax ids, [20] winner, [21] token, [22] mt19937 read index
+// (-1 unknown), [23] hash of the un-masked row's logits.
+#include <map>
+struct TraceBuf {
+  int32_t* buf;
+  int cap;
+  const uint32_t* rng_state;
+};
+static std::map<dd_lm*, TraceBuf> g_trace;
+struct TraceLanes {
+  const DDState* st[8];
+  const int32_t* argmax_base[8];
+  const uint8_t* keep[8];
+  const uint8_t* drop_bits[8];
+  const int32_t* n_drop[8];
+  const int32_t* member_tok[8];
+  const float* base_logits[8];
+  const uint32_t* rng_state[8];
+  int32_t* buf[8];
+  int cap[8], L[8];
+};
+__global__ __launch_bounds__(256) void k_trace_step(TraceLanes t, int K, int V) {
+  const int q = blockIdx.x;
+  if (!t.buf[q]) return;
+  const DDState* st = t.st[q];
+  const int idx = st->n_tok - 2;                       // the step that just ended emitted token n_tok - 1
+  if (idx < 0 || idx >= t.cap[q]) return;
+  __shared__ uint32_t sh[2][4];
+  uint32_t nk = 0, hb = 0, hl = 0;
+  const int planes = (K + 7) / 8;
+  for (int l = threadIdx.x; l < t.L[q]; l += 256) {
+    nk += t.keep[q][l] ? 1u : 0u;
+    for (int p = 0; p < planes; ++p) hb += (uint32_t)t.drop_bits[q][(size_t)p * t.L[q] + l] * (2654435761u * (uint32_t)(l + 1 + p * 8191));
+  }
+  for (int v = threadIdx.x; v < V; v += 256) hl += __float_as_uint(t.base_logits[q][v]) * (2246822519u * (uint32_t)(v + 1));
+  for (int o = 32; o > 0; o >>= 1) nk += __shfl_xor(nk, o), hb += __shfl_xor(hb, o), hl += __shfl_xor(hl, o);
+  __shared__ uint32_t sk[4], sb[4], sl[4];
+  if ((threadIdx.x & 63) == 0) sk[threadIdx.x >> 6] = nk, sb[threadIdx.x >> 6] = hb, sl[threadIdx.x >> 6] = hl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t* r = t.buf[q] + (size_t)idx * 32;
+    r[0] = st->n_tok, r[1] = t.argmax_base[q][0], r[2] = (int32_t)(sk[0] + sk[1] + sk[2] + sk[3]);
+    r[3] = (int32_t)(sb[0] + sb[1] + sb[2] + sb[3]);
+    for (int k = 0; k < 8; ++k) r[4 + k] = k < K ? t.n_drop[q][k] : 0, r[12 + k] = k < K ? t.member_tok[q][k] : 0;
+    r[20] = st->winner, r[21] = st->cur_tok, r[22] = t.rng_state[q] ? (int32_t)t.rng_state[q][624] : -1;
+    r[23] = (int32_t)(sl[0] + sl[1] + sl[2] + sl[3]);
+  }
+}
+static int trace_hook(dd_lm* const* qs, int ng, int K, hipStream_t st) {
+  TraceLanes t;
+  memset(&t, 0, sizeof(t));
+  bool any = false;
+  for (int g = 0; g < ng && g < 8; ++g) {
+    dd_lm* q = qs[g];
+    auto it = g_trace.find(q);
+    t.st[g] = q->state, t.argmax_base[g] = q->argmax_base, t.keep[g] = q->keep, t.drop_bits[g] = q->drop_bits, t.n_drop[g] = q->n_drop;
+    t.member_tok[g] = q->member_tok, t.base_logits[g] = q->base_logits, t.L[g] = q->L;
+    if (it != g_trace.end()) t.buf[g] = it->second.buf, t.cap[g] = it->second.cap, t.rng_state[g] = it->second.rng_state, any = true;
+  }
+  if (!any) return DD_OK;
+  k_trace_step<<<ng, 256, 0, st>>>(t, K, qs[0]->V);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+uint32_t* dd_rng_state_ptr(dd_rng* r);
+extern "C" int dd_tools_trace_attach(dd_lm* h, int32_t* buf_dev, int cap_steps, dd_rng* rng) {
+  DD_REQUIRE(h, "dd_tools_trace_attach: null handle");
+  dd_engine_bump_epoch();                               // the trace launch is part of a captured step
+  if (!buf_dev || cap_steps <= 0) g_trace.erase(h);
+  else g_trace[h] = {buf_dev, cap_steps, rng ? dd_rng_state_ptr(rng) : nullptr};
+  dd_engine_group_finish_hook = g_trace.empty() ? nullptr : trace_hook;
+  return DD_OK;
+}
+
+// LDS poison: `launches` grids of `wgs` workgroups that fill `lds_bytes` of LDS each with a quiet-NaN pattern and leave.  Enqueued on a
+// side stream beside a step, they leave NaNs in whatever LDS the step's next workgroups are given: a kernel that reads LDS it did
+// not write turns that into a token change.  (LDS is not cleared between workgroups on this hardware.)
+__global__ __launch_bounds__(256) void k_lds_poison(int n4, uint32_t salt, uint32_t* sink) {
+  extern __shared__ __align__(16) uint32_t lds_p[];
+  for (int i = threadIdx.x; i < n4; i += 256) lds_p[i] = 0x7FC00000u | ((salt + i) & 0x3FFFFFu);
+  __syncthreads();
+  if (lds_p[(threadIdx.x * 7) % n4] == 0x12345u) sink[0] = 1;     // keep the stores
+}
+extern "C" int dd_tools_lds_poison(int launches, int wgs, int lds_bytes, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(launches >= 1 && wgs >= 1 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024, "dd_tools_lds_poison: bad arguments");
+  static uint32_t* sink = nullptr;
+  static int attr_bytes = 0;
+  if (!sink) DD_HIP(hipMalloc((void**)&sink, 16));
+  if (lds_bytes > attr_bytes) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_lds_poison, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_bytes = lds_bytes;
+  }
+  static uint32_t salt = 1;
+  for (int i = 0; i < launches; ++i) {
+    k_lds_poison<<<wgs, 256, lds_bytes, st>>>(lds_bytes / 4, salt++, sink);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}
+
+// Scratch probe: a kernel shaped like the round-3 sampler (1,024 threads per workgroup, a 154-word private array indexed at run time
+// = 616 bytes of scratch per lane) that writes a lane-specific pattern into its scratch, lingers (`spin` rounds of dependent LDS
+// traffic with barriers), reads the pattern back and counts mismatches — the direct test of "private scratch is not private beside
+// other queues' kernels".  errors_dev[0] += mismatching words.
+__global__ __launch_bounds__(1024) void k_scratch_probe(int spin, uint32_t salt, const int* __restrict__ perm, unsigned int* errors) {
+  __shared__ uint32_t sh[1024];
+  uint32_t priv[154];
+  const uint32_t me = (blockIdx.x * 1024u + threadIdx.x) * 2654435761u + salt;
+  for (int i = 0; i < 154; ++i) priv[perm[i]] = me ^ (uint32_t)(i * 40503u);
+  uint32_t v = me;
+  for (int r = 0; r < spin; ++r) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    v = v * 1664525u + sh[(threadIdx.x * 33 + r) & 1023];
+    __syncthreads();
+  }
+  unsigned int bad = 0;
+  for (int i = 0; i < 154; ++i) bad += priv[perm[i]] != (me ^ (uint32_t)(i * 40503u)) ? 1u : 0u;
+  if (v == 0xdeadbeefu) bad += 1u << 30;                 // keep the loop
+  if (bad) atomicAdd(errors, bad);
+}
+extern "C" int dd_tools_scratch_probe(int launches, int wgs, int spin, unsigned int* errors_dev, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(launches >= 1 && wgs >= 1 && spin >= 0 && errors_dev, "dd_tools_scratch_probe: bad arguments");
+  static int* perm = nullptr;
+  if (!perm) {
+    int hperm[154];
+    for (int i = 0; i < 154; ++i) hperm[i] = (i * 37) % 154;      // a permutation: the index is a run-time value for the compiler
+    DD_HIP(hipMalloc((void**)&perm, sizeof(hperm)));
+    DD_HIP(hipMemcpy(perm, hperm, sizeof(hperm), hipMemcpyHostToDevice));
+  }
+  static uint32_t salt = 7;
+  for (int i = 0; i < launches; ++i) {
+    k_scratch_probe<<<wgs, 1024, 0, st>>>(spin, salt++, perm, errors_dev);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}
+
+// The lanes mask sampler on its own (the kernel the group step launches: keep sets + K masks of n sequences, one workgroup each), for the
+// unit reproducer: arrays of n device pointers / lengths as the engine would pass them.
+extern "C" int dd_tools_sample_masks_lanes(int n, const float* const* epi, const int32_t* L, uint8_t* const* keep, const int32_t* const* argmax,
+                                           const int32_t* const* topk, dd_rng* const* rngs, uint8_t* const* drop, int32_t* const* n_drop,
+                                           uint8_t* const* drop_bits, int k_top, const double* mprobs, int K, int mode, void* stream_) {
+  DD_REQUIRE(n >= 1 && n <= 32 && epi && L && keep && argmax && topk && rngs && drop && n_drop && drop_bits && mprobs, "dd_tools_sample_masks_lanes: bad arguments");
+  MaskLaneArgs ml[32];
+  for (int i = 0; i < n; ++i) ml[i] = {epi[i], L[i], keep[i], argmax[i], topk[i], dd_rng_state_ptr(rngs[i]), drop[i], n_drop[i], drop_bits[i], nullptr};
+  return dd_sample_masks_lanes(ml, n, k_top, mprobs, K, mode, (hipStream_t)stream_);
+}

@@ -42,10 +42,28 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * launches (default 1), 28 branches of the rider form (1..4, default 4), 29 weight requests in flight per wave of the nine-plane
  * qkv / gate-up kernels (4 or 8, default 4), 30 half planes for K <= 4 (two sequences per operand plane, default 1), 31 half planes
  * before the rider form where both apply and the line-up is not whole groups of fourteen (default 1), 33 the rider form's rings in stages with
- * the masks of the groups whose rows rode sampled between the stages on the caller's stream (default 1; 0: on the branches).  Keys of
+ * the masks of the groups whose rows rode sampled between the stages on the caller's stream (default 1; 0: on the branches), 34 the lanes
+ * mask sampler in its round-3 form (a private-scratch copy of its parameters, 616 bytes per lane; default 0).  Keys of
  * dd_set_tuning are forwarded.  Every call starts a new epoch of the step-graph
  * keys: a step captured under other settings is never replayed. */
 int dd_tools_set_tuning(int key, int value);
+
+/* Determinism diagnostics (tools/stress_lanes.py).
+ * dd_tools_trace_attach: from now on every group step appends one 32-int record per step to buf_dev[cap_steps][32] for this
+ * sequence (tokens so far, un-masked argmax, keep-set size, hash of the drop bits, n_drop[8], member argmax ids[8], winner, token,
+ * mt19937 read index, hash of the un-masked logits); buf_dev = NULL detaches.  rng: the sequence's generator (may be NULL).
+ * dd_tools_lds_poison: `launches` grids of `wgs` workgroups that fill lds_bytes of LDS with a NaN pattern (beside a step: a kernel
+ * that reads LDS it did not write turns it into a token change).
+ * dd_tools_scratch_probe: `launches` grids of `wgs` 1,024-thread workgroups with 616 bytes of private scratch per lane that write a
+ * pattern, linger for `spin` barrier rounds and verify it; errors_dev[0] += mismatching words. */
+int dd_tools_trace_attach(dd_lm* h, int32_t* buf_dev, int cap_steps, dd_rng* rng);
+/* The group step's mask sampler on its own (keep sets from argmax / top-k ids + the K masks of n <= 32 sequences, one workgroup per
+ * sequence, each from its own generator): arrays of n device pointers. */
+int dd_tools_sample_masks_lanes(int n, const float* const* epi, const int32_t* L, uint8_t* const* keep, const int32_t* const* argmax,
+                                const int32_t* const* topk, dd_rng* const* rngs, uint8_t* const* drop, int32_t* const* n_drop,
+                                uint8_t* const* drop_bits, int k_top, const double* mprobs, int K, int mode, void* stream);
+int dd_tools_lds_poison(int launches, int wgs, int lds_bytes, void* stream);
+int dd_tools_scratch_probe(int launches, int wgs, int spin, unsigned int* errors_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,9 @@ for i in range(len(shapes)):
                                  share_weights_with=engs[0] if engs else None))
 engs[0].load_synthetic(1, 0.02)
 embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(50 + i)).cuda() for i, (T0, _, _) in enumerate(shapes)]
-n_steps = 3
+n_steps = int(os.environ.get("DD_AB_STEPS", "3"))
+POISON = int(os.environ.get("DD_AB_POISON", "0"))     # LDS-poison launches beside every step (dd_tools_lds_poison)
+side = torch.cuda.Stream() if POISON else None
 res = {}
 for br in (1, 2):
     _lib.load().dd_tools_set_tuning(23, br)
@@ -33,6 +35,8 @@ for br in (1, 2):
     grp = lm.EngineGroup(engs)
     rec = [[] for _ in engs]
     for s in range(n_steps):
+        if POISON:
+            _lib.load().dd_tools_lds_poison(POISON, 512, 64 * 1024, side.cuda_stream)
         grp.decode_step(probs)
         for i, e in enumerate(engs):
             rec[i].append((e.last_step()["drop"].copy(), e.logits().copy(), e.base_logits().copy()))

@@ -1,0 +1,175 @@
+"""Unit-level reproducer attempts for the round-3 run-to-run token difference (DESIGN.md "Determinism").
+
+  sampler(scratch, beside, rounds):  the group step's mask sampler (k_sample_masks_lanes: 8 sequences, L = 576, K = 8, one 1,024-thread
+      workgroup per sequence, each drawing from its own mt19937 stream) launched back to back on its own stream — alone, or BESIDE 72-row
+      slice-resident GEMVs (gate/up and qkv of LLaVA-1.5-7B) looping on two other streams, the company it had on a rider branch — and every
+      launch's masks compared with the oracle sampler over the host mt19937.  scratch=True: the round-3 form of the kernel (616 bytes of
+      private scratch per lane; libdropdec_tools.so only).
+  probe(beside, rounds):  a kernel of the same shape that only writes a pattern into 616 bytes of private scratch per lane, lingers and
+      verifies it.
+
+    python tools/sampler_repro.py [rounds]      # prints one JSON line per configuration
+"""
+import json, os, sys, threading, time
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+import torch
+from dropoutdecoding_amd import _lib, lm
+from dropoutdecoding_amd.dropout import TorchCpuCompatRNG
+from oracle import dropout_ref as DR
+from oracle.mt19937 import TorchCpuMT19937
+
+N_SEQ, L_VIS, K_TOP, STEPS = 8, 576, 5, 24
+PROBS = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+
+
+class Company:
+    """72-row slice-resident GEMVs looping on two streams of their own (host threads: the timing hook synchronises)."""
+
+    def __init__(self, lib):
+        cfg = lm.LMConfig(32064, 4096, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
+        self.eng = lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=128, max_visual=32, kv_format="fp16", lib=lib)
+        self.eng.load_synthetic(0, 0.02)
+        self.lib, self.stop, self.threads, self.launches = lib, False, [], [0, 0]
+        self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def _loop(self, i, which):
+        ms, by = C.c_float(), C.c_double()
+        while not self.stop:
+            rc = self.lib.dd_lm_time_gemv(self.eng._h, which, 72, 64, C.byref(ms), C.byref(by), self.streams[i].cuda_stream)
+            assert rc == 0, self.lib.dd_last_error()
+            self.launches[i] += 64 + 2
+
+    def __enter__(self):
+        self.threads = [threading.Thread(target=self._loop, args=(0, 2)), threading.Thread(target=self._loop, args=(1, 0))]
+        for t in self.threads:
+            t.start()
+        time.sleep(0.05)
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        for t in self.threads:
+            t.join()
+
+
+def _inputs():
+    rs = np.random.RandomState(7)
+    seqs = []
+    for i in range(N_SEQ):
+        epi = (rs.rand(L_VIS) * 2).astype(np.float32)
+        topk = rs.randint(0, 400, (L_VIS, K_TOP)).astype(np.int32)
+        tok = int(topk[3 + i, 2])
+        keep = (topk == tok).any(1)
+        ref = TorchCpuMT19937(100 + i)
+        want = []
+        for _ in range(STEPS):
+            uni = torch.from_numpy(np.stack([ref.rand_f32(L_VIS) for _ in PROBS]))
+            want.append(DR.sample_masks(torch.from_numpy(epi), PROBS, torch.from_numpy(keep), DR.MODE_LLAVA_CUMULATIVE, uni).numpy())
+        seqs.append({"epi": epi, "topk": topk, "tok": tok, "keep": keep, "want": np.stack(want)})
+    return seqs
+
+
+def sampler(scratch: bool, beside: bool, rounds: int, lib=None, seqs=None) -> dict:
+    lib = lib or _lib.load_tools()
+    lib.dd_tools_set_tuning(34, 1 if scratch else 0)
+    seqs = seqs or _inputs()
+    K = len(PROBS)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    epi = [dev(s["epi"]) for s in seqs]
+    topk = [dev(s["topk"]) for s in seqs]
+    argmax = [torch.tensor([s["tok"]], dtype=torch.int32, device="cuda") for s in seqs]
+    keep = [torch.zeros(L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
+    drop = [torch.zeros(STEPS, K, L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
+    n_drop = [torch.zeros(STEPS, K, dtype=torch.int32, device="cuda") for _ in seqs]
+    bits = [torch.zeros(STEPS, L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
+    rngs = [TorchCpuCompatRNG(100 + i, lib=lib) for i in range(N_SEQ)]
+    want = [s["want"] for s in seqs]
+    want_bits = [np.bitwise_or.reduce(w.astype(np.uint8) << np.arange(K, dtype=np.uint8)[None, :, None], axis=1) for w in want]
+    st = torch.cuda.Stream()
+    arr = lambda ts: (C.c_void_p * N_SEQ)(*[t.data_ptr() if torch.is_tensor(t) else t for t in ts])
+    Ls = (C.c_int32 * N_SEQ)(*([L_VIS] * N_SEQ))
+    pr = (C.c_double * K)(*PROBS)
+    bad_launches, launches, first_bad = 0, 0, None
+    t0 = time.time()
+
+    def body():
+        nonlocal bad_launches, launches, first_bad
+        for r in range(rounds):
+            torch.cuda.synchronize()
+            for i, g in enumerate(rngs):
+                g.manual_seed(100 + i)
+            torch.cuda.synchronize()
+            for s in range(STEPS):
+                rc = lib.dd_tools_sample_masks_lanes(N_SEQ, arr(epi), Ls, arr(keep), arr(argmax), arr(topk), arr([g.handle.value for g in rngs]),
+                                                     arr([d[s].data_ptr() for d in drop]), arr([n[s].data_ptr() for n in n_drop]),
+                                                     arr([b[s].data_ptr() for b in bits]), K_TOP, pr, K, DR.MODE_LLAVA_CUMULATIVE, st.cuda_stream)
+                assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+            launches += STEPS
+            for i in range(N_SEQ):
+                got = drop[i].cpu().numpy().astype(bool)
+                gb = bits[i].cpu().numpy()
+                gn = n_drop[i].cpu().numpy()
+                for s in range(STEPS):
+                    if not (np.array_equal(got[s], want[i][s]) and np.array_equal(gb[s], want_bits[i][s]) and np.array_equal(gn[s], want[i][s].sum(1))):
+                        bad_launches += 1
+                        if first_bad is None:
+                            first_bad = {"round": r, "sequence": i, "launch": s, "wrong_mask_bytes": int((got[s] != want[i][s]).sum())}
+                        break
+
+    if beside:
+        with Company(lib) as co:
+            body()
+            company = sum(co.launches)
+    else:
+        body()
+        company = 0
+    lib.dd_tools_set_tuning(34, 0)
+    return {"test": "sampler", "scratch_form": scratch, "beside_72_row_gemvs": beside, "sampler_launches": launches, "workgroups_per_launch": N_SEQ,
+            "company_gemv_launches": company, "sequences_with_a_wrong_launch": bad_launches, "first_bad": first_bad, "seconds": round(time.time() - t0, 1)}
+
+
+def probe(beside: bool, rounds: int, lib=None, wgs: int = 8, spin: int = 200) -> dict:
+    lib = lib or _lib.load_tools()
+    err = torch.zeros(4, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+
+    def body():
+        for r in range(rounds):
+            rc = lib.dd_tools_scratch_probe(32, wgs, spin, err.data_ptr(), st.cuda_stream)
+            assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+
+    if beside:
+        with Company(lib) as co:
+            body()
+            company = sum(co.launches)
+    else:
+        body()
+        company = 0
+    return {"test": "scratch_probe", "beside_72_row_gemvs": beside, "probe_launches": rounds * 32, "workgroups_per_launch": wgs, "spin": spin,
+            "company_gemv_launches": company, "mismatching_words": int(err[0].item()), "seconds": round(time.time() - t0, 1)}
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    torch.cuda.set_device(0)
+    lib = _lib.load_tools()
+    seqs = _inputs()
+    out = []
+    for scratch in (False, True):
+        for beside in (False, True):
+            out.append(sampler(scratch, beside, rounds, lib, seqs))
+            print(json.dumps(out[-1]), flush=True)
+    for beside in (False, True):
+        for wgs in (8, 256):
+            out.append(probe(beside, rounds, lib, wgs=wgs))
+            print(json.dumps(out[-1]), flush=True)
+    if os.environ.get("DD_REPRO_LOG"):
+        with open(os.environ["DD_REPRO_LOG"], "w") as f:
+            json.dump(out, f, indent=1)
