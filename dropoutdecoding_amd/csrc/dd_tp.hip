@@ -84,7 +84,11 @@ extern "C" int dd_lm_tp_link(dd_lm* const* ranks, int world, int rows_cap) {
 // written this rank's slot (slot stride = rows * d floats for the seam's `rows`) and calls exchange(ctx, rows, stream), which
 // must all-gather the slots across the ranks in place, ordered on `stream`.
 extern "C" int dd_lm_tp_set_exchange(dd_lm* h, float* gather_dev, size_t gather_floats, int (*exchange)(void*, int, void*), void* ctx) {
-  DD_REQUIRE(h && gather_dev && gather_floats >= (size_t)h->tp_world * 8 * h->d, "dd_lm_tp_set_exchange: bad arguments");
+  DD_REQUIRE(h && gather_dev, "dd_lm_tp_set_exchange: null argument");
+  // a prefill may bring up to T_cap - 1 rows to a seam: a buffer that only fits the decode rows would fail there, long after this call
+  DD_REQUIRE(gather_floats >= (size_t)h->tp_world * h->T_cap * h->d,
+             "dd_lm_tp_set_exchange: the gather buffer holds %zu floats, %d ranks x %d rows (the KV capacity) x %d need %zu", gather_floats,
+             h->tp_world, h->T_cap, h->d, (size_t)h->tp_world * h->T_cap * h->d);
   DD_REQUIRE(h->tp_world == 1 || exchange, "dd_lm_tp_set_exchange: a rank of %d needs an exchange", h->tp_world);
   h->tp_gather = gather_dev, h->tp_gather_floats = gather_floats, h->tp_exchange = exchange, h->tp_ctx = ctx;
   return DD_OK;

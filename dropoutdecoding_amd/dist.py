@@ -36,6 +36,7 @@ def member_range(K: int, rank: int, world: int) -> Tuple[int, int]:
 class KShardDecoder:
     """Drives the phased engine API (step_base / step_members / export-import / step_commit) with two collectives per
     token.  `engine` is a DropoutEngine (GPU) or any object with the same phase methods (tests use a CPU stand-in)."""
+    EVENT_RING = 256      # timed tokens kept as event pairs before they are folded into the running totals
 
     def __init__(self, engine, rank: int, world: int, group=None, time_exchange: bool = False):
         self.e, self.rank, self.world, self.group = engine, rank, world, group
@@ -43,6 +44,7 @@ class KShardDecoder:
         # time_exchange: bracket every token's exchange (export ids -> all-reduce -> import -> export winner -> all-reduce ->
         # import) with events on the engine's stream; exchange_ms() reports the mean (bench.py --mode kshard)
         self._events = [] if time_exchange else None
+        self._ms_sum, self._ms_n = 0.0, 0          # totals of the pairs already read back (the list is drained every EVENT_RING tokens)
 
     def decode_step(self, mprobs: Optional[Sequence[float]] = None, uniforms=None) -> None:
         st = getattr(self.e, "torch_stream", None)
@@ -79,19 +81,29 @@ class KShardDecoder:
         if ev is not None:
             ev[1].record()
             self._events.append(ev)
+            if len(self._events) >= self.EVENT_RING:
+                self._drain()
         e.step_commit()
 
     def exchange_ms(self, reset: bool = False):
         """Mean milliseconds per token of the two collectives with their export / import kernels, and the bytes moved per rank."""
-        if not self._events:
+        if self._events is None:
             return None
-        torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in self._events]
-        out = {"ms_per_token": round(sum(ms) / len(ms), 4), "tokens": len(ms), "bytes_per_token": int(self.ids.numel() * 4 + self.rec.numel() * 4),
+        self._drain()
+        if not self._ms_n:
+            return None
+        out = {"ms_per_token": round(self._ms_sum / self._ms_n, 4), "tokens": self._ms_n, "bytes_per_token": int(self.ids.numel() * 4 + self.rec.numel() * 4),
                "collectives_per_token": 2, "backend": dist.get_backend(self.group), "world": self.world}
         if reset:
-            self._events = []
+            self._ms_sum, self._ms_n = 0.0, 0
         return out
+
+    def _drain(self) -> None:
+        if self._events:
+            self._events[-1][1].synchronize()
+            self._ms_sum += sum(a.elapsed_time(b) for a, b in self._events)
+            self._ms_n += len(self._events)
+            self._events = []
 
     def generate(self, n_new: int, mprobs=None) -> List[int]:
         toks = self.e.tokens()
@@ -145,14 +157,30 @@ class TensorParallelRank:
                 return 0
             except Exception as ex:                             # an exception must not unwind through the C frames
                 self.error = ex
+                self._abort_peers()                             # the other ranks are (or will be) waiting in this all-gather
                 return 1
         self._cb = _lib.TP_EXCHANGE_FN(exchange)                # kept alive with the object
         self._hs = (C.c_void_p * 1)(e._h)
+        # (the library checks the buffer against the engine's KV capacity: a prefill of max_seq rows must fit every rank's slot)
         e._ck(e.lib.dd_lm_tp_set_exchange(e._h, self.gather.data_ptr(), self.gather.numel(), self._cb, None), "dd_lm_tp_set_exchange")
 
     def load_state_dict(self, sd, prefix: str = "") -> None:
         from . import lm
         self.engine.load_state_dict(lm.tp_shard_state_dict(sd, self.cfg, self.rank, self.world, prefix))
+
+    def _abort_peers(self) -> None:
+        """A failed exchange on this rank leaves the others blocked in their all-gather until the process-group timeout: tear the
+        group down so that they fail now (their exchange raises, their step returns an error)."""
+        try:
+            pg = self.group if self.group is not None else dist.group.WORLD
+            if hasattr(pg, "abort"):
+                pg.abort()
+            elif hasattr(dist, "_abort_process_group"):
+                dist._abort_process_group(pg)
+            else:
+                dist.destroy_process_group(self.group)
+        except Exception:
+            pass
 
     def _check(self, rc: int, what: str) -> None:
         if rc != 0 and self.error is not None:

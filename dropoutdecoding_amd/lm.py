@@ -699,7 +699,12 @@ class EngineGroup:
             # (K <= 4: groups of fourteen — two sequences per operand plane, seven planes + two riding planes)
             group = 14 if (dropout and len(E[0]._probs(mprobs)[0]) <= 4 and len(E) % 14 == 0 and len(active) >= 28) else 8
             if eos_set and len(active) >= 16 and len(active) % group:
-                ended = [i for i in range(len(E)) if i not in active and any(t in eos_set for t in seen[i])]
+                # (a filler's host-side length still advances with every step it rides along: only lanes whose cache has room for
+                # all the steps the longest active lane may still take)
+                left = n_new - min(E[i]._n_enqueued for i in active)
+                cap = lambda e: (e.max_seq + 63) // 64 * 64
+                ended = [i for i in range(len(E)) if i not in active and any(t in eos_set for t in seen[i])
+                         and E[i].T0 + E[i]._n_enqueued + left + 1 < cap(E[i])]
                 need = -len(active) % group
                 if len(ended) >= need:
                     active = sorted(active + ended[:need])
