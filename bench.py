@@ -326,17 +326,27 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    # DD_BENCH_SHARE_DEVICE=1: every rank on cuda:0 over "gloo" — the only way a ONE-GPU box can run the world > 1 code paths (rank-private
+    # image shards, the barriers, all_reduce(MAX) of the time, rank 0's JSON relay, K-shard's exchange); RCCL refuses two ranks on one
+    # device.  Not a measurement of scaling: the line says so (`shared_device`).
+    share_dev = os.environ.get("DD_BENCH_SHARE_DEVICE", "0") not in ("", "0")
+    backend = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dev_index = 0 if share_dev else local
+        torch.cuda.set_device(dev_index)
+        if share_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = dist.get_backend()
     else:
         torch.cuda.set_device(0)
 
     from dropoutdecoding_amd import build
     if local == 0:
-        build.build()                      # one builder per node; the others wait (no concurrent writes of the .so)
+        build.build()                      # one builder per node; the others wait (build.py also takes a file lock)
     if use_dist:
         torch.distributed.barrier()
     from dropoutdecoding_amd import _lib as _ddlib
@@ -472,7 +482,7 @@ def main() -> int:
             single_two["note"] = "the same with speculation off: un-masked sweep, then the packed member sweep, every step (the reference's order)"
     if use_dist:
         torch.distributed.barrier()
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if backend == "gloo" else "cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     streams = world if args.mode == "replicas" else 1
@@ -488,7 +498,8 @@ def main() -> int:
     # carries sixteen sequences (classic form: one fused un-masked sweep + B / 16 member sweeps)
     half_planes = wide and B >= 16 and K_eff <= 4 and wname != "fp8"
     rider_hp = half_planes and B >= 28 and B % 14 == 0        # whole groups of fourteen: seven half planes + two riding planes per sweep
-    rider = wide and B >= 16 and B % 8 == 0 and wname != "fp8" and not half_planes
+    # (fp8 tiles: nine-plane kernels exist for Mistral-7B's shapes — config 5)
+    rider = wide and B >= 16 and B % 8 == 0 and (wname != "fp8" or args.config == 5) and not half_planes
     if rider or rider_hp:
         dom_rows = 72
     roof = None
@@ -570,6 +581,12 @@ def main() -> int:
             "single_stream": single, "single_stream_two_sweep": single_two, "single_stream_nonempty_keep_sets": single_keep,
             "roofline": roof,
         }
+        if use_dist:
+            # what the process group itself reports (the driver computes scaling from `value` per N; nothing is estimated here)
+            line["process_group"] = {"backend": backend, "ranks": torch.distributed.get_world_size(), "rccl_ranks": torch.distributed.get_world_size() if backend == "nccl" else 0,
+                                     "shared_device": share_dev,
+                                     "note": ("all ranks on ONE GPU over gloo: exercises the world > 1 code paths, not a scaling measurement" if share_dev
+                                              else "one rank per GPU; backend nccl = RCCL over xGMI")}
         if exchange is not None:
             line["kshard_exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline and args.config in (1, 2, 3):   # the CPU leg restates config 3's shapes

@@ -1499,12 +1499,15 @@ static int rider_branches(dd_lm* const* lanes, int n, int K, int* gs_out = nullp
   if (n % gs) return 0;
   if (gs_out) *gs_out = gs;
   dd_lm* h0 = lanes[0];
-  if (!h0->kv16 || h0->fp8 || !h0->gemv_part) return 0;
-  // shapes with nine-plane kernels (dd_gemv.hip try_slices9)
+  if (!h0->kv16 || !h0->gemv_part) return 0;
+  // shapes with nine-plane kernels (dd_gemv.hip try_slices9 / try_slices9_fp8)
   const int qt = h0->qkv_tiles, gt = 2 * h0->dff / 16;
-  if (h0->S_d != 128 || h0->S_q != 128 || !(h0->S_ff == 8 * 43 || h0->S_ff == 8 * 56) || (qt % 16) != 0 || qt / 16 * 4 > 256 ||
-      4 * ((gt + 23) / 24) > 256 || h0->d / 16 < 64 || h0->Vpad / 16 < 64)
+  if (h0->fp8) {                 // fp8 tiles: K = 4096 for qkv / o / gate-up / lm_head, K = 14336 for down (Mistral-7B: BASELINE config 5)
+    if (h0->S_d != 128 || h0->S_q != 128 || h0->S_ff != 8 * 56 || qt < 64 || gt < 64 || h0->d / 16 < 64 || h0->Vpad / 16 < 64) return 0;
+  } else if (h0->S_d != 128 || h0->S_q != 128 || !(h0->S_ff == 8 * 43 || h0->S_ff == 8 * 56) || (qt % 16) != 0 || qt / 16 * 4 > 256 ||
+             gt < 64 || h0->d / 16 < 64 || h0->Vpad / 16 < 64) {
     return 0;
+  }
   for (int m = 0; m < n; ++m) {
     const dd_lm* q = lanes[m];
     if (q->cfg.mask_mode != h0->cfg.mask_mode || q->cfg.k_top != h0->cfg.k_top || q->cfg.mask_mode == DD_MASK_IBLIP_KL ||

@@ -921,6 +921,18 @@ static int launch_slices_fp8(const SliceArgs& sa, hipStream_t st) {
   k_gemv_slices_fp8<NG, SPW2, CH, UW><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
+template <int NG, int SPW2, int CS2, int UW>
+static int launch_slices_fp8c(const SliceArgs& sa, hipStream_t st) {
+  constexpr size_t smem = (size_t)2 * CS2 * NG * 1024;
+  static bool attr = false;
+  if (!attr) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_fp8c<NG, SPW2, CS2, UW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  NOTE_KERNEL("k_gemv_slices_fp8c<%d, %d, %d, %d, 0>", NG, SPW2, CS2, UW);
+  k_gemv_slices_fp8c<NG, SPW2, CS2, UW><<<8 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  return DD_OK;
+}
 template <int EPI, int TILES, int NG>
 static void finish_fp8(const GemvArgs& a, int n_sets, int ch, hipStream_t st) {
   if (ch == 2) launch_finish<EPI, TILES, NG, 4>(a, n_sets, st);
@@ -932,7 +944,7 @@ template <int NG>
 static int try_slices_fp8(int epi, const GemvArgs& a, hipStream_t st) {
   const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;
   const int spw2 = a.S / 16;
-  if (a.S % 16 || nt < 64 || !(spw2 == 8 || (spw2 == 28 && NG == 2))) return SLICES_UNSUPPORTED;
+  if (a.S % 16 || nt < 64 || !(spw2 == 8 || spw2 == 28)) return SLICES_UNSUPPORTED;
   const int ch = (spw2 == 8 && NG <= 4) ? 2 : 1;
   if (a.part_floats < (size_t)(8 / ch) * nt * NG * 128) return SLICES_UNSUPPORTED;
   SliceArgs sa;
@@ -942,7 +954,14 @@ static int try_slices_fp8(int epi, const GemvArgs& a, hipStream_t st) {
   const int per_set = 256 / (8 / ch);                  // one round of workgroups (one per CU at 64-128 KiB of operands)
   sa.G = (nt + 7) / 8 < per_set ? (nt + 7) / 8 : per_set;
   if (spw2 == 28) {
-    if constexpr (NG == 2) RC_(launch_slices_fp8<2, 28, 1, 7>(sa, st));
+    // K = 14336 (down_proj of Mistral-7B): two planes hold a whole slice in LDS; four / eight planes stage it in chunks, one tile per wave
+    if constexpr (NG == 2) {
+      RC_(launch_slices_fp8<2, 28, 1, 7>(sa, st));
+    } else {
+      sa.G = (nt + 7) / 8;
+      if constexpr (NG == 4) RC_(launch_slices_fp8c<4, 28, 7, 7>(sa, st));
+      else RC_(launch_slices_fp8c<8, 28, 4, 4>(sa, st));
+    }
   } else if constexpr (NG <= 4) {
     RC_(launch_slices_fp8<NG, 8, 2, 8>(sa, st));
   } else {
@@ -1070,8 +1089,33 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
 // "rider": the base rows of the partner group's next pass, so that a group step needs no sweep of its own for them).  The 64-row
 // kernels with one more plane: a slice of K = 4096 is 144 KiB of LDS, one workgroup per CU as there; bf16 / fp16 tiles only, the
 // 7B families' shapes only (the engine does not plan riders otherwise).
+// (fp8 tiles: K = 4096 — 144 KiB of operands per slice, single slices — and K = 14336 in chunks; Mistral-7B's shapes, config 5)
+static int try_slices9_fp8(int epi, const GemvArgs& a, hipStream_t st) {
+  const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;
+  const int spw2 = a.S / 16;
+  if (a.S % 16 || nt < 64 || !(spw2 == 8 || (spw2 == 28 && epi == EPI_RESID))) return SLICES_UNSUPPORTED;
+  if (a.part_floats < (size_t)8 * nt * 9 * 128) return SLICES_UNSUPPORTED;
+  SliceArgs sa;
+  sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1, sa.n_groups = nt;
+  sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
+  sa.rstd_out = a.part + a.part_floats;
+  if (spw2 == 28) {
+    sa.G = (nt + 7) / 8;
+    RC_(launch_slices_fp8c<9, 28, 4, 4>(sa, st));
+  } else {
+    sa.G = (nt + 7) / 8 < 32 ? (nt + 7) / 8 : 32;        // one round of workgroups (one per CU: 144 KiB of operands each)
+    RC_(launch_slices_fp8<9, 8, 1, 8>(sa, st));
+  }
+  switch (epi) {
+    case EPI_STORE: launch_finish<EPI_STORE, 1, 9, 8>(a, nt, st); break;
+    case EPI_RESID: launch_finish<EPI_RESID, 1, 9, 8>(a, nt, st); break;
+    case EPI_SILU: launch_finish<EPI_SILU, 2, 9, 8>(a, a.n_tiles, st); break;
+    default: launch_finish<EPI_QKV, 1, 9, 8>(a, nt, st); break;
+  }
+  return DD_OK;
+}
 static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
-  if (a.fp8) return SLICES_UNSUPPORTED;
+  if (a.fp8) return try_slices9_fp8(epi, a, st);
   const int spw = a.S / GEMV_WAVES;
   const int nt = epi == EPI_SILU ? 2 * a.n_tiles : a.n_tiles;
   if (!(spw == 16 || spw == 43 || spw == 56) || nt < 64) return SLICES_UNSUPPORTED;
@@ -1106,8 +1150,13 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
       else RC_(launch_slices_k<1, 9, 8, 56, 8, 1, EPI_RESID>(sa, a.wf, st));
     }
     launch_finish<EPI_RESID, 1, 9, 8>(a, nt, st);
+  } else if (spw == 16 && 4 * ((nt + 23) / 24) > 256) {
+    // more gate/up tiles than three per wave of one round of slice PAIRS (Mistral-7B: 1792 tiles): single slices, tiles walked per wave
+    sa.G = 32;
+    RC_(launch_slices_k<1, 9, 8, 16, 16, 1, EPI_SILU>(sa, a.wf, st));
+    launch_finish<EPI_SILU, 2, 9, 8>(a, a.n_tiles, st);
   } else {
-    if (spw != 16 || 4 * ((nt + 23) / 24) > 256) return SLICES_UNSUPPORTED;
+    if (spw != 16) return SLICES_UNSUPPORTED;
     sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 23) / 24;
     DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
     // (four weight requests in flight per wave: with eight, three tiles per wave and nine planes the kernel needs 257 registers and

@@ -504,3 +504,100 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
     g = gn;
   }
 }
+
+// The same for LONG K (down_proj of Mistral-7B: K = 14336, 28 steps of 64 k per slice) at four / eight / nine operand planes: a slice of
+// all planes does not fit the LDS (28 x 2 x NG KiB), so it is staged in chunks of CS2 steps — the next chunk's operand pieces are
+// requested into registers at the start of the current chunk and committed between two barriers, the weight queue runs on across the
+// chunk boundary (as k_gemv_slices does for bf16's long K).  One tile per wave (g = j + G wave), single slices: the chain of slice q
+// is the 8-row fp8 kernel's wave q (64-k steps q, q + 8, ...; both halves of a step in order), the finishing kernel adds the eight
+// slices pairwise and applies the row scale — bit for bit the 8-row kernel.
+// grid = 8 * G workgroups of 512 threads; dynamic LDS = 2 * CS2 * NG KiB; UW divides CS2.
+template <int NG, int SPW2, int CS2, int UW, int EPI_TAG = 0>
+__global__ __launch_bounds__(512) void k_gemv_slices_fp8c(SliceArgs a) {
+  static_assert(SPW2 % CS2 == 0 && CS2 % UW == 0, "chunks of whole weight blocks");
+  constexpr int NCH = SPW2 / CS2, NBC = CS2 / UW;      // chunks per slice, weight blocks per chunk
+  constexpr int PIECES = 2 * CS2 * NG;                 // operand pieces (1 KiB) per chunk
+  constexpr int PW = (PIECES + 7) / 8;
+  extern __shared__ __align__(16) u32x4_t xs[];        // [2 * CS2][NG][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int S2 = a.S >> 1;
+  const size_t xplane = (size_t)a.S * 64;
+  const int n_tiles = a.n_groups;
+  if (a.ssq_in && blockIdx.x == 0) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+  const int g = j + a.G * wave;
+  const bool live = g < n_tiles;
+  const u32x4_t* const wp = a.W + ((size_t)(live ? g : 0) * S2 + q) * 64 + lane;      // step s of the slice: wp + 8 s tiles
+  u32x4_t xv[PW];
+  auto stage_issue = [&](int k) {                      // chunk k: steps k CS2 .. k CS2 + CS2 - 1, piece = (32-k half-step t, plane h)
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int p = wave + 8 * i, pc = p < PIECES ? p : 0;
+      const int t = pc / NG, h = pc % NG;
+      xv[i] = a.xop[(size_t)(2 * (q + 8 * (k * CS2 + (t >> 1))) + (t & 1)) * 64 + h * xplane + lane];
+    }
+  };
+  auto stage_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int p = wave + 8 * i;
+      if (p < PIECES) xs[(size_t)p * 64 + lane] = xv[i];
+    }
+  };
+  u32x4_t wc[UW], wn[UW];
+#pragma unroll
+  for (int u = 0; u < UW; ++u) wc[u] = __builtin_nontemporal_load(wp + (size_t)u * 8 * 64);
+  __builtin_amdgcn_sched_barrier(0);
+  stage_issue(0);
+  stage_commit();
+  __syncthreads();
+  f32x4_t acc[NG];
+#pragma unroll
+  for (int h = 0; h < NG; ++h) acc[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    if (k + 1 < NCH) stage_issue(k + 1);               // requested ahead of this chunk's later weight requests
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < NBC; ++b) {
+      const int s0 = k * CS2 + b * UW;                 // first step of this block
+      if (s0 + UW < SPW2) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) wn[u] = __builtin_nontemporal_load(wp + (size_t)(s0 + UW + u) * 8 * 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        u32x4_t k0, k1;
+        fp8x16_to_bf16(wc[u], k0, k1);
+        const u32x4_t* x0 = xs + ((size_t)(2 * (b * UW + u)) * NG) * 64 + lane;
+#pragma unroll
+        for (int h = 0; h < NG; ++h) {
+          acc[h] = dd_mfma16<0>(k0, x0[(size_t)h * 64], acc[h]);
+          acc[h] = dd_mfma16<0>(k1, x0[(size_t)(NG + h) * 64], acc[h]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UW; ++u) wc[u] = wn[u];
+    }
+    if (k + 1 < NCH) {
+      __syncthreads();                                 // every wave has read this chunk
+      stage_commit();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < NG; ++h) {                       // hi + lo column of a row (lanes c < 8 of 16); every lane takes part in the shuffle
+    f32x4_t v = acc[h];
+    v.x += __shfl_down(v.x, 8);
+    v.y += __shfl_down(v.y, 8);
+    v.z += __shfl_down(v.z, 8);
+    v.w += __shfl_down(v.w, 8);
+    acc[h] = v;
+  }
+  if (live && (lane & 8) == 0) {
+    const int l32 = (lane >> 4) * 8 + (lane & 7);
+#pragma unroll
+    for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)q * n_tiles + g) * NG + h) << 7) + l32 * 4] = acc[h];
+  }
+}

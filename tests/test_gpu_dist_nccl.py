@@ -118,3 +118,32 @@ def test_tensor_parallel_rank_exchange_over_rccl_world_1():
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["got"] == res["want"] == res["solo"] and res["same_logits"]
     assert res["exchanges"] == 4 * (1 + 2 * 8)
+
+
+@pytest.mark.parametrize("mode", ["replicas", "kshard"])
+def test_bench_gpus_2_on_one_device(mode):
+    """`python bench.py --gpus 2` with world = 2 on the ONE GPU a box has (DD_BENCH_SHARE_DEVICE=1: both ranks on cuda:0 over gloo; RCCL
+    refuses two ranks on one device): bench.py spawns its ranks, each decodes its own image shard (replicas) or its half of the members
+    (kshard, real engines exchanging ids + the winner's record every token), the barriers and the all_reduce(MAX) of the time run at
+    world 2 and rank 0 alone prints the JSON line.  Not a scaling measurement — the line carries `shared_device`."""
+    env = dict(os.environ, DD_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-new", "12", "--images-per-gpu", "16",
+           "--single-images", "0", "--no-roofline", "--no-cpu-baseline", "--mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 alone reports
+    line = json.loads(lines[0])
+    pg = line["process_group"]
+    assert line["n_gpus"] == 2 and pg["ranks"] == 2 and pg["backend"] == "gloo" and pg["shared_device"] is True and pg["rccl_ranks"] == 0
+    assert line["value"] > 0 and line["scaling"] == ("weak" if mode == "replicas" else "strong")
+    if mode == "replicas":
+        assert line["config"]["images_per_step_per_gpu"] == 16
+        # whole job = both ranks' tokens over the slower rank's time
+        assert abs(line["value"] - 2 * 16 * 12 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"] + 0.02
+    else:
+        x = line["kshard_exchange"]
+        assert x["world"] == 2 and x["backend"] == "gloo" and x["tokens"] >= 10 and x["collectives_per_token"] == 2
+    print(f"\n[bench.py --gpus 2 --mode {mode}, both ranks on one GPU over gloo] value {line['value']} tok/s, {line['ms_per_step']} ms per step")

@@ -77,6 +77,39 @@ def _same(a, b, what):
         np.testing.assert_array_equal(x, y, err_msg=f"{what}: rng stream after the run, lane {i}")
 
 
+@pytest.mark.parametrize("n_lanes", [16, 32])
+def test_rider_step_fp8_mistral_shapes(E, T, n_lanes):
+    """BASELINE config 5's weight format in the rider form: nine operand planes through k_gemv_slices_fp8<9, ...> (K = 4096) and the chunked
+    k_gemv_slices_fp8c<9, ...> (down_proj, K = 14336) — bit for bit the classic group step (64-row fp8 passes + a fused un-masked pass)
+    and every sequence decoded alone (the 8-row fp8 kernel)."""
+    d, dff, H, Hkv = 4096, 14336, 32, 8
+    cfg = E.LMConfig(2048, d, dff, 2, H, Hkv, 128, 1e-5, 1000000.0)
+    L = 40
+    engines = _group(E, T, cfg, n_lanes, "llava-next", L, weight_format="fp8")
+    gen = torch.Generator().manual_seed(11)
+    T0s = [L + 6 + (i % 5) for i in range(n_lanes)]
+    embs = [(torch.randn(T0, d, generator=gen) * 0.5).cuda() for T0 in T0s]
+    spans = [(2 + (i % 3), L) for i in range(n_lanes)]
+    steps = 5
+    ref = _run(E, T, engines, embs, spans, K8, steps, rider=False, graph=False)
+    for graph in (False, True):
+        got = _run(E, T, engines, embs, spans, K8, steps, rider=True, graph=graph)
+        _same(got, ref, f"fp8 rider, {n_lanes} lanes (graph {graph})")
+    for li in (0, 9, n_lanes - 1):
+        e = engines[li]
+        e.set_speculation("never")
+        e.rng.manual_seed(50 + li)
+        e.prefill(embs[li], *spans[li])
+        for s in range(steps):
+            e.decode_step(K8)
+            np.testing.assert_array_equal(e.logits(), ref[0][s][li][0], err_msg=f"fp8 rider: solo lane {li} step {s}")
+            np.testing.assert_array_equal(e.base_logits(), ref[0][s][li][1], err_msg=f"fp8 rider: solo lane {li} step {s} (un-masked)")
+        assert e.tokens() == ref[1][li]
+        e.set_speculation("default")
+    for e in reversed(engines):
+        e.close()
+
+
 @pytest.mark.parametrize("name,dims,n_lanes,probs", [
     ("llama-7b shapes, 16 lanes: one ring of two groups", (4096, 11008, 32, 32), 16, K8),
     ("llama-7b shapes, 32 lanes: two branches, rings of two", (4096, 11008, 32, 32), 32, K8),
