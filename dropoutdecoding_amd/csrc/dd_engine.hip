@@ -1243,6 +1243,8 @@ void dd_engine_set_graph(int on) { g_use_graph = on; }
 int dd_engine_use_graph() { return g_use_graph; }
 void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
 static int g_branches = 2;     // dd_tools_set_tuning key 23: member sweeps of a group step that run concurrently (1..4)
+static int g_fp32_fork = 0;    // dd_tools_set_tuning key 37: branches for fp32-cache engines too (round 3 saw lanes differ from their solo runs there)
+void dd_engine_set_fp32_fork(int on) { g_fp32_fork = on; }
 void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }
 // the same for the rider form (rings of at least two groups each): 64 lanes 42.5 / 38.2 / 36.9 ms per step with 2 / 3 / 4 branches
 // (tools/rider_ab.py), where the classic form gained nothing beyond two; dd_tools_set_tuning key 28
@@ -1767,7 +1769,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   const int nbr = g_branches < n_multi ? g_branches : n_multi;       // branches in use: the caller's stream + nbr - 1 side streams
   // (fp16-cache engines only: with the fp32 cache's VALU attention kernels running beside another sweep, lanes did not always
   // reproduce their solo runs bit for bit — cause not found; tools/lanes_mixed_ab.py shows it — so those keep one branch)
-  const bool fork = nbr >= 2 && h0->kv16 && h0->side[nbr - 2] != nullptr;
+  const bool fork = nbr >= 2 && (h0->kv16 || g_fp32_fork) && h0->side[nbr - 2] != nullptr;
   if (fork) {
     DD_HIP(hipEventRecord(h0->ev_fork, st));
     for (int i = 0; i + 1 < nbr; ++i) DD_HIP(hipStreamWaitEvent(h0->side[i], h0->ev_fork, 0));

@@ -864,6 +864,7 @@ static int launch_gemv_groups(const GemvArgs& a, hipStream_t st) {
 // families have (K = 4096: 16 k-steps per slice; K = 11008 / 14336: 43 / 56, staged in chunks of 16).  Anything else runs
 // through k_gemv_groups; both produce the same bits.
 static int g_gemv_slices = 1;     // dd_set_tuning key 13
+int g_exp_temporal = 0;        // dd_tools_set_tuning key 36: slice kernels load weight tiles with the default cache policy (A/B)
 int g_exp_U9 = 4;                // dd_tools_set_tuning key 29: weight requests in flight per wave of the nine-plane qkv kernel (4 or 8; gate/up: always 4)
 int g_exp_G[4] = {0, 0, 0, 0};   // dd_set_tuning keys 17..19: workgroups per slice of the 64-row kernels (qkv, o, gate/up); 0 = default
 static int g_slices_only = 0;     // dd_lm_time_gemv: launch the streaming kernel without its finishing kernel (timing only)
@@ -950,7 +951,7 @@ static int try_slices_fp8(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1, sa.n_groups = nt;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats;
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;
   const int per_set = 256 / (8 / ch);                  // one round of workgroups (one per CU at 64-128 KiB of operands)
   sa.G = (nt + 7) / 8 < per_set ? (nt + 7) / 8 : per_set;
   if (spw2 == 28) {
@@ -985,7 +986,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats;                              // 32 floats behind the partial sums
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;                              // 32 floats behind the partial sums
   const size_t need8 = (size_t)8 * nt * NG * 128, need4 = need8 / 2;
   if (epi == EPI_STORE) {
     // lm_head (K = 4096): the wave-split kernel streams it at 2.8 TB/s with four planes (operand reads from L2); the slice kernels
@@ -1098,7 +1099,7 @@ static int try_slices9_fp8(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1, sa.n_groups = nt;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats;
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;
   if (spw2 == 28) {
     sa.G = (nt + 7) / 8;
     RC_(launch_slices_fp8c<9, 28, 4, 4>(sa, st));
@@ -1122,7 +1123,7 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats;
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;
   const size_t need8 = (size_t)8 * nt * 9 * 128;
   if (a.part_floats < need8) return SLICES_UNSUPPORTED;
   sa.n_groups = nt;
@@ -1139,6 +1140,13 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
     else RC_(launch_slices_seq<9, 4, 2, EPI_QKV>(sa, a.wf, st));
     launch_finish<EPI_QKV, 1, 9, 4>(a, nt, st);
   } else if (epi == EPI_RESID) {
+    if (spw == 16 && g_exp_G[1] == -2 && (nt + 8 * 32 - 1) / (8 * 32) <= 1) {
+      // (A/B, tuning key 18 = -2) slice PAIRS, one slice resident at a time, one tile per wave on 4 * 32 = 128 workgroups: half the partial sums
+      sa.G = 32;
+      RC_(launch_slices_seq<9, 8, 1, EPI_RESID>(sa, a.wf, st));
+      launch_finish<EPI_RESID, 1, 9, 4>(a, nt, st);
+      return DD_OK;
+    }
     if (spw == 16) {
       // two tiles per wave on 8 * 16 = 128 workgroups at N = 4096: alone 14.7 us against 11.2 with one tile per wave on 256, but inside
       // the step, beside the other branch's kernels, the half-chip grid wins (20.9 vs 21.4 ms per 32-lane step; tuning key 18)

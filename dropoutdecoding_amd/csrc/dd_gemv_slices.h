@@ -42,7 +42,11 @@ struct SliceArgs {
   // the second reads the tiles from that XCD's L2 — HBM sees the weights once, each CU carries NG planes of MFMA / LDS work.
   // Partial sums are laid out for 2 * NG planes (plane = half * NG + h).  grid = 2 * (8 / CH) * G, a multiple of 16.
   int halves;
+  // 1: weight tiles with the default cache policy instead of non-temporal loads (A/B, dd_tools_set_tuning key 36: beside other branches that
+  // stream the same matrix moments later a tile may be served from the Infinity Cache)
+  int temporal;
 };
+__device__ __forceinline__ u32x4_t dd_ldw(int temporal, const u32x4_t* p) { return temporal ? *p : __builtin_nontemporal_load(p); }
 
 // rstd(row) = 1 / sqrt(mean(x^2) + eps) from per-workgroup partial sums of squares; wave w of the calling workgroup
 // (8 waves) assembles rows w, w + 8, ...  ONE definition for every kernel that needs it: the sum order is part of the result.
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
       for (int u = 0; u < UU; ++u)
 #pragma unroll
         for (int t = 0; t < TW; ++t)
-          w[t][u] = __builtin_nontemporal_load(a.W + ((size_t)(g * TW + t) * a.S + q) * 64 + lane + woff(u));
+          w[t][u] = dd_ldw(a.temporal, a.W + ((size_t)(g * TW + t) * a.S + q) * 64 + lane + woff(u));
     }
     __builtin_amdgcn_sched_barrier(0);
     stage_issue(0, SPW);
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
           for (int t = 0; t < TW; ++t) {
 #pragma unroll
             for (int h = 0; h < NG; ++h) acc[t][h] = mfma(w[t][u], b[h], acc[t][h]);
-            if (blk + 1 < NB) w[t][u] = __builtin_nontemporal_load(wp[t] + woff(s + UU));
-            else if (request_next_group) w[t][u] = __builtin_nontemporal_load(wn[t] + woff(u));
+            if (blk + 1 < NB) w[t][u] = dd_ldw(a.temporal, wp[t] + woff(s + UU));
+            else if (request_next_group) w[t][u] = dd_ldw(a.temporal, wn[t] + woff(u));
           }
           __builtin_amdgcn_sched_barrier(0);           // keep consume -> re-request order
         }
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < TW; ++t) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)u * wstep);
+      for (int t = 0; t < TW; ++t) w[t][u] = dd_ldw(a.temporal, wp[t] + (size_t)u * wstep);
     __builtin_amdgcn_sched_barrier(0);
     stage_commit(CS);
     __syncthreads();
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
           for (int t = 0; t < TW; ++t) {
 #pragma unroll
             for (int h = 0; h < NG; ++h) acc[t][h] = mfma(w[t][u], b[h], acc[t][h]);
-            if (c + U < SPW) w[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)(c + U) * wstep);
+            if (c + U < SPW) w[t][u] = dd_ldw(a.temporal, wp[t] + (size_t)(c + U) * wstep);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
   {
     const u32x4_t* p0 = wptr(0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(p0 + (size_t)u * wstep);
+    for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, p0 + (size_t)u * wstep);
   }
   __builtin_amdgcn_sched_barrier(0);
   stage(0);
@@ -366,8 +370,8 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
             for (int h = 0; h < NG; ++h) b[h] = xs[(size_t)(s * NG + h) * 64 + lane];
 #pragma unroll
             for (int h = 0; h < NG; ++h) acc[h] = dd_mfma16<WF>(w[u], b[h], acc[h]);
-            if (blk + 1 < NB) w[u] = __builtin_nontemporal_load(wp + (size_t)(s + U) * wstep);
-            else if (!last_item) w[u] = __builtin_nontemporal_load(wn + (size_t)u * wstep);
+            if (blk + 1 < NB) w[u] = dd_ldw(a.temporal, wp + (size_t)(s + U) * wstep);
+            else if (!last_item) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
         }
       } else if (!last_item) {                         // a slot this wave does not have: hand the ring to the next item
 #pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wn + (size_t)u * wstep);
+        for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
       }
     }
     if (half == 0) {
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
   if (any) {
     const u32x4_t* p = wptr(g, 0);
 #pragma unroll
-    for (int u = 0; u < UW; ++u) wc[u] = __builtin_nontemporal_load(p + (size_t)u * 8 * 64);
+    for (int u = 0; u < UW; ++u) wc[u] = dd_ldw(a.temporal, p + (size_t)u * 8 * 64);
   }
   __builtin_amdgcn_sched_barrier(0);
   {
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
       if (b + 1 < CH * NB || has_next) {
         const u32x4_t* p = b + 1 < CH * NB ? wptr(g, b + 1) : wptr(gn, 0);
 #pragma unroll
-        for (int u = 0; u < UW; ++u) wn[u] = __builtin_nontemporal_load(p + (size_t)u * 8 * 64);
+        for (int u = 0; u < UW; ++u) wn[u] = dd_ldw(a.temporal, p + (size_t)u * 8 * 64);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (b % NB == 0) {
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8c(SliceArgs a) {
   };
   u32x4_t wc[UW], wn[UW];
 #pragma unroll
-  for (int u = 0; u < UW; ++u) wc[u] = __builtin_nontemporal_load(wp + (size_t)u * 8 * 64);
+  for (int u = 0; u < UW; ++u) wc[u] = dd_ldw(a.temporal, wp + (size_t)u * 8 * 64);
   __builtin_amdgcn_sched_barrier(0);
   stage_issue(0);
   stage_commit();
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8c(SliceArgs a) {
       const int s0 = k * CS2 + b * UW;                 // first step of this block
       if (s0 + UW < SPW2) {
 #pragma unroll
-        for (int u = 0; u < UW; ++u) wn[u] = __builtin_nontemporal_load(wp + (size_t)(s0 + UW + u) * 8 * 64);
+        for (int u = 0; u < UW; ++u) wn[u] = dd_ldw(a.temporal, wp + (size_t)(s0 + UW + u) * 8 * 64);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

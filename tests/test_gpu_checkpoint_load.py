@@ -29,7 +29,7 @@ def test_sharded_fp16_checkpoint_through_from_pretrained(tmp_path):
     text = dict(cu.LLAVA15_7B_TEXT, num_hidden_layers=LAYERS)
     path = str(tmp_path / "llava-1.5-7b-layout")
     t0 = time.time()
-    wm = cu.write_llava_checkpoint(path, text, cu.CLIP_L_336, image_token_index=32000, seed=11, device="cuda")
+    wm = cu.write_llava_checkpoint(path, text, cu.CLIP_L_336, image_token_index=32000, seed=11, device="cuda", shard_bytes=2 * 10 ** 9)
     t_write = time.time() - t0
     files = sorted(os.listdir(path))
     shards = [f for f in files if f.endswith(".safetensors")]
