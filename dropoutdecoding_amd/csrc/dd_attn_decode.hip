@@ -493,6 +493,9 @@ static void attn16_grid(AttnDecodeArgs& b, int splits, int wg_per_tile) {
 }
 // all-tiles form (FULL) of k_attn_partial16: contexts of up to ATT_FULL_TILES tiles and enough (kv head, sequence) workgroups
 int g_attn16_full = 1;   // dd_set_tuning key 22
+// fp16 cache, GQA: all q heads of a kv group in ONE workgroup (up to 32 rows: four MFMA row blocks) read every K / V tile once instead of
+// once per GQA slice of 16 rows — the same rows through the same blocks of eight, so the same bits.  dd_tools_set_tuning key 38.
+int g_attn16_gh_all = 0;
 static bool attn16_full_ok(int splits, int wgs) { return g_attn16_full && splits <= ATT_FULL_TILES && wgs >= 128; }
 template <int NBT, int G, int GH, int ML>
 static int launch_attn16_full(const AttnDecodeArgs& a, dim3 grid, hipStream_t st) {
@@ -520,8 +523,14 @@ static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
   }
   if (a.kv16) {
     AttnDecodeArgs b = a;
-    attn16_grid(b, splits, a.n_kv * (G / GH));
-    k_attn_partial16<NBT, G, GH, 0><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, G / GH), 256, 0, st>>>(b);
+    constexpr int GHALL = (NBT * G > 32) ? 2 : G;
+    if (GHALL != GH && g_attn16_gh_all) {
+      attn16_grid(b, splits, a.n_kv * (G / GHALL));
+      k_attn_partial16<NBT, G, GHALL, 0><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, G / GHALL), 256, 0, st>>>(b);
+    } else {
+      attn16_grid(b, splits, a.n_kv * (G / GH));
+      k_attn_partial16<NBT, G, GH, 0><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, G / GH), 256, 0, st>>>(b);
+    }
   } else {
     k_attn_partial<NBT, G, GH><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
   }
@@ -572,8 +581,14 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
   }
   if (a.kv16) {
     AttnDecodeArgs b = a;
-    attn16_grid(b, splits, a.n_kv * NG * (G / GH) * (8 / NBT));
-    k_attn_partial16<NBT, G, GH, 2><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, NG * (G / GH) * (8 / NBT)), 256, 0, st>>>(b);
+    constexpr int GHALL = (NBT * G > 32) ? 2 : G;
+    if (GHALL != GH && g_attn16_gh_all) {
+      attn16_grid(b, splits, a.n_kv * NG * (G / GHALL) * (8 / NBT));
+      k_attn_partial16<NBT, G, GHALL, 2><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, NG * (G / GHALL) * (8 / NBT)), 256, 0, st>>>(b);
+    } else {
+      attn16_grid(b, splits, a.n_kv * NG * (G / GH) * (8 / NBT));
+      k_attn_partial16<NBT, G, GH, 2><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, NG * (G / GH) * (8 / NBT)), 256, 0, st>>>(b);
+    }
   } else {
     k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
   }
@@ -589,9 +604,8 @@ static int launch_attn_groups(const AttnDecodeArgs& a, hipStream_t st) {
   return launch_attn_groups_n<G, NG, 8>(a, st);
 }
 
-template <int G, int NBT>
-static int launch_attn_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, int planes_m, hipStream_t st) {
-  constexpr int GH = (NBT * G > 16) ? 2 : G;
+template <int G, int NBT, int GH>
+static int launch_attn_ride_gh(const AttnDecodeArgs& a, const AttnDecodeArgs& u, int planes_m, hipStream_t st) {
   const int splits_a = ddk_attn_grid_tiles(a.max_T, a.T_cap), splits_u = ddk_attn_grid_tiles(u.max_T, u.T_cap);
   DD_REQUIRE(splits_a >= 1 && splits_a <= ATT_MAX_SPLITS && splits_u >= 1 && splits_u <= ATT_MAX_SPLITS,
              "attn: %d / %d key tiles unsupported (1..%d)", splits_a, splits_u, ATT_MAX_SPLITS);
@@ -604,6 +618,14 @@ static int launch_attn_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, in
   if (u.n_lanes > 8) k_attn_combine_ride<G, 16><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
   else k_attn_combine_ride<G, 8><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
   return DD_OK;
+}
+template <int G, int NBT>
+static int launch_attn_ride(const AttnDecodeArgs& a, const AttnDecodeArgs& u, int planes_m, hipStream_t st) {
+  constexpr int GH16 = (NBT * G > 16) ? 2 : G, GHALL = (NBT * G > 32) ? 2 : G;
+  if constexpr (GHALL != GH16) {
+    if (g_attn16_gh_all) return launch_attn_ride_gh<G, NBT, GHALL>(a, u, planes_m, st);
+  }
+  return launch_attn_ride_gh<G, NBT, GH16>(a, u, planes_m, st);
 }
 // a: the member pass of a rider sweep (lane_groups == 8: eight sequences, one per plane — or, with half planes, fourteen in planes_m = 7
 // planes), u: un-masked rows of up to sixteen sequences (lanes form, own partial buffers), both over fp16 caches: the two attentions of

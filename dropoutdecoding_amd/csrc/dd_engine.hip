@@ -1253,6 +1253,22 @@ void dd_engine_set_rider_branches(int n) { g_rider_branches = n < 1 ? 1 : (n > 4
 static int g_ride_beside = 1;    // dd_tools_set_tuning key 27: the riding rows' attention in the members' launches (0: launches of its own)
 void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 
+// ---- debug: per-stage checksums of a multi-group sweep (libdropdec_tools.so sets the buffer; tools/race_bisect.py) ----------------------
+// trace[(sweep * n_layers + layer) * 8 + stage] += order-independent 32-bit sums of the stage's output (0 embed, 1 q rows, 2 new K rows,
+// 3 attention -> o_proj operand, 4 o_proj -> residual rows, 5 gate/up -> down operand, 6 down -> residual rows, 7 down -> next operand)
+uint32_t* g_dbg_trace = nullptr;
+int g_dbg_trace_cap = 0, g_dbg_sweeps = 0;
+__global__ __launch_bounds__(256) void k_dbg_sum(const uint32_t* __restrict__ p, size_t n, uint32_t* __restrict__ out) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += p[i] * (uint32_t)(2 * i + 1);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+static void dbg_sum(int sweep, int n_layers, int layer, int stage, const void* p, size_t bytes, hipStream_t st) {
+  if (!g_dbg_trace || sweep >= g_dbg_trace_cap) return;
+  k_dbg_sum<<<64, 256, 0, st>>>((const uint32_t*)p, bytes / 4, g_dbg_trace + ((size_t)sweep * n_layers + layer) * 8 + stage);
+}
+
 #define RIDER_KV_ROW0 16   // rows of the sweeping handle's new-K/V scratch that hold the riding un-masked rows (0..15: members)
 // rider / n_rider (ng == 8 only): up to 8 sequences whose UN-MASKED rows ride in a ninth operand plane of the sweep (row 64 + m =
 // sequence rider[m]); their logits go to rows 0.. of h->grp_logits.  See group_step_rider.
@@ -1273,6 +1289,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     for (int m = 0; m < K; ++m) el.state[row0(g) + m] = qs[g]->state;
   for (int m = 0; m < n_rider; ++m) el.state[ride_row0 + m] = rider[m]->state;
   RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * planes, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
+  const int dbg_sweep = g_dbg_trace ? g_dbg_sweeps++ : 0;
+  dbg_sum(dbg_sweep, h->Lyr, 0, 0, h->xop_d, (size_t)planes * h->S_d * 1024, st);
   int ssq_n = 1;
   for (int l = 0; l < h->Lyr; ++l) {
     LayerW& w = h->lw[l];
@@ -1310,6 +1328,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
       for (int m = 0; m < n_rider; ++m) a.state_rows[ride_row0 + m] = rider[m]->state;
     }
     RC(ddk_gemv_groups(EPI_QKV, a, st));
+    dbg_sum(dbg_sweep, h->Lyr, l, 1, h->qbuf, (size_t)8 * planes * h->q_dim * 4, st);
+    for (int g = 0; g < ng && g_dbg_trace; ++g) dbg_sum(dbg_sweep, h->Lyr, l, 2, a.knew_g[g], (size_t)rows_g * h->kv_dim * 4, st);
     if (n_rider) {
       // the riding rows: one single-query attention per sequence over its own cache (the fused base pass's form), into plane 8
       AttnDecodeArgs u;
@@ -1334,6 +1354,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     } else {
       RC(ddk_attn_decode(t, st));
     }
+    dbg_sum(dbg_sweep, h->Lyr, l, 3, h->xop_q, (size_t)planes * h->S_q * 1024, st);
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
     a.W = w.wo, a.S = h->S_q, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_q, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
@@ -1341,6 +1362,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
+    dbg_sum(dbg_sweep, h->Lyr, l, 4, h->xa, (size_t)8 * planes * d * 4, st);
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
     a.W = w.wgu, a.S = h->S_d, a.n_tiles = dff / 16, a.nb = K, a.xop = h->xop_d, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
@@ -1349,6 +1371,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_SILU, a, st));
+    dbg_sum(dbg_sweep, h->Lyr, l, 5, h->xop_ff, (size_t)planes * h->S_ff * 1024, st);
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
     a.W = w.wdown, a.S = h->S_ff, a.n_tiles = d / 16, a.nb = K, a.xop = h->xop_ff, a.n_groups = planes, a.nb_rider = n_rider, a.half_planes = hp;
@@ -1357,6 +1380,8 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
     RC(ddk_gemv_groups(EPI_RESID, a, st));
+    dbg_sum(dbg_sweep, h->Lyr, l, 6, h->xa, (size_t)8 * planes * d * 4, st);
+    dbg_sum(dbg_sweep, h->Lyr, l, 7, h->xop_d, (size_t)planes * h->S_d * 1024, st);
     ssq_n = d / 16;
   }
   GemvArgs a;

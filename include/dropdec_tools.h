@@ -63,6 +63,9 @@ int dd_tools_sample_masks_lanes(int n, const float* const* epi, const int32_t* L
                                 const int32_t* const* topk, dd_rng* const* rngs, uint8_t* const* drop, int32_t* const* n_drop,
                                 uint8_t* const* drop_bits, int k_top, const double* mprobs, int K, int mode, void* stream);
 int dd_tools_lds_poison(int launches, int wgs, int lds_bytes, void* stream);
+/* Per-stage checksums of every multi-group sweep enqueued from now on (eager launches): trace_dev [cap_sweeps][n_layers][8] uint32, zeroed by the
+ * caller; stage 0 embed, 1 q rows, 2 new K rows, 3 attention output, 4 o_proj, 5 gate/up, 6 down (rows), 7 down (next operand).  NULL: off. */
+int dd_tools_sweep_trace(uint32_t* trace_dev, int cap_sweeps);
 int dd_tools_scratch_probe(int launches, int wgs, int spin, unsigned int* errors_dev, void* stream);
 
 #ifdef __cplusplus

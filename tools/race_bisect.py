@@ -1,0 +1,74 @@
+"""Where does a two-branch group step first differ from the one-branch step?  Per-stage checksums of every multi-group sweep
+(dd_tools_sweep_trace: embed, q rows, new K rows, attention output, o_proj, gate/up, down) of the same decode run with 1 and with 2
+branches; prints the first (step, sweep, layer, stage) whose sums differ, for a few repetitions of the two-branch run.
+
+    python tools/race_bisect.py [kv=fp32] [lanes=12] [steps=3] ["key=value,..." applied to both runs]"""
+import os, sys
+os.environ.setdefault("DD_USE_TOOLS_LIB", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from dropoutdecoding_amd import _lib, lm
+
+torch.cuda.set_device(0)
+KV = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+NL = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+L = _lib.load()
+L.dd_tools_set_tuning(8, 0)           # eager launches: the trace numbers sweeps in host order
+L.dd_tools_set_tuning(37, 1)          # branches for fp32 caches too
+for kv in sys.argv[4:]:
+    for p in kv.split(","):
+        k_, v_ = p.split("=")
+        L.dd_tools_set_tuning(int(k_), int(v_))
+probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+shapes = [(608, 5, 576), (640, 9, 576), (600, 1, 576), (615, 20, 576), (609, 5, 576), (700, 60, 576),
+          (610, 3, 576), (633, 7, 576), (655, 11, 576), (602, 2, 576), (690, 33, 576), (611, 4, 576), (644, 8, 576), (603, 2, 576),
+          (620, 6, 576), (699, 30, 576)][:NL]
+engs = []
+for i in range(len(shapes)):
+    engs.append(lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=768, max_visual=576, seed=5217, kv_format=KV,
+                                 share_weights_with=engs[0] if engs else None))
+engs[0].load_synthetic(1, 0.02)
+embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(50 + i)).cuda() for i, (T0, _, _) in enumerate(shapes)]
+CAP = 64
+STAGE = ["embed", "q rows (qkv GEMV + finish)", "new K rows (qkv GEMV + finish)", "attention -> o_proj operand", "o_proj -> residual rows",
+         "gate/up -> down operand", "down -> residual rows", "down -> next operand"]
+trace = torch.zeros(CAP, 32, 8, dtype=torch.int32, device="cuda")
+
+
+def run(branches):
+    L.dd_tools_set_tuning(23, branches)
+    for e, x, (T0, s0, Lv) in zip(engs, embs, shapes):
+        e.rng.manual_seed(5217)
+        e.prefill(x, s0, Lv)
+    torch.cuda.synchronize()
+    trace.zero_()
+    torch.cuda.synchronize()
+    L.dd_tools_sweep_trace(trace.data_ptr(), CAP)
+    grp = lm.EngineGroup(engs)
+    for s in range(STEPS):
+        grp.decode_step(probs)
+    torch.cuda.synchronize()
+    L.dd_tools_sweep_trace(None, 0)
+    return trace.cpu().numpy().copy(), [e.tokens() for e in engs], [e.logits().copy() for e in engs]
+
+
+ref, rtoks, rlog = run(1)
+ref2, _, _ = run(1)
+print("one branch twice: traces", "equal" if np.array_equal(ref, ref2) else "DIFFER (!)")
+n_sweeps = int((ref.reshape(CAP, -1) != 0).any(1).sum())
+print(f"{n_sweeps} multi-group sweeps traced over {STEPS} steps")
+for rep in range(4):
+    got, toks, logs = run(2)
+    bad = np.argwhere(got != ref)
+    lanes_bad = [i for i in range(len(engs)) if not np.array_equal(logs[i], rlog[i])]
+    if len(bad) == 0:
+        print(f"rep {rep}: two branches: trace equal; lanes with different final logits: {lanes_bad}")
+        continue
+    first = bad[np.lexsort((bad[:, 2], bad[:, 1], bad[:, 0]))][0]
+    by_sweep = {}
+    for sw, ly, stg in bad:
+        by_sweep.setdefault(int(sw), []).append((int(ly), int(stg)))
+    msg = "; ".join(f"sweep {sw}: first at layer {min(v)[0]} stage '{STAGE[min(v)[1]]}' ({len(v)} cells)" for sw, v in sorted(by_sweep.items()))
+    print(f"rep {rep}: two branches: {len(bad)} trace cells differ; {msg}; lanes with different final logits: {lanes_bad}", flush=True)
