@@ -25,6 +25,7 @@
 // ML == 2 (groups): NBT == 8; blockIdx.z = group * (G / GH) + GQA slice; group g's 8 rows (members of sequence g) read
 // that sequence's cache and drop bits; results go to an (8 * a.lane_groups)-rows-per-head layout (row = 8 * group + member).
 // (fp32 cache; the fp16 cache goes through k_attn_partial16 below)
+int g_attn32_lds_pad = 0;      // dd_tools_set_tuning key 39 (debug): bytes added to the fp32 attention kernel's dynamic LDS request
 template <int NBT, int G, int GH, int ML = 0>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
@@ -590,6 +591,10 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
       k_attn_partial16<NBT, G, GH, 2><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, NG * (G / GH) * (8 / NBT)), 256, 0, st>>>(b);
     }
   } else {
+    if (g_attn32_lds_pad > 0) {
+      DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + g_attn32_lds_pad)));
+      k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem + g_attn32_lds_pad, st>>>(a);
+    } else
     k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
   }
   k_attn_combine<8 * NG, G><<<dim3(a.n_heads, 8 * NG), HEAD_DIM, 0, st>>>(a, splits);

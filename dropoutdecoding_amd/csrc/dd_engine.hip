@@ -1254,8 +1254,9 @@ static int g_ride_beside = 1;    // dd_tools_set_tuning key 27: the riding rows'
 void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 
 // ---- debug: per-stage checksums of a multi-group sweep (libdropdec_tools.so sets the buffer; tools/race_bisect.py) ----------------------
-// trace[(sweep * n_layers + layer) * 8 + stage] += order-independent 32-bit sums of the stage's output (0 embed, 1 q rows, 2 new K rows,
-// 3 attention -> o_proj operand, 4 o_proj -> residual rows, 5 gate/up -> down operand, 6 down -> residual rows, 7 down -> next operand)
+// trace[(sweep * n_layers + layer) * 16 + stage] += order-independent 32-bit sums of the stage's output (0 embed, 1 q rows, 2 new K rows,
+// 3 attention -> o_proj operand, 4 o_proj -> residual rows, 5 gate/up -> down operand, 6 down -> residual rows, 7 down -> next operand,
+// 8 / 9 the attention's per-tile statistics / outputs (the tiles every sequence of the sweep has), 10 new V rows)
 uint32_t* g_dbg_trace = nullptr;
 int g_dbg_trace_cap = 0, g_dbg_sweeps = 0;
 __global__ __launch_bounds__(256) void k_dbg_sum(const uint32_t* __restrict__ p, size_t n, uint32_t* __restrict__ out) {
@@ -1264,9 +1265,20 @@ __global__ __launch_bounds__(256) void k_dbg_sum(const uint32_t* __restrict__ p,
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
+__global__ __launch_bounds__(256) void k_dbg_sum_tiles(const uint32_t* __restrict__ p, int n_kv, int splits_grid, int row_words, int tiles,
+                                                       uint32_t* __restrict__ out) {
+  const size_t n = (size_t)n_kv * tiles * row_words;
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t kvh = i / ((size_t)tiles * row_words), rem = i % ((size_t)tiles * row_words);
+    acc += p[(kvh * splits_grid + rem / row_words) * row_words + rem % row_words] * (uint32_t)(2 * i + 1);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
 static void dbg_sum(int sweep, int n_layers, int layer, int stage, const void* p, size_t bytes, hipStream_t st) {
   if (!g_dbg_trace || sweep >= g_dbg_trace_cap) return;
-  k_dbg_sum<<<64, 256, 0, st>>>((const uint32_t*)p, bytes / 4, g_dbg_trace + ((size_t)sweep * n_layers + layer) * 8 + stage);
+  k_dbg_sum<<<64, 256, 0, st>>>((const uint32_t*)p, bytes / 4, g_dbg_trace + ((size_t)sweep * n_layers + layer) * 16 + stage);
 }
 
 #define RIDER_KV_ROW0 16   // rows of the sweeping handle's new-K/V scratch that hold the riding un-masked rows (0..15: members)
@@ -1353,6 +1365,15 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
       }
     } else {
       RC(ddk_attn_decode(t, st));
+    }
+    if (g_dbg_trace && dbg_sweep < g_dbg_trace_cap && !n_rider) {
+      int minT = 1 << 30;
+      for (int g = 0; g < ng; ++g) minT = qs[g]->T_host < minT ? qs[g]->T_host : minT;
+      const int tiles = (minT + 63) / 64, sg = ddk_attn_grid_tiles(t.max_T, h->T_cap), RT = 8 * (packed ? 8 : ng) * (h->H / h->Hkv);
+      uint32_t* tr = g_dbg_trace + ((size_t)dbg_sweep * h->Lyr + l) * 16;
+      k_dbg_sum_tiles<<<64, 256, 0, st>>>((const uint32_t*)h->part_ml, h->Hkv, sg, RT * 2, tiles, tr + 8);
+      k_dbg_sum_tiles<<<64, 256, 0, st>>>((const uint32_t*)h->part_o, h->Hkv, sg, RT * 128, tiles, tr + 9);
+      for (int g = 0; g < ng; ++g) dbg_sum(dbg_sweep, h->Lyr, l, 10, t.vnew_g[g], (size_t)rows_g * h->kv_dim * 4, st);
     }
     dbg_sum(dbg_sweep, h->Lyr, l, 3, h->xop_q, (size_t)planes * h->S_q * 1024, st);
     memset(&a, 0, sizeof(a));

@@ -100,7 +100,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // (616 bytes per lane; this library only); the product switches
 // (8, 11, 13-16) are forwarded to dd_set_tuning.  Every call bumps the graph-key epoch: steps captured under other settings are not replayed.
 extern int g_exp_G[4];
-extern int g_attn16_tpw, g_attn16_full, g_finish4, g_attn16_gh_all;
+extern int g_attn16_tpw, g_attn16_full, g_finish4, g_attn16_gh_all, g_attn32_lds_pad;
 void dd_engine_set_pairs(int on);
 void dd_engine_set_branches(int n);
 void dd_engine_set_rider(int on);
@@ -115,7 +115,7 @@ void dd_dropout_set_lanes_sampler_scratch(int on);   // dd_dropout.hip compiled 
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38,
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -136,6 +136,7 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 36) g_exp_temporal = value;
   else if (key == 37) dd_engine_set_fp32_fork(value);
   else if (key == 38) g_attn16_gh_all = value;
+  else if (key == 39) g_attn32_lds_pad = value;
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }

@@ -33,8 +33,10 @@ engs[0].load_synthetic(1, 0.02)
 embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(50 + i)).cuda() for i, (T0, _, _) in enumerate(shapes)]
 CAP = 64
 STAGE = ["embed", "q rows (qkv GEMV + finish)", "new K rows (qkv GEMV + finish)", "attention -> o_proj operand", "o_proj -> residual rows",
-         "gate/up -> down operand", "down -> residual rows", "down -> next operand"]
-trace = torch.zeros(CAP, 32, 8, dtype=torch.int32, device="cuda")
+         "gate/up -> down operand", "down -> residual rows", "down -> next operand", "attention tiles: statistics (partial kernel)",
+         "attention tiles: outputs (partial kernel)", "new V rows"] + ["-"] * 5
+ORDER = [0, 1, 2, 10, 8, 9, 3, 4, 5, 6, 7]          # pipeline order of the stages within a layer
+trace = torch.zeros(CAP, 32, 16, dtype=torch.int32, device="cuda")
 
 
 def run(branches):
@@ -66,9 +68,8 @@ for rep in range(4):
     if len(bad) == 0:
         print(f"rep {rep}: two branches: trace equal; lanes with different final logits: {lanes_bad}")
         continue
-    first = bad[np.lexsort((bad[:, 2], bad[:, 1], bad[:, 0]))][0]
     by_sweep = {}
     for sw, ly, stg in bad:
-        by_sweep.setdefault(int(sw), []).append((int(ly), int(stg)))
-    msg = "; ".join(f"sweep {sw}: first at layer {min(v)[0]} stage '{STAGE[min(v)[1]]}' ({len(v)} cells)" for sw, v in sorted(by_sweep.items()))
+        by_sweep.setdefault(int(sw), []).append((int(ly), ORDER.index(int(stg))))
+    msg = "; ".join(f"sweep {sw}: first at layer {min(v)[0]} stage '{STAGE[ORDER[min(v)[1]]]}' ({len(v)} cells)" for sw, v in sorted(by_sweep.items()))
     print(f"rep {rep}: two branches: {len(bad)} trace cells differ; {msg}; lanes with different final logits: {lanes_bad}", flush=True)

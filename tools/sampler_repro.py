@@ -32,13 +32,15 @@ class Company:
         cfg = lm.LMConfig(32064, 4096, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
         self.eng = lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=128, max_visual=32, kv_format="fp16", lib=lib)
         self.eng.load_synthetic(0, 0.02)
+        # (the timing hook records into events of the handle it is given: one handle per thread, over the same weights)
+        self.engs = [self.eng, lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=128, max_visual=32, kv_format="fp16", lib=lib, share_weights_with=self.eng)]
         self.lib, self.stop, self.threads, self.launches = lib, False, [], [0, 0]
         self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
     def _loop(self, i, which):
         ms, by = C.c_float(), C.c_double()
         while not self.stop:
-            rc = self.lib.dd_lm_time_gemv(self.eng._h, which, 72, 64, C.byref(ms), C.byref(by), self.streams[i].cuda_stream)
+            rc = self.lib.dd_lm_time_gemv(self.engs[i]._h, which, 72, 64, C.byref(ms), C.byref(by), self.streams[i].cuda_stream)
             assert rc == 0, self.lib.dd_last_error()
             self.launches[i] += 64 + 2
 
