@@ -307,7 +307,7 @@ def main() -> int:
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
     ap.add_argument("--images-per-gpu", type=int, default=None,
                     help="images decoded concurrently per GPU (lanes over one set of weights, 1..64); 1 = the reference's "
-                         "one-image-at-a-time loop; default 64 (config 5: 8)")
+                         "one-image-at-a-time loop; default 64 (config 5: 32, config 2: 56)")
     ap.add_argument("--no-batch-tower", action="store_true", help="one vision-tower call per image instead of one per 16 images (A/B)")
     ap.add_argument("--prefill-chunk", type=int, default=None, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (product switches)")
@@ -360,7 +360,7 @@ def main() -> int:
     ddcfg.settings["voting_numbers"] = list(probs)
     K_eff = 0 if args.original else len(probs)
     if args.images_per_gpu is None:
-        args.images_per_gpu = 8 if args.config == 5 else (56 if args.config == 2 else 64)      # K = 4: whole groups of fourteen
+        args.images_per_gpu = 32 if args.config == 5 else (56 if args.config == 2 else 64)     # K = 4: whole groups of fourteen
     if args.prefill_chunk is None:
         args.prefill_chunk = 2 if args.config == 5 else 16
     B = 1 if args.mode == "kshard" else max(1, min(64, args.images_per_gpu))

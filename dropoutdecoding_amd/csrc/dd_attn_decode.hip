@@ -81,6 +81,15 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     int ka = t0 + lane;
     if (ka >= span0 && ka < span0 + spanL) bits = bits_l[ka - span0];
   }
+  uint32_t dsum[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};       // debug checksums (a.dbg)
+  auto dacc = [&](int slot, float v, int salt) { dsum[slot] += __float_as_uint(v) * (uint32_t)(2 * salt + 1); };
+  if (a.dbg) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dacc(0, k4[i].x, i * 4), dacc(0, k4[i].y, i * 4 + 1), dacc(0, k4[i].z, i * 4 + 2), dacc(0, k4[i].w, i * 4 + 3);
+      dacc(1, v4[i].x, i * 4), dacc(1, v4[i].y, i * 4 + 1), dacc(1, v4[i].z, i * 4 + 2), dacc(1, v4[i].w, i * 4 + 3);
+    }
+  }
   // 2. q rows (r = g*NBT + m) into LDS
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     int r = i / HEAD_DIM, d = i % HEAD_DIM, g = g0 + r / NBT;
@@ -96,6 +105,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
+      if (a.dbg) dacc(2, q4.x + q4.y + q4.z + q4.w, r * 8 + i);
       sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
     }
     s_part[(wave * R + r) * ATT_SPLIT + lane] = sp;
@@ -107,11 +117,13 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     int m = ML == 1 ? 0 : mo + r % NBT;  // lanes: bit 0 of the sequence's own (leak) bits; groups: the member's bit
     float sv = (s_part[(0 * R + r) * ATT_SPLIT + lane] + s_part[(1 * R + r) * ATT_SPLIT + lane]) +
                (s_part[(2 * R + r) * ATT_SPLIT + lane] + s_part[(3 * R + r) * ATT_SPLIT + lane]);
+    if (a.dbg) dacc(3, sv, r);
     sv *= scaling;
     if (lane >= nkeys || ((bits >> (a.bit0 + m)) & 1u)) sv = -INFINITY;  // zero in the 2-D mask: weight exactly 0
     float mx = dd_wave_max(sv);
     float p = (sv == -INFINITY) ? 0.f : expf(sv - mx);
     float l = dd_wave_sum(p);
+    if (a.dbg) dacc(4, p, r);
     p_sh[lane * R + r] = p;
     if (lane == 0) {
       float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * 2;
@@ -129,7 +141,10 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     int key = wave * 16 + 2 * j + half;
     const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
+    for (int r = 0; r < R; ++r) {
+      if (a.dbg && dq == 0) dacc(5, pr[r], (wave * 8 + j) * R + r);
+      acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
+    }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -144,11 +159,21 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 6. fixed-order sum over the four waves
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     float o = (o_part[i] + o_part[R * HEAD_DIM + i]) + (o_part[2 * R * HEAD_DIM + i] + o_part[3 * R * HEAD_DIM + i]);
+    if (a.dbg) dacc(6, o, i);
     if (ML) {
       int r = i / HEAD_DIM, dd = i % HEAD_DIM;
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * HEAD_DIM + dd] = o;
     } else {
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
+    }
+  }
+  if (a.dbg) {
+    uint32_t* slot = a.dbg + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) << 3);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      uint32_t v = dsum[c];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) atomicAdd(slot + c, v);
     }
   }
 }

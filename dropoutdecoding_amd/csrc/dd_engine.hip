@@ -1259,6 +1259,8 @@ void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 // 8 / 9 the attention's per-tile statistics / outputs (the tiles every sequence of the sweep has), 10 new V rows)
 uint32_t* g_dbg_trace = nullptr;
 int g_dbg_trace_cap = 0, g_dbg_sweeps = 0;
+uint32_t* g_dbg_attn = nullptr;            // per-workgroup checksums of the fp32-cache attention tile pass: [sweep][layer][g_dbg_attn_stride]
+size_t g_dbg_attn_stride = 0;
 __global__ __launch_bounds__(256) void k_dbg_sum(const uint32_t* __restrict__ p, size_t n, uint32_t* __restrict__ out) {
   uint32_t acc = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += p[i] * (uint32_t)(2 * i + 1);
@@ -1320,6 +1322,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     t.qbuf = h->qbuf, t.T_cap = h->T_cap, t.nb = K, t.n_heads = h->H, t.n_kv = h->Hkv, t.bit0 = 0, t.kv16 = h->kv16;
     t.part_o = h->part_o, t.part_ml = h->part_ml, t.xop_out = h->xop_q;
     t.n_lanes = packed ? 8 : ng, t.lane_groups = packed ? 8 : ng, t.half_planes = packed ? 1 : 0;
+    if (g_dbg_attn && g_dbg_trace && dbg_sweep < g_dbg_trace_cap) t.dbg = g_dbg_attn + ((size_t)dbg_sweep * h->Lyr + l) * g_dbg_attn_stride;
     for (int g = 0; g < ng; ++g) {
       dd_lm* q = qs[g];
       float* kn = q->knew + (size_t)l * KV_ROWS * q->kv_dim;

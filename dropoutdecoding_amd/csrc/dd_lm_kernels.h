@@ -200,6 +200,8 @@ struct AttnDecodeArgs {
   const float* vnew_g[16];
   int half_planes;          // lane_groups == 8, K <= 4: plane g carries sequences 2 g (rows 0..3) and 2 g + 1 (rows 4..7); the lane_* arrays, knew_g
                             // and vnew_g are indexed by sequence (16), a member's drop bit is its index within its sequence
+  uint32_t* dbg;         // debug (fp32-cache kernel only; libdropdec_tools.so sets it): per-workgroup checksums of what the tile pass loaded and
+                         // exchanged through LDS: [wg][8] = K registers, V registers, q rows, scores read, p written, p read, outputs read, 0
   int max_T;             // host: largest prefix length among the lanes (grid sizing)
   int splits_stride, tiles_per_wg;   // set by the launchers of k_attn_partial16: tile stride of the partial buffers, key tiles per workgroup
   const float* lane_kc[16];

@@ -352,3 +352,44 @@ extern "C" int dd_tools_sweep_trace(uint32_t* trace_dev, int cap_sweeps) {
   g_dbg_trace = trace_dev, g_dbg_trace_cap = trace_dev ? cap_sweeps : 0, g_dbg_sweeps = 0;
   return DD_OK;
 }
+
+// Per-workgroup checksums inside the fp32-cache attention tile pass (k_attn_partial) of the traced sweeps: attn_dev [cap_sweeps][n_layers][stride_words],
+// workgroup (x, y, z) of a launch at ((z * grid.y + y) * grid.x + x) * 8: K registers, V registers, q rows read from LDS, scores read, p written,
+// p read, outputs read, 0.  Use together with dd_tools_sweep_trace (same sweep numbering); NULL: off.
+extern uint32_t* g_dbg_attn;
+extern size_t g_dbg_attn_stride;
+extern "C" int dd_tools_attn_trace(uint32_t* attn_dev, size_t stride_words) {
+  g_dbg_attn = attn_dev, g_dbg_attn_stride = attn_dev ? stride_words : 0;
+  return DD_OK;
+}
+
+// LDS / barrier isolation probe: the exchange pattern of the fp32-cache attention tile pass (256 threads, 30,720 bytes of dynamic LDS: every
+// wave writes two of eight rows of a [64][8] table, barrier, every thread reads whole rows written by the other waves) with values that
+// are a function of (workgroup, round, position), verified in place for `rounds` rounds.  errors_dev[0] += mismatching words.
+__global__ __launch_bounds__(256) void k_lds_barrier_probe(int rounds, uint32_t salt, unsigned int* errors) {
+  extern __shared__ __align__(16) uint32_t pl[];        // 7680 words; the table sits where p_sh sits in the attention kernel
+  uint32_t* tab = pl + 3072;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wg = (blockIdx.x * 2654435761u) ^ salt;
+  unsigned int bad = 0;
+  for (int rd = 0; rd < rounds; ++rd) {
+    for (int r = wave; r < 8; r += 4) tab[lane * 8 + r] = wg + (uint32_t)(rd * 7919 + (lane * 8 + r) * 31);
+    __syncthreads();
+    for (int j = 0; j < 8; ++j) {
+      const int key = (wave * 16 + 2 * j + (lane >> 5)) & 63;
+      for (int r = 0; r < 8; ++r) bad += tab[key * 8 + r] != wg + (uint32_t)(rd * 7919 + (key * 8 + r) * 31) ? 1u : 0u;
+    }
+    __syncthreads();
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+extern "C" int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* errors_dev, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(launches >= 1 && wgs >= 1 && rounds >= 1 && errors_dev, "dd_tools_lds_barrier_probe: bad arguments");
+  static uint32_t salt = 11;
+  for (int i = 0; i < launches; ++i) {
+    k_lds_barrier_probe<<<wgs, 256, 30720, st>>>(rounds, salt++, errors_dev);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}

@@ -66,7 +66,13 @@ int dd_tools_lds_poison(int launches, int wgs, int lds_bytes, void* stream);
 /* Per-stage checksums of every multi-group sweep enqueued from now on (eager launches): trace_dev [cap_sweeps][n_layers][8] uint32, zeroed by the
  * caller; stage 0 embed, 1 q rows, 2 new K rows, 3 attention output, 4 o_proj, 5 gate/up, 6 down (rows), 7 down (next operand).  NULL: off. */
 int dd_tools_sweep_trace(uint32_t* trace_dev, int cap_sweeps);
+/* With dd_tools_sweep_trace: per-workgroup checksums inside the fp32-cache attention tile pass, attn_dev [cap_sweeps][n_layers][stride_words]
+ * (8 words per workgroup: K registers, V registers, q rows read from LDS, scores read, p written, p read, outputs read, 0).  NULL: off. */
+int dd_tools_attn_trace(uint32_t* attn_dev, size_t stride_words);
 int dd_tools_scratch_probe(int launches, int wgs, int spin, unsigned int* errors_dev, void* stream);
+/* The LDS exchange pattern of the fp32-cache attention tile pass (256 threads, 30,720 bytes of dynamic LDS, rows written by one wave and read by
+ * the others across a barrier) with verifiable values: errors_dev[0] += mismatching words. */
+int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* errors_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,12 @@ STAGE = ["embed", "q rows (qkv GEMV + finish)", "new K rows (qkv GEMV + finish)"
          "attention tiles: outputs (partial kernel)", "new V rows"] + ["-"] * 5
 ORDER = [0, 1, 2, 10, 8, 9, 3, 4, 5, 6, 7]          # pipeline order of the stages within a layer
 trace = torch.zeros(CAP, 32, 16, dtype=torch.int32, device="cuda")
+ATTN_WGS = 32 * 12 * 8                     # workgroups of the widest attention tile pass (kv heads x key tiles x groups)
+ATTN = os.environ.get("DD_BISECT_ATTN", "1") not in ("", "0") and KV == "fp32"
+CAP_A = 2 * STEPS
+attn = torch.zeros(CAP_A, 32, ATTN_WGS * 8, dtype=torch.int32, device="cuda") if ATTN else None
+SLOT = ["K registers (global loads)", "V registers (global loads)", "q rows read from LDS", "scores read from LDS", "p written", "p read from LDS",
+        "outputs read from LDS", "-"]
 
 
 def run(branches):
@@ -46,23 +52,30 @@ def run(branches):
         e.prefill(x, s0, Lv)
     torch.cuda.synchronize()
     trace.zero_()
+    if ATTN:
+        attn.zero_()
     torch.cuda.synchronize()
-    L.dd_tools_sweep_trace(trace.data_ptr(), CAP)
+    L.dd_tools_sweep_trace(trace.data_ptr(), CAP if not ATTN else CAP_A)
+    if ATTN:
+        L.dd_tools_attn_trace(attn.data_ptr(), ATTN_WGS * 8)
     grp = lm.EngineGroup(engs)
     for s in range(STEPS):
         grp.decode_step(probs)
     torch.cuda.synchronize()
     L.dd_tools_sweep_trace(None, 0)
-    return trace.cpu().numpy().copy(), [e.tokens() for e in engs], [e.logits().copy() for e in engs]
+    L.dd_tools_attn_trace(None, 0)
+    return trace.cpu().numpy().copy(), [e.tokens() for e in engs], [e.logits().copy() for e in engs], (attn.cpu().numpy().copy() if ATTN else None)
 
 
-ref, rtoks, rlog = run(1)
-ref2, _, _ = run(1)
+ref, rtoks, rlog, ra = run(1)
+ref2, _, _, ra2 = run(1)
+if ATTN:
+    print('one branch twice: attention traces', 'equal' if np.array_equal(ra, ra2) else 'DIFFER (!)')
 print("one branch twice: traces", "equal" if np.array_equal(ref, ref2) else "DIFFER (!)")
 n_sweeps = int((ref.reshape(CAP, -1) != 0).any(1).sum())
 print(f"{n_sweeps} multi-group sweeps traced over {STEPS} steps")
 for rep in range(4):
-    got, toks, logs = run(2)
+    got, toks, logs, ga = run(2)
     bad = np.argwhere(got != ref)
     lanes_bad = [i for i in range(len(engs)) if not np.array_equal(logs[i], rlog[i])]
     if len(bad) == 0:
@@ -73,3 +86,13 @@ for rep in range(4):
         by_sweep.setdefault(int(sw), []).append((int(ly), ORDER.index(int(stg))))
     msg = "; ".join(f"sweep {sw}: first at layer {min(v)[0]} stage '{STAGE[ORDER[min(v)[1]]]}' ({len(v)} cells)" for sw, v in sorted(by_sweep.items()))
     print(f"rep {rep}: two branches: {len(bad)} trace cells differ; {msg}; lanes with different final logits: {lanes_bad}", flush=True)
+    if ATTN:
+        # inside the tile pass of each sweep's FIRST differing layer: which of the workgroup's checksums differ
+        for sw, v in sorted(by_sweep.items()):
+            ly = min(v)[0]
+            a1, a2 = ra[sw, ly].reshape(-1, 8), ga[sw, ly].reshape(-1, 8)
+            wg_bad = np.argwhere((a1 != a2).any(1)).flatten()
+            slots = sorted({int(c) for w in wg_bad for c in np.argwhere(a1[w] != a2[w]).flatten()})
+            wgs = [(int(w) % 32, (int(w) // 32) % 12, int(w) // (32 * 12)) for w in wg_bad[:6]]
+            print(f"      sweep {sw} layer {ly}: {len(wg_bad)} of {int((a1 != 0).any(1).sum())} tile workgroups differ; checksums that differ: {[SLOT[c] for c in slots]}; "
+                  f"first (kv head, tile, group): {wgs}", flush=True)

@@ -35,12 +35,13 @@ class Company:
         # (the timing hook records into events of the handle it is given: one handle per thread, over the same weights)
         self.engs = [self.eng, lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=128, max_visual=32, kv_format="fp16", lib=lib, share_weights_with=self.eng)]
         self.lib, self.stop, self.threads, self.launches = lib, False, [], [0, 0]
+        self.rows = 72
         self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
     def _loop(self, i, which):
         ms, by = C.c_float(), C.c_double()
         while not self.stop:
-            rc = self.lib.dd_lm_time_gemv(self.engs[i]._h, which, 72, 64, C.byref(ms), C.byref(by), self.streams[i].cuda_stream)
+            rc = self.lib.dd_lm_time_gemv(self.engs[i]._h, which, self.rows, 64, C.byref(ms), C.byref(by), self.streams[i].cuda_stream)
             assert rc == 0, self.lib.dd_last_error()
             self.launches[i] += 64 + 2
 
@@ -158,6 +159,33 @@ def probe(beside: bool, rounds: int, lib=None, wgs: int = 8, spin: int = 200) ->
             "company_gemv_launches": company, "mismatching_words": int(err[0].item()), "seconds": round(time.time() - t0, 1)}
 
 
+def lds_probe(beside: bool, rounds: int, lib=None, wgs: int = 3072, which=(2, 0), rows: int = 64) -> dict:
+    """The fp32-cache attention tile pass's LDS exchange pattern (dd_tools_lds_barrier_probe) alone / beside slice GEMVs of `rows` rows."""
+    lib = lib or _lib.load_tools()
+    err = torch.zeros(4, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+
+    def body():
+        for r in range(rounds):
+            rc = lib.dd_tools_lds_barrier_probe(16, wgs, 4, err.data_ptr(), st.cuda_stream)
+            assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+
+    if beside:
+        co = Company(lib)
+        co.rows = rows
+        with co:
+            body()
+            company = sum(co.launches)
+    else:
+        body()
+        company = 0
+    return {"test": "lds_barrier_probe", "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16, "workgroups_per_launch": wgs,
+            "company_gemv_launches": company, "mismatching_words": int(err[0].item()), "seconds": round(time.time() - t0, 1)}
+
+
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     torch.cuda.set_device(0)
@@ -172,6 +200,9 @@ if __name__ == "__main__":
         for wgs in (8, 256):
             out.append(probe(beside, rounds, lib, wgs=wgs))
             print(json.dumps(out[-1]), flush=True)
+    for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16)):
+        out.append(lds_probe(beside, rounds, lib, rows=rows or 64))
+        print(json.dumps(out[-1]), flush=True)
     if os.environ.get("DD_REPRO_LOG"):
         with open(os.environ["DD_REPRO_LOG"], "w") as f:
             json.dump(out, f, indent=1)
