@@ -393,3 +393,50 @@ extern "C" int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, uns
   }
   return DD_OK;
 }
+
+// LDS overlap probe: does a workgroup's dynamic LDS stay its own beside workgroups of ANOTHER dispatch with a different LDS size on the same CU?
+// `k_lds_hold` fills all of its dynamic LDS with a pattern that is a function of (workgroup, salt, word), holds it for `hold` rounds of
+// s_sleep + barrier, and verifies every word.  dd_tools_lds_overlap_probe runs a grid of 512-thread workgroups with lds_a bytes (A: the
+// size of a slice-resident GEMV's operand planes) on one stream and, concurrently, `launches_b` grids of 256-thread workgroups with lds_b
+// bytes (B: the fp32-cache attention tile pass's size) on another; errors_dev[0] / [1] += mismatching words seen by A / B workgroups,
+// errors_dev[2] / [3] = lowest / highest mismatching word offset seen by B (atomicMin / atomicMax).
+__global__ void k_lds_hold(int words, int hold, uint32_t salt, unsigned int* errors, int who) {
+  extern __shared__ __align__(16) uint32_t pl[];
+  const uint32_t me = (blockIdx.x * 2654435761u) ^ (salt * 40503u);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) pl[i] = me + (uint32_t)i * 2246822519u;
+  __syncthreads();
+  for (int h = 0; h < hold; ++h) {
+    __builtin_amdgcn_s_sleep(64);
+    __syncthreads();
+  }
+  unsigned int bad = 0, lo = 0xFFFFFFFFu, hi = 0;
+  for (int i = threadIdx.x; i < words; i += blockDim.x)
+    if (pl[i] != me + (uint32_t)i * 2246822519u) {
+      ++bad;
+      lo = (unsigned)i < lo ? (unsigned)i : lo, hi = (unsigned)i > hi ? (unsigned)i : hi;
+    }
+  if (bad) {
+    atomicAdd(errors + who, bad);
+    if (who == 1) atomicMin(errors + 2, lo), atomicMax(errors + 3, hi);
+  }
+}
+extern "C" int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,
+                                          void* stream_a, void* stream_b) {
+  DD_REQUIRE(lds_a >= 0 && lds_a <= 160 * 1024 && lds_b >= 4 && lds_b <= 160 * 1024 && errors_dev && wgs_b >= 1 && launches_b >= 1, "dd_tools_lds_overlap_probe: bad arguments");
+  static int attr_bytes = 0;
+  const int mx = lds_a > lds_b ? lds_a : lds_b;
+  if (mx > attr_bytes) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_lds_hold, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+    attr_bytes = mx;
+  }
+  static uint32_t salt = 3;
+  if (lds_a > 0 && wgs_a > 0) {
+    k_lds_hold<<<wgs_a, 512, lds_a, (hipStream_t)stream_a>>>(lds_a / 4, hold_a, salt++, errors_dev, 0);
+    DD_CHECK_LAUNCH();
+  }
+  for (int i = 0; i < launches_b; ++i) {
+    k_lds_hold<<<wgs_b, 256, lds_b, (hipStream_t)stream_b>>>(lds_b / 4, hold_b, salt++, errors_dev, 1);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}

@@ -73,6 +73,11 @@ int dd_tools_scratch_probe(int launches, int wgs, int spin, unsigned int* errors
 /* The LDS exchange pattern of the fp32-cache attention tile pass (256 threads, 30,720 bytes of dynamic LDS, rows written by one wave and read by
  * the others across a barrier) with verifiable values: errors_dev[0] += mismatching words. */
 int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* errors_dev, void* stream);
+/* LDS overlap probe: a grid of 512-thread workgroups holding a verifiable pattern in lds_a bytes of dynamic LDS on stream_a while launches_b grids
+ * of 256-thread workgroups do the same with lds_b bytes on stream_b; errors_dev[0] / [1] += corrupted words seen by A / B workgroups, [2] / [3] = lowest /
+ * highest corrupted word offset in a B workgroup (initialise to 0xFFFFFFFF / 0). */
+int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,
+                               void* stream_a, void* stream_b);
 
 #ifdef __cplusplus
 }
