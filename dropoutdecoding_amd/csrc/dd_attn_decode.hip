@@ -26,7 +26,7 @@
 // that sequence's cache and drop bits; results go to an (8 * a.lane_groups)-rows-per-head layout (row = 8 * group + member).
 // (fp32 cache; the fp16 cache goes through k_attn_partial16 below)
 int g_attn32_lds_pad = 0;      // dd_tools_set_tuning key 39 (debug): bytes added to the fp32 attention kernel's dynamic LDS request
-template <int NBT, int G, int GH, int ML = 0>
+template <int NBT, int G, int GH, int ML = 0, int DBG = 0>      // DBG: per-workgroup checksums into a.dbg (libdropdec_tools.so's race bisect; more registers)
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   constexpr int R = NBT * GH;        // rows of this workgroup
   const int lane_rows = a.n_lanes > 8 ? 16 : 8;   // ML == 1: rows per q head in the buffers (what the combine is built for)
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   }
   uint32_t dsum[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};       // debug checksums (a.dbg)
   auto dacc = [&](int slot, float v, int salt) { dsum[slot] += __float_as_uint(v) * (uint32_t)(2 * salt + 1); };
-  if (a.dbg) {
+  if constexpr (DBG) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       dacc(0, k4[i].x, i * 4), dacc(0, k4[i].y, i * 4 + 1), dacc(0, k4[i].z, i * 4 + 2), dacc(0, k4[i].w, i * 4 + 3);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
-      if (a.dbg) dacc(2, q4.x + q4.y + q4.z + q4.w, r * 8 + i);
+      if constexpr (DBG) dacc(2, q4.x + q4.y + q4.z + q4.w, r * 8 + i);
       sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
     }
     s_part[(wave * R + r) * ATT_SPLIT + lane] = sp;
@@ -117,13 +117,13 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     int m = ML == 1 ? 0 : mo + r % NBT;  // lanes: bit 0 of the sequence's own (leak) bits; groups: the member's bit
     float sv = (s_part[(0 * R + r) * ATT_SPLIT + lane] + s_part[(1 * R + r) * ATT_SPLIT + lane]) +
                (s_part[(2 * R + r) * ATT_SPLIT + lane] + s_part[(3 * R + r) * ATT_SPLIT + lane]);
-    if (a.dbg) dacc(3, sv, r);
+    if constexpr (DBG) dacc(3, sv, r);
     sv *= scaling;
     if (lane >= nkeys || ((bits >> (a.bit0 + m)) & 1u)) sv = -INFINITY;  // zero in the 2-D mask: weight exactly 0
     float mx = dd_wave_max(sv);
     float p = (sv == -INFINITY) ? 0.f : expf(sv - mx);
     float l = dd_wave_sum(p);
-    if (a.dbg) dacc(4, p, r);
+    if constexpr (DBG) dacc(4, p, r);
     p_sh[lane * R + r] = p;
     if (lane == 0) {
       float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * 2;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (a.dbg && dq == 0) dacc(5, pr[r], (wave * 8 + j) * R + r);
+      if (DBG && dq == 0) dacc(5, pr[r], (wave * 8 + j) * R + r);
       acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
     }
   }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   // 6. fixed-order sum over the four waves
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     float o = (o_part[i] + o_part[R * HEAD_DIM + i]) + (o_part[2 * R * HEAD_DIM + i] + o_part[3 * R * HEAD_DIM + i]);
-    if (a.dbg) dacc(6, o, i);
+    if constexpr (DBG) dacc(6, o, i);
     if (ML) {
       int r = i / HEAD_DIM, dd = i % HEAD_DIM;
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * HEAD_DIM + dd] = o;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
     }
   }
-  if (a.dbg) {
+  if (DBG && a.dbg) {
     uint32_t* slot = a.dbg + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) << 3);
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
@@ -616,7 +616,15 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
       k_attn_partial16<NBT, G, GH, 2><<<dim3(a.n_kv, (splits + b.tiles_per_wg - 1) / b.tiles_per_wg, NG * (G / GH) * (8 / NBT)), 256, 0, st>>>(b);
     }
   } else {
-    if (g_attn32_lds_pad > 0) {
+    bool traced = false;
+    if constexpr (G == 1 && NBT == 8) {              // (the traced instantiation exists for the MHA shape the race bisect runs)
+      if (a.dbg) {
+        k_attn_partial<NBT, G, GH, 2, 1><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
+        traced = true;
+      }
+    }
+    if (traced) {
+    } else if (g_attn32_lds_pad > 0) {
       DD_HIP(hipFuncSetAttribute((const void*)k_attn_partial<NBT, G, GH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem + g_attn32_lds_pad)));
       k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem + g_attn32_lds_pad, st>>>(a);
     } else

@@ -1245,6 +1245,10 @@ void dd_engine_set_pairs(int on) { g_pair_sweeps = on; }
 static int g_branches = 2;     // dd_tools_set_tuning key 23: member sweeps of a group step that run concurrently (1..4)
 static int g_fp32_fork = 0;    // dd_tools_set_tuning key 37: branches for fp32-cache engines too (round 3 saw lanes differ from their solo runs there)
 void dd_engine_set_fp32_fork(int on) { g_fp32_fork = on; }
+// dd_tools_set_tuning key 40 (debug; set before the first group step of a handle): the two branches of a classic group step on streams with DISJOINT
+// CU masks (branch 0 on a masked stream of its own instead of the caller's): concurrent, but never two branches' workgroups on one CU
+static int g_mask_branches = 0;
+void dd_engine_set_mask_branches(int on) { g_mask_branches = on; }
 void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }
 // the same for the rider form (rings of at least two groups each): 64 lanes 42.5 / 38.2 / 36.9 ms per step with 2 / 3 / 4 branches
 // (tools/rider_ab.py), where the classic form gained nothing beyond two; dd_tools_set_tuning key 28
@@ -1819,9 +1823,11 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   // (fp16-cache engines only: with the fp32 cache's VALU attention kernels running beside another sweep, lanes did not always
   // reproduce their solo runs bit for bit — cause not found; tools/lanes_mixed_ab.py shows it — so those keep one branch)
   const bool fork = nbr >= 2 && (h0->kv16 || g_fp32_fork) && h0->side[nbr - 2] != nullptr;
+  const bool masked0 = fork && g_mask_branches && nbr == 2 && h0->side[2];     // (debug) branch 0 on a CU-masked stream of its own
   if (fork) {
     DD_HIP(hipEventRecord(h0->ev_fork, st));
     for (int i = 0; i + 1 < nbr; ++i) DD_HIP(hipStreamWaitEvent(h0->side[i], h0->ev_fork, 0));
+    if (masked0) DD_HIP(hipStreamWaitEvent(h0->side[2], h0->ev_fork, 0));
   }
   int i_multi = 0;
   for (int m = 0; m < n; ++m) {
@@ -1831,7 +1837,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
       if (ng > 1) {
         const int br = fork ? i_multi % nbr : 0;               // branch 0 = the caller's stream on the leader's scratch
         dd_lm* scratch = br ? lanes[m] : h0;
-        hipStream_t bs = br ? h0->side[br - 1] : st;
+        hipStream_t bs = br ? h0->side[br - 1] : (masked0 ? h0->side[2] : st);
         if (ng == 16) {
           RC(lm_sweep_groups(scratch, lanes + m, 16, K, bs, nullptr, 0, true));
           RC(group_finish(scratch, lanes + m, 8, K, bs, 0));
@@ -1859,6 +1865,10 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
       DD_HIP(hipEventRecord(h0->ev_join[i], h0->side[i]));
       DD_HIP(hipStreamWaitEvent(st, h0->ev_join[i], 0));
     }
+  if (masked0) {
+    DD_HIP(hipEventRecord(h0->ev_join[2], h0->side[2]));
+    DD_HIP(hipStreamWaitEvent(st, h0->ev_join[2], 0));
+  }
   return DD_OK;
 }
 
@@ -2242,7 +2252,13 @@ static int group_side_stream(dd_lm* h0) {
   if (!h0->ev_fork) DD_HIP(hipEventCreateWithFlags(&h0->ev_fork, hipEventDisableTiming));
   for (int i = 0; i + 1 < want; ++i)
     if (!h0->side[i]) {
-      DD_HIP(hipStreamCreateWithFlags(&h0->side[i], hipStreamNonBlocking));
+      if (g_mask_branches) {
+        uint32_t mask[8];                                   // 256 CUs: side[0] the upper 128 mask bits, the others the lower 128
+        for (int w = 0; w < 8; ++w) mask[w] = ((i == 0) == (w >= 4)) ? 0xFFFFFFFFu : 0u;
+        DD_HIP(hipExtStreamCreateWithCUMask(&h0->side[i], 8, mask));
+      } else {
+        DD_HIP(hipStreamCreateWithFlags(&h0->side[i], hipStreamNonBlocking));
+      }
       DD_HIP(hipEventCreateWithFlags(&h0->ev_join[i], hipEventDisableTiming));
     }
   return DD_OK;
