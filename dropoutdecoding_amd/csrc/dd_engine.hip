@@ -1249,6 +1249,33 @@ void dd_engine_set_fp32_fork(int on) { g_fp32_fork = on; }
 // CU masks (branch 0 on a masked stream of its own instead of the caller's): concurrent, but never two branches' workgroups on one CU
 static int g_mask_branches = 0;
 void dd_engine_set_mask_branches(int on) { g_mask_branches = on; }
+// dd_tools_set_tuning key 41 (debug): the attention launches of a multi-group sweep on a CU-masked stream of the sweeping handle's own (fenced by
+// events against the sweep's stream) — 1: the first handle that asks gets the lower 128 CUs, the second the upper 128 (the two branches' attentions
+// never share a CU with EACH OTHER, but each still meets the other branch's GEMVs); 2: both on the lower 128
+static int g_attn_masked = 0;
+void dd_engine_set_attn_masked(int mode) { g_attn_masked = mode; }
+struct AttnSide {
+  hipStream_t st = nullptr;
+  hipEvent_t e_in = nullptr, e_out = nullptr;
+};
+static std::vector<std::pair<dd_lm*, AttnSide>> g_attn_sides;
+static int attn_side_for(dd_lm* h, AttnSide** out) {
+  for (auto& p : g_attn_sides)
+    if (p.first == h) {
+      *out = &p.second;
+      return DD_OK;
+    }
+  AttnSide a;
+  uint32_t mask[8];
+  const bool upper = g_attn_masked == 1 && (g_attn_sides.size() & 1);
+  for (int w = 0; w < 8; ++w) mask[w] = (upper == (w >= 4)) ? 0xFFFFFFFFu : 0u;
+  DD_HIP(hipExtStreamCreateWithCUMask(&a.st, 8, mask));
+  DD_HIP(hipEventCreateWithFlags(&a.e_in, hipEventDisableTiming));
+  DD_HIP(hipEventCreateWithFlags(&a.e_out, hipEventDisableTiming));
+  g_attn_sides.push_back({h, a});
+  *out = &g_attn_sides.back().second;
+  return DD_OK;
+}
 void dd_engine_set_branches(int n) { g_branches = n < 1 ? 1 : (n > 4 ? 4 : n); }
 // the same for the rider form (rings of at least two groups each): 64 lanes 42.5 / 38.2 / 36.9 ms per step with 2 / 3 / 4 branches
 // (tools/rider_ab.py), where the classic form gained nothing beyond two; dd_tools_set_tuning key 28
@@ -1370,6 +1397,14 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
         RC(ddk_attn_decode(t, st));
         RC(ddk_attn_decode(u, st));
       }
+    } else if (g_attn_masked) {
+      AttnSide* as = nullptr;
+      RC(attn_side_for(h, &as));
+      DD_HIP(hipEventRecord(as->e_in, st));
+      DD_HIP(hipStreamWaitEvent(as->st, as->e_in, 0));
+      RC(ddk_attn_decode(t, as->st));
+      DD_HIP(hipEventRecord(as->e_out, as->st));
+      DD_HIP(hipStreamWaitEvent(st, as->e_out, 0));
     } else {
       RC(ddk_attn_decode(t, st));
     }
