@@ -1258,6 +1258,39 @@ struct AttnSide {
   hipStream_t st = nullptr;
   hipEvent_t e_in = nullptr, e_out = nullptr;
 };
+// dd_tools_set_tuning key 42 (debug, with key 40 = 1: branches on disjoint CU halves): bit mask of kernel families of a multi-group sweep that run
+// on an UNMASKED stream instead (the whole chip: their workgroups may then share a CU with the other branch's kernels) — 1 qkv GEMV, 2 o_proj,
+// 4 gate/up, 8 down, 16 lm_head, 32 embed, 64 the finishing launches (argmax, vote, commit, step end), 128 attention
+static int g_unmask = 0;
+void dd_engine_set_unmask(int m) { g_unmask = m; }
+static std::vector<std::pair<dd_lm*, AttnSide>> g_full_sides;
+static int full_side_for(dd_lm* h, AttnSide** out) {
+  for (auto& p : g_full_sides)
+    if (p.first == h) {
+      *out = &p.second;
+      return DD_OK;
+    }
+  AttnSide a;
+  DD_HIP(hipStreamCreateWithFlags(&a.st, hipStreamNonBlocking));
+  DD_HIP(hipEventCreateWithFlags(&a.e_in, hipEventDisableTiming));
+  DD_HIP(hipEventCreateWithFlags(&a.e_out, hipEventDisableTiming));
+  g_full_sides.push_back({h, a});
+  *out = &g_full_sides.back().second;
+  return DD_OK;
+}
+// run `body(stream)` on the handle's unmasked stream when family `bit` is selected (fenced against `st`), else on `st`
+template <typename F>
+static int on_family(dd_lm* h, hipStream_t st, int bit, F&& body) {
+  if (!(g_unmask & bit)) return body(st);
+  AttnSide* fs = nullptr;
+  RC(full_side_for(h, &fs));
+  DD_HIP(hipEventRecord(fs->e_in, st));
+  DD_HIP(hipStreamWaitEvent(fs->st, fs->e_in, 0));
+  RC(body(fs->st));
+  DD_HIP(hipEventRecord(fs->e_out, fs->st));
+  DD_HIP(hipStreamWaitEvent(st, fs->e_out, 0));
+  return DD_OK;
+}
 static std::vector<std::pair<dd_lm*, AttnSide>> g_attn_sides;
 static int attn_side_for(dd_lm* h, AttnSide** out) {
   for (auto& p : g_attn_sides)
@@ -1333,7 +1366,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
   for (int g = 0; g < ng; ++g)
     for (int m = 0; m < K; ++m) el.state[row0(g) + m] = qs[g]->state;
   for (int m = 0; m < n_rider; ++m) el.state[ride_row0 + m] = rider[m]->state;
-  RC(ddk_embed_rows_lanes(h->embed, d, el, 8 * planes, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, st, h->wf));
+  RC(on_family(h, st, 32, [&](hipStream_t s2) { return ddk_embed_rows_lanes(h->embed, d, el, 8 * planes, h->xa, h->lw[0].norm1, h->xop_d, h->ssq_a, d / 16, s2, h->wf); }));
   const int dbg_sweep = g_dbg_trace ? g_dbg_sweeps++ : 0;
   dbg_sum(dbg_sweep, h->Lyr, 0, 0, h->xop_d, (size_t)planes * h->S_d * 1024, st);
   int ssq_n = 1;
@@ -1373,7 +1406,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
       if (n_rider > 8) a.knew_g[ride_slot0 + 1] = rk + (size_t)8 * h->kv_dim, a.vnew_g[ride_slot0 + 1] = rv + (size_t)8 * h->kv_dim;
       for (int m = 0; m < n_rider; ++m) a.state_rows[ride_row0 + m] = rider[m]->state;
     }
-    RC(ddk_gemv_groups(EPI_QKV, a, st));
+    RC(on_family(h, st, 1, [&](hipStream_t s2) { return ddk_gemv_groups(EPI_QKV, a, s2); }));
     dbg_sum(dbg_sweep, h->Lyr, l, 1, h->qbuf, (size_t)8 * planes * h->q_dim * 4, st);
     for (int g = 0; g < ng && g_dbg_trace; ++g) dbg_sum(dbg_sweep, h->Lyr, l, 2, a.knew_g[g], (size_t)rows_g * h->kv_dim * 4, st);
     if (n_rider) {
@@ -1406,7 +1439,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
       DD_HIP(hipEventRecord(as->e_out, as->st));
       DD_HIP(hipStreamWaitEvent(st, as->e_out, 0));
     } else {
-      RC(ddk_attn_decode(t, st));
+      RC(on_family(h, st, 128, [&](hipStream_t s2) { return ddk_attn_decode(t, s2); }));
     }
     if (g_dbg_trace && dbg_sweep < g_dbg_trace_cap && !n_rider) {
       int minT = 1 << 30;
@@ -1424,7 +1457,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.fp8 = h->fp8, a.wscale = w.s_o;
     a.out = h->xa, a.ldo = d, a.normw_next = w.norm2, a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_b, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
-    RC(ddk_gemv_groups(EPI_RESID, a, st));
+    RC(on_family(h, st, 2, [&](hipStream_t s2) { return ddk_gemv_groups(EPI_RESID, a, s2); }));
     dbg_sum(dbg_sweep, h->Lyr, l, 4, h->xa, (size_t)8 * planes * d * 4, st);
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
@@ -1433,7 +1466,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.ssq_in = h->ssq_b, a.ssq_n = d / 16, a.ssq_ld = d / 16, a.inv_k = 1.0f / d, a.eps = h->cfg.rms_eps;
     a.xop_next = h->xop_ff, a.S_next = h->S_ff;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
-    RC(ddk_gemv_groups(EPI_SILU, a, st));
+    RC(on_family(h, st, 4, [&](hipStream_t s2) { return ddk_gemv_groups(EPI_SILU, a, s2); }));
     dbg_sum(dbg_sweep, h->Lyr, l, 5, h->xop_ff, (size_t)planes * h->S_ff * 1024, st);
     memset(&a, 0, sizeof(a));
     a.wf = h->wf;
@@ -1442,7 +1475,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     a.out = h->xa, a.ldo = d, a.normw_next = (l + 1 < h->Lyr) ? h->lw[l + 1].norm1 : h->final_norm;
     a.xop_next = h->xop_d, a.S_next = h->S_d, a.ssq_out = h->ssq_a, a.ssq_ld = d / 16;
     a.part = h->gemv_part, a.part_floats = h->gemv_part_floats;
-    RC(ddk_gemv_groups(EPI_RESID, a, st));
+    RC(on_family(h, st, 8, [&](hipStream_t s2) { return ddk_gemv_groups(EPI_RESID, a, s2); }));
     dbg_sum(dbg_sweep, h->Lyr, l, 6, h->xa, (size_t)8 * planes * d * 4, st);
     dbg_sum(dbg_sweep, h->Lyr, l, 7, h->xop_d, (size_t)planes * h->S_d * 1024, st);
     ssq_n = d / 16;
@@ -1464,7 +1497,7 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
     if (n_rider > 8) a.out_g[ride_slot0 + 1] = h->grp_logits + (size_t)8 * h->Vpad;
     for (int m = 0; m < n_rider; ++m) a.state_rows[ride_row0 + m] = rider[m]->state;
   }
-  RC(ddk_gemv_groups(EPI_STORE, a, st));
+  RC(on_family(h, st, 16, [&](hipStream_t s2) { return ddk_gemv_groups(EPI_STORE, a, s2); }));
   return DD_OK;
 }
 
