@@ -446,3 +446,80 @@ extern "C" int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int 
   }
   return DD_OK;
 }
+
+// Register / load probes for the co-residency question (tools/sampler_repro.py): VALU-only 256-thread workgroups shaped like the fp32-cache attention
+// tile pass (about 120 VGPRs, 30,720 bytes of dynamic LDS so that they fit beside a slice-resident GEMV workgroup on a CU).
+//   k_vgpr_hold:  56 registers per lane hold a pattern across `hold` rounds of s_sleep + barrier, then are verified.
+//   k_gload_hold: 16 outstanding 16-byte global loads per lane from a buffer whose contents are a function of the address, requested up front
+//                 (as the tile pass requests its K / V rows), consumed after `hold` rounds; verified against the function.
+// errors_dev[0] += mismatching words.
+__global__ __launch_bounds__(256) void k_vgpr_hold(int hold, uint32_t salt, unsigned int* errors) {
+  extern __shared__ __align__(16) uint32_t pl[];
+  uint32_t r[56];
+  const uint32_t me = ((blockIdx.x * 256u + threadIdx.x) * 2654435761u) ^ salt;
+#pragma unroll
+  for (int i = 0; i < 56; ++i) {
+    r[i] = me + (uint32_t)i * 40503u;
+    asm volatile("" : "+v"(r[i]));
+  }
+  pl[threadIdx.x] = me;
+  for (int h = 0; h < hold; ++h) {
+    __builtin_amdgcn_s_sleep(32);
+    __syncthreads();
+  }
+  unsigned int bad = pl[threadIdx.x] != me ? 1u : 0u;
+#pragma unroll
+  for (int i = 0; i < 56; ++i) {
+    asm volatile("" : "+v"(r[i]));
+    bad += r[i] != me + (uint32_t)i * 40503u ? 1u : 0u;
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+__global__ __launch_bounds__(256) void k_gload_hold(const u32x4_t* __restrict__ buf, size_t n16, int hold, uint32_t salt, unsigned int* errors) {
+  extern __shared__ __align__(16) uint32_t pl[];
+  u32x4_t v[16];
+  size_t idx[16];
+  const size_t base = ((size_t)(blockIdx.x * 256u + threadIdx.x) * 2654435761u + salt) % n16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    idx[i] = (base + (size_t)i * 8191u * 64u) % n16;      // strided like rows of a cache
+    v[i] = buf[idx[i]];
+  }
+  pl[threadIdx.x] = salt;
+  for (int h = 0; h < hold; ++h) {
+    __builtin_amdgcn_s_sleep(16);
+    __syncthreads();
+  }
+  unsigned int bad = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t w = (uint32_t)(idx[i] * 4u) * 2246822519u;
+    bad += (v[i].x != w) + (v[i].y != w + 1u) + (v[i].z != w + 2u) + (v[i].w != w + 3u);
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+__global__ void k_gload_fill(u32x4_t* buf, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint32_t w = (uint32_t)(i * 4u) * 2246822519u;
+    buf[i] = (u32x4_t){w, w + 1u, w + 2u, w + 3u};
+  }
+}
+extern "C" int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int* errors_dev, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE((kind == 0 || kind == 1) && launches >= 1 && wgs >= 1 && hold >= 0 && errors_dev, "dd_tools_hold_probe: bad arguments");
+  static u32x4_t* buf = nullptr;
+  const size_t n16 = (size_t)64 << 20;                    // 1 GiB
+  if (kind == 1 && !buf) {
+    DD_HIP(hipMalloc((void**)&buf, n16 * 16));
+    k_gload_fill<<<4096, 256, 0, st>>>(buf, n16);
+    DD_CHECK_LAUNCH();
+    DD_HIP(hipStreamSynchronize(st));
+  }
+  static uint32_t salt = 5;
+  for (int i = 0; i < launches; ++i) {
+    if (kind == 0) k_vgpr_hold<<<wgs, 256, 30720, st>>>(hold, salt++, errors_dev);
+    else k_gload_hold<<<wgs, 256, 30720, st>>>(buf, n16, hold, salt++, errors_dev);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}

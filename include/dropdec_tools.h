@@ -76,6 +76,10 @@ int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* 
 /* LDS overlap probe: a grid of 512-thread workgroups holding a verifiable pattern in lds_a bytes of dynamic LDS on stream_a while launches_b grids
  * of 256-thread workgroups do the same with lds_b bytes on stream_b; errors_dev[0] / [1] += corrupted words seen by A / B workgroups, [2] / [3] = lowest /
  * highest corrupted word offset in a B workgroup (initialise to 0xFFFFFFFF / 0). */
+/* Register / load probes shaped like the fp32-cache attention tile pass (256 threads, ~120 VGPRs, 30,720 bytes of dynamic LDS): kind 0 holds a pattern in
+ * 96 registers per lane across `hold` sleep + barrier rounds; kind 1 keeps 16 outstanding 16-byte global loads per lane from a 1 GiB buffer of known contents.
+ * errors_dev[0] += mismatching words. */
+int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int* errors_dev, void* stream);
 int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,
                                void* stream_a, void* stream_b);
 

@@ -186,6 +186,36 @@ def lds_probe(beside: bool, rounds: int, lib=None, wgs: int = 3072, which=(2, 0)
             "company_gemv_launches": company, "mismatching_words": int(err[0].item()), "seconds": round(time.time() - t0, 1)}
 
 
+def hold_probe(kind: int, beside: bool, rounds: int, lib=None, rows: int = 64) -> dict:
+    """dd_tools_hold_probe (0: registers, 1: outstanding global loads) alone / beside slice GEMVs of `rows` rows."""
+    lib = lib or _lib.load_tools()
+    err = torch.zeros(4, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    lib.dd_tools_hold_probe(kind, 1, 64, 1, err.data_ptr(), st.cuda_stream)       # (allocates / fills the load probe's buffer)
+    torch.cuda.synchronize()
+    err.zero_()
+    torch.cuda.synchronize()
+    t0 = time.time()
+
+    def body():
+        for r in range(rounds):
+            rc = lib.dd_tools_hold_probe(kind, 16, 3072, 24, err.data_ptr(), st.cuda_stream)
+            assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+
+    if beside:
+        co = Company(lib)
+        co.rows = rows
+        with co:
+            body()
+            company = sum(co.launches)
+    else:
+        body()
+        company = 0
+    return {"test": ["vgpr_hold_probe", "global_load_hold_probe"][kind], "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16,
+            "workgroups_per_launch": 3072, "company_gemv_launches": company, "mismatching_words": int(err[0].item()), "seconds": round(time.time() - t0, 1)}
+
+
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     torch.cuda.set_device(0)
@@ -203,6 +233,10 @@ if __name__ == "__main__":
     for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16)):
         out.append(lds_probe(beside, rounds, lib, rows=rows or 64))
         print(json.dumps(out[-1]), flush=True)
+    for kind in (0, 1):
+        for beside, rows in ((False, 0), (True, 64), (True, 32)):
+            out.append(hold_probe(kind, beside, rounds, lib, rows=rows or 64))
+            print(json.dumps(out[-1]), flush=True)
     if os.environ.get("DD_REPRO_LOG"):
         with open(os.environ["DD_REPRO_LOG"], "w") as f:
             json.dump(out, f, indent=1)
