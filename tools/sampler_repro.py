@@ -186,6 +186,35 @@ def lds_probe(beside: bool, rounds: int, lib=None, wgs: int = 3072, which=(2, 0)
             "company_gemv_launches": company, "mismatching_words": int(err[0].item()), "seconds": round(time.time() - t0, 1)}
 
 
+def lds_full_probe(beside: bool, rounds: int, lib=None, rows: int = 64, lds_bytes: int = 30720) -> dict:
+    """Workgroups that hold and verify a pattern in ALL of their dynamic LDS (k_lds_hold) alone / beside slice GEMVs of `rows` rows."""
+    lib = lib or _lib.load_tools()
+    err = torch.tensor([0, 0, -1, 0], dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+
+    def body():
+        for r in range(rounds):
+            rc = lib.dd_tools_lds_overlap_probe(0, 0, 0, lds_bytes, 3072, 8, 16, err.data_ptr(), st.cuda_stream, st.cuda_stream)
+            assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+
+    if beside:
+        co = Company(lib)
+        co.rows = rows
+        with co:
+            body()
+            company = sum(co.launches)
+    else:
+        body()
+        company = 0
+    e = [int(x) & 0xFFFFFFFF for x in err.tolist()]
+    return {"test": "lds_full_pattern_probe", "lds_bytes": lds_bytes, "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16,
+            "workgroups_per_launch": 3072, "company_gemv_launches": company, "corrupted_words": e[1],
+            "first_bad_byte": None if not e[1] else e[2] * 4, "last_bad_byte": None if not e[1] else e[3] * 4 + 3, "seconds": round(time.time() - t0, 1)}
+
+
 def hold_probe(kind: int, beside: bool, rounds: int, lib=None, rows: int = 64) -> dict:
     """dd_tools_hold_probe (0: registers, 1: outstanding global loads) alone / beside slice GEMVs of `rows` rows."""
     lib = lib or _lib.load_tools()
@@ -232,6 +261,9 @@ if __name__ == "__main__":
             print(json.dumps(out[-1]), flush=True)
     for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16)):
         out.append(lds_probe(beside, rounds, lib, rows=rows or 64))
+        print(json.dumps(out[-1]), flush=True)
+    for beside, rows, nbytes in ((False, 0, 30720), (True, 64, 30720), (True, 32, 30720), (True, 16, 30720), (True, 64, 12288), (True, 32, 66560)):
+        out.append(lds_full_probe(beside, rounds, lib, rows=rows or 64, lds_bytes=nbytes))
         print(json.dumps(out[-1]), flush=True)
     for kind in (0, 1):
         for beside, rows in ((False, 0), (True, 64), (True, 32)):
