@@ -1323,6 +1323,7 @@ void dd_engine_set_ride_beside(int on) { g_ride_beside = on; }
 // 8 / 9 the attention's per-tile statistics / outputs (the tiles every sequence of the sweep has), 10 new V rows)
 uint32_t* g_dbg_trace = nullptr;
 int g_dbg_trace_cap = 0, g_dbg_sweeps = 0;
+int g_dbg_replay = 0;                       // dd_tools_sweep_trace flag: launch every traced attention twice (stages 11 / 12 = the second launch's tiles)
 uint32_t* g_dbg_attn = nullptr;            // per-workgroup checksums of the fp32-cache attention tile pass: [sweep][layer][g_dbg_attn_stride]
 size_t g_dbg_attn_stride = 0;
 __global__ __launch_bounds__(256) void k_dbg_sum(const uint32_t* __restrict__ p, size_t n, uint32_t* __restrict__ out) {
@@ -1440,6 +1441,26 @@ static int lm_sweep_groups(dd_lm* h, dd_lm* const* qs, int ng, int K, hipStream_
       DD_HIP(hipStreamWaitEvent(st, as->e_out, 0));
     } else {
       RC(on_family(h, st, 128, [&](hipStream_t s2) { return ddk_attn_decode(t, s2); }));
+    }
+    if (g_dbg_trace && dbg_sweep < g_dbg_trace_cap && !n_rider && g_dbg_replay) {
+      // (debug) the same attention launched a second time into spare buffers: do two launches over the same inputs agree with each other?
+      static std::vector<std::pair<dd_lm*, float*>> spare;
+      float* sp = nullptr;
+      for (auto& e : spare) sp = e.first == h ? e.second : sp;
+      const size_t n_o = (size_t)h->Hkv * (h->T_cap / 64) * GROUP_ROWS * (h->H / h->Hkv) * 128, n_ml = n_o / 64, n_x = (size_t)h->S_q * 64 * GROUP_PLANES * 4;
+      if (!sp) {
+        DD_HIP(hipMalloc((void**)&sp, (n_o + n_ml + n_x) * 4));
+        spare.push_back({h, sp});
+      }
+      AttnDecodeArgs t2 = t;
+      t2.part_o = sp, t2.part_ml = sp + n_o, t2.xop_out = (u32x4_t*)(sp + n_o + n_ml), t2.dbg = nullptr;
+      RC(ddk_attn_decode(t2, st));
+      int minT2 = 1 << 30;
+      for (int g = 0; g < ng; ++g) minT2 = qs[g]->T_host < minT2 ? qs[g]->T_host : minT2;
+      const int tiles2 = (minT2 + 63) / 64, sg2 = ddk_attn_grid_tiles(t.max_T, h->T_cap), RT2 = 8 * (packed ? 8 : ng) * (h->H / h->Hkv);
+      uint32_t* tr2 = g_dbg_trace + ((size_t)dbg_sweep * h->Lyr + l) * 16;
+      k_dbg_sum_tiles<<<64, 256, 0, st>>>((const uint32_t*)t2.part_ml, h->Hkv, sg2, RT2 * 2, tiles2, tr2 + 11);
+      k_dbg_sum_tiles<<<64, 256, 0, st>>>((const uint32_t*)t2.part_o, h->Hkv, sg2, RT2 * 128, tiles2, tr2 + 12);
     }
     if (g_dbg_trace && dbg_sweep < g_dbg_trace_cap && !n_rider) {
       int minT = 1 << 30;

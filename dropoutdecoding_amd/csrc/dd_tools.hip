@@ -352,9 +352,11 @@ extern "C" int dd_tools_sample_masks_lanes(int n, const float* const* epi, const
 // Per-stage checksums of the multi-group sweeps (dd_engine.hip dbg_sum): trace_dev [cap_sweeps][n_layers][8] uint32, zeroed by the caller;
 // sweeps are numbered in the order the host enqueues them from this call on.  NULL switches it off.
 extern uint32_t* g_dbg_trace;
-extern int g_dbg_trace_cap, g_dbg_sweeps;
+extern int g_dbg_trace_cap, g_dbg_sweeps, g_dbg_replay;
 extern "C" int dd_tools_sweep_trace(uint32_t* trace_dev, int cap_sweeps) {
   dd_engine_bump_epoch();
+  g_dbg_replay = cap_sweeps < 0 ? 1 : 0;             // negative capacity: also launch every traced attention a second time (stages 11 / 12)
+  if (cap_sweeps < 0) cap_sweeps = -cap_sweeps;
   g_dbg_trace = trace_dev, g_dbg_trace_cap = trace_dev ? cap_sweeps : 0, g_dbg_sweeps = 0;
   return DD_OK;
 }

@@ -34,10 +34,11 @@ embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(50 + i)).c
 CAP = 64
 STAGE = ["embed", "q rows (qkv GEMV + finish)", "new K rows (qkv GEMV + finish)", "attention -> o_proj operand", "o_proj -> residual rows",
          "gate/up -> down operand", "down -> residual rows", "down -> next operand", "attention tiles: statistics (partial kernel)",
-         "attention tiles: outputs (partial kernel)", "new V rows"] + ["-"] * 5
-ORDER = [0, 1, 2, 10, 8, 9, 3, 4, 5, 6, 7]          # pipeline order of the stages within a layer
+         "attention tiles: outputs (partial kernel)", "new V rows", "2nd launch: tile statistics", "2nd launch: tile outputs"] + ["-"] * 3
+ORDER = [0, 1, 2, 10, 8, 9, 11, 12, 3, 4, 5, 6, 7]          # pipeline order of the stages within a layer
 trace = torch.zeros(CAP, 32, 16, dtype=torch.int32, device="cuda")
 ATTN_WGS = 32 * 12 * 8                     # workgroups of the widest attention tile pass (kv heads x key tiles x groups)
+REPLAY = os.environ.get("DD_BISECT_REPLAY", "0") not in ("", "0")      # every traced attention launched twice: do the two launches agree?
 ATTN = os.environ.get("DD_BISECT_ATTN", "1") not in ("", "0") and KV == "fp32"
 CAP_A = 2 * STEPS
 attn = torch.zeros(CAP_A, 32, ATTN_WGS * 8, dtype=torch.int32, device="cuda") if ATTN else None
@@ -55,7 +56,7 @@ def run(branches):
     if ATTN:
         attn.zero_()
     torch.cuda.synchronize()
-    L.dd_tools_sweep_trace(trace.data_ptr(), CAP if not ATTN else CAP_A)
+    L.dd_tools_sweep_trace(trace.data_ptr(), (CAP if not ATTN else CAP_A) * (-1 if REPLAY else 1))
     if ATTN:
         L.dd_tools_attn_trace(attn.data_ptr(), ATTN_WGS * 8)
     grp = lm.EngineGroup(engs)
@@ -86,6 +87,11 @@ for rep in range(4):
         by_sweep.setdefault(int(sw), []).append((int(ly), ORDER.index(int(stg))))
     msg = "; ".join(f"sweep {sw}: first at layer {min(v)[0]} stage '{STAGE[ORDER[min(v)[1]]]}' ({len(v)} cells)" for sw, v in sorted(by_sweep.items()))
     print(f"rep {rep}: two branches: {len(bad)} trace cells differ; {msg}; lanes with different final logits: {lanes_bad}", flush=True)
+    if REPLAY:
+        g9, g12, r9 = got[:, :, 9], got[:, :, 12], ref[:, :, 9]
+        live = r9 != 0
+        print(f"      tile outputs over {int(live.sum())} (sweep, layer) cells: 1st launch != reference in {int((g9 != r9)[live].sum())}, 2nd launch != reference in "
+              f"{int((g12 != r9)[live].sum())}, 1st != 2nd in {int((g9 != g12)[live].sum())}; in the one-branch run 1st != 2nd in {int((ref[:, :, 9] != ref[:, :, 12])[live].sum())}", flush=True)
     if ATTN:
         # inside the tile pass of each sweep's FIRST differing layer: which of the workgroup's checksums differ
         for sw, v in sorted(by_sweep.items()):
