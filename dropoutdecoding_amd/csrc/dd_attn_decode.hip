@@ -25,6 +25,7 @@
 // ML == 2 (groups): NBT == 8; blockIdx.z = group * (G / GH) + GQA slice; group g's 8 rows (members of sequence g) read
 // that sequence's cache and drop bits; results go to an (8 * a.lane_groups)-rows-per-head layout (row = 8 * group + member).
 // (fp32 cache; the fp16 cache goes through k_attn_partial16 below)
+int g_attn32_nopk = 0;         // dd_tools_set_tuning key 43 (experiment): the fp32 tile pass with scalar instead of packed FP32 multiply-adds
 int g_attn32_lds_pad = 0;      // dd_tools_set_tuning key 39 (debug): bytes added to the fp32 attention kernel's dynamic LDS request
 template <int NBT, int G, int GH, int ML = 0, int DBG = 0>      // DBG: per-workgroup checksums into a.dbg (libdropdec_tools.so's race bisect; more registers)
 __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
   }
   uint32_t dsum[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};       // debug checksums (a.dbg)
   auto dacc = [&](int slot, float v, int salt) { dsum[slot] += __float_as_uint(v) * (uint32_t)(2 * salt + 1); };
-  if constexpr (DBG) {
+  if constexpr (DBG == 1) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       dacc(0, k4[i].x, i * 4), dacc(0, k4[i].y, i * 4 + 1), dacc(0, k4[i].z, i * 4 + 2), dacc(0, k4[i].w, i * 4 + 3);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       f32x4_t q4 = *(const f32x4_t*)&q_sh[r * HEAD_DIM + (wave * 8 + i) * 4];
-      if constexpr (DBG) dacc(2, q4.x + q4.y + q4.z + q4.w, r * 8 + i);
+      if constexpr (DBG == 1) dacc(2, q4.x + q4.y + q4.z + q4.w, r * 8 + i);
       sp += q4.x * k4[i].x + q4.y * k4[i].y + q4.z * k4[i].z + q4.w * k4[i].w;
     }
     s_part[(wave * R + r) * ATT_SPLIT + lane] = sp;
@@ -117,13 +118,13 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     int m = ML == 1 ? 0 : mo + r % NBT;  // lanes: bit 0 of the sequence's own (leak) bits; groups: the member's bit
     float sv = (s_part[(0 * R + r) * ATT_SPLIT + lane] + s_part[(1 * R + r) * ATT_SPLIT + lane]) +
                (s_part[(2 * R + r) * ATT_SPLIT + lane] + s_part[(3 * R + r) * ATT_SPLIT + lane]);
-    if constexpr (DBG) dacc(3, sv, r);
+    if constexpr (DBG == 1) dacc(3, sv, r);
     sv *= scaling;
     if (lane >= nkeys || ((bits >> (a.bit0 + m)) & 1u)) sv = -INFINITY;  // zero in the 2-D mask: weight exactly 0
     float mx = dd_wave_max(sv);
     float p = (sv == -INFINITY) ? 0.f : expf(sv - mx);
     float l = dd_wave_sum(p);
-    if constexpr (DBG) dacc(4, p, r);
+    if constexpr (DBG == 1) dacc(4, p, r);
     p_sh[lane * R + r] = p;
     if (lane == 0) {
       float* ml = a.part_ml + (((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * 2;
@@ -142,24 +143,40 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
     const float* pr = &p_sh[min(key, ATT_SPLIT - 1) * R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (DBG && dq == 0) dacc(5, pr[r], (wave * 8 + j) * R + r);
-      acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
+      if (DBG == 1 && dq == 0) dacc(5, pr[r], (wave * 8 + j) * R + r);
+      if constexpr (DBG == 2) {              // (experiment, dd_tools_set_tuning key 43) the same fused multiply-adds as SCALAR instructions: no v_pk_fma_f32
+        const float pv = pr[r];
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[r].x) : "v"(pv), "v"(v4[j].x));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[r].y) : "v"(pv), "v"(v4[j].y));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[r].z) : "v"(pv), "v"(v4[j].z));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[r].w) : "v"(pv), "v"(v4[j].w));
+      } else {
+        acc[r] += pr[r] * v4[j];   // p = 0 for dead / dropped keys
+      }
     }
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     f32x4_t o = acc[r];
+    if constexpr (DBG == 2) {
+      float t0 = __shfl_xor(o.x, 32), t1 = __shfl_xor(o.y, 32), t2 = __shfl_xor(o.z, 32), t3 = __shfl_xor(o.w, 32);
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(o.x) : "v"(t0));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(o.y) : "v"(t1));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(o.z) : "v"(t2));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(o.w) : "v"(t3));
+    } else {
     o.x += __shfl_xor(o.x, 32);
     o.y += __shfl_xor(o.y, 32);
     o.z += __shfl_xor(o.z, 32);
     o.w += __shfl_xor(o.w, 32);
+    }
     if (half == 0) *(f32x4_t*)&o_part[(wave * R + r) * HEAD_DIM + dq * 4] = o;
   }
   __syncthreads();
   // 6. fixed-order sum over the four waves
   for (int i = tid; i < R * HEAD_DIM; i += 256) {
     float o = (o_part[i] + o_part[R * HEAD_DIM + i]) + (o_part[2 * R * HEAD_DIM + i] + o_part[3 * R * HEAD_DIM + i]);
-    if constexpr (DBG) dacc(6, o, i);
+    if constexpr (DBG == 1) dacc(6, o, i);
     if (ML) {
       int r = i / HEAD_DIM, dd = i % HEAD_DIM;
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + buf_row(r)) * HEAD_DIM + dd] = o;
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
       a.part_o[(((size_t)kvh * gridDim.y + split) * RT + g0 * NBT) * HEAD_DIM + i] = o;
     }
   }
-  if (DBG && a.dbg) {
+  if (DBG == 1 && a.dbg) {
     uint32_t* slot = a.dbg + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) << 3);
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
@@ -620,6 +637,9 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
     if constexpr (G == 1 && NBT == 8) {              // (the traced instantiation exists for the MHA shape the race bisect runs)
       if (a.dbg) {
         k_attn_partial<NBT, G, GH, 2, 1><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
+        traced = true;
+      } else if (g_attn32_nopk) {
+        k_attn_partial<NBT, G, GH, 2, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
         traced = true;
       }
     }

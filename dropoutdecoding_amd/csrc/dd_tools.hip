@@ -100,7 +100,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // (616 bytes per lane; this library only); the product switches
 // (8, 11, 13-16) are forwarded to dd_set_tuning.  Every call bumps the graph-key epoch: steps captured under other settings are not replayed.
 extern int g_exp_G[4];
-extern int g_attn16_tpw, g_attn16_full, g_finish4, g_attn16_gh_all, g_attn32_lds_pad;
+extern int g_attn16_tpw, g_attn16_full, g_finish4, g_attn16_gh_all, g_attn32_lds_pad, g_attn32_nopk;
 void dd_engine_set_pairs(int on);
 void dd_engine_set_branches(int n);
 void dd_engine_set_rider(int on);
@@ -118,7 +118,7 @@ void dd_dropout_set_lanes_sampler_scratch(int on);   // dd_dropout.hip compiled 
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39 || key == 40 || key == 41 || key == 42,
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39 || key == 40 || key == 41 || key == 42 || key == 43,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -143,6 +143,7 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 40) dd_engine_set_mask_branches(value);
   else if (key == 41) dd_engine_set_attn_masked(value);
   else if (key == 42) dd_engine_set_unmask(value);
+  else if (key == 43) g_attn32_nopk = value;
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }
@@ -521,6 +522,44 @@ extern "C" int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, un
   for (int i = 0; i < launches; ++i) {
     if (kind == 0) k_vgpr_hold<<<wgs, 256, 30720, st>>>(hold, salt++, errors_dev);
     else k_gload_hold<<<wgs, 256, 30720, st>>>(buf, n16, hold, salt++, errors_dev);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}
+
+// Packed-FP32 probe: v_pk_fma_f32 chains (plain and with the broadcast op_sel forms the fp32 attention tile pass compiles to) against the same
+// multiply-adds issued as scalar v_fma_f32, on identical operands, `iters` rounds per lane; 256-thread workgroups with 30,720 bytes of dynamic LDS
+// (they fit beside a slice-resident GEMV workgroup).  errors_dev[0] += lanes whose packed and scalar results differ in any bit.
+typedef float dd_f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_pk_probe(int iters, uint32_t salt, unsigned int* errors) {
+  extern __shared__ __align__(16) uint32_t pl[];
+  const uint32_t me = ((blockIdx.x * 256u + threadIdx.x) * 2654435761u) ^ salt;
+  float a0 = 0.5f + (float)(me & 1023u) * (1.0f / 1024.0f), a1 = 0.25f + (float)((me >> 10) & 1023u) * (1.0f / 2048.0f);
+  float b0 = 1.0f - (float)((me >> 20) & 255u) * (1.0f / 512.0f), b1 = 0.75f + (float)((me >> 5) & 511u) * (1.0f / 4096.0f);
+  dd_f32x2 accp = {0.f, 0.f}, accb = {0.f, 0.f};
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+  pl[threadIdx.x] = me;
+  for (int it = 0; it < iters; ++it) {
+    dd_f32x2 x = {a0, a1}, y = {b0, b1};
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(accp) : "v"(x), "v"(y));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(accb) : "v"(x), "v"(y));     // second operand: its low half for both lanes
+    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(a0), "v"(b0));
+    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(a1), "v"(b1));
+    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t0) : "v"(a0), "v"(b0));
+    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t1) : "v"(a1), "v"(b0));
+    a0 = a0 * 0.999f + 0.001f, a1 = a1 * 1.0005f - 0.0003f, b0 = b0 * 0.9995f + 0.0004f, b1 = b1 * 1.0002f - 0.0001f;
+    if ((it & 63) == 63) __syncthreads();
+  }
+  const bool bad = __float_as_uint(accp.x) != __float_as_uint(s0) || __float_as_uint(accp.y) != __float_as_uint(s1) ||
+                   __float_as_uint(accb.x) != __float_as_uint(t0) || __float_as_uint(accb.y) != __float_as_uint(t1) || pl[threadIdx.x] != me;
+  if (bad) atomicAdd(errors, 1u);
+}
+extern "C" int dd_tools_pk_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(launches >= 1 && wgs >= 1 && iters >= 1 && errors_dev, "dd_tools_pk_probe: bad arguments");
+  static uint32_t salt = 17;
+  for (int i = 0; i < launches; ++i) {
+    k_pk_probe<<<wgs, 256, 30720, st>>>(iters, salt++, errors_dev);
     DD_CHECK_LAUNCH();
   }
   return DD_OK;

@@ -79,6 +79,9 @@ int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* 
 /* Register / load probes shaped like the fp32-cache attention tile pass (256 threads, ~120 VGPRs, 30,720 bytes of dynamic LDS): kind 0 holds a pattern in
  * 96 registers per lane across `hold` sleep + barrier rounds; kind 1 keeps 16 outstanding 16-byte global loads per lane from a 1 GiB buffer of known contents.
  * errors_dev[0] += mismatching words. */
+/* v_pk_fma_f32 chains against the same multiply-adds as scalar v_fma_f32 on identical operands (256-thread workgroups, 30,720 bytes of dynamic LDS);
+ * errors_dev[0] += lanes whose packed and scalar results differ. */
+int dd_tools_pk_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
 int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int* errors_dev, void* stream);
 int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,
                                void* stream_a, void* stream_b);

@@ -215,6 +215,34 @@ def lds_full_probe(beside: bool, rounds: int, lib=None, rows: int = 64, lds_byte
             "first_bad_byte": None if not e[1] else e[2] * 4, "last_bad_byte": None if not e[1] else e[3] * 4 + 3, "seconds": round(time.time() - t0, 1)}
 
 
+def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64) -> dict:
+    """Packed vs scalar FP32 multiply-add chains (dd_tools_pk_probe) alone / beside slice GEMVs of `rows` rows."""
+    lib = lib or _lib.load_tools()
+    err = torch.zeros(4, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+
+    def body():
+        for r in range(rounds):
+            rc = lib.dd_tools_pk_probe(16, 3072, 512, err.data_ptr(), st.cuda_stream)
+            assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+
+    if beside:
+        co = Company(lib)
+        co.rows = rows
+        with co:
+            body()
+            company = sum(co.launches)
+    else:
+        body()
+        company = 0
+    return {"test": "packed_fp32_probe", "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16, "workgroups_per_launch": 3072,
+            "lanes_checked": rounds * 16 * 3072 * 256, "company_gemv_launches": company, "lanes_with_wrong_packed_result": int(err[0].item()),
+            "seconds": round(time.time() - t0, 1)}
+
+
 def hold_probe(kind: int, beside: bool, rounds: int, lib=None, rows: int = 64) -> dict:
     """dd_tools_hold_probe (0: registers, 1: outstanding global loads) alone / beside slice GEMVs of `rows` rows."""
     lib = lib or _lib.load_tools()
@@ -261,6 +289,9 @@ if __name__ == "__main__":
             print(json.dumps(out[-1]), flush=True)
     for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16)):
         out.append(lds_probe(beside, rounds, lib, rows=rows or 64))
+        print(json.dumps(out[-1]), flush=True)
+    for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16), (True, 72)):
+        out.append(pk_probe(beside, rounds, lib, rows=rows or 64))
         print(json.dumps(out[-1]), flush=True)
     for beside, rows, nbytes in ((False, 0, 30720), (True, 64, 30720), (True, 32, 30720), (True, 16, 30720), (True, 64, 12288), (True, 32, 66560)):
         out.append(lds_full_probe(beside, rounds, lib, rows=rows or 64, lds_bytes=nbytes))
