@@ -564,3 +564,65 @@ extern "C" int dd_tools_pk_probe(int launches, int wgs, int iters, unsigned int*
   }
   return DD_OK;
 }
+
+// P.V probe: step 5 of the fp32-cache attention tile pass as it is written there — eight rows' accumulators += p (read from LDS, one 32-byte row
+// per key) x V (sixteen bytes per lane and key, in registers); the compiler turns the vector form into v_pk_fma_f32 with broadcast op_sel forms fed
+// by ds_read_b128 — next to the SAME sums issued as scalar v_fma_f32, compared bit for bit, `iters` rounds.  errors_dev[0] += lanes that differ.
+__global__ __launch_bounds__(256) void k_pv_probe(int iters, uint32_t salt, unsigned int* errors) {
+  extern __shared__ __align__(16) float pf[];
+  float* p_sh = pf + 3072;                             // where the tile pass keeps its probabilities: [64 keys][8 rows]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  const uint32_t me = ((blockIdx.x * 256u + threadIdx.x) * 2654435761u) ^ salt;
+  f32x4_t v4[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    v4[j] = (f32x4_t){0.5f + (float)((me >> j) & 255u) * (1.0f / 256.0f), -0.25f + (float)((me >> (j + 3)) & 127u) * (1.0f / 128.0f),
+                      1.0f - (float)((me >> (j + 7)) & 63u) * (1.0f / 64.0f), 0.125f + (float)((me >> (j + 11)) & 31u) * (1.0f / 32.0f)};
+  unsigned int bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    for (int r = wave; r < 8; r += 4) p_sh[lane * 8 + r] = (float)((lane * 8 + r + it * 13 + (int)(salt & 31u)) & 511) * (1.0f / 512.0f);
+    __syncthreads();
+    f32x4_t acc[8], ref[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = ref[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = wave * 16 + 2 * j + half;
+      const float* pr = &p_sh[key * 8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] += pr[r] * v4[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int key = wave * 16 + 2 * j + half;
+      const float* pr = &p_sh[key * 8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float pv = pr[r];
+        asm volatile("" : "+v"(pv));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ref[r].x) : "v"(pv), "v"(v4[j].x));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ref[r].y) : "v"(pv), "v"(v4[j].y));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ref[r].z) : "v"(pv), "v"(v4[j].z));
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(ref[r].w) : "v"(pv), "v"(v4[j].w));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      bad += (__float_as_uint(acc[r].x) != __float_as_uint(ref[r].x)) | (__float_as_uint(acc[r].y) != __float_as_uint(ref[r].y)) |
+             (__float_as_uint(acc[r].z) != __float_as_uint(ref[r].z)) | (__float_as_uint(acc[r].w) != __float_as_uint(ref[r].w));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v4[j] = v4[j] * 0.9995f + 0.0003f;
+    __syncthreads();
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+extern "C" int dd_tools_pv_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(launches >= 1 && wgs >= 1 && iters >= 1 && errors_dev, "dd_tools_pv_probe: bad arguments");
+  static uint32_t salt = 23;
+  for (int i = 0; i < launches; ++i) {
+    k_pv_probe<<<wgs, 256, 30720, st>>>(iters, salt++, errors_dev);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}

@@ -81,6 +81,9 @@ int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* 
  * errors_dev[0] += mismatching words. */
 /* v_pk_fma_f32 chains against the same multiply-adds as scalar v_fma_f32 on identical operands (256-thread workgroups, 30,720 bytes of dynamic LDS);
  * errors_dev[0] += lanes whose packed and scalar results differ. */
+/* The P.V step of the fp32-cache attention tile pass as the compiler emits it (v_pk_fma_f32 fed by ds_read_b128) next to the same sums as scalar
+ * v_fma_f32, compared bit for bit; errors_dev[0] += (lane, row) results that differ. */
+int dd_tools_pv_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
 int dd_tools_pk_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
 int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int* errors_dev, void* stream);
 int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,

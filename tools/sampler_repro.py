@@ -215,8 +215,8 @@ def lds_full_probe(beside: bool, rounds: int, lib=None, rows: int = 64, lds_byte
             "first_bad_byte": None if not e[1] else e[2] * 4, "last_bad_byte": None if not e[1] else e[3] * 4 + 3, "seconds": round(time.time() - t0, 1)}
 
 
-def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64) -> dict:
-    """Packed vs scalar FP32 multiply-add chains (dd_tools_pk_probe) alone / beside slice GEMVs of `rows` rows."""
+def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64, pv: bool = False) -> dict:
+    """Packed vs scalar FP32 multiply-add chains (dd_tools_pk_probe; pv: the tile pass's own P.V step, dd_tools_pv_probe) alone / beside slice GEMVs."""
     lib = lib or _lib.load_tools()
     err = torch.zeros(4, dtype=torch.int32, device="cuda")
     st = torch.cuda.Stream()
@@ -225,7 +225,8 @@ def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64) -> dict:
 
     def body():
         for r in range(rounds):
-            rc = lib.dd_tools_pk_probe(16, 3072, 512, err.data_ptr(), st.cuda_stream)
+            rc = (lib.dd_tools_pv_probe(16, 3072, 16, err.data_ptr(), st.cuda_stream) if pv
+                  else lib.dd_tools_pk_probe(16, 3072, 512, err.data_ptr(), st.cuda_stream))
             assert rc == 0, lib.dd_last_error()
             st.synchronize()
 
@@ -238,7 +239,7 @@ def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64) -> dict:
     else:
         body()
         company = 0
-    return {"test": "packed_fp32_probe", "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16, "workgroups_per_launch": 3072,
+    return {"test": "pv_step_probe" if pv else "packed_fp32_probe", "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16, "workgroups_per_launch": 3072,
             "lanes_checked": rounds * 16 * 3072 * 256, "company_gemv_launches": company, "lanes_with_wrong_packed_result": int(err[0].item()),
             "seconds": round(time.time() - t0, 1)}
 
@@ -290,9 +291,10 @@ if __name__ == "__main__":
     for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16)):
         out.append(lds_probe(beside, rounds, lib, rows=rows or 64))
         print(json.dumps(out[-1]), flush=True)
-    for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16), (True, 72)):
-        out.append(pk_probe(beside, rounds, lib, rows=rows or 64))
-        print(json.dumps(out[-1]), flush=True)
+    for pv in (True, False):
+        for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16), (True, 72)):
+            out.append(pk_probe(beside, rounds, lib, rows=rows or 64, pv=pv))
+            print(json.dumps(out[-1]), flush=True)
     for beside, rows, nbytes in ((False, 0, 30720), (True, 64, 30720), (True, 32, 30720), (True, 16, 30720), (True, 64, 12288), (True, 32, 66560)):
         out.append(lds_full_probe(beside, rounds, lib, rows=rows or 64, lds_bytes=nbytes))
         print(json.dumps(out[-1]), flush=True)
