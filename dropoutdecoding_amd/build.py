@@ -31,6 +31,12 @@ HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h
            os.path.join(ROOT, "include", "dropdec_tools.h"), os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
+# Product objects are compiled WITHOUT packed FP32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32).  Found in round 4 (DESIGN.md
+# "Determinism"): on gfx950 a wave's v_pk_fma_f32 over operands just returned from LDS gives wrong sums while a workgroup of an MFMA kernel (the
+# slice-resident GEMVs of another branch of the step) is resident on the same CU — tools/sampler_repro.py `pv_step_probe` shows it in isolation,
+# tests/test_gpu_sampler_repro.py guards it.  The scalar forms are unaffected; nothing on the path is bound by VALU issue.  dd_tools.hip keeps the
+# packed forms: the probe needs them.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # kernels allowed to use scratch in the PRODUCT library: none
 SCRATCH_ALLOWED: tuple = ()
 
@@ -112,6 +118,31 @@ def _check_scratch(objs) -> None:
         raise RuntimeError("kernels of the product library use private scratch (see dropoutdecoding_amd/build.py):\n" + msg)
 
 
+def packed_fp32_ops(obj_path: str) -> int:
+    """Number of packed FP32 VALU instructions in the gfx950 code of a (fat) object file."""
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="ddobj")
+    try:
+        shutil.copy(obj_path, os.path.join(d, "x.o"))
+        subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", "x.o"], cwd=d, capture_output=True, timeout=120)
+        n = 0
+        for f in os.listdir(d):
+            if "amdgcn" in f:
+                out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", f], cwd=d, capture_output=True, text=True,
+                                     timeout=600).stdout
+                n += len(re.findall(r"\bv_pk_(?:fma|add|mul)_f32\b", out))
+        return n
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _check_packed_fp32(objs) -> None:
+    bad = [(os.path.basename(o), n) for o in objs for n in [packed_fp32_ops(o)] if n]
+    if bad:
+        raise RuntimeError("product objects contain packed FP32 VALU instructions (see NO_PACKED_FP32 in dropoutdecoding_amd/build.py): " + str(bad))
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the sources whose content (or a header's) changed and link.  One builder at a time (file lock), a bounded number of
     hipcc jobs, objects and stamps written to temporaries and renamed."""
@@ -129,11 +160,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
 def _build_locked(force: bool, verbose: bool, bdir: str) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, tools_objs, todo = [], [], []
-    units = [(s, [], s.replace(".hip", ".o")) for s in SOURCES + TOOLS_SOURCES]
-    units += [(s, extra, s.replace(".hip", "_tools.o")) for s, extra in TOOLS_VARIANTS.items()]
-    for s, extra, oname in units:
+    units = [(s, [] if s in TOOLS_SOURCES else NO_PACKED_FP32, s.replace(".hip", ".o"), False) for s in SOURCES + TOOLS_SOURCES]
+    units += [(s, NO_PACKED_FP32 + extra, s.replace(".hip", "_tools.o"), True) for s, extra in TOOLS_VARIANTS.items()]
+    for s, extra, oname, is_variant in units:
         o = os.path.join(bdir, oname)
-        if extra:
+        if is_variant:
             pass                                          # variant objects: picked per library below
         elif s in TOOLS_SOURCES:
             tools_objs.append(o)
@@ -193,6 +224,7 @@ def _build_locked(force: bool, verbose: bool, bdir: str) -> str:
     if failed is not None:
         raise failed
     _check_scratch(objs)
+    _check_packed_fp32(objs)
     variant_of = {os.path.join(bdir, s.replace(".hip", ".o")): os.path.join(bdir, s.replace(".hip", "_tools.o")) for s in TOOLS_VARIANTS}
     tools_members = [variant_of.get(o, o) for o in objs] + tools_objs
     for lib, members in ((LIB, objs), (TOOLS_LIB, tools_members)):

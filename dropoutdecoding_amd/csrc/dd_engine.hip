@@ -1909,9 +1909,9 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   int n_multi = 0;
   for (int m = 0; m < n; m += width(m)) n_multi += width(m) > 1 ? 1 : 0;
   const int nbr = g_branches < n_multi ? g_branches : n_multi;       // branches in use: the caller's stream + nbr - 1 side streams
-  // (fp16-cache engines only: with the fp32 cache's VALU attention kernels running beside another sweep, lanes did not always
-  // reproduce their solo runs bit for bit — cause not found; tools/lanes_mixed_ab.py shows it — so those keep one branch)
-  const bool fork = nbr >= 2 && (h0->kv16 || g_fp32_fork) && h0->side[nbr - 2] != nullptr;
+  // (fp32-cache engines ran one branch in round 3: beside another branch's GEMVs their VALU attention kernel gave different bits — its packed
+  // FP32 multiply-adds, see build.py NO_PACKED_FP32 and DESIGN.md "Determinism".  Key 37 = -1 restores the single branch for the A/B.)
+  const bool fork = nbr >= 2 && (h0->kv16 || g_fp32_fork >= 0) && h0->side[nbr - 2] != nullptr;
   const bool masked0 = fork && g_mask_branches && nbr == 2 && h0->side[2];     // (debug) branch 0 on a CU-masked stream of its own
   if (fork) {
     DD_HIP(hipEventRecord(h0->ev_fork, st));

@@ -1,4 +1,12 @@
-"""Unit level of the determinism work (DESIGN.md "Determinism"): the group step's mask sampler — 8 sequences, L = 576, K = 8, one
+"""Unit level of the determinism work (DESIGN.md "Determinism").
+
+THE FINDING (round 4): on gfx950, packed FP32 multiply-adds (v_pk_fma_f32) over operands just read from LDS give wrong sums while a workgroup of
+an MFMA kernel is resident on the same CU — `pv_step_probe` below is the unit reproducer (the P.V step of the fp32-cache attention tile pass next to
+the same sums as scalar v_fma_f32: 0 of 10^8 lanes differ alone, ~10^6 beside the 64-row slice GEMVs).  The product library is therefore built
+without packed FP32 instructions (build.py NO_PACKED_FP32, gated), and the engine-level regression — an fp32-cache group step on two branches
+equals every sequence decoded alone — is tests/test_gpu_fp32_branches.py.
+
+Also here: the group step's mask sampler — 8 sequences, L = 576, K = 8, one
 1,024-thread workgroup per sequence, each drawing from its own mt19937 stream — launched back to back on a stream of its own BESIDE
 72-row slice-resident GEMVs looping on two other streams (what it met on a branch of the rider step), every launch's keep set, masks,
 bit planes and counts compared with the oracle sampler over the host mt19937 (models/llava.py:443-482, 589-662).
@@ -51,6 +59,39 @@ def test_lanes_sampler_beside_72_row_gemvs_matches_the_oracle(scratch_form):
     assert beside["sequences_with_a_wrong_launch"] == 0, beside
     print(f"\n[sampler, scratch form {scratch_form}] {beside['sampler_launches']} launches of 8 workgroups beside {beside['company_gemv_launches']} "
           f"72-row GEMV launches: all masks equal the oracle's")
+
+
+def test_product_objects_have_no_packed_fp32_instructions():
+    """CPU half of the finding: every object of libdropdec.so disassembles to zero v_pk_{fma,add,mul}_f32 (the build refuses otherwise); the
+    probe's own object keeps them."""
+    import os
+    from dropoutdecoding_amd import build
+    build.build()
+    bdir = os.path.join(build.HERE, "build")
+    for s_ in build.SOURCES:
+        assert build.packed_fp32_ops(os.path.join(bdir, s_.replace(".hip", ".o"))) == 0, s_
+    assert build.packed_fp32_ops(os.path.join(bdir, "dd_tools.o")) > 0
+
+
+@pytest.mark.gpu
+def test_pv_step_probe_packed_fp32_beside_mfma_workgroups():
+    """The unit reproducer.  Alone, packed and scalar sums agree in every lane.  Beside 64-row slice-resident GEMVs (MFMA workgroups that leave room
+    for the probe's 256-thread, 30 KiB-LDS workgroups on their CUs) they disagree in about one lane of a hundred on the MI355X boxes of round 4 —
+    reported, not asserted: a board / firmware on which the count is 0 simply no longer needs the workaround."""
+    import sampler_repro as R
+    import torch
+    torch.cuda.set_device(0)
+    from dropoutdecoding_amd import _lib, build
+    build.build()
+    lib = _lib.load_tools()
+    alone = R.pk_probe(False, 4, lib, pv=True)
+    assert alone["lanes_with_wrong_packed_result"] == 0, alone
+    beside = R.pk_probe(True, 6, lib, rows=64, pv=True)
+    assert beside["company_gemv_launches"] > 0
+    plain = R.pk_probe(True, 4, lib, rows=64, pv=False)         # register-fed packed chains: unaffected
+    print(f"\n[packed FP32 beside MFMA workgroups] P.V step (LDS-fed v_pk_fma_f32): {beside['lanes_with_wrong_packed_result']} of {beside['lanes_checked']} "
+          f"lane results differ from the scalar sums beside {beside['company_gemv_launches']} 64-row GEMV launches (alone: 0 of {alone['lanes_checked']}); "
+          f"register-fed chains: {plain['lanes_with_wrong_packed_result']} of {plain['lanes_checked']}")
 
 
 @pytest.mark.gpu
