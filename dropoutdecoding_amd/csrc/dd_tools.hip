@@ -626,3 +626,59 @@ extern "C" int dd_tools_pv_probe(int launches, int wgs, int iters, unsigned int*
   }
   return DD_OK;
 }
+
+// The same question for operands returned by GLOBAL loads (the finishing kernel of the slice GEMVs adds eight 16-byte partial-sum loads per thread
+// with v_pk_add_f32): packed sums next to the same sums as scalar v_add_f32, bit for bit.  errors_dev[0] += lanes that differ.
+__global__ __launch_bounds__(256) void k_pkadd_gload_probe(const f32x4_t* __restrict__ buf, size_t n16, int iters, uint32_t salt, unsigned int* errors) {
+  extern __shared__ __align__(16) uint32_t pl[];
+  pl[threadIdx.x] = salt;
+  unsigned int bad = 0;
+  size_t base = ((size_t)(blockIdx.x * 256u + threadIdx.x) * 2654435761u + salt) % n16;
+  for (int it = 0; it < iters; ++it) {
+    f32x4_t v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = buf[(base + (size_t)q * 4099u * 64u) % n16];
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) acc = acc + (v[q] + v[q + 1]);          // the finishing kernel's pairwise order
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      float t0 = v[q].x, t1 = v[q].y, t2 = v[q].z, t3 = v[q].w;
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(t0) : "v"(v[q + 1].x));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(t1) : "v"(v[q + 1].y));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(t2) : "v"(v[q + 1].z));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(t3) : "v"(v[q + 1].w));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[0]) : "v"(t0));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[1]) : "v"(t1));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[2]) : "v"(t2));
+      asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[3]) : "v"(t3));
+    }
+    bad += (__float_as_uint(acc.x) != __float_as_uint(r[0])) | (__float_as_uint(acc.y) != __float_as_uint(r[1])) |
+           (__float_as_uint(acc.z) != __float_as_uint(r[2])) | (__float_as_uint(acc.w) != __float_as_uint(r[3]));
+    base = (base + 7919u * 64u) % n16;
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+__global__ void k_fill_floats(float* buf, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    buf[i] = (float)((uint32_t)(i * 2654435761u) >> 8) * (1.0f / 16777216.0f) - 0.5f;
+}
+extern "C" int dd_tools_pkadd_gload_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  DD_REQUIRE(launches >= 1 && wgs >= 1 && iters >= 1 && errors_dev, "dd_tools_pkadd_gload_probe: bad arguments");
+  static f32x4_t* buf = nullptr;
+  const size_t n16 = (size_t)16 << 20;                    // 256 MiB of floats
+  if (!buf) {
+    DD_HIP(hipMalloc((void**)&buf, n16 * 16));
+    k_fill_floats<<<4096, 256, 0, st>>>((float*)buf, n16 * 4);
+    DD_CHECK_LAUNCH();
+    DD_HIP(hipStreamSynchronize(st));
+  }
+  static uint32_t salt = 29;
+  for (int i = 0; i < launches; ++i) {
+    k_pkadd_gload_probe<<<wgs, 256, 4096, st>>>(buf, n16, iters, salt++, errors_dev);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}

@@ -84,6 +84,8 @@ int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* 
 /* The P.V step of the fp32-cache attention tile pass as the compiler emits it (v_pk_fma_f32 fed by ds_read_b128) next to the same sums as scalar
  * v_fma_f32, compared bit for bit; errors_dev[0] += (lane, row) results that differ. */
 int dd_tools_pv_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
+/* Packed sums of eight 16-byte GLOBAL loads per thread (the slice GEMVs' finishing kernel) next to the same sums as scalar v_add_f32. */
+int dd_tools_pkadd_gload_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
 int dd_tools_pk_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
 int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int* errors_dev, void* stream);
 int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,

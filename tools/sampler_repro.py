@@ -215,7 +215,7 @@ def lds_full_probe(beside: bool, rounds: int, lib=None, rows: int = 64, lds_byte
             "first_bad_byte": None if not e[1] else e[2] * 4, "last_bad_byte": None if not e[1] else e[3] * 4 + 3, "seconds": round(time.time() - t0, 1)}
 
 
-def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64, pv: bool = False) -> dict:
+def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64, pv=False) -> dict:
     """Packed vs scalar FP32 multiply-add chains (dd_tools_pk_probe; pv: the tile pass's own P.V step, dd_tools_pv_probe) alone / beside slice GEMVs."""
     lib = lib or _lib.load_tools()
     err = torch.zeros(4, dtype=torch.int32, device="cuda")
@@ -225,7 +225,8 @@ def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64, pv: bool = Fal
 
     def body():
         for r in range(rounds):
-            rc = (lib.dd_tools_pv_probe(16, 3072, 16, err.data_ptr(), st.cuda_stream) if pv
+            rc = (lib.dd_tools_pkadd_gload_probe(16, 3072, 16, err.data_ptr(), st.cuda_stream) if pv == "gload" else
+                  lib.dd_tools_pv_probe(16, 3072, 16, err.data_ptr(), st.cuda_stream) if pv
                   else lib.dd_tools_pk_probe(16, 3072, 512, err.data_ptr(), st.cuda_stream))
             assert rc == 0, lib.dd_last_error()
             st.synchronize()
@@ -239,7 +240,7 @@ def pk_probe(beside: bool, rounds: int, lib=None, rows: int = 64, pv: bool = Fal
     else:
         body()
         company = 0
-    return {"test": "pv_step_probe" if pv else "packed_fp32_probe", "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16, "workgroups_per_launch": 3072,
+    return {"test": "packed_add_of_global_loads_probe" if pv == "gload" else ("pv_step_probe" if pv else "packed_fp32_probe"), "beside_gemvs_of_rows": rows if beside else 0, "probe_launches": rounds * 16, "workgroups_per_launch": 3072,
             "lanes_checked": rounds * 16 * 3072 * 256, "company_gemv_launches": company, "lanes_with_wrong_packed_result": int(err[0].item()),
             "seconds": round(time.time() - t0, 1)}
 
@@ -291,7 +292,7 @@ if __name__ == "__main__":
     for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16)):
         out.append(lds_probe(beside, rounds, lib, rows=rows or 64))
         print(json.dumps(out[-1]), flush=True)
-    for pv in (True, False):
+    for pv in (True, "gload", False):
         for beside, rows in ((False, 0), (True, 64), (True, 32), (True, 16), (True, 72)):
             out.append(pk_probe(beside, rounds, lib, rows=rows or 64, pv=pv))
             print(json.dumps(out[-1]), flush=True)
