@@ -605,3 +605,4 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8c(SliceArgs a) {
     for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)q * n_tiles + g) * NG + h) << 7) + l32 * 4] = acc[h];
   }
 }
+

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__
   int row = blockIdx.x;
   const float* xr = x + (size_t)(row_index ? row_index[row] : row) * d;
   float ss = 0.f;
-  for (int i = threadIdx.x; i < d; i += 256) ss += xr[i] * xr[i];
+  for (int i = threadIdx.x; i < d; i += 256) ss = __builtin_fmaf(xr[i], xr[i], ss);
   ss = dd_wave_sum(ss);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
   __syncthreads();
@@ -44,8 +44,104 @@ __global__ __launch_bounds__(256) void k_rmsnorm_split(const float* __restrict__
     }
   }
 }
+// The same values for SIXTEEN rows per workgroup (one row of operand tiles): k_rmsnorm_split's 16-byte stores of one row land in 512
+// different 1 KiB tiles — 16 of a tile's 64 pieces come from 16 workgroups at 16 different times, and the planes reached HBM at 1.3 TB/s
+// (72 us for the 2960 x 4096 rows of a NeXT prompt, 2.7 % of config 5; round 4).  Here a wave writes whole tiles, 1 KiB per store.
+// Bit for bit k_rmsnorm_split: a row's sum of squares is its 256 partial sums (element t + 256 j into partial t, j ascending, fused
+// multiply-add) reduced by the xor butterfly 32 .. 1 within each 64 and the four results added in order — lane L of the row's wave holds
+// partials 4 L .. 4 L + 3, so the butterfly's steps 32 .. 4 are lane steps 8 .. 1 and its steps 2, 1 are register pairs (additions commute,
+// every partner pair forms the same sum) —, and y = w * (x * rstd) is the same expression.  d % 256 == 0; rows beyond M untouched.
+__global__ __launch_bounds__(512) void k_rmsnorm_split16(const float* __restrict__ x, int M, int d, const float* __restrict__ w, float eps,
+                                                         uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int wf) {
+  __shared__ float sh_rstd[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 16;
+  const int nj = d >> 8;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = row0 + 2 * wave + rr;
+    if (row < M) {
+      const f32x4_t* xr = (const f32x4_t*)(x + (size_t)row * d) + lane;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int j0 = 0; j0 < nj; j0 += 8) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < nj) v[u] = xr[(size_t)(j0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < nj) {
+            s0 = __builtin_fmaf(v[u].x, v[u].x, s0);
+            s1 = __builtin_fmaf(v[u].y, v[u].y, s1);
+            s2 = __builtin_fmaf(v[u].z, v[u].z, s2);
+            s3 = __builtin_fmaf(v[u].w, v[u].w, s3);
+          }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+        s3 += __shfl_xor(s3, o);
+      }
+      const float a0 = s0 + s2, a1 = s1 + s3;            // butterfly step 2: partial t with t ^ 2
+      const float q = a0 + a1;                           // step 1; lanes 16 v .. 16 v + 15 hold the sum of partials 64 v .. 64 v + 63
+      const float q0 = __shfl(q, 0), q1 = __shfl(q, 16), q2 = __shfl(q, 32), q3 = __shfl(q, 48);
+      if (lane == 0) sh_rstd[2 * wave + rr] = 1.0f / sqrtf((q0 + q1 + q2 + q3) / (float)d + eps);
+    }
+  }
+  __syncthreads();
+  const int S = d >> 5;
+  const int r = lane & 15, hq = lane >> 4;
+  const int row = row0 + r;
+  if (row >= M) return;
+  const float rstd = sh_rstd[r];
+  const float* xr = x + (size_t)row * d + 8 * hq;
+  const float* wr = w + 8 * hq;
+  u32x4_t* th = (u32x4_t*)hi + (size_t)blockIdx.x * S * 64 + lane;
+  u32x4_t* tl = (u32x4_t*)lo + (size_t)blockIdx.x * S * 64 + lane;
+  for (int ks0 = wave; ks0 < S; ks0 += 8 * 4) {
+    f32x4_t xa[4][2], wa[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ks = ks0 + 8 * u;
+      if (ks < S) {
+        xa[u][0] = *(const f32x4_t*)(xr + ks * 32);
+        xa[u][1] = *(const f32x4_t*)(xr + ks * 32 + 4);
+        wa[u][0] = *(const f32x4_t*)(wr + ks * 32);
+        wa[u][1] = *(const f32x4_t*)(wr + ks * 32 + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ks = ks0 + 8 * u;
+      if (ks < S) {
+        uint32_t hh[8], ll[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float y = wa[u][j >> 2][j & 3] * (xa[u][j >> 2][j & 3] * rstd);
+          dd_split(y, hh[j], ll[j], wf);
+        }
+        u32x4_t vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vh[j] = hh[2 * j] | (hh[2 * j + 1] << 16);
+          vl[j] = ll[2 * j] | (ll[2 * j + 1] << 16);
+        }
+        th[(size_t)ks * 64] = vh;
+        tl[(size_t)ks * 64] = vl;
+      }
+    }
+  }
+}
+int g_rmsnorm16 = 1;             // dd_tools_set_tuning key 45: 0 = one row per workgroup everywhere (the round-1..3 kernel)
 int ddk_rmsnorm_split(const float* x, int M, int d, const float* w, float eps, uint16_t* hi, uint16_t* lo,
                       const int32_t* row_index, float* normed, hipStream_t st, int wf) {
+  if (g_rmsnorm16 && hi && lo && !row_index && !normed && (d & 255) == 0 && M >= 64) {
+    k_rmsnorm_split16<<<(M + 15) / 16, 512, 0, st>>>(x, M, d, w, eps, hi, lo, wf);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   k_rmsnorm_split<<<M, 256, 0, st>>>(x, d, w, eps, hi, lo, row_index, normed, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
@@ -724,6 +820,204 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* qbuf, co
   }
 }
 
+// -----------------------------------------------------------------------------------------------
+// The same attention for the fp16 cache and heads of 128 with the K / V tiles staged as MFMA OPERANDS (round 4).  k_attn_prefill_mfma stages
+// a tile as fp32 and every wave splits it hi + lo again for its own 16 queries: ~800 of the ~1,000 vector instructions a wave spends per
+// 32 keys, and the V^T pieces by 4-byte LDS reads — 0.23 PFLOP/s at 2,960 positions (config 5: 938 us per layer, a sixth of the run).
+// Here the staging threads split each value ONCE (the same dd_split_hl of the same fp32 value: the same operand bits) and write the A
+// pieces where the waves read them with one ds_read_b128 each:
+//   Kop[kt][ks][hi|lo][lane (g4 << 4) | c16] = key 16 kt + c16, d 32 ks + 8 g4 .. + 8   — one 16-byte chunk of the cache's [d/8][T][8]
+//   Vop[dt][hi|lo][lane (g4 << 4) | c16]     = d 16 dt + c16, key slots {4 g4 + j, 16 + 4 g4 + j}; an octet of the cache's [T/8][d][8] is the
+//                                              4-slot halves of two lanes
+// and a wave owns QB blocks of 16 queries that share every operand read (QB = 2: half the LDS bytes per flop).  Per 16-query block the MFMA
+// sequence, the softmax and the skipping of key tiles beyond the block are k_attn_prefill_mfma's, so a row's output has the same bits.
+// The heaviest workgroups (last queries of a causal prompt) are scheduled first.
+// -----------------------------------------------------------------------------------------------
+template <int G, int QB>
+__global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads,
+                                                             uint16_t* o_hi, uint16_t* o_lo, const uint8_t* __restrict__ drop_plane, int drop_bit,
+                                                             int span_start, int span_len, int q0, float scaling, int wf,
+                                                             const SeqTab* tab, int seq_rows, size_t off_k, size_t off_v) {
+  constexpr int HD = 128, KS = 4, DT = 8, C8 = 16;
+  constexpr int QW = 16 * QB, QG = 4 * QW;
+  const int by = gridDim.y - 1 - blockIdx.y;
+  if (tab) {
+    const int sq = blockIdx.z;
+    T = tab->T[sq];
+    if (by * QG >= T) return;
+    kc = tab->kc[sq] + off_k, vc = tab->vc[sq] + off_v;
+    const size_t r0 = (size_t)sq * seq_rows * (n_heads * HD);
+    qbuf += r0, o_hi += r0, o_lo += r0;
+  }
+  __shared__ u32x4_t Kop[2][KS][2][64];
+  __shared__ u32x4_t Vop[DT][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int head = blockIdx.x, kvh = head / G;
+  const int q_dim = n_heads * HD;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int shift = q0 & 15;
+  const int blk_first = by * QG - shift;
+  const int blk_last = min(blk_first + QG - 1, T - 1);
+  if (blk_last < 0) return;
+  const int p_max = q0 + blk_last;
+  int t_q[QB], pos_q[QB], qb_pmax[QB];
+  bool qb_live[QB];
+  u32x4_t qh[QB][KS], ql[QB][KS];
+  f32x4_t acc[QB][DT];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int first = blk_first + wave * QW + qb * 16;
+    t_q[qb] = first + c16;
+    pos_q[qb] = q0 + max(0, min(t_q[qb], T - 1));
+    qb_pmax[qb] = q0 + min(first + 15, T - 1);
+    qb_live[qb] = first < T && first + 15 >= 0;
+    const float* qr = qbuf + (size_t)max(0, min(t_q[qb], T - 1)) * q_dim + head * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float v[8];
+      *(f32x4_t*)&v[0] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8);
+      *(f32x4_t*)&v[4] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8 + 4);
+      fa_split8(v, qh[qb][ks], ql[qb][ks]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[qb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    m_run[qb] = -INFINITY, l_run[qb] = 0.f;
+  }
+  for (int t0 = 0; t0 <= p_max; t0 += FA_KEYS) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + 256 * it;
+      {
+        const int kk = i & 31, c = i >> 5;
+        const int key = min(t0 + kk, p_max);
+        const f16x8_t kh = *(const f16x8_t*)((const dd_half*)kc + (((size_t)kvh * C8 + c) * T_cap + key) * 8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)kh[j];
+        u32x4_t hi, lo;
+        fa_split8(v, hi, lo);
+        const int ln = ((c & 3) << 4) | (kk & 15);
+        Kop[kk >> 4][c >> 2][0][ln] = hi;
+        Kop[kk >> 4][c >> 2][1][ln] = lo;
+      }
+      {
+        const int dd = i & 127, oc = i >> 7;
+        const int octet = min((t0 >> 3) + oc, p_max >> 3);
+        const f16x8_t vh = *(const f16x8_t*)((const dd_half*)vc + (((size_t)kvh * (T_cap >> 3) + octet) * HD + dd) * 8);
+        uint32_t h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dd_split_hl((float)vh[j], h[j], l[j]);
+        const int half = oc >> 1, ga = (2 * oc) & 3;
+        uint32_t* ph0 = (uint32_t*)&Vop[dd >> 4][0][(ga << 4) | (dd & 15)] + 2 * half;
+        uint32_t* pl0 = (uint32_t*)&Vop[dd >> 4][1][(ga << 4) | (dd & 15)] + 2 * half;
+        *(u32x2_t*)ph0 = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *(u32x2_t*)pl0 = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+        *(u32x2_t*)(ph0 + 16 * 4) = (u32x2_t){h[4] | (h[5] << 16), h[6] | (h[7] << 16)};      // lane group ga + 1: 16 lanes of 16 bytes on
+        *(u32x2_t*)(pl0 + 16 * 4) = (u32x2_t){l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+      }
+    }
+    __syncthreads();
+    bool use[QB], any = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) use[qb] = qb_live[qb] && t0 <= qb_pmax[qb], any = any || use[qb];
+    if (!any) continue;
+    f32x4_t sacc[QB][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) sacc[qb][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4_t kh = Kop[kt][ks][0][lane], kl = Kop[kt][ks][1][lane];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          if (use[qb]) {
+            sacc[qb][kt] = FA_MFMA(kh, qh[qb][ks], sacc[qb][kt]);
+            sacc[qb][kt] = FA_MFMA(kl, qh[qb][ks], sacc[qb][kt]);
+            sacc[qb][kt] = FA_MFMA(kh, ql[qb][ks], sacc[qb][kt]);
+          }
+      }
+    }
+    u32x4_t ph[QB], pl[QB];
+    float corr[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      if (!use[qb]) continue;
+      float sv[8];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = t0 + kt * 16 + g4 * 4 + r;
+          bool ok = key <= pos_q[qb];
+          if (ok && drop_plane && key >= span_start && key < span_start + span_len) ok = !((drop_plane[key - span_start] >> drop_bit) & 1);
+          sv[kt * 4 + r] = ok ? sacc[qb][kt][r] * scaling : -INFINITY;
+        }
+      float mx = sv[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sv[j]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qb], mx);
+      float p[8], ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p[j] = (sv[j] == -INFINITY) ? 0.f : expf(sv[j] - m_new);
+        ps += p[j];
+      }
+      ps += __shfl_xor(ps, 16);
+      ps += __shfl_xor(ps, 32);
+      corr[qb] = (m_run[qb] == -INFINITY) ? 0.f : expf(m_run[qb] - m_new);
+      l_run[qb] = l_run[qb] * corr[qb] + ps;
+      m_run[qb] = m_new;
+      fa_split8(p, ph[qb], pl[qb]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const u32x4_t vh = Vop[dt][0][lane], vl = Vop[dt][1][lane];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+        if (use[qb]) {
+          f32x4_t a = acc[qb][dt] * corr[qb];
+          a = FA_MFMA(vh, ph[qb], a);
+          a = FA_MFMA(vl, ph[qb], a);
+          a = FA_MFMA(vh, pl[qb], a);
+          acc[qb][dt] = a;
+        }
+    }
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    if (!(t_q[qb] >= 0 && t_q[qb] < T)) continue;
+    const float inv = 1.0f / l_run[qb];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      uint32_t hh[4], ll[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dd_split(acc[qb][dt][r] * inv, hh[r], ll[r], wf);
+      const size_t o = apack_off(t_q[qb], head * HD + dt * 16 + g4 * 4, q_dim >> 5);
+      *(u32x2_t*)(o_hi + o) = (u32x2_t){hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
+      *(u32x2_t*)(o_lo + o) = (u32x2_t){ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
+    }
+  }
+}
+int g_prefill_attn16 = 2;         // dd_tools_set_tuning key 46: query blocks per wave of k_attn_prefill_mfma16 (1 / 2); 0 = k_attn_prefill_mfma<G, 128, 1>
+template <int QB>
+static int launch_prefill_mfma16(int G, dim3 grid, hipStream_t st, const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads,
+                                 uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start, int span_len, int q0,
+                                 int wf, const SeqTab* tab, int seq_rows, size_t off_k, size_t off_v) {
+#define F16_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 0.08838834764831845f, wf, tab, seq_rows, off_k, off_v
+  if (G == 1) k_attn_prefill_mfma16<1, QB><<<grid, 256, 0, st>>>(F16_ARGS);
+  else if (G == 2) k_attn_prefill_mfma16<2, QB><<<grid, 256, 0, st>>>(F16_ARGS);
+  else if (G == 4) k_attn_prefill_mfma16<4, QB><<<grid, 256, 0, st>>>(F16_ARGS);
+  else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
+#undef F16_ARGS
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 // bidirectional attention of the CLIP tower (head_dim 64, q pre-scaled by the QKV epilogue), same kernel
 int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, int Tc, int n_heads, uint16_t* o_hi, uint16_t* o_lo,
                       hipStream_t st, int head_pitch, int Tk, float scaling) {
@@ -785,6 +1079,13 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
   if (g_prefill_mfma) {
     dim3 g2(n_heads, (T + (q0 & 15) + 63) / 64);
 #define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f, wf, T
+    if (kv16 && g_prefill_attn16) {
+      const int qg = 64 * (g_prefill_attn16 == 1 ? 1 : 2);
+      dim3 g3(n_heads, (T + (q0 & 15) + qg - 1) / qg);
+      if (g_prefill_attn16 == 1)
+        return launch_prefill_mfma16<1>(G, g3, st, qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, nullptr, 0, 0, 0);
+      return launch_prefill_mfma16<2>(G, g3, st, qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, nullptr, 0, 0, 0);
+    }
     if (kv16) {
       if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
       else if (G == 2) k_attn_prefill_mfma<2, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
@@ -814,6 +1115,13 @@ int ddk_attn_prefill_seqs(const float* qbuf, const SeqTab* tab, size_t off_k, si
   DD_REQUIRE(g_prefill_mfma, "attn_prefill_seqs: the matrix-core prefill attention is switched off");
   dim3 g2(n_heads, (max_T + 63) / 64, n);
 #define FS_ARGS qbuf, nullptr, nullptr, max_T, T_cap, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 1, 0.08838834764831845f, wf, max_T, tab, seq_rows, off_k, off_v
+  if (kv16 && g_prefill_attn16) {
+    const int qg = 64 * (g_prefill_attn16 == 1 ? 1 : 2);
+    dim3 g3(n_heads, (max_T + qg - 1) / qg, n);
+    if (g_prefill_attn16 == 1)
+      return launch_prefill_mfma16<1>(G, g3, st, qbuf, nullptr, nullptr, max_T, T_cap, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, wf, tab, seq_rows, off_k, off_v);
+    return launch_prefill_mfma16<2>(G, g3, st, qbuf, nullptr, nullptr, max_T, T_cap, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, wf, tab, seq_rows, off_k, off_v);
+  }
   if (kv16) {
     if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FS_ARGS);
     else if (G == 2) k_attn_prefill_mfma<2, 128, 1><<<g2, 256, 0, st>>>(FS_ARGS);
