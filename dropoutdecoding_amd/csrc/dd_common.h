@@ -71,6 +71,17 @@ __device__ __forceinline__ void dd_split_hl(float x, uint32_t& hi, uint32_t& lo)
   hi = dd_bf16_rn(x);
   lo = dd_bf16_rn(x - dd_bf16_to_f32(hi));
 }
+// Two values at once on gfx950's packed convert: v_cvt_pk_bf16_f32 rounds to nearest even like dd_bf16_rn (finite inputs), so hi / lo are the
+// bits dd_split_hl gives — as packed pairs (a in the low half), 6 vector instructions instead of 18 (round 4: the prefill attention spent
+// more of its time splitting operands than on the matrix cores).
+typedef __bf16 dd_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float dd_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void dd_split_hl2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const dd_f32x2_t v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dd_bf16x2_t));
+  const dd_f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, dd_bf16x2_t));
+}
 // The same for engines that keep fp16 weights (weight_format 2: fp16-native checkpoints stay exact — the reference loads
 // every model with torch_dtype=float16, chair_test/chair_test.py:189-213): operands of the f16 MFMA.  hi + lo carries
 // ~22 mantissa bits; |x| beyond fp16's range saturates (the reference's own fp16 activations live in that range).

@@ -651,6 +651,14 @@ __device__ __forceinline__ void fa_split8(const float* v, u32x4_t& hi, u32x4_t& 
   hi = (u32x4_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
   lo = (u32x4_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
 }
+__device__ __forceinline__ void fa_split8p(const float* v, u32x4_t& hi, u32x4_t& lo) {      // fa_split8's bits by packed converts
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t h, l;
+    dd_split_hl2(v[2 * j], v[2 * j + 1], h, l);
+    hi[j] = h, lo[j] = l;
+  }
+}
 #define FA_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, B), C, 0, 0, 0)
 
 // HD = head dimension (128: the LM; 64: the CLIP tower, bidirectional, q pre-scaled)
@@ -878,12 +886,26 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
       float v[8];
       *(f32x4_t*)&v[0] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8);
       *(f32x4_t*)&v[4] = *(const f32x4_t*)(qr + ks * 32 + g4 * 8 + 4);
-      fa_split8(v, qh[qb][ks], ql[qb][ks]);
+      fa_split8p(v, qh[qb][ks], ql[qb][ks]);
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[qb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     m_run[qb] = -INFINITY, l_run[qb] = 0.f;
   }
+  // the staging thread's pieces of a tile: K chunk (key kk, d-chunk c) and V octet (dimension dd, octet oc), two of each; the NEXT tile's are
+  // requested before this tile's products start, so the cache latency runs under the matrix-core work
+  f16x8_t kreg[2], vreg[2];
+  auto request = [&](int t0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i = tid + 256 * it;
+      const int key = min(t0 + (i & 31), p_max);
+      kreg[it] = *(const f16x8_t*)((const dd_half*)kc + (((size_t)kvh * C8 + (i >> 5)) * T_cap + key) * 8);
+      const int octet = min((t0 >> 3) + (i >> 7), p_max >> 3);
+      vreg[it] = *(const f16x8_t*)((const dd_half*)vc + (((size_t)kvh * (T_cap >> 3) + octet) * HD + (i & 127)) * 8);
+    }
+  };
+  request(0);
   for (int t0 = 0; t0 <= p_max; t0 += FA_KEYS) {
     __syncthreads();
 #pragma unroll
@@ -891,33 +913,30 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
       const int i = tid + 256 * it;
       {
         const int kk = i & 31, c = i >> 5;
-        const int key = min(t0 + kk, p_max);
-        const f16x8_t kh = *(const f16x8_t*)((const dd_half*)kc + (((size_t)kvh * C8 + c) * T_cap + key) * 8);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)kh[j];
+        for (int j = 0; j < 8; ++j) v[j] = (float)kreg[it][j];
         u32x4_t hi, lo;
-        fa_split8(v, hi, lo);
+        fa_split8p(v, hi, lo);
         const int ln = ((c & 3) << 4) | (kk & 15);
         Kop[kk >> 4][c >> 2][0][ln] = hi;
         Kop[kk >> 4][c >> 2][1][ln] = lo;
       }
       {
         const int dd = i & 127, oc = i >> 7;
-        const int octet = min((t0 >> 3) + oc, p_max >> 3);
-        const f16x8_t vh = *(const f16x8_t*)((const dd_half*)vc + (((size_t)kvh * (T_cap >> 3) + octet) * HD + dd) * 8);
-        uint32_t h[8], l[8];
+        uint32_t h[4], l[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dd_split_hl((float)vh[j], h[j], l[j]);
+        for (int j = 0; j < 4; ++j) dd_split_hl2((float)vreg[it][2 * j], (float)vreg[it][2 * j + 1], h[j], l[j]);
         const int half = oc >> 1, ga = (2 * oc) & 3;
         uint32_t* ph0 = (uint32_t*)&Vop[dd >> 4][0][(ga << 4) | (dd & 15)] + 2 * half;
         uint32_t* pl0 = (uint32_t*)&Vop[dd >> 4][1][(ga << 4) | (dd & 15)] + 2 * half;
-        *(u32x2_t*)ph0 = (u32x2_t){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-        *(u32x2_t*)pl0 = (u32x2_t){l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
-        *(u32x2_t*)(ph0 + 16 * 4) = (u32x2_t){h[4] | (h[5] << 16), h[6] | (h[7] << 16)};      // lane group ga + 1: 16 lanes of 16 bytes on
-        *(u32x2_t*)(pl0 + 16 * 4) = (u32x2_t){l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+        *(u32x2_t*)ph0 = (u32x2_t){h[0], h[1]};
+        *(u32x2_t*)pl0 = (u32x2_t){l[0], l[1]};
+        *(u32x2_t*)(ph0 + 16 * 4) = (u32x2_t){h[2], h[3]};      // lane group ga + 1: 16 lanes of 16 bytes on
+        *(u32x2_t*)(pl0 + 16 * 4) = (u32x2_t){l[2], l[3]};
       }
     }
+    if (t0 + FA_KEYS <= p_max) request(t0 + FA_KEYS);
     __syncthreads();
     bool use[QB], any = false;
 #pragma unroll
@@ -972,7 +991,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
       corr[qb] = (m_run[qb] == -INFINITY) ? 0.f : expf(m_run[qb] - m_new);
       l_run[qb] = l_run[qb] * corr[qb] + ps;
       m_run[qb] = m_new;
-      fa_split8(p, ph[qb], pl[qb]);
+      fa_split8p(p, ph[qb], pl[qb]);
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -1003,7 +1022,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
     }
   }
 }
-int g_prefill_attn16 = 2;         // dd_tools_set_tuning key 46: query blocks per wave of k_attn_prefill_mfma16 (1 / 2); 0 = k_attn_prefill_mfma<G, 128, 1>
+int g_prefill_attn16 = 1;         // dd_tools_set_tuning key 46: query blocks per wave of k_attn_prefill_mfma16 (1 / 2); 0 = k_attn_prefill_mfma<G, 128, 1>
 template <int QB>
 static int launch_prefill_mfma16(int G, dim3 grid, hipStream_t st, const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads,
                                  uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start, int span_len, int q0,

@@ -18,6 +18,23 @@ if [ "$WHAT" = stats ]; then
   rm -rf /tmp/${R}_stats
   tail -1 $OUT/${R}_bench_under_rocprof.log | cut -c1-200
   head -32 $OUT/${R}_kernel_stats.csv | cut -c1-160
+elif [ "$WHAT" = stats5 ]; then
+  # BASELINE config 5 (LLaVA-NeXT-Mistral-7B shapes, fp8 matrices): one batch of 32 images, 16 new tokens each
+  rm -rf /tmp/${R}_stats5
+  timeout 1000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_stats5 -- python3 bench.py --config 5 --steps 1 --warmup 0 --n-new 16 --no-cpu-baseline --no-roofline --single-images 0 > $OUT/${R}_c5_bench_under_rocprof.log 2>&1
+  echo "rocprof rc=$?"
+  f=$(find /tmp/${R}_stats5 -name "*kernel_stats.csv" | head -1)
+  head -60 "$f" > $OUT/${R}_c5_kernel_stats.csv
+  rm -rf /tmp/${R}_stats5
+  head -24 $OUT/${R}_c5_kernel_stats.csv | cut -c1-160
+elif [ "$WHAT" = pmc5 ]; then
+  for c in FETCH_SIZE:fetch WRITE_SIZE:write; do
+    rm -rf /tmp/${R}_pmc5_${c##*:}
+    timeout 500 rocprofv3 --pmc ${c%%:*} --kernel-trace --output-format csv -d /tmp/${R}_pmc5_${c##*:} -- python3 bench.py --config 5 --steps 1 --warmup 0 --n-new 3 --images-per-gpu 16 --no-cpu-baseline --no-roofline --single-images 0 > $OUT/${R}_c5_pmc_${c##*:}.log 2>&1
+    echo "pmc ${c%%:*} rc=$?"
+  done
+  python3 tools/pmc_summary.py /tmp/${R}_pmc5_fetch /tmp/${R}_pmc5_write > $OUT/${R}_c5_pmc_summary.json
+  rm -rf /tmp/${R}_pmc5_fetch /tmp/${R}_pmc5_write
 else
   for c in FETCH_SIZE:fetch WRITE_SIZE:write SQ_VALU_MFMA_BUSY_CYCLES:mfma; do
     rm -rf /tmp/${R}_pmc_${c##*:}
