@@ -43,7 +43,16 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * qkv / gate-up kernels (4 or 8, default 4), 30 half planes for K <= 4 (two sequences per operand plane, default 1), 31 half planes
  * before the rider form where both apply and the line-up is not whole groups of fourteen (default 1), 33 the rider form's rings in stages with
  * the masks of the groups whose rows rode sampled between the stages on the caller's stream (default 1; 0: on the branches), 34 the lanes
- * mask sampler in its round-3 form (a private-scratch copy of its parameters, 616 bytes per lane; default 0).  Keys of
+ * mask sampler in its round-3 form (a private-scratch copy of its parameters, 616 bytes per lane; default 0).
+ * Round 4: 36 default-policy instead of non-temporal weight loads in the slice GEMVs (default 0), 38 the GQA decode attention with all q heads
+ * of a kv head in one workgroup (default 0: two heads per workgroup), 45 prefill RMSNorm + split with sixteen rows per workgroup (default 1;
+ * 0: one row per workgroup), 46 prefill attention over the fp16 cache with operand-staged K / V tiles and 1 or 2 query blocks per wave
+ * (default 1; 0: the fp32-staged kernel).  Keys of the determinism bisect (all default to the product's behaviour): 37 fp32-cache
+ * engines fork their member sweeps (-1: one branch as in round 3), 39 extra dynamic LDS bytes requested by the fp32-cache attention tile pass
+ * (so that it cannot share a CU with a slice GEMV), 40 the branches' streams on disjoint CU masks, 41 CU-mask only the attention launches,
+ * 42 bit mask of kernel families launched on the UNMASKED stream while 40 is on (1 embed, 2 GEMVs, 4 attention, 8 finishing kernels),
+ * 43 the fp32-cache tile pass with scalar instead of packed FP32 multiply-adds in its P.V step (tools library only: the product library has
+ * no packed FP32 at all).  Keys of
  * dd_set_tuning are forwarded.  Every call starts a new epoch of the step-graph
  * keys: a step captured under other settings is never replayed. */
 int dd_tools_set_tuning(int key, int value);

@@ -18,4 +18,6 @@ DD_STRESS_K=4 timeout 900 python tools/stress_lanes.py 56 ${HP_REPS:-30} 100 > $
 timeout 900 python tools/stress_lanes.py 32 ${CLASSIC_REPS:-30} 100 "26=0" > $O/classic_k8_32.log 2>&1
 # InstructBLIP (quantile masks, vote on the hidden state), 64 lanes
 DD_STRESS_FAMILY=iblip timeout 900 python tools/stress_lanes.py 64 ${IBLIP_REPS:-30} 100 > $O/iblip_k8_64.log 2>&1
+# fp32 cache, classic form on two branches, 16 lanes (round 3 kept these on one branch)
+DD_STRESS_KV=fp32 timeout 900 python tools/stress_lanes.py 16 ${FP32_REPS:-30} 100 > $O/classic_fp32_16.log 2>&1
 tail -n 2 $O/*.log
