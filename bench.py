@@ -360,9 +360,9 @@ def main() -> int:
     ddcfg.settings["voting_numbers"] = list(probs)
     K_eff = 0 if args.original else len(probs)
     if args.images_per_gpu is None:
-        args.images_per_gpu = 32 if args.config == 5 else (56 if args.config == 2 else 64)     # K = 4: whole groups of fourteen
+        args.images_per_gpu = 56 if args.config == 2 else 64     # K = 4: whole groups of fourteen
     if args.prefill_chunk is None:
-        args.prefill_chunk = 2 if args.config == 5 else 16
+        args.prefill_chunk = 4 if args.config == 5 else 16     # config 5: 4 x 3072 rows per pass over the (fp8-expanded) weights
     B = 1 if args.mode == "kshard" else max(1, min(64, args.images_per_gpu))
 
     def barrier():

@@ -728,8 +728,9 @@ static int prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, i
 // (608 rows alone are five blocks: 0.81 PFLOP/s; thousands of rows: 1.05).  Rows are independent in every kernel of
 // the prefill except the attention, which runs per sequence as before; each accumulator tile sees the MFMA sequence of
 // the one-sequence prefill, so every sequence's logits, scores, first token and cache are bit-identical to
-// dd_lm_prefill on it alone.  fp8 weights, different cache capacities or a batch too small for the large blocks fall
-// back to one dd_lm_prefill per sequence.
+// dd_lm_prefill on it alone.  fp8 matrices are expanded to bf16 tiles once per BATCH and matrix (round 4; one prefill per sequence
+// expanded every matrix per sequence: 2 % of config 5).  Different cache capacities or a batch too small for the large blocks fall back to
+// one dd_lm_prefill per sequence.
 // -----------------------------------------------------------------------------------------------
 extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* const* embeds, const int32_t* T0s,
                                    const int32_t* span_starts, const int32_t* span_lens, void* stream_) {
@@ -738,7 +739,7 @@ extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* cons
   dd_lm* h0 = lanes[0];
   DD_REQUIRE(h0, "dd_lm_prefill_group: null handle");
   dd_lm* owner = h0->wsrc ? h0->wsrc : h0;
-  bool batched = !h0->fp8 && n > 1;
+  bool batched = n > 1;
   int maxT = 0;
   for (int i = 0; i < n; ++i) {
     dd_lm* q = lanes[i];
@@ -802,13 +803,23 @@ extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* cons
   DD_HIP(hipMemsetAsync(bx, 0, M * d * 4, st));            // padding rows: zeros (finite everywhere downstream, never stored)
   for (int i = 0; i < n; ++i)
     DD_HIP(hipMemcpyAsync(bx + (size_t)i * seq_rows * d, embeds[i], (size_t)T0s[i] * d * 4, hipMemcpyDeviceToDevice, st));
+  auto wsel = [&](GemmArgs& g, u32x4_t* W, float* scale, int n_tiles, int S) -> int {      // as in prefill_layers
+    if (!h0->fp8) {
+      g.W = W;
+      return DD_OK;
+    }
+    int rc = ddk_dequant_tiles(W, h0->deq_tmp, n_tiles, S, st);
+    g.W = h0->deq_tmp, g.wscale = scale;
+    return rc;
+  };
   for (int l = 0; l < h0->Lyr; ++l) {
     LayerW& w = h0->lw[l];
     RC(ddk_rmsnorm_split(bx, (int)M, d, w.norm1, h0->cfg.rms_eps, b1h, b1l, nullptr, nullptr, st, h0->wf));
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.wf = h0->wf;
-    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_d, g.n_tiles = h0->qkv_tiles, g.W = w.wqkv;
+    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_d, g.n_tiles = h0->qkv_tiles;
+    RC(wsel(g, w.wqkv, w.s_qkv, h0->qkv_tiles, h0->S_d));
     g.qbuf = bq, g.T_cap = h0->T_cap, g.q_tiles = h0->q_tiles, g.k_tiles = h0->k_tiles, g.q_dim = h0->q_dim, g.kv_dim = h0->kv_dim;
     g.pos0 = 0, g.kv16 = h0->kv16, g.rope_cos = h0->rope_cos, g.rope_sin = h0->rope_sin;
     g.seq_rows = seq_rows, g.seq_tab = h0->seq_tab, g.seq_off_k = (size_t)l * h0->lsk, g.seq_off_v = (size_t)l * h0->lsv;
@@ -826,17 +837,20 @@ extern "C" int dd_lm_prefill_group(dd_lm* const* lanes, int n, const float* cons
     }
     memset(&g, 0, sizeof(g));
     g.wf = h0->wf;
-    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_q, g.n_tiles = d / 16, g.out = bx, g.ldo = d, g.W = w.wo;
+    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_q, g.n_tiles = d / 16, g.out = bx, g.ldo = d;
+    RC(wsel(g, w.wo, w.s_o, d / 16, h0->S_q));
     RC(ddk_gemm(EPI_RESID, g, st));
     RC(ddk_rmsnorm_split(bx, (int)M, d, w.norm2, h0->cfg.rms_eps, b1h, b1l, nullptr, nullptr, st, h0->wf));
     memset(&g, 0, sizeof(g));
     g.wf = h0->wf;
-    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_d, g.n_tiles = 2 * dff / 16, g.W = w.wgu;
+    g.a_hi = b1h, g.a_lo = b1l, g.M = (int)M, g.S = h0->S_d, g.n_tiles = 2 * dff / 16;
+    RC(wsel(g, w.wgu, w.s_gu, 2 * dff / 16, h0->S_d));
     g.o_hi = b2h, g.o_lo = b2l, g.ld_planes = dff;
     RC(ddk_gemm(EPI_SILU, g, st));
     memset(&g, 0, sizeof(g));
     g.wf = h0->wf;
-    g.a_hi = b2h, g.a_lo = b2l, g.M = (int)M, g.S = h0->S_ff, g.n_tiles = d / 16, g.out = bx, g.ldo = d, g.W = w.wdown;
+    g.a_hi = b2h, g.a_lo = b2l, g.M = (int)M, g.S = h0->S_ff, g.n_tiles = d / 16, g.out = bx, g.ldo = d;
+    RC(wsel(g, w.wdown, w.s_down, d / 16, h0->S_ff));
     RC(ddk_gemm(EPI_RESID, g, st));
   }
   for (int i = 0; i < n; ++i) RC(prefill_tail(lanes[i], bx + (size_t)i * seq_rows * d, T0s[i], span_starts[i], span_lens[i], st));

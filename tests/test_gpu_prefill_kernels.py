@@ -7,7 +7,7 @@ models/llava.py:294-303; first-token ensemble :336-337):
   wave — and one or two 16-query blocks per wave, against the kernel that stages fp32 tiles (tools key 46 = 2 / 1 / 0).
 
 Compared after every form of prefill that reaches them: one prompt, prompts of several sequences as one matrix, an extension against the cache
-(queries at a non-zero position), the first-token ensemble (masked keys); MHA and GQA; bf16 and fp16 weights.  Engines in libdropdec_tools.so."""
+(queries at a non-zero position), the first-token ensemble (masked keys); MHA and GQA; bf16, fp16 and fp8 weights (fp8: the batch of prompts shares one bf16 expansion per matrix).  Engines in libdropdec_tools.so."""
 import numpy as np
 import pytest
 import torch
@@ -27,7 +27,8 @@ def _same(a, b):
         assert np.array_equal(a[3][k], b[3][k], equal_nan=True), k
 
 
-@pytest.mark.parametrize("d,H,Hkv,T0,fmt", [(256, 2, 2, 100, "bf16"), (512, 4, 2, 321, "fp16"), (512, 4, 1, 203, "bf16"), (4096, 32, 32, 129, "bf16")])
+@pytest.mark.parametrize("d,H,Hkv,T0,fmt", [(256, 2, 2, 100, "bf16"), (512, 4, 2, 321, "fp16"), (512, 4, 1, 203, "bf16"), (4096, 32, 32, 129, "bf16"),
+                                                (512, 4, 2, 421, "fp8")])
 def test_prefill_kernel_forms_leave_the_same_bits(d, H, Hkv, T0, fmt):
     from dropoutdecoding_amd import _lib, build
     build.build()
@@ -61,6 +62,11 @@ def test_prefill_kernel_forms_leave_the_same_bits(d, H, Hkv, T0, fmt):
             e.rng.manual_seed(9)
         lm.prefill_group(engs, embs, [(s0, L)] * 3)                    # three prompts as one matrix, ragged lengths
         rec += [_state(e) for e in engs]
+        if (norm16, attn16) == (1, 2):                                 # ... and each of them as its own prefill leaves it (fp8: one expansion per batch)
+            for e, x, grouped in zip(engs, embs, rec[-3:]):
+                e.rng.manual_seed(9)
+                e.prefill(x, s0, L)
+                _same(_state(e), grouped)
         eng.rng.manual_seed(9)
         eng.prefill(embs[0], s0, L, first_step_ensemble=True, mprobs=[0.3, 0.6])      # masked keys in the prompt pass
         rec.append(_state(eng))
