@@ -841,13 +841,17 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* qbuf, co
 // sequence, the softmax and the skipping of key tiles beyond the block are k_attn_prefill_mfma's, so a row's output has the same bits.
 // The heaviest workgroups (last queries of a causal prompt) are scheduled first.
 // -----------------------------------------------------------------------------------------------
-template <int G, int QB>
-__global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads,
+// HD = 128 (the LM), 64 / 96 (the vision towers: bidirectional, Tk keys, q pre-scaled); KV16: fp16 cache layouts, else the fp32 ones
+// (K transposed [d/4][T_cap][4], V [T_cap][HD]: fp32-cache engines and the towers' K / V buffers).
+template <int G, int QB, int HD = 128, int KV16 = 1>
+__global__ __launch_bounds__(256, QB == 1 ? ((KV16 || HD < 128) ? 4 : 3) : 2) void k_attn_prefill_mfma16(const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads,
                                                              uint16_t* o_hi, uint16_t* o_lo, const uint8_t* __restrict__ drop_plane, int drop_bit,
-                                                             int span_start, int span_len, int q0, float scaling, int wf,
+                                                             int span_start, int span_len, int q0, int causal, float scaling, int wf, int Tk,
                                                              const SeqTab* tab, int seq_rows, size_t off_k, size_t off_v) {
-  constexpr int HD = 128, KS = 4, DT = 8, C8 = 16;
+  constexpr int KS = HD / 32, DT = HD / 16, C8 = HD / 8, C4 = HD / 4;
   constexpr int QW = 16 * QB, QG = 4 * QW;
+  constexpr int NK = 32 * C8, NV = 4 * HD;                 // staging pieces per tile: K chunks (key, 8 d), V octets (8 keys, d)
+  constexpr int ITS = (NK + 255) / 256;
   const int by = gridDim.y - 1 - blockIdx.y;
   if (tab) {
     const int sq = blockIdx.z;
@@ -856,6 +860,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
     kc = tab->kc[sq] + off_k, vc = tab->vc[sq] + off_v;
     const size_t r0 = (size_t)sq * seq_rows * (n_heads * HD);
     qbuf += r0, o_hi += r0, o_lo += r0;
+    Tk = T;
   }
   __shared__ u32x4_t Kop[2][KS][2][64];
   __shared__ u32x4_t Vop[DT][2][64];
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
   const int blk_first = by * QG - shift;
   const int blk_last = min(blk_first + QG - 1, T - 1);
   if (blk_last < 0) return;
-  const int p_max = q0 + blk_last;
+  const int p_max = causal ? q0 + blk_last : Tk - 1;
   int t_q[QB], pos_q[QB], qb_pmax[QB];
   bool qb_live[QB];
   u32x4_t qh[QB][KS], ql[QB][KS];
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
     const int first = blk_first + wave * QW + qb * 16;
     t_q[qb] = first + c16;
     pos_q[qb] = q0 + max(0, min(t_q[qb], T - 1));
-    qb_pmax[qb] = q0 + min(first + 15, T - 1);
+    qb_pmax[qb] = causal ? q0 + min(first + 15, T - 1) : Tk - 1;
     qb_live[qb] = first < T && first + 15 >= 0;
     const float* qr = qbuf + (size_t)max(0, min(t_q[qb], T - 1)) * q_dim + head * HD;
 #pragma unroll
@@ -892,30 +897,51 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
     for (int dt = 0; dt < DT; ++dt) acc[qb][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     m_run[qb] = -INFINITY, l_run[qb] = 0.f;
   }
-  // the staging thread's pieces of a tile: K chunk (key kk, d-chunk c) and V octet (dimension dd, octet oc), two of each; the NEXT tile's are
-  // requested before this tile's products start, so the cache latency runs under the matrix-core work
-  f16x8_t kreg[2], vreg[2];
+  // the staging thread's pieces of a tile: K chunk (key kk = i & 31, d-chunk c = i >> 5) and V octet (dimension dd = i % HD, octet oc = i / HD);
+  // the NEXT tile's are requested before this tile's products start, so the cache latency runs under the matrix-core work
+  constexpr int RW = KV16 ? 1 : 2;                         // 16-byte registers per piece: 8 halves, or 8 floats
+  u32x4_t kraw[ITS][RW], vraw[ITS][RW];
   auto request = [&](int t0) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < ITS; ++it) {
       const int i = tid + 256 * it;
-      const int key = min(t0 + (i & 31), p_max);
-      kreg[it] = *(const f16x8_t*)((const dd_half*)kc + (((size_t)kvh * C8 + (i >> 5)) * T_cap + key) * 8);
-      const int octet = min((t0 >> 3) + (i >> 7), p_max >> 3);
-      vreg[it] = *(const f16x8_t*)((const dd_half*)vc + (((size_t)kvh * (T_cap >> 3) + octet) * HD + (i & 127)) * 8);
+      if (NK % 256 && i >= NK) break;
+      const int kk = i & 31, c = i >> 5, dd = i % HD, oc = i / HD;
+      const int key = min(t0 + kk, p_max);
+      if constexpr (KV16) {
+        kraw[it][0] = *(const u32x4_t*)((const dd_half*)kc + (((size_t)kvh * C8 + c) * T_cap + key) * 8);
+        const int octet = min((t0 >> 3) + oc, p_max >> 3);             // keys past p_max inside the last octet carry weight 0
+        vraw[it][0] = *(const u32x4_t*)((const dd_half*)vc + (((size_t)kvh * (T_cap >> 3) + octet) * HD + dd) * 8);
+      } else {
+        kraw[it][0] = *(const u32x4_t*)(kc + (((size_t)kvh * C4 + 2 * c) * T_cap + key) * 4);
+        kraw[it][1] = *(const u32x4_t*)(kc + (((size_t)kvh * C4 + 2 * c + 1) * T_cap + key) * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          vraw[it][j >> 2][j & 3] = __float_as_uint(vc[((size_t)kvh * T_cap + min(t0 + 8 * oc + j, p_max)) * HD + dd]);
+      }
+    }
+  };
+  auto piece = [&](const u32x4_t (&raw)[RW], float* v) {
+    if constexpr (KV16) {
+      const f16x8_t h = __builtin_bit_cast(f16x8_t, raw[0]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __uint_as_float(raw[j >> 2][j & 3]);
     }
   };
   request(0);
   for (int t0 = 0; t0 <= p_max; t0 += FA_KEYS) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < ITS; ++it) {
       const int i = tid + 256 * it;
+      if (NK % 256 && i >= NK) break;
       {
         const int kk = i & 31, c = i >> 5;
         float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)kreg[it][j];
+        piece(kraw[it], v);
         u32x4_t hi, lo;
         fa_split8p(v, hi, lo);
         const int ln = ((c & 3) << 4) | (kk & 15);
@@ -923,17 +949,18 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
         Kop[kk >> 4][c >> 2][1][ln] = lo;
       }
       {
-        const int dd = i & 127, oc = i >> 7;
-        uint32_t h[4], l[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dd_split_hl2((float)vreg[it][2 * j], (float)vreg[it][2 * j + 1], h[j], l[j]);
+        const int dd = i % HD, oc = i / HD;
+        float v[8];
+        piece(vraw[it], v);
+        u32x4_t hi, lo;
+        fa_split8p(v, hi, lo);
         const int half = oc >> 1, ga = (2 * oc) & 3;
         uint32_t* ph0 = (uint32_t*)&Vop[dd >> 4][0][(ga << 4) | (dd & 15)] + 2 * half;
         uint32_t* pl0 = (uint32_t*)&Vop[dd >> 4][1][(ga << 4) | (dd & 15)] + 2 * half;
-        *(u32x2_t*)ph0 = (u32x2_t){h[0], h[1]};
-        *(u32x2_t*)pl0 = (u32x2_t){l[0], l[1]};
-        *(u32x2_t*)(ph0 + 16 * 4) = (u32x2_t){h[2], h[3]};      // lane group ga + 1: 16 lanes of 16 bytes on
-        *(u32x2_t*)(pl0 + 16 * 4) = (u32x2_t){l[2], l[3]};
+        *(u32x2_t*)ph0 = (u32x2_t){hi[0], hi[1]};
+        *(u32x2_t*)pl0 = (u32x2_t){lo[0], lo[1]};
+        *(u32x2_t*)(ph0 + 16 * 4) = (u32x2_t){hi[2], hi[3]};      // lane group ga + 1: 16 lanes of 16 bytes on
+        *(u32x2_t*)(pl0 + 16 * 4) = (u32x2_t){lo[2], lo[3]};
       }
     }
     if (t0 + FA_KEYS <= p_max) request(t0 + FA_KEYS);
@@ -970,7 +997,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = t0 + kt * 16 + g4 * 4 + r;
-          bool ok = key <= pos_q[qb];
+          bool ok = causal ? key <= pos_q[qb] : key < Tk;
           if (ok && drop_plane && key >= span_start && key < span_start + span_len) ok = !((drop_plane[key - span_start] >> drop_bit) & 1);
           sv[kt * 4 + r] = ok ? sacc[qb][kt][r] * scaling : -INFINITY;
         }
@@ -1022,19 +1049,29 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void k_attn_prefill_mfma16(co
     }
   }
 }
-int g_prefill_attn16 = 1;         // dd_tools_set_tuning key 46: query blocks per wave of k_attn_prefill_mfma16 (1 / 2); 0 = k_attn_prefill_mfma<G, 128, 1>
-template <int QB>
+int g_prefill_attn16 = 1;         // dd_tools_set_tuning key 46: query blocks per wave of k_attn_prefill_mfma16 (1 / 2); 0 = k_attn_prefill_mfma (fp32-staged tiles)
+template <int QB, int KV16>
 static int launch_prefill_mfma16(int G, dim3 grid, hipStream_t st, const float* qbuf, const float* kc, const float* vc, int T, int T_cap, int n_heads,
                                  uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start, int span_len, int q0,
                                  int wf, const SeqTab* tab, int seq_rows, size_t off_k, size_t off_v) {
-#define F16_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 0.08838834764831845f, wf, tab, seq_rows, off_k, off_v
-  if (G == 1) k_attn_prefill_mfma16<1, QB><<<grid, 256, 0, st>>>(F16_ARGS);
-  else if (G == 2) k_attn_prefill_mfma16<2, QB><<<grid, 256, 0, st>>>(F16_ARGS);
-  else if (G == 4) k_attn_prefill_mfma16<4, QB><<<grid, 256, 0, st>>>(F16_ARGS);
+#define F16_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f, wf, T, tab, seq_rows, off_k, off_v
+  if (G == 1) k_attn_prefill_mfma16<1, QB, 128, KV16><<<grid, 256, 0, st>>>(F16_ARGS);
+  else if (G == 2) k_attn_prefill_mfma16<2, QB, 128, KV16><<<grid, 256, 0, st>>>(F16_ARGS);
+  else if (G == 4) k_attn_prefill_mfma16<4, QB, 128, KV16><<<grid, 256, 0, st>>>(F16_ARGS);
   else DD_REQUIRE(false, "attn_prefill: GQA group %d unsupported", G);
 #undef F16_ARGS
   DD_CHECK_LAUNCH();
   return DD_OK;
+}
+template <int KV16>
+static int launch_prefill_staged(int G, int n_heads, int rows, int nz, hipStream_t st, const float* qbuf, const float* kc, const float* vc, int T, int T_cap,
+                                 uint16_t* o_hi, uint16_t* o_lo, const uint8_t* drop_plane, int drop_bit, int span_start, int span_len, int q0,
+                                 int wf, const SeqTab* tab, int seq_rows, size_t off_k, size_t off_v) {
+  const int qg = 64 * (g_prefill_attn16 == 1 ? 1 : 2);
+  dim3 g3(n_heads, (rows + qg - 1) / qg, nz);
+  if (g_prefill_attn16 == 1)
+    return launch_prefill_mfma16<1, KV16>(G, g3, st, qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, tab, seq_rows, off_k, off_v);
+  return launch_prefill_mfma16<2, KV16>(G, g3, st, qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, tab, seq_rows, off_k, off_v);
 }
 
 // bidirectional attention of the CLIP tower (head_dim 64, q pre-scaled by the QKV epilogue), same kernel
@@ -1042,6 +1079,14 @@ int ddk_attn_vit_mfma(const float* q, const float* kt, const float* v, int T, in
                       hipStream_t st, int head_pitch, int Tk, float scaling) {
   DD_REQUIRE(head_pitch == 64 || head_pitch == 96, "attn_vit: head pitch %d (64, or 96 for 88-wide heads)", head_pitch);
   if (Tk <= 0) Tk = T;
+  if (g_prefill_attn16) {
+#define VS_ARGS q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 0, scaling, 0, Tk, nullptr, 0, 0, 0
+    if (head_pitch == 96) k_attn_prefill_mfma16<1, 1, 96, 0><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(VS_ARGS);
+    else k_attn_prefill_mfma16<1, 1, 64, 0><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(VS_ARGS);
+#undef VS_ARGS
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   if (head_pitch == 96)
     k_attn_prefill_mfma<1, 96><<<dim3(n_heads, (T + 63) / 64), 256, 0, st>>>(q, kt, v, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0,
                                                                             0, scaling, 0, Tk);
@@ -1067,6 +1112,14 @@ int ddk_attn_vit_mfma_batch(const float* q, const SeqTab* tab, int n, int img_ro
                             hipStream_t st, int head_pitch) {
   DD_REQUIRE(head_pitch == 64 || head_pitch == 96, "attn_vit: head pitch %d (64, or 96 for 88-wide heads)", head_pitch);
   dim3 grid(n_heads, (T + 63) / 64, n);
+  if (g_prefill_attn16) {
+#define VB_ARGS q, nullptr, nullptr, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 0, 1.0f, 0, T, tab, img_rows, 0, 0
+    if (head_pitch == 96) k_attn_prefill_mfma16<1, 1, 96, 0><<<grid, 256, 0, st>>>(VB_ARGS);
+    else k_attn_prefill_mfma16<1, 1, 64, 0><<<grid, 256, 0, st>>>(VB_ARGS);
+#undef VB_ARGS
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   if (head_pitch == 96)
     k_attn_prefill_mfma<1, 96><<<grid, 256, 0, st>>>(q, nullptr, nullptr, T, Tc, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 0, 1.0f, 0, T, tab, img_rows, 0, 0);
   else
@@ -1098,12 +1151,10 @@ int ddk_attn_prefill(const float* qbuf, const float* kc, const float* vc, int T,
   if (g_prefill_mfma) {
     dim3 g2(n_heads, (T + (q0 & 15) + 63) / 64);
 #define FA_ARGS qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, 1, 0.08838834764831845f, wf, T
-    if (kv16 && g_prefill_attn16) {
-      const int qg = 64 * (g_prefill_attn16 == 1 ? 1 : 2);
-      dim3 g3(n_heads, (T + (q0 & 15) + qg - 1) / qg);
-      if (g_prefill_attn16 == 1)
-        return launch_prefill_mfma16<1>(G, g3, st, qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, nullptr, 0, 0, 0);
-      return launch_prefill_mfma16<2>(G, g3, st, qbuf, kc, vc, T, T_cap, n_heads, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, nullptr, 0, 0, 0);
+    if (g_prefill_attn16) {
+      if (kv16)
+        return launch_prefill_staged<1>(G, n_heads, T + (q0 & 15), 1, st, qbuf, kc, vc, T, T_cap, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, nullptr, 0, 0, 0);
+      return launch_prefill_staged<0>(G, n_heads, T + (q0 & 15), 1, st, qbuf, kc, vc, T, T_cap, o_hi, o_lo, drop_plane, drop_bit, span_start, span_len, q0, wf, nullptr, 0, 0, 0);
     }
     if (kv16) {
       if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FA_ARGS);
@@ -1134,12 +1185,10 @@ int ddk_attn_prefill_seqs(const float* qbuf, const SeqTab* tab, size_t off_k, si
   DD_REQUIRE(g_prefill_mfma, "attn_prefill_seqs: the matrix-core prefill attention is switched off");
   dim3 g2(n_heads, (max_T + 63) / 64, n);
 #define FS_ARGS qbuf, nullptr, nullptr, max_T, T_cap, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, 1, 0.08838834764831845f, wf, max_T, tab, seq_rows, off_k, off_v
-  if (kv16 && g_prefill_attn16) {
-    const int qg = 64 * (g_prefill_attn16 == 1 ? 1 : 2);
-    dim3 g3(n_heads, (max_T + qg - 1) / qg, n);
-    if (g_prefill_attn16 == 1)
-      return launch_prefill_mfma16<1>(G, g3, st, qbuf, nullptr, nullptr, max_T, T_cap, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, wf, tab, seq_rows, off_k, off_v);
-    return launch_prefill_mfma16<2>(G, g3, st, qbuf, nullptr, nullptr, max_T, T_cap, n_heads, o_hi, o_lo, nullptr, 0, 0, 0, 0, wf, tab, seq_rows, off_k, off_v);
+  if (g_prefill_attn16) {
+    if (kv16)
+      return launch_prefill_staged<1>(G, n_heads, max_T, n, st, qbuf, nullptr, nullptr, max_T, T_cap, o_hi, o_lo, nullptr, 0, 0, 0, 0, wf, tab, seq_rows, off_k, off_v);
+    return launch_prefill_staged<0>(G, n_heads, max_T, n, st, qbuf, nullptr, nullptr, max_T, T_cap, o_hi, o_lo, nullptr, 0, 0, 0, 0, wf, tab, seq_rows, off_k, off_v);
   }
   if (kv16) {
     if (G == 1) k_attn_prefill_mfma<1, 128, 1><<<g2, 256, 0, st>>>(FS_ARGS);

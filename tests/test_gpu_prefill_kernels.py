@@ -3,7 +3,7 @@ models/llava.py:294-303; first-token ensemble :336-337):
 
 * RMSNorm + hi/lo split with sixteen rows per workgroup (whole 1 KiB operand tiles per wave store) against one row per workgroup — the same
   256 partial sums per row in the same butterfly order, the same y = w * (x * rstd) (tools key 45);
-* causal prefill attention over the fp16 cache with the K / V tiles staged as MFMA operands — split hi + lo once per workgroup instead of once per
+* prefill attention (fp16 or fp32 cache; the vision towers' bidirectional form too) with the K / V tiles staged as MFMA operands — split hi + lo once per workgroup instead of once per
   wave — and one or two 16-query blocks per wave, against the kernel that stages fp32 tiles (tools key 46 = 2 / 1 / 0).
 
 Compared after every form of prefill that reaches them: one prompt, prompts of several sequences as one matrix, an extension against the cache
@@ -27,9 +27,10 @@ def _same(a, b):
         assert np.array_equal(a[3][k], b[3][k], equal_nan=True), k
 
 
-@pytest.mark.parametrize("d,H,Hkv,T0,fmt", [(256, 2, 2, 100, "bf16"), (512, 4, 2, 321, "fp16"), (512, 4, 1, 203, "bf16"), (4096, 32, 32, 129, "bf16"),
-                                                (512, 4, 2, 421, "fp8")])
-def test_prefill_kernel_forms_leave_the_same_bits(d, H, Hkv, T0, fmt):
+@pytest.mark.parametrize("d,H,Hkv,T0,fmt,kv", [(256, 2, 2, 100, "bf16", "fp16"), (512, 4, 2, 321, "fp16", "fp16"), (512, 4, 1, 203, "bf16", "fp16"),
+                                                   (4096, 32, 32, 129, "bf16", "fp16"), (512, 4, 2, 421, "fp8", "fp16"), (512, 4, 2, 300, "bf16", "fp32"),
+                                                   (256, 2, 1, 150, "fp16", "fp32")])
+def test_prefill_kernel_forms_leave_the_same_bits(d, H, Hkv, T0, fmt, kv):
     from dropoutdecoding_amd import _lib, build
     build.build()
     from dropoutdecoding_amd import lm
@@ -38,7 +39,7 @@ def test_prefill_kernel_forms_leave_the_same_bits(d, H, Hkv, T0, fmt):
     L, s0 = 64, 7
     engs = []
     for i in range(3):
-        engs.append(lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=T0 + 160, max_visual=L, seed=9 + i, kv_format="fp16", lib=T,
+        engs.append(lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=T0 + 160, max_visual=L, seed=9 + i, kv_format=kv, lib=T,
                                      weight_format=fmt, share_weights_with=engs[0] if engs else None))
     engs[0].load_synthetic(seed=4, std=0.05)
     g = torch.Generator().manual_seed(1)
@@ -82,3 +83,15 @@ def test_prefill_kernel_forms_leave_the_same_bits(d, H, Hkv, T0, fmt):
             _same(a, b)
             if len(a) > 4:
                 assert a[4] == b[4], key
+
+
+def test_vision_towers_same_bits_with_operand_staged_attention():
+    """CLIP tower + projector (heads of 64), the EVA-style tower (heads of 88 at a pitch of 96): tools key 46 = 0 / 1, in a child process whose
+    towers live in libdropdec_tools.so (tests/vit_attn_ab.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "vit_attn_ab.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "clip ok" in r.stdout and "eva ok" in r.stdout
