@@ -19,9 +19,9 @@ if [ "$WHAT" = stats ]; then
   tail -1 $OUT/${R}_bench_under_rocprof.log | cut -c1-200
   head -32 $OUT/${R}_kernel_stats.csv | cut -c1-160
 elif [ "$WHAT" = stats5 ]; then
-  # BASELINE config 5 (LLaVA-NeXT-Mistral-7B shapes, fp8 matrices): one batch of 32 images, 16 new tokens each
+  # BASELINE config 5 (LLaVA-NeXT-Mistral-7B shapes, fp8 matrices): one batch of 64 images, 32 new tokens each
   rm -rf /tmp/${R}_stats5
-  timeout 1000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_stats5 -- python3 bench.py --config 5 --steps 1 --warmup 0 --n-new 16 --no-cpu-baseline --no-roofline --single-images 0 > $OUT/${R}_c5_bench_under_rocprof.log 2>&1
+  timeout 1000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_stats5 -- python3 bench.py --config 5 --steps 1 --warmup 0 --n-new 32 --no-cpu-baseline --no-roofline --single-images 0 > $OUT/${R}_c5_bench_under_rocprof.log 2>&1
   echo "rocprof rc=$?"
   f=$(find /tmp/${R}_stats5 -name "*kernel_stats.csv" | head -1)
   head -60 "$f" > $OUT/${R}_c5_kernel_stats.csv
