@@ -183,19 +183,22 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def _profile_files():
-    """The newest committed rocprofv3 summaries (profiles/rNN_*): PMC traffic / MFMA busy and kernel-trace durations."""
+def _profile_files(tag: str = ""):
+    """The newest committed rocprofv3 summaries (profiles/rNN_<tag>pmc_summary.json, rNN_<tag>kernel_stats.csv; tag "c5_" = the config-5
+    collection): PMC traffic / MFMA busy and kernel-trace durations.  Other files that merely end in the same words do not count."""
     import glob
-    pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    st = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.csv")))
-    rel = lambda p_: os.path.relpath(p_, ROOT) if p_ else None
-    return rel(pm[-1] if pm else None), rel(st[-1] if st else None)
+    import re
+    def newest(suffix):
+        c = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)) if re.fullmatch(r"r\d\d_" + re.escape(tag + suffix), os.path.basename(f)))
+        return os.path.relpath(c[-1], ROOT) if c else None
+    return newest("pmc_summary.json") if not tag else (newest("pmc_summary.json") or _profile_files()[0]), \
+        newest("kernel_stats.csv") if not tag else (newest("kernel_stats.csv") or _profile_files()[1])
 
 
-def committed_profile(kernel: str):
+def committed_profile(kernel: str, tag: str = ""):
     """HBM traffic / MFMA busy / kernel-trace average of `kernel` from the committed profile of the newest round — NOT measured in
     this run (bench.py cannot collect PMCs); the kernel is matched by the name the library reports for what it launched."""
-    pmc, stats = _profile_files()
+    pmc, stats = _profile_files(tag)
     traffic = mfma_util = stats_avg_us = None
     try:
         for name, v in json.load(open(os.path.join(ROOT, pmc)))["kernels"].items():
@@ -214,7 +217,7 @@ def committed_profile(kernel: str):
     return {"traffic": traffic, "mfma_util": mfma_util, "stats_avg_us": stats_avg_us, "pmc_file": pmc, "stats_file": stats}
 
 
-def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows8, wide):
+def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows8, wide, profile_tag=""):
     """The dominant kernel (gate/up decode GEMV of the member pass) timed alone with HIP events on its launch stream while cycling over
     the layers' weights, on an engine of its own created through libdropdec_tools.so (the timing hooks are not in the product library)."""
     from dropoutdecoding_amd import _lib, lm
@@ -241,7 +244,7 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
     sweep_ms = eng.time_sweep(rows8, 5)
     sweep_bytes = eng.algorithmic_bytes(0)
     eng.close()
-    prof = committed_profile(kernel)
+    prof = committed_profile(kernel, profile_tag)
     achieved = by / (ms * 1e-3) / 1e9
     rows_what = ("the members of a group of sequences + the un-masked rows of another group riding in further operand planes" if dom_rows == 72
                  else f"the members of {dom_rows // 8} sequences")
@@ -505,7 +508,7 @@ def main() -> int:
     roof = None
     if rank == 0 and not args.no_roofline:
         try:
-            roof = roofline_leg(lm_cfg, family, wname, "fp16", T0, L, dom_rows, rows8, wide)
+            roof = roofline_leg(lm_cfg, family, wname, "fp16", T0, L, dom_rows, rows8, wide, "c5_" if args.config == 5 else "")
         except Exception as e:                                         # the throughput number must still be reported
             roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                     "error": f"{type(e).__name__}: {e}"}
