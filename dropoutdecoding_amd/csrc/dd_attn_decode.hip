@@ -256,8 +256,16 @@ __device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int h
 // statistics and outputs in LDS instead of the partial buffers and runs the merge itself (attn_combine_core, the body the
 // stand-alone k_attn_combine runs over the buffers): no partial-buffer round trip, no second launch, the same bits.
 #define ATT_FULL_TILES 12
-template <int NBT, int G, int GH, int ML, int FULL = 0>
-__device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, const int bx, const int by, const int bz) {
+// PF = 0: ONE register set for a tile's K / V fragments instead of two (the next tile is requested only when this one is done): 96 instead of
+// 144 VGPRs, so that a workgroup fits on a CU BESIDE a nine-plane slice GEMV workgroup (2 x 200-208 VGPRs per SIMD lane, 144 KiB of LDS) —
+// the rider sweeps' attention then overlaps the other branches' qkv / o_proj / down streams instead of waiting for their CUs (round 4: 64-lane
+// step 36.4 -> 35.0 ms).  Same arithmetic, only the load timing differs: the same bits.
+// sh: ATTN16_SH_FLOATS(NBT * GH) floats of the caller's static LDS (q rows, tile probabilities, per-wave maxima / sums) — passed in so that the
+// two bodies of the rider kernel, of which a workgroup runs one, share one allocation: with a buffer each the kernel asked for 19.5 KiB at
+// GQA 4 and could not sit beside a 144-KiB slice GEMV workgroup.
+#define ATTN16_SH_FLOATS(R_) ((((R_) + 7) / 8 * 8) * ((HEAD_DIM + 4) + (ATT_SPLIT + 4) + 8))
+template <int NBT, int G, int GH, int ML, int FULL = 0, int PF = 1>
+__device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, const int bx, const int by, const int bz, float* const sh) {
   constexpr int R = NBT * GH, RB = (R + 7) / 8, RP = RB * 8;
   extern __shared__ __align__(16) float full_sh[];        // FULL: [tiles][RP][HEAD_DIM] outputs, then [tiles][RP][2] statistics
   float* const fo_sh = full_sh;
@@ -278,9 +286,9 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
     if (ML == 2) return (g0 + r / NBT) * 8 * a.lane_groups + lane_row * 8 + mo + r % NBT;
     return g0 * NBT + r;
   };
-  __shared__ __align__(16) float q_sh[RP][HEAD_DIM + 4];
-  __shared__ __align__(16) float p_sh[RP][ATT_SPLIT + 4];
-  __shared__ float red_sh[2][4][RP];
+  float (*const q_sh)[HEAD_DIM + 4] = (float (*)[HEAD_DIM + 4])sh;
+  float (*const p_sh)[ATT_SPLIT + 4] = (float (*)[ATT_SPLIT + 4])(sh + RP * (HEAD_DIM + 4));
+  float (*const red_sh)[4][RP] = (float (*)[4][RP])(sh + RP * (HEAD_DIM + 4) + RP * (ATT_SPLIT + 4));
   if (a.skip_if && *a.skip_if) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, h4 = lane >> 4;
@@ -300,7 +308,9 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
 
   // every K / V request of a tile at once (dead keys: the last live key's chunk / whatever the octet holds — cache memory is
   // zero-initialised and only ever holds finite values; their probabilities are exactly 0)
-  auto load_tile = [&](int split, u32x4_t (&kf)[4], u32x4_t (&vf)[2][2], uint32_t (&kbits)[4]) {
+  // member index of this lane's rows within their sequence (8 blk is a multiple of NBT: the same for every row block)
+  const int m_lane = ML == 1 ? 0 : mo_bit + (c & 7) % NBT;
+  auto load_tile = [&](int split, u32x4_t (&kf)[4], u32x4_t (&vf)[2][2], uint32_t& kmask) {
     const int t0 = split * ATT_SPLIT, nkeys = min(ATT_SPLIT, T - t0);
     const int key = t0 + min(16 * wave + c, nkeys - 1);
 #pragma unroll
@@ -310,14 +320,16 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
         vf[dt][k2] = *(const u32x4_t*)(vc_l + (((size_t)kvh * (a.T_cap >> 3) + (t0 >> 3) + 4 * k2 + h4) * HEAD_DIM + 32 * wave + 16 * dt + c) * 8);
+    kmask = 0u;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {              // drop bits of this lane's keys 16 w + 4 h4 + reg
+    for (int reg = 0; reg < 4; ++reg) {              // drop flags of this lane's keys 16 w + 4 h4 + reg for its member: bit reg
       const int kk = 16 * wave + 4 * h4 + reg, ka = t0 + kk;
-      kbits[reg] = (bits_l && kk < nkeys && ka >= span0 && ka < span0 + spanL) ? bits_l[ka - span0] : 0u;
+      const uint32_t bits = (bits_l && kk < nkeys && ka >= span0 && ka < span0 + spanL) ? bits_l[ka - span0] : 0u;
+      kmask |= ((bits >> (a.bit0 + m_lane)) & 1u) << reg;
     }
   };
-  u32x4_t kf[2][4], vf[2][2][2];
-  uint32_t kbits[2][4];
+  u32x4_t kf[PF ? 2 : 1][4], vf[PF ? 2 : 1][2][2];
+  uint32_t kbits[PF ? 2 : 1];
   load_tile(split0, kf[0], vf[0], kbits[0]);
   // q rows (r = g * NBT + m) into LDS, zero for rows past R or past the live members
   for (int i = tid; i < RP * HEAD_DIM; i += 256) {
@@ -354,7 +366,7 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
   }
   const float scaling = 0.08838834764831845f;  // head_dim ** -0.5
 
-  auto tile = [&](int split, const u32x4_t (&kfr)[4], const u32x4_t (&vfr)[2][2], const uint32_t (&kb)[4]) {
+  auto tile = [&](int split, const u32x4_t (&kfr)[4], const u32x4_t (&vfr)[2][2], const uint32_t kb) {
     const int t0 = split * ATT_SPLIT, nkeys = min(ATT_SPLIT, T - t0);
     float pmax[RB], sv[RB][4];
 #pragma unroll
@@ -366,13 +378,12 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
         sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dd_f16x8_t, kfr[ks]), __builtin_bit_cast(dd_f16x8_t, qb[blk][ks]), sacc, 0, 0, 0);
       // hi + lo columns; mask; the wave's maximum per row (lanes c < 8 carry row 8 blk + c, keys 16 w + 4 h4 + reg)
       const int row = 8 * blk + (c & 7);
-      const int m = ML == 1 ? 0 : mo_bit + row % NBT;
       float mx = -INFINITY;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         float s = (sacc[reg] + __shfl_down(sacc[reg], 8)) * scaling;
         const int kk = 16 * wave + 4 * h4 + reg;
-        if (kk >= nkeys || ((kb[reg] >> (a.bit0 + m)) & 1u)) s = -INFINITY;   // zero in the 2-D mask: weight exactly 0
+        if (kk >= nkeys || ((kb >> reg) & 1u)) s = -INFINITY;   // zero in the 2-D mask: weight exactly 0
         sv[blk][reg] = s;
         mx = fmaxf(mx, s);
       }
@@ -439,15 +450,25 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
       }
     }
   };
-  // tiles in pairs with the other register set prefetching: the next tile's loads are in flight while this one is computed
-  for (int sp = split0; sp < split1; sp += 2) {
-    if (sp + 1 < split1) load_tile(sp + 1, kf[1], vf[1], kbits[1]);
-    tile(sp, kf[0], vf[0], kbits[0]);
-    if (sp + 1 < split1) {
-      __syncthreads();                                  // p_sh / red_sh are reused
-      if (sp + 2 < split1) load_tile(sp + 2, kf[0], vf[0], kbits[0]);
-      tile(sp + 1, kf[1], vf[1], kbits[1]);
-      if (sp + 2 < split1) __syncthreads();
+  if constexpr (!PF) {
+    for (int sp = split0; sp < split1; ++sp) {
+      if (sp > split0) {
+        __syncthreads();                                  // p_sh / red_sh are reused
+        load_tile(sp, kf[0], vf[0], kbits[0]);
+      }
+      tile(sp, kf[0], vf[0], kbits[0]);
+    }
+  } else {
+    // tiles in pairs with the other register set prefetching: the next tile's loads are in flight while this one is computed
+    for (int sp = split0; sp < split1; sp += 2) {
+      if (sp + 1 < split1) load_tile(sp + 1, kf[PF ? 1 : 0], vf[PF ? 1 : 0], kbits[PF ? 1 : 0]);
+      tile(sp, kf[0], vf[0], kbits[0]);
+      if (sp + 1 < split1) {
+        __syncthreads();                                  // p_sh / red_sh are reused
+        if (sp + 2 < split1) load_tile(sp + 2, kf[0], vf[0], kbits[0]);
+        tile(sp + 1, kf[PF ? 1 : 0], vf[PF ? 1 : 0], kbits[PF ? 1 : 0]);
+        if (sp + 2 < split1) __syncthreads();
+      }
     }
   }
   if constexpr (FULL) {
@@ -472,16 +493,21 @@ __device__ __forceinline__ void attn_partial16_body(const AttnDecodeArgs& a, con
 
 template <int NBT, int G, int GH, int ML, int FULL = 0>
 __global__ __launch_bounds__(256) void k_attn_partial16(AttnDecodeArgs a) {
-  attn_partial16_body<NBT, G, GH, ML, FULL>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+  __shared__ __align__(16) float sh[ATTN16_SH_FLOATS(NBT * GH)];
+  attn_partial16_body<NBT, G, GH, ML, FULL>(a, blockIdx.x, blockIdx.y, blockIdx.z, sh);
 }
 // Rider sweeps (dd_engine.hip group_step_rider): the members of eight sequences (a: the groups form, workgroups z < za) AND the
 // riding un-masked rows of up to eight other sequences (u: the lanes form, one row per sequence) in ONE launch — the two are
 // independent and each alone leaves the chip half idle; the bodies are the ones above, so every row keeps its bits.
-template <int G, int GH, int NBT>
-__global__ __launch_bounds__(256) void k_attn_partial16_ride(AttnDecodeArgs a, AttnDecodeArgs u, int za) {
-  if ((int)blockIdx.z < za) attn_partial16_body<NBT, G, GH, 2, 0>(a, blockIdx.x, blockIdx.y, blockIdx.z);
-  else attn_partial16_body<1, G, G, 1, 0>(u, blockIdx.x, blockIdx.y, blockIdx.z - za);
+// One register set (PF = 0) under a register cap wherever the rows fit: MHA 94 VGPRs (cap 96), GQA with up to 16 rows per workgroup 119 (cap 128) —
+// beside the nine-plane GEMVs' 2 x 200-208 (bf16) or 2 x 176-184 (fp8) per SIMD lane; 32 rows per workgroup keep two sets.
+template <int G, int GH, int NBT, int PF = ((G == 1 || NBT * GH <= 16) ? 0 : 1)>
+__global__ __launch_bounds__(256, PF ? 1 : (G == 1 ? 5 : 4)) void k_attn_partial16_ride(AttnDecodeArgs a, AttnDecodeArgs u, int za) {
+  __shared__ __align__(16) float sh[ATTN16_SH_FLOATS(NBT * GH > G ? NBT * GH : G)];
+  if ((int)blockIdx.z < za) attn_partial16_body<NBT, G, GH, 2, 0, PF>(a, blockIdx.x, blockIdx.y, blockIdx.z, sh);
+  else attn_partial16_body<1, G, G, 1, 0, PF>(u, blockIdx.x, blockIdx.y, blockIdx.z - za, sh);
 }
+int g_attn16_ride_pf = 0;        // dd_tools_set_tuning key 47: 1 = the two-register-set (round-3) form for every rider sweep
 
 // grid (n_heads, nb), block 128 (thread = d): the merge above over the partial buffers in memory
 template <int NBT, int G>
@@ -672,7 +698,8 @@ static int launch_attn_ride_gh(const AttnDecodeArgs& a, const AttnDecodeArgs& u,
   attn16_grid(v, splits_u, u.n_kv * u.n_lanes);
   const int ya = (splits_a + b.tiles_per_wg - 1) / b.tiles_per_wg, yu = (splits_u + v.tiles_per_wg - 1) / v.tiles_per_wg;
   const int za = planes_m * (G / GH) * (8 / NBT);
-  k_attn_partial16_ride<G, GH, NBT><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
+  if (g_attn16_ride_pf) k_attn_partial16_ride<G, GH, NBT, 1><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
+  else k_attn_partial16_ride<G, GH, NBT><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
   if (u.n_lanes > 8) k_attn_combine_ride<G, 16><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
   else k_attn_combine_ride<G, 8><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
   return DD_OK;

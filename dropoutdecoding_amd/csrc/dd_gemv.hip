@@ -1158,7 +1158,7 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
       else RC_(launch_slices_k<1, 9, 8, 56, 8, 1, EPI_RESID>(sa, a.wf, st));
     }
     launch_finish<EPI_RESID, 1, 9, 8>(a, nt, st);
-  } else if (spw == 16 && 4 * ((nt + 23) / 24) > 256) {
+  } else if (spw == 16 && (4 * ((nt + 23) / 24) > 256 || g_exp_G[2] == -2)) {      // (A/B, tuning key 19 = -2: single slices for every gate/up)
     // more gate/up tiles than three per wave of one round of slice PAIRS (Mistral-7B: 1792 tiles): single slices, tiles walked per wave
     sa.G = 32;
     RC_(launch_slices_k<1, 9, 8, 16, 16, 1, EPI_SILU>(sa, a.wf, st));
