@@ -1166,9 +1166,15 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
   } else {
     if (spw != 16) return SLICES_UNSUPPORTED;
     sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 23) / 24;
-    DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
+    DD_REQUIRE(g_exp_G[2] == -3 || (nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
     // (four weight requests in flight per wave: with eight, three tiles per wave and nine planes the kernel needs 257 registers and
     // spills 28 bytes per lane to private scratch — that instantiation is gone, build.py refuses kernels with scratch)
+    if (g_exp_G[2] == -3) {
+      // (A/B, tuning key 19 = -3) two tiles per wave on 4 * ceil(nt / 16) workgroups (11008: 344, more than one per CU): 196 instead of 236
+      // VGPRs, so that the rider sweeps' attention (94) fits beside this kernel too
+      sa.G = (nt + 15) / 16;
+      RC_(launch_slices_seq<9, 4, 2, EPI_SILU>(sa, a.wf, st));
+    } else
     RC_(launch_slices_seq<9, 4, 3, EPI_SILU>(sa, a.wf, st));
     launch_finish<EPI_SILU, 2, 9, 4>(a, a.n_tiles, st);
   }

@@ -26,5 +26,5 @@ bash tools/collect_profiles.sh r04 stats > $O/collect_stats.log 2>&1
 bash tools/collect_profiles.sh r04 pmc > $O/collect_pmc.log 2>&1
 bash tools/collect_profiles.sh r04 stats5 > $O/collect_stats5.log 2>&1
 bash tools/collect_profiles.sh r04 pmc5 > $O/collect_pmc5.log 2>&1
-timeout 600 python tools/rider_ab.py 64 "26=1" "33=0" > $O/rider_ab_64.log 2>&1; grep -v amdgpu $O/rider_ab_64.log | cut -c1-200
+timeout 600 python tools/rider_ab.py 64 "26=1" "33=0" "47=1" > $O/rider_ab_64.log 2>&1; grep -v amdgpu $O/rider_ab_64.log | cut -c1-200
 timeout 600 python tools/prefill_ab.py > $O/prefill_ab.log 2>&1; grep -v amdgpu $O/prefill_ab.log | cut -c1-200
