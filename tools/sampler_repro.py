@@ -75,7 +75,7 @@ def _inputs():
     return seqs
 
 
-def sampler(scratch: bool, beside: bool, rounds: int, lib=None, seqs=None) -> dict:
+def sampler(scratch: bool, beside: bool, rounds: int, lib=None, seqs=None, rows: int = 72) -> dict:
     lib = lib or _lib.load_tools()
     lib.dd_tools_set_tuning(34, 1 if scratch else 0)
     seqs = seqs or _inputs()
@@ -124,14 +124,16 @@ def sampler(scratch: bool, beside: bool, rounds: int, lib=None, seqs=None) -> di
                         break
 
     if beside:
-        with Company(lib) as co:
+        co = Company(lib)
+        co.rows = rows            # 72 / 64 rows: 144 / 128 KiB of LDS per GEMV workgroup — the sampler's 76-KiB workgroups cannot share their CUs; 32 / 16 rows can
+        with co:
             body()
             company = sum(co.launches)
     else:
         body()
         company = 0
     lib.dd_tools_set_tuning(34, 0)
-    return {"test": "sampler", "scratch_form": scratch, "beside_72_row_gemvs": beside, "sampler_launches": launches, "workgroups_per_launch": N_SEQ,
+    return {"test": "sampler", "scratch_form": scratch, "beside_72_row_gemvs": beside, "company_rows": rows if beside else 0, "sampler_launches": launches, "workgroups_per_launch": N_SEQ,
             "company_gemv_launches": company, "sequences_with_a_wrong_launch": bad_launches, "first_bad": first_bad, "seconds": round(time.time() - t0, 1)}
 
 
