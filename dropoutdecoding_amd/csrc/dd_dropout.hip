@@ -923,6 +923,18 @@ static int g_lanes_sampler_scratch = 0;
 void dd_dropout_set_lanes_sampler_scratch(int on) { g_lanes_sampler_scratch = on; }
 #endif
 
+// Dynamic LDS the sampler kernels REQUEST: what they use (76 KiB) padded to 156 KiB, so that no workgroup of a kernel that needs more than ~3 KiB of
+// LDS — the decode attention's tile pass, the slice GEMVs, the prefill attention: every MFMA kernel of the library — is placed on the sampler's CU
+// while it runs.  Round 4's unit reproducer (tools/sampler_repro.py sampler_streams): the sampler on a stream of its own beside a group taking
+// rider steps produced a wrong mt19937 regeneration (64 consecutive state words) about once in 70,000 launches — the run-to-run difference of the
+// branch-local sampling schedule; never alone, never beside GEMVs whose LDS excludes it anyway.  dd_tools_set_tuning key 48 = 0:
+// request only what is used.
+int g_sampler_lds_pad = 1;
+static size_t sampler_smem() {
+  const size_t used = (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4;
+  const size_t padded = (size_t)156 * 1024;
+  return g_sampler_lds_pad && padded > used ? padded : used;
+}
 int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st) {
   DD_REQUIRE(lanes && n >= 1 && n <= 32 && K >= 1 && K <= 64 && mode >= 0 && mode <= 4, "dd_sample_masks_lanes: bad arguments");
   MaskLanes M;
@@ -940,17 +952,17 @@ int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const dou
     M.topk[m] = lanes[m].topk, M.rng_state[m] = lanes[m].rng_state, M.drop[m] = lanes[m].drop, M.n_drop[m] = lanes[m].n_drop;
     M.drop_bits[m] = lanes[m].drop_bits, M.gate[m] = lanes[m].gate;
   }
-  size_t smem = (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4;
+  const size_t smem = sampler_smem();
   static bool attr_set = false;
   if (!attr_set) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     attr_set = true;
   }
 #ifdef DD_KEEP_SCRATCH_SAMPLER
   if (g_lanes_sampler_scratch) {
     static bool attr2 = false;
     if (!attr2) {
-      DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes_scratch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes_scratch, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       attr2 = true;
     }
     k_sample_masks_lanes_scratch<<<n, MASK_THREADS, smem, st>>>(M);
@@ -989,10 +1001,10 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
     P.scale[k] = (float)(mprobs[k] - 0.1);  // double subtraction, then one rounding to fp32
     P.q[k] = (float)(1.0 - mprobs[k]);
   }
-  size_t smem = (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4;
+  const size_t smem = sampler_smem();
   static bool attr_set = false;
   if (!attr_set) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     attr_set = true;
   }
   k_sample_masks<<<1, MASK_THREADS, smem, st>>>(P);

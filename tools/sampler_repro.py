@@ -67,11 +67,12 @@ def _inputs():
         tok = int(topk[3 + i, 2])
         keep = (topk == tok).any(1)
         ref = TorchCpuMT19937(100 + i)
-        want = []
+        want, unis = [], []
         for _ in range(STEPS):
             uni = torch.from_numpy(np.stack([ref.rand_f32(L_VIS) for _ in PROBS]))
+            unis.append(uni.numpy())
             want.append(DR.sample_masks(torch.from_numpy(epi), PROBS, torch.from_numpy(keep), DR.MODE_LLAVA_CUMULATIVE, uni).numpy())
-        seqs.append({"epi": epi, "topk": topk, "tok": tok, "keep": keep, "want": np.stack(want)})
+        seqs.append({"epi": epi, "topk": topk, "tok": tok, "keep": keep, "want": np.stack(want), "uniforms": np.stack(unis)})
     return seqs
 
 
@@ -135,6 +136,139 @@ def sampler(scratch: bool, beside: bool, rounds: int, lib=None, seqs=None, rows:
     lib.dd_tools_set_tuning(34, 0)
     return {"test": "sampler", "scratch_form": scratch, "beside_72_row_gemvs": beside, "company_rows": rows if beside else 0, "sampler_launches": launches, "workgroups_per_launch": N_SEQ,
             "company_gemv_launches": company, "sequences_with_a_wrong_launch": bad_launches, "first_bad": first_bad, "seconds": round(time.time() - t0, 1)}
+
+
+class StepCompany:
+    """A group of `lanes` sequences (LLaVA-1.5-7B matrices, 2 layers) taking rider steps in a loop on the engines' own stream: the company a
+    branch-local sampler has inside a group step — attention tile passes (MFMA, a few KiB of LDS, 95 VGPRs), combine and finishing kernels, which
+    fit on a CU beside the sampler's 76-KiB workgroup where the 144-KiB slice GEMVs do not."""
+
+    def __init__(self, lib, lanes=32):
+        cfg = lm.LMConfig(32064, 4096, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
+        self.engs = []
+        for i in range(lanes):
+            self.engs.append(lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=608 + 140, max_visual=576, seed=7 + i, kv_format="fp16", lib=lib,
+                                              share_weights_with=self.engs[0] if self.engs else None))
+        self.engs[0].load_synthetic(0, 0.02)
+        g = torch.Generator().manual_seed(3)
+        self.embs = [(torch.randn(608, 4096, generator=g) * 0.5).cuda() for _ in range(lanes)]
+        self.stop, self.steps, self.thread = False, 0, None
+
+    def _loop(self):
+        torch.cuda.set_device(0)
+        while not self.stop:
+            lm.prefill_group(self.engs[:16], self.embs[:16], [(5, 576)] * 16)
+            if len(self.engs) > 16:
+                lm.prefill_group(self.engs[16:32], self.embs[16:32], [(5, 576)] * (len(self.engs[16:32])))
+            grp = lm.EngineGroup(self.engs)
+            for _ in range(120):
+                if self.stop:
+                    break
+                grp.decode_step(PROBS)
+                self.steps += 1
+            torch.cuda.synchronize()
+
+    def __enter__(self):
+        self.thread = threading.Thread(target=self._loop)
+        self.thread.start()
+        time.sleep(2.0)
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        self.thread.join()
+        for e in reversed(self.engs):
+            e.close()
+
+
+def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 0) -> dict:
+    """The lanes sampler from `n_streams` host threads at once, each on a stream of its own with sequences (and rng streams) of its own — the
+    branch-local form's launch pattern —, optionally beside a group of `company_lanes` sequences taking rider steps; every launch against the
+    oracle."""
+    lib = lib or _lib.load_tools()
+    lib.dd_tools_set_tuning(34, 0)
+    seqs = _inputs()
+    K = len(PROBS)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    want = [s_["want"] for s_ in seqs]
+    want_bits = [np.bitwise_or.reduce(w.astype(np.uint8) << np.arange(K, dtype=np.uint8)[None, :, None], axis=1) for w in want]
+    bad, launches, first_bad = [0] * n_streams, [0] * n_streams, [None] * n_streams
+    events = []
+    t0 = time.time()
+
+    def worker(t):
+        torch.cuda.set_device(0)
+        epi = [dev(s_["epi"]) for s_ in seqs]
+        topk = [dev(s_["topk"]) for s_ in seqs]
+        argmax = [torch.tensor([s_["tok"]], dtype=torch.int32, device="cuda") for s_ in seqs]
+        keep = [torch.zeros(L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
+        drop = [torch.zeros(STEPS, K, L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
+        n_drop = [torch.zeros(STEPS, K, dtype=torch.int32, device="cuda") for _ in seqs]
+        bits = [torch.zeros(STEPS, L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
+        rngs = [TorchCpuCompatRNG(100 + i, lib=lib) for i in range(N_SEQ)]
+        st = torch.cuda.Stream()
+        arr = lambda ts: (C.c_void_p * N_SEQ)(*[x.data_ptr() if torch.is_tensor(x) else x for x in ts])
+        Ls = (C.c_int32 * N_SEQ)(*([L_VIS] * N_SEQ))
+        pr = (C.c_double * K)(*PROBS)
+        for r in range(rounds):
+            for i, g in enumerate(rngs):
+                g.manual_seed(100 + i)
+            torch.cuda.current_stream().synchronize()
+            for s_ in range(STEPS):
+                rc = lib.dd_tools_sample_masks_lanes(N_SEQ, arr(epi), Ls, arr(keep), arr(argmax), arr(topk), arr([g.handle.value for g in rngs]),
+                                                     arr([d[s_].data_ptr() for d in drop]), arr([n[s_].data_ptr() for n in n_drop]),
+                                                     arr([b[s_].data_ptr() for b in bits]), K_TOP, pr, K, DR.MODE_LLAVA_CUMULATIVE, st.cuda_stream)
+                assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+            launches[t] += STEPS
+            with torch.cuda.stream(st):
+                got_all = [d.cpu().numpy().astype(bool) for d in drop]
+                gb_all = [b.cpu().numpy() for b in bits]
+                gn_all = [n.cpu().numpy() for n in n_drop]
+            for i in range(N_SEQ):
+                for s_ in range(STEPS):
+                    if not (np.array_equal(got_all[i][s_], want[i][s_]) and np.array_equal(gb_all[i][s_], want_bits[i][s_]) and
+                            np.array_equal(gn_all[i][s_], want[i][s_].sum(1))):
+                        bad[t] += 1
+                        k_bad = [int(k) for k in range(K) if not np.array_equal(got_all[i][s_][k], want[i][s_][k])]
+                        if k_bad and len(events) < 12:
+                            k0 = k_bad[0]
+                            pos = np.nonzero(got_all[i][s_][k0] != want[i][s_][k0])[0]
+                            p = DR.drop_probability(torch.from_numpy(seqs[i]["epi"]), PROBS[k0]).numpy()
+                            margin = seqs[i]["uniforms"][s_][k0] - p                      # < 0: the reference drops the token
+                            # would the got mask of member k0 be the reference's under ANOTHER member's uniforms (a stale / early buffer)?
+                            prev = want[i][s_][k0 - 1] if k0 else np.zeros(L_VIS, bool)
+                            alt = {}
+                            for kk in range(K):
+                                m_alt = (prev | (seqs[i]["uniforms"][s_][kk] < p)) & ~seqs[i]["keep"]
+                                alt[kk] = int((m_alt != got_all[i][s_][k0]).sum())
+                            events.append({"stream": t, "round": r, "sequence": i, "launch": s_, "first_wrong_member": k0, "wrong_positions": pos[:48].tolist(),
+                                           "n_wrong_positions": int(len(pos)), "waves_of_wrong_positions": sorted({int(x) // 64 for x in pos}),
+                                           "margin_r_minus_p_at_wrong_positions": [round(float(x), 4) for x in margin[pos[:12]]],
+                                           "mismatch_if_member_k0_had_used_uniforms_of_member": alt})
+                        if first_bad[t] is None:
+                            first_bad[t] = {"stream": t, "round": r, "sequence": i, "launch": s_, "members_with_wrong_masks": k_bad,
+                                            "wrong_mask_bytes": int((got_all[i][s_] != want[i][s_]).sum()),
+                                            "n_drop_got": gn_all[i][s_].tolist(), "n_drop_want": want[i][s_].sum(1).tolist()}
+                        break
+
+    def run():
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_streams)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+
+    steps = 0
+    if company_lanes:
+        with StepCompany(lib, company_lanes) as co:
+            run()
+            steps = co.steps
+    else:
+        run()
+    return {"test": "sampler_streams", "streams": n_streams, "sampler_launches": sum(launches), "workgroups_per_launch": N_SEQ,
+            "company_rider_steps": steps, "company_lanes": company_lanes, "sequences_with_a_wrong_launch": sum(bad),
+            "first_bad": [f for f in first_bad if f], "events": events, "seconds": round(time.time() - t0, 1)}
 
 
 def probe(beside: bool, rounds: int, lib=None, wgs: int = 8, spin: int = 200) -> dict:
