@@ -48,7 +48,8 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * of a kv head in one workgroup (default 0: two heads per workgroup), 45 prefill RMSNorm + split with sixteen rows per workgroup (default 1;
  * 0: one row per workgroup), 46 prefill attention over the fp16 cache with operand-staged K / V tiles and 1 or 2 query blocks per wave
  * (default 1; 0: the fp32-staged kernel), 47 the MHA rider sweeps' attention tile pass with two register sets (the round-3 form, 144 VGPRs;
- * default 0: one set, 94 VGPRs, so that it shares CUs with the other branches' slice GEMVs).  Keys of the determinism bisect (all default to the product's behaviour): 37 fp32-cache
+ * default 0: one set, 94 VGPRs, so that it shares CUs with the other branches' slice GEMVs), 48 the mask samplers' LDS request padded to 156 KiB so that
+ * they run alone on their CU (default 1; 0: the 76 KiB they use — the unit reproducer of DESIGN.md 3e needs that).  Keys of the determinism bisect (all default to the product's behaviour): 37 fp32-cache
  * engines fork their member sweeps (-1: one branch as in round 3), 39 extra dynamic LDS bytes requested by the fp32-cache attention tile pass
  * (so that it cannot share a CU with a slice GEMV), 40 the branches' streams on disjoint CU masks, 41 CU-mask only the attention launches,
  * 42 bit mask of kernel families launched on the UNMASKED stream while 40 is on (1 embed, 2 GEMVs, 4 attention, 8 finishing kernels),
