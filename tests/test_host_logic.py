@@ -169,6 +169,34 @@ def test_bench_gpus_n_starts_its_own_ranks_before_any_gpu_call(monkeypatch):
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_bench_takes_its_committed_profile_from_the_rounds_own_files(tmp_path, monkeypatch):
+    """`roofline.traffic` / `kernel_stats_avg_us` come from profiles/rNN_pmc_summary.json and rNN_kernel_stats.csv of the newest round (config 5:
+    rNN_c5_*) — not from any other file that merely ends in the same words (round 4: a tool's r04_prefill_ab_*_kernel_stats.csv sorted last and
+    the bench line carried a null)."""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    kern = "k_gemv_slices_seq<9, 4, 16, 3, 0, 2>"
+    for name, avg in (("r03_kernel_stats.csv", 48400.0), ("r04_kernel_stats.csv", 47850.0), ("r04_c5_kernel_stats.csv", 30390.0),
+                      ("r04_prefill_ab_mistral_kernel_stats.csv", 1.0)):
+        (prof / name).write_text('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                                 f'"void {kern}(SliceArgs)",10,{avg * 10},{avg},1.0,1,2,0.0\n')
+    for name, rd in (("r03_pmc_summary.json", 1), ("r04_pmc_summary.json", 184000000), ("r04_c5_pmc_summary.json", 55000000)):
+        (prof / name).write_text(json.dumps({"kernels": {f"void {kern}(SliceArgs)": {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": 1000}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench._profile_files() == (os.path.join("profiles", "r04_pmc_summary.json"), os.path.join("profiles", "r04_kernel_stats.csv"))
+    assert bench._profile_files("c5_") == (os.path.join("profiles", "r04_c5_pmc_summary.json"), os.path.join("profiles", "r04_c5_kernel_stats.csv"))
+    got = bench.committed_profile(kern)
+    assert got["stats_avg_us"] == 47.85 and got["traffic"] == 184001000 and got["stats_file"].endswith("r04_kernel_stats.csv")
+    assert bench.committed_profile(kern, "c5_")["stats_avg_us"] == 30.39
+    (prof / "r04_c5_kernel_stats.csv").unlink()                      # no config-5 trace this round: fall back to the default collection
+    assert bench._profile_files("c5_")[1] == os.path.join("profiles", "r04_kernel_stats.csv")
+
+
 def test_tensor_parallel_shards_reassemble_the_layer():
     """lm.tp_local_config / tp_shard_state_dict: head-aligned slices, d_ff padded to a multiple of 256 with zero rows / columns —
     the ranks' partial MLP and attention-output products add up to the un-sharded layer's."""
