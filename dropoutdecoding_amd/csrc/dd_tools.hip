@@ -686,3 +686,87 @@ extern "C" int dd_tools_pkadd_gload_probe(int launches, int wgs, int iters, unsi
   }
   return DD_OK;
 }
+
+// ----------------------------------------------------------------------------------------------
+// The sampler's co-residency fault, shrunk to its victim phase (second half; written at the end of round 4, to be RUN by the next
+// one: the round's GPU minutes were spent).  A workgroup of the sampler's shape — 1,024 threads, `lds_bytes` of dynamic LDS with the 624-word
+// generator block at the sampler's offset — does nothing but the mt19937 regeneration of dd_dropout.hip mt_twist_block (three block-parallel
+// sweeps and the last word, each `barrier; read three words; barrier; write`) `iters` times over, and after each regeneration wave 0 ALONE recomputes
+// the same 624 words from a copy of the old state, in order, 64 at a time, with no block barrier (a wave's LDS operations execute in order), and
+// all threads compare.  out[0] counts differing words, out[1..7] hold the first difference (workgroup, iteration, word, got, want, and the words
+// at index - 1 / + 1 as computed by the sweeps).  Run it on a stream of its own beside a group taking rider steps (tools/sampler_repro.py
+// twist_probe): differences there and none alone would put the fault between the barriers and the LDS of this phase, whatever else the sampler does.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tw_mix(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__global__ __launch_bounds__(1024) void k_twist_probe(uint32_t seed, int iters, int mt_word_offset, unsigned int* out) {
+  extern __shared__ __align__(16) uint32_t tw_lds[];
+  uint32_t* mt = tw_lds + mt_word_offset;       // the block under test, where the sampler keeps it
+  uint32_t* old_s = tw_lds;                     // [624] copy of the state before the regeneration
+  uint32_t* chk = tw_lds + 640;                 // [624] wave 0's in-order recomputation
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 624; i += 1024) {
+    uint32_t x = seed ^ (uint32_t)(blockIdx.x * 0x9e3779b9u) ^ (uint32_t)(i * 0x85ebca6bu);
+    x ^= x >> 15, x *= 0x2c1b3c6du, x ^= x >> 12, x *= 0x297a2d39u, x ^= x >> 15;
+    mt[i] = x;
+  }
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    for (int i = tid; i < 624; i += 1024) old_s[i] = mt[i];
+    // --- the phase under test: mt_twist_block as the sampler runs it ---
+    const int segs[4][2] = {{0, 227}, {227, 454}, {454, 623}, {623, 624}};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      __syncthreads();
+      uint32_t nv = 0;
+      const int i = segs[s][0] + tid;
+      const bool act = i < segs[s][1];
+      if (act) nv = tw_mix(mt[i], mt[(i + 1) % 624], mt[(i + 397) % 624]);
+      __syncthreads();
+      if (act) mt[i] = nv;
+    }
+    __syncthreads();
+    // --- wave 0's recomputation, in order ---
+    if (tid < 64) {
+      for (int b = 0; b < 624; b += 64) {
+        const int i = b + tid;
+        if (i < 623) {
+          const uint32_t c = i < 227 ? old_s[i + 397] : chk[i - 227];
+          chk[i] = tw_mix(old_s[i], old_s[i + 1], c);
+        }
+      }
+      if (tid == 0) chk[623] = tw_mix(old_s[623], chk[0], chk[396]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 624; i += 1024) {
+      if (mt[i] != chk[i]) {
+        if (atomicAdd(&out[0], 1u) == 0u) {
+          out[1] = blockIdx.x, out[2] = (unsigned)it, out[3] = (unsigned)i, out[4] = mt[i], out[5] = chk[i];
+          out[6] = mt[(i + 623) % 624], out[7] = mt[(i + 1) % 624];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 624; i += 1024) mt[i] = chk[i];      // continue from the reference state
+    __syncthreads();
+  }
+}
+extern "C" int dd_tools_twist_probe(int launches, int wgs, int iters, int lds_bytes, unsigned int* out_dev, void* stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  const int mt_off = (8192 * 4 * 2 + 8192) / 4;                  // the sampler's layout: after its two float arrays and its byte array
+  DD_REQUIRE(launches >= 1 && wgs >= 1 && iters >= 1 && out_dev && lds_bytes >= (mt_off + 624 + 8) * 4 && lds_bytes <= 156 * 1024,
+             "dd_tools_twist_probe: bad arguments (lds_bytes %d .. %d)", (mt_off + 632) * 4, 156 * 1024);
+  static bool attr = false;
+  if (!attr) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_twist_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    attr = true;
+  }
+  static uint32_t salt = 17;
+  for (int i = 0; i < launches; ++i) {
+    k_twist_probe<<<wgs, 1024, lds_bytes, st>>>(salt++, iters, mt_off, out_dev);
+    DD_CHECK_LAUNCH();
+  }
+  return DD_OK;
+}

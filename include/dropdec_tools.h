@@ -97,6 +97,11 @@ int dd_tools_lds_barrier_probe(int launches, int wgs, int rounds, unsigned int* 
 int dd_tools_pv_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
 /* Packed sums of eight 16-byte GLOBAL loads per thread (the slice GEMVs' finishing kernel) next to the same sums as scalar v_add_f32. */
 int dd_tools_pkadd_gload_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
+/* The mask sampler's co-residency fault shrunk to its victim phase: `wgs` workgroups of 1,024 threads with `lds_bytes` of dynamic
+ * LDS (77,856 = the sampler's own request before its padding .. 159,744) regenerate an mt19937 block `iters` times the way the sampler does and
+ * check every regeneration against an in-order recomputation by one wave.  out_dev[0] += differing words; out_dev[1..7] = the first difference
+ * (workgroup, iteration, word index, got, want, neighbours).  tools/sampler_repro.py twist_probe runs it beside a group taking rider steps. */
+int dd_tools_twist_probe(int launches, int wgs, int iters, int lds_bytes, unsigned int* out_dev, void* stream);
 int dd_tools_pk_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
 int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int* errors_dev, void* stream);
 int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,

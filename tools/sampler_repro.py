@@ -7,6 +7,11 @@
       private scratch per lane; libdropdec_tools.so only).
   probe(beside, rounds):  a kernel of the same shape that only writes a pattern into 616 bytes of private scratch per lane, lingers and
       verifies it.
+  sampler_streams(n_streams, rounds, lib, company_lanes):  THE reproducer of the round-3 event (found at the end of round 4): the sampler from
+      one or more streams beside a group of `company_lanes` sequences taking rider steps (StepCompany) — wrong masks about once in 50,000
+      launches with the un-padded kernel (tools key 48 = 0), none with the padded one.  Each StepCompany builds 32 engines on a host thread;
+      the fourth one in a process once failed to come back — run a few legs per process.
+  twist_probe(rounds, lib, company_lanes):  only the sampler's mt19937 regeneration, checked inside the kernel (dd_tools_twist_probe).
 
     python tools/sampler_repro.py [rounds]      # prints one JSON line per configuration
 """
@@ -269,6 +274,39 @@ def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 
     return {"test": "sampler_streams", "streams": n_streams, "sampler_launches": sum(launches), "workgroups_per_launch": N_SEQ,
             "company_rider_steps": steps, "company_lanes": company_lanes, "sequences_with_a_wrong_launch": sum(bad),
             "first_bad": [f for f in first_bad if f], "events": events, "seconds": round(time.time() - t0, 1)}
+
+
+def twist_probe(rounds: int, lib=None, company_lanes: int = 32, lds_bytes: int = 77856, wgs: int = 8, iters: int = 64) -> dict:
+    """dd_tools_twist_probe (csrc/dd_tools.hip): only the mt19937 regeneration of the sampler, in workgroups of the sampler's shape, checked in the
+    kernel against an in-order recomputation — on a stream of its own, alone (company_lanes = 0) or beside a group taking rider steps.  Written at
+    the end of round 4 and not yet run on a GPU."""
+    lib = lib or _lib.load_tools()
+    out = torch.zeros(8, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    t0 = time.time()
+    launches = 0
+
+    def body():
+        nonlocal launches
+        for r in range(rounds):
+            rc = lib.dd_tools_twist_probe(16, wgs, iters, lds_bytes, out.data_ptr(), st.cuda_stream)
+            assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+            launches += 16
+
+    steps = 0
+    if company_lanes:
+        with StepCompany(lib, company_lanes) as co:
+            body()
+            steps = co.steps
+    else:
+        body()
+    o = out.cpu().numpy().astype(np.uint32)
+    return {"test": "mt19937_regeneration_probe", "probe_launches": launches, "workgroups_per_launch": wgs, "regenerations_per_workgroup": iters,
+            "lds_bytes": lds_bytes, "company_lanes": company_lanes, "company_rider_steps": steps, "differing_words": int(o[0]),
+            "first": None if o[0] == 0 else {"workgroup": int(o[1]), "iteration": int(o[2]), "word": int(o[3]), "got": int(o[4]), "want": int(o[5]),
+                                              "word_before": int(o[6]), "word_after": int(o[7])},
+            "seconds": round(time.time() - t0, 1)}
 
 
 def probe(beside: bool, rounds: int, lib=None, wgs: int = 8, spin: int = 200) -> dict:
