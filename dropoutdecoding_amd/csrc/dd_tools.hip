@@ -736,6 +736,10 @@ __global__ __launch_bounds__(1024) void k_twist_probe(uint32_t seed, int iters, 
           const uint32_t c = i < 227 ? old_s[i + 397] : chk[i - 227];
           chk[i] = tw_mix(old_s[i], old_s[i + 1], c);
         }
+        // the next 64 words read what OTHER lanes of this wave just wrote: keep the compiler from moving those loads above these stores
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       if (tid == 0) chk[623] = tw_mix(old_s[623], chk[0], chk[396]);
     }
