@@ -186,7 +186,7 @@ class StepCompany:
             e.close()
 
 
-def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 0) -> dict:
+def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 0, sync_each: bool = False) -> dict:
     """The lanes sampler from `n_streams` host threads at once, each on a stream of its own with sequences (and rng streams) of its own — the
     branch-local form's launch pattern —, optionally beside a group of `company_lanes` sequences taking rider steps; every launch against the
     oracle."""
@@ -224,6 +224,8 @@ def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 
                                                      arr([d[s_].data_ptr() for d in drop]), arr([n[s_].data_ptr() for n in n_drop]),
                                                      arr([b[s_].data_ptr() for b in bits]), K_TOP, pr, K, DR.MODE_LLAVA_CUMULATIVE, st.cuda_stream)
                 assert rc == 0, lib.dd_last_error()
+                if sync_each:
+                    st.synchronize()          # (experiment) no two sampler launches back to back: the host waits for each
             st.synchronize()
             launches[t] += STEPS
             with torch.cuda.stream(st):
@@ -271,7 +273,7 @@ def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 
             steps = co.steps
     else:
         run()
-    return {"test": "sampler_streams", "streams": n_streams, "sampler_launches": sum(launches), "workgroups_per_launch": N_SEQ,
+    return {"test": "sampler_streams", "streams": n_streams, "host_waits_for_every_launch": sync_each, "sampler_launches": sum(launches), "workgroups_per_launch": N_SEQ,
             "company_rider_steps": steps, "company_lanes": company_lanes, "sequences_with_a_wrong_launch": sum(bad),
             "first_bad": [f for f in first_bad if f], "events": events, "seconds": round(time.time() - t0, 1)}
 
