@@ -926,8 +926,8 @@ void dd_dropout_set_lanes_sampler_scratch(int on) { g_lanes_sampler_scratch = on
 // Dynamic LDS the sampler kernels REQUEST: what they use (76 KiB) padded to 156 KiB, so that no workgroup of a kernel that needs more than ~3 KiB of
 // LDS — the decode attention's tile pass, the slice GEMVs, the prefill attention: every MFMA kernel of the library — is placed on the sampler's CU
 // while it runs.  Round 4's unit reproducer (tools/sampler_repro.py sampler_streams): the sampler on a stream of its own beside a group taking
-// rider steps produced a wrong mt19937 regeneration (64 consecutive state words) about once in 70,000 launches — the run-to-run difference of the
-// branch-local sampling schedule; never alone, never beside GEMVs whose LDS excludes it anyway.  dd_tools_set_tuning key 48 = 0:
+// rider steps found a 256-byte chunk of its mt19937 block in LDS changed between two uses about once in 50,000 launches — the run-to-run difference
+// of the branch-local sampling schedule; never alone, never beside GEMVs whose LDS excludes it anyway.  dd_tools_set_tuning key 48 = 0:
 // request only what is used.
 int g_sampler_lds_pad = 1;
 static size_t sampler_smem() {

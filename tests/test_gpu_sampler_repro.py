@@ -13,8 +13,8 @@ bit planes and counts compared with the oracle sampler over the host mt19937 (mo
 Also: no kernel of the product library may use private scratch (the build gate), and the sampler's round-3 form — which did — is only in
 libdropdec_tools.so.  tools/sampler_repro.py runs the same bodies for many more rounds.
 
-SECOND FINDING (end of round 4): the sampler itself is a victim of co-residency — on a stream of its own beside a group taking rider steps it
-regenerates 64 consecutive mt19937 state words wrongly about once in 50,000 launches (tools/sampler_repro.py sampler_streams(1, rounds, lib, 32);
+SECOND FINDING (end of round 4): the sampler itself is a victim of co-residency — on a stream of its own beside a group taking rider steps a
+256-byte chunk of its mt19937 block in LDS goes wrong between two uses about once in 50,000 launches (tools/sampler_repro.py sampler_streams(1, rounds, lib, 32);
 profiles/r04_determinism/r04_s30_*.json, r04_s31_*.log; never beside the GEMV company used below, whatever its width).  The kernels now request
 156 KiB of LDS so that no MFMA workgroup shares their CU: 0 wrong launches in 384,000.  That reproducer needs minutes of a second engine looping
 on a host thread, so it lives in tools/, not in this suite."""
