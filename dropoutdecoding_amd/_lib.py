@@ -27,7 +27,8 @@ SYMBOLS = [
 # include/dropdec_tools.h: libdropdec_tools.so only (bench.py's roofline leg, tools/)
 TOOLS_LIB_PATH = os.path.join(_HERE, "libdropdec_tools.so")
 TOOLS_SYMBOLS = ["dd_lm_time_sweep", "dd_lm_time_gemv", "dd_tools_last_gemv_kernel", "dd_hbm_read_bench", "dd_tools_set_tuning",
-                 "dd_tools_trace_attach", "dd_tools_lds_poison", "dd_tools_scratch_probe", "dd_tools_sample_masks_lanes", "dd_tools_sweep_trace", "dd_tools_attn_trace", "dd_tools_lds_barrier_probe", "dd_tools_lds_overlap_probe", "dd_tools_hold_probe", "dd_tools_pk_probe", "dd_tools_pv_probe", "dd_tools_pkadd_gload_probe", "dd_tools_twist_probe"]
+                 "dd_tools_trace_attach", "dd_tools_lds_poison", "dd_tools_scratch_probe", "dd_tools_sample_masks_lanes", "dd_tools_sweep_trace", "dd_tools_attn_trace", "dd_tools_lds_barrier_probe", "dd_tools_lds_overlap_probe", "dd_tools_hold_probe", "dd_tools_pk_probe", "dd_tools_pv_probe", "dd_tools_pkadd_gload_probe", "dd_tools_twist_probe", "dd_tools_barrier_probe", "dd_tools_pk_war_probe",
+                 "dd_tools_sampler_dbg_attach", "dd_tools_sampler_dbg_words", "dd_tools_sampler_dbg_launches"]
 
 
 TP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)     # int exchange(void* ctx, int rows, void* stream)
@@ -104,6 +105,13 @@ def load_tools() -> C.CDLL:
         lib.dd_tools_pv_probe.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
         lib.dd_tools_pkadd_gload_probe.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
         lib.dd_tools_twist_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        lib.dd_tools_pk_war_probe.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
+        lib.dd_tools_barrier_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        lib.dd_tools_sampler_dbg_attach.argtypes = [vp]
+        lib.dd_tools_sampler_dbg_words.restype = C.c_size_t
+        lib.dd_tools_sampler_dbg_words.argtypes = []
+        lib.dd_tools_sampler_dbg_launches.restype = C.c_uint
+        lib.dd_tools_sampler_dbg_launches.argtypes = []
         lib.dd_tools_sample_masks_lanes.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]
     return _tools
 

@@ -27,7 +27,7 @@ TOOLS_SOURCES = ["dd_tools.hip"]      # only in libdropdec_tools.so
 SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_gemv.hip", "dd_attn_decode.hip", "dd_prefill.hip", "dd_engine.hip", "dd_tp.hip", "dd_vision.hip"]
 # sources that libdropdec_tools.so takes in a second compilation with extra macros (A/B variants that must not be in the product)
 TOOLS_VARIANTS = {"dd_dropout.hip": ["-DDD_KEEP_SCRATCH_SAMPLER"]}
-HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", "dd_engine_internal.h",
+HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", "dd_engine_internal.h", "dd_sampler_block.h",
            os.path.join(ROOT, "include", "dropdec_tools.h"), os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]

@@ -501,20 +501,35 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
   return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
-// Regenerate the 624 words held in LDS. The sequential recurrence new[i] = f(old[i], old[i+1], x[i+397 mod 624])
-// only reaches back 227 places, so it runs as three block-parallel sweeps plus the last word.
-__device__ void mt_twist_block(uint32_t* mt) {
-  const int segs[4][2] = {{0, 227}, {227, 454}, {454, 623}, {623, 624}};
-  for (int s = 0; s < 4; ++s) {
-    __syncthreads();
+// ----------------------------------------------------------------------------------------------
+// ONE WAVE per generator (round 5).  Until round 5 every kernel that touches a generator block was a 1,024-thread workgroup whose phases were
+// fenced by s_barrier; that form is the victim of the co-residency fault of DESIGN.md 3e (its waves fall out of step across s_barrier while the
+// kernels of a rider step share the CU; csrc/dd_sampler_block.h keeps it for the reproducer).  A single wavefront needs no barrier: its LDS
+// operations execute in program order, so "all reads of this chunk before its writes, this chunk before the next" is the order of the instructions.
+// DD_WSYNC only stops the COMPILER from moving LDS accesses across a phase boundary (other lanes' data); it emits no s_barrier.
+// ----------------------------------------------------------------------------------------------
+#define DD_WSYNC()                                            \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+
+// Regenerate the 624 words held in LDS, one wave, 64 words at a time in index order: new[i] = f(cur[i], cur[i+1], cur[i+397 mod 624]) reads
+// words the sequential recurrence has not reached yet (i+1: same chunk, read before the chunk's writes; i+397 < 624: a later chunk) or has
+// already replaced (i+397-624 = i-227 and, for i = 623, word 0: earlier chunks) — the sequential algorithm's values exactly.
+__device__ __forceinline__ void mt_twist_wave(uint32_t* mt) {
+  const int lane = threadIdx.x;
+#pragma unroll 1
+  for (int b = 0; b < MT_N; b += 64) {
+    const int i = b + lane;
+    const bool act = i < MT_N;
     uint32_t nv = 0;
-    int i = segs[s][0] + (int)threadIdx.x;
-    bool act = i < segs[s][1];
-    if (act) nv = mt_mix(mt[i], mt[(i + 1) % MT_N], mt[(i + MT_M) % MT_N]);
-    __syncthreads();
+    if (act) nv = mt_mix(mt[i], mt[i + 1 == MT_N ? 0 : i + 1], mt[i + MT_M >= MT_N ? i + MT_M - MT_N : i + MT_M]);
+    DD_WSYNC();
     if (act) mt[i] = nv;
+    DD_WSYNC();
   }
-  __syncthreads();
 }
 
 __device__ __forceinline__ float mt_temper_uniform(uint32_t y) {
@@ -545,38 +560,6 @@ __device__ __forceinline__ float philox_uniform(uint32_t x) {
   return u == 1.0f ? 0.0f : u;
 }
 
-// Fill out[0..n) (LDS or global) with the next n uniforms; generator block in LDS, *idx block-uniform.
-__device__ void mt_fill_block(uint32_t* mt, int* idx_sh, float* out, int n) {
-  __syncthreads();
-  if ((uint32_t)*idx_sh == PHILOX_TAG) {   // one rand_like: element t = subsequence t at the current offset; offset += 4
-    const unsigned long long off = (unsigned long long)mt[2] | ((unsigned long long)mt[3] << 32);
-    const uint32_t k0 = mt[0], k1 = mt[1];
-    for (int t = threadIdx.x; t < n; t += blockDim.x) out[t] = philox_uniform(philox_first(k0, k1, off >> 2, (unsigned long long)t));
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long o2 = off + 4ull;
-      mt[2] = (uint32_t)o2, mt[3] = (uint32_t)(o2 >> 32);
-    }
-    __syncthreads();
-    return;
-  }
-  int pos = 0;
-  while (pos < n) {
-    __syncthreads();
-    int idx = *idx_sh;
-    if (idx >= MT_N) {
-      mt_twist_block(mt);
-      idx = 0;
-    }
-    int take = min(n - pos, MT_N - idx);
-    for (int t = threadIdx.x; t < take; t += blockDim.x) out[pos + t] = mt_temper_uniform(mt[idx + t]);
-    __syncthreads();
-    if (threadIdx.x == 0) *idx_sh = idx + take;
-    pos += take;
-  }
-  __syncthreads();
-}
-
 __global__ void k_philox_seed(uint32_t* st, unsigned long long seed, unsigned long long offset) {
   for (int i = threadIdx.x; i < MT_N; i += blockDim.x) st[i] = 0u;
   __syncthreads();
@@ -586,15 +569,57 @@ __global__ void k_philox_seed(uint32_t* st, unsigned long long seed, unsigned lo
   }
 }
 
-__global__ __launch_bounds__(1024) void k_mt_uniform(uint32_t* st, float* out, int n) {
-  __shared__ uint32_t mt[MT_N];
-  __shared__ int idx_sh;
-  for (int i = threadIdx.x; i < MT_N; i += blockDim.x) mt[i] = st[i];
-  if (threadIdx.x == 0) idx_sh = (int)st[MT_N];
-  __syncthreads();
-  mt_fill_block(mt, &idx_sh, out, n);
-  for (int i = threadIdx.x; i < MT_N; i += blockDim.x) st[i] = mt[i];
-  if (threadIdx.x == 0) st[MT_N] = (uint32_t)idx_sh;
+// Fill out[0..n) (LDS or global) with the next n uniforms of the generator block in LDS (one wave); idx: the read index (wave-uniform register).
+__device__ __forceinline__ void mt_fill_wave(uint32_t* mt, int& idx, float* out, int n) {
+  const int lane = threadIdx.x;
+  DD_WSYNC();
+  if ((uint32_t)idx == PHILOX_TAG) {   // one rand_like: element t = subsequence t at the current offset; offset += 4
+    const unsigned long long off = (unsigned long long)mt[2] | ((unsigned long long)mt[3] << 32);
+    const uint32_t k0 = mt[0], k1 = mt[1];
+    for (int t = lane; t < n; t += 64) out[t] = philox_uniform(philox_first(k0, k1, off >> 2, (unsigned long long)t));
+    DD_WSYNC();
+    if (lane == 0) {
+      const unsigned long long o2 = off + 4ull;
+      mt[2] = (uint32_t)o2, mt[3] = (uint32_t)(o2 >> 32);
+    }
+    DD_WSYNC();
+    return;
+  }
+  int pos = 0;
+  while (pos < n) {
+    if (idx >= MT_N) {
+      mt_twist_wave(mt);
+      idx = 0;
+    }
+    const int take = min(n - pos, MT_N - idx);
+    for (int t = lane; t < take; t += 64) out[pos + t] = mt_temper_uniform(mt[idx + t]);
+    idx += take;
+    pos += take;
+  }
+  DD_WSYNC();
+}
+
+// dd_rng_uniform, mt19937: one wave walks the stream (a draw of n costs n / 624 regenerations of ~1 us)
+__global__ __launch_bounds__(64) void k_mt_uniform(uint32_t* st, float* out, int n) {
+  __shared__ uint32_t mt[MT_N + 8];
+  for (int i = threadIdx.x; i < MT_N; i += 64) mt[i] = st[i];
+  int idx = (int)st[MT_N];
+  mt_fill_wave(mt, idx, out, n);
+  for (int i = threadIdx.x; i < MT_N; i += 64) st[i] = mt[i];
+  if (threadIdx.x == 0) st[MT_N] = (uint32_t)idx;
+}
+// dd_rng_uniform, Philox: every element is its own subsequence — a plain grid, no LDS; the offset advances in k_philox_advance
+__global__ __launch_bounds__(256) void k_philox_uniform(const uint32_t* __restrict__ st, float* __restrict__ out, int n) {
+  const unsigned long long off = (unsigned long long)st[2] | ((unsigned long long)st[3] << 32);
+  const uint32_t k0 = st[0], k1 = st[1];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n) out[t] = philox_uniform(philox_first(k0, k1, off >> 2, (unsigned long long)t));
+}
+__global__ void k_philox_advance(uint32_t* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const unsigned long long o2 = ((unsigned long long)st[2] | ((unsigned long long)st[3] << 32)) + 4ull;
+    st[2] = (uint32_t)o2, st[3] = (uint32_t)(o2 >> 32);
+  }
 }
 
 extern "C" int dd_rng_create(uint32_t seed, dd_rng** out) {
@@ -651,7 +676,12 @@ extern "C" int dd_rng_uniform(dd_rng* r, float* out, int n, void* stream_) {
   DD_REQUIRE(r && out && n >= 0, "dd_rng_uniform: bad arguments");
   if (n == 0) return DD_OK;
   DD_REQUIRE(r->kind == 0 || n <= 524288, "dd_rng_uniform: a Philox draw covers at most 524288 elements per call (got %d)", n);
-  k_mt_uniform<<<1, 1024, 0, (hipStream_t)stream_>>>(r->state, out, n);
+  if (r->kind == 1) {
+    k_philox_uniform<<<(n + 255) / 256, 256, 0, (hipStream_t)stream_>>>(r->state, out, n);
+    k_philox_advance<<<1, 64, 0, (hipStream_t)stream_>>>(r->state);
+  } else {
+    k_mt_uniform<<<1, 64, 0, (hipStream_t)stream_>>>(r->state, out, n);
+  }
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -659,10 +689,9 @@ uint32_t* dd_rng_state_ptr(dd_rng* r) { return r ? r->state : nullptr; }
 unsigned long long dd_rng_serial(dd_rng* r) { return r ? r->serial : 0ull; }
 
 // ----------------------------------------------------------------------------------------------
-// Mask sampler: one workgroup, all K members of a step (get_image_attention_mask "epis")
+// Mask sampler: one WAVE, all K members of a step (get_image_attention_mask "epis")
 // ----------------------------------------------------------------------------------------------
 #define MASK_MAX_L 8192
-#define MASK_THREADS 1024
 
 struct MaskParams {
   const float* epi;
@@ -681,31 +710,6 @@ struct MaskParams {
   float q[64];            // f32(1 - mprob)     (reference instructblip.py:450); directly behind scale[]: the kernels stage both as one table
 };
 static_assert(offsetof(MaskParams, q) == offsetof(MaskParams, scale) + 64 * sizeof(float), "scale[] and q[] must be adjacent");
-
-__device__ float block_min_max(const float* e, int L, bool want_max, float* sh) {
-  float v = want_max ? -INFINITY : INFINITY;
-  for (int l = threadIdx.x; l < L; l += blockDim.x) v = want_max ? fmaxf(v, e[l]) : fminf(v, e[l]);
-  if (!want_max) v = -v;
-  v = block_max_f(v, sh);
-  return want_max ? v : -v;
-}
-
-// exclusive prefix of `flag` over the block in thread order; returns prefix, *total gets the block total
-__device__ int block_exclusive_scan_flag(bool flag, int* sh /*>=17*/, int* total) {
-  unsigned long long b = __ballot(flag);
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  int within = __popcll(b & ((1ull << lane) - 1ull));
-  __syncthreads();
-  if (lane == 0) sh[w] = __popcll(b);
-  __syncthreads();
-  int off = 0, tot = 0;
-  for (int j = 0; j < nw; ++j) {
-    if (j < w) off += sh[j];
-    tot += sh[j];
-  }
-  *total = tot;
-  return off + within;
-}
 
 // The per-sequence operands of one workgroup's sampling, in registers.
 struct MaskSeq {
@@ -728,136 +732,152 @@ struct MaskConst {
   const float* scale;   // [K] f32(mprob - 0.1), in LDS
   const float* q;       // [K] f32(1 - mprob), in LDS
 };
-__device__ __forceinline__ void sample_masks_body(const MaskConst C, const MaskSeq P, unsigned char* smem) {
-  float* e = (float*)smem;                       // [Lp]
-  float* u = e + MASK_MAX_L;                     // [Lp] uniforms of the current member, or sort buffer
-  uint8_t* running = (uint8_t*)(u + MASK_MAX_L);  // [L]
-  uint32_t* mt = (uint32_t*)(running + MASK_MAX_L);
-  __shared__ float sh_f[16];
-  __shared__ int sh_i[17];
-  __shared__ int idx_sh;
-  const int L = P.L, tid = threadIdx.x;
+// One wave samples all K members of one sequence.  Dynamic LDS (smem, Lp = L rounded up to a power of two >= 64):
+//   e[Lp] f32 | u[Lp] f32 (the current member's uniforms, or the sort buffer) | running[Lp] u8 | keep[Lp] u8 | mt[632] u32
+// keep_lds: the keep flags are already in LDS (the lanes kernel computes them there); else they are copied from P.keep (null: empty set).
+__device__ __forceinline__ size_t sampler_lp(int L) {
+  int Lp = 64;
+  while (Lp < L) Lp <<= 1;
+  return (size_t)Lp;
+}
+__device__ __forceinline__ void sample_masks_wave(const MaskConst C, const MaskSeq P, unsigned char* smem, const bool keep_lds) {
+  const int L = P.L, lane = threadIdx.x;
+  const int Lp = (int)sampler_lp(L);
+  float* e = (float*)smem;                          // [Lp]
+  float* u = e + Lp;                                // [Lp]
+  uint8_t* running = (uint8_t*)(u + Lp);            // [Lp]
+  uint8_t* keep = running + Lp;                     // [Lp]
+  uint32_t* mt = (uint32_t*)(keep + Lp);            // [MT_N + 8]
+  const bool no_overlap = C.mode == DD_MASK_NEXT_NO_OVERLAP || C.mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP;
 
-  for (int l = tid; l < L; l += MASK_THREADS) {
+  for (int l = lane; l < L; l += 64) {
     e[l] = P.epi[l];
     running[l] = 0;
+    if (!keep_lds) keep[l] = (P.keep && !no_overlap) ? P.keep[l] : (uint8_t)0;
   }
+  int idx = 0;
   if (C.rng_mode == DD_RNG_MT19937) {
     const uint32_t* src = P.rng_in ? P.rng_in : P.rng_state;
-    for (int i = tid; i < MT_N; i += MASK_THREADS) mt[i] = src[i];
-    if (tid == 0) idx_sh = (int)src[MT_N];
+    for (int i = lane; i < MT_N; i += 64) mt[i] = src[i];
+    idx = (int)src[MT_N];
   }
-  __syncthreads();
+  DD_WSYNC();
   float lo = 0.f, hi = 0.f;
   if (C.mode != DD_MASK_IBLIP_QUANTILE) {
-    lo = block_min_max(e, L, false, sh_f);  // torch.quantile(e, 0) == min   (llava.py:641)
-    hi = block_min_max(e, L, true, sh_f);   // torch.quantile(e, 1) == max   (llava.py:642)
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (int l = lane; l < L; l += 64) {
+      vmin = fminf(vmin, e[l]);                      // torch.quantile(e, 0) == min   (llava.py:641)
+      vmax = fmaxf(vmax, e[l]);                      // torch.quantile(e, 1) == max   (llava.py:642)
+    }
+    lo = -dd_wave_max(-vmin);
+    hi = dd_wave_max(vmax);
   } else {
-    // ascending bitonic sort of e into u (padded with +inf): torch.quantile sorts first
-    int Lp = 1;
-    while (Lp < L) Lp <<= 1;
-    for (int l = tid; l < Lp; l += MASK_THREADS) u[l] = l < L ? e[l] : INFINITY;
-    __syncthreads();
+    // ascending bitonic sort of e into u (padded with +inf): torch.quantile sorts first.  One wave: a pass's pairs are disjoint, passes follow
+    // each other in program order.
+    for (int l = lane; l < Lp; l += 64) u[l] = l < L ? e[l] : INFINITY;
+    DD_WSYNC();
     for (int k2 = 2; k2 <= Lp; k2 <<= 1) {
       for (int j = k2 >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < Lp; i += MASK_THREADS) {
-          int ixj = i ^ j;
+        for (int i = lane; i < Lp; i += 64) {
+          const int ixj = i ^ j;
           if (ixj > i) {
-            float a = u[i], b = u[ixj];
-            bool up = ((i & k2) == 0);
+            const float a = u[i], b = u[ixj];
+            const bool up = ((i & k2) == 0);
             if ((a > b) == up) {
               u[i] = b;
               u[ixj] = a;
             }
           }
         }
-        __syncthreads();
+        DD_WSYNC();
       }
     }
   }
 
   for (int k = 0; k < C.K; ++k) {   // DD_MASK_IBLIP_KL runs the NEXT_RESET rule: its keep flags come from dd_kl_keep instead of the overlap
     if (C.mode != DD_MASK_LLAVA_CUMULATIVE && C.mode != DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP) {  // reset: llavanext.py:546, instructblip.py:121
-      for (int l = tid; l < L; l += MASK_THREADS) running[l] = 0;
+      for (int l = lane; l < L; l += 64) running[l] = 0;
     }
     float thr = 0.f;
     if (C.mode == DD_MASK_IBLIP_QUANTILE) {
       // torch.quantile(e, q) with linear interpolation, fp32: rank = q*(n-1); lerp(sorted[floor], sorted[ceil], frac)
       // ATen's lerp: weight < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w), contracted to one fma on the CPU build.
-      float rank = C.q[k] * (float)(L - 1);
-      float fl = floorf(rank);
-      int i0 = (int)fl, i1 = (int)ceilf(rank);
-      float w = rank - fl;
-      float a = u[i0], b = u[i1], diff = b - a;
+      const float rank = C.q[k] * (float)(L - 1);
+      const float fl = floorf(rank);
+      const int i0 = (int)fl, i1 = (int)ceilf(rank);
+      const float w = rank - fl;
+      const float a = u[i0], b = u[i1], diff = b - a;
       thr = (w < 0.5f) ? fmaf(w, diff, a) : fmaf(-diff, 1.0f - w, b);
     } else if (C.rng_mode == DD_RNG_MT19937) {
-      mt_fill_block(mt, &idx_sh, u, L);  // one rand_like(e) per member (llava.py:650)
+      mt_fill_wave(mt, idx, u, L);  // one rand_like(e) per member (llava.py:650)
     }
-    __syncthreads();
+    DD_WSYNC();
     const float scale = C.scale[k];
     const float range = __fsub_rn(hi, lo);
-    const bool no_overlap = C.mode == DD_MASK_NEXT_NO_OVERLAP || C.mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP;
-    int total = 0, cnt = 0;
-    for (int base = 0; base < L; base += MASK_THREADS) {
-      int l = base + tid;
+    int cnt = 0;
+    for (int base = 0; base < L; base += 64) {
+      const int l = base + lane;
       bool dropped = false;
       if (l < L) {
         bool d;
         if (C.mode == DD_MASK_IBLIP_QUANTILE) {
           d = e[l] >= thr;  // instructblip.py:453
         } else {
-          float r = (C.rng_mode == DD_RNG_MT19937) ? u[l] : P.uniforms[(size_t)k * L + l];
+          const float r = (C.rng_mode == DD_RNG_MT19937) ? u[l] : P.uniforms[(size_t)k * L + l];
           // p = 0.1 + (mprob-0.1)*(clamp(e,lo,hi)-lo)/(hi-lo), every step rounded to fp32 (llava.py:646-647)
-          float c = fminf(fmaxf(e[l], lo), hi);
-          float p = __fadd_rn(0.1f, __fdiv_rn(__fmul_rn(scale, __fsub_rn(c, lo)), range));
+          const float c = fminf(fmaxf(e[l], lo), hi);
+          const float p = __fadd_rn(0.1f, __fdiv_rn(__fmul_rn(scale, __fsub_rn(c, lo)), range));
           d = r < p;  // llava.py:653 (NaN p when hi == lo: nothing dropped)
         }
         uint8_t run = running[l] | (d ? 1 : 0);                      // llava.py:654-657, in place
-        if (!no_overlap && P.keep && P.keep[l]) run = 0;  // llava.py:660 keep-restore (keep null: an empty keep set)
+        if (keep[l]) run = 0;                                        // llava.py:660 keep-restore (no-overlap modes / an empty set: keep[] is zero)
         running[l] = run;
         P.drop[(size_t)k * L + l] = run;
         dropped = run != 0;
+        if (P.drop_bits) {
+          uint8_t* bp = P.drop_bits + (size_t)(k >> 3) * L + l;
+          const uint8_t cur = (k & 7) ? *bp : 0;                     // (this lane wrote it for member k - 1)
+          *bp = cur | (uint8_t)((run ? 1 : 0) << (k & 7));
+        }
       }
-      int off = block_exclusive_scan_flag(dropped, sh_i, &total);
-      if (P.idx && dropped) P.idx[(size_t)k * L + cnt + off] = l;
-      cnt += total;
+      const unsigned long long b = __ballot(dropped);
+      if (P.idx && dropped) P.idx[(size_t)k * L + cnt + __popcll(b & ((1ull << lane) - 1ull))] = l;
+      cnt += __popcll(b);
     }
     if (P.idx)
-      for (int l = cnt + tid; l < L; l += MASK_THREADS) P.idx[(size_t)k * L + l] = -1;
-    if (tid == 0) P.n_drop[k] = cnt;  // masked_numbers (llava.py:661-662)
-    __syncthreads();
-    if (P.drop_bits) {
-      for (int l = tid; l < L; l += MASK_THREADS) {
-        uint8_t* bp = P.drop_bits + (size_t)(k >> 3) * L + l;
-        uint8_t cur = (k & 7) ? *bp : 0;
-        *bp = cur | (uint8_t)((running[l] ? 1 : 0) << (k & 7));
-      }
-    }
-    __syncthreads();
+      for (int l = cnt + lane; l < L; l += 64) P.idx[(size_t)k * L + l] = -1;
+    if (lane == 0) P.n_drop[k] = cnt;  // masked_numbers (llava.py:661-662)
+    DD_WSYNC();
   }
   if (C.rng_mode == DD_RNG_MT19937 && !P.rng_in) {
-    for (int i = tid; i < MT_N; i += MASK_THREADS) P.rng_state[i] = mt[i];
-    if (tid == 0) P.rng_state[MT_N] = (uint32_t)idx_sh;
+    for (int i = lane; i < MT_N; i += 64) P.rng_state[i] = mt[i];
+    if (lane == 0) P.rng_state[MT_N] = (uint32_t)idx;
   }
 }
+static size_t sampler_wave_smem(int L) {
+  size_t Lp = 64;
+  while (Lp < (size_t)L) Lp <<= 1;
+  return Lp * 10 + (MT_N + 8) * 4;
+}
 
-__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks(MaskParams P) {
+__global__ __launch_bounds__(64) void k_sample_masks(MaskParams P) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (P.gate && *P.gate) return;          // sequence finished (EOS): draw nothing, write nothing
   __shared__ float sh_tab[128];
   {
     const float __attribute__((address_space(4)))* tab = (const float __attribute__((address_space(4)))*)(
         (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MaskParams, scale));
-    if (threadIdx.x < 128) sh_tab[threadIdx.x] = tab[threadIdx.x];
+    sh_tab[threadIdx.x] = tab[threadIdx.x];
+    sh_tab[threadIdx.x + 64] = tab[threadIdx.x + 64];
   }
-  __syncthreads();
+  DD_WSYNC();
   const MaskSeq S = {P.epi, P.L, P.keep, P.uniforms, P.rng_state, P.drop, P.n_drop, P.idx, P.drop_bits, P.rng_in};
   const MaskConst C = {P.K, P.mode, P.rng_mode, sh_tab, sh_tab + 64};
-  sample_masks_body(C, S, smem);
+  sample_masks_wave(C, S, smem, false);
 }
 
 // Group step: the keep set (models/llava.py:443-482 from the base argmax already on the device) and the K masks of up to
-// 16 sequences in ONE launch, one workgroup per sequence, each from its own mt19937 state.
+// 32 sequences in ONE launch, one wave per sequence, each from its own mt19937 state.
 struct MaskLanes {
   MaskParams common;                 // K, mode, rng_mode, scale[], q[]; per-sequence fields below override the rest
   int n, k_top;
@@ -872,69 +892,49 @@ struct MaskLanes {
   uint8_t* drop_bits[32];
   const int32_t* gate[32];
 };
-__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks_lanes(MaskLanes M) {
+__global__ __launch_bounds__(64) void k_sample_masks_lanes(MaskLanes M) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int m = blockIdx.x;
   if (M.gate[m] && *M.gate[m]) return;    // this sequence finished (EOS): its stream and masks stay as they are
   const int L = M.L[m], k = M.k_top;
   const int tok = M.argmax[m][0];
-  for (int l = threadIdx.x; l < L; l += MASK_THREADS) {
+  uint8_t* keep_sh = smem + sampler_lp(L) * 9;       // sample_masks_wave's keep[]
+  const bool no_overlap = M.common.mode == DD_MASK_NEXT_NO_OVERLAP || M.common.mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP;
+  for (int l = threadIdx.x; l < L; l += 64) {
     bool hit = false;
     for (int j = 0; j < k; ++j) hit |= (M.topk[m][(size_t)l * k + j] == tok);
     M.keep[m][l] = hit ? 1 : 0;
+    keep_sh[l] = (hit && !no_overlap) ? 1 : 0;
   }
   __shared__ float sh_tab[128];
   {  // scale[] and q[] are adjacent in the kernel arguments: 128 floats read straight from the kernarg segment
     const float __attribute__((address_space(4)))* tab = (const float __attribute__((address_space(4)))*)(
         (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MaskLanes, common.scale));
-    if (threadIdx.x < 128) sh_tab[threadIdx.x] = tab[threadIdx.x];
+    sh_tab[threadIdx.x] = tab[threadIdx.x];
+    sh_tab[threadIdx.x + 64] = tab[threadIdx.x + 64];
   }
-  __syncthreads();                   // keep[] is read back by this same workgroup
+  DD_WSYNC();
   // (uniforms / idx / rng_in are null for lanes — taken from the zeroed common block, not written as literal nullptr: with the
   // constants folded into the inlined body hipcc 7.2's instcombine dies on the dead injected-uniforms load)
   const MaskSeq S = {M.epi[m], L, M.keep[m], M.common.uniforms, M.rng_state[m], M.drop[m], M.n_drop[m], M.common.idx, M.drop_bits[m], M.common.rng_in};
   const MaskConst C = {M.common.K, M.common.mode, M.common.rng_mode, sh_tab, sh_tab + 64};
-  sample_masks_body(C, S, smem);
+  sample_masks_wave(C, S, smem, true);
 }
 #ifdef DD_KEEP_SCRATCH_SAMPLER
-// The form this kernel had until round 4, kept in libdropdec_tools.so ONLY (build.py compiles this file a second time with the macro)
-// for the A/B of tools/stress_lanes.py and the unit reproducer: the by-value copy below is indexed by the member loop, so the compiler
-// keeps it in private scratch (616 bytes per lane).
-__global__ __launch_bounds__(MASK_THREADS) void k_sample_masks_lanes_scratch(MaskLanes M) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int m = blockIdx.x;
-  if (M.gate[m] && *M.gate[m]) return;
-  const int L = M.L[m], k = M.k_top;
-  const int tok = M.argmax[m][0];
-  for (int l = threadIdx.x; l < L; l += MASK_THREADS) {
-    bool hit = false;
-    for (int j = 0; j < k; ++j) hit |= (M.topk[m][(size_t)l * k + j] == tok);
-    M.keep[m][l] = hit ? 1 : 0;
-  }
-  __syncthreads();
-  MaskParams P = M.common;           // (uniforms, idx, rng_in: null in the common block)
-  P.epi = M.epi[m], P.L = L, P.keep = M.keep[m], P.rng_state = M.rng_state[m];
-  P.drop = M.drop[m], P.n_drop = M.n_drop[m], P.drop_bits = M.drop_bits[m];
-  const MaskSeq S = {P.epi, P.L, P.keep, P.uniforms, P.rng_state, P.drop, P.n_drop, P.idx, P.drop_bits, P.rng_in};
-  const MaskConst C = {P.K, P.mode, P.rng_mode, P.scale, P.q};     // tables in the private copy
-  sample_masks_body(C, S, smem);
-}
-static int g_lanes_sampler_scratch = 0;
-void dd_dropout_set_lanes_sampler_scratch(int on) { g_lanes_sampler_scratch = on; }
+#include "dd_sampler_block.h"          // the 1,024-thread forms, for tools/sampler_repro.py (dd_tools_set_tuning key 34: 1 scratch, 2 checking, 3 plain)
 #endif
 
-// Dynamic LDS the sampler kernels REQUEST: what they use (76 KiB) padded to 156 KiB, so that no workgroup of a kernel that needs more than ~3 KiB of
-// LDS — the decode attention's tile pass, the slice GEMVs, the prefill attention: every MFMA kernel of the library — is placed on the sampler's CU
-// while it runs.  Round 4's unit reproducer (tools/sampler_repro.py sampler_streams): the sampler on a stream of its own beside a group taking
-// rider steps found a 256-byte chunk of its mt19937 block in LDS changed between two uses about once in 50,000 launches — the run-to-run difference
-// of the branch-local sampling schedule; never alone, never beside GEMVs whose LDS excludes it anyway.  dd_tools_set_tuning key 48 = 0:
-// request only what is used.
+// (tools library) dynamic LDS the 1,024-thread forms of dd_sampler_block.h REQUEST: dd_tools_set_tuning key 48 = 0: the 76 KiB they use; 1: 156 KiB
+// (round 4's fence: no kernel with more than ~3 KiB of LDS shares the CU); n > 1: n KiB (the request sweep of DESIGN.md 3e).
 int g_sampler_lds_pad = 1;
+#ifdef DD_KEEP_SCRATCH_SAMPLER
+static size_t sampler_smem_used() { return (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4; }
 static size_t sampler_smem() {
-  const size_t used = (size_t)MASK_MAX_L * 4 * 2 + MASK_MAX_L + (MT_N + 8) * 4;
-  const size_t padded = (size_t)156 * 1024;
-  return g_sampler_lds_pad && padded > used ? padded : used;
+  const size_t used = sampler_smem_used();
+  const size_t padded = (size_t)(g_sampler_lds_pad == 1 ? 156 : g_sampler_lds_pad) * 1024;
+  return g_sampler_lds_pad && padded > used ? (padded > (size_t)156 * 1024 ? (size_t)156 * 1024 : padded) : used;
 }
+#endif
 int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const double* mprobs, int K, int mode, hipStream_t st) {
   DD_REQUIRE(lanes && n >= 1 && n <= 32 && K >= 1 && K <= 64 && mode >= 0 && mode <= 4, "dd_sample_masks_lanes: bad arguments");
   MaskLanes M;
@@ -952,25 +952,37 @@ int dd_sample_masks_lanes(const MaskLaneArgs* lanes, int n, int k_top, const dou
     M.topk[m] = lanes[m].topk, M.rng_state[m] = lanes[m].rng_state, M.drop[m] = lanes[m].drop, M.n_drop[m] = lanes[m].n_drop;
     M.drop_bits[m] = lanes[m].drop_bits, M.gate[m] = lanes[m].gate;
   }
-  const size_t smem = sampler_smem();
-  static bool attr_set = false;
-  if (!attr_set) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    attr_set = true;
-  }
+  int Lmax = 1;
+  for (int m = 0; m < n; ++m) Lmax = lanes[m].L > Lmax ? lanes[m].L : Lmax;
 #ifdef DD_KEEP_SCRATCH_SAMPLER
   if (g_lanes_sampler_scratch) {
+    const size_t smem = sampler_smem();
     static bool attr2 = false;
     if (!attr2) {
+      DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes_scratch, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes_block, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       attr2 = true;
     }
-    k_sample_masks_lanes_scratch<<<n, MASK_THREADS, smem, st>>>(M);
+    if (g_lanes_sampler_scratch == 2) {
+      DD_REQUIRE(g_sampler_dbg_buf, "dd_sample_masks_lanes: the checking sampler needs dd_tools_sampler_dbg_attach first");
+      k_sample_masks_lanes_dbg<<<n, MASK_THREADS, smem, st>>>(M, g_sampler_dbg_buf, ++g_sampler_dbg_tag, (int)sampler_smem_used());
+    } else if (g_lanes_sampler_scratch == 3) {
+      k_sample_masks_lanes_block<<<n, MASK_THREADS, smem, st>>>(M);
+    } else {
+      k_sample_masks_lanes_scratch<<<n, MASK_THREADS, smem, st>>>(M);
+    }
     DD_CHECK_LAUNCH();
     return DD_OK;
   }
 #endif
-  k_sample_masks_lanes<<<n, MASK_THREADS, smem, st>>>(M);
+  const size_t smem = sampler_wave_smem(Lmax);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks_lanes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sampler_wave_smem(MASK_MAX_L)));
+    attr_set = true;
+  }
+  k_sample_masks_lanes<<<n, 64, smem, st>>>(M);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -1001,13 +1013,13 @@ int dd_sample_masks_impl(const float* epi, int L, const double* mprobs, int K, c
     P.scale[k] = (float)(mprobs[k] - 0.1);  // double subtraction, then one rounding to fp32
     P.q[k] = (float)(1.0 - mprobs[k]);
   }
-  const size_t smem = sampler_smem();
+  const size_t smem = sampler_wave_smem(L);
   static bool attr_set = false;
   if (!attr_set) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    DD_HIP(hipFuncSetAttribute((const void*)k_sample_masks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sampler_wave_smem(MASK_MAX_L)));
     attr_set = true;
   }
-  k_sample_masks<<<1, MASK_THREADS, smem, st>>>(P);
+  k_sample_masks<<<1, 64, smem, st>>>(P);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -46,7 +46,9 @@ struct SliceArgs {
   // stream the same matrix moments later a tile may be served from the Infinity Cache)
   int temporal;
 };
-__device__ __forceinline__ u32x4_t dd_ldw(int temporal, const u32x4_t* p) { return temporal ? *p : __builtin_nontemporal_load(p); }
+// (temporal bit 1, value 2: TIMING EXPERIMENT of the tools library — the kernels skip the operand planes' staging and compute on whatever the LDS
+// holds; how much of a launch the blocking stage-in costs.  Never set by the product.)
+__device__ __forceinline__ u32x4_t dd_ldw(int temporal, const u32x4_t* p) { return (temporal & 1) ? *p : __builtin_nontemporal_load(p); }
 
 // rstd(row) = 1 / sqrt(mean(x^2) + eps) from per-workgroup partial sums of squares; wave w of the calling workgroup
 // (8 waves) assembles rows w, w + 8, ...  ONE definition for every kernel that needs it: the sum order is part of the result.
@@ -160,8 +162,10 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
           w[t][u] = dd_ldw(a.temporal, a.W + ((size_t)(g * TW + t) * a.S + q) * 64 + lane + woff(u));
     }
     __builtin_amdgcn_sched_barrier(0);
-    stage_issue(0, SPW);
-    stage_commit(SPW);
+    if (!(a.temporal & 2)) {
+      stage_issue(0, SPW);
+      stage_commit(SPW);
+    }
     __syncthreads();
     if (!any) return;
     while (true) {
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
     for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, p0 + (size_t)u * wstep);
   }
   __builtin_amdgcn_sched_barrier(0);
-  stage(0);
+  if (!(a.temporal & 2)) stage(0);
   __syncthreads();
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
     }
     if (half == 0) {
       __syncthreads();                                 // every wave has finished reading slice 2 qs
-      stage(1);
+      if (!(a.temporal & 2)) stage(1);
       __syncthreads();
     }
   }

@@ -102,7 +102,26 @@ int dd_tools_pkadd_gload_probe(int launches, int wgs, int iters, unsigned int* e
  * check every regeneration against an in-order recomputation by one wave.  out_dev[0] += differing words; out_dev[1..7] = the first difference
  * (workgroup, iteration, word index, got, want, neighbours).  tools/sampler_repro.py twist_probe runs it beside a group taking rider steps. */
 int dd_tools_twist_probe(int launches, int wgs, int iters, int lds_bytes, unsigned int* out_dev, void* stream);
+/* s_barrier looked at directly (round 5): `wgs` workgroups of `threads` (256 / 512 / 1024) threads with lds_bytes of dynamic LDS; per iteration every
+ * thread stores the iteration number to its word of a block at the sampler's generator offset, barrier, reads the other waves' words, barrier, then
+ * idles a wave-dependent while.  out_dev[0] += words that were not this iteration's, [1] += one iteration old, [2] += of a later iteration,
+ * [3..7] = first event (workgroup, iteration, reader wave, writer wave, value). */
+int dd_tools_barrier_probe(int launches, int wgs, int threads, int iters, int lds_bytes, unsigned int* out_dev, void* stream);
 int dd_tools_pk_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
+/* The packed-FP32 fault read as a write-after-read hazard (round 5): the P.V step with its registers fixed by hand — variant 0: the re-load
+ * (ds_read_b128) overwrites the operand registers right behind the v_pk_fma_f32 that read them (the compiler's shape); 1: sixteen wait states
+ * between; 2: the re-load goes to registers no packed op of the last twelve read.  errors_dev[0..2] += (lane, row) results of each variant
+ * that differ from scalar v_fma_f32 sums of the same operands. */
+int dd_tools_pk_war_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream);
+/* The checking sampler (dd_tools_set_tuning(34, 2)): the lanes sampler with every thread's word of the mt19937 block mirrored in a register and
+ * compared with the block in LDS at each member's start, before each regeneration, after each fill and at each member's end.  buf_dev:
+ * dd_tools_sampler_dbg_words() zeroed uint32 words; afterwards word 0 != 0 = a check failed, word 1 = failed checks, words 2..12 = workgroup,
+ * member, regenerations so far, check site, launch tag, read index, checks so far, LDS words dumped, HW_ID, XCC_ID, LDS_ALLOC; then five blocks
+ * of 640 words from word 16: the registers' copy, the block as read, the block a few microseconds later, the state the launch loaded, (free);
+ * then the workgroup's whole dynamic LDS. */
+int dd_tools_sampler_dbg_attach(uint32_t* buf_dev);
+size_t dd_tools_sampler_dbg_words(void);
+unsigned int dd_tools_sampler_dbg_launches(void);
 int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int* errors_dev, void* stream);
 int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,
                                void* stream_a, void* stream_b);

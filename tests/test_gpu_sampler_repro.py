@@ -6,18 +6,19 @@ the same sums as scalar v_fma_f32: 0 of 10^8 lanes differ alone, ~10^6 beside th
 without packed FP32 instructions (build.py NO_PACKED_FP32, gated), and the engine-level regression — an fp32-cache group step on two branches
 equals every sequence decoded alone — is tests/test_gpu_fp32_branches.py.
 
-Also here: the group step's mask sampler — 8 sequences, L = 576, K = 8, one
-1,024-thread workgroup per sequence, each drawing from its own mt19937 stream — launched back to back on a stream of its own BESIDE
-72-row slice-resident GEMVs looping on two other streams (what it met on a branch of the rider step), every launch's keep set, masks,
-bit planes and counts compared with the oracle sampler over the host mt19937 (models/llava.py:443-482, 589-662).
-Also: no kernel of the product library may use private scratch (the build gate), and the sampler's round-3 form — which did — is only in
-libdropdec_tools.so.  tools/sampler_repro.py runs the same bodies for many more rounds.
+Also here: the group step's mask sampler — 8 sequences, L = 576, K = 8, each drawing from its own mt19937 stream — launched back to back on a
+stream of its own BESIDE 72-row slice-resident GEMVs looping on two other streams, every launch's keep set, masks, bit planes and counts compared
+with the oracle sampler over the host mt19937 (models/llava.py:443-482, 589-662): the product's one-wave form and the two 1,024-thread forms
+libdropdec_tools.so keeps.  Also: no kernel of the product library may use private scratch (the build gate), and the sampler's round-3 form — which
+did — is only in libdropdec_tools.so.  tools/sampler_repro.py runs the same bodies for many more rounds.
 
-SECOND FINDING (end of round 4): the sampler itself is a victim of co-residency — on a stream of its own beside a group taking rider steps a
-256-byte chunk of its mt19937 block in LDS goes wrong between two uses about once in 50,000 launches (tools/sampler_repro.py sampler_streams(1, rounds, lib, 32);
-profiles/r04_determinism/r04_s30_*.json, r04_s31_*.log; never beside the GEMV company used below, whatever its width).  The kernels now request
-156 KiB of LDS so that no MFMA workgroup shares their CU: 0 wrong launches in 384,000.  That reproducer needs minutes of a second engine looping
-on a host thread, so it lives in tools/, not in this suite."""
+SECOND FINDING (rounds 4-5): the 1,024-thread sampler is a victim of co-residency — on a stream of its own beside a group taking rider steps its
+generator block in LDS ends up wrong about once in 50,000 launches (tools/sampler_repro.py sampler_streams; profiles/r04_determinism/,
+profiles/r05_sampler_fault/).  Round 5 captured the words: they are the sampler's OWN values of other generations — stores of two of the four
+regenerating waves missing for two regenerations in a row, values of the next generation visible before a regeneration's entry barrier — i.e. the
+sixteen waves of the workgroup out of step across s_barrier; and a dynamic-LDS request that keeps a second sampler workgroup off the CU (84 KiB)
+does not stop it, 120 KiB barely, 156 KiB does.  The product sampler is now ONE WAVE per sequence with no barrier at all
+(csrc/dd_dropout.hip); `test_one_wave_sampler_is_clean_where_the_block_form_fails` runs both forms in the failing company."""
 import os
 import sys
 
@@ -43,13 +44,13 @@ def test_no_product_kernel_uses_private_scratch():
             assert k["scratch"] == 0, (o, k)
     assert n > 300
     lanes = [k for k in res["dd_dropout.o"] if "k_sample_masks_lanes" in k["name"]]
-    assert len(lanes) == 1 and lanes[0]["scratch"] == 0
+    assert len(lanes) == 1 and lanes[0]["scratch"] == 0          # (the one-wave sampler; the 1,024-thread forms are tools-only)
     old = [k for k in res["dd_dropout_tools.o"] if "k_sample_masks_lanes_scratch" in k["name"]]
     assert len(old) == 1 and old[0]["scratch"] == 616
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scratch_form", [False, True])
+@pytest.mark.parametrize("scratch_form", ["wave", "block", "scratch"])
 def test_lanes_sampler_beside_72_row_gemvs_matches_the_oracle(scratch_form):
     import sampler_repro as R
     import torch
@@ -110,3 +111,25 @@ def test_private_scratch_survives_beside_other_queues():
     lib = _lib.load_tools()
     out = R.probe(True, 6, lib, wgs=8)
     assert out["mismatching_words"] == 0, out
+
+
+@pytest.mark.gpu
+def test_one_wave_sampler_is_clean_where_the_block_form_fails():
+    """The in-suite determinism guard.  The sampler on a stream of its own beside 32 sequences taking rider steps — the
+    company in which round 4's 1,024-thread kernel draws wrong masks about once in 50,000 launches when it requests only the LDS it uses:
+    ~25 s of that form, its wrong launches REPORTED (a board on which the count is 0 does not fail the suite), then ~40 s of the product's
+    one-wave form in the same company, ASSERTED clean."""
+    import sampler_repro as R
+    import torch
+    torch.cuda.set_device(0)
+    from dropoutdecoding_amd import _lib, build
+    build.build()
+    lib = _lib.load_tools()
+    block = R.sampler_streams(1, 10 ** 6, lib, 32, lds_kib=0, form="block", seconds=25.0)
+    wave = R.sampler_streams(1, 10 ** 6, lib, 32, form="wave", seconds=40.0)
+    lib.dd_tools_set_tuning(48, 1)
+    print(f"\n[sampler beside rider steps] 1,024-thread form, 76 KiB request: {block['sequences_with_a_wrong_launch']} wrong in {block['sampler_launches']} "
+          f"launches of 8 workgroups ({block['company_rider_steps']} rider steps beside); one-wave form: {wave['sequences_with_a_wrong_launch']} wrong in "
+          f"{wave['sampler_launches']} launches ({wave['company_rider_steps']} rider steps beside)")
+    assert wave["company_rider_steps"] > 100 and wave["sampler_launches"] > 20000, wave
+    assert wave["sequences_with_a_wrong_launch"] == 0, wave

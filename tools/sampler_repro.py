@@ -83,7 +83,9 @@ def _inputs():
 
 def sampler(scratch: bool, beside: bool, rounds: int, lib=None, seqs=None, rows: int = 72) -> dict:
     lib = lib or _lib.load_tools()
-    lib.dd_tools_set_tuning(34, 1 if scratch else 0)
+    # scratch: True / "scratch" = round 3's form (private scratch), False / "block" = round 4's 1,024-thread kernel, "wave" = the product's one-wave sampler
+    form = scratch if isinstance(scratch, str) else ("scratch" if scratch else "block")
+    lib.dd_tools_set_tuning(34, {"wave": 0, "scratch": 1, "block": 3}[form])
     seqs = seqs or _inputs()
     K = len(PROBS)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -139,7 +141,7 @@ def sampler(scratch: bool, beside: bool, rounds: int, lib=None, seqs=None, rows:
         body()
         company = 0
     lib.dd_tools_set_tuning(34, 0)
-    return {"test": "sampler", "scratch_form": scratch, "beside_72_row_gemvs": beside, "company_rows": rows if beside else 0, "sampler_launches": launches, "workgroups_per_launch": N_SEQ,
+    return {"test": "sampler", "sampler_form": form, "beside_72_row_gemvs": beside, "company_rows": rows if beside else 0, "sampler_launches": launches, "workgroups_per_launch": N_SEQ,
             "company_gemv_launches": company, "sequences_with_a_wrong_launch": bad_launches, "first_bad": first_bad, "seconds": round(time.time() - t0, 1)}
 
 
@@ -148,8 +150,11 @@ class StepCompany:
     branch-local sampler has inside a group step — attention tile passes (MFMA, a few KiB of LDS, 95 VGPRs), combine and finishing kernels, which
     fit on a CU beside the sampler's 76-KiB workgroup where the 144-KiB slice GEMVs do not."""
 
-    def __init__(self, lib, lanes=32):
+    def __init__(self, lib, lanes=32, mode="full"):
+        """mode: "full" = prefills + 120 rider steps in turn (round 4's company); "steps" = rider steps only beside the test (the prompts are
+        prefilled again every 120 steps under self.lock, which the test's workers hold around their launches); "prefill" = batched prefills only."""
         cfg = lm.LMConfig(32064, 4096, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
+        self.mode = mode
         self.engs = []
         for i in range(lanes):
             self.engs.append(lm.DropoutEngine(cfg, family=lm.FAMILY_LLAVA, max_seq=608 + 140, max_visual=576, seed=7 + i, kv_format="fp16", lib=lib,
@@ -157,14 +162,27 @@ class StepCompany:
         self.engs[0].load_synthetic(0, 0.02)
         g = torch.Generator().manual_seed(3)
         self.embs = [(torch.randn(608, 4096, generator=g) * 0.5).cuda() for _ in range(lanes)]
-        self.stop, self.steps, self.thread = False, 0, None
+        self.stop, self.steps, self.thread, self.prefills = False, 0, None, 0
+        self.lock = threading.Lock()
+
+    def _prefill(self):
+        lm.prefill_group(self.engs[:16], self.embs[:16], [(5, 576)] * 16)
+        if len(self.engs) > 16:
+            lm.prefill_group(self.engs[16:32], self.embs[16:32], [(5, 576)] * (len(self.engs[16:32])))
 
     def _loop(self):
         torch.cuda.set_device(0)
         while not self.stop:
-            lm.prefill_group(self.engs[:16], self.embs[:16], [(5, 576)] * 16)
-            if len(self.engs) > 16:
-                lm.prefill_group(self.engs[16:32], self.embs[16:32], [(5, 576)] * (len(self.engs[16:32])))
+            if self.mode == "steps":                 # the prompts are prefilled while no sampler launch of the test is in flight
+                with self.lock:
+                    self._prefill()
+                    torch.cuda.synchronize()
+            else:
+                self._prefill()
+            self.prefills += 1
+            if self.mode == "prefill":
+                torch.cuda.synchronize()
+                continue
             grp = lm.EngineGroup(self.engs)
             for _ in range(120):
                 if self.stop:
@@ -186,20 +204,123 @@ class StepCompany:
             e.close()
 
 
-def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 0, sync_each: bool = False) -> dict:
+_GEN_CACHE = {}
+
+
+def _generations(seed: int, n: int):
+    """[n][624] uint32: the first n regenerated blocks of the mt19937 stream seeded with `seed` (oracle/mt19937.py)."""
+    from oracle import mt19937 as MT
+    if (seed, n) not in _GEN_CACHE:
+        st = MT.seed_state(seed)
+        out = []
+        for _ in range(n):
+            MT._twist(st[:MT.N])
+            out.append(st[:MT.N].copy())
+        _GEN_CACHE[(seed, n)] = np.stack(out)
+    return _GEN_CACHE[(seed, n)]
+
+
+def analyse_dump(d: np.ndarray, test_seeds, company_seeds=()) -> dict:
+    """Provenance of the words the checking sampler found wrong (dd_dropout.hip mt_dbg_check; layout in include/dropdec_tools.h)."""
+    d = d.astype(np.uint32)
+    hdr = {"failed_checks": int(d[1]), "workgroup": int(d[2]), "member": int(np.int32(d[3])), "regenerations_before": int(d[4]),
+           "check_site": {1: "before a regeneration", 3: "member start", 4: "after the member's uniforms", 5: "member end"}.get(int(d[5]), int(d[5])),
+           "launch_tag": int(d[6]), "read_index": int(d[7]), "checks_before": int(d[8]), "hw_id": hex(int(d[10])), "xcc_id": int(d[11]) & 0xF,
+           "lds_alloc": hex(int(d[12]))}
+    shadow, seen, later, src = (d[16 + i * 640:16 + i * 640 + 624] for i in range(4))
+    nw = int(d[9])
+    lds = d[16 + 5 * 640:16 + 5 * 640 + nw]
+    W = np.nonzero(shadow != seen)[0]
+    runs, start = [], None
+    for i in W.tolist() + [None]:
+        if start is None:
+            start = prev = i
+        elif i is None or i != prev + 1:
+            runs.append([int(start), int(prev)])
+            start = prev = i
+        else:
+            prev = i
+    out = dict(hdr)
+    out["wrong_words"] = int(len(W))
+    out["wrong_word_runs"] = runs[:8]
+    out["still_wrong_microseconds_later"] = int((later[W] != shadow[W]).sum())
+    out["later_read_equals_first_read"] = bool(np.array_equal(later[W], seen[W]))
+    if not len(W):
+        return out
+    # which stream / generation is the block the registers hold?
+    n_gen = 200
+    owner = None
+    for kind, seeds in (("test", test_seeds), ("company", company_seeds)):
+        for sd in seeds:
+            G = _generations(sd, n_gen)
+            hit = np.nonzero((G == shadow[None, :]).sum(1) > 500)[0]
+            if len(hit):
+                owner = (kind, sd, int(hit[0]))
+                break
+        if owner:
+            break
+    out["block_in_registers_is"] = None if owner is None else {"stream": owner[0], "seed": owner[1], "generation": owner[2]}
+    # provenance of the wrong values
+    prov = {"zero": int((seen[W] == 0).sum()), "launch_start_state_same_index": int((seen[W] == src[W]).sum())}
+    if owner:
+        G = _generations(owner[1], n_gen)
+        g = owner[2]
+        for dg in (-3, -2, -1, 1, 2):
+            if 0 <= g + dg < n_gen:
+                prov[f"own_generation_{dg:+d}_same_index"] = int((seen[W] == G[g + dg][W]).sum())
+        seedwords = __import__("oracle.mt19937", fromlist=["x"]).seed_state(owner[1])[:624]
+        prov["own_seed_state_same_index"] = int((seen[W] == seedwords[W]).sum())
+    table = {}
+    for kind, seeds in (("test", test_seeds), ("company", company_seeds)):
+        for sd in seeds:
+            G = _generations(sd, n_gen)
+            for v in np.unique(seen[W]):
+                gi, wi = np.nonzero(G == v)
+                if len(gi):
+                    table.setdefault(f"{kind}:{sd}", []).append([int(v), int(gi[0]), int(wi[0])])
+    prov["values_found_in_any_generation_of"] = {k: {"count": len(v), "first": v[:4]} for k, v in table.items()}
+    # the workgroup's own LDS: do the wrong values, or the right ones, sit anywhere else in it?
+    mt_off = (8192 * 4 * 2 + 8192) // 4
+    other = np.concatenate([lds[:mt_off], lds[mt_off + 624:]])
+    prov["wrong_values_elsewhere_in_own_lds"] = int(np.isin(seen[W], other).sum())
+    prov["right_values_elsewhere_in_own_lds"] = int(np.isin(shadow[W], other).sum())
+    u_bits = lds[8192:8192 + 8192]
+    prov["wrong_values_equal_uniform_buffer_words"] = int(np.isin(seen[W], u_bits).sum())
+    # are the wrong values the tempered / untempered neighbours of something?  crude tests
+    prov["wrong_equals_right_shifted_by_words"] = {str(k): int((seen[W] == np.roll(shadow, k)[W]).sum()) for k in (-64, -1, 1, 64)}
+    out["provenance_of_wrong_values"] = prov
+    out["sample"] = [{"word": int(i), "want": hex(int(shadow[i])), "got": hex(int(seen[i])), "later": hex(int(later[i])), "launch_start": hex(int(src[i]))} for i in W[:6]]
+    return out
+
+
+def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 0, sync_each: bool = False, n_seq: int = N_SEQ, lds_kib: int = -1,
+                    dbg: bool = False, company_mode: str = "full", dump_prefix: str = "", max_events: int = 4, seconds: float = 0.0,
+                    form: str = "block") -> dict:
     """The lanes sampler from `n_streams` host threads at once, each on a stream of its own with sequences (and rng streams) of its own — the
     branch-local form's launch pattern —, optionally beside a group of `company_lanes` sequences taking rider steps; every launch against the
-    oracle."""
+    oracle.  n_seq: workgroups (sequences) per launch; lds_kib: the kernel's dynamic-LDS request (tools key 48: 0 = the 76 KiB it uses, 1 = the
+    product's 156 KiB, n = n KiB; -1 = leave as set); dbg: the checking sampler (tools key 34 = 2) — the generator block mirrored in registers and
+    verified, the first failure of every round dumped and analysed (analyse_dump); seconds > 0: stop after that long even if rounds remain."""
     lib = lib or _lib.load_tools()
-    lib.dd_tools_set_tuning(34, 0)
-    seqs = _inputs()
+    # form: "wave" = the product's one-wave sampler (round 5); "block" = round 4's 1,024-thread kernel; "scratch" = round 3's; dbg: the checking block form
+    lib.dd_tools_set_tuning(34, 2 if dbg else {"wave": 0, "scratch": 1, "block": 3}[form])
+    if lds_kib >= 0:
+        lib.dd_tools_set_tuning(48, lds_kib)
+    seqs = _inputs()[:n_seq]
     K = len(PROBS)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     want = [s_["want"] for s_ in seqs]
     want_bits = [np.bitwise_or.reduce(w.astype(np.uint8) << np.arange(K, dtype=np.uint8)[None, :, None], axis=1) for w in want]
     bad, launches, first_bad = [0] * n_streams, [0] * n_streams, [None] * n_streams
-    events = []
+    events, dumps = [], []
     t0 = time.time()
+    dbg_buf = None
+    if dbg:
+        assert n_streams == 1, "the checking sampler has one dump buffer"
+        dbg_buf = torch.zeros(int(lib.dd_tools_sampler_dbg_words()), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        lib.dd_tools_sampler_dbg_attach(dbg_buf.data_ptr())
+    co_ref = [None]
 
     def worker(t):
         torch.cuda.set_device(0)
@@ -210,29 +331,44 @@ def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 
         drop = [torch.zeros(STEPS, K, L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
         n_drop = [torch.zeros(STEPS, K, dtype=torch.int32, device="cuda") for _ in seqs]
         bits = [torch.zeros(STEPS, L_VIS, dtype=torch.uint8, device="cuda") for _ in seqs]
-        rngs = [TorchCpuCompatRNG(100 + i, lib=lib) for i in range(N_SEQ)]
+        rngs = [TorchCpuCompatRNG(100 + i, lib=lib) for i in range(n_seq)]
         st = torch.cuda.Stream()
-        arr = lambda ts: (C.c_void_p * N_SEQ)(*[x.data_ptr() if torch.is_tensor(x) else x for x in ts])
-        Ls = (C.c_int32 * N_SEQ)(*([L_VIS] * N_SEQ))
+        arr = lambda ts: (C.c_void_p * n_seq)(*[x.data_ptr() if torch.is_tensor(x) else x for x in ts])
+        Ls = (C.c_int32 * n_seq)(*([L_VIS] * n_seq))
         pr = (C.c_double * K)(*PROBS)
+        import contextlib
         for r in range(rounds):
-            for i, g in enumerate(rngs):
-                g.manual_seed(100 + i)
-            torch.cuda.current_stream().synchronize()
-            for s_ in range(STEPS):
-                rc = lib.dd_tools_sample_masks_lanes(N_SEQ, arr(epi), Ls, arr(keep), arr(argmax), arr(topk), arr([g.handle.value for g in rngs]),
-                                                     arr([d[s_].data_ptr() for d in drop]), arr([n[s_].data_ptr() for n in n_drop]),
-                                                     arr([b[s_].data_ptr() for b in bits]), K_TOP, pr, K, DR.MODE_LLAVA_CUMULATIVE, st.cuda_stream)
-                assert rc == 0, lib.dd_last_error()
-                if sync_each:
-                    st.synchronize()          # (experiment) no two sampler launches back to back: the host waits for each
-            st.synchronize()
+            if seconds and time.time() - t0 > seconds:
+                break
+            lock = co_ref[0].lock if co_ref[0] is not None and co_ref[0].mode == "steps" else contextlib.nullcontext()
+            with lock:
+                for i, g in enumerate(rngs):
+                    g.manual_seed(100 + i)
+                torch.cuda.current_stream().synchronize()
+                for s_ in range(STEPS):
+                    rc = lib.dd_tools_sample_masks_lanes(n_seq, arr(epi), Ls, arr(keep), arr(argmax), arr(topk), arr([g.handle.value for g in rngs]),
+                                                         arr([d[s_].data_ptr() for d in drop]), arr([n[s_].data_ptr() for n in n_drop]),
+                                                         arr([b[s_].data_ptr() for b in bits]), K_TOP, pr, K, DR.MODE_LLAVA_CUMULATIVE, st.cuda_stream)
+                    assert rc == 0, lib.dd_last_error()
+                    if sync_each:
+                        st.synchronize()          # (experiment) no two sampler launches back to back: the host waits for each
+                st.synchronize()
             launches[t] += STEPS
             with torch.cuda.stream(st):
                 got_all = [d.cpu().numpy().astype(bool) for d in drop]
                 gb_all = [b.cpu().numpy() for b in bits]
                 gn_all = [n.cpu().numpy() for n in n_drop]
-            for i in range(N_SEQ):
+                if dbg and int(dbg_buf[0].item()) != 0:
+                    d = dbg_buf.cpu().numpy().copy()
+                    dbg_buf.zero_()
+                    st.synchronize()
+                    if len(dumps) < max_events:
+                        a = analyse_dump(d, [100 + i for i in range(n_seq)], [7 + i for i in range(company_lanes)])
+                        a["round"] = r
+                        dumps.append(a)
+                        if dump_prefix:
+                            np.save(f"{dump_prefix}_{len(dumps)}.npy", d[:16 + 5 * 640 + int(d[9])])
+            for i in range(n_seq):
                 for s_ in range(STEPS):
                     if not (np.array_equal(got_all[i][s_], want[i][s_]) and np.array_equal(gb_all[i][s_], want_bits[i][s_]) and
                             np.array_equal(gn_all[i][s_], want[i][s_].sum(1))):
@@ -241,18 +377,8 @@ def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 
                         if k_bad and len(events) < 12:
                             k0 = k_bad[0]
                             pos = np.nonzero(got_all[i][s_][k0] != want[i][s_][k0])[0]
-                            p = DR.drop_probability(torch.from_numpy(seqs[i]["epi"]), PROBS[k0]).numpy()
-                            margin = seqs[i]["uniforms"][s_][k0] - p                      # < 0: the reference drops the token
-                            # would the got mask of member k0 be the reference's under ANOTHER member's uniforms (a stale / early buffer)?
-                            prev = want[i][s_][k0 - 1] if k0 else np.zeros(L_VIS, bool)
-                            alt = {}
-                            for kk in range(K):
-                                m_alt = (prev | (seqs[i]["uniforms"][s_][kk] < p)) & ~seqs[i]["keep"]
-                                alt[kk] = int((m_alt != got_all[i][s_][k0]).sum())
                             events.append({"stream": t, "round": r, "sequence": i, "launch": s_, "first_wrong_member": k0, "wrong_positions": pos[:48].tolist(),
-                                           "n_wrong_positions": int(len(pos)), "waves_of_wrong_positions": sorted({int(x) // 64 for x in pos}),
-                                           "margin_r_minus_p_at_wrong_positions": [round(float(x), 4) for x in margin[pos[:12]]],
-                                           "mismatch_if_member_k0_had_used_uniforms_of_member": alt})
+                                           "n_wrong_positions": int(len(pos)), "waves_of_wrong_positions": sorted({int(x) // 64 for x in pos})})
                         if first_bad[t] is None:
                             first_bad[t] = {"stream": t, "round": r, "sequence": i, "launch": s_, "members_with_wrong_masks": k_bad,
                                             "wrong_mask_bytes": int((got_all[i][s_] != want[i][s_]).sum()),
@@ -266,16 +392,21 @@ def sampler_streams(n_streams: int, rounds: int, lib=None, company_lanes: int = 
         for th in ths:
             th.join()
 
-    steps = 0
+    steps = prefills = 0
     if company_lanes:
-        with StepCompany(lib, company_lanes) as co:
+        with StepCompany(lib, company_lanes, company_mode) as co:
+            co_ref[0] = co
             run()
-            steps = co.steps
+            steps, prefills = co.steps, co.prefills
     else:
         run()
-    return {"test": "sampler_streams", "streams": n_streams, "host_waits_for_every_launch": sync_each, "sampler_launches": sum(launches), "workgroups_per_launch": N_SEQ,
-            "company_rider_steps": steps, "company_lanes": company_lanes, "sequences_with_a_wrong_launch": sum(bad),
-            "first_bad": [f for f in first_bad if f], "events": events, "seconds": round(time.time() - t0, 1)}
+    lib.dd_tools_set_tuning(34, 0)
+    if dbg:
+        lib.dd_tools_sampler_dbg_attach(None)
+    return {"test": "sampler_streams", "sampler_form": "checking block form" if dbg else form, "streams": n_streams, "host_waits_for_every_launch": sync_each, "sampler_launches": sum(launches), "workgroups_per_launch": n_seq,
+            "lds_request_key_48": lds_kib, "checking_sampler": dbg, "company_mode": company_mode if company_lanes else None,
+            "company_rider_steps": steps, "company_prefill_rounds": prefills, "company_lanes": company_lanes, "sequences_with_a_wrong_launch": sum(bad),
+            "first_bad": [f for f in first_bad if f], "events": events, "generator_block_dumps": dumps, "seconds": round(time.time() - t0, 1)}
 
 
 def twist_probe(rounds: int, lib=None, company_lanes: int = 32, lds_bytes: int = 77856, wgs: int = 8, iters: int = 64) -> dict:
@@ -308,6 +439,40 @@ def twist_probe(rounds: int, lib=None, company_lanes: int = 32, lds_bytes: int =
             "lds_bytes": lds_bytes, "company_lanes": company_lanes, "company_rider_steps": steps, "differing_words": int(o[0]),
             "first": None if o[0] == 0 else {"workgroup": int(o[1]), "iteration": int(o[2]), "word": int(o[3]), "got": int(o[4]), "want": int(o[5]),
                                               "word_before": int(o[6]), "word_after": int(o[7])},
+            "seconds": round(time.time() - t0, 1)}
+
+
+def barrier_probe(rounds: int, lib=None, company_lanes: int = 32, threads: int = 1024, lds_bytes: int = 77856, wgs: int = 8, iters: int = 600,
+                  seconds: float = 0.0, company_mode: str = "full") -> dict:
+    """dd_tools_barrier_probe: s_barrier + LDS visibility of a workgroup of the sampler's shape, alone or beside a group taking rider steps."""
+    lib = lib or _lib.load_tools()
+    out = torch.zeros(8, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    t0 = time.time()
+    launches = 0
+
+    def body():
+        nonlocal launches
+        for r in range(rounds):
+            if seconds and time.time() - t0 > seconds:
+                break
+            rc = lib.dd_tools_barrier_probe(16, wgs, threads, iters, lds_bytes, out.data_ptr(), st.cuda_stream)
+            assert rc == 0, lib.dd_last_error()
+            st.synchronize()
+            launches += 16
+
+    steps = 0
+    if company_lanes:
+        with StepCompany(lib, company_lanes, company_mode) as co:
+            body()
+            steps = co.steps
+    else:
+        body()
+    o = out.cpu().numpy().astype(np.uint32)
+    return {"test": "barrier_probe", "threads_per_workgroup": threads, "lds_bytes": lds_bytes, "probe_launches": launches, "workgroups_per_launch": wgs,
+            "barrier_pairs_per_workgroup": iters, "company_lanes": company_lanes, "company_rider_steps": steps,
+            "words_not_of_this_iteration": int(o[0]), "one_iteration_old": int(o[1]), "of_a_later_iteration": int(o[2]),
+            "first": None if o[0] == 0 else {"workgroup": int(o[3]), "iteration": int(o[4]), "reader_wave": int(o[5]), "writer_wave": int(o[6]), "value": int(o[7])},
             "seconds": round(time.time() - t0, 1)}
 
 
