@@ -310,12 +310,13 @@ def main() -> int:
     ap.add_argument("--original", action="store_true", help="stock greedy decode (K=1, no dropout), BASELINE configs[0]")
     ap.add_argument("--images-per-gpu", type=int, default=None,
                     help="images decoded concurrently per GPU (lanes over one set of weights, 1..64); 1 = the reference's "
-                         "one-image-at-a-time loop; default 64 (config 5: 32, config 2: 56)")
+                         "one-image-at-a-time loop; default 64 (config 2: 56)")
     ap.add_argument("--no-batch-tower", action="store_true", help="one vision-tower call per image instead of one per 16 images (A/B)")
     ap.add_argument("--prefill-chunk", type=int, default=None, help="prompts per LM prefill pass (dd_lm_prefill_group); 1 = one prefill per image")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dd_set_tuning(key, value) before the run (product switches)")
     ap.add_argument("--single-images", type=int, default=5, help="images of the one-image-at-a-time legs (after one warm-up image)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the isolated-kernel leg (libdropdec_tools.so)")
+    ap.add_argument("--no-build", action="store_true", help="never compile: raise when libdropdec.so is stale (for runs under a profiler)")
     args = ap.parse_args()
     if args.config == 1:
         args.original = True
@@ -324,6 +325,14 @@ def main() -> int:
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return spawn_ranks(args)                    # nothing in this process has touched the GPU yet
+
+    # Build (or check) the libraries BEFORE this process touches the GPU: hipcc is a child process tree, and on this pool a process that has
+    # initialised the GPU — under rocprofv3 that is every process, from its first instruction — must not start one.  Every rank
+    # calls it: build.py serialises the builders with a file lock, the later ones find the tree fresh.  --no-build / DD_NO_BUILD=1: raise instead.
+    from dropoutdecoding_amd import build
+    if args.no_build:
+        os.environ["DD_NO_BUILD"] = "1"
+    build.build()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -347,9 +356,6 @@ def main() -> int:
     else:
         torch.cuda.set_device(0)
 
-    from dropoutdecoding_amd import build
-    if local == 0:
-        build.build()                      # one builder per node; the others wait (build.py also takes a file lock)
     if use_dist:
         torch.distributed.barrier()
     from dropoutdecoding_amd import _lib as _ddlib

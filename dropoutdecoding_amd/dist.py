@@ -123,6 +123,30 @@ class KShardDecoder:
 # all-gather (torch.distributed: "nccl" = RCCL over xGMI; "gloo" stages through the host for the tests) as the engine's
 # exchange.  lm.TensorParallelGroup is the single-process form (all ranks on one device).
 # ---------------------------------------------------------------------------------------------------------------------
+_TP_ERROR_KEY = "dropoutdecoding_amd/tp_exchange_error"
+
+
+def _tp_store():
+    from torch.distributed import distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
+def tp_flag_error(group, rank: int, what: str) -> None:
+    """Mark the tensor-parallel job as failed in the rendezvous store (visible to every rank, whatever the backend)."""
+    _tp_store().set(_TP_ERROR_KEY, f"rank {rank}: {what}"[:400])
+
+
+def tp_peer_failed(group) -> str:
+    """'' or the failed rank's message: checked before every exchange, so that a rank does not walk into a collective its peer has left."""
+    try:
+        st = _tp_store()
+        if st.check([_TP_ERROR_KEY]):
+            return st.get(_TP_ERROR_KEY).decode(errors="replace")
+    except Exception:
+        return ""              # no store (a group built without one): nothing to check against
+    return ""
+
+
 class TensorParallelRank:
     """One rank of a sharded model in its own process.  `cfg` is the FULL model's LMConfig; the rank's engine holds its slices."""
 
@@ -142,6 +166,9 @@ class TensorParallelRank:
 
         def exchange(ctx, rows, stream):
             try:
+                failed = tp_peer_failed(self.group)
+                if failed:
+                    raise RuntimeError(f"tensor-parallel exchange: a peer's exchange failed ({failed})")
                 n = rows * d
                 out = self.gather[: world * n]
                 mine = out[rank * n:(rank + 1) * n]
@@ -169,18 +196,32 @@ class TensorParallelRank:
         self.engine.load_state_dict(lm.tp_shard_state_dict(sd, self.cfg, self.rank, self.world, prefix))
 
     def _abort_peers(self) -> None:
-        """A failed exchange on this rank leaves the others blocked in their all-gather until the process-group timeout: tear the
-        group down so that they fail now (their exchange raises, their step returns an error)."""
+        """A failed exchange on this rank leaves the others blocked in their all-gather until the process-group timeout.  Two things are done
+        about it, neither silently: (1) an error flag in the rendezvous store (`tp_flag_error`), which every rank checks BEFORE it enters an
+        exchange (`tp_peer_failed`) — works on every backend, and is all that "gloo" offers: a rank already inside the collective stays there
+        until the group's timeout; (2) on "nccl" (RCCL) the communicator is aborted, so that ranks already inside fail now.  Whatever goes wrong
+        while doing so is kept in `self.abort_error` and warned about, not swallowed."""
+        import warnings
+        self.abort_error = None
+        try:
+            tp_flag_error(self.group, self.rank, repr(self.error))
+        except Exception as ex:
+            self.abort_error = ex
+            warnings.warn(f"TensorParallelRank: could not flag the failed exchange in the store: {ex!r}")
         try:
             pg = self.group if self.group is not None else dist.group.WORLD
+            if dist.get_backend(pg) != "nccl":
+                return                                          # gloo: no abort; the flag is what the peers get
             if hasattr(pg, "abort"):
                 pg.abort()
             elif hasattr(dist, "_abort_process_group"):
                 dist._abort_process_group(pg)
             else:
                 dist.destroy_process_group(self.group)
-        except Exception:
-            pass
+        except Exception as ex:
+            self.abort_error = ex
+            warnings.warn(f"TensorParallelRank: aborting the process group after a failed exchange raised {ex!r}; "
+                          "the peers will time out in their all-gather instead of failing now")
 
     def _check(self, rc: int, what: str) -> None:
         if rc != 0 and self.error is not None:

@@ -221,3 +221,47 @@ def test_tensor_parallel_plan_equals_the_unsharded_forward(world):
     for rank, err, tok_ok, n_ar, wbytes in res:
         assert err < 1e-5 and tok_ok and n_ar == 4
     assert len({r[4] for r in res}) == 1                      # every rank streams the same share of the weights
+
+
+def _tp_flag_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dropoutdecoding_amd import dist as dd
+    assert dd.tp_peer_failed(None) == ""
+    dist.barrier()
+    if rank == 1:
+        # a rank whose exchange raised: what TensorParallelRank._abort_peers does, on an object without an engine
+        obj = dd.TensorParallelRank.__new__(dd.TensorParallelRank)
+        obj.group, obj.rank, obj.error = None, rank, RuntimeError("exchange broke")
+        obj._abort_peers()
+        q.put(("aborter", repr(obj.abort_error)))          # gloo has no abort: nothing raised, nothing swallowed
+    else:
+        import time
+        t0 = time.time()
+        msg = ""
+        while not msg and time.time() - t0 < 20:
+            msg = dd.tp_peer_failed(None)
+            time.sleep(0.05)
+        q.put(("peer", msg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tp_failed_exchange_is_flagged_to_the_peers_over_gloo():
+    """`_abort_peers` was untested and swallowed everything.  On gloo (no communicator abort) a failing rank flags the job in
+    the rendezvous store and its peers see the flag before they enter their next exchange."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_tp_flag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got["aborter"] == "None"
+    assert "rank 1" in got["peer"] and "exchange broke" in got["peer"]

@@ -7,9 +7,12 @@
 
 Environment: DD_STRESS_K (8 | 4 | 3 ...: members), DD_STRESS_FAMILY (llava | iblip), DD_STRESS_T0 (prompt length), DD_STRESS_POISON=n (n LDS-poison
 launches of 512 workgroups beside every step), DD_STRESS_STOP=n (stop after n differing repetitions), DD_STRESS_KV (fp16 | fp32),
-DD_STRESS_LOG=path (append one JSON line with the summary)."""
+DD_STRESS_LOG=path (append one JSON line with the summary).  Exit code 1 when a repetition or a solo check differs."""
 import json, os, sys, time
-os.environ.setdefault("DD_USE_TOOLS_LIB", "1")
+# the shipped libdropdec.so unless a tools-only feature is asked for (tuning keys, the step trace, LDS poison): the summary records which
+NEED_TOOLS = len(sys.argv) > 4 or any(os.environ.get(k, "0") not in ("", "0") for k in ("DD_STRESS_TRACE", "DD_STRESS_POISON"))
+if NEED_TOOLS:
+    os.environ.setdefault("DD_USE_TOOLS_LIB", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import numpy as np
@@ -131,7 +134,8 @@ for rep in range(R):
             break
     if rep % 20 == 19:
         print(f"  ... rep {rep + 1}: {bad} differing so far, {time.time() - t_start:.0f} s", flush=True)
-summary = {"lanes": B, "repetitions": reps_done, "steps_per_repetition": S, "steps_total": reps_done * S, "K": K, "family": FAMILY, "kv": KV,
+summary = {"tool": "stress_lanes", "library": "libdropdec_tools.so" if os.environ.get("DD_USE_TOOLS_LIB", "0") not in ("", "0") else "libdropdec.so",
+           "lanes": B, "repetitions": reps_done, "steps_per_repetition": S, "steps_total": reps_done * S, "K": K, "family": FAMILY, "kv": KV,
            "settings": sys.argv[4:], "trace": TRACE, "solo_checks": reps_done if SOLO else 0, "poison_launches_per_step": POISON,
            "differ_from_first": bad, "differ_from_solo": bad_solo, "events": events[:20], "seconds": round(time.time() - t_start, 1)}
 print(f"{bad} of {reps_done - 1} repetitions differ from the first, {bad_solo} of {reps_done if SOLO else 0} solo checks differ "
@@ -140,3 +144,4 @@ print(json.dumps(summary))
 if os.environ.get("DD_STRESS_LOG"):
     with open(os.environ["DD_STRESS_LOG"], "a") as f:
         f.write(json.dumps(summary) + "\n")
+sys.exit(1 if bad or bad_solo else 0)      # a guard, not a log: a differing repetition fails the wrapper script
