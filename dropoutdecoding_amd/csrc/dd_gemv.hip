@@ -872,34 +872,58 @@ void ddk_set_gemv_slices(int on) { g_gemv_slices = on; }
 void ddk_set_slices_only(int on) { g_slices_only = on; }
 #define SLICES_UNSUPPORTED 1
 
+extern int g_seq_prog;
 template <int TW, int NG, int U, int SPW, int CS, int CH, int TAG>
 static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)CH * (SPW < CS ? SPW : CS) * NG * 1024;
+  // progressive stage-in (dd_gemv_slices.h PROG): whole-slice kernels with at least two ring blocks per tile group
+  constexpr int PROG_OK = (SPW <= CS && (CH * SPW) / (SPW < U ? SPW : U) >= 2) ? 1 : 0;
   static bool attr = false;
   if (!attr) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
   const int grid = (sa.halves == 2 ? 2 : 1) * (8 / CH) * sa.G;
-  NOTE_KERNEL("k_gemv_slices<%d, %d, %d, %d, %d, %d, %d, %d>", TW, NG, U, SPW, CS, CH, wf ? 1 : 0, TAG);
-  if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
-  else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG><<<grid, GEMV_THREADS, smem, st>>>(sa);
+  const int prog = g_seq_prog && PROG_OK;
+  NOTE_KERNEL("k_gemv_slices<%d, %d, %d, %d, %d, %d, %d, %d, %d>", TW, NG, U, SPW, CS, CH, wf ? 1 : 0, TAG, prog);
+  if (prog) {
+    if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG, PROG_OK><<<grid, GEMV_THREADS, smem, st>>>(sa);
+    else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG, PROG_OK><<<grid, GEMV_THREADS, smem, st>>>(sa);
+  } else {
+    if (wf) k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG, 0><<<grid, GEMV_THREADS, smem, st>>>(sa);
+    else k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG, 0><<<grid, GEMV_THREADS, smem, st>>>(sa);
+  }
   return DD_OK;
 }
 // (16 instead of 8 weight requests in flight per wave measured the same or slower: qkv 26.3 vs 25.4 us, gate/up 38.4 vs 38.0)
+// dd_tools_set_tuning key 49: progressive stage-in of the operand planes in the slice-pair kernels (dd_gemv_slices.h PROG; 0: the blocking
+// stage-in of rounds 2-4).  Same bits either way.
+int g_seq_prog = 1;
 template <int NG, int U, int MAXG, int TAG>
 static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)16 * NG * 1024;
+  // (nine planes with eight requests in flight and two tiles per wave: the progressive form needs 257+ registers — it keeps the blocking stage-in)
+  constexpr int PROG_OK = (NG == 9 && U == 8 && MAXG >= 2) ? 0 : 1;
   static bool attr = false;
   if (!attr) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG);
-  if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-  else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  const int prog = g_seq_prog && PROG_OK;
+  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG, prog);
+  if (prog) {
+    if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, PROG_OK><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+    else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, PROG_OK><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  } else {
+    if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, 0><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+    else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, 0><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  }
   return DD_OK;
 }
 

@@ -82,7 +82,9 @@ __device__ __forceinline__ int dd_part_index(int n, int m) { return (((n >> 2) *
 // grid = (8 / CH) * G workgroups of 512 threads; dynamic LDS = CH * min(SPW, CS) * NG KiB
 // EPI_TAG: the epilogue of the finishing kernel that follows (unused here: it only keeps the instantiations of the four
 // matrices apart, so that a kernel trace names each of them)
-template <int TW, int NG, int U, int SPW, int CS, int CH = 1, int WF = 0, int EPI_TAG = 0>
+// PROG = 1 (round 5; whole-slice kernels only): progressive stage-in, as in k_gemv_slices_seq below — only the first ring block's pieces are staged
+// before the weight stream starts, the following blocks' pieces are requested while the wave's FIRST tile group consumes the block before them.
+template <int TW, int NG, int U, int SPW, int CS, int CH = 1, int WF = 0, int EPI_TAG = 0, int PROG = 0>
 __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
   constexpr int NCH = (SPW + CS - 1) / CS;             // LDS chunks per slice
   constexpr int PW = (CH * CS * NG + 7) / 8;           // operand pieces (1 KiB) per wave and chunk
@@ -162,12 +164,49 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
           w[t][u] = dd_ldw(a.temporal, a.W + ((size_t)(g * TW + t) * a.S + q) * 64 + lane + woff(u));
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!(a.temporal & 2)) {
-      stage_issue(0, SPW);
-      stage_commit(SPW);
+    constexpr int PWB = (UU * NG + 7) / 8;             // operand pieces per wave and ring block (progressive stage-in)
+    u32x4_t xb[PROG ? PWB : 1];
+    auto issue_blk = [&](int b) {                      // pieces of steps b UU .. b UU + UU - 1 of the NS-step space (slice q + s / SPW, step s % SPW)
+#pragma unroll
+      for (int i = 0; i < PWB; ++i) {
+        const int p = wave + 8 * i, pc = p < UU * NG ? p : 0;
+        const int sidx = b * UU + pc / NG;
+        xb[PROG ? i : 0] = xop[(size_t)(q + sidx / SPW + 8 * (sidx % SPW)) * 64 + (pc % NG) * xplane + lane];
+      }
+    };
+    auto commit_blk = [&](int b) {
+#pragma unroll
+      for (int i = 0; i < PWB; ++i) {
+        const int p = wave + 8 * i;
+        if (p < UU * NG) xs[(size_t)(b * UU * NG + p) * 64 + lane] = xb[PROG ? i : 0];
+      }
+    };
+    if constexpr (PROG) {
+      if (!(a.temporal & 2)) {
+        issue_blk(0);
+        commit_blk(0);
+      }
+      __syncthreads();
+      if (!any) {                                      // no tile group: this wave only stages its share of the following blocks
+#pragma unroll
+        for (int b = 1; b < NB; ++b) {
+          if (!(a.temporal & 2)) {
+            issue_blk(b);
+            commit_blk(b);
+          }
+          __syncthreads();
+        }
+        return;
+      }
+    } else {
+      if (!(a.temporal & 2)) {
+        stage_issue(0, SPW);
+        stage_commit(SPW);
+      }
+      __syncthreads();
+      if (!any) return;
     }
-    __syncthreads();
-    if (!any) return;
+    bool first_group = PROG != 0;
     while (true) {
       const int gn = g + a.G * 8;
       const bool has_next = gn < a.n_groups;
@@ -212,13 +251,36 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
             }
         }
       };
+      auto pre = [&](int blk) {
+        if constexpr (PROG) {
+          if (first_group && blk + 1 < NB && !(a.temporal & 2)) issue_blk(blk + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto post = [&](int blk) {
+        if constexpr (PROG) {
+          if (first_group && blk + 1 < NB) {           // workgroup-uniform: every wave with a tile group is in its first one
+            if (!(a.temporal & 2)) commit_blk(blk + 1);
+            __syncthreads();
+          }
+        }
+      };
       if (has_next) {
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) block(blk, true);
+        for (int blk = 0; blk < NB; ++blk) {
+          pre(blk);
+          block(blk, true);
+          post(blk);
+        }
       } else {
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) block(blk, false);
+        for (int blk = 0; blk < NB; ++blk) {
+          pre(blk);
+          block(blk, false);
+          post(blk);
+        }
       }
+      first_group = false;
       store_partials(g, sum);
       if (!has_next) break;
       g = gn;
@@ -294,11 +356,18 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
 // partial sum per pair — half the partial-sum traffic of single slices (gate/up at 64 rows: 22.5 instead of 45 MB written and
 // read back) for a second operand load per workgroup.  Same chains, same order: (hi+lo)(2p) + (hi+lo)(2p+1) as the pair kernels.
 // grid = 4 * G workgroups of 512 threads; dynamic LDS = SPW * NG KiB; a.part laid out for NP = 4.
-template <int NG, int U, int SPW, int MAXG, int WF = 0, int EPI_TAG = 0>
+// PROG = 1 (round 5): PROGRESSIVE stage-in.  The blocking form stages a whole slice of all planes (144 KiB at nine planes: ~3 us at the ~50 GB/s
+// a CU takes from L2) before its waves stream a single weight tile, twice per workgroup, and the HBM stream waits meanwhile with only the ring's
+// first requests in flight.  Here only the first U steps' pieces are staged up front; while the wave's FIRST tile consumes block b of the slice,
+// the pieces of block b + 1 are requested into registers (ahead of the ring's re-requests, so they return first) and committed to LDS behind the
+// block, one barrier per block; later tiles find the whole slice resident.  The second slice's first block is requested before the barrier that
+// ends the first slice.  Same chains, same order of every sum: the same bits.
+template <int NG, int U, int SPW, int MAXG, int WF = 0, int EPI_TAG = 0, int PROG = 0>
 __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
   static_assert(SPW % U == 0, "ring depth must divide the slice");
   constexpr int PW = (SPW * NG + 7) / 8;               // operand pieces (1 KiB) per wave and slice
   constexpr int NB = SPW / U;
+  constexpr int PWC = (U * NG + 7) / 8;                // ... per wave and block of U steps (progressive stage-in)
   extern __shared__ __align__(16) u32x4_t xs[];        // [SPW][NG][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qs = blockIdx.x & 3, j = blockIdx.x >> 2;
@@ -349,6 +418,90 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
     for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, p0 + (size_t)u * wstep);
   }
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (PROG) {
+    u32x4_t xv[PWC];
+    auto issue_blk = [&](int half, int b) {            // pieces of steps b U .. b U + U - 1 of slice 2 qs + half -> registers
+#pragma unroll
+      for (int i = 0; i < PWC; ++i) {
+        const int p = wave + 8 * i, pc = p < U * NG ? p : 0;
+        xv[i] = a.xop[(size_t)(2 * qs + half + 8 * (b * U + pc / NG)) * 64 + (pc % NG) * xplane + lane];
+      }
+    };
+    auto commit_blk = [&](int b) {
+#pragma unroll
+      for (int i = 0; i < PWC; ++i) {
+        const int p = wave + 8 * i;
+        if (p < U * NG) xs[(size_t)(b * U * NG + p) * 64 + lane] = xv[i];
+      }
+    };
+    if (!(a.temporal & 2)) {
+      issue_blk(0, 0);
+      commit_blk(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int gi = 0; gi < MAXG; ++gi) {
+        const int item = half * MAXG + gi;
+        const bool live = gi < ng;                     // wave-uniform
+        const bool last_item = item == 2 * MAXG - 1;
+        const u32x4_t* wp = wptr(item);
+        const u32x4_t* wn = wptr(last_item ? item : item + 1);
+        f32x4_t acc[NG];
+#pragma unroll
+        for (int h = 0; h < NG; ++h) acc[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          const bool stage_next = gi == 0 && blk + 1 < NB;       // compile-time after unrolling
+          if (stage_next && !(a.temporal & 2)) issue_blk(half, blk + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (live) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int s = blk * U + u;
+              u32x4_t b[NG];
+#pragma unroll
+              for (int h = 0; h < NG; ++h) b[h] = xs[(size_t)(s * NG + h) * 64 + lane];
+#pragma unroll
+              for (int h = 0; h < NG; ++h) acc[h] = dd_mfma16<WF>(w[u], b[h], acc[h]);
+              if (blk + 1 < NB) w[u] = dd_ldw(a.temporal, wp + (size_t)(s + U) * wstep);
+              else if (!last_item) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else if (blk + 1 == NB && !last_item) {    // a slot this wave does not have: hand the ring to the next item
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
+          }
+          if (stage_next) {
+            if (!(a.temporal & 2)) commit_blk(blk + 1);
+            __syncthreads();                           // block blk + 1 of the slice is resident (written where nothing has been read yet)
+          }
+        }
+        if (live) {
+#pragma unroll
+          for (int h = 0; h < NG; ++h) {
+            f32x4_t f = fold(acc[h]);
+            if (half == 0) sum[gi][h] = f;
+            else sum[gi][h] = sum[gi][h] + f;          // (hi+lo)(2p) + (hi+lo)(2p+1)
+          }
+          if (half == 1 && (lane & 8) == 0) {
+            const int l32 = (lane >> 4) * 8 + (lane & 7);
+#pragma unroll
+            for (int h = 0; h < NG; ++h)
+              *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + gidx[gi]) * NG + h) << 7) + l32 * 4] = sum[gi][h];
+          }
+        }
+      }
+      if (half == 0) {
+        if (!(a.temporal & 2)) issue_blk(1, 0);        // in flight while the slower waves finish slice 2 qs
+        __syncthreads();                               // every wave has finished reading slice 2 qs
+        if (!(a.temporal & 2)) commit_blk(0);
+        __syncthreads();
+      }
+    }
+    return;
+  }
   if (!(a.temporal & 2)) stage(0);
   __syncthreads();
 #pragma unroll

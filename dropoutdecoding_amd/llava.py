@@ -75,7 +75,7 @@ class CustomLlavaForConditionalGeneration(DropoutVLM):
 
     # ---- construction ---------------------------------------------------------------------------
     @classmethod
-    def from_hf_model(cls, hf, max_new_tokens: int = 1024, device="cuda", original: bool = False):
+    def from_hf_model(cls, hf, max_new_tokens: int = 1024, device="cuda", original: bool = False, tp=None, tp_group=None):
         """Wrap an already-loaded transformers LlavaForConditionalGeneration (4.44 or 5.x attribute layout)."""
         cfg = hf.config
         inner = getattr(hf, "model", hf)
@@ -85,7 +85,7 @@ class CustomLlavaForConditionalGeneration(DropoutVLM):
         lm_cfg = LMConfig.from_hf(cfg.text_config)
         vc = cfg.vision_config
         L = (vc.image_size // vc.patch_size) ** 2 + (0 if cfg.vision_feature_select_strategy == "default" else 1)
-        eng = build_engine(lm_cfg, cls.family, checkpoint_dtype=sd["lm_head.weight"].dtype, max_visual=L, max_new_tokens=max_new_tokens, seed=_config.effective_seed)
+        eng = build_engine(lm_cfg, cls.family, checkpoint_dtype=sd["lm_head.weight"].dtype, max_visual=L, max_new_tokens=max_new_tokens, seed=_config.effective_seed, tp=tp, tp_group=tp_group)
         eng.load_state_dict(sd)
         dev = eng.device
         embed = sd["model.embed_tokens.weight"].to(dev, torch.float16 if eng.weight_format == "fp16" else torch.bfloat16)   # the engine's 16-bit type
@@ -103,7 +103,7 @@ class CustomLlavaForConditionalGeneration(DropoutVLM):
         from transformers import LlavaForConditionalGeneration
         hf = LlavaForConditionalGeneration.from_pretrained(model_path, torch_dtype=torch_dtype, low_cpu_mem_usage=True)
         dev = device_map if isinstance(device_map, (str, torch.device)) and str(device_map) not in ("auto", "balanced") else "cuda"
-        return cls.from_hf_model(hf, max_new_tokens=max_new_tokens, device=dev)
+        return cls.from_hf_model(hf, max_new_tokens=max_new_tokens, device=dev, tp=kw.get("tp"), tp_group=kw.get("tp_group"))
 
     @classmethod
     def from_synthetic(cls, lm_cfg: Optional[LMConfig] = None, seed: int = 0, max_new_tokens: int = 256,

@@ -66,12 +66,12 @@ class CustomLlavaNextForConditionalGeneration(DropoutVLM):
         return super()._decode_loop(n_new, eos, chunk)
 
     @classmethod
-    def from_hf_model(cls, hf, max_new_tokens: int = 1024, max_visual: int = 2944, original: bool = False):
+    def from_hf_model(cls, hf, max_new_tokens: int = 1024, max_visual: int = 2944, original: bool = False, tp=None, tp_group=None):
         cfg = hf.config
         sd = lm_state_dict_from_hf(hf)
         lm_cfg = LMConfig.from_hf(cfg.text_config)
         eng = build_engine(lm_cfg, cls.family, checkpoint_dtype=sd["lm_head.weight"].dtype, max_visual=max_visual, max_new_tokens=max_new_tokens,
-                           use_random=bool(settings["use_random"][0]), seed=_config.effective_seed)
+                           use_random=bool(settings["use_random"][0]), seed=_config.effective_seed, tp=tp, tp_group=tp_group)
         eng.load_state_dict(sd)
         dev = eng.device
         embed = sd["model.embed_tokens.weight"].to(dev, torch.float16 if eng.weight_format == "fp16" else torch.bfloat16)   # the engine's 16-bit type
@@ -127,4 +127,4 @@ class CustomLlavaNextForConditionalGeneration(DropoutVLM):
     def from_pretrained(cls, model_path, torch_dtype=torch.float16, device_map="auto", max_new_tokens: int = 1024, **kw):
         from transformers import LlavaNextForConditionalGeneration
         hf = LlavaNextForConditionalGeneration.from_pretrained(model_path, torch_dtype=torch_dtype, low_cpu_mem_usage=True)
-        return cls.from_hf_model(hf, max_new_tokens=max_new_tokens)
+        return cls.from_hf_model(hf, max_new_tokens=max_new_tokens, tp=kw.get("tp"), tp_group=kw.get("tp_group"))

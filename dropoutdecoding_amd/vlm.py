@@ -128,7 +128,7 @@ class DropoutVLM:
         # the `# if True:` toggle of llava.py:336-337; never for the stock greedy (`--original`) path
         first = bool(settings.get("first_step_ensemble", False)) and not self.original
         if (self.supports_prefix_reuse and bool(settings.get("reuse_image_prefix", False)) and not first
-                and self._try_reuse_prefix(input_ids, inputs, stream)):
+                and getattr(self.engine, "tp_rank", None) is None and self._try_reuse_prefix(input_ids, inputs, stream)):
             eos = self.eos_token_ids if eos_token_id is None else (
                 list(eos_token_id) if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
             return input_ids, max_new_tokens, eos
@@ -142,7 +142,13 @@ class DropoutVLM:
         self.start_image_pos, self.end_image_pos = [start], [start + L - 1]
         self.start_generation_pos = embeds.shape[0]
         self.masked_numbers = []
-        if defer_prefill and not first:
+        tpr = getattr(self.engine, "tp_rank", None)
+        if tpr is not None:
+            # a tensor-parallel rank (build_engine(tp=...)): every rank of the group makes this same call with the same arguments
+            if first or defer_prefill or stream is not None:
+                raise ValueError("a tensor-parallel model decodes one image at a time on the engine's stream (no first-step ensemble, no lanes)")
+            tpr.prefill(embeds, start, L)
+        elif defer_prefill and not first:
             self._deferred = (embeds, start, L)
         else:
             self.engine.prefill(embeds, start, L, first_step_ensemble=first, stream=stream)
@@ -207,6 +213,8 @@ class DropoutVLM:
         rng stream seeded like a fresh process) that borrows this engine's weights.  See generate_group()."""
         import copy
         eng = self.engine
+        if getattr(eng, "tp_rank", None) is not None:
+            raise ValueError("lanes over a tensor-parallel model are not built (DESIGN.md 7a): one image at a time per group of ranks")
         lane = copy.copy(self)
         lane.engine = DropoutEngine(eng.cfg, family=eng.family, max_seq=eng.max_seq, max_visual=eng.max_visual,
                                     seed=eng.seed, use_random=eng.use_random, iblip_positions=eng.iblip_positions,
@@ -221,6 +229,20 @@ class DropoutVLM:
         eng = self.engine
         dropout = not self.original
         ks = getattr(self, "kshard", None)             # dist.KShardDecoder: members sharded over ranks
+        tpr = getattr(eng, "tp_rank", None)            # dist.TensorParallelRank: the weights sharded over ranks
+        if tpr is not None:
+            # every rank decodes the same tokens and must issue the same exchanges: fixed chunks, the EOS looked for in the tokens every rank
+            # has (the device-side stop makes the steps of a chunk past an EOS no-ops, as in the un-sharded loop)
+            eng.set_eos(eos)
+            toks = eng.tokens()
+            while len(toks) < n_new and not (eos and any(t in eos for t in toks)):
+                for _ in range(min(chunk, n_new - len(toks))):
+                    tpr.decode_step(dropout=dropout)
+                toks = eng.tokens()
+            hit = [i for i, t in enumerate(toks) if eos and t in eos]
+            if hit:
+                toks = toks[:hit[0] + 1]
+            return toks[:n_new]
         if ks is None and not self.collect_diagnostics:
             # steps are enqueued without host syncs; the pinned token mirror is watched for EOS (look-ahead steps past
             # it are device-side no-ops: no tokens, no rng draws)
@@ -256,15 +278,30 @@ class DropoutVLM:
 
 
 def build_engine(lm_cfg: LMConfig, family: str, max_visual: int, max_new_tokens: int = 1024, prompt_tokens: int = 256,
-                 use_random: bool = False, seed: Optional[int] = None, checkpoint_dtype=None) -> DropoutEngine:
+                 use_random: bool = False, seed: Optional[int] = None, checkpoint_dtype=None, tp=None, tp_group=None) -> DropoutEngine:
+    """The engine behind a drop-in class.  tp = (rank, world): THIS process holds rank `rank` of a tensor-parallel model over `world` GPUs
+    (dist.TensorParallelRank: the rank's head / d_ff slices, the two all-gathers per layer over `tp_group` — "nccl" = RCCL over xGMI); the
+    engine returned is the rank's, with the driver attached as `engine.tp_rank` — load_state_dict on it takes the FULL state dict."""
     max_seq = max_visual + prompt_tokens + max_new_tokens + 8
     wfmt = settings.get("weight_format", "auto")
     if wfmt == "auto":            # keep the checkpoint's own 16-bit type: fp16 checkpoints (all the reference loads) stay exact
         wfmt = "fp16" if checkpoint_dtype == torch.float16 else "bf16"
-    return DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, use_random=use_random,
-                         mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)),
-                         weight_format=wfmt, kv_format=settings.get("kv_cache", "fp16"),
-                         rng_stream=settings.get("rng_stream", "cpu"))
+    kw = dict(use_random=use_random, mask_method=settings.get("mask_method", "epis"), use_avg=bool(settings.get("use_avg", False)),
+              weight_format=wfmt, kv_format=settings.get("kv_cache", "fp16"), rng_stream=settings.get("rng_stream", "cpu"))
+    if tp is not None:
+        from .dist import TensorParallelRank
+        rank, world = int(tp[0]), int(tp[1])
+        if not 0 <= rank < world:
+            raise ValueError(f"tp=(rank, world): got {tp}")
+        tpr = TensorParallelRank(lm_cfg, rank, world, group=tp_group, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, **kw)
+        eng = tpr.engine
+        eng.tp_rank = tpr
+        eng.load_state_dict_full = eng.load_state_dict
+        eng.load_state_dict = tpr.load_state_dict             # the wrappers hand over the FULL dict: the rank keeps its slices
+        return eng
+    eng = DropoutEngine(lm_cfg, family=family, max_seq=max_seq, max_visual=max_visual, seed=seed, **kw)
+    eng.tp_rank = None
+    return eng
 
 
 _NON_VISUAL_KEYS = ("input_ids", "attention_mask", "max_new_tokens", "max_length", "eos_token_id")

@@ -125,8 +125,8 @@ def test_one_wave_sampler_is_clean_where_the_block_form_fails():
     from dropoutdecoding_amd import _lib, build
     build.build()
     lib = _lib.load_tools()
-    block = R.sampler_streams(1, 10 ** 6, lib, 32, lds_kib=0, form="block", seconds=25.0)
     wave = R.sampler_streams(1, 10 ** 6, lib, 32, form="wave", seconds=40.0)
+    block = R.sampler_streams(1, 10 ** 6, lib, 32, lds_kib=0, form="block", seconds=25.0)
     lib.dd_tools_set_tuning(48, 1)
     print(f"\n[sampler beside rider steps] 1,024-thread form, 76 KiB request: {block['sequences_with_a_wrong_launch']} wrong in {block['sampler_launches']} "
           f"launches of 8 workgroups ({block['company_rider_steps']} rider steps beside); one-wave form: {wave['sequences_with_a_wrong_launch']} wrong in "
