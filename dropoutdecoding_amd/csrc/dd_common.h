@@ -126,6 +126,22 @@ __device__ __forceinline__ float dd_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+// Softmax statistics of one 64-column block of a logits row, held by a 16-lane group as four values per lane (lane c: columns c, c + 16, c + 32,
+// c + 48 of the block; invalid columns = -INFINITY): m = the block's maximum, s = sum exp(x - m).  The order of every operation is part of the
+// result: the prefill GEMM's epilogue (dd_prefill.hip gemm_epilogue) and the stand-alone scorer (dd_dropout.hip k_row_partials) both call this.
+__device__ __forceinline__ void dd_row_block_stats(const float (&x)[4], float& m, float& s) {
+  float mm = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+  float ss = 0.f;
+  if (mm != -INFINITY) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ss += expf(x[j] - mm);          // exp(-inf) = 0 for the invalid columns
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
+  m = mm, s = ss;
+}
 __device__ __forceinline__ float dd_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -77,82 +77,62 @@ __device__ float block_max_f(float v, float* sh) {
 
 // ----------------------------------------------------------------------------------------------
 // Uncertainty scorer (calculate_vision_uncertainty, reference models/llava.py:710-756)
-//   pass A: per row softmax statistics (max, sum exp) + top-k ids        (llava.py:722, 428-441)
+//   pass A: per row softmax statistics (max, sum exp) as 64-column block partials + a fixed-order combine   (llava.py:722) — the partials come
+//           from the lm_head GEMM's epilogue in the engine's prefill (no read of the logits), from k_row_partials for the stand-alone call
 //   pass B: partial column sums of p over row chunks, B2 combine -> p_avg (llava.py:732)
-//   pass C: per row epi / alea / var                                      (llava.py:728,735-739)
-// HBM-bound: 3 reads of the [L][V] fp32 logits (pass A keeps its row in LDS: k_row_stats_topk_lds).
+//   pass C: per row epi / alea / var + the top-k ids, the row held in LDS  (llava.py:728,735-739, 428-441)
+// HBM-bound: the engine reads the [L][V] fp32 logits twice (B, C); the stand-alone C-ABI call three times (A, B, C).
 // ----------------------------------------------------------------------------------------------
 #define UNC_THREADS 512
 #define UNC_LSPLIT 8
 
-__global__ __launch_bounds__(UNC_THREADS) void k_row_stats_topk(const float* __restrict__ logits, int V, int ld,
-                                                                float* __restrict__ row_max, float* __restrict__ row_sum,
-                                                                int k_top, float* __restrict__ topk_vals,
-                                                                int32_t* __restrict__ topk_ids) {
-  __shared__ ArgMax sh_am[16];
-  __shared__ double sh_d[16];
-  __shared__ float sh_f[16];
+// Round 5: the row statistics as BLOCK PARTIALS.  {max, sum exp(x - max)} per row and 64-column block (dd_row_block_stats) — produced by the lm_head
+// GEMM's epilogue while the logits are still in its accumulators (dd_prefill.hip, GemmArgs::rowstat: the north star's "softmax reduction fused into
+// the unembedding product"), or, for the stand-alone C-ABI scorer, by k_row_partials from the stored logits with the same arithmetic — and one
+// fixed-order combine per row.  The engine's prefill then reads the [L][V] logits twice (column mean; epi + top-k) instead of three times.
+__global__ __launch_bounds__(256) void k_row_partials(const float* __restrict__ logits, int V, int ld, float* __restrict__ partials, int n_cb) {
   const float* x = logits + (size_t)blockIdx.x * ld;
-  float m = -INFINITY;
-  for (int v = threadIdx.x; v < V; v += UNC_THREADS) m = fmaxf(m, x[v]);
-  m = block_max_f(m, sh_f);
-  double s = 0;
-  for (int v = threadIdx.x; v < V; v += UNC_THREADS) s += (double)expf(x[v] - m);
-  s = block_sum_d(s, sh_d);
-  if (threadIdx.x == 0) {
-    row_max[blockIdx.x] = m;
-    row_sum[blockIdx.x] = (float)s;
-  }
-  // top-k by repeated "next in (value desc, index asc) order" selection; the row is L2-resident
-  float pv = INFINITY;
-  int pi = -1;
-  for (int j = 0; j < k_top; ++j) {
-    ArgMax a = {-INFINITY, 0x7fffffff};
-    for (int v = threadIdx.x; v < V; v += UNC_THREADS) {
-      float xv = x[v];
-      bool after = (xv < pv) || (xv == pv && v > pi);
-      if (after && better(xv, v, a.v, a.i)) {
-        a.v = xv;
-        a.i = v;
-      }
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (int cb0 = 0; cb0 < n_cb; cb0 += 16) {              // (uniform trip count: every lane takes part in the shuffles)
+    const int cb = cb0 + grp;
+    float x4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = cb * 64 + 16 * j + c;
+      x4[j] = (cb < n_cb && col < V) ? x[col] : -INFINITY;
     }
-    a = block_argmax(a, sh_am);
-    pv = a.v;
-    pi = a.i;
-    if (threadIdx.x == 0) {
-      if (topk_vals) topk_vals[(size_t)blockIdx.x * k_top + j] = a.v;
-      if (topk_ids) topk_ids[(size_t)blockIdx.x * k_top + j] = a.i;
+    float m, sum;
+    dd_row_block_stats(x4, m, sum);
+    if (c == 0 && cb < n_cb) {
+      partials[((size_t)blockIdx.x * n_cb + cb) * 2] = m;
+      partials[((size_t)blockIdx.x * n_cb + cb) * 2 + 1] = sum;
     }
   }
 }
-
-// The same pass with the row held in LDS: one workgroup reads its row from memory ONCE (16-byte loads; 125 KiB at V = 32064
-// fit the CU's 160 KiB) and takes max, sum-exp and the k_top selection sweeps from LDS — the [L][V] logits are read once
-// here instead of 2 + k_top times.  Same arithmetic, same order: results identical to k_row_stats_topk.
-__global__ __launch_bounds__(UNC_THREADS) void k_row_stats_topk_lds(const float* __restrict__ logits, int V, int ld,
-                                                                    float* __restrict__ row_max, float* __restrict__ row_sum,
-                                                                    int k_top, float* __restrict__ topk_vals,
-                                                                    int32_t* __restrict__ topk_ids) {
-  extern __shared__ __align__(16) float row_sh[];
-  __shared__ ArgMax sh_am[16];
-  __shared__ double sh_d[16];
-  __shared__ float sh_f[16];
-  const float* xg = logits + (size_t)blockIdx.x * ld;
-  const int V4 = V >> 2;
-  for (int i = threadIdx.x; i < V4; i += UNC_THREADS) *(f32x4_t*)&row_sh[4 * i] = *(const f32x4_t*)(xg + 4 * i);
-  for (int v = 4 * V4 + threadIdx.x; v < V; v += UNC_THREADS) row_sh[v] = xg[v];
-  __syncthreads();
-  const float* x = row_sh;
+// one wave per row: M = max of the block maxima; S = sum over blocks of s_b * exp(m_b - M), each lane over its blocks in index order in fp64, then the
+// wave's butterfly — a fixed order, so the same bits every run
+__global__ __launch_bounds__(64) void k_row_stats_combine(const float* __restrict__ partials, int n_cb, float* __restrict__ row_max,
+                                                          float* __restrict__ row_sum) {
+  const float* p = partials + (size_t)blockIdx.x * n_cb * 2;
   float m = -INFINITY;
-  for (int v = threadIdx.x; v < V; v += UNC_THREADS) m = fmaxf(m, x[v]);
-  m = block_max_f(m, sh_f);
+  for (int b = threadIdx.x; b < n_cb; b += 64) m = fmaxf(m, p[2 * b]);
+  m = dd_wave_max(m);
   double s = 0;
-  for (int v = threadIdx.x; v < V; v += UNC_THREADS) s += (double)expf(x[v] - m);
-  s = block_sum_d(s, sh_d);
+  for (int b = threadIdx.x; b < n_cb; b += 64) {
+    const float mb = p[2 * b];
+    if (mb != -INFINITY) s += (double)(p[2 * b + 1] * expf(mb - m));
+  }
+  s = dd_wave_sum_d(s);
   if (threadIdx.x == 0) {
     row_max[blockIdx.x] = m;
     row_sum[blockIdx.x] = (float)s;
   }
+}
+// top-k ids of every row (value descending, index ascending), the row read from memory (rows too long for the LDS)
+__global__ __launch_bounds__(UNC_THREADS) void k_row_topk(const float* __restrict__ logits, int V, int ld, int k_top, float* __restrict__ topk_vals,
+                                                          int32_t* __restrict__ topk_ids) {
+  __shared__ ArgMax sh_am[16];
+  const float* x = logits + (size_t)blockIdx.x * ld;
   float pv = INFINITY;
   int pi = -1;
   for (int j = 0; j < k_top; ++j) {
@@ -228,6 +208,64 @@ __global__ __launch_bounds__(UNC_THREADS) void k_row_epi(const float* __restrict
   }
 }
 
+// pass C with the row held in LDS: epi / alea / var AND the k_top selection sweeps from one read of the row (the arithmetic of k_row_epi and of
+// k_row_topk, same order: same results)
+__global__ __launch_bounds__(UNC_THREADS) void k_row_epi_topk_lds(const float* __restrict__ logits, int V, int ld, const float* __restrict__ row_max,
+                                                                  const float* __restrict__ row_sum, const float* __restrict__ p_avg,
+                                                                  float* __restrict__ var_tok, float* __restrict__ epi_tok, float* __restrict__ alea_tok,
+                                                                  int k_top, float* __restrict__ topk_vals, int32_t* __restrict__ topk_ids) {
+  extern __shared__ __align__(16) float row_sh[];
+  __shared__ ArgMax sh_am[16];
+  __shared__ double sh_d[16];
+  const float* xg = logits + (size_t)blockIdx.x * ld;
+  const int V4 = V >> 2;
+  for (int i = threadIdx.x; i < V4; i += UNC_THREADS) *(f32x4_t*)&row_sh[4 * i] = *(const f32x4_t*)(xg + 4 * i);
+  for (int v = 4 * V4 + threadIdx.x; v < V; v += UNC_THREADS) row_sh[v] = xg[v];
+  __syncthreads();
+  const float* x = row_sh;
+  const float m = row_max[blockIdx.x], s = row_sum[blockIdx.x];
+  double epi = 0, alea = 0, sp = 0, sp2 = 0;
+  for (int v = threadIdx.x; v < V; v += UNC_THREADS) {
+    float p = expf(x[v] - m) / s;
+    float lp = logf(p + 1e-10f);
+    float lpa = logf(p_avg[v] + 1e-10f);
+    epi += (double)(p * (lp - lpa));
+    alea += (double)(p * lp);
+    sp += (double)p;
+    sp2 += (double)p * (double)p;
+  }
+  epi = block_sum_d(epi, sh_d);
+  alea = block_sum_d(alea, sh_d);
+  sp = block_sum_d(sp, sh_d);
+  sp2 = block_sum_d(sp2, sh_d);
+  if (threadIdx.x == 0) {
+    epi_tok[blockIdx.x] = (float)epi;
+    alea_tok[blockIdx.x] = (float)(-alea);
+    double mean = sp / V;
+    var_tok[blockIdx.x] = (float)((sp2 - (double)V * mean * mean) / (double)(V - 1));  // unbiased (torch.var)
+  }
+  float pv = INFINITY;
+  int pi = -1;
+  for (int j = 0; j < k_top; ++j) {
+    ArgMax a = {-INFINITY, 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += UNC_THREADS) {
+      float xv = x[v];
+      bool after = (xv < pv) || (xv == pv && v > pi);
+      if (after && better(xv, v, a.v, a.i)) {
+        a.v = xv;
+        a.i = v;
+      }
+    }
+    a = block_argmax(a, sh_am);
+    pv = a.v;
+    pi = a.i;
+    if (threadIdx.x == 0) {
+      if (topk_vals) topk_vals[(size_t)blockIdx.x * k_top + j] = a.v;
+      if (topk_ids) topk_ids[(size_t)blockIdx.x * k_top + j] = a.i;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_means3(const float* a, const float* b, const float* c, int L, float* out3) {
   __shared__ double sh_d[16];
   double sa = 0, sb = 0, sc = 0;
@@ -246,50 +284,76 @@ __global__ __launch_bounds__(256) void k_means3(const float* a, const float* b, 
   }
 }
 
+static int unc_n_cb(int V) { return (V + 63) / 64; }
 extern "C" size_t dd_uncertainty_workspace_bytes(int L, int V) {
-  // row_max[L] row_sum[L] p_avg[V] (fp32) + partial[UNC_LSPLIT][V] (fp64), 256-byte aligned pieces
+  // row_max[L] row_sum[L] p_avg[V] (fp32) + partial[UNC_LSPLIT][V] (fp64) + block partials [L][ceil(V/64)][2] (fp32), 256-byte aligned pieces
   size_t a = ((size_t)L * 4 + 255) / 256 * 256;
   size_t p = ((size_t)V * 4 + 255) / 256 * 256;
-  return 2 * a + p + (size_t)UNC_LSPLIT * V * 8 + 256;
+  size_t bp = ((size_t)L * unc_n_cb(V) * 8 + 255) / 256 * 256;
+  return 2 * a + p + (size_t)UNC_LSPLIT * V * 8 + 256 + bp;
+}
+// where the block partials of a workspace for (L_cap rows, V) live — the engine hands this to the lm_head GEMM (GemmArgs::rowstat)
+float* dd_uncertainty_partials(void* ws, int L_cap, int V, int* n_cb) {
+  size_t a = ((size_t)L_cap * 4 + 255) / 256 * 256, p = ((size_t)V * 4 + 255) / 256 * 256;
+  *n_cb = unc_n_cb(V);
+  return (float*)((char*)ws + 2 * a + p + (size_t)UNC_LSPLIT * V * 8 + 256);
 }
 
-extern "C" int dd_vision_uncertainty(const float* logits, int L, int V, int ld, float* var_tok, float* epi_tok,
-                                     float* alea_tok, float* scalars3, int k_top, float* topk_vals,
-                                     int32_t* topk_ids, void* ws, size_t ws_bytes, void* stream_) {
-  hipStream_t st = (hipStream_t)stream_;
+// partials_ready: the block partials already sit in the workspace laid out for L_cap rows (written by the lm_head GEMM's epilogue); null: this
+// call computes them from the logits (k_row_partials: the same arithmetic, the same bits).
+int dd_vision_uncertainty_impl(const float* logits, int L, int V, int ld, float* var_tok, float* epi_tok, float* alea_tok, float* scalars3,
+                               int k_top, float* topk_vals, int32_t* topk_ids, void* ws, size_t ws_bytes, hipStream_t st, int L_cap,
+                               bool partials_ready) {
   DD_REQUIRE(logits && var_tok && epi_tok && alea_tok && ws, "dd_vision_uncertainty: null pointer");
-  DD_REQUIRE(L >= 1 && V >= 2 && ld >= V, "dd_vision_uncertainty: bad shape L=%d V=%d ld=%d", L, V, ld);
+  DD_REQUIRE(L >= 1 && V >= 2 && ld >= V && L_cap >= L, "dd_vision_uncertainty: bad shape L=%d V=%d ld=%d", L, V, ld);
   DD_REQUIRE(k_top >= 0 && k_top <= DD_MAX_TOPK && k_top <= V, "dd_vision_uncertainty: k_top=%d out of range", k_top);
-  DD_REQUIRE(ws_bytes >= dd_uncertainty_workspace_bytes(L, V), "dd_vision_uncertainty: workspace too small");
-  size_t a = ((size_t)L * 4 + 255) / 256 * 256, p = ((size_t)V * 4 + 255) / 256 * 256;
+  DD_REQUIRE(ws_bytes >= dd_uncertainty_workspace_bytes(L_cap, V), "dd_vision_uncertainty: workspace too small");
+  size_t a = ((size_t)L_cap * 4 + 255) / 256 * 256, p = ((size_t)V * 4 + 255) / 256 * 256;
   char* base = (char*)ws;
   float* row_max = (float*)base;
   float* row_sum = (float*)(base + a);
   float* p_avg = (float*)(base + 2 * a);
   double* partial = (double*)(base + 2 * a + p);
-  const size_t row_bytes = (size_t)V * sizeof(float);
-  if (row_bytes <= 150 * 1024 && (ld & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
-    static bool attr = false;
-    if (!attr) {
-      DD_HIP(hipFuncSetAttribute((const void*)k_row_stats_topk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr = true;
-    }
-    k_row_stats_topk_lds<<<L, UNC_THREADS, row_bytes, st>>>(logits, V, ld, row_max, row_sum, k_top, topk_vals, topk_ids);
-  } else {
-    k_row_stats_topk<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, row_max, row_sum, k_top, topk_vals, topk_ids);
+  int n_cb = 0;
+  float* bpart = dd_uncertainty_partials(ws, L_cap, V, &n_cb);
+  if (!partials_ready) {
+    k_row_partials<<<L, 256, 0, st>>>(logits, V, ld, bpart, n_cb);
+    DD_CHECK_LAUNCH();
   }
+  k_row_stats_combine<<<L, 64, 0, st>>>(bpart, n_cb, row_max, row_sum);
   DD_CHECK_LAUNCH();
   k_col_partial<<<dim3((V + 255) / 256, UNC_LSPLIT), 256, 0, st>>>(logits, L, V, ld, row_max, row_sum, partial);
   DD_CHECK_LAUNCH();
   k_col_combine<<<(V + 255) / 256, 256, 0, st>>>(partial, L, V, p_avg);
   DD_CHECK_LAUNCH();
-  k_row_epi<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, row_max, row_sum, p_avg, var_tok, epi_tok, alea_tok);
-  DD_CHECK_LAUNCH();
+  const size_t row_bytes = (size_t)V * sizeof(float);
+  if (row_bytes <= 150 * 1024 && (ld & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
+    static bool attr = false;
+    if (!attr) {
+      DD_HIP(hipFuncSetAttribute((const void*)k_row_epi_topk_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr = true;
+    }
+    k_row_epi_topk_lds<<<L, UNC_THREADS, row_bytes, st>>>(logits, V, ld, row_max, row_sum, p_avg, var_tok, epi_tok, alea_tok, k_top, topk_vals, topk_ids);
+    DD_CHECK_LAUNCH();
+  } else {
+    k_row_epi<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, row_max, row_sum, p_avg, var_tok, epi_tok, alea_tok);
+    DD_CHECK_LAUNCH();
+    if (k_top > 0) {
+      k_row_topk<<<L, UNC_THREADS, 0, st>>>(logits, V, ld, k_top, topk_vals, topk_ids);
+      DD_CHECK_LAUNCH();
+    }
+  }
   if (scalars3) {
     k_means3<<<1, 256, 0, st>>>(var_tok, epi_tok, alea_tok, L, scalars3);
     DD_CHECK_LAUNCH();
   }
   return DD_OK;
+}
+extern "C" int dd_vision_uncertainty(const float* logits, int L, int V, int ld, float* var_tok, float* epi_tok,
+                                     float* alea_tok, float* scalars3, int k_top, float* topk_vals,
+                                     int32_t* topk_ids, void* ws, size_t ws_bytes, void* stream_) {
+  return dd_vision_uncertainty_impl(logits, L, V, ld, var_tok, epi_tok, alea_tok, scalars3, k_top, topk_vals, topk_ids, ws, ws_bytes,
+                                    (hipStream_t)stream_, L, false);
 }
 
 // ----------------------------------------------------------------------------------------------

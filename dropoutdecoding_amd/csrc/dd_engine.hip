@@ -233,7 +233,7 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->scalars, 4);
   DA(h->topk_vals, (size_t)h->Lmax * DD_MAX_TOPK);
   DA(h->topk_ids, (size_t)h->Lmax * DD_MAX_TOPK);
-  h->unc_ws_bytes = dd_uncertainty_workspace_bytes(h->Lmax, h->V);
+  h->unc_ws_bytes = dd_uncertainty_workspace_bytes(h->Lmax + 1, h->V);      // (+ 1: the lm_head GEMM also runs the last position: its block partials land there too)
   char* ws;
   DA(ws, h->unc_ws_bytes);
   h->unc_ws = ws;
@@ -655,8 +655,13 @@ static int prefill_layers(dd_lm* h, int T0, const uint8_t* drop_plane, int drop_
 
 // final norm + lm_head over `n_rows` rows of h->px selected by row_index (device) -> logits [n_rows][Vpad];
 // the normed rows stay in h->pq
+float* dd_uncertainty_partials(void* ws, int L_cap, int V, int* n_cb);
+int dd_vision_uncertainty_impl(const float* logits, int L, int V, int ld, float* var_tok, float* epi_tok, float* alea_tok, float* scalars3,
+                               int k_top, float* topk_vals, int32_t* topk_ids, void* ws, size_t ws_bytes, hipStream_t st, int L_cap,
+                               bool partials_ready);
+// rowstat: the scorer's softmax block partials, written by the GEMM's epilogue (GemmArgs::rowstat; prefill_tail)
 static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* logits, hipStream_t st,
-                        const float* src = nullptr) {
+                        const float* src = nullptr, float* rowstat = nullptr, int rowstat_ld = 0) {
   const int d = h->d;
   RC(ddk_rmsnorm_split(src ? src : h->px, n_rows, d, h->final_norm, h->cfg.rms_eps, h->p1_hi, h->p1_lo, row_index, h->pq, st, h->wf));
   GemmArgs g;
@@ -670,6 +675,7 @@ static int prefill_head(dd_lm* h, const int32_t* row_index, int n_rows, float* l
     g.W = h->deq_tmp, g.wscale = h->s_lm;
   }
   g.out = logits, g.ldo = h->Vpad, g.n_valid = h->V;
+  g.rowstat = rowstat, g.rowstat_ld = rowstat_ld;
   return ddk_gemm(EPI_STORE, g, st);
 }
 
@@ -704,10 +710,13 @@ static int prefill_tail(dd_lm* h, const float* x_rows, int T0, int span_start, i
   // llava.py:294-305, but consumes just these: llava.py:311-314 and HF's greedy argmax)
   k_prefill_rows<<<(L + 1 + 255) / 256, 256, 0, st>>>(h->row_index, span_start, L, T0);   // no host data: prefill stays asynchronous
   DD_CHECK_LAUNCH();
-  RC(prefill_head(h, h->row_index, L + 1, h->image_logits, st, x_rows));
+  // the scorer's row statistics come out of the lm_head GEMM's epilogue as block partials (the logits are read twice afterwards, not three times)
+  int n_cb = 0;
+  float* bpart = dd_uncertainty_partials(h->unc_ws, h->Lmax + 1, h->V, &n_cb);
+  RC(prefill_head(h, h->row_index, L + 1, h->image_logits, st, x_rows, bpart, n_cb));
   DD_HIP(hipMemcpyAsync(h->last_hidden, h->pq + (size_t)L * d, (size_t)d * 4, hipMemcpyDeviceToDevice, st));
-  RC(dd_vision_uncertainty(h->image_logits, L, h->V, h->Vpad, h->var, h->epi, h->alea, h->scalars, h->cfg.k_top,
-                           h->topk_vals, h->topk_ids, h->unc_ws, h->unc_ws_bytes, st));
+  RC(dd_vision_uncertainty_impl(h->image_logits, L, h->V, h->Vpad, h->var, h->epi, h->alea, h->scalars, h->cfg.k_top,
+                                h->topk_vals, h->topk_ids, h->unc_ws, h->unc_ws_bytes, st, h->Lmax + 1, true));
   DD_HIP(hipMemcpyAsync(h->last_logits, h->image_logits + (size_t)L * h->Vpad, (size_t)h->Vpad * 4,
                         hipMemcpyDeviceToDevice, st));
   RC(dd_argmax_rows(h->last_logits, 1, h->V, h->Vpad, h->argmax_base, st));

@@ -877,7 +877,9 @@ template <int TW, int NG, int U, int SPW, int CS, int CH, int TAG>
 static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)CH * (SPW < CS ? SPW : CS) * NG * 1024;
   // progressive stage-in (dd_gemv_slices.h PROG): whole-slice kernels with at least two ring blocks per tile group
-  constexpr int PROG_OK = (SPW <= CS && (CH * SPW) / (SPW < U ? SPW : U) >= 2) ? 1 : 0;
+  // Measured (profiles/r05_progressive_stage_in.log): it pays at two and four planes (16 / 32 rows: gate/up 33.7 -> 32.7 / 36.4 -> 35.0 us) and
+  // costs at eight and nine (the per-block barriers of the first tile group: 64-lane step 36.4 -> 37.7 ms) — so only NG <= 4 takes it.
+  constexpr int PROG_OK = (NG <= 4 && SPW <= CS && (CH * SPW) / (SPW < U ? SPW : U) >= 2) ? 1 : 0;
   static bool attr = false;
   if (!attr) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 0, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -899,14 +901,17 @@ static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   return DD_OK;
 }
 // (16 instead of 8 weight requests in flight per wave measured the same or slower: qkv 26.3 vs 25.4 us, gate/up 38.4 vs 38.0)
-// dd_tools_set_tuning key 49: progressive stage-in of the operand planes in the slice-pair kernels (dd_gemv_slices.h PROG; 0: the blocking
-// stage-in of rounds 2-4).  Same bits either way.
+// dd_tools_set_tuning key 49: progressive stage-in of the operand planes (dd_gemv_slices.h PROG): 1 (default) = where it was measured to pay (the
+// whole-slice kernels at two and four planes), 0 = never (the blocking stage-in of rounds 2-4), 2 = also the slice-pair kernels.  Same bits always.
 int g_seq_prog = 1;
 template <int NG, int U, int MAXG, int TAG>
 static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)16 * NG * 1024;
   // (nine planes with eight requests in flight and two tiles per wave: the progressive form needs 257+ registers — it keeps the blocking stage-in)
-  constexpr int PROG_OK = (NG == 9 && U == 8 && MAXG >= 2) ? 0 : 1;
+  // ... and the slice-pair kernels, which exist for eight and nine planes only, keep the blocking stage-in (tools key 49 = 2 forces the progressive
+  // form where it fits, for the A/B)
+  constexpr int PROG_FITS = (NG == 9 && U == 8 && MAXG >= 2) ? 0 : 1;
+  constexpr int PROG_OK = PROG_FITS;
   static bool attr = false;
   if (!attr) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -915,7 +920,7 @@ static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  const int prog = g_seq_prog && PROG_OK;
+  const int prog = g_seq_prog == 2 && PROG_OK;
   NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG, prog);
   if (prog) {
     if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, PROG_OK><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);

@@ -238,6 +238,11 @@ struct GemmArgs {
   int n_tiles;           // 16-col tiles (EPI_SILU: gate/up tiles interleaved, n_tiles = 2 * d_ff/16)
   float* out;            // EPI_STORE [M][ldo] / EPI_RESID x[M][ldo]
   int ldo, n_valid;
+  // EPI_STORE, optional (the lm_head over the visual span: the scorer's softmax statistics fused into the GEMM, round 5): per row and 64-column
+  // block {max, sum exp(x - max)} -> rowstat[(row * rowstat_ld + block) * 2 + {0, 1}] (dd_row_block_stats: ONE definition of the arithmetic, shared
+  // with the stand-alone scorer's k_row_partials, so that the fused and the stand-alone paths give the same bits)
+  float* rowstat;
+  int rowstat_ld;
   uint16_t* o_hi;        // EPI_SILU planes [M][ld_planes]
   uint16_t* o_lo;
   int ld_planes;

@@ -181,6 +181,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
         kc_r = a.seq_tab->kc[sq] + a.seq_off_k, vc_r = a.seq_tab->vc[sq] + a.seq_off_v;
       }
       const int pos_c = a.pos0 + max(0, min(lrow, live_rows - 1));   // EPI_QKV: clamped position (rotary table row)
+      float yv[EPI == EPI_STORE ? NJ : 1];                           // EPI_STORE: the row's values of the wave's tiles, for the fused row statistics
       dd_static_for<0, NJ>([&](auto jc_) {
         constexpr int j = decltype(jc_)::value;
         const int nt = nt_base + j;
@@ -191,6 +192,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
         if (EPI == EPI_STORE) {
           int col = nt * 16 + c;
           if (ok && col < a.n_valid) a.out[(size_t)row * a.ldo + col] = y;
+          yv[EPI == EPI_STORE ? j : 0] = (wv[j] && col < a.n_valid) ? y : -INFINITY;
         } else if (EPI == EPI_RESID) {
           int col = nt * 16 + c;
           if (ok) a.out[(size_t)row * a.ldo + col] += y;
@@ -266,6 +268,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
           }
         }
       });
+      if constexpr (EPI == EPI_STORE && (NJ % 4) == 0) {
+        if (a.rowstat) {                                             // (uniform: every lane of the wave takes part in the shuffles)
+          dd_static_for<0, NJ / 4>([&](auto sb_) {
+            constexpr int sb = decltype(sb_)::value;
+            const float x4[4] = {yv[4 * sb], yv[4 * sb + 1], yv[4 * sb + 2], yv[4 * sb + 3]};
+            float m, sum;
+            dd_row_block_stats(x4, m, sum);
+            const int cb = (nt_base >> 2) + sb;
+            if (c == 0 && row < a.M && cb < a.rowstat_ld) {
+              a.rowstat[((size_t)row * a.rowstat_ld + cb) * 2] = m;
+              a.rowstat[((size_t)row * a.rowstat_ld + cb) * 2 + 1] = sum;
+            }
+          });
+        }
+      }
     });
   });
 }

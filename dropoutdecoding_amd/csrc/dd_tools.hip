@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(256) void k_pk_war_probe(int iters, uint32_t salt, 
           : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
           : "v"(va), "v"(vb), "v"(addr)
           : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "memory");
-    } else {
+    } else if constexpr (VARIANT == 2) {
       asm volatile(
           "ds_read_b128 v[40:43], %18\n"
           "ds_read_b128 v[44:47], %18 offset:16\n"
@@ -1711,6 +1711,1109 @@ __global__ __launch_bounds__(256) void k_pk_war_probe(int iters, uint32_t salt, 
           : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
           : "v"(va), "v"(vb), "v"(addr)
           : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "memory");
+    } else if constexpr (VARIANT == 3) {
+      asm volatile(
+          "ds_read_b128 v[40:43], %18\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:16\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:32\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:48\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:64\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:80\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:96\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:112\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:128\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:144\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:160\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:176\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:192\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:208\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:224\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:240\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:256\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:272\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:288\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:304\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:320\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:336\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:352\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:368\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:384\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:400\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:416\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:432\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:448\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:464\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:480\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "ds_read_b128 v[40:43], %18 offset:496\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+          : "v"(va), "v"(vb), "v"(addr)
+          : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "memory");
+    } else if constexpr (VARIANT == 4) {
+      asm volatile(
+          "ds_read_b128 v[40:43], %18\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:16\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:32\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:48\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:64\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:80\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:96\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:112\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:128\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:144\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:160\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:176\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:192\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:208\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:224\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:240\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:256\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:272\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:288\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:304\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:320\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:336\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:352\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:368\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:384\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:400\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:416\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:432\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:448\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:464\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:480\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[40:41], %6 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %7, %17, v[40:41], %7 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          "ds_read_b128 v[40:43], %18 offset:496\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_mov_b32 v40, v43\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[40:41], %14 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %15, %17, v[40:41], %15 op_sel_hi:[1,0,1]\n"
+          "s_nop 7\n"
+          "s_nop 7\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+          : "v"(va), "v"(vb), "v"(addr)
+          : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "memory");
+    } else {
+      asm volatile(
+          "ds_read_b128 v[40:43], %18\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:16\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:32\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:48\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:64\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:80\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:96\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:112\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:128\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:144\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:160\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:176\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:192\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:208\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:224\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:240\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:256\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:272\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:288\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:304\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:320\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:336\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:352\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:368\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:384\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:400\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:416\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:432\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:448\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:464\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:480\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %0, %16, v[40:41], %0 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %1, %17, v[40:41], %1 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %2, %16, v[40:41], %2 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %3, %17, v[40:41], %3 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %4, %16, v[42:43], %4 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %5, %17, v[42:43], %5 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %6, %16, v[42:43], %6 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %7, %17, v[42:43], %7 op_sel:[0,1,0]\n"
+          "ds_read_b128 v[40:43], %18 offset:496\n"
+          "s_waitcnt lgkmcnt(0)\n"
+          "v_pk_fma_f32 %8, %16, v[40:41], %8 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %9, %17, v[40:41], %9 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %10, %16, v[40:41], %10 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %11, %17, v[40:41], %11 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %12, %16, v[42:43], %12 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %13, %17, v[42:43], %13 op_sel_hi:[1,0,1]\n"
+          "v_pk_fma_f32 %14, %16, v[42:43], %14 op_sel:[0,1,0]\n"
+          "v_pk_fma_f32 %15, %17, v[42:43], %15 op_sel:[0,1,0]\n"
+          : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+          : "v"(va), "v"(vb), "v"(addr)
+          : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "memory");
     }
     // scalar reference: the same sums, same order per accumulator
     float ref[16][2];
@@ -1738,7 +2841,8 @@ __global__ __launch_bounds__(256) void k_pk_war_probe(int iters, uint32_t salt, 
   }
   if (bad) atomicAdd(errors + VARIANT, bad);
 }
-// errors_dev[0..2] += (lane, row) results of variant 0 / 1 / 2 that differ from the scalar sums; `launches` rounds of the three variants in turn.
+// errors_dev[0..5] += (lane, row) results of variants 0..5 (tools/gen_pk_war_probe.py: 0-2 the LDS-fed pair as src0; 3-5 hipcc's own group
+// replicated: as compiled / with sixteen wait states before the re-load / without its v_mov) that differ from the scalar sums.
 extern "C" int dd_tools_pk_war_probe(int launches, int wgs, int iters, unsigned int* errors_dev, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(launches >= 1 && wgs >= 1 && iters >= 1 && errors_dev, "dd_tools_pk_war_probe: bad arguments");
@@ -1746,7 +2850,10 @@ extern "C" int dd_tools_pk_war_probe(int launches, int wgs, int iters, unsigned 
   for (int i = 0; i < launches; ++i) {
     k_pk_war_probe<0><<<wgs, 256, 30720, st>>>(iters, salt, errors_dev);
     k_pk_war_probe<1><<<wgs, 256, 30720, st>>>(iters, salt, errors_dev);
-    k_pk_war_probe<2><<<wgs, 256, 30720, st>>>(iters, salt++, errors_dev);
+    k_pk_war_probe<2><<<wgs, 256, 30720, st>>>(iters, salt, errors_dev);
+    k_pk_war_probe<3><<<wgs, 256, 30720, st>>>(iters, salt, errors_dev);
+    k_pk_war_probe<4><<<wgs, 256, 30720, st>>>(iters, salt, errors_dev);
+    k_pk_war_probe<5><<<wgs, 256, 30720, st>>>(iters, salt++, errors_dev);
     DD_CHECK_LAUNCH();
   }
   return DD_OK;

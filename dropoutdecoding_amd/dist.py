@@ -193,7 +193,9 @@ class TensorParallelRank:
 
     def load_state_dict(self, sd, prefix: str = "") -> None:
         from . import lm
-        self.engine.load_state_dict(lm.tp_shard_state_dict(sd, self.cfg, self.rank, self.world, prefix))
+        # (the class's method, not the instance attribute: vlm.build_engine(tp=...) points engine.load_state_dict at THIS method, so that the
+        # drop-in classes can hand over the full state dict)
+        lm.DropoutEngine.load_state_dict(self.engine, lm.tp_shard_state_dict(sd, self.cfg, self.rank, self.world, prefix))
 
     def _abort_peers(self) -> None:
         """A failed exchange on this rank leaves the others blocked in their all-gather until the process-group timeout.  Two things are done

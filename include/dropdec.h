@@ -101,6 +101,11 @@ int dd_rng_create_philox(unsigned long long seed, unsigned long long offset, dd_
  *   topk_vals [L][k] fp32 / topk_ids [L][k] int32 (either may be NULL), descending, ties ->
  *   lowest id first
  *   workspace_dev: at least dd_uncertainty_workspace_bytes(L, V) bytes
+ * Softmax statistics: {max, sum exp(x - max)} per row and 64-column block, combined per row in a
+ * fixed order — inside dd_lm_prefill those block statistics come out of the lm_head GEMM's epilogue
+ * (the softmax reduction fused into the unembedding product: the [L][V] logits are then read twice,
+ * for the column mean and for epi / alea / var + top-k); this stand-alone entry point computes them
+ * from the stored logits with the same arithmetic, so both give the same bits.
  * ------------------------------------------------------------------------------------------ */
 size_t dd_uncertainty_workspace_bytes(int L, int V);
 int dd_vision_uncertainty(const float* logits_dev, int L, int V, int ld,

@@ -23,7 +23,7 @@ from dropoutdecoding_amd import _lib
 
 
 def pk_war(rounds, lib, beside, rows=64):
-    err = torch.zeros(4, dtype=torch.int32, device="cuda")
+    err = torch.zeros(8, dtype=torch.int32, device="cuda")
     st = torch.cuda.Stream()
     torch.cuda.synchronize()
     t0 = time.time()
@@ -43,7 +43,9 @@ def pk_war(rounds, lib, beside, rows=64):
         body()
     e = err.tolist()
     return {"test": "pk_fma_war_probe", "beside_gemvs_of_rows": rows if beside else 0, "results_checked_per_variant": rounds * 16 * 3072 * 256 * 16 * 2,
-            "wrong_v0_reload_behind_packed_ops": e[0], "wrong_v1_sixteen_wait_states": e[1], "wrong_v2_distinct_registers": e[2], "seconds": round(time.time() - t0, 1)}
+            "wrong_v0_reload_behind_packed_ops": e[0], "wrong_v1_sixteen_wait_states": e[1], "wrong_v2_distinct_registers": e[2],
+            "wrong_v3_compilers_group": e[3], "wrong_v4_compilers_group_sixteen_wait_states": e[4], "wrong_v5_compilers_group_without_v_mov": e[5],
+            "seconds": round(time.time() - t0, 1)}
 
 
 def main():
