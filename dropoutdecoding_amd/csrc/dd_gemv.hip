@@ -901,34 +901,21 @@ static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   return DD_OK;
 }
 // (16 instead of 8 weight requests in flight per wave measured the same or slower: qkv 26.3 vs 25.4 us, gate/up 38.4 vs 38.0)
-// dd_tools_set_tuning key 49: progressive stage-in of the operand planes (dd_gemv_slices.h PROG): 1 (default) = where it was measured to pay (the
-// whole-slice kernels at two and four planes), 0 = never (the blocking stage-in of rounds 2-4), 2 = also the slice-pair kernels.  Same bits always.
+// dd_tools_set_tuning key 49: progressive stage-in of the operand planes (dd_gemv_slices.h PROG) in the whole-slice kernels at two and four planes
+// (default 1; 0 = the blocking stage-in of rounds 2-4).  Same bits either way.
 int g_seq_prog = 1;
 template <int NG, int U, int MAXG, int TAG>
 static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)16 * NG * 1024;
-  // (nine planes with eight requests in flight and two tiles per wave: the progressive form needs 257+ registers — it keeps the blocking stage-in)
-  // ... and the slice-pair kernels, which exist for eight and nine planes only, keep the blocking stage-in (tools key 49 = 2 forces the progressive
-  // form where it fits, for the A/B)
-  constexpr int PROG_FITS = (NG == 9 && U == 8 && MAXG >= 2) ? 0 : 1;
-  constexpr int PROG_OK = PROG_FITS;
   static bool attr = false;
   if (!attr) {
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  const int prog = g_seq_prog == 2 && PROG_OK;
-  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG, prog);
-  if (prog) {
-    if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, PROG_OK><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-    else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, PROG_OK><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-  } else {
-    if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG, 0><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-    else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, 0><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-  }
+  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG);
+  if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 
@@ -1203,6 +1190,9 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
       // VGPRs, so that the rider sweeps' attention (94) fits beside this kernel too
       sa.G = (nt + 15) / 16;
       RC_(launch_slices_seq<9, 4, 2, EPI_SILU>(sa, a.wf, st));
+    } else if (g_exp_U9 == 8) {
+      // (tuning key 29 = 8) eight weight requests in flight per wave: possible since the folded sums of two tiles share a register set (round 5)
+      RC_(launch_slices_seq<9, 8, 3, EPI_SILU>(sa, a.wf, st));
     } else
     RC_(launch_slices_seq<9, 4, 3, EPI_SILU>(sa, a.wf, st));
     launch_finish<EPI_SILU, 2, 9, 4>(a, a.n_tiles, st);

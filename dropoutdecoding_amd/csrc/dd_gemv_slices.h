@@ -356,20 +356,25 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
 // partial sum per pair — half the partial-sum traffic of single slices (gate/up at 64 rows: 22.5 instead of 45 MB written and
 // read back) for a second operand load per workgroup.  Same chains, same order: (hi+lo)(2p) + (hi+lo)(2p+1) as the pair kernels.
 // grid = 4 * G workgroups of 512 threads; dynamic LDS = SPW * NG KiB; a.part laid out for NP = 4.
-// PROG = 1 (round 5): PROGRESSIVE stage-in.  The blocking form stages a whole slice of all planes (144 KiB at nine planes: ~3 us at the ~50 GB/s
-// a CU takes from L2) before its waves stream a single weight tile, twice per workgroup, and the HBM stream waits meanwhile with only the ring's
-// first requests in flight.  Here only the first U steps' pieces are staged up front; while the wave's FIRST tile consumes block b of the slice,
-// the pieces of block b + 1 are requested into registers (ahead of the ring's re-requests, so they return first) and committed to LDS behind the
-// block, one barrier per block; later tiles find the whole slice resident.  The second slice's first block is requested before the barrier that
-// ends the first slice.  Same chains, same order of every sum: the same bits.
-template <int NG, int U, int SPW, int MAXG, int WF = 0, int EPI_TAG = 0, int PROG = 0>
-__global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
+// Round 5: the folded sums of TWO tiles share one register set.  After the fold (hi + lo column of a row: lanes c and c + 8 of a 16-lane group)
+// only half the lanes of an accumulator carry a result, so the sum of tile 2 s sits in the lanes with bit 3 clear and that of tile 2 s + 1 in the
+// lanes with bit 3 set (v + shfl_xor(v, 8) gives hi + lo in the one half and lo + hi — the same bits — in the other): (MAXG + 1) / 2 sets instead
+// of MAXG, 36 registers fewer at nine planes and two or three tiles per wave.  With that the nine-plane gate/up kernel fits on a SIMD beside the
+// rider sweeps' attention workgroups and has room for eight weight requests in flight.
+// (A progressive stage-in of the operand planes was built and measured here in round 5 and removed again: at eight and nine planes the per-block
+// barriers of the first tile cost more than the staging they hide — 64-lane step 36.4 -> 37.7 ms, profiles/r05_progressive_stage_in.log; the
+// whole-slice kernels above keep it for two and four planes, where it pays.)
+// (amdgpu_waves_per_eu(1, 2): the LDS admits one workgroup per CU = two waves per SIMD; without the hint the compiler aims the two-tile forms at
+// three waves and spills three registers to private scratch to get under 168 — which build.py refuses)
+template <int NG, int U, int SPW, int MAXG, int WF = 0, int EPI_TAG = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_gemv_slices_seq(SliceArgs a) {
   static_assert(SPW % U == 0, "ring depth must divide the slice");
   constexpr int PW = (SPW * NG + 7) / 8;               // operand pieces (1 KiB) per wave and slice
   constexpr int NB = SPW / U;
-  constexpr int PWC = (U * NG + 7) / 8;                // ... per wave and block of U steps (progressive stage-in)
+  constexpr int NSET = (MAXG + 1) / 2;                 // register sets of folded sums: two tiles each
   extern __shared__ __align__(16) u32x4_t xs[];        // [SPW][NG][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool hi_half = (lane & 8) != 0;
   const int qs = blockIdx.x & 3, j = blockIdx.x >> 2;
   const size_t xplane = (size_t)a.S * 64;
   const int n_tiles = a.n_groups;
@@ -401,14 +406,18 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
       if (p < SPW * NG) xs[(size_t)p * 64 + lane] = xv[i];
     }
   };
-  auto fold = [&](f32x4_t v) -> f32x4_t {
-    v.x += __shfl_down(v.x, 8);
-    v.y += __shfl_down(v.y, 8);
-    v.z += __shfl_down(v.z, 8);
-    v.w += __shfl_down(v.w, 8);
+  auto fold2 = [&](f32x4_t v) -> f32x4_t {             // hi + lo column of a row, in BOTH lanes of the pair (a + b and b + a: the same bits)
+    v.x += __shfl_xor(v.x, 8);
+    v.y += __shfl_xor(v.y, 8);
+    v.z += __shfl_xor(v.z, 8);
+    v.w += __shfl_xor(v.w, 8);
     return v;
   };
-  f32x4_t sum[MAXG][NG];
+  f32x4_t sum[NSET][NG];
+#pragma unroll
+  for (int s_ = 0; s_ < NSET; ++s_)
+#pragma unroll
+    for (int h = 0; h < NG; ++h) sum[s_][h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // the ring runs over the wave's items (slice half, group) in order; the next item's first U tiles are requested while the
   // current item's last block is consumed — also across the operand swap
   u32x4_t w[U];
@@ -418,90 +427,6 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
     for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, p0 + (size_t)u * wstep);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (PROG) {
-    u32x4_t xv[PWC];
-    auto issue_blk = [&](int half, int b) {            // pieces of steps b U .. b U + U - 1 of slice 2 qs + half -> registers
-#pragma unroll
-      for (int i = 0; i < PWC; ++i) {
-        const int p = wave + 8 * i, pc = p < U * NG ? p : 0;
-        xv[i] = a.xop[(size_t)(2 * qs + half + 8 * (b * U + pc / NG)) * 64 + (pc % NG) * xplane + lane];
-      }
-    };
-    auto commit_blk = [&](int b) {
-#pragma unroll
-      for (int i = 0; i < PWC; ++i) {
-        const int p = wave + 8 * i;
-        if (p < U * NG) xs[(size_t)(b * U * NG + p) * 64 + lane] = xv[i];
-      }
-    };
-    if (!(a.temporal & 2)) {
-      issue_blk(0, 0);
-      commit_blk(0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int gi = 0; gi < MAXG; ++gi) {
-        const int item = half * MAXG + gi;
-        const bool live = gi < ng;                     // wave-uniform
-        const bool last_item = item == 2 * MAXG - 1;
-        const u32x4_t* wp = wptr(item);
-        const u32x4_t* wn = wptr(last_item ? item : item + 1);
-        f32x4_t acc[NG];
-#pragma unroll
-        for (int h = 0; h < NG; ++h) acc[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-          const bool stage_next = gi == 0 && blk + 1 < NB;       // compile-time after unrolling
-          if (stage_next && !(a.temporal & 2)) issue_blk(half, blk + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (live) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int s = blk * U + u;
-              u32x4_t b[NG];
-#pragma unroll
-              for (int h = 0; h < NG; ++h) b[h] = xs[(size_t)(s * NG + h) * 64 + lane];
-#pragma unroll
-              for (int h = 0; h < NG; ++h) acc[h] = dd_mfma16<WF>(w[u], b[h], acc[h]);
-              if (blk + 1 < NB) w[u] = dd_ldw(a.temporal, wp + (size_t)(s + U) * wstep);
-              else if (!last_item) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          } else if (blk + 1 == NB && !last_item) {    // a slot this wave does not have: hand the ring to the next item
-#pragma unroll
-            for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
-          }
-          if (stage_next) {
-            if (!(a.temporal & 2)) commit_blk(blk + 1);
-            __syncthreads();                           // block blk + 1 of the slice is resident (written where nothing has been read yet)
-          }
-        }
-        if (live) {
-#pragma unroll
-          for (int h = 0; h < NG; ++h) {
-            f32x4_t f = fold(acc[h]);
-            if (half == 0) sum[gi][h] = f;
-            else sum[gi][h] = sum[gi][h] + f;          // (hi+lo)(2p) + (hi+lo)(2p+1)
-          }
-          if (half == 1 && (lane & 8) == 0) {
-            const int l32 = (lane >> 4) * 8 + (lane & 7);
-#pragma unroll
-            for (int h = 0; h < NG; ++h)
-              *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + gidx[gi]) * NG + h) << 7) + l32 * 4] = sum[gi][h];
-          }
-        }
-      }
-      if (half == 0) {
-        if (!(a.temporal & 2)) issue_blk(1, 0);        // in flight while the slower waves finish slice 2 qs
-        __syncthreads();                               // every wave has finished reading slice 2 qs
-        if (!(a.temporal & 2)) commit_blk(0);
-        __syncthreads();
-      }
-    }
-    return;
-  }
   if (!(a.temporal & 2)) stage(0);
   __syncthreads();
 #pragma unroll
@@ -513,10 +438,10 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
       const bool last_item = item == 2 * MAXG - 1;
       const u32x4_t* wp = wptr(item);
       const u32x4_t* wn = wptr(last_item ? item : item + 1);
-      f32x4_t acc[NG];
-#pragma unroll
-      for (int h = 0; h < NG; ++h) acc[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       if (live) {
+        f32x4_t acc[NG];
+#pragma unroll
+        for (int h = 0; h < NG; ++h) acc[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
@@ -532,21 +457,27 @@ __global__ __launch_bounds__(512) void k_gemv_slices_seq(SliceArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        const bool mine = ((gi & 1) != 0) == hi_half;  // this half of the lanes keeps tile gi's sum
 #pragma unroll
         for (int h = 0; h < NG; ++h) {
-          f32x4_t f = fold(acc[h]);
-          if (half == 0) sum[gi][h] = f;
-          else sum[gi][h] = sum[gi][h] + f;            // (hi+lo)(2p) + (hi+lo)(2p+1)
-        }
-        if (half == 1 && (lane & 8) == 0) {
-          const int l32 = (lane >> 4) * 8 + (lane & 7);
-#pragma unroll
-          for (int h = 0; h < NG; ++h)
-            *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + gidx[gi]) * NG + h) << 7) + l32 * 4] = sum[gi][h];
+          const f32x4_t f = fold2(acc[h]);
+          f32x4_t& d = sum[gi >> 1][h];
+          const f32x4_t nv = half == 0 ? f : d + f;    // (hi+lo)(2p) + (hi+lo)(2p+1)
+          d.x = mine ? nv.x : d.x, d.y = mine ? nv.y : d.y, d.z = mine ? nv.z : d.z, d.w = mine ? nv.w : d.w;
         }
       } else if (!last_item) {                         // a slot this wave does not have: hand the ring to the next item
 #pragma unroll
         for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
+      }
+      if (half == 1 && ((gi & 1) || gi == MAXG - 1)) { // the set's two tiles are complete: each half of the lanes stores its tile
+        const int st = gi >> 1;
+        const int my_gi = 2 * st + (hi_half ? 1 : 0);
+        const int my_g = j + a.G * (wave + 8 * my_gi);  // = gidx[my_gi], as arithmetic (a lane-dependent index into gidx[] would put it in scratch)
+        if (my_gi < MAXG && my_gi < ng) {
+          const int l32 = (lane >> 4) * 8 + (lane & 7);
+#pragma unroll
+          for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + my_g) * NG + h) << 7) + l32 * 4] = sum[st][h];
+        }
       }
     }
     if (half == 0) {
