@@ -534,7 +534,8 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
       (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_SILU || epi == EPI_QKV || ((epi == EPI_ACT || epi == EPI_QKV_VIT) && !a.wf)))
     return launch_gemm_big(epi, a, st);
   long big = (long)((a.n_tiles + 7) / 8) * ((a.M + 127) / 128);      // workgroups of the 128x128 tiling
-  if (big >= 150) return launch_gemm<4, 4>(epi, a, st);
+  // (a.rowstat: the fused row statistics need a wave that owns whole 64-column blocks — the 4 x 4 and 4 x 8 tilings)
+  if (big >= 150 || (epi == EPI_STORE && a.rowstat)) return launch_gemm<4, 4>(epi, a, st);
   return launch_gemm<2, 2>(epi, a, st);                              // 64x64 blocks: 4x the workgroups
 }
 
