@@ -287,7 +287,10 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
     in_step = by / (prof["stats_avg_us"] * 1e-6) / 1e9 if prof["stats_avg_us"] else None
     return {"bound": "hbm", "kernel": what, "kernel_name": kernel, "achieved": round(in_step if in_step else achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round((in_step if in_step else achieved) / HBM_PEAK_GBS, 4),
-            "frac_source": ("in-step average duration from " + str(prof["stats_file"]) if in_step else "isolated launches (no committed kernel trace names this kernel)"),
+            "frac_source": ("in-step average duration from " + str(prof["stats_file"]) + " (inside the step the kernel shares its CUs with the other branches' "
+                            "attention and finishing workgroups — since round 5 every one of them fits beside it —, so its own duration is longer than alone "
+                            "while the step is shorter: group_step.frac_at_value is the step-level figure)" if in_step
+                            else "isolated launches (no committed kernel trace names this kernel)"),
             "achieved_isolated": round(achieved, 1), "frac_isolated": round(achieved / HBM_PEAK_GBS, 4),
             "finishing_share": finishing_share(prof["stats_file"]) if prof["stats_file"] and dom_rows == 72 else None,
             "traffic": prof["traffic"],

@@ -797,7 +797,9 @@ struct MaskConst {
   const float* q;       // [K] f32(1 - mprob), in LDS
 };
 // One wave samples all K members of one sequence.  Dynamic LDS (smem, Lp = L rounded up to a power of two >= 64):
-//   e[Lp] f32 | u[Lp] f32 (the current member's uniforms, or the sort buffer) | running[Lp] u8 | keep[Lp] u8 | mt[632] u32
+//   e[Lp] f32 | u[Lp] f32 (the current member's uniforms, or the sort buffer) | running[Lp] u8 | keep[Lp] u8 | bits[Lp] u8 | mt[632] u32
+// (bits: the bit plane of the current eight members, built in LDS and stored once per plane — a global read-modify-write per member and position
+// costs a memory round trip per 64 positions when there is one wave to hide it: 49 -> @@ us per launch at L = 576, K = 8)
 // keep_lds: the keep flags are already in LDS (the lanes kernel computes them there); else they are copied from P.keep (null: empty set).
 __device__ __forceinline__ size_t sampler_lp(int L) {
   int Lp = 64;
@@ -811,12 +813,14 @@ __device__ __forceinline__ void sample_masks_wave(const MaskConst C, const MaskS
   float* u = e + Lp;                                // [Lp]
   uint8_t* running = (uint8_t*)(u + Lp);            // [Lp]
   uint8_t* keep = running + Lp;                     // [Lp]
-  uint32_t* mt = (uint32_t*)(keep + Lp);            // [MT_N + 8]
+  uint8_t* bits = keep + Lp;                        // [Lp]
+  uint32_t* mt = (uint32_t*)(bits + Lp);            // [MT_N + 8]
   const bool no_overlap = C.mode == DD_MASK_NEXT_NO_OVERLAP || C.mode == DD_MASK_LLAVA_CUMULATIVE_NO_OVERLAP;
 
   for (int l = lane; l < L; l += 64) {
     e[l] = P.epi[l];
     running[l] = 0;
+    bits[l] = 0;
     if (!keep_lds) keep[l] = (P.keep && !no_overlap) ? P.keep[l] : (uint8_t)0;
   }
   int idx = 0;
@@ -899,9 +903,9 @@ __device__ __forceinline__ void sample_masks_wave(const MaskConst C, const MaskS
         P.drop[(size_t)k * L + l] = run;
         dropped = run != 0;
         if (P.drop_bits) {
-          uint8_t* bp = P.drop_bits + (size_t)(k >> 3) * L + l;
-          const uint8_t cur = (k & 7) ? *bp : 0;                     // (this lane wrote it for member k - 1)
-          *bp = cur | (uint8_t)((run ? 1 : 0) << (k & 7));
+          const uint8_t nb = (uint8_t)(((k & 7) ? bits[l] : 0) | ((run ? 1 : 0) << (k & 7)));   // (this lane wrote bits[l] for member k - 1)
+          bits[l] = nb;
+          if ((k & 7) == 7 || k == C.K - 1) P.drop_bits[(size_t)(k >> 3) * L + l] = nb;         // the plane is complete
         }
       }
       const unsigned long long b = __ballot(dropped);
@@ -921,7 +925,7 @@ __device__ __forceinline__ void sample_masks_wave(const MaskConst C, const MaskS
 static size_t sampler_wave_smem(int L) {
   size_t Lp = 64;
   while (Lp < (size_t)L) Lp <<= 1;
-  return Lp * 10 + (MT_N + 8) * 4;
+  return Lp * 11 + (MT_N + 8) * 4;
 }
 
 __global__ __launch_bounds__(64) void k_sample_masks(MaskParams P) {

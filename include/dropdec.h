@@ -36,8 +36,9 @@ extern "C" {
 #define DD_ESTATE (-4)     /* call sequence error (e.g. decode before prefill) */
 
 #define DD_MAX_MEMBERS_PER_PASS 8   /* ensemble members packed into one weight sweep */
-#define DD_MAX_MEMBERS 16           /* K = len(settings['voting_numbers']) per decode step: 1..16 (two packed sweeps); the
-                                     * reference accepts any list length (models/llava.py:340) but ships 3 and 4, BASELINE uses 8 */
+#define DD_MAX_MEMBERS 64           /* K = len(settings['voting_numbers']) per decode step: 1..64 (ceil(K / 8) packed sweeps; the mask
+                                     * sampler's per-member table and the per-layer rows of new K / V hold 64); the reference accepts any
+                                     * list length (models/llava.py:340) but ships 3 and 4, BASELINE uses 8 */
 #define DD_MAX_TOPK 16
 
 /* mask-sampler modes: which family's get_image_attention_mask() semantics to follow */

@@ -222,6 +222,13 @@ def test_two_packed_sweeps_K12(E):
     _rand_case(E, FAMILY_LLAVA, rc, 40, 3, 30, [0.1 + 0.05 * i for i in range(12)], 6)
 
 
+def test_three_packed_sweeps_K20(E):
+    """K up to DD_MAX_MEMBERS = 64 (round 5; models/llava.py:340 takes any list): 20 members = three packed sweeps (8 + 8 + 4), three bit planes of
+    drop flags, cumulative masks across all 20 — tokens, masks, votes against the oracle."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    _rand_case(E, FAMILY_LLAVA, rc, 40, 3, 30, [0.1 + 0.035 * i for i in range(20)], 5)
+
+
 def test_gqa_group4_long_context_many_key_tiles(E):
     """Mistral-style GQA (8 q heads / 2 kv heads), theta 1e6, 300-token prefix: 5 key tiles per kv head, visual span
     crossing tile boundaries."""
