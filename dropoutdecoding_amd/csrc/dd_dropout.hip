@@ -579,23 +579,31 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
   } while (0)
 
-// Regenerate the 624 words held in LDS, one wave, 64 words at a time in index order: new[i] = f(cur[i], cur[i+1], cur[i+397 mod 624]) reads
-// words the sequential recurrence has not reached yet (i+1: same chunk, read before the chunk's writes; i+397 < 624: a later chunk) or has
-// already replaced (i+397-624 = i-227 and, for i = 623, word 0: earlier chunks) — the sequential algorithm's values exactly.
+// Regenerate the 624 words held in LDS, one wave, in index order: new[i] = f(cur[i], cur[i+1], cur[i+397 mod 624]) reads words the sequential
+// recurrence has not reached yet (i+1: read before this round's writes; i+397 < 624: a later chunk) or has already replaced (i+397-624 = i-227
+// and, for i = 623, word 0: earlier rounds) — the sequential algorithm's values exactly.
+// Three chunks (192 words) per round: a chunk's inputs are old words of its own and later chunks, and new words at least 227 - 63 = 164 places back,
+// i.e. of chunks at least two before it — so chunks c, c + 1, c + 2 read everything first and then write, four dependent rounds instead of ten.
 __device__ __forceinline__ void mt_twist_wave(uint32_t* mt) {
   const int lane = threadIdx.x;
 #pragma unroll 1
-  for (int b = 0; b < MT_N; b += 64) {
-    const int i = b + lane;
-    const bool act = i < MT_N;
-    uint32_t nv = 0;
-    if (act) nv = mt_mix(mt[i], mt[i + 1 == MT_N ? 0 : i + 1], mt[i + MT_M >= MT_N ? i + MT_M - MT_N : i + MT_M]);
+  for (int b0 = 0; b0 < MT_N; b0 += 192) {
+    uint32_t nv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = b0 + 64 * j + lane;
+      nv[j] = 0;
+      if (i < MT_N) nv[j] = mt_mix(mt[i], mt[i + 1 == MT_N ? 0 : i + 1], mt[i + MT_M >= MT_N ? i + MT_M - MT_N : i + MT_M]);
+    }
     DD_WSYNC();
-    if (act) mt[i] = nv;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = b0 + 64 * j + lane;
+      if (i < MT_N) mt[i] = nv[j];
+    }
     DD_WSYNC();
   }
 }
-
 __device__ __forceinline__ float mt_temper_uniform(uint32_t y) {
   y ^= y >> 11;
   y ^= (y << 7) & 0x9d2c5680u;
@@ -883,34 +891,41 @@ __device__ __forceinline__ void sample_masks_wave(const MaskConst C, const MaskS
     const float scale = C.scale[k];
     const float range = __fsub_rn(hi, lo);
     int cnt = 0;
-    for (int base = 0; base < L; base += 64) {
-      const int l = base + lane;
-      bool dropped = false;
-      if (l < L) {
-        bool d;
-        if (C.mode == DD_MASK_IBLIP_QUANTILE) {
-          d = e[l] >= thr;  // instructblip.py:453
-        } else {
-          const float r = (C.rng_mode == DD_RNG_MT19937) ? u[l] : P.uniforms[(size_t)k * L + l];
-          // p = 0.1 + (mprob-0.1)*(clamp(e,lo,hi)-lo)/(hi-lo), every step rounded to fp32 (llava.py:646-647)
-          const float c = fminf(fmaxf(e[l], lo), hi);
-          const float p = __fadd_rn(0.1f, __fdiv_rn(__fmul_rn(scale, __fsub_rn(c, lo)), range));
-          d = r < p;  // llava.py:653 (NaN p when hi == lo: nothing dropped)
-        }
-        uint8_t run = running[l] | (d ? 1 : 0);                      // llava.py:654-657, in place
-        if (keep[l]) run = 0;                                        // llava.py:660 keep-restore (no-overlap modes / an empty set: keep[] is zero)
-        running[l] = run;
-        P.drop[(size_t)k * L + l] = run;
-        dropped = run != 0;
-        if (P.drop_bits) {
-          const uint8_t nb = (uint8_t)(((k & 7) ? bits[l] : 0) | ((run ? 1 : 0) << (k & 7)));   // (this lane wrote bits[l] for member k - 1)
-          bits[l] = nb;
-          if ((k & 7) == 7 || k == C.K - 1) P.drop_bits[(size_t)(k >> 3) * L + l] = nb;         // the plane is complete
+    for (int base = 0; base < L; base += 256) {       // four positions per lane and round: their LDS reads and divisions overlap
+      bool dropped[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int l = base + 64 * j + lane;
+        dropped[j] = false;
+        if (l < L) {
+          bool d;
+          if (C.mode == DD_MASK_IBLIP_QUANTILE) {
+            d = e[l] >= thr;  // instructblip.py:453
+          } else {
+            const float r = (C.rng_mode == DD_RNG_MT19937) ? u[l] : P.uniforms[(size_t)k * L + l];
+            // p = 0.1 + (mprob-0.1)*(clamp(e,lo,hi)-lo)/(hi-lo), every step rounded to fp32 (llava.py:646-647)
+            const float c = fminf(fmaxf(e[l], lo), hi);
+            const float p = __fadd_rn(0.1f, __fdiv_rn(__fmul_rn(scale, __fsub_rn(c, lo)), range));
+            d = r < p;  // llava.py:653 (NaN p when hi == lo: nothing dropped)
+          }
+          uint8_t run = running[l] | (d ? 1 : 0);                      // llava.py:654-657, in place
+          if (keep[l]) run = 0;                                        // llava.py:660 keep-restore (no-overlap modes / an empty set: keep[] is zero)
+          running[l] = run;
+          P.drop[(size_t)k * L + l] = run;
+          dropped[j] = run != 0;
+          if (P.drop_bits) {
+            const uint8_t nb = (uint8_t)(((k & 7) ? bits[l] : 0) | ((run ? 1 : 0) << (k & 7)));   // (this lane wrote bits[l] for member k - 1)
+            bits[l] = nb;
+            if ((k & 7) == 7 || k == C.K - 1) P.drop_bits[(size_t)(k >> 3) * L + l] = nb;         // the plane is complete
+          }
         }
       }
-      const unsigned long long b = __ballot(dropped);
-      if (P.idx && dropped) P.idx[(size_t)k * L + cnt + __popcll(b & ((1ull << lane) - 1ull))] = l;
-      cnt += __popcll(b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                    // positions in order: round, then lane
+        const unsigned long long b = __ballot(dropped[j]);
+        if (P.idx && dropped[j]) P.idx[(size_t)k * L + cnt + __popcll(b & ((1ull << lane) - 1ull))] = base + 64 * j + lane;
+        cnt += __popcll(b);
+      }
     }
     if (P.idx)
       for (int l = cnt + lane; l < L; l += 64) P.idx[(size_t)k * L + l] = -1;

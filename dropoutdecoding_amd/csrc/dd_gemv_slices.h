@@ -47,7 +47,7 @@ struct SliceArgs {
   int temporal;
 };
 // (temporal bit 1, value 2: TIMING EXPERIMENT of the tools library — the kernels skip the operand planes' staging and compute on whatever the LDS
-// holds; how much of a launch the blocking stage-in costs.  Never set by the product.)
+// holds; how much of a launch the blocking stage-in costs.  Bit 2, value 4: the slice-pair kernels write no partial sums.  Never set by the product.)
 __device__ __forceinline__ u32x4_t dd_ldw(int temporal, const u32x4_t* p) { return (temporal & 1) ? *p : __builtin_nontemporal_load(p); }
 
 // rstd(row) = 1 / sqrt(mean(x^2) + eps) from per-workgroup partial sums of squares; wave w of the calling workgroup
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int st = gi >> 1;
         const int my_gi = 2 * st + (hi_half ? 1 : 0);
         const int my_g = j + a.G * (wave + 8 * my_gi);  // = gidx[my_gi], as arithmetic (a lane-dependent index into gidx[] would put it in scratch)
-        if (my_gi < MAXG && my_gi < ng) {
+        if (my_gi < MAXG && my_gi < ng && !(a.temporal & 4)) {      // (temporal bit 2: timing experiment — no partial sums written)
           const int l32 = (lane >> 4) * 8 + (lane & 7);
 #pragma unroll
           for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + my_g) * NG + h) << 7) + l32 * 4] = sum[st][h];
