@@ -43,13 +43,16 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * qkv / gate-up kernels (4 or 8, default 4), 30 half planes for K <= 4 (two sequences per operand plane, default 1), 31 half planes
  * before the rider form where both apply and the line-up is not whole groups of fourteen (default 1), 33 the rider form's rings in stages with
  * the masks of the groups whose rows rode sampled between the stages on the caller's stream (default 1; 0: on the branches), 34 the lanes
- * mask sampler in its round-3 form (a private-scratch copy of its parameters, 616 bytes per lane; default 0).
+ * mask sampler in one of the 1,024-thread forms this library keeps (csrc/dd_sampler_block.h; default 0 = the product's one-wave kernel; 1 = round 3's
+ * form with a private-scratch copy of its parameters, 616 bytes per lane; 2 = the checking form, dd_tools_sampler_dbg_attach; 3 = round 4's kernel).
  * Round 4: 36 default-policy instead of non-temporal weight loads in the slice GEMVs (default 0), 38 the GQA decode attention with all q heads
  * of a kv head in one workgroup (default 0: two heads per workgroup), 45 prefill RMSNorm + split with sixteen rows per workgroup (default 1;
  * 0: one row per workgroup), 46 prefill attention over the fp16 cache with operand-staged K / V tiles and 1 or 2 query blocks per wave
  * (default 1; 0: the fp32-staged kernel), 47 the MHA rider sweeps' attention tile pass with two register sets (the round-3 form, 144 VGPRs;
- * default 0: one set, 94 VGPRs, so that it shares CUs with the other branches' slice GEMVs), 48 the mask samplers' LDS request padded to 156 KiB so that
- * they run alone on their CU (default 1; 0: the 76 KiB they use — the unit reproducer of DESIGN.md 3e needs that).  Keys of the determinism bisect (all default to the product's behaviour): 37 fp32-cache
+ * default 0: one set, 94 VGPRs, so that it shares CUs with the other branches' slice GEMVs), 48 the dynamic-LDS request of the 1,024-thread sampler forms (key 34 > 0): 1 = 156 KiB, round 4's
+ * fence (default); 0 = the 76 KiB they use — the unit reproducer of DESIGN.md 3e needs that; n = n KiB (round 5's request sweep).  Round 5: 49 the
+ * progressive stage-in of the operand planes in the whole-slice GEMV kernels at two and four planes (default 1; 0: blocking, as in rounds 2-4); 36
+ * also takes timing-only bits: 2 = the slice kernels skip the stage-in, 4 = the slice-pair kernels write no partial sums (results garbage).  Keys of the determinism bisect (all default to the product's behaviour): 37 fp32-cache
  * engines fork their member sweeps (-1: one branch as in round 3), 39 extra dynamic LDS bytes requested by the fp32-cache attention tile pass
  * (so that it cannot share a CU with a slice GEMV), 40 the branches' streams on disjoint CU masks, 41 CU-mask only the attention launches,
  * 42 bit mask of kernel families launched on the UNMASKED stream while 40 is on (1 embed, 2 GEMVs, 4 attention, 8 finishing kernels),

@@ -1,17 +1,20 @@
-"""Unit-level reproducer attempts for the round-3 run-to-run token difference (DESIGN.md "Determinism").
+"""Unit-level reproducers and probes of the two co-residency faults.
 
-  sampler(scratch, beside, rounds):  the group step's mask sampler (k_sample_masks_lanes: 8 sequences, L = 576, K = 8, one 1,024-thread
-      workgroup per sequence, each drawing from its own mt19937 stream) launched back to back on its own stream — alone, or BESIDE 72-row
-      slice-resident GEMVs (gate/up and qkv of LLaVA-1.5-7B) looping on two other streams, the company it had on a rider branch — and every
-      launch's masks compared with the oracle sampler over the host mt19937.  scratch=True: the round-3 form of the kernel (616 bytes of
-      private scratch per lane; libdropdec_tools.so only).
-  probe(beside, rounds):  a kernel of the same shape that only writes a pattern into 616 bytes of private scratch per lane, lingers and
-      verifies it.
-  sampler_streams(n_streams, rounds, lib, company_lanes):  THE reproducer of the round-3 event (found at the end of round 4): the sampler from
-      one or more streams beside a group of `company_lanes` sequences taking rider steps (StepCompany) — wrong masks about once in 50,000
-      launches with the un-padded kernel (tools key 48 = 0), none with the padded one.  Each StepCompany builds 32 engines on a host thread;
-      the fourth one in a process once failed to come back — run a few legs per process.
-  twist_probe(rounds, lib, company_lanes):  only the sampler's mt19937 regeneration, checked inside the kernel (dd_tools_twist_probe).
+  sampler(form, beside, rounds):  the group step's mask sampler (8 sequences, L = 576, K = 8, each drawing from its own mt19937 stream) launched
+      back to back on its own stream — alone, or BESIDE 72-row slice-resident GEMVs (gate/up and qkv of LLaVA-1.5-7B) looping on two other streams
+      — and every launch's masks compared with the oracle sampler over the host mt19937.  form: "wave" = the product's one-wave kernel (round 5),
+      "block" / False = round 4's 1,024-thread kernel, "scratch" / True = round 3's (616 bytes of private scratch per lane); the block forms live
+      in libdropdec_tools.so only (csrc/dd_sampler_block.h).
+  sampler_streams(n_streams, rounds, lib, company_lanes, ...):  THE reproducer of the sampler fault: the sampler from one or more (high-priority)
+      streams beside a group of `company_lanes` sequences taking rider steps (StepCompany) — wrong masks about once in 50,000 launches with the
+      1,024-thread forms requesting the LDS they use (lds_kib = 0), none with the one-wave form.  n_seq / lds_kib / company_mode / dbg: round 5's
+      experiments (workgroups per launch, the LDS request sweep, the company cut down, the checking form that dumps the wrong words;
+      tools/r05_sampler_fault.py runs them one process per leg: a process that builds several StepCompanies once hung).
+  analyse_dump(d, ...):  where the wrong words of a dump come from (which stream, which generation, zeros, the launch-start state, elsewhere in LDS).
+  twist_probe / barrier_probe:  only the regeneration sweeps / only store - barrier - read-the-other-waves - barrier, in workgroups of the block
+      sampler's shape, beside the same company: both clean.
+  probe / lds_probe / lds_full_probe / hold_probe / pk_probe:  round 4's probes (private scratch, LDS exchange, LDS isolation, registers and loads in
+      flight, packed FP32 chains and the P.V step).
 
     python tools/sampler_repro.py [rounds]      # prints one JSON line per configuration
 """
