@@ -131,5 +131,9 @@ def test_one_wave_sampler_is_clean_where_the_block_form_fails():
     print(f"\n[sampler beside rider steps] 1,024-thread form, 76 KiB request: {block['sequences_with_a_wrong_launch']} wrong in {block['sampler_launches']} "
           f"launches of 8 workgroups ({block['company_rider_steps']} rider steps beside); one-wave form: {wave['sequences_with_a_wrong_launch']} wrong in "
           f"{wave['sampler_launches']} launches ({wave['company_rider_steps']} rider steps beside)")
+    import warnings
+    warnings.warn(UserWarning(    # (so that a `pytest -q` log carries the counts: warnings are summarised at the end of the run)
+        f"sampler beside rider steps: 1,024-thread form un-fenced {block['sequences_with_a_wrong_launch']} wrong in {block['sampler_launches']} launches; "
+        f"one-wave form {wave['sequences_with_a_wrong_launch']} wrong in {wave['sampler_launches']} launches"))
     assert wave["company_rider_steps"] > 100 and wave["sampler_launches"] > 20000, wave
     assert wave["sequences_with_a_wrong_launch"] == 0, wave
