@@ -806,8 +806,8 @@ struct MaskConst {
 };
 // One wave samples all K members of one sequence.  Dynamic LDS (smem, Lp = L rounded up to a power of two >= 64):
 //   e[Lp] f32 | u[Lp] f32 (the current member's uniforms, or the sort buffer) | running[Lp] u8 | keep[Lp] u8 | bits[Lp] u8 | mt[632] u32
-// (bits: the bit plane of the current eight members, built in LDS and stored once per plane — a global read-modify-write per member and position
-// costs a memory round trip per 64 positions when there is one wave to hide it: 49 -> @@ us per launch at L = 576, K = 8)
+// (bits: the bit plane of the current eight members, built in LDS and stored once per plane instead of a global read-modify-write per member and
+// position.  Measured, L = 576, K = 8: 49 -> 45 us per launch; the kernel is bound by what ONE wave can issue)
 // keep_lds: the keep flags are already in LDS (the lanes kernel computes them there); else they are copied from P.keep (null: empty set).
 __device__ __forceinline__ size_t sampler_lp(int L) {
   int Lp = 64;
