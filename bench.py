@@ -247,6 +247,43 @@ def finishing_share(stats_file):
                     "attention's combine, streaming = the slice GEMVs + the attention's tile pass"}
 
 
+def sweep_traffic(stats_file, pmc_file, n_layers, sweeps, sequences):
+    """What ONE layer of one rider sweep moves between L2 and the memory side, all of its kernels together (weights, caches, partial sums both
+    ways, operand planes) — from the committed PMC passes (bytes per launch) and kernel trace (launches per layer) — and what that makes per
+    decoded token of a group step.  The per-kernel `roofline.frac` prices ONE kernel by its algorithmic bytes; this is the step as the memory
+    system sees it."""
+    import csv
+    import re
+    pat = re.compile(r"void (k_gemv_slices_seq<9,|k_gemv_slices<\d+, 9,|k_gemv_slices_fp8c?<9,|k_attn_partial16_ride<|k_gemv_finish4<\d+, \d+, 9, \d+>|k_attn_combine_ride<)")
+    try:
+        rows = {r["Name"]: r for r in csv.DictReader(open(os.path.join(ROOT, stats_file)))}
+        pmc = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
+    except Exception:
+        return None
+    calls = max((int(r["Calls"]) for n, r in rows.items() if re.match(r"void k_gemv_slices_seq<9,|void k_gemv_slices_fp8<9,", n)), default=0)
+    rd = wr = us = 0.0
+    missing = []
+    for n, r in rows.items():
+        if not pat.match(n):
+            continue
+        per_layer = int(r["Calls"]) / max(calls, 1)
+        us += float(r["TotalDurationNs"]) / max(calls, 1) / 1e3
+        v = pmc.get(n)
+        if v is None or v.get("hbm_read_bytes_per_launch") is None:
+            missing.append(n.split("(")[0][5:])
+            continue
+        rd += v["hbm_read_bytes_per_launch"] * per_layer
+        wr += v.get("hbm_write_bytes_per_launch", 0) * per_layer
+    if not calls or rd == 0:
+        return None
+    per_tok = (rd + wr) * n_layers * sweeps / sequences
+    return {"read_bytes_per_layer_sweep": round(rd), "written_bytes_per_layer_sweep": round(wr), "kernel_us_per_layer_sweep": round(us, 1),
+            "bytes_per_token": round(per_tok), "kernels_without_counters": missing, "files": [pmc_file, stats_file],
+            "note": "L2 <-> memory-side bytes of every kernel of a rider sweep's layer (PMC FETCH_SIZE / WRITE_SIZE per launch x launches per layer); "
+                    "a 64-lane step is layers x sweeps of these — divide by the step time of tools/rider_ab.py for the rate inside the decode steps "
+                    "(DESIGN.md 3: 190.6 GB in 35.5 ms = 5.4 TB/s); GBs_at_value below has the vision front-end and the prefill inside the time"}
+
+
 def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows8, wide, profile_tag=""):
     """The dominant kernel (gate/up decode GEMV of the member pass) timed alone with HIP events on its launch stream while cycling over
     the layers' weights, on an engine of its own created through libdropdec_tools.so (the timing hooks are not in the product library)."""
@@ -613,6 +650,12 @@ def main() -> int:
                                       "64-row launch's rows and takes ~1.13x its time (gate_up_streaming_kernel_by_rows.us_per_8_rows), but a step needs one "
                                       "sweep fewer; frac_at_value = bytes the steps stream per token x tokens/s per GPU / 8 TB/s, with the vision front-end "
                                       "and the prefill inside the time"}
+        if rider and roof.get("kernel_stats_file"):
+            tr = sweep_traffic(roof["kernel_stats_file"], roof["traffic_source"]["file"], lm_cfg.num_layers, sweeps, B)
+            if tr:
+                tr["GBs_at_value"] = round(tr["bytes_per_token"] * per_gpu / 1e9, 1)
+                tr["frac_at_value"] = round(tr["bytes_per_token"] * per_gpu / 1e9 / HBM_PEAK_GBS, 4)
+            roof["group_step"]["memory_side_traffic"] = tr
     if roof is not None and single:
         roof["end_to_end"] = end_to_end(single, lm_cfg, T0 + args.n_new / 2, weight_bytes, 2.0)
         if single_two:

@@ -873,6 +873,10 @@ void ddk_set_slices_only(int on) { g_slices_only = on; }
 #define SLICES_UNSUPPORTED 1
 
 extern int g_seq_prog;
+// dd_tools_set_tuning key 50: the rows' rstd in a workgroup of its own behind the streaming ones (SliceArgs::rstd_wg; default 1; 0 = workgroup 0
+// does it before its own weight stream, as until round 5's last day).  Same bits either way.
+int g_rstd_wg = 1;
+static inline int rstd_blocks(const SliceArgs& sa) { return sa.rstd_wg && sa.ssq_in ? (sa.halves == 2 ? 2 : 1) : 0; }
 template <int TW, int NG, int U, int SPW, int CS, int CH, int TAG>
 static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
   constexpr size_t smem = (size_t)CH * (SPW < CS ? SPW : CS) * NG * 1024;
@@ -888,7 +892,7 @@ static int launch_slices_k(const SliceArgs& sa, int wf, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices<TW, NG, U, SPW, CS, CH, 1, TAG, PROG_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  const int grid = (sa.halves == 2 ? 2 : 1) * (8 / CH) * sa.G;
+  const int grid = (sa.halves == 2 ? 2 : 1) * (8 / CH) * sa.G + rstd_blocks(sa);
   const int prog = g_seq_prog && PROG_OK;
   NOTE_KERNEL("k_gemv_slices<%d, %d, %d, %d, %d, %d, %d, %d, %d>", TW, NG, U, SPW, CS, CH, wf ? 1 : 0, TAG, prog);
   if (prog) {
@@ -914,8 +918,8 @@ static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
     attr = true;
   }
   NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG);
-  if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
-  else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG><<<4 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG><<<4 * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
+  else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG><<<4 * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 
@@ -935,7 +939,7 @@ static int launch_slices_fp8(const SliceArgs& sa, hipStream_t st) {
     attr = true;
   }
   NOTE_KERNEL("k_gemv_slices_fp8<%d, %d, %d, %d, 0>", NG, SPW2, CH, UW);
-  k_gemv_slices_fp8<NG, SPW2, CH, UW><<<(8 / CH) * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  k_gemv_slices_fp8<NG, SPW2, CH, UW><<<(8 / CH) * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 template <int NG, int SPW2, int CS2, int UW>
@@ -947,7 +951,7 @@ static int launch_slices_fp8c(const SliceArgs& sa, hipStream_t st) {
     attr = true;
   }
   NOTE_KERNEL("k_gemv_slices_fp8c<%d, %d, %d, %d, 0>", NG, SPW2, CS2, UW);
-  k_gemv_slices_fp8c<NG, SPW2, CS2, UW><<<8 * sa.G, GEMV_THREADS, smem, st>>>(sa);
+  k_gemv_slices_fp8c<NG, SPW2, CS2, UW><<<8 * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
 template <int EPI, int TILES, int NG>
@@ -967,7 +971,7 @@ static int try_slices_fp8(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1, sa.n_groups = nt;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal, sa.rstd_wg = g_rstd_wg;
   const int per_set = 256 / (8 / ch);                  // one round of workgroups (one per CU at 64-128 KiB of operands)
   sa.G = (nt + 7) / 8 < per_set ? (nt + 7) / 8 : per_set;
   if (spw2 == 28) {
@@ -1002,7 +1006,7 @@ static int try_slices(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;                              // 32 floats behind the partial sums
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal, sa.rstd_wg = g_rstd_wg;                              // 32 floats behind the partial sums
   const size_t need8 = (size_t)8 * nt * NG * 128, need4 = need8 / 2;
   if (epi == EPI_STORE) {
     // lm_head (K = 4096): the wave-split kernel streams it at 2.8 TB/s with four planes (operand reads from L2); the slice kernels
@@ -1115,7 +1119,7 @@ static int try_slices9_fp8(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1, sa.n_groups = nt;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal, sa.rstd_wg = g_rstd_wg;
   if (spw2 == 28) {
     sa.G = (nt + 7) / 8;
     RC_(launch_slices_fp8c<9, 28, 4, 4>(sa, st));
@@ -1139,7 +1143,7 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
   SliceArgs sa;
   sa.W = a.W, sa.xop = a.xop, sa.part = a.part, sa.S = a.S, sa.halves = 1;
   sa.ssq_in = a.ssq_in, sa.ssq_n = a.ssq_n, sa.ssq_ld = a.ssq_ld, sa.inv_k = a.inv_k, sa.eps = a.eps;
-  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal;
+  sa.rstd_out = a.part + a.part_floats, sa.temporal = g_exp_temporal, sa.rstd_wg = g_rstd_wg;
   const size_t need8 = (size_t)8 * nt * 9 * 128;
   if (a.part_floats < need8) return SLICES_UNSUPPORTED;
   sa.n_groups = nt;

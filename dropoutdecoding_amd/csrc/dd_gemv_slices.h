@@ -45,7 +45,13 @@ struct SliceArgs {
   // 1: weight tiles with the default cache policy instead of non-temporal loads (A/B, dd_tools_set_tuning key 36: beside other branches that
   // stream the same matrix moments later a tile may be served from the Infinity Cache)
   int temporal;
+  // 1 (the product since round 5's last day): the launch carries one workgroup more per half (blockIdx.x >= the streaming workgroups' count) that
+  // does nothing but the rows' rstd.  Until then workgroup 0 did it BEFORE its own weight stream: the launch ended 4-6 us late, waiting for that
+  // one workgroup (tools/seq_lab.hip: gate/up at 72 rows 48.1 -> 43.5 us).  0: the old placement (A/B, dd_tools_set_tuning key 50).  Same bits.
+  int rstd_wg;
 };
+// (temporal bit 3, value 8: TIMING EXPERIMENT — k_gemv_slices_seq writes a tile pair's partial sums as soon as the pair is complete, as it did until
+// round 5's last day, instead of at the end of the wave's stream)
 // (temporal bit 1, value 2: TIMING EXPERIMENT of the tools library — the kernels skip the operand planes' staging and compute on whatever the LDS
 // holds; how much of a launch the blocking stage-in costs.  Bit 2, value 4: the slice-pair kernels write no partial sums.  Never set by the product.)
 __device__ __forceinline__ u32x4_t dd_ldw(int temporal, const u32x4_t* p) { return (temporal & 1) ? *p : __builtin_nontemporal_load(p); }
@@ -104,7 +110,15 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
   const u32x4_t* const xop = a.xop + (size_t)half * NG * xplane;
   const int ng_all = a.halves == 2 ? 2 * NG : NG, plane0 = half * NG;
   const int n_tiles = a.n_groups * TW;
-  if (a.ssq_in && (blockIdx.x == 0 || (a.halves == 2 && blockIdx.x == 8)))   // the first workgroup of each half: its rows' rstd
+  {
+    const int work_blocks = (a.halves == 2 ? 2 : 1) * NQ * a.G;
+    if ((int)blockIdx.x >= work_blocks) {              // SliceArgs::rstd_wg: the workgroup(s) behind the streaming ones — a half's rows' rstd
+      const int hh = blockIdx.x - work_blocks;
+      if (a.ssq_in) dd_rows_rstd<NG>(a.ssq_in + (size_t)hh * 8 * NG * a.ssq_ld, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out + hh * 8 * NG);
+      return;
+    }
+  }
+  if (!a.rstd_wg && a.ssq_in && (blockIdx.x == 0 || (a.halves == 2 && blockIdx.x == 8)))   // (old placement) the first workgroup of each half
     dd_rows_rstd<NG>(a.ssq_in + (size_t)half * 8 * NG * a.ssq_ld, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out + half * 8 * NG);
 
   u32x4_t xv[PW];
@@ -378,7 +392,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const int qs = blockIdx.x & 3, j = blockIdx.x >> 2;
   const size_t xplane = (size_t)a.S * 64;
   const int n_tiles = a.n_groups;
-  if (blockIdx.x == 0 && a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+  if ((int)blockIdx.x >= 4 * a.G) {                    // SliceArgs::rstd_wg: the workgroup behind the streaming ones — the rows' rstd
+    if (a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+    return;
+  }
+  if (!a.rstd_wg && blockIdx.x == 0 && a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);   // (old placement)
   const size_t wstep = 8 * 64;
   int gidx[MAXG];
   int ng = 0;
@@ -418,6 +436,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   for (int s_ = 0; s_ < NSET; ++s_)
 #pragma unroll
     for (int h = 0; h < NG; ++h) sum[s_][h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto store_set = [&](int st) {                       // a set's two tiles are complete: each half of the lanes stores its tile
+    const int my_gi = 2 * st + (hi_half ? 1 : 0);
+    const int my_g = j + a.G * (wave + 8 * my_gi);      // = gidx[my_gi], as arithmetic (a lane-dependent index into gidx[] would put it in scratch)
+    if (my_gi < MAXG && my_gi < ng && !(a.temporal & 4)) {      // (temporal bit 2: timing experiment — no partial sums written)
+      const int l32 = (lane >> 4) * 8 + (lane & 7);
+#pragma unroll
+      for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + my_g) * NG + h) << 7) + l32 * 4] = sum[st][h];
+    }
+  };
   // the ring runs over the wave's items (slice half, group) in order; the next item's first U tiles are requested while the
   // current item's last block is consumed — also across the operand swap
   u32x4_t w[U];
@@ -469,22 +496,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
       }
-      if (half == 1 && ((gi & 1) || gi == MAXG - 1)) { // the set's two tiles are complete: each half of the lanes stores its tile
-        const int st = gi >> 1;
-        const int my_gi = 2 * st + (hi_half ? 1 : 0);
-        const int my_g = j + a.G * (wave + 8 * my_gi);  // = gidx[my_gi], as arithmetic (a lane-dependent index into gidx[] would put it in scratch)
-        if (my_gi < MAXG && my_gi < ng && !(a.temporal & 4)) {      // (temporal bit 2: timing experiment — no partial sums written)
-          const int l32 = (lane >> 4) * 8 + (lane & 7);
-#pragma unroll
-          for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + my_g) * NG + h) << 7) + l32 * 4] = sum[st][h];
-        }
-      }
+      if (half == 1 && (a.temporal & 8) && ((gi & 1) || gi == MAXG - 1)) store_set(gi >> 1);   // (timing experiment: the round-5 placement)
     }
     if (half == 0) {
+      // (requesting the second slice's pieces BEFORE this barrier — their latency beside the slower waves' last tile — was measured: no gain,
+      // 60 registers; tools/seq_lab.hip, profiles/r05_lab/)
       __syncthreads();                                 // every wave has finished reading slice 2 qs
       if (!(a.temporal & 2)) stage(1);
       __syncthreads();
     }
+  }
+  // Every partial sum is written HERE, after the wave's last weight request has been consumed: gfx950 counts loads and stores in one counter
+  // (vmcnt) that retires in order, so a store issued in mid-stream makes every later weight piece wait for the store's acknowledgement.
+  if (!(a.temporal & 8)) {
+#pragma unroll
+    for (int st = 0; st < NSET; ++st) store_set(st);
   }
 }
 
@@ -510,7 +536,11 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
   const int S2 = a.S >> 1;
   const size_t xplane = (size_t)a.S * 64;
   const int n_tiles = a.n_groups;
-  if (a.ssq_in && blockIdx.x == 0) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+  if ((int)blockIdx.x >= NQ * a.G) {                   // SliceArgs::rstd_wg: the workgroup behind the streaming ones — the rows' rstd
+    if (a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+    return;
+  }
+  if (!a.rstd_wg && a.ssq_in && blockIdx.x == 0) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
   int g = j + a.G * wave;
   const bool any = g < n_tiles;
   // block b (0 .. CH * NB - 1) of tile g: slice q + b / NB, 64-k steps (b % NB) * UW ...; consecutive steps of a slice are 8 apart
@@ -616,7 +646,11 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8c(SliceArgs a) {
   const int S2 = a.S >> 1;
   const size_t xplane = (size_t)a.S * 64;
   const int n_tiles = a.n_groups;
-  if (a.ssq_in && blockIdx.x == 0) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+  if ((int)blockIdx.x >= 8 * a.G) {                    // SliceArgs::rstd_wg: the workgroup behind the streaming ones — the rows' rstd
+    if (a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
+    return;
+  }
+  if (!a.rstd_wg && a.ssq_in && blockIdx.x == 0) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
   const int g = j + a.G * wave;
   const bool live = g < n_tiles;
   const u32x4_t* const wp = a.W + ((size_t)(live ? g : 0) * S2 + q) * 64 + lane;      // step s of the slice: wp + 8 s tiles

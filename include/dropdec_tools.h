@@ -52,7 +52,9 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * default 0: one set, 94 VGPRs, so that it shares CUs with the other branches' slice GEMVs), 48 the dynamic-LDS request of the 1,024-thread sampler forms (key 34 > 0): 1 = 156 KiB, round 4's
  * fence (default); 0 = the 76 KiB they use — the unit reproducer of DESIGN.md 3e needs that; n = n KiB (round 5's request sweep).  Round 5: 49 the
  * progressive stage-in of the operand planes in the whole-slice GEMV kernels at two and four planes (default 1; 0: blocking, as in rounds 2-4); 36
- * also takes timing-only bits: 2 = the slice kernels skip the stage-in, 4 = the slice-pair kernels write no partial sums (results garbage).  Keys of the determinism bisect (all default to the product's behaviour): 37 fp32-cache
+ * also takes timing-only bits: 2 = the slice kernels skip the stage-in, 4 = the slice-pair kernels write no partial sums (results garbage), 8 = the
+ * slice-pair kernels write a tile pair's partial sums in mid-stream (as until round 5's last day; same bits); 50 the rows' rstd of a slice GEMV in a
+ * workgroup of its own behind the streaming ones (default 1; 0: workgroup 0 computes it before its own weight stream; same bits).  Keys of the determinism bisect (all default to the product's behaviour): 37 fp32-cache
  * engines fork their member sweeps (-1: one branch as in round 3), 39 extra dynamic LDS bytes requested by the fp32-cache attention tile pass
  * (so that it cannot share a CU with a slice GEMV), 40 the branches' streams on disjoint CU masks, 41 CU-mask only the attention launches,
  * 42 bit mask of kernel families launched on the UNMASKED stream while 40 is on (1 embed, 2 GEMVs, 4 attention, 8 finishing kernels),

@@ -52,6 +52,18 @@ def test_finishing_share_of_the_committed_round_5_trace():
     assert 40.0 < prof["stats_avg_us"] < 55.0 and prof["traffic"] and prof["traffic"] > 150e6      # gate/up: 180 MB algorithmic per launch
 
 
+def test_sweep_traffic_of_the_committed_round_5_profile():
+    """`roofline.group_step.memory_side_traffic`: every kernel of a rider sweep's layer from the committed PMC passes — the weights are 405 MB of
+    the ~740 MB a layer of a 72-row sweep moves (caches 165, partial sums both ways ~150): DESIGN.md 3 "the step as the memory system sees it"."""
+    bench = importlib.import_module("bench")
+    pmc, stats = bench._profile_files()
+    t = bench.sweep_traffic(stats, pmc, 32, 8, 64)
+    assert 600e6 < t["read_bytes_per_layer_sweep"] < 720e6 and 60e6 < t["written_bytes_per_layer_sweep"] < 110e6, t
+    assert t["bytes_per_token"] == round((t["read_bytes_per_layer_sweep"] + t["written_bytes_per_layer_sweep"]) * 32 * 8 / 64)
+    assert 150 < t["kernel_us_per_layer_sweep"] < 260
+    assert bench.sweep_traffic("profiles/absent.csv", pmc, 32, 8, 64) is None
+
+
 def _dump(shadow, seen, later, src, lds_words=8192 * 3):
     d = np.zeros(16 + 5 * 640 + lds_words, np.uint32)
     d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9] = 1, 5, 3, 7, 1, 1234, 624, 99, lds_words
