@@ -307,3 +307,33 @@ def test_full_size_64_lanes_repeat_bitwise(E):
             np.testing.assert_array_equal(a, b, err_msg=f"repetition {rep}: KV checksums, lane {i}")
     for e in reversed(engines):
         e.close()
+
+
+@pytest.mark.parametrize("weight_format,family,dims", [("bf16", "llava-1.5", (4096, 11008, 32, 32)), ("fp8", "llava-next", (4096, 14336, 32, 8))])
+def test_rstd_workgroup_and_store_placement_do_not_change_a_bit(E, T, weight_format, family, dims):
+    """Round 5, last day (DESIGN.md 3g): the slice kernels' rstd runs in a workgroup of its own behind the streaming ones (SliceArgs::rstd_wg, tools
+    key 50) and the slice-pair kernels write their partial sums after the stream (key 36 bit 8 = the old mid-stream placement).  Where things are
+    computed and when they are stored is not arithmetic: 16 lanes in the rider form, both placements, every output compared."""
+    d, dff, H, Hkv = dims
+    cfg = E.LMConfig(2048, d, dff, 2, H, Hkv, 128, 1e-5, 10000.0)
+    L = 24
+    n_lanes = 16
+    engines = _group(E, T, cfg, n_lanes, family, L, **({"weight_format": "fp8"} if weight_format == "fp8" else {}))
+    gen = torch.Generator().manual_seed(21)
+    T0s = [L + 6 + (i % 5) for i in range(n_lanes)]
+    embs = [(torch.randn(T0, d, generator=gen) * 0.5).cuda() for T0 in T0s]
+    spans = [(2 + (i % 3), L) for i in range(n_lanes)]
+    try:
+        new = _run(E, T, engines, embs, spans, K8, 4, rider=True, graph=True)
+        T.dd_tools_set_tuning(50, 0)
+        T.dd_tools_set_tuning(36, 8)
+        old = _run(E, T, engines, embs, spans, K8, 4, rider=True, graph=True)
+        _same(old, new, f"rstd in workgroup 0 + mid-stream stores vs the product's placements ({weight_format})")
+        T.dd_tools_set_tuning(36, 0)
+        half = _run(E, T, engines, embs, spans, K8, 4, rider=True, graph=False)
+        _same(half, new, f"rstd in workgroup 0 only ({weight_format})")
+    finally:
+        T.dd_tools_set_tuning(50, 1)
+        T.dd_tools_set_tuning(36, 0)
+        for e in reversed(engines):
+            e.close()
