@@ -281,7 +281,7 @@ def sweep_traffic(stats_file, pmc_file, n_layers, sweeps, sequences):
             "bytes_per_token": round(per_tok), "kernels_without_counters": missing, "files": [pmc_file, stats_file],
             "note": "L2 <-> memory-side bytes of every kernel of a rider sweep's layer (PMC FETCH_SIZE / WRITE_SIZE per launch x launches per layer); "
                     "a 64-lane step is layers x sweeps of these — divide by the step time of tools/rider_ab.py for the rate inside the decode steps "
-                    "(DESIGN.md 3: 190.6 GB in 35.5 ms = 5.4 TB/s); GBs_at_value below has the vision front-end and the prefill inside the time"}
+                    "(DESIGN.md 3g: 190.6 GB in 35.5 ms = 5.4 TB/s); GBs_at_value below has the vision front-end and the prefill inside the time"}
 
 
 def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows8, wide, profile_tag=""):
