@@ -134,3 +134,20 @@ def test_packed_fp32_gate_fails_closed(tmp_path):
         build.packed_fp32_ops(str(junk))
     with pytest.raises(Exception):
         build.packed_fp32_ops(str(tmp_path / "absent.o"))
+
+
+@pytest.mark.parametrize("src,product_flags", [("stream_lab.hip", False), ("mall_lab.hip", False), ("seq_lab.hip", True), ("fuse_lab.hip", True),
+                                               ("pkfma_war_repro.hip", False)])
+def test_lab_tools_still_compile_for_gfx950(tmp_path, src, product_flags):
+    """The stand-alone measurement tools of DESIGN.md 3e / 3g cross-compile (seq_lab / fuse_lab include csrc/dd_gemv_slices.h: a change of the product
+    kernel's interface shows up here, not on the GPU box)."""
+    import shutil
+    import subprocess
+    from dropoutdecoding_amd import build
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    cmd = [hipcc, f"--offload-arch={build.ARCH}", "-O3", "-std=c++17", *(build.NO_PACKED_FP32 if product_flags else []), "-c",
+           os.path.join(ROOT, "tools", src), "-o", str(tmp_path / "x.o")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
