@@ -124,6 +124,8 @@ class KShardDecoder:
 # exchange.  lm.TensorParallelGroup is the single-process form (all ranks on one device).
 # ---------------------------------------------------------------------------------------------------------------------
 _TP_ERROR_KEY = "dropoutdecoding_amd/tp_exchange_error"
+_TP_POLL_S = 0.05             # a rank looks at its job's flag at most this often (one store round trip per look)
+_tp_generation: dict = {}      # ranks of a group -> TensorParallelRank objects built on it so far (the same count on every rank)
 
 
 def _tp_store():
@@ -131,20 +133,41 @@ def _tp_store():
     return c10d._get_default_store()
 
 
-def tp_flag_error(group, rank: int, what: str) -> None:
+def tp_error_key(group, generation: int = 0) -> str:
+    """The store key of ONE tensor-parallel job: the group's global ranks + the how-many-th job on that group this is.  Sub-groups
+    that share the default store and successive jobs on one group therefore never see each other's flag."""
+    try:
+        ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+    except Exception:
+        ranks = []
+    return f"{_TP_ERROR_KEY}/{'-'.join(map(str, ranks))}/{generation}"
+
+
+def tp_flag_error(group, rank: int, what: str, generation: int = 0) -> None:
     """Mark the tensor-parallel job as failed in the rendezvous store (visible to every rank, whatever the backend)."""
-    _tp_store().set(_TP_ERROR_KEY, f"rank {rank}: {what}"[:400])
+    _tp_store().set(tp_error_key(group, generation), f"rank {rank}: {what}"[:400])
 
 
-def tp_peer_failed(group) -> str:
-    """'' or the failed rank's message: checked before every exchange, so that a rank does not walk into a collective its peer has left."""
+def tp_peer_failed(group, generation: int = 0) -> str:
+    """'' or the failed rank's message.  No default store (a group built without one) is the only thing read as "nothing to check
+    against"; a store that fails to answer raises — a broken store must not look like a healthy job."""
     try:
         st = _tp_store()
-        if st.check([_TP_ERROR_KEY]):
-            return st.get(_TP_ERROR_KEY).decode(errors="replace")
     except Exception:
-        return ""              # no store (a group built without one): nothing to check against
+        return ""
+    key = tp_error_key(group, generation)
+    if st.check([key]):
+        return st.get(key).decode(errors="replace")
     return ""
+
+
+def tp_clear_error(group, generation: int = 0) -> bool:
+    """Remove the job's flag (teardown).  False when the store kind cannot delete keys (FileStore): the key is namespaced per job, so
+    a flag left behind is never read by a later job."""
+    try:
+        return bool(_tp_store().delete_key(tp_error_key(group, generation)))
+    except Exception:
+        return False
 
 
 class TensorParallelRank:
@@ -162,13 +185,17 @@ class TensorParallelRank:
         self.gather = torch.zeros(world * self.rows_cap * cfg.hidden_size, dtype=torch.float32, device=e.device)
         self.exchanges = 0
         self.error = None
+        # which job on this group this is: every rank builds its TensorParallelRank objects in the same order, so the count agrees
+        gkey = tp_error_key(group).rsplit("/", 1)[0]
+        self.generation = _tp_generation[gkey] = _tp_generation.get(gkey, -1) + 1
+        self._last_poll = 0.0
         d = cfg.hidden_size
 
         def exchange(ctx, rows, stream):
+            # (no store round trip in here: there are two exchanges per layer and sweep — ~128 per token — and on "nccl" they are
+            # asynchronous and latency-bound.  The job's flag is looked at once per prefill / decode step, `_poll_peers`, and again
+            # when an exchange raises)
             try:
-                failed = tp_peer_failed(self.group)
-                if failed:
-                    raise RuntimeError(f"tensor-parallel exchange: a peer's exchange failed ({failed})")
                 n = rows * d
                 out = self.gather[: world * n]
                 mine = out[rank * n:(rank + 1) * n]
@@ -183,7 +210,11 @@ class TensorParallelRank:
                 self.exchanges += 1
                 return 0
             except Exception as ex:                             # an exception must not unwind through the C frames
-                self.error = ex
+                try:                                            # was it a peer leaving first?  say so
+                    failed = tp_peer_failed(self.group, self.generation)
+                except Exception:
+                    failed = ""
+                self.error = RuntimeError(f"tensor-parallel exchange failed after a peer's failure ({failed}): {ex!r}") if failed else ex
                 self._abort_peers()                             # the other ranks are (or will be) waiting in this all-gather
                 return 1
         self._cb = _lib.TP_EXCHANGE_FN(exchange)                # kept alive with the object
@@ -206,7 +237,7 @@ class TensorParallelRank:
         import warnings
         self.abort_error = None
         try:
-            tp_flag_error(self.group, self.rank, repr(self.error))
+            tp_flag_error(self.group, self.rank, repr(self.error), getattr(self, "generation", 0))
         except Exception as ex:
             self.abort_error = ex
             warnings.warn(f"TensorParallelRank: could not flag the failed exchange in the store: {ex!r}")
@@ -225,6 +256,24 @@ class TensorParallelRank:
             warnings.warn(f"TensorParallelRank: aborting the process group after a failed exchange raised {ex!r}; "
                           "the peers will time out in their all-gather instead of failing now")
 
+    def _poll_peers(self, force: bool = False) -> None:
+        """Once per prefill / decode step, and at most every _TP_POLL_S: has a peer flagged this job as failed?  Then this rank must
+        not walk into a collective its peer has left."""
+        import time
+        now = time.monotonic()
+        if not force and now - self._last_poll < _TP_POLL_S:
+            return
+        self._last_poll = now
+        failed = tp_peer_failed(self.group, self.generation)
+        if failed:
+            raise RuntimeError(f"tensor-parallel job: a peer's exchange failed ({failed})")
+
+    def close(self) -> None:
+        """Teardown: the job's flag leaves the store (rank 0 of the job deletes it), the engine is released."""
+        if self.rank == 0:
+            tp_clear_error(self.group, self.generation)
+        self.engine.close()
+
     def _check(self, rc: int, what: str) -> None:
         if rc != 0 and self.error is not None:
             err, self.error = self.error, None
@@ -233,6 +282,7 @@ class TensorParallelRank:
 
     def prefill(self, embeds: torch.Tensor, span_start: int, span_len: int) -> None:
         e = self.engine
+        self._poll_peers(force=True)
         x = embeds.reshape(-1, embeds.shape[-1]).float().contiguous()
         e.torch_stream.wait_stream(torch.cuda.current_stream(e.device))
         x.record_stream(e.torch_stream)
@@ -242,6 +292,7 @@ class TensorParallelRank:
     def decode_step(self, mprobs: Optional[Sequence[float]] = None, dropout: bool = True) -> None:
         import ctypes as C
         e = self.engine
+        self._poll_peers()
         probs, arr = e._probs(mprobs)
         K = len(probs) if dropout else 0
         rs = (C.c_void_p * 1)(e.rng.handle)

@@ -43,6 +43,10 @@ class StepRecord:
     logits: np.ndarray                # fp32 [V] (winner's)
     base_logits: np.ndarray           # fp32 [V]
     phases: Dict[str, float] = field(default_factory=dict)
+    # diagnostics for the parity tests (not part of the reference's state): top-1 minus top-2 of what each member's
+    # argmax ran over (llava.py:27 / instructblip.py:125-137), relative to the largest magnitude — tells a legitimate
+    # near-tie flip (inside the 1e-3 logits tolerance) from a wrong result
+    member_margin: List[float] = field(default_factory=list)
 
 
 class RefDecoder:
@@ -198,12 +202,17 @@ class RefDecoder:
         if self.family == FAMILY_IBLIP:
             self.leaked = drop[K - 1].clone()
         ph["vote"] += time.perf_counter() - t0
+        voted = [h[-1].float() for h in member_hid] if (self.family == FAMILY_IBLIP and not self.use_avg) else member_logits
+        margins = []
+        for v in voted:
+            top2 = torch.topk(v.float().flatten(), 2).values
+            margins.append(float((top2[0] - top2[1]) / v.float().abs().max().clamp_min(1e-30)))
         self.cache = member_cache[win]                                   # llava.py:373
         tok = int(torch.argmax(logits))                                  # HF greedy
         return StepRecord(int(torch.argmax(base_logits)), keep.numpy().copy(),
                           None if uniforms is None else uniforms.numpy().copy(), drop.numpy().copy(),
                           [int(d.sum()) for d in drop], ids, win, tok, logits.numpy().copy(),
-                          base_logits.numpy().copy(), ph)
+                          base_logits.numpy().copy(), ph, margins)
 
     def generate(self, embeds: torch.Tensor, span_start: int, span_len: int, n_new: int,
                  eos: Optional[int] = None) -> List[int]:

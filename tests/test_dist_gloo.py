@@ -232,7 +232,7 @@ def _tp_flag_worker(rank, world, port, q):
     if rank == 1:
         # a rank whose exchange raised: what TensorParallelRank._abort_peers does, on an object without an engine
         obj = dd.TensorParallelRank.__new__(dd.TensorParallelRank)
-        obj.group, obj.rank, obj.error = None, rank, RuntimeError("exchange broke")
+        obj.group, obj.rank, obj.error, obj.generation = None, rank, RuntimeError("exchange broke"), 3
         obj._abort_peers()
         q.put(("aborter", repr(obj.abort_error)))          # gloo has no abort: nothing raised, nothing swallowed
     else:
@@ -240,9 +240,22 @@ def _tp_flag_worker(rank, world, port, q):
         t0 = time.time()
         msg = ""
         while not msg and time.time() - t0 < 20:
-            msg = dd.tp_peer_failed(None)
+            msg = dd.tp_peer_failed(None, 3)
             time.sleep(0.05)
-        q.put(("peer", msg))
+        # the flag belongs to ONE job — another job on the same group (generation 4), or one on a sub-group sharing the
+        # default store, does not see it; a rank polls once per step (rate-limited), not once per exchange; teardown removes the key
+        other_job, sub_group_key = dd.tp_peer_failed(None, 4), dd.tp_error_key(dist.new_group([0]) if False else None, 3)
+        obj = dd.TensorParallelRank.__new__(dd.TensorParallelRank)
+        obj.group, obj.rank, obj.generation, obj._last_poll = None, rank, 3, 0.0
+        raised = ""
+        try:
+            obj._poll_peers()
+        except RuntimeError as ex:
+            raised = str(ex)
+        obj.generation = 4
+        obj._poll_peers(force=True)                        # a healthy job on the same group: nothing raised
+        cleared = dd.tp_clear_error(None, 3)
+        q.put(("peer", (msg, other_job, sub_group_key, raised, cleared, dd.tp_peer_failed(None, 3))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -264,4 +277,8 @@ def test_tp_failed_exchange_is_flagged_to_the_peers_over_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got["aborter"] == "None"
-    assert "rank 1" in got["peer"] and "exchange broke" in got["peer"]
+    msg, other_job, key, raised, cleared, after = got["peer"]
+    assert "rank 1" in msg and "exchange broke" in msg
+    assert other_job == "" and key.endswith("/0-1/3")
+    assert "a peer's exchange failed" in raised and "exchange broke" in raised
+    assert cleared and after == ""

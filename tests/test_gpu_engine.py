@@ -283,7 +283,9 @@ def test_instructblip_positions_from_leaked_mask_444_rule(E, golden_dir):
 
 def test_full_size_llava15_7b_properties(E):
     """BASELINE config size (LLaVA-1.5-7B shapes, 576 visual + 32 prompt tokens, K=8), synthetic weights.
-    The oracle cannot run at this size in seconds, so size-independent properties are checked instead:
+    Size-independent properties at the full depth — the oracle comparisons of these widths are
+    tests/test_gpu_7b_shapes_vs_oracle.py (two layers, every lane and step form against its own RefDecoder) and, once per round on
+    the GPU box, tests/test_gpu_full_depth_oracle.py (all 32 layers; profiles/r06_full_size_oracle.log):
     replay determinism, members == un-masked pass when nothing is dropped (the vote is then unanimous and the
     token equals stock greedy), masks obey the reference's invariants, K-sharded phases == the single call."""
     eng = E.DropoutEngine(E.LLAVA15_7B, family=FAMILY_LLAVA, max_seq=704, max_visual=576, seed=5217)
