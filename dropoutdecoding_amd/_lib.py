@@ -28,7 +28,8 @@ SYMBOLS = [
 TOOLS_LIB_PATH = os.path.join(_HERE, "libdropdec_tools.so")
 TOOLS_SYMBOLS = ["dd_lm_time_sweep", "dd_lm_time_gemv", "dd_tools_last_gemv_kernel", "dd_hbm_read_bench", "dd_tools_set_tuning",
                  "dd_tools_trace_attach", "dd_tools_lds_poison", "dd_tools_scratch_probe", "dd_tools_sample_masks_lanes", "dd_tools_sweep_trace", "dd_tools_attn_trace", "dd_tools_lds_barrier_probe", "dd_tools_lds_overlap_probe", "dd_tools_hold_probe", "dd_tools_pk_probe", "dd_tools_pv_probe", "dd_tools_pkadd_gload_probe", "dd_tools_twist_probe", "dd_tools_barrier_probe", "dd_tools_pk_war_probe",
-                 "dd_tools_sampler_dbg_attach", "dd_tools_sampler_dbg_words", "dd_tools_sampler_dbg_launches"]
+                 "dd_tools_sampler_dbg_attach", "dd_tools_sampler_dbg_words", "dd_tools_sampler_dbg_launches",
+                 "dd_tools_stream_create_cu_mask", "dd_tools_stream_destroy", "dd_tools_cu_probe"]
 
 
 TP_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)     # int exchange(void* ctx, int rows, void* stream)
@@ -108,6 +109,9 @@ def load_tools() -> C.CDLL:
         lib.dd_tools_pk_war_probe.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]
         lib.dd_tools_barrier_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         lib.dd_tools_sampler_dbg_attach.argtypes = [vp]
+        lib.dd_tools_stream_create_cu_mask.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.POINTER(vp)]
+        lib.dd_tools_stream_destroy.argtypes = [vp]
+        lib.dd_tools_cu_probe.argtypes = [vp, C.c_int, C.c_int, vp]
         lib.dd_tools_sampler_dbg_words.restype = C.c_size_t
         lib.dd_tools_sampler_dbg_words.argtypes = []
         lib.dd_tools_sampler_dbg_launches.restype = C.c_uint

@@ -2659,15 +2659,17 @@ extern "C" double dd_lm_step_algorithmic_bytes(const dd_lm* h, int K) {
 // Switches of the product library (the measurement hooks and the experiment knobs live in libdropdec_tools.so: dd_tools.hip):
 // 8 = replay decode steps from hipGraphs (default 1), 11 = short prompt chunks through the decode GEMVs (default 1),
 // 13 = slice-resident 16 / 32 / 64-row GEMVs (default 1; 0: the K-split-over-waves kernels, same bits), 14 = process default of the
-// speculation policy (dd_lm_set_speculation), 15 / 16 = block order / big-block threshold of the prefill GEMM (same bits).
+// speculation policy (dd_lm_set_speculation), 15 / 16 = block order / big-block threshold of the prefill GEMM (same bits),
+// 20 = form of that big block (1: LDS-DMA 160 x 512, the default; 0: the register-staged 128 x 512 block of round 3; same bits).
 extern "C" int dd_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
-  DD_REQUIRE(key == 8 || key == 11 || (key >= 13 && key <= 16), "dd_set_tuning: unknown key %d (8, 11, 13, 14, 15, 16)", key);
+  DD_REQUIRE(key == 8 || key == 11 || (key >= 13 && key <= 16) || key == 20, "dd_set_tuning: unknown key %d (8, 11, 13, 14, 15, 16, 20)", key);
   if (key == 8) dd_engine_set_graph(value);
   else if (key == 11) dd_engine_set_extend_rows(value);
   else if (key == 13) ddk_set_gemv_slices(value);
   else if (key == 14) dd_engine_set_speculate(value);
   else if (key == 15) ddk_set_gemm_xcd_order(value);
+  else if (key == 20) ddk_set_gemm_dma(value);
   else ddk_set_gemm_big_rows(value);
   return DD_OK;
 }

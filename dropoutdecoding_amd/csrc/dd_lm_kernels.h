@@ -161,6 +161,7 @@ int ddk_tp_add_rows(float* x, const float* gather, int W, size_t n, hipStream_t 
 void ddk_set_tuning(int key, int value);
 void ddk_set_gemv_slices(int on);
 void ddk_set_gemm_big_rows(int rows);  // dd_set_tuning key 16: rows from which the prefill GEMM uses the 128 x 512 LDS-staged block (0: never; same bits)
+void ddk_set_gemm_dma(int on);         // dd_set_tuning key 20: LDS-DMA 160 x 512 block of the prefill GEMM (default on; 0: the register-staged 128 x 512 block; same bits)
 void ddk_set_gemm_xcd_order(int on);   // dd_set_tuning key 15: XCD-aware block order of the prefill GEMM (default on; same bits)
 void ddk_set_slices_only(int on);
 void ddk_set_attn_split(int v);

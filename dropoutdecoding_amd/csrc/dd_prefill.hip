@@ -464,6 +464,129 @@ __global__ __launch_bounds__(512) void k_gemm_big(GemmArgs a) {
   gemm_epilogue<EPI, MI, NJ, WF>(a, acc, m_base, nt_base, wv, lane);
 }
 
+// Round 6: the same product with the operand fragments brought in by LDS-DMA (`global_load_lds_dwordx4`: global memory -> LDS with no
+// register in between) and a 160 x 512 block.  The pre-tiled fragments are lane-linear 1 KiB pieces, which is exactly what one LDS-DMA
+// wave instruction writes (wave-uniform LDS base + 16 bytes per lane), so the copy needs no registers, no ds_write pass and no
+// `s_waitcnt` before the LDS writes: k_gemm_big's 24 staging VGPRs go to a fifth row of accumulator tiles per wave (MTB = 10: 5 x 8
+// tiles, 160 accumulator registers).  Why 160 rows: a prefill group is 16 x 640 rows; with 128-row blocks the N = 4096 matrices
+// (o_proj, down_proj) make 80 x 8 = 640 workgroups = 2.5 rounds of the 256 CUs, with 160-row blocks 64 x 8 = 512 = two full rounds
+// (qkv: 7.5 -> 6 rounds, gate/up 13.4 -> 10.75), and a block's operand bytes per flop drop by 13 %.  Three LDS stages of
+// (2 MTB + 32) KiB (156 KiB at MTB = 10): step ks multiplies from stage ks % 3, the A fragments of step ks + 1 are read from stage
+// (ks + 1) % 3 behind the step's MFMAs (and its first two W fragments with them: the next step's matrix work then starts right behind
+// the barrier), the fragments of step ks + 2 land in stage (ks + 2) % 3 meanwhile.  One raw `s_barrier` per
+// step behind `s_waitcnt vmcnt(0)` (the only vector-memory operations in flight are the step's own LDS-DMA pieces; `__syncthreads()`
+// would do the same here, the raw form only keeps the compiler from adding its own waits).  Per accumulator tile the MFMA sequence
+// is k_gemm's (k ascending; hi then lo): the same bits (tests/test_gpu_engine.py::test_prefill_gemm_block_shapes_and_orders_give_the_same_bits).
+template <int EPI, int WF, int MTB>
+__global__ __launch_bounds__(512) void k_gemm_dma(GemmArgs a) {
+  extern __shared__ __align__(16) u32x4_t gd_sh[];          // [3 stages][FR fragments][64]
+  constexpr int MI = MTB / 2, NJ = 8;
+  constexpr int FR = 2 * MTB + GB_NT;                        // 1 KiB fragments per k-step: A hi, A lo, W
+  constexpr int NC = (FR + 7) / 8;                           // LDS-DMA pieces per wave and k-step
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  int bx, by;
+  {
+    const int gy = a.grid_y, total = gridDim.x, per = total >> 3, id = blockIdx.x;
+    const int v = a.xcd_order && id < (per << 3) ? (id & 7) * per + (id >> 3) : id;
+    bx = v / gy, by = v - bx * gy;
+  }
+  const int S = a.S;
+  const int m_tiles = (a.M + 15) >> 4;
+  // copy duty of this wave: fragments wave + 8 i (a wave whose last index falls past FR repeats its previous piece: every wave
+  // issues the same number of pieces)
+  const u32x4_t* src[NC];
+  int dst[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    int f = wave + 8 * i;
+    if (f >= FR) f -= 8;
+    dst[i] = f * 64;
+    if (f < MTB) src[i] = (const u32x4_t*)a.a_hi + (size_t)min(by * MTB + f, m_tiles - 1) * S * 64 + lane;
+    else if (f < 2 * MTB) src[i] = (const u32x4_t*)a.a_lo + (size_t)min(by * MTB + f - MTB, m_tiles - 1) * S * 64 + lane;
+    else src[i] = a.W + (size_t)min(bx * GB_NT + f - 2 * MTB, a.n_tiles - 1) * S * 64 + lane;
+  }
+  auto issue = [&](int ks, int stage) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)ks * 64),
+                                       (__attribute__((address_space(3))) void*)(gd_sh + stage * (FR * 64) + dst[i]), 16, 0, 0);
+  };
+  const int m_base = by * (16 * MTB) + wr * (16 * MI);
+  const int nt_base = bx * GB_NT + wc * NJ;
+  bool wv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) wv[j] = (nt_base + j) < a.n_tiles;
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  issue(0, 0);
+  issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  u32x4_t ahi[MI], alo[MI], wq[2][2];
+  const int w_off = (2 * MTB + wc * NJ) * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    ahi[i] = gd_sh[(wr * MI + i) * 64 + lane];
+    alo[i] = gd_sh[(MTB + wr * MI + i) * 64 + lane];
+  }
+  wq[0][0] = gd_sh[w_off];
+  wq[0][1] = gd_sh[w_off + 64];
+  auto mm = [&](const int jp, const u32x4_t (&w2)[2]) {     // the 4 MI MFMAs of W fragments 2 jp, 2 jp + 1 (per tile: hi, then lo)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][2 * jp + jj] = dd_mfma16<WF>(ahi[i], w2[jj], acc[i][2 * jp + jj]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][2 * jp + jj] = dd_mfma16<WF>(alo[i], w2[jj], acc[i][2 * jp + jj]);
+    }
+  };
+  int s_cur = 0;                                               // ks % 3
+  for (int ks = 0; ks < S; ++ks) {
+    const int s_next = s_cur == 2 ? 0 : s_cur + 1, s_next2 = s_next == 2 ? 0 : s_next + 1;
+    // At the top the wave holds A(ks) and W fragments 0, 1 of step ks (read before the barrier that ended step ks - 1), so its matrix
+    // work restarts at once; the W fragments come two at a time, the next pair requested before the current pair's 4 MI MFMAs issue
+    // (left to itself the compiler reads a pair, waits for it with the matrix pipe running dry, multiplies, reads the next).
+    const u32x4_t* st = gd_sh + s_cur * (FR * 64) + w_off;
+    wq[1][0] = st[2 * 64];
+    wq[1][1] = st[3 * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0, wq[0]);
+    // the pieces of step ks + 2 go out behind the first MFMAs: stage (ks + 2) % 3 held step ks - 1, which every wave finished reading
+    // before the barrier that ended it
+    if (ks + 2 < S) issue(ks + 2, s_next2);
+    wq[0][0] = st[4 * 64];
+    wq[0][1] = st[5 * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    mm(1, wq[1]);
+    wq[1][0] = st[6 * 64];
+    wq[1][1] = st[7 * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    mm(2, wq[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(3, wq[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < S) {                                          // stage (ks + 1) % 3 was published by the barrier that ended step ks - 1
+      const u32x4_t* sn = gd_sh + s_next * (FR * 64);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        ahi[i] = sn[(wr * MI + i) * 64 + lane];
+        alo[i] = sn[(MTB + wr * MI + i) * 64 + lane];
+      }
+      wq[0][0] = sn[w_off];
+      wq[0][1] = sn[w_off + 64];
+    }
+    // the pieces of step ks + 2 have had three quarters of this step's MFMAs to land; nothing else of this wave is in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    s_cur = s_next;
+  }
+  gemm_epilogue<EPI, MI, NJ, WF>(a, acc, m_base, nt_base, wv, lane);
+}
+
 static int g_gemm_big_rows = 1024;   // tuning key 16: rows from which ddk_gemm uses the 128 x 512 block (0: never)
 void ddk_set_gemm_big_rows(int v) { g_gemm_big_rows = v; }
 static int launch_gemm_big(int epi, const GemmArgs& a_, hipStream_t st);
@@ -490,6 +613,43 @@ static int launch_gemm(int epi, const GemmArgs& a_, hipStream_t st) {
     case EPI_QKV_VIT: k_gemm<EPI_QKV_VIT, MI, NJ><<<grid, 256, 0, st>>>(a); break;
     default: DD_REQUIRE(false, "gemm: unknown epilogue %d", epi);
   }
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+static int g_gemm_dma = 1;        // dd_set_tuning key 20: 1 = the LDS-DMA block (round 6; 160 or 128 rows by the launch's rounds; 10 / 8: always that one), 0 = the register-staged 128 x 512 block
+void ddk_set_gemm_dma(int v) { g_gemm_dma = (v == 8 || v == 10) ? v : (v ? 1 : 0); }
+template <int MTB>
+static int launch_gemm_dma(int epi, const GemmArgs& a_, hipStream_t st) {
+  GemmArgs a = a_;
+  const int gx = (a.n_tiles + GB_NT - 1) / GB_NT;
+  a.grid_y = (a.M + 16 * MTB - 1) / (16 * MTB);
+  a.xcd_order = g_gemm_xcd_order && a.grid_y <= 8;
+  const size_t lds = (size_t)3 * (2 * MTB + GB_NT) * 64 * sizeof(u32x4_t);   // 156 KiB at MTB = 10
+  dim3 grid(gx * a.grid_y);
+#define GDK(E_, W_)                                                                                                               \
+  do {                                                                                                                            \
+    static bool attr = false;                                                                                                     \
+    if (!attr) {                                                                                                                  \
+      DD_HIP(hipFuncSetAttribute((const void*)k_gemm_dma<E_, W_, MTB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+      attr = true;                                                                                                                \
+    }                                                                                                                             \
+    k_gemm_dma<E_, W_, MTB><<<grid, 512, lds, st>>>(a);                                                                           \
+  } while (0)
+#define GD(E_)                  \
+  if (a.wf) GDK(E_, 1);         \
+  else GDK(E_, 0)
+  switch (epi) {
+    case EPI_STORE: GD(EPI_STORE); break;
+    case EPI_RESID: GD(EPI_RESID); break;
+    case EPI_SILU: GD(EPI_SILU); break;
+    case EPI_QKV: GD(EPI_QKV); break;
+    case EPI_ACT: GDK(EPI_ACT, 0); break;
+    case EPI_QKV_VIT: GDK(EPI_QKV_VIT, 0); break;
+    default: DD_REQUIRE(false, "gemm (160 x 512 block): epilogue %d not built", epi);
+  }
+#undef GD
+#undef GDK
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -532,7 +692,16 @@ int ddk_gemm(int epi, const GemmArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S >= 2 && (a.S & 1) == 0, "gemm: K=%d must be a multiple of 64", a.S * 32);
   if (g_gemm_big_rows > 0 && a.M >= g_gemm_big_rows &&
       (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_SILU || epi == EPI_QKV || ((epi == EPI_ACT || epi == EPI_QKV_VIT) && !a.wf)))
-    return launch_gemm_big(epi, a, st);
+  {
+    if (!g_gemm_dma) return launch_gemm_big(epi, a, st);
+    // 160- or 128-row blocks: whichever needs fewer (rounds of 256 workgroups) x (rows per block); a tie goes to the larger block
+    // (fewer operand bytes per flop).  16 x 640 rows: 160 everywhere; one 2,960-row prompt (config 5): gate/up 160, down_proj (152 / 192
+    // workgroups, less than one round either way) 128.  g_gemm_dma == 8 / 10 force one of them (A/B).
+    const long gx = (a.n_tiles + GB_NT - 1) / GB_NT;
+    const long r10 = (gx * ((a.M + 159) / 160) + 255) / 256 * 10, r8 = (gx * ((a.M + 127) / 128) + 255) / 256 * 8;
+    const bool ten = g_gemm_dma == 10 || (g_gemm_dma != 8 && r10 <= r8);
+    return ten ? launch_gemm_dma<10>(epi, a, st) : launch_gemm_dma<8>(epi, a, st);
+  }
   long big = (long)((a.n_tiles + 7) / 8) * ((a.M + 127) / 128);      // workgroups of the 128x128 tiling
   // (a.rowstat: the fused row statistics need a wave that owns whole 64-column blocks — the 4 x 4 and 4 x 8 tilings)
   if (big >= 150 || (epi == EPI_STORE && a.rowstat)) return launch_gemm<4, 4>(epi, a, st);

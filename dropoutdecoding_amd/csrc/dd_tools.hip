@@ -129,7 +129,7 @@ extern "C" size_t dd_tools_sampler_dbg_words(void) { return dd_dropout_sampler_d
 extern "C" unsigned int dd_tools_sampler_dbg_launches(void) { return dd_dropout_sampler_dbg_tag(); }
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
-  if (key == 8 || key == 11 || (key >= 13 && key <= 16)) return dd_set_tuning(key, value);
+  if (key == 8 || key == 11 || (key >= 13 && key <= 16) || key == 20) return dd_set_tuning(key, value);
   DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39 || key == 40 || key == 41 || key == 42 || key == 43 || key == 45 || key == 46 || key == 47 || key == 48 || key == 49 || key == 50,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
@@ -3066,5 +3066,34 @@ extern "C" int dd_tools_twist_probe(int launches, int wgs, int iters, int lds_by
     k_twist_probe<<<wgs, 1024, lds_bytes, st>>>(salt++, iters, mt_off, out_dev);
     DD_CHECK_LAUNCH();
   }
+  return DD_OK;
+}
+
+// ---- round 6: a stream that runs on a subset of the CUs, and a probe of where its workgroups land (tools/cu_partition_lab.py) ------------
+// hipExtStreamCreateWithCUMask: bit i of the 256-bit mask enables CU i in the driver's numbering; how that numbering maps onto the eight
+// XCDs is not documented here, so the probe reports what a mask really gives: every workgroup writes its XCC_ID and HW_ID and then holds
+// its CU for `hold` rounds of s_sleep, so that a grid of a few workgroups per CU spreads over every CU the stream may use.
+extern "C" int dd_tools_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out) {
+  DD_REQUIRE(mask && words >= 1 && words <= 8 && stream_out, "dd_tools_stream_create_cu_mask: bad arguments");
+  hipStream_t st = nullptr;
+  DD_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+  *stream_out = (void*)st;
+  return DD_OK;
+}
+extern "C" int dd_tools_stream_destroy(void* stream_) {
+  DD_HIP(hipStreamDestroy((hipStream_t)stream_));
+  return DD_OK;
+}
+__global__ __launch_bounds__(64) void k_cu_probe(uint32_t* out, int hold) {
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = (uint32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));       // XCC_ID
+    out[2 * blockIdx.x + 1] = (uint32_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID: CU / SH / SE ids
+  }
+  for (int i = 0; i < hold; ++i) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int dd_tools_cu_probe(uint32_t* out_dev, int wgs, int hold, void* stream_) {
+  DD_REQUIRE(out_dev && wgs >= 1 && hold >= 0, "dd_tools_cu_probe: bad arguments");
+  k_cu_probe<<<wgs, 64, 0, (hipStream_t)stream_>>>(out_dev, hold);
+  DD_CHECK_LAUNCH();
   return DD_OK;
 }

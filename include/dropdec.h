@@ -513,7 +513,8 @@ int dd_qformer_forward(dd_qformer* h, const int32_t* text_ids_dev, int n_text, c
  *   14 process default of the speculation policy of single-sequence steps (dd_lm_set_speculation: 0 never, 1 always,
  *      2 adaptive = default),
  *   15 XCD-aware block order of the prefill GEMM (default 1; same bits), 16 rows from which the prefill GEMM uses its
- *      128 x 512 LDS-staged block (default 1024; 0: never; same bits).
+ *      big LDS-staged block (default 1024; 0: never; same bits), 20 form of that block (default 1: 160 x 512, operand
+ *      fragments by LDS-DMA; 0: round 3's register-staged 128 x 512 block; same bits).
  * Kernel-variant experiment knobs and the timing hooks of bench.py / tools/ are not part of this library: they live in
  * libdropdec_tools.so (include/dropdec_tools.h). */
 int dd_set_tuning(int key, int value);

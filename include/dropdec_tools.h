@@ -131,6 +131,13 @@ int dd_tools_hold_probe(int kind, int launches, int wgs, int hold, unsigned int*
 int dd_tools_lds_overlap_probe(int lds_a, int wgs_a, int hold_a, int lds_b, int wgs_b, int hold_b, int launches_b, unsigned int* errors_dev,
                                void* stream_a, void* stream_b);
 
+/* Round 6 (prefill beside decode by CU partition, tools/cu_partition_lab.py): a HIP stream whose kernels run only on the CUs whose bits are
+ * set in mask[0..words) (hipExtStreamCreateWithCUMask; 8 words = 256 CUs), and a probe that reports where workgroups launched on a stream
+ * land: out_dev[2 i] = XCC_ID, out_dev[2 i + 1] = HW_ID of workgroup i, each holding its CU for `hold` rounds of s_sleep(64). */
+int dd_tools_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
+int dd_tools_stream_destroy(void* stream);
+int dd_tools_cu_probe(uint32_t* out_dev, int wgs, int hold, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
