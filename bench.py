@@ -214,7 +214,34 @@ def committed_profile(kernel: str, tag: str = ""):
                 stats_avg_us = round(float(row["AverageNs"]) / 1e3, 2)
     except Exception:
         pass
-    return {"traffic": traffic, "mfma_util": mfma_util, "stats_avg_us": stats_avg_us, "pmc_file": pmc, "stats_file": stats}
+    # the in-step figures describe the tree the profile was collected on.  tools/collect_profiles.sh writes the hash of the
+    # decode kernels' sources beside the summaries (profiles/rNN_sources.json); when it differs from this tree's, the line says so.
+    matches, note = None, "no source stamp beside the committed profile (collected before round 6)"
+    try:
+        import re
+        tag_r = re.match(r"profiles/(r\d\d)_", stats or "").group(1)
+        stamp = json.load(open(os.path.join(ROOT, "profiles", f"{tag_r}_sources.json")))
+        now = decode_sources_hash()
+        matches = stamp.get("decode_sources_sha256") == now
+        note = ("the committed profile was collected on these decode-kernel sources" if matches else
+                f"the decode-kernel sources changed since the committed profile ({tag_r}) was collected: achieved / frac describe that tree; "
+                "achieved_isolated / frac_isolated are measured in this run")
+    except Exception:
+        pass
+    return {"traffic": traffic, "mfma_util": mfma_util, "stats_avg_us": stats_avg_us, "pmc_file": pmc, "stats_file": stats,
+            "matches_tree": matches, "tree_note": note}
+
+
+DECODE_SOURCES = ["dd_gemv.hip", "dd_gemv_slices.h", "dd_attn_decode.hip", "dd_lm_kernels.hip", "dd_lm_kernels.h", "dd_lm_device.h", "dd_common.h"]
+
+
+def decode_sources_hash() -> str:
+    """sha256 over the sources of the decode step's kernels (what the committed per-kernel profile figures depend on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in DECODE_SOURCES:
+        h.update(open(os.path.join(ROOT, "dropoutdecoding_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def finishing_share(stats_file):
@@ -284,6 +311,31 @@ def sweep_traffic(stats_file, pmc_file, n_layers, sweeps, sequences):
                     "(DESIGN.md 3g: 190.6 GB in 35.5 ms = 5.4 TB/s); GBs_at_value below has the vision front-end and the prefill inside the time"}
 
 
+def measured_read_ceiling(tools):
+    """What a plain streaming READ reaches on THIS box, measured in this run (dd_hbm_read_bench, HIP events on the launch stream): 1 GiB windows
+    of a 6 GiB buffer (far beyond the 256 MiB memory-side cache), median of 9.  `peak` stays the 8 TB/s of the spec; this is the ceiling a
+    kernel that only reads can be held against (the guide's measured copy: 6.29 TB/s)."""
+    import ctypes as C
+    try:
+        buf = torch.empty(6 << 30, dtype=torch.uint8, device="cuda")
+        buf.zero_()
+        st = torch.cuda.current_stream().cuda_stream
+        vals, off, nbytes = [], 0, 1 << 30
+        for _ in range(9):
+            off = (off + nbytes + (512 << 20)) % ((6 << 30) - nbytes - 1)
+            off -= off % 4096
+            g = C.c_float()
+            if tools.dd_hbm_read_bench(buf.data_ptr() + off, nbytes, 1, 4096, C.byref(g), st) != 0:
+                return None
+            vals.append(g.value)
+        del buf
+        torch.cuda.empty_cache()
+        vals.sort()
+        return round(vals[len(vals) // 2], 1)
+    except Exception:
+        return None
+
+
 def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows8, wide, profile_tag=""):
     """The dominant kernel (gate/up decode GEMV of the member pass) timed alone with HIP events on its launch stream while cycling over
     the layers' weights, on an engine of its own created through libdropdec_tools.so (the timing hooks are not in the product library)."""
@@ -311,6 +363,7 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
     sweep_ms = eng.time_sweep(rows8, 5)
     sweep_bytes = eng.algorithmic_bytes(0)
     eng.close()
+    measured_read = measured_read_ceiling(tools)
     prof = committed_profile(kernel, profile_tag)
     achieved = by / (ms * 1e-3) / 1e9
     rows_what = ("the members of a group of sequences + the un-masked rows of another group riding in further operand planes" if dom_rows == 72
@@ -328,6 +381,12 @@ def roofline_leg(lm_cfg, family, weight_format, kv_format, T0, L, dom_rows, rows
                             "attention and finishing workgroups — since round 5 every one of them fits beside it —, so its own duration is longer than alone "
                             "while the step is shorter: group_step.frac_at_value is the step-level figure)" if in_step
                             else "isolated launches (no committed kernel trace names this kernel)"),
+            # the same two rates against what a plain read reaches on THIS box in THIS run (not the 8 TB/s of the spec): the kernel's distance from
+            # the memory system's own ceiling
+            "measured_read_GBs": measured_read, "measured_read_source": "dd_hbm_read_bench, 1 GiB windows of a 6 GiB buffer, median of 9, measured in this run",
+            "frac_of_measured": (round((in_step if in_step else achieved) / measured_read, 4) if measured_read else None),
+            "frac_of_measured_isolated": (round(achieved / measured_read, 4) if measured_read else None),
+            "profile_matches_tree": prof["matches_tree"], "profile_tree_note": prof["tree_note"],
             "achieved_isolated": round(achieved, 1), "frac_isolated": round(achieved / HBM_PEAK_GBS, 4),
             "finishing_share": finishing_share(prof["stats_file"]) if prof["stats_file"] and dom_rows == 72 else None,
             "traffic": prof["traffic"],
@@ -653,6 +712,11 @@ def main() -> int:
         if rider and roof.get("kernel_stats_file"):
             tr = sweep_traffic(roof["kernel_stats_file"], roof["traffic_source"]["file"], lm_cfg.num_layers, sweeps, B)
             if tr:
+                # PMC bytes of a layer of one sweep / its algorithmic bytes (the layer's matrices once + the sixteen caches a rider sweep reads:
+                # eight groups' members and eight riding rows) — 1.0 would mean nothing but weights and caches moves
+                alg_layer = (w_only - lm_cfg.vocab_size * lm_cfg.hidden_size * weight_bytes) / lm_cfg.num_layers + 16 * kv_seq / lm_cfg.num_layers
+                tr["algorithmic_bytes_per_layer_sweep"] = round(alg_layer)
+                roof["step_traffic_ratio"] = tr["step_traffic_ratio"] = round((tr["read_bytes_per_layer_sweep"] + tr["written_bytes_per_layer_sweep"]) / alg_layer, 3)
                 tr["GBs_at_value"] = round(tr["bytes_per_token"] * per_gpu / 1e9, 1)
                 tr["frac_at_value"] = round(tr["bytes_per_token"] * per_gpu / 1e9 / HBM_PEAK_GBS, 4)
             roof["group_step"]["memory_side_traffic"] = tr

@@ -15,6 +15,7 @@ from __future__ import annotations
 import fcntl
 import os
 import re
+import signal
 import subprocess
 import sys
 
@@ -26,7 +27,10 @@ TOOLS_LIB = os.path.join(HERE, "libdropdec_tools.so")
 TOOLS_SOURCES = ["dd_tools.hip"]      # only in libdropdec_tools.so
 SOURCES = ["dd_dropout.hip", "dd_lm_kernels.hip", "dd_gemv.hip", "dd_attn_decode.hip", "dd_prefill.hip", "dd_engine.hip", "dd_tp.hip", "dd_vision.hip"]
 # sources that libdropdec_tools.so takes in a second compilation with extra macros (A/B variants that must not be in the product)
-TOOLS_VARIANTS = {"dd_dropout.hip": ["-DDD_KEEP_SCRATCH_SAMPLER"]}
+TOOLS_VARIANTS = {"dd_dropout.hip": ["-DDD_KEEP_SCRATCH_SAMPLER"],
+                  # the slice GEMVs' timing experiments (dd_gemv_slices.h DD_TEXP: skipped stage-in, dropped partial sums, round-5 store
+                  # placement) are compiled into the tools library only
+                  "dd_gemv.hip": ["-DDD_TIMING_EXPERIMENTS"]}
 HEADERS = ["dd_common.h", "dd_lm_kernels.h", "dd_lm_device.h", "dd_gemv_slices.h", "dd_engine_internal.h", "dd_sampler_block.h",
            os.path.join(ROOT, "include", "dropdec_tools.h"), os.path.join(ROOT, "include", "dropdec.h")]
 ARCH = "gfx950"
@@ -167,7 +171,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     if os.environ.get("DD_NO_BUILD", "0") not in ("", "0"):
+        # from here on a compile WOULD start (stale tree, or force=True on a fresh one): a process that may not spawn hipcc stops here
         require_fresh()
+        raise RuntimeError("build(force=True) under DD_NO_BUILD / --no-build: this process may not compile (run "
+                           "`python3 -m dropoutdecoding_amd.build` from a process that has not touched the GPU)")
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     with open(os.path.join(bdir, ".lock"), "w") as lock:
@@ -243,10 +250,14 @@ def _build_locked(force: bool, verbose: bool, bdir: str) -> str:
         if verbose:
             print(" ".join(cmd))
         err_f = open(err_path, "w")
-        running.append((subprocess.Popen(cmd, stderr=err_f), cmd, o, stamp, want, tmp_o, err_path, err_f))
+        # its own session = its own process group: hipcc is a driver whose clang / lld children outlive a kill() of the driver alone
+        running.append((subprocess.Popen(cmd, stderr=err_f, start_new_session=True), cmd, o, stamp, want, tmp_o, err_path, err_f))
     if failed is not None:                             # one unit failed: the others are not worth waiting for
         for item in running:
-            item[0].kill()
+            try:
+                os.killpg(item[0].pid, signal.SIGKILL)   # the whole group, so that no child keeps writing the temporaries reap() unlinks
+            except (ProcessLookupError, PermissionError):
+                item[0].kill()
     while running:
         reap(block=True)
     if failed is not None:

@@ -64,6 +64,22 @@ static int dalloc(dd_lm* h, T** p, size_t n) {
     if (rc__ != DD_OK) return rc__; \
   } while (0)
 
+void dd_engine_bump_epoch();
+// member_logits for K > 16: one re-allocation to DD_MAX_MEMBERS rows.  Steps already enqueued may still read the old buffer, so the
+// device is drained first and the old buffer stays in the handle's list until destroy (2 MB); captured graphs hold the old pointer:
+// the tuning epoch moves, every cached graph of the process is re-captured on its next use.
+static int ensure_member_rows(dd_lm* h, int K) {
+  if (!h || K <= h->member_rows_cap) return DD_OK;
+  DD_REQUIRE(K <= MAX_MEMBERS, "K=%d members (1..%d)", K, MAX_MEMBERS);
+  DD_HIP(hipDeviceSynchronize());
+  float* p = nullptr;
+  RC(dalloc(h, &p, (size_t)MAX_MEMBERS * h->Vpad));
+  h->member_logits = p;
+  h->member_rows_cap = MAX_MEMBERS;
+  dd_engine_bump_epoch();
+  return DD_OK;
+}
+
 extern "C" int dd_lm_destroy(dd_lm* h) {
   if (!h) return DD_OK;
   for (void* p : h->allocs) (void)hipFree(p);
@@ -203,7 +219,10 @@ static int lm_create_impl(const dd_lm_config* c, dd_lm* parent, dd_lm** out) {
   DA(h->chunk_states, 32);
   DA(h->chunk_k, (size_t)32 * h->kv_dim);
   DA(h->chunk_v, (size_t)32 * h->kv_dim);
-  DA(h->member_logits, (size_t)MAX_MEMBERS * h->Vpad);
+  // (the one per-sequence buffer whose size follows DD_MAX_MEMBERS: 8.2 MB at 64 members and V = 32064 — 0.5 GB over 64 lanes —, so it
+  // starts at 16 rows, the reference's own lists have 3-8 entries, and grows once when a longer list arrives: ensure_member_rows)
+  h->member_rows_cap = 16;
+  DA(h->member_logits, (size_t)h->member_rows_cap * h->Vpad);
   DA(h->last_logits, h->Vpad);
   DA(h->last_hidden, d);
   DA(h->argmax_base, 4);
@@ -1034,6 +1053,7 @@ extern "C" int dd_lm_prefill_ensemble(dd_lm* h, const float* embeds, int T0, int
   RC(dd_lm_prefill(h, embeds, T0, span_start, span_len, stream_));
   if (K == 0) return DD_OK;
   DD_REQUIRE(K >= 1 && K <= MAX_MEMBERS && mprobs, "dd_lm_prefill_ensemble: K=%d out of range (1..%d)", K, MAX_MEMBERS);
+  RC(ensure_member_rows(h, K));
   DD_REQUIRE(span_start >= 1, "dd_lm_prefill_ensemble: the visual span must not start at position 0 (a fully masked "
                               "first row has no defined attention; the reference toggle exists for LLaVA only)");
   const int d = h->d, L = span_len;
@@ -1183,6 +1203,7 @@ extern "C" int dd_lm_step_base(dd_lm* h, const double* mprobs, int K, dd_rng* rn
     return DD_ESTATE;
   }
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS, "dd_lm_step: K=%d out of range (0..%d)", K, MAX_MEMBERS);
+  RC(ensure_member_rows(h, K));
   DD_REQUIRE(K == 0 || mprobs, "dd_lm_step: mprobs required");
   if (h->T_host + 1 >= h->T_cap) {
     dd_set_error("dd_lm_step: KV cache full (%d tokens)", h->T_cap);
@@ -1847,6 +1868,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
   hipStream_t st = (hipStream_t)stream_;
   DD_REQUIRE(lanes && n >= 1 && n <= GROUP_MAX_LANES, "dd_lm_group_step: 1..%d sequences per group (got %d)", GROUP_MAX_LANES, n);
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_group_step: bad K / mprobs");
+  for (int m = 0; lanes && m < n; ++m) RC(ensure_member_rows(lanes[m], K));
   dd_lm* h0 = lanes[0];
   DD_REQUIRE(h0, "dd_lm_group_step: null handle");
   dd_lm* owner = h0->wsrc ? h0->wsrc : h0;
@@ -2174,6 +2196,7 @@ static int decode_step_queued(dd_lm* h, const double* mprobs, int K, dd_rng* rng
     return DD_ESTATE;
   }
   DD_REQUIRE(K >= 0 && K <= MAX_MEMBERS && (K == 0 || mprobs), "dd_lm_step: bad K / mprobs");
+  RC(ensure_member_rows(h, K));
   if (h->T_host + 1 >= h->T_cap) {
     dd_set_error("dd_lm_step: KV cache full (%d tokens)", h->T_cap);
     return DD_ESTATE;
@@ -2232,6 +2255,7 @@ static int decode_step_queued(dd_lm* h, const double* mprobs, int K, dd_rng* rng
   return rc;
 }
 extern "C" int dd_lm_decode_step(dd_lm* h, const double* mprobs, int K, dd_rng* rng, const float* uniforms, void* stream) {
+  if (h && K > 16 && K <= MAX_MEMBERS) RC(ensure_member_rows(h, K));      // (before any capture starts)
   DD_REQUIRE(h, "dd_lm_decode_step: null handle");
   // queued steps never tell the host how their check went: "adaptive" speculates here like "always"
   return decode_step_queued(h, mprobs, K, rng, uniforms, stream, spec_mode_of(h) != 0);
@@ -2276,6 +2300,7 @@ static int replay_or_capture(dd_lm* h, unsigned long long key, hipStream_t st, b
 // Results are those of dd_lm_decode_step in every case; *held (optional) reports what the check said.  Falls back to
 // dd_lm_decode_step where the speculative step does not apply (K = 0 or > 8, injected uniforms, speculation switched off).
 extern "C" int dd_lm_decode_step_sync(dd_lm* h, const double* mprobs, int K, dd_rng* rng, void* stream, int* held) {
+  if (h && K > 16 && K <= MAX_MEMBERS) RC(ensure_member_rows(h, K));
   DD_REQUIRE(h, "dd_lm_decode_step_sync: null handle");
   DD_REQUIRE(h->tp_world == 1, "this handle is a tensor-parallel shard: drive it through dd_lm_tp_* (include/dropdec.h)");
   hipStream_t st = (hipStream_t)stream;
@@ -2380,6 +2405,8 @@ static int group_side_stream(dd_lm* h0) {
 // changed since it was captured; the cache lives in the first lane.
 extern "C" int dd_lm_group_step(dd_lm* const* lanes, int n, const double* mprobs, int K, dd_rng* const* rngs, void* stream_) {
   hipStream_t st = (hipStream_t)stream_;
+  if (K > 16 && K <= MAX_MEMBERS)                    // (before any capture starts: growing the members' logits drains the device)
+    for (int m = 0; lanes && m < n && m < GROUP_MAX_LANES; ++m) RC(ensure_member_rows(lanes[m], K));
   bool graphable = g_use_graph && st != nullptr && lanes && n >= 1 && n <= GROUP_MAX_LANES && lanes[0] && (K == 0 || mprobs);
   for (int m = 0; graphable && m < n; ++m)
     graphable = lanes[m] && lanes[m]->prefilled && lanes[m]->steps_since_prefill >= 1 &&

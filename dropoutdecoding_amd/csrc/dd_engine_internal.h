@@ -58,6 +58,7 @@ struct dd_lm {
   size_t gemv_part_floats = 0;
   u32x4_t *xop_d, *xop_q, *xop_ff;
   float *base_logits, *member_logits, *last_logits, *last_hidden;
+  int member_rows_cap = 0;    // rows member_logits holds: 16 at creation, DD_MAX_MEMBERS from the first step with K > 16 on (ensure_member_rows)
   int32_t *argmax_base, *member_tok, *member_vote, *tokens;
   uint8_t *keep, *drop, *drop_bits, *leak_bits;
   int32_t* n_drop;

@@ -54,6 +54,13 @@ struct SliceArgs {
 // round 5's last day, instead of at the end of the wave's stream)
 // (temporal bit 1, value 2: TIMING EXPERIMENT of the tools library — the kernels skip the operand planes' staging and compute on whatever the LDS
 // holds; how much of a launch the blocking stage-in costs.  Bit 2, value 4: the slice-pair kernels write no partial sums.  Never set by the product.)
+// The timing experiments (bits 1..3: garbage results, or the round-5 store placement) exist only in libdropdec_tools.so's build of this
+// header (build.py TOOLS_VARIANTS: -DDD_TIMING_EXPERIMENTS); in the product library the branches are compiled out.
+#ifdef DD_TIMING_EXPERIMENTS
+#define DD_TEXP(a_, bit_) ((a_).temporal & (bit_))
+#else
+#define DD_TEXP(a_, bit_) 0
+#endif
 __device__ __forceinline__ u32x4_t dd_ldw(int temporal, const u32x4_t* p) { return (temporal & 1) ? *p : __builtin_nontemporal_load(p); }
 
 // rstd(row) = 1 / sqrt(mean(x^2) + eps) from per-workgroup partial sums of squares; wave w of the calling workgroup
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
       }
     };
     if constexpr (PROG) {
-      if (!(a.temporal & 2)) {
+      if (!DD_TEXP(a, 2)) {
         issue_blk(0);
         commit_blk(0);
       }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
       if (!any) {                                      // no tile group: this wave only stages its share of the following blocks
 #pragma unroll
         for (int b = 1; b < NB; ++b) {
-          if (!(a.temporal & 2)) {
+          if (!DD_TEXP(a, 2)) {
             issue_blk(b);
             commit_blk(b);
           }
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
         return;
       }
     } else {
-      if (!(a.temporal & 2)) {
+      if (!DD_TEXP(a, 2)) {
         stage_issue(0, SPW);
         stage_commit(SPW);
       }
@@ -267,14 +274,14 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
       };
       auto pre = [&](int blk) {
         if constexpr (PROG) {
-          if (first_group && blk + 1 < NB && !(a.temporal & 2)) issue_blk(blk + 1);
+          if (first_group && blk + 1 < NB && !DD_TEXP(a, 2)) issue_blk(blk + 1);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
       auto post = [&](int blk) {
         if constexpr (PROG) {
           if (first_group && blk + 1 < NB) {           // workgroup-uniform: every wave with a tile group is in its first one
-            if (!(a.temporal & 2)) commit_blk(blk + 1);
+            if (!DD_TEXP(a, 2)) commit_blk(blk + 1);
             __syncthreads();
           }
         }
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   auto store_set = [&](int st) {                       // a set's two tiles are complete: each half of the lanes stores its tile
     const int my_gi = 2 * st + (hi_half ? 1 : 0);
     const int my_g = j + a.G * (wave + 8 * my_gi);      // = gidx[my_gi], as arithmetic (a lane-dependent index into gidx[] would put it in scratch)
-    if (my_gi < MAXG && my_gi < ng && !(a.temporal & 4)) {      // (temporal bit 2: timing experiment — no partial sums written)
+    if (my_gi < MAXG && my_gi < ng && !DD_TEXP(a, 4)) {      // (temporal bit 2: timing experiment — no partial sums written)
       const int l32 = (lane >> 4) * 8 + (lane & 7);
 #pragma unroll
       for (int h = 0; h < NG; ++h) *(f32x4_t*)&a.part[((((size_t)qs * n_tiles + my_g) * NG + h) << 7) + l32 * 4] = sum[st][h];
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, p0 + (size_t)u * wstep);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (!(a.temporal & 2)) stage(0);
+  if (!DD_TEXP(a, 2)) stage(0);
   __syncthreads();
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -496,19 +503,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
       }
-      if (half == 1 && (a.temporal & 8) && ((gi & 1) || gi == MAXG - 1)) store_set(gi >> 1);   // (timing experiment: the round-5 placement)
+      if (half == 1 && DD_TEXP(a, 8) && ((gi & 1) || gi == MAXG - 1)) store_set(gi >> 1);   // (timing experiment: the round-5 placement)
     }
     if (half == 0) {
       // (requesting the second slice's pieces BEFORE this barrier — their latency beside the slower waves' last tile — was measured: no gain,
       // 60 registers; tools/seq_lab.hip, profiles/r05_lab/)
       __syncthreads();                                 // every wave has finished reading slice 2 qs
-      if (!(a.temporal & 2)) stage(1);
+      if (!DD_TEXP(a, 2)) stage(1);
       __syncthreads();
     }
   }
   // Every partial sum is written HERE, after the wave's last weight request has been consumed: gfx950 counts loads and stores in one counter
   // (vmcnt) that retires in order, so a store issued in mid-stream makes every later weight piece wait for the store's acknowledgement.
-  if (!(a.temporal & 8)) {
+  if (!DD_TEXP(a, 8)) {
 #pragma unroll
     for (int st = 0; st < NSET; ++st) store_set(st);
   }

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(512) void k_gemm_dma(GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     mm(2, wq[0]);
     __builtin_amdgcn_sched_barrier(0);
-    mm(3, wq[1]);
+    mm(3, wq[1]);                                              // (s_setprio(1) around the step's MFMAs: measured 2 % slower)
     __builtin_amdgcn_sched_barrier(0);
     if (ks + 1 < S) {                                          // stage (ks + 1) % 3 was published by the barrier that ended step ks - 1
       const u32x4_t* sn = gd_sh + s_next * (FR * 64);

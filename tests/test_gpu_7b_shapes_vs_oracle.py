@@ -165,10 +165,13 @@ def _report(checks, what):
 
 
 def _lanes(E, cfg, n, family, max_visual, **kw):
+    import time
+    t0 = time.time()
     engines = []
     for i in range(n):
         engines.append(E.DropoutEngine(cfg, family=family, max_seq=max_visual + 96, max_visual=max_visual, seed=50 + i, kv_format="fp16",
                                        share_weights_with=engines[0] if engines else None, **kw))
+    print(f"\n[{n} engines created in {time.time() - t0:.0f} s]", end="")
     return engines
 
 
@@ -181,6 +184,8 @@ def _inputs(n, d, L, seed):
 
 
 def _group_vs_oracle(E, engines, refs, embs, spans, probs, steps, what):
+    import time
+    t0 = time.time()
     for i, (e, emb, (s0, L)) in enumerate(zip(engines, embs, spans)):
         e.rng.manual_seed(50 + i)
         e.prefill(emb.cuda(), s0, L)
@@ -195,6 +200,7 @@ def _group_vs_oracle(E, engines, refs, embs, spans, probs, steps, what):
             c.step(s)
     for c in checks:
         c.tokens()
+    print(f"\n[engine side: {len(engines)} lanes, prefill + {steps} group steps + comparisons in {time.time() - t0:.0f} s]", end="")
     _report(checks, what)
 
 

@@ -216,6 +216,27 @@ def test_masks_random_trials_vs_oracle(ops, fam, mode):
         np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), ref.numpy(), err_msg=f"trial {trial} L={L} probs={probs}")
 
 
+@pytest.mark.parametrize("fam,mode", MODES)
+def test_masks_and_vote_at_the_member_limit_K64(ops, fam, mode):
+    """K = DD_MAX_MEMBERS = 64 through the stand-alone operators — 64 probabilities in the kernel's argument table, 64 rows
+    of flags and counts (the cumulative rule carries a member's zeros through all 64), a 64-way vote — against the oracle; K = 65 refused."""
+    rs = np.random.RandomState(64)
+    for L in (33, 576, 2928):
+        probs = [float(p) for p in np.linspace(0.1, 0.9, 64)]
+        epi = torch.from_numpy((rs.rand(L) * 2).astype(np.float32))
+        keep = torch.from_numpy(rs.rand(L) < 0.05)
+        uni = torch.from_numpy(rs.rand(64, L).astype(np.float32))
+        ref = DR.sample_masks(epi, probs, keep, mode, uni)
+        drop, nd = ops.sample_masks(epi.cuda(), probs, keep.cuda(), mode, uniforms=uni.cuda())
+        np.testing.assert_array_equal(drop.cpu().numpy().astype(bool), ref.numpy(), err_msg=f"{fam} L={L}")
+        assert nd.cpu().tolist() == [int(r.sum()) for r in ref]
+    for _ in range(20):
+        ids = rs.randint(0, 6, 64)
+        assert ops.select_by_vote(torch.from_numpy(ids).cuda()) == DR.vote(ids.tolist())
+    with pytest.raises(Exception):
+        ops.sample_masks(torch.rand(10).cuda(), [0.5] * 65, None, mode, uniforms=torch.rand(65, 10).cuda())
+
+
 def test_mask_rng_stream_continues_across_steps(ops):
     """Two steps of K=3 consume 6 consecutive rand_like(epi) draws of one stream (reference llava.py:650)."""
     L, probs = 100, [0.3, 0.5, 0.7]

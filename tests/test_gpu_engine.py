@@ -229,6 +229,44 @@ def test_three_packed_sweeps_K20(E):
     _rand_case(E, FAMILY_LLAVA, rc, 40, 3, 30, [0.1 + 0.035 * i for i in range(20)], 5)
 
 
+def test_eight_packed_sweeps_K64_the_limit(E):
+    """DD_MAX_MEMBERS itself — 64 members = eight packed sweeps, eight bit planes of drop flags, a full 64-entry
+    probability table; the members' logits buffer starts at 16 rows and grows on the first such step (dd_engine.hip ensure_member_rows),
+    with a K = 5 step BEFORE (graphs captured against the small buffer must not be replayed) and the NeXT rule's reset masks after."""
+    rc = RefCfg(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    cfg = E.LMConfig(512, 256, 512, 2, 2, 2, 128, 1e-5, 10000.0)
+    w = random_weights(rc, 21, 0.05)
+    probs64 = [0.1 + 0.0125 * i for i in range(64)]
+    for family in (FAMILY_LLAVA, FAMILY_NEXT):
+        eng = E.DropoutEngine(cfg, family=family, max_seq=64, max_visual=30, seed=3)
+        eng.load_state_dict(w)
+        emb = torch.randn(40, 256, generator=torch.Generator().manual_seed(3)) * 0.8
+        eng.prefill(emb.cuda(), 3, 30)
+        eng.decode_step(probs64[:5])
+        eng.decode_step(probs64[:5])                          # (replayed from the graph cache)
+        first = eng.tokens()
+        eng.rng.manual_seed(3)
+        eng.prefill(emb.cuda(), 3, 30)
+        ref = RefDecoder(family, rc, w, probs64, seed=3)
+        want = ref.generate(emb, 3, 30, 5)
+        for s in range(4):
+            eng.decode_step(probs64)
+            st, r = eng.last_step(), ref.records[s]
+            np.testing.assert_array_equal(st["drop"], r.drop, err_msg=f"{family} step {s}")
+            assert st["masked_numbers"].tolist() == r.masked_numbers
+            assert st["member_argmax"].tolist() == r.member_argmax and st["winner"] == r.winner, (family, s)
+            assert close(eng.logits(), r.logits), (family, s)
+        assert eng.tokens() == want
+        eng.rng.manual_seed(3)
+        eng.prefill(emb.cuda(), 3, 30)                        # and back to a short list on the grown buffer
+        eng.decode_step(probs64[:5])
+        eng.decode_step(probs64[:5])
+        assert eng.tokens() == first
+        with pytest.raises(Exception):
+            eng.decode_step(probs64 + [0.5])                  # 65 members
+        eng.close()
+
+
 def test_gqa_group4_long_context_many_key_tiles(E):
     """Mistral-style GQA (8 q heads / 2 kv heads), theta 1e6, 300-token prefix: 5 key tiles per kv head, visual span
     crossing tile boundaries."""

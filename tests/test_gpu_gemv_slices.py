@@ -123,3 +123,37 @@ def test_fp8_slice_kernels_bit_identical_to_wave_split_kernels(E, name, dff, n_l
     e.set_speculation("default")
     for e in reversed(engines):
         e.close()
+
+
+@pytest.mark.parametrize("n_lanes", [2, 4])
+def test_progressive_stage_in_leaves_the_same_bits(E, n_lanes):
+    """the progressive stage-in of the operand planes (dd_gemv_slices.h PROG, tools key 49: the default at two and four
+    planes, where it pays 3 %) is claimed to give the same bits as the blocking stage-in it replaced — here both run: 2 lanes (16 member
+    rows, NG = 2) and 4 lanes (32 rows, NG = 4), LLaMA-7B widths, every logit, token and KV checksum equal."""
+    from dropoutdecoding_amd import _lib
+    T = _lib.load_tools()
+    d = 4096
+    cfg = E.LMConfig(2048, d, 11008, 2, 32, 32, 128, 1e-5, 10000.0)
+    L = 24
+    engines = _group(E, cfg, n_lanes, "llava-1.5", L, lib=T)
+    gen = torch.Generator().manual_seed(21)
+    embs = [(torch.randn(L + 6 + i, d, generator=gen) * 0.5).cuda() for i in range(n_lanes)]
+    spans = [(2 + (i % 3), L) for i in range(n_lanes)]
+    probs = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
+    outs = []
+    try:
+        for prog in (1, 0, 1):
+            T.dd_tools_set_tuning(49, prog)
+            outs.append(_run(E, engines, embs, spans, probs, 4, slices=True, graph=False))
+    finally:
+        T.dd_tools_set_tuning(49, 1)
+    for o in outs[1:]:
+        assert o[1] == outs[0][1]
+        for sa, sb in zip(o[0], outs[0][0]):
+            for (la, ba), (lb, bb) in zip(sa, sb):
+                np.testing.assert_array_equal(la, lb)
+                np.testing.assert_array_equal(ba, bb)
+        for x, y in zip(o[2], outs[0][2]):
+            np.testing.assert_array_equal(x, y)
+    for e in reversed(engines):
+        e.close()

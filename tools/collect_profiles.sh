@@ -13,6 +13,11 @@ OUT=gpurun_out
 # stale would spawn hipcc (an exec from a GPU-initialised process: refused / fatal on this pool).  DD_NO_BUILD makes build.build() raise instead.
 python3 -m dropoutdecoding_amd.build > $OUT/${R}_build.log 2>&1 || { echo "build failed"; tail -5 $OUT/${R}_build.log; exit 1; }
 export DD_NO_BUILD=1
+# the sources the per-kernel figures belong to (bench.py: roofline.profile_matches_tree)
+python3 -c "
+import json, sys; sys.path.insert(0, '.')
+import bench
+json.dump({'decode_sources_sha256': bench.decode_sources_hash(), 'files': bench.DECODE_SOURCES}, open('$OUT/${R}_sources.json', 'w'), indent=1)"
 if [ "$WHAT" = stats ]; then
   rm -rf /tmp/${R}_stats
   timeout 1000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${R}_stats -- python3 bench.py --steps 1 --warmup 0 --n-new 32 --no-cpu-baseline --no-roofline --single-images 1 > $OUT/${R}_bench_under_rocprof.log 2>&1

@@ -6,6 +6,7 @@
 // changes one ingredient at a time: the operand stage-in (SliceArgs::temporal bit 1), the partial-sum stores (bit 2), the rstd prologue of
 // workgroup 0 (ssq_in), the tile count (1,376 = 2.97 tiles per wave over 58 workgroups per slice pair = 232 workgroups on 256 CUs; 1,392: even;
 // 1,536 over 64 per pair: 256 workgroups, three tiles per wave), and the data (constant / random bit patterns).
+#define DD_TIMING_EXPERIMENTS 1   // the timing-only branches of dd_gemv_slices.h (DD_TEXP) are compiled out of the product library
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
