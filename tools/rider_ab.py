@@ -14,11 +14,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 settings = sys.argv[2:] or ["26=0", "26=1"]
 steps = 24
 engs = []
+C5 = os.environ.get("DD_AB_MODEL", "") == "mistral-fp8"       # BASELINE config 5's shapes: GQA 4, 2,928 visual tokens, fp8 matrices
+T0, LV = (2960, 2928) if C5 else (608, 576)
 for i in range(B):
-    engs.append(lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format="fp16",
-                                 share_weights_with=engs[0] if engs else None))
+    engs.append(lm.DropoutEngine(lm.MISTRAL_7B if C5 else lm.LLAVA15_7B, family=lm.FAMILY_NEXT if C5 else lm.FAMILY_LLAVA, max_seq=T0 + 176, max_visual=LV,
+                                 kv_format="fp16", weight_format="fp8" if C5 else "bf16", share_weights_with=engs[0] if engs else None))
 engs[0].load_synthetic(0, 0.02)
-embs = [torch.randn(608, 4096, generator=torch.Generator().manual_seed(i)).cuda() for i in range(B)]
+embs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(i)).cuda() for i in range(B)]
 L = _lib.load()
 first = None
 for rep in range(2):
@@ -28,7 +30,7 @@ for rep in range(2):
             L.dd_tools_set_tuning(k, v)
         for e, x in zip(engs, embs):
             e.rng.manual_seed(24)
-            e.prefill(x, 5, 576)
+            e.prefill(x, 5, LV)
         g = lm.EngineGroup(engs)
         for _ in range(4):
             g.decode_step(PROBS)
