@@ -551,6 +551,8 @@ def main() -> int:
         # batches back to back: while one set of lanes decodes, the next batch's CLIP + prefill run on a second stream
         pipe = GroupPipeline(model, lanes=B)
         pipe.prefill_chunk = max(1, args.prefill_chunk)
+        if args.config == 5:
+            pipe.tower_chunk = 6          # two tower calls of three 5-tile images each (16 tiles per call), ahead of 4-prompt prefill passes
 
     def batch_inputs(i, n=B):
         out = []

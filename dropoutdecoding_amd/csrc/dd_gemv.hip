@@ -938,10 +938,12 @@ static int launch_slices_fp8(const SliceArgs& sa, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_fp8<NG, SPW2, CH, UW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  NOTE_KERNEL("k_gemv_slices_fp8<%d, %d, %d, %d, 0>", NG, SPW2, CH, UW);
+  NOTE_KERNEL("k_gemv_slices_fp8<%d, %d, %d, %d, 0, 0>", NG, SPW2, CH, UW);
   k_gemv_slices_fp8<NG, SPW2, CH, UW><<<(8 / CH) * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;
 }
+int g_fp8_xpf = 1;       // dd_tools_set_tuning key 52: the nine-plane fp8 kernel's operand fragments through a ring, five reads ahead of their MFMAs
+                         // (default; 0: requested where the compiler puts them — one MFMA ahead; same bits)
 template <int NG, int SPW2, int CS2, int UW>
 static int launch_slices_fp8c(const SliceArgs& sa, hipStream_t st) {
   constexpr size_t smem = (size_t)2 * CS2 * NG * 1024;
@@ -1125,6 +1127,16 @@ static int try_slices9_fp8(int epi, const GemvArgs& a, hipStream_t st) {
     RC_(launch_slices_fp8c<9, 28, 4, 4>(sa, st));
   } else {
     sa.G = (nt + 7) / 8 < 32 ? (nt + 7) / 8 : 32;        // one round of workgroups (one per CU: 144 KiB of operands each)
+    if (g_fp8_xpf) {
+      constexpr size_t smem = (size_t)2 * 8 * 9 * 1024;
+      static bool attr = false;
+      if (!attr) {
+        DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_fp8<9, 8, 1, 8, 0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+      }
+      NOTE_KERNEL("k_gemv_slices_fp8<9, 8, 1, 8, 0, 6>");
+      k_gemv_slices_fp8<9, 8, 1, 8, 0, 6><<<8 * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
+    } else
     RC_(launch_slices_fp8<9, 8, 1, 8>(sa, st));
   }
   switch (epi) {

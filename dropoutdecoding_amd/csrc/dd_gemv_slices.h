@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // SPW2 = 64-k steps per slice (K / 512); CH = slices per workgroup (2: the pair is added here, half the partial sums);
 // UW = weight loads in flight per wave (a divisor of SPW2).  A wave owns whole tiles g = j + G (wave + 8 i) over its slice(s).
 // grid = (8 / CH) * G workgroups of 512 threads; dynamic LDS = CH * 2 * SPW2 * NG KiB.
-template <int NG, int SPW2, int CH, int UW, int EPI_TAG = 0>
+template <int NG, int SPW2, int CH, int UW, int EPI_TAG = 0, int XPF = 0>
 __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
   static_assert(SPW2 % UW == 0, "loads in flight must divide the slice");
   constexpr int NB = SPW2 / UW;                        // weight blocks per (tile, slice)
@@ -607,10 +607,26 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
         u32x4_t k0, k1;
         fp8x16_to_bf16(wc[u], k0, k1);
         const u32x4_t* x0 = xs + ((size_t)(ch * 2 * SPW2 + 2 * (s0 + u)) * NG) * 64 + lane;
+        if constexpr (NG >= 8 && XPF > 0) {
+          // round 6: the operand fragments through a ring of XPF registers sets, XPF - 1 reads ahead of the MFMA that consumes them.  Left to
+          // the compiler a fragment is requested one MFMA (16 cycles) before its use, an LDS read takes several times that, and the
+          // nine-plane loop runs at the LDS latency: 18 fragments per 1 KiB of weights.  Fragment i = (plane i >> 1, half i & 1): the
+          // MFMA order per accumulator is unchanged.
+          u32x4_t fr[XPF];
+#pragma unroll
+          for (int i = 0; i < XPF - 1; ++i) fr[i] = x0[(size_t)(((i & 1) ? NG : 0) + (i >> 1)) * 64];
+#pragma unroll
+          for (int i = 0; i < 2 * NG; ++i) {
+            if (i + XPF - 1 < 2 * NG) fr[(i + XPF - 1) % XPF] = x0[(size_t)((((i + XPF - 1) & 1) ? NG : 0) + ((i + XPF - 1) >> 1)) * 64];
+            acc[i >> 1] = dd_mfma16<0>((i & 1) ? k1 : k0, fr[i % XPF], acc[i >> 1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
 #pragma unroll
         for (int h = 0; h < NG; ++h) {
           acc[h] = dd_mfma16<0>(k0, x0[(size_t)h * 64], acc[h]);
           acc[h] = dd_mfma16<0>(k1, x0[(size_t)(NG + h) * 64], acc[h]);
+        }
         }
       }
       if (b % NB == NB - 1) {                          // the slice's chain is complete
@@ -634,6 +650,10 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
   }
 }
 
+// (Round 6, measured and NOT kept: the same kernel with TWO tiles per wave in lock-step, every operand fragment feeding both tiles' MFMAs —
+// half the LDS reads per weight byte.  Bit-identical, 255 VGPRs, and slower: Mistral-7B's gate/up at 72 rows 39.0 -> 42.2 us alone, the 64-lane
+// step 44.3 -> 45.6 ms.  The nine-plane fp8 kernel is bound neither by the LDS bandwidth nor — XPF, above: 40.5 -> 38.7 us — much by its latency;
+// profiles/r06_lab/fp8_two_tiles_per_wave.log, fp8_fragment_ring.log.)
 // The same for LONG K (down_proj of Mistral-7B: K = 14336, 28 steps of 64 k per slice) at four / eight / nine operand planes: a slice of
 // all planes does not fit the LDS (28 x 2 x NG KiB), so it is staged in chunks of CS2 steps — the next chunk's operand pieces are
 // requested into registers at the start of the current chunk and committed between two barriers, the weight queue runs on across the

@@ -60,6 +60,42 @@ class CustomLlavaNextForConditionalGeneration(DropoutVLM):
             feats = torch.cat(list(feats), dim=0)
         return feats
 
+    def _visual_embeds_batch(self, inputs_list):
+        """One tower call for the anyres tiles of SEVERAL images (dd_vit_forward takes up to 16 tiles as one matrix: three 5-tile images
+        = 9,600 rows instead of 3,200 per call, so the tower's GEMMs launch three times the workgroups — an N = 1024 projection over one
+        image's tiles is 40 workgroups on 256 CUs); every tile goes through the tower on its own rows, so each image's tokens are bit for
+        bit those of its own call.  The unpad / newline packing stays per image (HF index arithmetic)."""
+        if self.tower_hip is None or any(inp.get("pixel_values") is None or inp.get("image_sizes") is None for inp in inputs_list):
+            return [self._visual_embeds(**inp) for inp in inputs_list]
+        from transformers.models.llava_next.modeling_llava_next import image_size_to_num_patches
+        tiles = []
+        for inp in inputs_list:
+            n = image_size_to_num_patches(image_size=inp["image_sizes"][0], grid_pinpoints=self.config.image_grid_pinpoints,
+                                          patch_size=self.config.vision_config.image_size)
+            pv = inp["pixel_values"].to(self.device)
+            tiles.append(pv[0][:n] if pv.dim() == 5 else pv[:n])
+        out, i = [None] * len(inputs_list), 0
+        while i < len(inputs_list):
+            j, total = i, 0
+            while j < len(inputs_list) and total + tiles[j].shape[0] <= 16 and (j == i or tiles[j].shape[1:] == tiles[i].shape[1:]):
+                total += tiles[j].shape[0]
+                j += 1
+            if j == i:                                                    # (an image of more than 16 tiles: its own path)
+                out[i] = self._visual_embeds(**inputs_list[i])
+                i += 1
+                continue
+            feats = self.tower_hip(torch.cat(tiles[i:j], dim=0))          # [tiles of images i..j-1, 576, d] fp32
+            at = 0
+            for k in range(i, j):
+                f = feats[at:at + tiles[k].shape[0]]
+                at += tiles[k].shape[0]
+                packed, _ = self._hf.pack_image_features([f], inputs_list[k]["image_sizes"].to(self.device),
+                                                         vision_feature_select_strategy="default",
+                                                         image_newline=self._hf.image_newline.float())
+                out[k] = torch.cat(list(packed), dim=0) if isinstance(packed, (list, tuple)) else packed
+            i = j
+        return out
+
     def _decode_loop(self, n_new, eos, chunk: int = 16):
         # settings['use_random'] is read at every step in the reference (llavanext.py:547); the engine's mode is
         # fixed per sequence, which is equivalent as long as the flag does not change mid-generation.

@@ -379,6 +379,8 @@ class GroupPipeline:
         self.sets = [[model] + [model.spawn_lane() for _ in range(lanes - 1)], [model.spawn_lane() for _ in range(lanes)]]
         self.pre_stream = torch.cuda.Stream(device=model.device)
         self.prefill_chunk = 16          # sequences per LM prefill pass (dd_lm_prefill_group); 1: one prefill per image
+        self.tower_chunk = None          # images per vision-tower call (None: as many as a prefill pass takes); LLaVA-NeXT: 6 = two calls of
+                                         # three 5-tile images (a tower call takes 16 tiles) while the LM prefill takes 4 prompts per pass
 
     def _stage(self, lanes, batch, kw):
         """-> per-image closures that each enqueue one image's front-end + prefill on the second stream"""
@@ -389,7 +391,7 @@ class GroupPipeline:
                 return False
             if not state["vis"]:                       # the vision tower for the next chunk of images, one call
                 with torch.cuda.stream(self.pre_stream):
-                    nxt = [inp for _, inp in state["todo"][:self.prefill_chunk]]
+                    nxt = [inp for _, inp in state["todo"][:(self.tower_chunk or self.prefill_chunk)]]
                     state["vis"] = _batched_visuals(state["todo"][0][0], nxt)
                 return True
             m, inp = state["todo"].pop(0)

@@ -59,7 +59,8 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * (so that it cannot share a CU with a slice GEMV), 40 the branches' streams on disjoint CU masks, 41 CU-mask only the attention launches,
  * 42 bit mask of kernel families launched on the UNMASKED stream while 40 is on (1 embed, 2 GEMVs, 4 attention, 8 finishing kernels),
  * 43 the fp32-cache tile pass with scalar instead of packed FP32 multiply-adds in its P.V step (tools library only: the product library has
- * no packed FP32 at all).  Keys of
+ * no packed FP32 at all), 52 (round 6) the nine-plane fp8 slice kernel's operand fragments through a ring read five ahead of their MFMAs
+ * (default 1; 0: where the compiler requests them; same bits).  Keys of
  * dd_set_tuning are forwarded.  Every call starts a new epoch of the step-graph
  * keys: a step captured under other settings is never replayed. */
 int dd_tools_set_tuning(int key, int value);

@@ -299,6 +299,18 @@ def test_configs_4_and_5_through_their_drop_in_classes_at_full_size():
         assert out.shape == (1, 24) and out[0, :20].tolist() == ids[0].tolist()
         assert n.start_image_pos == [4] and n.end_image_pos == [4 + 2928 - 1] and n.start_generation_pos == 19 + 2928
         assert n.image_features[1].shape == (1, 2928, 10)
+        # round 6: the anyres tiles of several images in ONE tower call (three 5-tile images = 15 of the 16 tiles a call takes, the fourth
+        # in a call of its own): every image's visual tokens bit for bit those of its own call, and the ids of generate_group with them
+        kws = [dict(input_ids=ids, pixel_values=torch.randn(1, 5, 3, 336, 336, generator=g), image_sizes=torch.tensor([[672, 672]])) for _ in range(4)]
+        vis = n._visual_embeds_batch([{k: v for k, v in kw.items() if k != "input_ids"} for kw in kws])
+        for kw, v in zip(kws, vis):
+            one = n._visual_embeds(pixel_values=kw["pixel_values"], image_sizes=kw["image_sizes"])
+            assert v.shape == one.shape == (2928, 4096)
+            assert torch.equal(v, one)
+        lanes = [n.spawn_lane(), n.spawn_lane()]
+        outs = generate_group(lanes, kws[:2], max_new_tokens=3, eos_token_id=[])
+        for kw, o in zip(kws[:2], outs):
+            assert o.tolist() == n.spawn_lane().generate(**kw, max_new_tokens=3, eos_token_id=[]).tolist()
     finally:
         ddc.settings.clear()
         ddc.settings.update(saved)

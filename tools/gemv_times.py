@@ -15,7 +15,9 @@ for kv in sys.argv[1:]:                      # key=value: dd_tools_set_tuning; r
         row_sets = (int(v_),)
     else:
         _lib.load().dd_tools_set_tuning(int(k_), int(v_))
-e = lm.DropoutEngine(lm.LLAVA15_7B, family=lm.FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format="fp16")
+C5 = os.environ.get("DD_AB_MODEL", "") == "mistral-fp8"       # BASELINE config 5's matrices: Mistral-7B shapes, fp8 tiles
+e = lm.DropoutEngine(lm.MISTRAL_7B if C5 else lm.LLAVA15_7B, family=lm.FAMILY_NEXT if C5 else lm.FAMILY_LLAVA, max_seq=784, max_visual=576, kv_format="fp16",
+                     weight_format="fp8" if C5 else "bf16")
 e.load_synthetic(0, 0.02)
 e.prefill(torch.randn(608, 4096, generator=torch.Generator().manual_seed(0)).cuda(), 5, 576)
 names = {0: "qkv", 1: "o_proj", 2: "gate/up", 3: "down"}
