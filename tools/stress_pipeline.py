@@ -38,6 +38,8 @@ model = M.from_synthetic(max_new_tokens=N_NEW + 8)
 eng = model.engine
 pipe = GroupPipeline(model, lanes=B)
 pipe.prefill_chunk = 4 if cfg_no == 5 else 16
+if cfg_no == 5:
+    pipe.tower_chunk = 6              # as bench.py --config 5: the anyres tiles of three images per vision-tower call (round 6)
 lanes_all = pipe.sets[0] + pipe.sets[1]
 prompt_len = 32
 
