@@ -40,39 +40,43 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   const u32x4_t* xp = a.xop + (size_t)s0 * 64 + lane;
   auto ldw = [](const u32x4_t* p) -> u32x4_t { return NT ? __builtin_nontemporal_load(p) : *p; };
 
-  // Everything the epilogue needs from memory is requested BEFORE the weight stream so its latency hides behind it:
-  // the folded RMSNorm's rstd (wave w assembles row w's sum of squares from the producer's slots), the residual
-  // input + next norm weight (EPI_RESID) and the rotary cos/sin (EPI_QKV).  The sum-of-squares slots are only
-  // REQUESTED here; they are reduced after the first weight batch has been issued (loads return in order, so waiting
-  // on them does not wait on the weights behind them).
+  // What the epilogue needs from memory is REQUESTED before the weight stream and USED after it — by every thread, at clamped addresses,
+  // with no divergent branch around a load.  (Round 6: the form before this one loaded inside `if (threadIdx.x < 128 && em < a.nb)` and reduced
+  // the rows' rstd before the stream; the compiler answers a load inside a divergent block with `s_waitcnt vmcnt(0)` at the block's end,
+  // and the dependent ones — the row's state pointer out of the argument table, its position, the rotary entry at that position — queued
+  // up: two to four memory round trips in EVERY workgroup before its first weight request, with the whole chip waiting at a kernel's start.)
+  // Up front: the sum-of-squares slots of row `wave` (one 16-byte load per lane covers 256 slots: every workgroup of the launch reads these
+  // same few lines, so the request count matters), the residual input + next norm weight (EPI_RESID), the row's state pointer (EPI_QKV /
+  // EPI_STORE).  After the stream: the rstd, and the dependent loads — position -> rotary cos / sin, the finished flag — which then hit in L2.
   const bool has_ssq = a.ssq_in != nullptr;
   f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
-  // row `wave`'s slots are contiguous: one 16-byte load per lane covers 256 slots (every workgroup of the launch reads
-  // these same few lines, so the request count matters: strided 4-byte reads here cost ~2 us per launch)
-  if (has_ssq && 4 * lane < a.ssq_n) sv = *(const f32x4_t*)(a.ssq_in + (size_t)wave * a.ssq_ld + 4 * lane);
-  float pre0 = 0.f, pre1 = 0.f;
-  {
-    const int em = threadIdx.x & 7, en = threadIdx.x >> 3;
-    if (threadIdx.x < 128 && em < a.nb) {
-      if (EPI == EPI_RESID) {
-        pre0 = a.out[(size_t)em * a.ldo + tile0 * 16 + en];
-        pre1 = a.normw_next[tile0 * 16 + en];
-      } else if (EPI == EPI_QKV) {
-        if (tile0 < a.q_tiles + a.k_tiles) {
-          int ht = tile0 < a.q_tiles ? tile0 : tile0 - a.q_tiles;
-          int f = (ht & 7) * 8 + (en & 7);
-          const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
-          int pos = sp->pos;
-          pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
-          pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
-        }
-      } else if (EPI == EPI_STORE) {
-        // logits of a sequence that already emitted its EOS are not overwritten by look-ahead steps (DDState::done)
-        const DDState* sp = a.state_rows[em] ? a.state_rows[em] : a.state;
-        if (sp && sp->done) pre0 = 1.f;
-      }
-    }
+  if (has_ssq) {                                       // (wave-uniform branch)
+    const int i4 = min(4 * lane, max((a.ssq_n - 1) & ~3, 0));    // lanes past the last slot re-read it: masked where the slots are added up
+    sv = *(const f32x4_t*)(a.ssq_in + (size_t)wave * a.ssq_ld + i4);
   }
+  const int em = threadIdx.x & 7, en = (threadIdx.x >> 3) & 15, emc = min(em, a.nb - 1);
+  float pre0 = 0.f, pre1 = 0.f;
+  const DDState* sp_row = nullptr;
+  if (EPI == EPI_RESID) {
+    pre0 = a.out[(size_t)emc * a.ldo + tile0 * 16 + en];
+    pre1 = a.normw_next[tile0 * 16 + en];
+  } else if (EPI == EPI_QKV || EPI == EPI_STORE) {
+    sp_row = a.state_rows[emc] ? a.state_rows[emc] : a.state;
+  }
+  auto late_prefetch = [&]() {                         // after the weight stream: the loads that depend on loaded values
+    if (EPI == EPI_QKV) {
+      if (tile0 < a.q_tiles + a.k_tiles) {             // (workgroup-uniform)
+        const int ht = tile0 < a.q_tiles ? tile0 : tile0 - a.q_tiles;
+        const int f = (ht & 7) * 8 + (en & 7);
+        const int pos = sp_row->pos;
+        pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
+        pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+      }
+    } else if (EPI == EPI_STORE) {
+      // logits of a sequence that already emitted its EOS are not overwritten by look-ahead steps (DDState::done)
+      if (sp_row && sp_row->done) pre0 = 1.f;
+    }
+  };
 
   if constexpr (FP8) {
     // fp8 weights: one 1 KiB load = 64 k of a tile row = two MFMA k-steps; wave w takes 64-k steps w, w+8, ...
@@ -125,7 +129,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
     }
   };
-  finish_rstd();
   if constexpr (!FP8 && PIPE == 0) {
     // batches: U steps requested together, then consumed; the other resident waves cover the drain
     int s = 0;
@@ -201,6 +204,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
       if (s + U + u < n) use(u);
   }
 
+  late_prefetch();
+  finish_rstd();
 #pragma unroll
   for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
   __syncthreads();
@@ -512,8 +517,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
   const u32x4_t* xp = a.xop + (size_t)wave * 64 + lane;      // plane g: + g * S * 64
   const size_t xplane = (size_t)S * 64;
   GroupsPre<TILES> pre;
-  groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
-  groups_rstd<NG>(a, rstd_sh);
+  // (round 6: the epilogue's operands and the rows' rstd are fetched AFTER the weight stream — groups_prefetch loads inside a divergent
+  // branch and follows pointers, the compiler waits for those loads where they stand: in front of the first weight request, as in k_gemv)
 
   if constexpr (FP8) {
     // fp8 weights: one 1 KiB load = 64 k of a tile row = two MFMA k-steps, expanded exactly to bf16 in registers ONCE and
@@ -599,6 +604,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_groups(GemvArgs a) {
       }
   }
 
+  groups_prefetch<EPI, TILES, NG>(a, tile0, pre);
+  groups_rstd<NG>(a, rstd_sh);
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll

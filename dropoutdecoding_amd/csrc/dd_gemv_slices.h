@@ -591,6 +591,10 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
 #pragma unroll
     for (int b = 0; b < CH * NB; ++b) {
       // request the next block (of this tile, or the first of the wave's next tile) before consuming this one
+      if (DD_TEXP(a, 64)) {                            // (timing experiment: the weight stream stops after the first block — LDS reads + MFMAs alone)
+#pragma unroll
+        for (int u = 0; u < UW; ++u) wn[u] = wc[u];
+      } else
       if (b + 1 < CH * NB || has_next) {
         const u32x4_t* p = b + 1 < CH * NB ? wptr(g, b + 1) : wptr(gn, 0);
 #pragma unroll
@@ -615,6 +619,18 @@ __global__ __launch_bounds__(512) void k_gemv_slices_fp8(SliceArgs a) {
           u32x4_t fr[XPF];
 #pragma unroll
           for (int i = 0; i < XPF - 1; ++i) fr[i] = x0[(size_t)(((i & 1) ? NG : 0) + (i >> 1)) * 64];
+          if (DD_TEXP(a, 16)) {                        // (timing experiment, tools library: no further fragment reads — every MFMA multiplies fragment 0)
+#pragma unroll
+            for (int i = 0; i < 2 * NG; ++i) acc[i >> 1] = dd_mfma16<0>((i & 1) ? k1 : k0, fr[0], acc[i >> 1]);
+          } else if (DD_TEXP(a, 32)) {                 // (timing experiment: all 18 fragment reads, but only the first plane's two MFMAs)
+#pragma unroll
+            for (int i = 0; i < 2 * NG; ++i) {
+              if (i + XPF - 1 < 2 * NG) fr[(i + XPF - 1) % XPF] = x0[(size_t)((((i + XPF - 1) & 1) ? NG : 0) + ((i + XPF - 1) >> 1)) * 64];
+              if (i < 2) acc[0] = dd_mfma16<0>((i & 1) ? k1 : k0, fr[i % XPF], acc[0]);
+              else acc[i >> 1].x += __builtin_bit_cast(float, fr[i % XPF].x);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else
 #pragma unroll
           for (int i = 0; i < 2 * NG; ++i) {
             if (i + XPF - 1 < 2 * NG) fr[(i + XPF - 1) % XPF] = x0[(size_t)((((i + XPF - 1) & 1) ? NG : 0) + ((i + XPF - 1) >> 1)) * 64];
