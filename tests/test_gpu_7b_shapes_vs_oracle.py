@@ -21,7 +21,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle.decode_ref import FAMILY_LLAVA, FAMILY_NEXT, RefDecoder
+from oracle.decode_ref import FAMILY_IBLIP, FAMILY_LLAVA, FAMILY_NEXT, RefDecoder
 from oracle.lm_ref import LMConfig as RefCfg, random_weights
 
 K8 = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8]
@@ -80,8 +80,12 @@ def _thresholds(epi, probs):
 
 
 def _mask_margin(r, ref, probs):
-    if r.uniforms is None:
-        return 1.0
+    if r.uniforms is None:            # InstructBLIP: drop where e >= quantile(e, 1 - p) (instructblip.py:450-453): how close an uncertainty sits to a threshold
+        e = ref.epi.numpy().astype(np.float64)
+        thr = np.quantile(e, 1.0 - np.asarray(probs, np.float64))
+        d = np.abs(e[None, :] - thr[:, None])
+        d[d == 0.0] = np.inf          # (a threshold that IS an element — weight 0 of the interpolation — is the same element on both sides)
+        return float(d.min() / np.ptp(e))
     return float(np.abs(r.uniforms - _thresholds(ref.epi.numpy(), probs)).min())
 
 
@@ -296,5 +300,26 @@ def test_solo_mistral7b_bf16_both_step_forms_vs_oracle(E, mistral_w):
         worst = _solo_vs_oracle(engines[li], refs[li], embs[li], spans[li], K8, steps, 50 + li, mode,
                                 f"mistral-7b shapes bf16, lane {li} alone (speculation {mode})")
         print(f"  lane {li} alone, speculation {mode}: worst logits error {worst:.2e}")
+    for e in reversed(engines):
+        e.close()
+
+
+def test_rider_step_instructblip_rule_llama7b_shapes_every_lane_vs_oracle(E, llama_w):
+    """(e) BASELINE config 4's rule at its language model's widths (Vicuna-7B = LLaMA-7B shapes): quantile masks (no random draws), the vote on the
+    argmax of the final hidden state, the last member's zeros leaking into the next un-masked row — 16 lanes in the rider form, each against its own
+    oracle, then one lane alone.  32 visual tokens at the start of the sequence, as the Q-Former delivers them."""
+    dims, w = llama_w
+    d = dims[1]
+    rc, cfg = RefCfg(*dims), E.LMConfig(*dims)
+    L, n, steps = 32, 16, 3
+    gen = torch.Generator().manual_seed(13)
+    embs = [torch.randn(L + 8 + (i % 5), d, generator=gen) * 0.5 for i in range(n)]
+    spans = [(0, L)] * n
+    refs = _oracle_lanes(FAMILY_IBLIP, rc, w, K8, embs, spans, steps + 1)
+    engines = _lanes(E, cfg, n, FAMILY_IBLIP, L)
+    engines[0].load_state_dict(w)
+    _group_vs_oracle(E, engines, refs, embs, spans, K8, steps, "llama-7b shapes, InstructBLIP rule, 16 lanes K = 8 (rider form)")
+    worst = _solo_vs_oracle(engines[7], refs[7], embs[7], spans[7], K8, steps, 57, "never", "llama-7b shapes, InstructBLIP rule, lane 7 alone")
+    print(f"  lane 7 alone: worst logits error {worst:.2e}")
     for e in reversed(engines):
         e.close()

@@ -13,7 +13,9 @@ lib = _lib.load()
 MISTRAL = lm.LMConfig(32064, 4096, 14336, 8, 32, 8, 128, 1e-5, 1000000.0)
 LLAVA = dataclasses.replace(lm.LLAVA15_7B, num_layers=8)
 ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
-for name, cfg, T0, n, wf in (("llava", LLAVA, 608, 16, "bf16"), ("mistral", MISTRAL, 2960, 1, "bf16"), ("mistral-fp8", MISTRAL, 2960, 1, "fp8")):
+FORMS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 0, 1, 0, 1]     # 8 / 10: the LDS-DMA block with 128 / 160 rows forced
+for name, cfg, T0, n, wf in (("llava", LLAVA, 608, 16, "bf16"), ("mistral", MISTRAL, 2960, 1, "bf16"), ("mistral-fp8", MISTRAL, 2960, 1, "fp8"),
+                            ("mistral4-fp8", MISTRAL, 2960, 4, "fp8")):
     if ONLY and not name.startswith(ONLY):
         continue
     L = T0 - 32
@@ -24,7 +26,7 @@ for name, cfg, T0, n, wf in (("llava", LLAVA, 608, 16, "bf16"), ("mistral", MIST
     lanes[0].load_synthetic(0, 0.02)
     xs = [torch.randn(T0, 4096, generator=torch.Generator().manual_seed(i)).cuda() for i in range(n)]
     ref = None
-    for form in (0, 1, 0, 1, 0, 1):
+    for form in FORMS:
         lib.dd_tools_set_tuning(20, form)
 
         def go():
@@ -42,7 +44,7 @@ for name, cfg, T0, n, wf in (("llava", LLAVA, 608, 16, "bf16"), ("mistral", MIST
         sig = tuple((e.image_logits().tobytes(), e.logits().tobytes(), e.kv_sums().tobytes()) for e in lanes)
         if ref is None:
             ref = sig
-        print(f"{name}: {n} x {T0} rows, 8 layers, GEMM block form {form} ({'LDS-DMA 160 x 512' if form else 'register-staged 128 x 512'}): {ms:.2f} ms "
+        print(f"{name}: {n} x {T0} rows, 8 layers, GEMM block form {form} ({ {0: 'register-staged 128 x 512', 1: 'LDS-DMA, rows by the launch', 8: 'LDS-DMA 128 x 512', 10: 'LDS-DMA 160 x 512'}[form]}): {ms:.2f} ms "
               f"({ms / 8 * 1e3:.0f} us per layer)   same bits as the first run: {sig == ref}", flush=True)
     for e in reversed(lanes):
         e.close()
