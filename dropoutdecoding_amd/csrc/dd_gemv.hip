@@ -930,6 +930,25 @@ static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
   return DD_OK;
 }
 
+#ifdef DD_TIMING_EXPERIMENTS
+// (tools library only) QUADS: four slices added up inside a workgroup, two partial sums per tile instead of four — the sums come out in an order
+// no other pass width produces, so this is a timing experiment (dd_tools_set_tuning key 53: 1 = 96 / 86 workgroups per quad for
+// qkv / gate-up (one / two tiles per wave), 2 = gate/up on 128 per quad)
+int g_seq_quads = 0;
+template <int NG, int U, int MAXG, int TAG>
+static int launch_slices_seq_quads(const SliceArgs& sa, int wf, hipStream_t st) {
+  constexpr size_t smem = (size_t)16 * NG * 1024;
+  static bool attr = false;
+  if (!attr) {
+    DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr = true;
+  }
+  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, 0, %d, 4>", NG, U, MAXG, TAG);
+  DD_REQUIRE(!wf, "quads: bf16 tiles only");
+  k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG, 4><<<2 * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
+  return DD_OK;
+}
+#endif
 int g_finish4 = 15;   // dd_tools_set_tuning key 24: the four-columns-per-thread finishing kernel per epilogue (bit = EPI_*; 0: k_gemv_finish, same bits)
 template <int EPI, int TILES, int NG, int NP>
 static void launch_finish(const GemvArgs& a, int n_sets, hipStream_t st) {
@@ -1173,6 +1192,14 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
     launch_finish<EPI_STORE, 1, 9, 8>(a, nt, st);
   } else if (epi == EPI_QKV) {
     if (spw != 16 || (nt % 16) != 0 || nt / 16 * 4 > 256) return SLICES_UNSUPPORTED;
+#ifdef DD_TIMING_EXPERIMENTS
+    if (g_seq_quads && !a.wf && nt % 8 == 0 && nt / 8 <= 128) {
+      sa.G = nt / 8;                                     // one tile per wave, 2 * G workgroups
+      RC_(launch_slices_seq_quads<9, 4, 1, EPI_QKV>(sa, a.wf, st));
+      launch_finish<EPI_QKV, 1, 9, 2>(a, nt, st);
+      return DD_OK;
+    }
+#endif
     sa.G = g_exp_G[0] > 0 ? g_exp_G[0] : nt / 16;
     DD_REQUIRE((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
     if (g_exp_U9 == 8) RC_(launch_slices_seq<9, 8, 2, EPI_QKV>(sa, a.wf, st));
@@ -1204,6 +1231,16 @@ static int try_slices9(int epi, const GemvArgs& a, hipStream_t st) {
     launch_finish<EPI_SILU, 2, 9, 8>(a, a.n_tiles, st);
   } else {
     if (spw != 16) return SLICES_UNSUPPORTED;
+#ifdef DD_TIMING_EXPERIMENTS
+    if (g_seq_quads && !a.wf) {
+      sa.G = g_seq_quads == 2 ? 128 : (nt + 15) / 16;    // two tiles per wave
+      if ((nt + 8 * sa.G - 1) / (8 * sa.G) <= 2) {
+        RC_(launch_slices_seq_quads<9, 4, 2, EPI_SILU>(sa, a.wf, st));
+        launch_finish<EPI_SILU, 2, 9, 2>(a, a.n_tiles, st);
+        return DD_OK;
+      }
+    }
+#endif
     sa.G = g_exp_G[2] > 0 ? g_exp_G[2] : (nt + 23) / 24;
     DD_REQUIRE(g_exp_G[2] == -3 || (nt + 8 * sa.G - 1) / (8 * sa.G) <= 3, "gemv_slices_seq: %d tiles over %d workgroups per pair", nt, sa.G);
     // (four weight requests in flight per wave: with eight, three tiles per wave and nine planes the kernel needs 257 registers and

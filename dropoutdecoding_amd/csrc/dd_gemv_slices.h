@@ -387,8 +387,12 @@ __global__ __launch_bounds__(512) void k_gemv_slices(SliceArgs a) {
 // whole-slice kernels above keep it for two and four planes, where it pays.)
 // (amdgpu_waves_per_eu(1, 2): the LDS admits one workgroup per CU = two waves per SIMD; without the hint the compiler aims the two-tile forms at
 // three waves and spills three registers to private scratch to get under 168 — which build.py refuses)
-template <int NG, int U, int SPW, int MAXG, int WF = 0, int EPI_TAG = 0>
+// NH = slices a workgroup adds up one after the other: 2 = the pairs above (the product); 4 = QUADS — a timing experiment of round 6 (tools
+// library only: the sums come out in the order ((s0 + s1) + s2) + s3, which no other pass width produces): half the partial sums again for two more
+// operand stage-ins per workgroup (tools key 53).
+template <int NG, int U, int SPW, int MAXG, int WF = 0, int EPI_TAG = 0, int NH = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_gemv_slices_seq(SliceArgs a) {
+  constexpr int NQS = 8 / NH;                          // workgroups per tile group: one per run of NH slices
   static_assert(SPW % U == 0, "ring depth must divide the slice");
   constexpr int PW = (SPW * NG + 7) / 8;               // operand pieces (1 KiB) per wave and slice
   constexpr int NB = SPW / U;
@@ -396,10 +400,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   extern __shared__ __align__(16) u32x4_t xs[];        // [SPW][NG][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool hi_half = (lane & 8) != 0;
-  const int qs = blockIdx.x & 3, j = blockIdx.x >> 2;
+  const int qs = blockIdx.x % NQS, j = blockIdx.x / NQS;
   const size_t xplane = (size_t)a.S * 64;
   const int n_tiles = a.n_groups;
-  if ((int)blockIdx.x >= 4 * a.G) {                    // SliceArgs::rstd_wg: the workgroup behind the streaming ones — the rows' rstd
+  if ((int)blockIdx.x >= NQS * a.G) {                    // SliceArgs::rstd_wg: the workgroup behind the streaming ones — the rows' rstd
     if (a.ssq_in) dd_rows_rstd<NG>(a.ssq_in, a.ssq_n, a.ssq_ld, a.inv_k, a.eps, a.rstd_out);
     return;
   }
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   auto wptr = [&](int item) -> const u32x4_t* {        // item = slice half * MAXG + group slot (clamped to a live group)
     const int half = item / MAXG, gi = item % MAXG;
     const int g = gidx[gi < ng ? gi : 0] < n_tiles ? gidx[gi < ng ? gi : 0] : 0;
-    return a.W + ((size_t)g * a.S + 2 * qs + half) * 64 + lane;
+    return a.W + ((size_t)g * a.S + NH * qs + half) * 64 + lane;
   };
   auto stage = [&](int half) {                         // operand slice 2 qs + half -> LDS (all waves)
     u32x4_t xv[PW];
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (int i = 0; i < PW; ++i) {
       int p = wave + 8 * i;
       int pc = p < SPW * NG ? p : 0;
-      xv[i] = a.xop[(size_t)(2 * qs + half + 8 * (pc / NG)) * 64 + (pc % NG) * xplane + lane];
+      xv[i] = a.xop[(size_t)(NH * qs + half + 8 * (pc / NG)) * 64 + (pc % NG) * xplane + lane];
     }
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
@@ -464,12 +468,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   if (!DD_TEXP(a, 2)) stage(0);
   __syncthreads();
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NH; ++half) {
 #pragma unroll
     for (int gi = 0; gi < MAXG; ++gi) {
       const int item = half * MAXG + gi;
       const bool live = gi < ng;                       // wave-uniform
-      const bool last_item = item == 2 * MAXG - 1;
+      const bool last_item = item == NH * MAXG - 1;
       const u32x4_t* wp = wptr(item);
       const u32x4_t* wn = wptr(last_item ? item : item + 1);
       if (live) {
@@ -503,13 +507,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int u = 0; u < U; ++u) w[u] = dd_ldw(a.temporal, wn + (size_t)u * wstep);
       }
-      if (half == 1 && DD_TEXP(a, 8) && ((gi & 1) || gi == MAXG - 1)) store_set(gi >> 1);   // (timing experiment: the round-5 placement)
+      if (half == NH - 1 && DD_TEXP(a, 8) && ((gi & 1) || gi == MAXG - 1)) store_set(gi >> 1);   // (timing experiment: the round-5 placement)
     }
-    if (half == 0) {
+    if (half + 1 < NH) {
       // (requesting the second slice's pieces BEFORE this barrier — their latency beside the slower waves' last tile — was measured: no gain,
       // 60 registers; tools/seq_lab.hip, profiles/r05_lab/)
       __syncthreads();                                 // every wave has finished reading slice 2 qs
-      if (!DD_TEXP(a, 2)) stage(1);
+      if (!DD_TEXP(a, 2)) stage(half + 1);
       __syncthreads();
     }
   }
