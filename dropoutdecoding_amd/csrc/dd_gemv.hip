@@ -18,6 +18,95 @@
 // NT  = non-temporal weight loads (read-once stream, keeps L2/MALL for the x operand and the KV cache)
 // ILV = k-steps interleaved over the 8 waves (wave w takes steps w, w+8, ...: at any instant the workgroup reads
 //       8 consecutive KiB) instead of one contiguous chunk per wave
+// Everything behind the LDS reduction of an 8-row pass, for the TILES tiles tile0.. of tile group tg (k_gemv: tg = blockIdx.x; k_gemv_loop walks
+// several groups per workgroup).  red: [TILES][8 waves][256] accumulators as the waves stored them; rstd_sh must be visible (barrier before the call).
+template <int EPI, int TILES, int FP8, int WF>
+__device__ __forceinline__ void gemv8_epilogue(const GemvArgs& a, const int tile0, const int tg, const float* red, const float* rstd_sh, float* ssq_sh,
+                                               const float pre0, const float pre1) {
+  // D[n][c]: lane = (n>>2)*16 + c, reg = n&3.  y[m][n] = sum_w (D_w[n][m] + D_w[n][m+8])   (hi + lo columns)
+  const int t = threadIdx.x;
+  // fixed order: (hi + lo) per wave, waves added in pairs, pairs in sequence — the order the slice-resident kernels
+  // reproduce from partial sums (dd_gemv_slices.h): y = sum_p ((hi+lo)(2p) + (hi+lo)(2p+1))
+  auto tile_sum = [&](int tt, int n, int m) -> float {
+    float y = 0.f;
+    int o = ((n >> 2) * 16 + m) * 4 + (n & 3);
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; w += 2) {
+      const float* r = &red[(tt * GEMV_WAVES + w) * 256];
+      y += (r[o] + r[o + 32]) + (r[256 + o] + r[256 + o + 32]);
+    }
+    if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
+    return y;
+  };
+
+  if (EPI == EPI_STORE) {
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float y = tile_sum(0, n, m);
+        if (a.ssq_in) y *= rstd_sh[m];
+        int col = tile0 * 16 + n;
+        if (col < a.n_valid && pre0 == 0.f) a.out[(size_t)m * a.ldo + col] = y;
+      }
+    }
+  } else if (EPI == EPI_RESID) {
+    float sq = 0.f;
+    int m = t & 7, n = t >> 3;
+    if (t < 128 && m < a.nb) {
+      float y = tile_sum(0, n, m);
+      int col = tile0 * 16 + n;
+      float xn = pre0 + y;
+      a.out[(size_t)m * a.ldo + col] = xn;
+      xop_store(a.xop_next, col, m, pre1 * xn, WF);
+      sq = xn * xn;
+    }
+    if (t < 128) ssq_sh[n * 8 + m] = sq;
+    __syncthreads();
+    if (t < 8) {
+      float v = 0.f;
+      for (int i = 0; i < 16; ++i) v += ssq_sh[i * 8 + t];
+      a.ssq_out[(size_t)t * a.ssq_ld + tg] = v;
+    }
+  } else if (EPI == EPI_SILU) {
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float g = tile_sum(0, n, m), u = tile_sum(TILES - 1, n, m);
+        if (a.ssq_in) {
+          g *= rstd_sh[m];
+          u *= rstd_sh[m];
+        }
+        float act = g / (1.0f + expf(-g));  // silu
+        xop_store(a.xop_next, tg * 16 + n, m, act * u, WF);
+      }
+    }
+  } else {  // EPI_QKV
+    if (t < 128) {
+      int m = t & 7, n = t >> 3;
+      if (m < a.nb) {
+        float y = tile_sum(0, n, m);
+        if (a.ssq_in) y *= rstd_sh[m];
+        int nt = tile0;
+        if (nt < a.q_tiles + a.k_tiles) {
+          float yp = tile_sum(0, n ^ 8, m);
+          if (a.ssq_in) yp *= rstd_sh[m];
+          bool is_q = nt < a.q_tiles;
+          int ht = is_q ? nt : nt - a.q_tiles;
+          int head = ht >> 3, f = (ht & 7) * 8 + (n & 7);
+          float c = pre0, sn = pre1;
+          float o = dd_rope_mix(y, yp, c, sn, n < 8);     // q*cos + rotate_half(q)*sin (HF apply_rotary_pos_emb)
+          int i = (n < 8) ? f : ROPE_HALF + f;
+          if (is_q) a.qbuf[(size_t)m * a.q_dim + head * HEAD_DIM + i] = o;
+          else a.knew[(size_t)m * a.kv_dim + head * HEAD_DIM + i] = o;
+        } else {
+          int col = (nt - a.q_tiles - a.k_tiles) * 16 + n;
+          a.vnew[(size_t)m * a.kv_dim + col] = y;
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, int TILES, int U, int NT, int ILV, int FP8 = 0, int PIPE = 0, int WF = 0>
 __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   __shared__ float red[TILES * GEMV_WAVES * 256];
@@ -210,90 +299,112 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv(GemvArgs a) {
   for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
   __syncthreads();
 
-  // D[n][c]: lane = (n>>2)*16 + c, reg = n&3.  y[m][n] = sum_w (D_w[n][m] + D_w[n][m+8])   (hi + lo columns)
-  const int t = threadIdx.x;
-  // fixed order: (hi + lo) per wave, waves added in pairs, pairs in sequence — the order the slice-resident kernels
-  // reproduce from partial sums (dd_gemv_slices.h): y = sum_p ((hi+lo)(2p) + (hi+lo)(2p+1))
-  auto tile_sum = [&](int tt, int n, int m) -> float {
-    float y = 0.f;
-    int o = ((n >> 2) * 16 + m) * 4 + (n & 3);
-#pragma unroll
-    for (int w = 0; w < GEMV_WAVES; w += 2) {
-      const float* r = &red[(tt * GEMV_WAVES + w) * 256];
-      y += (r[o] + r[o + 32]) + (r[256 + o] + r[256 + o + 32]);
-    }
-    if (FP8) y *= a.wscale[(size_t)(tile0 + tt) * 16 + n];
-    return y;
-  };
-
-  if (EPI == EPI_STORE) {
-    if (t < 128) {
-      int m = t & 7, n = t >> 3;
-      if (m < a.nb) {
-        float y = tile_sum(0, n, m);
-        if (a.ssq_in) y *= rstd_sh[m];
-        int col = tile0 * 16 + n;
-        if (col < a.n_valid && pre0 == 0.f) a.out[(size_t)m * a.ldo + col] = y;
-      }
-    }
-  } else if (EPI == EPI_RESID) {
-    float sq = 0.f;
-    int m = t & 7, n = t >> 3;
-    if (t < 128 && m < a.nb) {
-      float y = tile_sum(0, n, m);
-      int col = tile0 * 16 + n;
-      float xn = pre0 + y;
-      a.out[(size_t)m * a.ldo + col] = xn;
-      xop_store(a.xop_next, col, m, pre1 * xn, WF);
-      sq = xn * xn;
-    }
-    if (t < 128) ssq_sh[n * 8 + m] = sq;
-    __syncthreads();
-    if (t < 8) {
-      float v = 0.f;
-      for (int i = 0; i < 16; ++i) v += ssq_sh[i * 8 + t];
-      a.ssq_out[(size_t)t * a.ssq_ld + blockIdx.x] = v;
-    }
-  } else if (EPI == EPI_SILU) {
-    if (t < 128) {
-      int m = t & 7, n = t >> 3;
-      if (m < a.nb) {
-        float g = tile_sum(0, n, m), u = tile_sum(TILES - 1, n, m);
-        if (a.ssq_in) {
-          g *= rstd_sh[m];
-          u *= rstd_sh[m];
-        }
-        float act = g / (1.0f + expf(-g));  // silu
-        xop_store(a.xop_next, blockIdx.x * 16 + n, m, act * u, WF);
-      }
-    }
-  } else {  // EPI_QKV
-    if (t < 128) {
-      int m = t & 7, n = t >> 3;
-      if (m < a.nb) {
-        float y = tile_sum(0, n, m);
-        if (a.ssq_in) y *= rstd_sh[m];
-        int nt = tile0;
-        if (nt < a.q_tiles + a.k_tiles) {
-          float yp = tile_sum(0, n ^ 8, m);
-          if (a.ssq_in) yp *= rstd_sh[m];
-          bool is_q = nt < a.q_tiles;
-          int ht = is_q ? nt : nt - a.q_tiles;
-          int head = ht >> 3, f = (ht & 7) * 8 + (n & 7);
-          float c = pre0, sn = pre1;
-          float o = dd_rope_mix(y, yp, c, sn, n < 8);     // q*cos + rotate_half(q)*sin (HF apply_rotary_pos_emb)
-          int i = (n < 8) ? f : ROPE_HALF + f;
-          if (is_q) a.qbuf[(size_t)m * a.q_dim + head * HEAD_DIM + i] = o;
-          else a.knew[(size_t)m * a.kv_dim + head * HEAD_DIM + i] = o;
-        } else {
-          int col = (nt - a.q_tiles - a.k_tiles) * 16 + n;
-          a.vnew[(size_t)m * a.kv_dim + col] = y;
-        }
-      }
-    }
-  }
+  gemv8_epilogue<EPI, TILES, FP8, WF>(a, tile0, blockIdx.x, red, rstd_sh, ssq_sh, pre0, pre1);
 }
 
+// The 8-row GEMV for K = 4096 with the rows' operand slice in REGISTERS and several tile groups per workgroup (round 6).  In k_gemv a workgroup
+// lives for one tile group: it loads its operand fragments from L2 beside the weights (1 KiB of x per KiB of weights, for every workgroup again),
+// reduces through the LDS, runs its epilogue and ends — the stream of the NEXT workgroup on that CU starts behind all of that.  Timing experiments
+// (profiles/r06_lab/gemv8_ablation.log) put the operand loads at 1-2.4 us and the reduction + epilogue at 1-2 us of a 20-34 us kernel.  Here a
+// workgroup keeps wave w's sixteen operand fragments (k-steps w, w + 8, ...) in 64 registers for its whole life, walks tile groups
+// blockIdx.x, blockIdx.x + gridDim.x, ..., and requests the next group's first eight weight tiles BEFORE it reduces and finishes the current group, so
+// the weight stream runs through reduction and epilogue.  Per tile the MFMA chain (k-steps in order) and the reduction (gemv8_epilogue) are k_gemv's:
+// the same bits (tests/test_gpu_engine.py goldens, tests/test_gpu_7b_shapes_vs_oracle.py solo runs, lanes vs solo everywhere).
+template <int EPI, int TILES, int WF>
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv_loop(GemvArgs a, int n_groups) {
+  constexpr int NS = 16, U = 8;                        // k-steps per wave (K = 4096); weight tiles per batch
+  __shared__ float red[2][TILES * GEMV_WAVES * 256];
+  __shared__ float rstd_sh[8];
+  __shared__ float ssq_sh[8 * 16];
+  if (a.skip_if && *a.skip_if) return;
+  int g = blockIdx.x;
+  if (g >= n_groups) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = a.S;
+  auto wptr = [&](int grp, int t) -> const u32x4_t* { return a.W + ((size_t)(grp * TILES + t) * S + wave) * 64 + lane; };
+  u32x4_t wa[TILES][U], wb[TILES][U];
+  auto issue = [&](u32x4_t (&w)[TILES][U], int grp, int half) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) w[t][u] = __builtin_nontemporal_load(wptr(grp, t) + (size_t)(half * U + u) * GEMV_WAVES * 64);
+  };
+  issue(wa, g, 0);                                     // the weight stream starts before anything else is asked for
+  u32x4_t xr[NS];
+  {
+    const u32x4_t* xp = a.xop + (size_t)wave * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) xr[i] = xp[(size_t)i * GEMV_WAVES * 64];
+  }
+  const bool has_ssq = a.ssq_in != nullptr;
+  f32x4_t sv = {0.f, 0.f, 0.f, 0.f};
+  if (has_ssq) {
+    const int i4 = min(4 * lane, max((a.ssq_n - 1) & ~3, 0));
+    sv = *(const f32x4_t*)(a.ssq_in + (size_t)wave * a.ssq_ld + i4);
+  }
+  const int em = threadIdx.x & 7, en = (threadIdx.x >> 3) & 15, emc = min(em, a.nb - 1);
+  const DDState* sp_row = nullptr;
+  if (EPI == EPI_QKV || EPI == EPI_STORE) sp_row = a.state_rows[emc] ? a.state_rows[emc] : a.state;
+  int pos = 0;
+  float done_f = 0.f;
+  bool first = true;
+  int par = 0;
+  for (; g < n_groups; g += gridDim.x) {
+    const int gn = g + gridDim.x;
+    const int tile0 = g * TILES;
+    issue(wb, g, 1);
+    float pre0 = 0.f, pre1 = 0.f;
+    if (EPI == EPI_RESID) {
+      pre0 = a.out[(size_t)emc * a.ldo + tile0 * 16 + en];
+      pre1 = a.normw_next[tile0 * 16 + en];
+    }
+    if (first) {                                       // (once per workgroup: the row's position / finished flag)
+      if (EPI == EPI_QKV) pos = sp_row->pos;
+      if (EPI == EPI_STORE) done_f = (sp_row && sp_row->done) ? 1.f : 0.f;
+    }
+    f32x4_t acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) acc[t] = dd_mfma16<WF>(wa[t][u], xr[u], acc[t]);
+    if (gn < n_groups) issue(wa, gn, 0);               // the next group's first batch travels through this group's reduction and epilogue
+    if (EPI == EPI_QKV) {
+      if (tile0 < a.q_tiles + a.k_tiles) {             // (workgroup-uniform)
+        const int ht = tile0 < a.q_tiles ? tile0 : tile0 - a.q_tiles;
+        const int f = (ht & 7) * 8 + (en & 7);
+        pre0 = a.rope_cos[(size_t)pos * ROPE_HALF + f];
+        pre1 = a.rope_sin[(size_t)pos * ROPE_HALF + f];
+      }
+    } else if (EPI == EPI_STORE) {
+      pre0 = done_f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) acc[t] = dd_mfma16<WF>(wb[t][u], xr[U + u], acc[t]);
+    if (first) {
+      if (has_ssq) {
+        const int i0 = 4 * lane;
+        float v = 0.f;
+        if (i0 < a.ssq_n) v += sv.x;
+        if (i0 + 1 < a.ssq_n) v += sv.y;
+        if (i0 + 2 < a.ssq_n) v += sv.z;
+        if (i0 + 3 < a.ssq_n) v += sv.w;
+        for (int i = lane + 256; i < a.ssq_n; i += 64) v += a.ssq_in[(size_t)wave * a.ssq_ld + i];
+        v = dd_wave_sum(v);
+        if (lane == 0) rstd_sh[wave] = 1.0f / sqrtf(v * a.inv_k + a.eps);
+      }
+      first = false;
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) *(f32x4_t*)&red[par][(t * GEMV_WAVES + wave) * 256 + lane * 4] = acc[t];
+    __syncthreads();
+    gemv8_epilogue<EPI, TILES, 0, WF>(a, tile0, g, red[par], rstd_sh, ssq_sh, pre0, pre1);
+    par ^= 1;
+  }
+}
 // Tensor-parallel seam of a row-parallel matrix (o_proj, down_proj; dd_tp.hip): every rank's k_gemv wrote its partial product
 // y_r [rows][N] (EPI_STORE) into slot r of `gather` [W][rows][N]; this adds the slots in rank order and runs k_gemv's EPI_RESID
 // epilogue on the sum: x += y, the next matrix's packed operand z = normw * x, the sum-of-squares slots of the folded RMSNorm.
@@ -359,11 +470,34 @@ static void launch_gemv(const GemvArgs& a_, hipStream_t st) {
 #undef GV
 }
 
+int g_gemv_loop = 1;            // dd_tools_set_tuning key 54: k_gemv_loop for the K = 4096 matrices of an 8-row pass (0: k_gemv; n > 1: n workgroups)
+template <int EPI, int TILES>
+static void launch_gemv_loop(const GemvArgs& a, int n_groups, hipStream_t st) {
+  // one workgroup per CU (165-230 VGPRs: two waves per SIMD), each walking ceil(n_groups / 256) tile groups
+  const int grid = g_gemv_loop > 1 ? (g_gemv_loop < n_groups ? g_gemv_loop : n_groups) : (n_groups < 256 ? n_groups : 256);
+  NOTE_KERNEL("k_gemv_loop<%d, %d, %d>", EPI, TILES, a.wf ? 1 : 0);
+  if (a.wf) k_gemv_loop<EPI, TILES, 1><<<grid, GEMV_THREADS, 0, st>>>(a, n_groups);
+  else k_gemv_loop<EPI, TILES, 0><<<grid, GEMV_THREADS, 0, st>>>(a, n_groups);
+}
+
 int ddk_gemv(int epi, const GemvArgs& a, hipStream_t st) {
   DD_REQUIRE(a.S % GEMV_WAVES == 0 && a.S >= GEMV_WAVES, "gemv: K=%d must be a multiple of 256", a.S * 32);
   DD_REQUIRE(a.nb >= 1 && a.nb <= 8, "gemv: nb=%d", a.nb);
   DD_REQUIRE(!a.fp8 || a.wscale, "gemv: fp8 weights need row scales");
   DD_REQUIRE(!a.ssq_in || a.ssq_n >= 1, "gemv: ssq_n");
+  if (g_gemv_loop && !a.fp8 && a.S == 16 * GEMV_WAVES && a.n_tiles > 256 && (g_gemv_loop > 1 || a.n_tiles % 256 == 0)) {
+    // K = 4096 and a whole number of tile groups per CU: LLaMA-7B's qkv (768 tiles: 20.3 -> 19.2 us).  Measured and left on k_gemv: gate/up (688
+    // tile pairs = 2.69 per workgroup, the third round two thirds empty: 34.0 -> 40.3 us); o_proj's 256 tiles are one group per workgroup either way
+    // (dd_tools_set_tuning key 54 > 1 forces the form with that many workgroups for every K = 4096 matrix)
+    switch (epi) {
+      case EPI_STORE: launch_gemv_loop<EPI_STORE, 1>(a, a.n_tiles, st); break;
+      case EPI_RESID: launch_gemv_loop<EPI_RESID, 1>(a, a.n_tiles, st); break;
+      case EPI_SILU: launch_gemv_loop<EPI_SILU, 2>(a, a.n_tiles, st); break;
+      default: launch_gemv_loop<EPI_QKV, 1>(a, a.n_tiles, st); break;
+    }
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   switch (epi) {
     case EPI_STORE: launch_gemv<EPI_STORE, 1>(a, st); break;
     case EPI_RESID: launch_gemv<EPI_RESID, 1>(a, st); break;

@@ -114,7 +114,7 @@ void dd_engine_set_fp32_fork(int on);
 void dd_engine_set_mask_branches(int on);
 void dd_engine_set_attn_masked(int mode);
 void dd_engine_set_unmask(int m);
-extern int g_exp_U9, g_exp_temporal, g_rmsnorm16, g_prefill_attn16, g_attn16_ride_pf, g_sampler_lds_pad, g_seq_prog, g_rstd_wg, g_fp8_xpf, g_seq_quads;
+extern int g_exp_U9, g_exp_temporal, g_rmsnorm16, g_prefill_attn16, g_attn16_ride_pf, g_sampler_lds_pad, g_seq_prog, g_rstd_wg, g_fp8_xpf, g_seq_quads, g_gemv_loop;
 void dd_dropout_set_lanes_sampler_scratch(int on);   // dd_dropout.hip compiled with -DDD_KEEP_SCRATCH_SAMPLER (this library only)
 void dd_dropout_set_sampler_dbg(uint32_t* buf);
 uint32_t dd_dropout_sampler_dbg_tag();
@@ -130,7 +130,7 @@ extern "C" unsigned int dd_tools_sampler_dbg_launches(void) { return dd_dropout_
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16) || key == 20) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39 || key == 40 || key == 41 || key == 42 || key == 43 || key == 45 || key == 46 || key == 47 || key == 48 || key == 49 || key == 50 || key == 52 || key == 53,
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39 || key == 40 || key == 41 || key == 42 || key == 43 || key == 45 || key == 46 || key == 47 || key == 48 || key == 49 || key == 50 || key == 52 || key == 53 || key == 54,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -164,6 +164,7 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 50) g_rstd_wg = value;
   else if (key == 52) g_fp8_xpf = value;
   else if (key == 53) g_seq_quads = value;
+  else if (key == 54) g_gemv_loop = value;
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }

@@ -61,7 +61,9 @@ int dd_hbm_read_bench(const void* buf_dev, size_t bytes, int iters, int n_blocks
  * 43 the fp32-cache tile pass with scalar instead of packed FP32 multiply-adds in its P.V step (tools library only: the product library has
  * no packed FP32 at all), 52 (round 6) the nine-plane fp8 slice kernel's operand fragments through a ring read five ahead of their MFMAs
  * (default 1; 0: where the compiler requests them; same bits), 53 (round 6, TIMING ONLY: sums in an order no other width produces) four K slices
- * per workgroup in the nine-plane qkv / gate-up kernels (1: 96 / 86 workgroups per quad, 2: gate/up on 128).  Keys of
+ * per workgroup in the nine-plane qkv / gate-up kernels (1: 96 / 86 workgroups per quad, 2: gate/up on 128), 54 (round 6) the 8-row GEMV that keeps
+ * the rows' operand in registers and walks several tile groups per workgroup (k_gemv_loop: default 1 = where the tile count is a multiple of 256;
+ * 0: never; n > 1: n workgroups for every K = 4096 matrix; same bits).  Keys of
  * dd_set_tuning are forwarded.  Every call starts a new epoch of the step-graph
  * keys: a step captured under other settings is never replayed. */
 int dd_tools_set_tuning(int key, int value);
