@@ -201,8 +201,13 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnDecodeArgs a) {
 // explicit fused multiply-adds, so that a row's bits do not depend on which of the two produced it.
 // ld_ml(tile) -> (max, sum) of the tile for this row; ld_o(tile) -> its un-normalised output at dimension d.
 // sh: 2 + ATT_MAX_SPLITS + 2 + 2 floats of shared memory for this group of 128 threads.
+// PRE (round 6; the stand-alone merge over the partial buffers in memory): the outputs of the first ATT_COMB_PRE tiles are requested at the top,
+// with every other load of the block, instead of behind the two barriers — one memory round trip per launch instead of two.  The multiply-adds
+// and their order are unchanged: the same bits (tests/test_gpu_single_stream_attn.py; dd_tools_set_tuning key 55 = 0 restores the late loads).
+// Worth 0.3 % of a two-sweep single-sequence step, 3 % of its speculative step (profiles/r06_lab/attn_one_launch_ab.log).
 #define ATT_COMB_SH (2 + ATT_MAX_SPLITS + 2 + 2)
-template <typename LD_ML, typename LD_O>
+#define ATT_COMB_PRE 16
+template <int PRE = 0, typename LD_ML, typename LD_O>
 __device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int head, int kvh, int m, bool wide, int d, int splits, float* sh,
                                                   LD_ML ld_ml, LD_O ld_o, bool store = true) {
   float* red = sh;
@@ -223,6 +228,11 @@ __device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int h
   float ms0 = -INFINITY, ls0 = 0.f, ms1 = -INFINITY, ls1 = 0.f;   // two tiles per thread: up to 256 tiles
   if (d < splits) ld_ml(d, ms0, ls0);
   if (d + 128 < splits) ld_ml(d + 128, ms1, ls1);
+  float opre[PRE ? PRE : 1];
+  if constexpr (PRE > 0) {
+#pragma unroll
+    for (int sp = 0; sp < PRE; ++sp) opre[sp] = sp < splits ? ld_o(sp) : 0.f;
+  }
   float part = dd_wave_sum(qd * kd);
   float mloc = dd_wave_max(fmaxf(ms0, ms1));
   if (lane == 0) { red[wv] = part; mx_sh[wv] = mloc; }
@@ -238,7 +248,14 @@ __device__ __forceinline__ void attn_combine_core(const AttnDecodeArgs& a, int h
   float w_self = expf(s_self - M);
   float den = w_self + (den_sh[0] + den_sh[1]);
   float num = w_self * vd;
-  for (int sp = 0; sp < splits; ++sp) num = __builtin_fmaf(w_sh[sp], ld_o(sp), num);
+  if constexpr (PRE > 0) {
+#pragma unroll
+    for (int sp = 0; sp < PRE; ++sp)
+      if (sp < splits) num = __builtin_fmaf(w_sh[sp], opre[sp], num);
+    for (int sp = PRE; sp < splits; ++sp) num = __builtin_fmaf(w_sh[sp], ld_o(sp), num);
+  } else {
+    for (int sp = 0; sp < splits; ++sp) num = __builtin_fmaf(w_sh[sp], ld_o(sp), num);
+  }
   if (!store) return;
   if (wide) xop_store16(a.xop_out, head * HEAD_DIM + d, m, num / den, q_dim >> 5, a.wf);
   else xop_store(a.xop_out, head * HEAD_DIM + d, m, num / den, a.wf);
@@ -510,7 +527,7 @@ __global__ __launch_bounds__(256, PF ? 1 : (G == 1 ? 5 : 4)) void k_attn_partial
 int g_attn16_ride_pf = 0;        // dd_tools_set_tuning key 47: 1 = the two-register-set (round-3) form for every rider sweep
 
 // grid (n_heads, nb), block 128 (thread = d): the merge above over the partial buffers in memory
-template <int NBT, int G>
+template <int NBT, int G, int PRE = 0>
 __device__ __forceinline__ void attn_combine_body(const AttnDecodeArgs& a, int splits_grid, const int bx, const int by) {
   constexpr int R = NBT * G;
   __shared__ float sh[ATT_COMB_SH];
@@ -525,20 +542,26 @@ __device__ __forceinline__ void attn_combine_body(const AttnDecodeArgs& a, int s
   const size_t ml_stride = (size_t)R * 2;
   const float* po = a.part_o + ((size_t)kvh * splits_grid * R + r) * HEAD_DIM + d;
   const size_t o_stride = (size_t)R * HEAD_DIM;
-  attn_combine_core(
+  attn_combine_core<PRE>(
       a, head, kvh, m, NBT > 8, d, splits, sh, [&](int t, float& mx, float& l) { mx = mlb[t * ml_stride], l = mlb[t * ml_stride + 1]; },
       [&](int t) -> float { return po[(size_t)t * o_stride]; });
 }
-template <int NBT, int G>
+template <int NBT, int G, int PRE = 0>
 __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine(AttnDecodeArgs a, int splits_grid) {
-  attn_combine_body<NBT, G>(a, splits_grid, blockIdx.x, blockIdx.y);
+  attn_combine_body<NBT, G, PRE>(a, splits_grid, blockIdx.x, blockIdx.y);
+}
+int g_attn_comb_pre = 1;         // dd_tools_set_tuning key 55: 0 = the merge launches request the tiles' outputs behind their barriers (until round 6)
+template <int NBT, int G>
+static void launch_combine(const AttnDecodeArgs& a, int rows, int splits, hipStream_t st) {
+  if (g_attn_comb_pre) k_attn_combine<NBT, G, ATT_COMB_PRE><<<dim3(a.n_heads, rows), HEAD_DIM, 0, st>>>(a, splits);
+  else k_attn_combine<NBT, G><<<dim3(a.n_heads, rows), HEAD_DIM, 0, st>>>(a, splits);
 }
 // the merges of a rider sweep in one launch: rows 0..63 the members' (a), rows 64.. the riding rows' (u)
 // (rows_a = 8 x the member planes; RU = rows per head of the riding rows' partial buffers: 8, or 16 with more than eight of them)
-template <int G, int RU>
+template <int G, int RU, int PRE = 0>
 __global__ __launch_bounds__(HEAD_DIM) void k_attn_combine_ride(AttnDecodeArgs a, AttnDecodeArgs u, int splits_a, int splits_u, int rows_a) {
-  if ((int)blockIdx.y < rows_a) attn_combine_body<64, G>(a, splits_a, blockIdx.x, blockIdx.y);
-  else attn_combine_body<RU, G>(u, splits_u, blockIdx.x, blockIdx.y - rows_a);
+  if ((int)blockIdx.y < rows_a) attn_combine_body<64, G, PRE>(a, splits_a, blockIdx.x, blockIdx.y);
+  else attn_combine_body<RU, G, PRE>(u, splits_u, blockIdx.x, blockIdx.y - rows_a);
 }
 
 // Key tiles the partial kernel is LAUNCHED with: the live count rounded up to a multiple of 4 (workgroups of tiles past
@@ -603,7 +626,7 @@ static int launch_attn(const AttnDecodeArgs& a, hipStream_t st) {
   } else {
     k_attn_partial<NBT, G, GH><<<dim3(a.n_kv, splits, G / GH), 256, smem, st>>>(a);
   }
-  k_attn_combine<NBT, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
+  launch_combine<NBT, G>(a, a.nb, splits, st);
   return DD_OK;
 }
 
@@ -624,8 +647,8 @@ static int launch_attn_lanes(const AttnDecodeArgs& a, hipStream_t st) {
   } else {
     k_attn_partial<1, G, G, 1><<<dim3(a.n_kv, splits, a.n_lanes), 256, smem, st>>>(a);
   }
-  if (a.n_lanes > 8) k_attn_combine<16, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
-  else k_attn_combine<8, G><<<dim3(a.n_heads, a.nb), HEAD_DIM, 0, st>>>(a, splits);
+  if (a.n_lanes > 8) launch_combine<16, G>(a, a.nb, splits, st);
+  else launch_combine<8, G>(a, a.nb, splits, st);
   return DD_OK;
 }
 
@@ -676,7 +699,7 @@ static int launch_attn_groups_n(const AttnDecodeArgs& a, hipStream_t st) {
     } else
     k_attn_partial<NBT, G, GH, 2><<<dim3(a.n_kv, splits, NG * (G / GH) * (8 / NBT)), 256, smem, st>>>(a);
   }
-  k_attn_combine<8 * NG, G><<<dim3(a.n_heads, 8 * NG), HEAD_DIM, 0, st>>>(a, splits);
+  launch_combine<8 * NG, G>(a, 8 * NG, splits, st);
   return DD_OK;
 }
 // multi-group pass: members of NG sequences (8 rows each), every group over its own cache
@@ -700,8 +723,14 @@ static int launch_attn_ride_gh(const AttnDecodeArgs& a, const AttnDecodeArgs& u,
   const int za = planes_m * (G / GH) * (8 / NBT);
   if (g_attn16_ride_pf) k_attn_partial16_ride<G, GH, NBT, 1><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
   else k_attn_partial16_ride<G, GH, NBT><<<dim3(a.n_kv, ya > yu ? ya : yu, za + u.n_lanes), 256, 0, st>>>(b, v, za);
-  if (u.n_lanes > 8) k_attn_combine_ride<G, 16><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
-  else k_attn_combine_ride<G, 8><<<dim3(a.n_heads, 8 * planes_m + u.nb), HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
+  const dim3 cgrid(a.n_heads, 8 * planes_m + u.nb);
+  if (g_attn_comb_pre) {
+    if (u.n_lanes > 8) k_attn_combine_ride<G, 16, ATT_COMB_PRE><<<cgrid, HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
+    else k_attn_combine_ride<G, 8, ATT_COMB_PRE><<<cgrid, HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
+  } else {
+    if (u.n_lanes > 8) k_attn_combine_ride<G, 16><<<cgrid, HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
+    else k_attn_combine_ride<G, 8><<<cgrid, HEAD_DIM, 0, st>>>(a, u, splits_a, splits_u, 8 * planes_m);
+  }
   return DD_OK;
 }
 template <int G, int NBT>

@@ -101,7 +101,7 @@ extern "C" int dd_lm_time_gemv(dd_lm* h, int which, int nb, int iters, float* me
 // dynamic-LDS request of those forms (0: the 76 KiB they use, 1: 156 KiB, n: n KiB); the product switches
 // (8, 11, 13-16) are forwarded to dd_set_tuning.  Every call bumps the graph-key epoch: steps captured under other settings are not replayed.
 extern int g_exp_G[4];
-extern int g_attn16_tpw, g_attn16_full, g_finish4, g_attn16_gh_all, g_attn32_lds_pad, g_attn32_nopk;
+extern int g_attn16_tpw, g_attn16_full, g_finish4, g_attn16_gh_all, g_attn32_lds_pad, g_attn32_nopk, g_attn_comb_pre;
 void dd_engine_set_pairs(int on);
 void dd_engine_set_branches(int n);
 void dd_engine_set_rider(int on);
@@ -130,7 +130,7 @@ extern "C" unsigned int dd_tools_sampler_dbg_launches(void) { return dd_dropout_
 extern "C" int dd_tools_set_tuning(int key, int value) {
   dd_engine_bump_epoch();
   if (key == 8 || key == 11 || (key >= 13 && key <= 16) || key == 20) return dd_set_tuning(key, value);
-  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39 || key == 40 || key == 41 || key == 42 || key == 43 || key == 45 || key == 46 || key == 47 || key == 48 || key == 49 || key == 50 || key == 52 || key == 53 || key == 54,
+  DD_REQUIRE(key == 0 || key == 1 || key == 2 || key == 4 || key == 9 || key == 10 || key == 12 || (key >= 17 && key <= 19) || (key >= 21 && key <= 24) || (key >= 26 && key <= 31) || key == 33 || key == 34 || key == 36 || key == 37 || key == 38 || key == 39 || key == 40 || key == 41 || key == 42 || key == 43 || key == 45 || key == 46 || key == 47 || key == 48 || key == 49 || key == 50 || key == 52 || key == 53 || key == 54 || key == 55,
              "dd_tools_set_tuning: unknown key %d", key);
   if (key == 9) dd_engine_set_pairs(value);
   else if (key == 10) ddk_set_attn_split(value);
@@ -165,6 +165,7 @@ extern "C" int dd_tools_set_tuning(int key, int value) {
   else if (key == 52) g_fp8_xpf = value;
   else if (key == 53) g_seq_quads = value;
   else if (key == 54) g_gemv_loop = value;
+  else if (key == 55) g_attn_comb_pre = value;
   else ddk_set_tuning(key, value);      // 0, 4; 1 and 2 are settled (accepted, ignored)
   return DD_OK;
 }
