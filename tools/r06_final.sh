@@ -19,6 +19,11 @@ for what in "$@"; do
     bash tools/collect_profiles.sh r06 pmc
     bash tools/collect_profiles.sh r06 stats5
     bash tools/collect_profiles.sh r06 pmc5
+    # the bench lines below read the newest profile under profiles/ (roofline.kernel_stats_file, traffic, profile_matches_tree): on this box
+    # that is what was just collected on this tree (the same files are committed from gpurun_out/ afterwards)
+    for f in r06_kernel_stats.csv r06_pmc_summary.json r06_sources.json r06_c5_kernel_stats.csv r06_c5_pmc_summary.json; do
+      [ -s $O/$f ] && cp $O/$f profiles/$f
+    done
   elif [ "$what" = benches ]; then
     timeout 900 python3 bench.py > $O/r06_bench_line.json 2> $O/r06_bench_line.err; echo "bench c3 rc=$? $(cut -c1-140 $O/r06_bench_line.json)"
     timeout 900 python3 bench.py --config 2 --no-cpu-baseline > $O/r06_bench_config2.json 2> $O/r06_bench_config2.err; echo "bench c2 rc=$? $(cut -c1-140 $O/r06_bench_config2.json)"
