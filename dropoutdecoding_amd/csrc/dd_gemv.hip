@@ -1058,7 +1058,7 @@ static int launch_slices_seq(const SliceArgs& sa, int wf, hipStream_t st) {
     DD_HIP(hipFuncSetAttribute((const void*)k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
-  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d>", NG, U, MAXG, wf ? 1 : 0, TAG);
+  NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d, 2>", NG, U, MAXG, wf ? 1 : 0, TAG);   // (the last argument: slices per workgroup, pairs)
   if (wf) k_gemv_slices_seq<NG, U, 16, MAXG, 1, TAG><<<4 * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
   else k_gemv_slices_seq<NG, U, 16, MAXG, 0, TAG><<<4 * sa.G + rstd_blocks(sa), GEMV_THREADS, smem, st>>>(sa);
   return DD_OK;

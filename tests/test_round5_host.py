@@ -50,7 +50,11 @@ def test_finishing_share_of_the_committed_round_5_trace():
     assert 0.15 < bench.finishing_share(os.path.join("profiles", "r05_kernel_stats.csv"))["share"] < 0.25
     got = bench.finishing_share(stats)
     assert 0.15 < got["share"] < 0.25, got
-    prof = bench.committed_profile("k_gemv_slices_seq<9, 4, 16, 3, 0, 2>")
+    # the name as the library reports it (csrc/dd_gemv.hip NOTE_KERNEL) and as the trace prints it: since round 6 with the slices-per-workgroup
+    # argument (the first r06 bench line lost its in-step figures to a name that lacked it)
+    src = open(os.path.join(os.path.dirname(bench.__file__), "dropoutdecoding_amd", "csrc", "dd_gemv.hip")).read()
+    assert 'NOTE_KERNEL("k_gemv_slices_seq<%d, %d, 16, %d, %d, %d, 2>"' in src
+    prof = bench.committed_profile("k_gemv_slices_seq<9, 4, 16, 3, 0, 2, 2>")
     assert 40.0 < prof["stats_avg_us"] < 55.0 and prof["traffic"] and prof["traffic"] > 150e6      # gate/up: 180 MB algorithmic per launch
 
 
