@@ -148,6 +148,29 @@ def test_argmax_first_maximal_index(ops):
     assert ops.argmax_rows(x.cuda()).tolist() == torch.argmax(x, -1).tolist() == [17, 999, 0]
 
 
+@pytest.mark.parametrize("V", [32064, 32001, 4099, 7])
+def test_argmax_vocabulary_rows_ties_and_unaligned_rows(ops, V):
+    """The row scan reads 16 bytes per load where the row is aligned (round 6) and one float otherwise: vocabulary-sized rows, ties placed in
+    different vector lanes / rounds / the scalar tail, rows that start off a 16-byte boundary (odd widths; a view with a storage offset) —
+    always torch.argmax's first maximal index (models/llava.py:297, 352: `torch.argmax(logits, dim=-1)`)."""
+    g = torch.Generator().manual_seed(V)
+    x = torch.randn(9, V, generator=g)
+    x[1, V - 1] = 9.0                                   # the last element (scalar tail when V % 4 != 0)
+    x[2, 0] = x[2, V - 1] = 9.0                         # tie between the first and the last
+    if V > 4200:
+        x[3, 4097] = x[3, 4098] = x[3, 1025] = 9.0      # ties inside one vector and across rounds
+        x[4, 4096 * 4 % V] = 9.0
+    x[5] = -2.5                                         # all equal: index 0
+    x[6, V // 2:] = float("-inf")
+    want = torch.argmax(x, -1).tolist()
+    assert ops.argmax_rows(x.cuda()).tolist() == want
+    big = torch.zeros(9 * V + 3)
+    big[3:] = x.reshape(-1)
+    y = big.cuda()[3:].view(9, V)                       # same values on the device, every row off the 16-byte grid whatever V is
+    assert y.data_ptr() % 16 != 0 and y.is_contiguous()
+    assert ops.argmax_rows(y).tolist() == want
+
+
 MODES = [("llava", DR.MODE_LLAVA_CUMULATIVE), ("next", DR.MODE_NEXT_RESET), ("next_no_overlap", DR.MODE_NEXT_NO_OVERLAP),
          ("iblip", DR.MODE_IBLIP_QUANTILE)]
 
