@@ -185,32 +185,32 @@ __global__ __launch_bounds__(1024) void k_embed_rows(const uint16_t* __restrict_
                                                      float* __restrict__ x, const float* __restrict__ normw,
                                                      u32x4_t* __restrict__ xop, float* __restrict__ ssq, int ssq_ld,
                                                      const int32_t* __restrict__ skip_if, int wf) {
+  // one workgroup per row (round 6: a single workgroup wrote all eight rows — 128 KB of fp32 and 64 K two-byte operand stores from one CU, 12 us);
+  // every row's sum of squares is reduced as before (thread t over columns t, t + 1024, ..., wave sums, the 16 waves in order): the same bits
   __shared__ float sh[16];
   if (skip_if && *skip_if) return;
+  const int m = blockIdx.x;
   int tok = state->cur_tok;
   float ss = 0.f;
   for (int i = threadIdx.x; i < d; i += 1024) {
     float e = dd_w16_to_f32(embed[(size_t)tok * d + i], wf);
     ss += e * e;
     float z = normw[i] * e;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      x[(size_t)m * d + i] = e;
-      xop_store(xop, i, m, z, wf);
-    }
+    x[(size_t)m * d + i] = e;
+    xop_store(xop, i, m, z, wf);
   }
   ss = dd_wave_sum(ss);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x == 0) {
     float v = 0.f;
     for (int i = 0; i < 16; ++i) v += sh[i];
-    ssq[(size_t)threadIdx.x * ssq_ld] = v;
+    ssq[(size_t)m * ssq_ld] = v;
   }
 }
 int ddk_embed_rows(const uint16_t* embed, int d, const DDState* state, float* x, const float* normw, u32x4_t* xop,
                    float* ssq, int ssq_ld, hipStream_t st, const int32_t* skip_if, int wf) {
-  k_embed_rows<<<1, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld, skip_if, wf);
+  k_embed_rows<<<8, 1024, 0, st>>>(embed, d, state, x, normw, xop, ssq, ssq_ld, skip_if, wf);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
