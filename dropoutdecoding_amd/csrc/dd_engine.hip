@@ -491,7 +491,7 @@ __global__ __launch_bounds__(1024) void k_step_end(DDState* st, int K, const int
   if (st->done) return;          // the sequence ended at an EOS: this enqueued-ahead step emits and advances nothing
   int win = K > 0 ? st->winner : 0;
   const float* src = K > 0 ? member_logits + (size_t)win * Vpad : base_logits;
-  for (int i = threadIdx.x; i < Vpad; i += 1024) last_logits[i] = src[i];
+  for (int i = threadIdx.x; i < (Vpad >> 2); i += 1024) ((f32x4_t*)last_logits)[i] = ((const f32x4_t*)src)[i];   // Vpad: a multiple of 16
   if (leak && K > 0)
     for (int l = threadIdx.x; l < L; l += 1024)
       leak_bits[l] = (drop_bits[(size_t)((K - 1) >> 3) * L + l] >> ((K - 1) & 7)) & 1;  // Q2: last member's zeros stay
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(1024) void k_step_end_lanes(StepEndLanes t, int K, 
   if (st->done) return;
   const int win = st->winner;
   const float* src = t.member_logits[q] + (size_t)win * Vpad;
-  for (int i = threadIdx.x; i < Vpad; i += 1024) t.last_logits[q][i] = src[i];
+  for (int i = threadIdx.x; i < (Vpad >> 2); i += 1024) ((f32x4_t*)t.last_logits[q])[i] = ((const f32x4_t*)src)[i];   // Vpad: a multiple of 16
   if (t.leak[q])
     for (int l = threadIdx.x; l < t.L[q]; l += 1024)
       t.leak_bits[q][l] = (t.drop_bits[q][(size_t)((K - 1) >> 3) * t.L[q] + l] >> ((K - 1) & 7)) & 1;
@@ -1634,13 +1634,16 @@ struct ScatterTab {
   int32_t* argmax[GROUP_MAX_LANES];
   const DDState* st[GROUP_MAX_LANES];
 };
-__global__ void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, ScatterTab tab) {
+// grid (rows, ROW_COPY_WGS): a logits row is Vpad floats (a multiple of 16, rows of hipMalloc'ed buffers): 16-byte accesses, eight workgroups
+// per row (round 6: one workgroup copying a 128-KB row four bytes at a time took 63 us at the end of every rider sweep, in front of the masks)
+#define ROW_COPY_WGS 8
+__global__ __launch_bounds__(256) void k_scatter_base(const float* grp_logits, const int32_t* grp_argmax, int Vpad, ScatterTab tab) {
   int m = blockIdx.x;
   if (tab.st[m]->done) return;
-  const float* src = grp_logits + (size_t)m * Vpad;
-  float* dst = tab.logits[m];
-  for (int i = threadIdx.x; i < Vpad; i += 256) dst[i] = src[i];
-  if (threadIdx.x == 0) tab.argmax[m][0] = grp_argmax[m];
+  const f32x4_t* src = (const f32x4_t*)(grp_logits + (size_t)m * Vpad);
+  f32x4_t* dst = (f32x4_t*)tab.logits[m];
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < (Vpad >> 2); i += gridDim.y * 256) dst[i] = src[i];
+  if (blockIdx.y == 0 && threadIdx.x == 0) tab.argmax[m][0] = grp_argmax[m];
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -1716,13 +1719,13 @@ struct PromoteTab {
   int32_t* adst[GROUP_MAX_LANES];
   const DDState* st[GROUP_MAX_LANES];
 };
-__global__ void k_promote_base(PromoteTab tab, int Vpad) {
+__global__ __launch_bounds__(256) void k_promote_base(PromoteTab tab, int Vpad) {
   const int m = blockIdx.x;
   if (tab.st[m]->done) return;
-  const float* src = tab.src[m];
-  float* dst = tab.dst[m];
-  for (int i = threadIdx.x; i < Vpad; i += 256) dst[i] = src[i];
-  if (threadIdx.x == 0) tab.adst[m][0] = tab.asrc[m][0];
+  const f32x4_t* src = (const f32x4_t*)tab.src[m];
+  f32x4_t* dst = (f32x4_t*)tab.dst[m];
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < (Vpad >> 2); i += gridDim.y * 256) dst[i] = src[i];
+  if (blockIdx.y == 0 && threadIdx.x == 0) tab.adst[m][0] = tab.asrc[m][0];
 }
 
 // gs = 8: one sequence per member plane; gs = 14 (K <= 4): half planes — fourteen sequences in seven planes, their partners' un-masked
@@ -1764,7 +1767,7 @@ static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, in
       dd_lm* q = lanes[m];
       tab.src[m] = q->base_next, tab.dst[m] = q->base_logits, tab.asrc[m] = q->argmax_next, tab.adst[m] = q->argmax_base, tab.st[m] = q->state;
     }
-    k_promote_base<<<n_early, 256, 0, st>>>(tab, h0->Vpad);
+    k_promote_base<<<dim3(n_early, ROW_COPY_WGS), 256, 0, st>>>(tab, h0->Vpad);
     DD_CHECK_LAUNCH();
   } else {
     RC(lm_sweep(h0, n_early, nullptr, 0, h0->grp_logits, st, lanes));
@@ -1772,7 +1775,7 @@ static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, in
     ScatterTab tab;
     memset(&tab, 0, sizeof(tab));
     for (int m = 0; m < n_early; ++m) tab.logits[m] = lanes[m]->base_logits, tab.argmax[m] = lanes[m]->argmax_base, tab.st[m] = lanes[m]->state;
-    k_scatter_base<<<n_early, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
+    k_scatter_base<<<dim3(n_early, ROW_COPY_WGS), 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
     DD_CHECK_LAUNCH();
   }
   RC(masks(0, n_early, st));
@@ -1833,7 +1836,7 @@ static int group_step_rider(dd_lm* const* lanes, int n, const double* mprobs, in
         dd_lm* q = rd[m];
         tab.logits[m] = ahead ? q->base_next : q->base_logits, tab.argmax[m] = ahead ? q->argmax_next : q->argmax_base, tab.st[m] = q->state;
       }
-      k_scatter_base<<<gs, 256, 0, bs>>>(scratch->grp_logits, scratch->grp_argmax, h0->Vpad, tab);
+      k_scatter_base<<<dim3(gs, ROW_COPY_WGS), 256, 0, bs>>>(scratch->grp_logits, scratch->grp_argmax, h0->Vpad, tab);
       DD_CHECK_LAUNCH();
       if (!ahead) {
         if (g_rider_staged) late[n_late++] = pg;
@@ -1911,7 +1914,7 @@ static int group_step_eager(dd_lm* const* lanes, int n, const double* mprobs, in
     ScatterTab tab;
     memset(&tab, 0, sizeof(tab));
     for (int m = 0; m < n; ++m) tab.logits[m] = lanes[m]->base_logits, tab.argmax[m] = lanes[m]->argmax_base, tab.st[m] = lanes[m]->state;
-    k_scatter_base<<<n, 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
+    k_scatter_base<<<dim3(n, ROW_COPY_WGS), 256, 0, st>>>(h0->grp_logits, h0->grp_argmax, h0->Vpad, tab);
     DD_CHECK_LAUNCH();
   }
   // masks of every sequence first (each from its own rng stream), then the members: two sequences per 16-row sweep where

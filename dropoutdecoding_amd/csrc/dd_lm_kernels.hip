@@ -349,6 +349,7 @@ int ddk_mean_rows(float* rows, int K, int ld, int n, const int32_t* gate, hipStr
 }
 
 // append the chosen row's new K/V of every layer at position T  (the winner's cache, reference llava.py:373)
+#define COMMIT_WGS 4       // workgroups per layer (round 6: one workgroup per layer walked 4,096 scattered two-byte stores sixteen deep: 14 us)
 __global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ knew, const float* __restrict__ vnew,
                                                    int rows_per_layer, int kv_dim, float* __restrict__ kc,
                                                    float* __restrict__ vc, size_t lsk, size_t lsv, int T_cap,
@@ -361,13 +362,13 @@ __global__ __launch_bounds__(256) void k_commit_kv(const float* __restrict__ kne
   const float* vr = vnew + ((size_t)layer * rows_per_layer + row) * kv_dim;
   float* kl = kc + (size_t)layer * lsk;
   float* vl = vc + (size_t)layer * lsv;
-  for (int i = threadIdx.x; i < kv_dim; i += 256) {
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < kv_dim; i += gridDim.y * 256) {     // grid (layers, COMMIT_WGS): the elements are independent
     int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
     dd_kv_store(kl, vl, kv16, kvh, idx, T, T_cap, true, kr[i]);
     dd_kv_store(kl, vl, kv16, kvh, idx, T, T_cap, false, vr[i]);
   }
 }
-// the same for up to 4 sequences in one launch: grid (layers, sequences)
+// the same for up to 4 sequences in one launch: grid (layers, sequences, COMMIT_WGS)
 __global__ __launch_bounds__(256) void k_commit_kv_lanes(CommitLanes t, int rows_per_layer, int kv_dim, int T_cap) {
   const int layer = blockIdx.x, q = blockIdx.y;
   const DDState* state = t.state[q];
@@ -377,20 +378,20 @@ __global__ __launch_bounds__(256) void k_commit_kv_lanes(CommitLanes t, int rows
   const float* vr = t.vnew[q] + ((size_t)layer * rows_per_layer + row) * kv_dim;
   float* kl = t.kc[q] + (size_t)layer * t.lsk;
   float* vl = t.vc[q] + (size_t)layer * t.lsv;
-  for (int i = threadIdx.x; i < kv_dim; i += 256) {
+  for (int i = blockIdx.z * 256 + threadIdx.x; i < kv_dim; i += gridDim.z * 256) {
     int kvh = i / HEAD_DIM, idx = i % HEAD_DIM;
     dd_kv_store(kl, vl, t.kv16, kvh, idx, T, T_cap, true, kr[i]);
     dd_kv_store(kl, vl, t.kv16, kvh, idx, T, T_cap, false, vr[i]);
   }
 }
 int ddk_commit_kv_lanes(const CommitLanes& t, int n, int n_layers, int rows_per_layer, int kv_dim, int T_cap, hipStream_t st) {
-  k_commit_kv_lanes<<<dim3(n_layers, n), 256, 0, st>>>(t, rows_per_layer, kv_dim, T_cap);
+  k_commit_kv_lanes<<<dim3(n_layers, n, COMMIT_WGS), 256, 0, st>>>(t, rows_per_layer, kv_dim, T_cap);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 int ddk_commit_kv(const float* knew, const float* vnew, int n_layers, int rows_per_layer, int kv_dim, float* kc,
                   float* vc, size_t lsk, size_t lsv, int T_cap, const DDState* state, int use_winner, hipStream_t st, int kv16) {
-  k_commit_kv<<<n_layers, 256, 0, st>>>(knew, vnew, rows_per_layer, kv_dim, kc, vc, lsk, lsv, T_cap, state, use_winner, kv16);
+  k_commit_kv<<<dim3(n_layers, COMMIT_WGS), 256, 0, st>>>(knew, vnew, rows_per_layer, kv_dim, kc, vc, lsk, lsv, T_cap, state, use_winner, kv16);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
